@@ -1,0 +1,96 @@
+/*
+ * synchformer_hip.h - C ABI of libsynchformer_hip.so: the MI355X (gfx950 / CDNA4) kernels behind
+ * Synchformer.forward().
+ *
+ * This is the drop-in boundary of the build.  The reference has no native
+ * layer of its own - every op below is reached in the reference through a torch.nn module call; each entry
+ * point cites the reference call sites it replaces (paths relative to v-iashin/Synchformer).
+ *
+ * Conventions
+ *   - plain pointers to DEVICE memory + sizes; no torch / HIP types in signatures (`stream` is a hipStream_t
+ *     passed as void*; NULL = the null stream).  The caller owns every buffer; nothing here allocates.
+ *   - bf16 operands are raw uint16_t bit patterns; accumulation and all statistics are fp32.
+ *   - return 0 on success; non-zero = hipError_t of a failed launch, or -1 for a rejected argument.
+ *     `sf_last_error()` returns a thread-local human-readable message for the last non-zero return.
+ *   - every launcher is asynchronous on `stream` and re-entrant (no global mutable state but the error string).
+ *   - "row map": `const int64_t map[6] = {n12, n2, sA, s1, s2, off}` sends logical row r to physical row
+ *         (r / n12) * sA + ((r % n12) / n2) * s1 + (r % n2) * s2 + off          (NULL = identity)
+ *     which expresses every reshape / CLS-drop / concat / transpose the reference does with view/cat/einops.
+ */
+#ifndef SYNCHFORMER_HIP_H
+#define SYNCHFORMER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2, SF_U8 = 3 };   /* element types */
+enum { SF_EPI_NONE = 0, SF_EPI_GELU = 1 };                  /* GEMM epilogue activation */
+
+#define SF_ABI_VERSION 1
+int sf_abi_version(void);
+const char* sf_last_error(void);
+/* "gfx950" + build flags; lets the host assert it loaded the library it built */
+const char* sf_build_info(void);
+
+/* C[cmap(m), n] = epi(sum_k A[m,k] * W[n,k] + bias[n]) (+ R[rmap(m), n]);  A: M x K bf16 (row stride lda),
+ * W: N x K bf16 (an nn.Linear / flattened conv weight, row stride ldw), bias fp32 or NULL, C bf16|fp32,
+ * R fp32 or NULL (may alias C for an in-place residual).  K % 64 == 0.  Exact-erf GELU when SF_EPI_GELU.
+ * Replaces nn.Linear at vit_helper.py:103,155,392-396; modeling_ast.py:142-146,199,263,274;
+ * modules/transformer.py:59-61,74,86-91; nn.MultiheadAttention in/out proj + linear1/2 at
+ * motionformer.py:329; Conv3d vit_helper.py:436-443 and Conv2d modeling_ast.py:113-117 (after sf_im2col_*);
+ * vproj/aproj sync_model.py:55-56; off_head/sync_head sync_model.py:172,189. */
+int sf_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, void* C,
+                 int c_dtype, int64_t ldc, const int64_t* c_map, const float* R, int64_t ldr, const int64_t* r_map,
+                 int epilogue, int64_t M, int64_t N, int64_t K, void* stream);
+
+/* y[omap(r), :] (=|+=) LayerNorm(x[imap(r), :]) * gamma + beta over 768 columns; x fp32, y bf16|fp32.
+ * Replaces nn.LayerNorm at vit_helper.py:366-375, motionformer.py:232, modeling_ast.py:301,315,535,
+ * sync_model.py:157,169, modules/transformer.py:94-95 and norm1/norm2 inside motionformer.py:329. */
+int sf_layernorm768(const float* x, int64_t ldx, const int64_t* in_map, const float* gamma, const float* beta, void* y,
+                    int y_dtype, int64_t ldy, const int64_t* out_map, int accumulate, int64_t rows, float eps,
+                    void* stream);
+
+/* dst[(s*dst_seq_rows + l), :] = table[l, :], l < L, s < n_seq (fp32, 768 cols): lays positional tables and
+ * CLS/DISTILL/OFF/MOD token rows under every sequence (video_model_builder.py:221-254, modeling_ast.py:84-90,
+ * sync_model.py:153-165, motionformer.py:306-307). */
+int sf_broadcast_rows768(float* dst, int64_t ld, int64_t dst_seq_rows, const float* table, int64_t L, int64_t n_seq,
+                         void* stream);
+
+/* y[r, :] = cast(x[imap(r), :]) (768 cols, x fp32, y bf16|fp32): the x[:, 0] / x[:, 1:] style slicing at
+ * motionformer.py:231,332, ast.py:232-236, sync_model.py:172. */
+int sf_gather_rows768(const float* x, int64_t ldx, const int64_t* in_map, void* y, int y_dtype, int64_t ldy,
+                      int64_t rows, void* stream);
+
+/* Patch gather for Conv3d(3->768, k=s=(2,16,16)) (vit_helper.py:436-444) with extract_vfeats' permute
+ * (sync_model.py:74) folded in: vid (n_seg,16,3,224,224) of `dtype` -> out bf16 (n_seg*1568, 1536).
+ * dtype SF_U8 additionally applies RGBToHalfToZeroOne + RGBNormalize(0.5,0.5) (dataset/transforms.py:647-669)
+ * with the reference's fp16 roundings. */
+int sf_im2col_video(const void* vid, int dtype, uint16_t* out, int64_t n_seg, void* stream);
+
+/* Patch gather for Conv2d(1->768, k16, stride 10) (modeling_ast.py:113-117): spec fp32 (n_seg, F, Ta) ->
+ * out bf16 (n_seg*nf*nt, 256), nf=(F-16)/10+1, nt=(Ta-16)/10+1, row = (n*nf + fi)*nt + ti. */
+int sf_im2col_spec(const float* spec, uint16_t* out, int64_t n_seg, int F, int Ta, void* stream);
+
+/* Grouped multi-head attention, out = softmax(scale * q k^T) v.  q/k/v/out are column slices of packed bf16
+ * matrices (head h at columns h*head_dim..); a sequence is `seq_rows` rows; group g of a sequence owns tokens
+ * row0 + g*group_stride + i*tok_stride (i < n_tok), plus row `cls_row` as an extra first key when >= 0.
+ * n_tok + (cls_row>=0) <= 208; head_dim 64 or 96.  Replaces qkv_attn on the regrouped patches in
+ * DividedAttention.forward (vit_helper.py:129-147), ASTSelfAttention (modeling_ast.py:156-176) and
+ * SelfAttention (modules/transformer.py:67-70). */
+int sf_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld, uint16_t* out, int64_t ldo,
+                 int64_t n_seq, int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok,
+                 int cls_row, int heads, int head_dim, float scale, void* stream);
+
+/* One query row per sequence against n_keys consecutive rows (head_dim 64): the Motionformer CLS query
+ * (vit_helper.py:126) and the only output row the aggregator layers ever read (motionformer.py:329-332). */
+int sf_attention_cls(const uint16_t* q, int64_t q_seq_rows, int q_row, const uint16_t* k, const uint16_t* v, int64_t ld,
+                     int64_t kv_seq_rows, int kv_row0, int n_keys, uint16_t* out, int64_t ldo, int64_t out_seq_rows,
+                     int out_row, int64_t n_seq, int heads, int head_dim, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYNCHFORMER_HIP_H */

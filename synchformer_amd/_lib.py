@@ -1,0 +1,66 @@
+"""ctypes binding of libsynchformer_hip.so (C ABI declared in include/synchformer_hip.h).
+
+The product path has NO fallback: if the library is missing or a symbol is absent this module raises, and
+every op raises `RuntimeError` with `sf_last_error()` on a non-zero return (the reference's only error
+convention is Python exceptions, e.g. scripts/train_sync.py:188-190).
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+LIB_DIR = Path(__file__).resolve().parent / 'lib'
+LIB_NAME = 'libsynchformer_hip.so'
+ABI_VERSION = 1
+
+_i64, _i32, _f32, _ptr = C.c_int64, C.c_int, C.c_float, C.c_void_p
+
+# name -> argtypes; restype is int unless listed in _RESTYPES.  Mirrors include/synchformer_hip.h 1:1
+# (tests/test_abi.py parses the header and checks every declared symbol is exported and listed here).
+SIGNATURES = {
+    'sf_abi_version': [],
+    'sf_last_error': [],
+    'sf_build_info': [],
+    'sf_gemm_bf16': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i64, _ptr, _ptr, _i64, _ptr, _i32, _i64, _i64, _i64, _ptr],
+    'sf_layernorm768': [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i64, _ptr, _i32, _i64, _f32, _ptr],
+    'sf_broadcast_rows768': [_ptr, _i64, _i64, _ptr, _i64, _i64, _ptr],
+    'sf_gather_rows768': [_ptr, _i64, _ptr, _ptr, _i32, _i64, _i64, _ptr],
+    'sf_im2col_video': [_ptr, _i32, _ptr, _i64, _ptr],
+    'sf_im2col_spec': [_ptr, _ptr, _i64, _i32, _i32, _ptr],
+    'sf_attention': [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _ptr],
+    'sf_attention_cls': [_ptr, _i64, _i32, _ptr, _ptr, _i64, _i64, _i32, _i32, _ptr, _i64, _i64, _i32, _i64, _i32, _i32, _f32, _ptr],
+}
+_RESTYPES = {'sf_last_error': C.c_char_p, 'sf_build_info': C.c_char_p}
+
+_lib = None
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get('SYNCHFORMER_HIP_LIB', LIB_DIR / LIB_NAME))
+
+
+def load():
+    """Load (once) and type the shared library.  Raises if it is absent - build it with
+    `python -c "import __graft_entry__ as g; g.build()"` or `make -C synchformer_amd/csrc`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not path.exists():
+        raise RuntimeError(f'{path} not found: the HIP extension is not built. There is no CPU fallback; run '
+                           f'`python -c "import __graft_entry__ as g; g.build()"` first.')
+    lib = C.CDLL(str(path))
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError -> loud failure on a stale build
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    got = lib.sf_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f'{path}: ABI version {got}, expected {ABI_VERSION} (stale build?)')
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().sf_last_error().decode(errors='replace')
+        raise RuntimeError(f'{what} failed (rc={rc}): {msg}')

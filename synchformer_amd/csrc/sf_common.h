@@ -1,0 +1,87 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) Synchformer kernels.
+// wave = 64 lanes everywhere in this directory; nothing here is portable and nothing is meant to be.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;   // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define SF_WAVE 64
+
+// ---- error plumbing (host) --------------------------------------------------------------------------
+void sf_set_error(const char* fmt, ...);
+#define SF_CHECK_ARG(cond, ...)                                  \
+  do {                                                           \
+    if (!(cond)) { sf_set_error(__VA_ARGS__); return -1; }       \
+  } while (0)
+#define SF_LAUNCH_CHECK()                                                        \
+  do {                                                                           \
+    hipError_t e__ = hipGetLastError();                                          \
+    if (e__ != hipSuccess) { sf_set_error("%s: %s", __func__, hipGetErrorString(e__)); return (int)e__; } \
+  } while (0)
+
+// ---- row maps -----------------------------------------------------------------------------------------
+// A logical row r (< 2^31) of an operand lives at physical row
+//     (r / n12) * sA + ((r % n12) / n2) * s1 + (r % n2) * s2 + off
+// Host passes `const int64_t[6] = {n12, n2, sA, s1, s2, off}` or NULL for identity (n12 == 0 marks identity).
+struct RowMap {
+  uint32_t n12, n2;
+  int64_t sA, s1, s2, off;
+};
+static inline RowMap sf_rowmap(const int64_t* m) {
+  RowMap r;
+  if (m) { r.n12 = (uint32_t)m[0]; r.n2 = (uint32_t)m[1]; r.sA = m[2]; r.s1 = m[3]; r.s2 = m[4]; r.off = m[5]; }
+  else   { r.n12 = 0; r.n2 = 1; r.sA = 0; r.s1 = 0; r.s2 = 1; r.off = 0; }
+  return r;
+}
+__device__ __forceinline__ int64_t map_row(const RowMap& m, int64_t r) {
+  if (m.n12 == 0) return r;                                // identity (wave-uniform branch)
+  const uint32_t ur = (uint32_t)r;
+  const uint32_t a = ur / m.n12, rem = ur - a * m.n12;
+  const uint32_t i1 = rem / m.n2, i2 = rem - i1 * m.n2;
+  return (int64_t)a * m.sA + (int64_t)i1 * m.s1 + (int64_t)i2 * m.s2 + m.off;
+}
+
+// ---- bf16 <-> f32 ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {   // round-to-nearest-even, NaN kept quiet
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float f16_to_f32(uint16_t h) { return __half2float(__ushort_as_half(h)); }
+
+// ---- wave reductions ------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact-erf GELU (nn.GELU default).  erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, i.e. below one
+// fp32 ulp of the GELU output for |x| < 4 and far below the bf16 rounding applied right after).
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const float e = 1.0f - p * t * __expf(-z * z);        // erf(|x|/sqrt2)
+  return 0.5f * x * (1.0f + copysignf(e, x));
+}

@@ -1,0 +1,271 @@
+// Row-wise HBM-bound kernels for the 768-wide token matrices of the Synchformer hot path:
+// LayerNorm (wave-per-row reduction), table broadcast, row gather/cast, im2col gathers for the two
+// patch-embedding convolutions, and the fused u8 -> normalised-bf16 RGB front-end.
+// All of these are bandwidth kernels: 16-byte-per-lane coalesced accesses, no LDS, one wave per row.
+#include "sf_common.h"
+#include "../../include/synchformer_hip.h"
+
+#define D_MODEL 768
+
+// ------------------------------------------------------------------------------------------------------
+// LayerNorm over 768 columns.  One wave per row: lane holds 3 x float4 (cols i*256 + lane*4 .. +3), so
+// every wave-instruction touches 1 KiB contiguous.  Two-pass (mean, then centred variance) in registers -
+// the same arithmetic order class as torch's fp32 LayerNorm.  Output bf16 (GEMM operand) or fp32, optional
+// accumulate (y += LN(x)) used to drop normalised features onto a pre-filled positional table.
+// Replaces nn.LayerNorm call sites: vit_helper.py:366-375 (norm1/2/3), motionformer.py:232,
+// modeling_ast.py:301,315,535, sync_model.py:157,169, modules/transformer.py:94-95.
+// ------------------------------------------------------------------------------------------------------
+template <bool OUT_BF16, bool ACCUM>
+__global__ __launch_bounds__(256) void layernorm768_kernel(const float* __restrict__ x, int64_t ldx, RowMap in_map,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, void* __restrict__ y,
+                                                            int64_t ldy, RowMap out_map, int64_t rows, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* xr = x + map_row(in_map, r) * ldx;
+  float4 v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum(s) * (1.0f / D_MODEL);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+    q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / D_MODEL) + eps);
+  const int64_t orow = map_row(out_map, r);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * 256 + lane * 4;
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 b = *reinterpret_cast<const float4*>(beta + c);
+    float4 o;
+    o.x = v[i].x * rstd * g.x + b.x; o.y = v[i].y * rstd * g.y + b.y;
+    o.z = v[i].z * rstd * g.z + b.z; o.w = v[i].w * rstd * g.w + b.w;
+    if (OUT_BF16) {
+      uint2 p; p.x = pack_bf2(o.x, o.y); p.y = pack_bf2(o.z, o.w);
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + orow * ldy + c) = p;
+    } else {
+      float* yp = reinterpret_cast<float*>(y) + orow * ldy + c;
+      if (ACCUM) { const float4 t = *reinterpret_cast<const float4*>(yp); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+      *reinterpret_cast<float4*>(yp) = o;
+    }
+  }
+}
+
+extern "C" int sf_layernorm768(const float* x, int64_t ldx, const int64_t* in_map, const float* gamma,
+                               const float* beta, void* y, int y_dtype, int64_t ldy, const int64_t* out_map,
+                               int accumulate, int64_t rows, float eps, void* stream) {
+  SF_CHECK_ARG(x && gamma && beta && y, "sf_layernorm768: null pointer");
+  SF_CHECK_ARG(y_dtype == SF_BF16 || y_dtype == SF_F32, "sf_layernorm768: y_dtype must be bf16 or f32");
+  SF_CHECK_ARG(!(accumulate && y_dtype != SF_F32), "sf_layernorm768: accumulate needs f32 output");
+  SF_CHECK_ARG((ldx % 4) == 0 && (ldy % 4) == 0, "sf_layernorm768: ld must be a multiple of 4");
+  if (rows <= 0) return 0;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  RowMap im = sf_rowmap(in_map), om = sf_rowmap(out_map);
+  if (y_dtype == SF_BF16)
+    hipLaunchKernelGGL((layernorm768_kernel<true, false>), grid, block, 0, s, x, ldx, im, gamma, beta, y, ldy, om, rows, eps);
+  else if (accumulate)
+    hipLaunchKernelGGL((layernorm768_kernel<false, true>), grid, block, 0, s, x, ldx, im, gamma, beta, y, ldy, om, rows, eps);
+  else
+    hipLaunchKernelGGL((layernorm768_kernel<false, false>), grid, block, 0, s, x, ldx, im, gamma, beta, y, ldy, om, rows, eps);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// dst[(seq * dst_seq_rows + l) * ld + :] = table[l, :]  for l < L, seq < n_seq   (fp32, cols = 768)
+// Lays the positional table (+ CLS / DISTILL / OFF / MOD token rows, folded in at weight-prep time) under
+// every sequence; the patch-embed GEMM / LayerNorm then accumulate onto it.  Replaces the cat/expand/add
+// glue at video_model_builder.py:221-254, modeling_ast.py:84-90, sync_model.py:153-165,
+// motionformer.py:306-307.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void broadcast_rows768_kernel(float* __restrict__ dst, int64_t ld,
+                                                                 int64_t dst_seq_rows, const float* __restrict__ table,
+                                                                 int64_t L, int64_t total_rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= total_rows) return;
+  const int64_t seq = r / L, l = r - seq * L;
+  const float* t = table + l * D_MODEL;
+  float* d = dst + (seq * dst_seq_rows + l) * ld;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    *reinterpret_cast<float4*>(d + i * 256 + lane * 4) = *reinterpret_cast<const float4*>(t + i * 256 + lane * 4);
+}
+
+extern "C" int sf_broadcast_rows768(float* dst, int64_t ld, int64_t dst_seq_rows, const float* table, int64_t L,
+                                    int64_t n_seq, void* stream) {
+  SF_CHECK_ARG(dst && table, "sf_broadcast_rows768: null pointer");
+  SF_CHECK_ARG(L > 0 && dst_seq_rows >= L && (ld % 4) == 0, "sf_broadcast_rows768: bad shape");
+  const int64_t total = L * n_seq;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(broadcast_rows768_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     dst, ld, dst_seq_rows, table, L, total);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Row gather + cast: y[r, :] = (bf16|f32) x[map(r), :]   (cols = 768, x fp32)
+// ------------------------------------------------------------------------------------------------------
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void gather_rows768_kernel(const float* __restrict__ x, int64_t ldx, RowMap in_map,
+                                                              void* __restrict__ y, int64_t ldy, int64_t rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* xr = x + map_row(in_map, r) * ldx;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * 256 + lane * 4;
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    if (OUT_BF16) {
+      uint2 p; p.x = pack_bf2(v.x, v.y); p.y = pack_bf2(v.z, v.w);
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + r * ldy + c) = p;
+    } else {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + r * ldy + c) = v;
+    }
+  }
+}
+
+extern "C" int sf_gather_rows768(const float* x, int64_t ldx, const int64_t* in_map, void* y, int y_dtype, int64_t ldy,
+                                 int64_t rows, void* stream) {
+  SF_CHECK_ARG(x && y, "sf_gather_rows768: null pointer");
+  SF_CHECK_ARG(y_dtype == SF_BF16 || y_dtype == SF_F32, "sf_gather_rows768: y_dtype must be bf16 or f32");
+  if (rows <= 0) return 0;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  RowMap im = sf_rowmap(in_map);
+  if (y_dtype == SF_BF16)
+    hipLaunchKernelGGL((gather_rows768_kernel<true>), grid, block, 0, (hipStream_t)stream, x, ldx, im, y, ldy, rows);
+  else
+    hipLaunchKernelGGL((gather_rows768_kernel<false>), grid, block, 0, (hipStream_t)stream, x, ldx, im, y, ldy, rows);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Video patch gather (im2col for Conv3d k = s = (2,16,16), vit_helper.py:436-444) fused with the RGB
+// front-end (RGBToHalfToZeroOne + RGBNormalize, dataset/transforms.py:647-669) when the input is uint8.
+//   vid : (N, T=16, C=3, H=224, W=224)  - the layout Synchformer.forward receives (sync_model.py:43), i.e.
+//         BEFORE extract_vfeats' permute; the permute is folded into the gather.
+//   out : bf16 (N*1568, 1536), row = n*1568 + f*196 + h*14 + w, col = ((c*2 + dt)*16 + dh)*16 + dw
+// One thread moves one 16-pixel patch row (dw run): 16/32/64 B in, 32 B out; a wave covers 64 consecutive
+// (patch-col w, dh) runs so reads walk along W within an image row and writes are 32-B pieces of A rows.
+// ------------------------------------------------------------------------------------------------------
+template <int DT>  // 0 f32, 1 bf16, 2 f16, 3 u8
+__device__ __forceinline__ void load16(const void* p, float* f) {
+  if (DT == SF_F32) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { float4 v = q[i]; f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w; }
+  } else if (DT == SF_BF16 || DT == SF_F16) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      uint4 v = q[i];
+      uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (DT == SF_BF16) { f[8 * i + 2 * j] = bf2f((bf16_t)(w[j] & 0xffff)); f[8 * i + 2 * j + 1] = bf2f((bf16_t)(w[j] >> 16)); }
+        else { f[8 * i + 2 * j] = f16_to_f32((uint16_t)(w[j] & 0xffff)); f[8 * i + 2 * j + 1] = f16_to_f32((uint16_t)(w[j] >> 16)); }
+      }
+    }
+  } else {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        // reference: x.half().div(255.) then .sub(0.5).div(0.5) on half tensors (CPU half ops = fp32 op + one
+        // rounding to fp16 each): reproduce exactly those roundings.
+        const float a = __half2float(__float2half((float)((w[j] >> (8 * b)) & 0xff) / 255.0f));
+        const float cen = __half2float(__float2half(a - 0.5f));
+        f[4 * j + b] = cen * 2.0f;   // /0.5 is exact
+      }
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void im2col_video_kernel(const void* __restrict__ vid, bf16_t* __restrict__ out,
+                                                            int64_t total_runs) {
+  // run index = (((n*8 + f)*2 + dt)*3 + c)*224*14 + (h*16+dh)*14 + w   (walks memory order of `vid` per frame)
+  const int64_t run = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (run >= total_runs) return;
+  const int w = (int)(run % 14);
+  int64_t t = run / 14;
+  const int y = (int)(t % 224); t /= 224;
+  const int c = (int)(t % 3); t /= 3;
+  const int dt = (int)(t % 2); t /= 2;
+  const int f = (int)(t % 8);
+  const int64_t n = t / 8;
+  const int64_t src = ((((n * 16 + (f * 2 + dt)) * 3 + c) * 224 + y) * 224) + w * 16;
+  const int esz = (DT == SF_F32) ? 4 : (DT == SF_U8 ? 1 : 2);
+  float v[16];
+  load16<DT>(reinterpret_cast<const char*>(vid) + src * esz, v);
+  const int h = y >> 4, dh = y & 15;
+  const int64_t row = n * 1568 + f * 196 + h * 14 + w;
+  const int col = ((c * 2 + dt) * 16 + dh) * 16;
+  uint4 o0, o1;
+  o0.x = pack_bf2(v[0], v[1]); o0.y = pack_bf2(v[2], v[3]); o0.z = pack_bf2(v[4], v[5]); o0.w = pack_bf2(v[6], v[7]);
+  o1.x = pack_bf2(v[8], v[9]); o1.y = pack_bf2(v[10], v[11]); o1.z = pack_bf2(v[12], v[13]); o1.w = pack_bf2(v[14], v[15]);
+  uint4* dst = reinterpret_cast<uint4*>(out + row * 1536 + col);
+  dst[0] = o0; dst[1] = o1;
+}
+
+extern "C" int sf_im2col_video(const void* vid, int dtype, bf16_t* out, int64_t n_seg, void* stream) {
+  SF_CHECK_ARG(vid && out, "sf_im2col_video: null pointer");
+  SF_CHECK_ARG(dtype >= 0 && dtype <= 3, "sf_im2col_video: bad dtype %d", dtype);
+  const int64_t total = n_seg * 16 * 3 * 224 * 14;
+  if (total <= 0) return 0;
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case SF_F32: hipLaunchKernelGGL((im2col_video_kernel<SF_F32>), grid, block, 0, s, vid, out, total); break;
+    case SF_BF16: hipLaunchKernelGGL((im2col_video_kernel<SF_BF16>), grid, block, 0, s, vid, out, total); break;
+    case SF_F16: hipLaunchKernelGGL((im2col_video_kernel<SF_F16>), grid, block, 0, s, vid, out, total); break;
+    default: hipLaunchKernelGGL((im2col_video_kernel<SF_U8>), grid, block, 0, s, vid, out, total); break;
+  }
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Spectrogram patch gather (im2col for Conv2d(1->768, k16, stride 10), modeling_ast.py:113-117).
+//   spec: fp32 (N, F=128, Ta=66) - the layout Synchformer.forward receives (B,S,1,F,Ta); the reference's
+//         permute to (Ta,F) and transpose back (sync_model.py:84, modeling_ast.py:114-115) cancel out.
+//   out : bf16 (N*72, 256), row = n*72 + fi*6 + ti, col = df*16 + dt  (value spec[n, 10fi+df, 10ti+dt])
+// Tiny (18 K elements per segment): one thread per output element pair.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col_spec_kernel(const float* __restrict__ spec, bf16_t* __restrict__ out,
+                                                           int64_t total_pairs, int F, int Ta, int nf, int nt) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= total_pairs) return;
+  const int col = (int)(p % 128) * 2;
+  const int64_t row = p / 128;
+  const int ti = (int)(row % nt);
+  const int fi = (int)((row / nt) % nf);
+  const int64_t n = row / ((int64_t)nt * nf);
+  const int df = col >> 4, dtc = col & 15;
+  const float* s = spec + (n * F + (fi * 10 + df)) * Ta + ti * 10 + dtc;
+  *reinterpret_cast<uint32_t*>(out + row * 256 + col) = pack_bf2(s[0], s[1]);
+}
+
+extern "C" int sf_im2col_spec(const float* spec, bf16_t* out, int64_t n_seg, int F, int Ta, void* stream) {
+  SF_CHECK_ARG(spec && out, "sf_im2col_spec: null pointer");
+  SF_CHECK_ARG(F >= 16 && Ta >= 16, "sf_im2col_spec: spectrogram smaller than one patch");
+  const int nf = (F - 16) / 10 + 1, nt = (Ta - 16) / 10 + 1;
+  const int64_t total = n_seg * nf * nt * 128;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(im2col_spec_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, spec,
+                     out, total, F, Ta, nf, nt);
+  SF_LAUNCH_CHECK();
+  return 0;
+}

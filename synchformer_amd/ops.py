@@ -1,0 +1,136 @@
+"""Tensor-level wrappers over the C ABI (one Python function per `sf_*` entry point).
+
+torch is plumbing here: device memory (`Tensor.data_ptr()`), the current HIP stream and dtype bookkeeping.
+All compute happens in libsynchformer_hip.so; there is no eager / CPU fallback - a CPU tensor raises.
+Also registered as `torch.ops.synchformer.*` custom ops (see `register_torch_ops`) so the kernels are visible
+to the dispatcher, as the reference's callers would expect of a PyTorch-ROCm extension.
+"""
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+SF_F32, SF_BF16, SF_F16, SF_U8 = 0, 1, 2, 3
+EPI_NONE, EPI_GELU = 0, 1
+_DT = {torch.float32: SF_F32, torch.bfloat16: SF_BF16, torch.float16: SF_F16, torch.uint8: SF_U8}
+
+RowMap = Optional[Sequence[int]]   # (n12, n2, sA, s1, s2, off) or None
+
+
+def rowmap(n12: int, n2: int, sA: int, s1: int, s2: int, off: int):
+    return (int(n12), int(n2), int(sA), int(s1), int(s2), int(off))
+
+
+def _map(m: RowMap):
+    if m is None:
+        return None
+    assert len(m) == 6
+    return (C.c_int64 * 6)(*m)
+
+
+def _dev(t: torch.Tensor, name: str) -> int:
+    if not t.is_cuda:
+        raise RuntimeError(f'{name}: expected a HIP device tensor, got {t.device} (no CPU fallback exists)')
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, f'expected a row-major 2-D view, got {tuple(t.shape)} / {t.stride()}'
+    return t.stride(0)
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *, M: Optional[int] = None,
+         residual: Optional[torch.Tensor] = None, gelu: bool = False, c_map: RowMap = None, r_map: RowMap = None):
+    """out[cmap(m)] = act(a[m] @ w.T + bias) (+ residual[rmap(m)]).  a (>=M, K) bf16, w (N, K) bf16."""
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    M = a.shape[0] if M is None else M
+    N, K = w.shape
+    assert a.shape[1] == K
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() >= N
+    if residual is not None:
+        assert residual.dtype == torch.float32
+    rc = _lib.load().sf_gemm_bf16(
+        _dev(a, 'a'), _ld(a), _dev(w, 'w'), _ld(w), _dev(bias, 'bias') if bias is not None else None,
+        _dev(out, 'out'), _DT[out.dtype], _ld(out), _map(c_map),
+        _dev(residual, 'residual') if residual is not None else None, _ld(residual) if residual is not None else 0,
+        _map(r_map), EPI_GELU if gelu else EPI_NONE, M, N, K, _stream())
+    _lib.check(rc, 'sf_gemm_bf16')
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, eps: float, *,
+              rows: Optional[int] = None, in_map: RowMap = None, out_map: RowMap = None, accumulate: bool = False):
+    assert x.dtype == torch.float32 and x.shape[1] == 768 and out.shape[1] == 768
+    rows = x.shape[0] if rows is None else rows
+    rc = _lib.load().sf_layernorm768(_dev(x, 'x'), _ld(x), _map(in_map), _dev(gamma, 'gamma'), _dev(beta, 'beta'),
+                                     _dev(out, 'out'), _DT[out.dtype], _ld(out), _map(out_map), int(accumulate), rows,
+                                     float(eps), _stream())
+    _lib.check(rc, 'sf_layernorm768')
+    return out
+
+
+def broadcast_rows(dst: torch.Tensor, table: torch.Tensor, n_seq: int, dst_seq_rows: int):
+    assert dst.dtype == torch.float32 and table.dtype == torch.float32 and table.shape[1] == 768 and table.is_contiguous()
+    rc = _lib.load().sf_broadcast_rows768(_dev(dst, 'dst'), _ld(dst), dst_seq_rows, _dev(table, 'table'), table.shape[0],
+                                          n_seq, _stream())
+    _lib.check(rc, 'sf_broadcast_rows768')
+    return dst
+
+
+def gather_rows(x: torch.Tensor, out: torch.Tensor, rows: int, in_map: RowMap = None):
+    assert x.dtype == torch.float32
+    rc = _lib.load().sf_gather_rows768(_dev(x, 'x'), _ld(x), _map(in_map), _dev(out, 'out'), _DT[out.dtype], _ld(out), rows,
+                                       _stream())
+    _lib.check(rc, 'sf_gather_rows768')
+    return out
+
+
+def im2col_video(vid: torch.Tensor, out: torch.Tensor):
+    """vid (n_seg, 16, 3, 224, 224) contiguous of u8/f16/bf16/f32 -> out bf16 (n_seg*1568, 1536)."""
+    assert vid.is_contiguous() and tuple(vid.shape[1:]) == (16, 3, 224, 224), tuple(vid.shape)
+    assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.shape[1] == 1536
+    rc = _lib.load().sf_im2col_video(_dev(vid, 'vid'), _DT[vid.dtype], _dev(out, 'out'), vid.shape[0], _stream())
+    _lib.check(rc, 'sf_im2col_video')
+    return out
+
+
+def im2col_spec(spec: torch.Tensor, out: torch.Tensor):
+    """spec fp32 (n_seg, F, Ta) contiguous -> out bf16 (n_seg*nf*nt, 256)."""
+    assert spec.is_contiguous() and spec.dtype == torch.float32 and spec.dim() == 3
+    assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.shape[1] == 256
+    rc = _lib.load().sf_im2col_spec(_dev(spec, 'spec'), _dev(out, 'out'), spec.shape[0], spec.shape[1], spec.shape[2],
+                                    _stream())
+    _lib.check(rc, 'sf_im2col_spec')
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, n_seq: int, seq_rows: int,
+              n_groups: int, row0: int, group_stride: int, tok_stride: int, n_tok: int, cls_row: int, heads: int,
+              head_dim: int, scale: float):
+    """q/k/v: column-slice views (rows, heads*head_dim) of a packed bf16 projection; see include/synchformer_hip.h."""
+    assert q.dtype == k.dtype == v.dtype == out.dtype == torch.bfloat16
+    assert _ld(q) == _ld(k) == _ld(v)
+    rc = _lib.load().sf_attention(_dev(q, 'q'), _dev(k, 'k'), _dev(v, 'v'), _ld(q), _dev(out, 'out'), _ld(out), n_seq,
+                                  seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim,
+                                  float(scale), _stream())
+    _lib.check(rc, 'sf_attention')
+    return out
+
+
+def attention_cls(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, n_seq: int, q_seq_rows: int,
+                  q_row: int, kv_seq_rows: int, kv_row0: int, n_keys: int, out_seq_rows: int, out_row: int, heads: int,
+                  head_dim: int, scale: float):
+    assert q.dtype == k.dtype == v.dtype == out.dtype == torch.bfloat16
+    assert _ld(q) == _ld(k) == _ld(v)
+    rc = _lib.load().sf_attention_cls(_dev(q, 'q'), q_seq_rows, q_row, _dev(k, 'k'), _dev(v, 'v'), _ld(q), kv_seq_rows,
+                                      kv_row0, n_keys, _dev(out, 'out'), _ld(out), out_seq_rows, out_row, n_seq, heads,
+                                      head_dim, float(scale), _stream())
+    _lib.check(rc, 'sf_attention_cls')
+    return out

@@ -1,0 +1,138 @@
+"""Deterministic synthetic weights and inputs for the Synchformer hot path.
+
+There is no network for checkpoints or datasets, so parity fixtures, `bench.py` and `smoke()` all run on
+random-init weights of the reference's architecture and on synthetic clips.  Values
+come from numpy's Philox bit generator keyed by `(seed, crc32(name))`, which is bit-reproducible on any
+machine with this numpy version - so the GPU box regenerates exactly the tensors the golden fixtures
+were produced from (tests/golden/make_golden.py) without shipping 237 M parameters.
+
+State-dict schema = SURVEY.md §8(b) (513 tensors for configs/sync.yaml); key names, shapes and order are
+the reference's (`model/sync_model.py`, `motionformer.py`, `modeling_ast.py`, `modules/transformer.py`).
+"""
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+D = 768
+FF = 3072
+
+
+def _enc_layer(prefix):  # nn.TransformerEncoderLayer + cls_token (motionformer.py:275-347)
+    return [
+        (f'{prefix}.cls_token', (1, 1, D)),
+        (f'{prefix}.self_attn.in_proj_weight', (3 * D, D)), (f'{prefix}.self_attn.in_proj_bias', (3 * D,)),
+        (f'{prefix}.self_attn.out_proj.weight', (D, D)), (f'{prefix}.self_attn.out_proj.bias', (D,)),
+        (f'{prefix}.linear1.weight', (FF, D)), (f'{prefix}.linear1.bias', (FF,)),
+        (f'{prefix}.linear2.weight', (D, FF)), (f'{prefix}.linear2.bias', (D,)),
+        (f'{prefix}.norm1.weight', (D,)), (f'{prefix}.norm1.bias', (D,)),
+        (f'{prefix}.norm2.weight', (D,)), (f'{prefix}.norm2.bias', (D,)),
+    ]
+
+
+def state_dict_schema(n_pos: int = 198, n_out: int = 21, vis_depth: int = 12, aud_depth: int = 12,
+                      sync_depth: int = 3, head: str = 'off_head') -> 'OrderedDict[str, tuple]':
+    """Ordered name -> shape for `Synchformer.state_dict()` built from configs/sync.yaml.
+    `head='sync_head'` gives the GlobalTransformerWithSyncabilityHead variant (sync_model.py:176-190)."""
+    s = []
+    v = 'vfeat_extractor'
+    s += [(f'{v}.cls_token', (1, 1, D)), (f'{v}.pos_embed', (1, 197, D)), (f'{v}.temp_embed', (1, 8, D)),
+          (f'{v}.patch_embed.proj.weight', (D, 3, 16, 16)), (f'{v}.patch_embed.proj.bias', (D,)),
+          (f'{v}.patch_embed_3d.proj.weight', (D, 3, 2, 16, 16)), (f'{v}.patch_embed_3d.proj.bias', (D,))]
+    for i in range(vis_depth):
+        b = f'{v}.blocks.{i}'
+        s += [(f'{b}.norm1.weight', (D,)), (f'{b}.norm1.bias', (D,))]
+        for a in ('attn', 'timeattn'):
+            s += [(f'{b}.{a}.qkv.weight', (3 * D, D)), (f'{b}.{a}.qkv.bias', (3 * D,)),
+                  (f'{b}.{a}.proj.weight', (D, D)), (f'{b}.{a}.proj.bias', (D,))]
+        s += [(f'{b}.norm2.weight', (D,)), (f'{b}.norm2.bias', (D,)),
+              (f'{b}.mlp.fc1.weight', (FF, D)), (f'{b}.mlp.fc1.bias', (FF,)),
+              (f'{b}.mlp.fc2.weight', (D, FF)), (f'{b}.mlp.fc2.bias', (D,)),
+              (f'{b}.norm3.weight', (D,)), (f'{b}.norm3.bias', (D,))]
+    s += [(f'{v}.norm.weight', (D,)), (f'{v}.norm.bias', (D,))]
+    s += _enc_layer(f'{v}.spatial_attn_agg')
+    a = 'afeat_extractor'
+    e = f'{a}.ast.embeddings'
+    s += [(f'{e}.cls_token', (1, 1, D)), (f'{e}.distillation_token', (1, 1, D)),
+          (f'{e}.position_embeddings', (1, 74, D)),
+          (f'{e}.patch_embeddings.projection.weight', (D, 1, 16, 16)),
+          (f'{e}.patch_embeddings.projection.bias', (D,))]
+    for i in range(aud_depth):
+        L = f'{a}.ast.encoder.layer.{i}'
+        for n in ('query', 'key', 'value'):
+            s += [(f'{L}.attention.attention.{n}.weight', (D, D)), (f'{L}.attention.attention.{n}.bias', (D,))]
+        s += [(f'{L}.attention.output.dense.weight', (D, D)), (f'{L}.attention.output.dense.bias', (D,)),
+              (f'{L}.intermediate.dense.weight', (FF, D)), (f'{L}.intermediate.dense.bias', (FF,)),
+              (f'{L}.output.dense.weight', (D, FF)), (f'{L}.output.dense.bias', (D,)),
+              (f'{L}.layernorm_before.weight', (D,)), (f'{L}.layernorm_before.bias', (D,)),
+              (f'{L}.layernorm_after.weight', (D,)), (f'{L}.layernorm_after.bias', (D,))]
+    s += [(f'{a}.ast.layernorm.weight', (D,)), (f'{a}.ast.layernorm.bias', (D,))]
+    s += _enc_layer(f'{a}.freq_attn_agg')
+    s += [('vproj.weight', (D, D)), ('vproj.bias', (D,)), ('aproj.weight', (D, D)), ('aproj.bias', (D,))]
+    t = 'transformer'
+    s += [(f'{t}.OFF_tok', (1, 1, D)), (f'{t}.MOD_tok', (1, 1, D)),
+          (f'{t}.vis_in_lnorm.weight', (D,)), (f'{t}.vis_in_lnorm.bias', (D,)),
+          (f'{t}.aud_in_lnorm.weight', (D,)), (f'{t}.aud_in_lnorm.bias', (D,)),
+          (f'{t}.pos_emb_cfg.pos_emb', (1, n_pos, D))]
+    for i in range(sync_depth):
+        b = f'{t}.blocks.{i}'
+        s += [(f'{b}.ln1.weight', (D,)), (f'{b}.ln1.bias', (D,)), (f'{b}.ln2.weight', (D,)), (f'{b}.ln2.bias', (D,))]
+        for n in ('key', 'query', 'value', 'proj'):
+            s += [(f'{b}.attn.{n}.weight', (D, D)), (f'{b}.attn.{n}.bias', (D,))]
+        s += [(f'{b}.mlp.0.weight', (FF, D)), (f'{b}.mlp.0.bias', (FF,)),
+              (f'{b}.mlp.2.weight', (D, FF)), (f'{b}.mlp.2.bias', (D,))]
+    s += [(f'{t}.ln_f.weight', (D,)), (f'{t}.ln_f.bias', (D,)),
+          (f'{t}.{head}.weight', (n_out, D)), (f'{t}.{head}.bias', (n_out,))]
+    return OrderedDict(s)
+
+
+_NORM_KEYS = ('norm', 'lnorm', '.ln1.', '.ln2.', '.ln_f.', 'layernorm')
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.Generator(np.random.Philox(key=[seed & 0xFFFFFFFF, zlib.crc32(name.encode())]))
+
+
+def fill_tensor(name: str, shape, seed: int, gain: float = 1.0) -> torch.Tensor:
+    """One tensor of the synthetic checkpoint (fp32).  Everything is non-degenerate on purpose: biases and
+    `patch_embed_3d.proj.weight` are non-zero (the reference zero-inits the latter, vmb:61, which would
+    make the visual branch input-independent - BASELINE.md §3), LayerNorm gains are 1 +- 0.1."""
+    n = _rng(seed, name).standard_normal(size=tuple(shape), dtype=np.float32)
+    is_norm = any(k in name for k in _NORM_KEYS)
+    if is_norm and name.endswith('weight'):
+        arr = 1.0 + 0.1 * n
+    elif name.endswith(('OFF_tok', 'MOD_tok', 'pos_emb_cfg.pos_emb')):
+        arr = n  # torch.randn init in the reference (sync_model.py:129-130, transformer.py:127)
+    elif name.endswith('weight') and len(shape) >= 2:
+        arr = (0.02 * gain) * n
+    else:
+        arr = 0.02 * n  # biases, tokens, position tables
+    return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
+
+
+def make_state_dict(seed: int = 1337, gain: float = 1.0, **schema_kw) -> 'OrderedDict[str, torch.Tensor]':
+    return OrderedDict((k, fill_tensor(k, shp, seed, gain)) for k, shp in state_dict_schema(**schema_kw).items())
+
+
+def make_video_u8(B: int, S: int = 14, seed: int = 1337, T: int = 16, H: int = 224, W: int = 224) -> torch.Tensor:
+    """(B, S, T, 3, H, W) uint8 frames, U{0..255} (SURVEY §8d synthetic input)."""
+    g = _rng(seed, f'video{B}x{S}')
+    return torch.from_numpy(g.integers(0, 256, size=(B, S, T, 3, H, W), dtype=np.uint8))
+
+
+def make_wave(B: int, S: int = 14, seed: int = 1337, n: int = 10240) -> torch.Tensor:
+    """(B, S, n) fp32 waveform segments U(-1, 1): 0.64 s @ 16 kHz (transforms.py:431)."""
+    g = _rng(seed, f'wave{B}x{S}')
+    return torch.from_numpy((g.random(size=(B, S, n), dtype=np.float32) * 2.0 - 1.0).astype(np.float32))
+
+
+def make_spectrogram(B: int, S: int = 14, seed: int = 1337, F: int = 128, Ta: int = 66) -> torch.Tensor:
+    """(B, S, 1, F, Ta) fp32 'already normalised' log-mel: N(0, 0.5^2) (SURVEY §8d alternative input)."""
+    g = _rng(seed, f'spec{B}x{S}')
+    return torch.from_numpy(0.5 * g.standard_normal(size=(B, S, 1, F, Ta), dtype=np.float32))
+
+
+def make_targets(B: int, n_cls: int = 21, seed: int = 1337) -> torch.Tensor:
+    g = _rng(seed, f'targets{B}')
+    return torch.from_numpy(g.integers(0, n_cls, size=(B,), dtype=np.int64))

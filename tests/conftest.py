@@ -1,0 +1,24 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU visible')
+    from synchformer_amd import _lib
+    _lib.load()   # fail loudly if the HIP extension is missing on a GPU box
+    return torch.device('cuda:0')

@@ -1,0 +1,106 @@
+"""Generate golden vectors by running the REAL reference (/root/reference) on CPU in the build container.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Inputs and weights are regenerated from seeds by `synchformer_amd.synth` (numpy Philox, bit-reproducible),
+so the fixtures hold only seeds + expected OUTPUTS (data, not reference source).  The reference cannot
+travel to the GPU box; these files can.
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(HERE.parent.parent))
+
+import ref_import  # noqa: E402
+from synchformer_amd import synth  # noqa: E402
+
+SEED = 1337
+TOK_V = [0, 1, 2, 197, 1000, 1568]   # token rows of the (1569) visual sequence kept in fixtures
+TOK_A = [0, 1, 2, 3, 40, 73]         # token rows of the (74) audio sequence kept in fixtures
+
+
+def rgb_frontend_ref(u8):
+    # the reference's own two transforms (dataset/transforms.py:653, :657-669 -> torchvision Normalize),
+    # applied verbatim in half precision; torchvision is absent so Normalize is spelled out.
+    x = u8.half().div(255.)
+    mean = torch.as_tensor([0.5, 0.5, 0.5], dtype=x.dtype).view(-1, 1, 1)
+    std = torch.as_tensor([0.5, 0.5, 0.5], dtype=x.dtype).view(-1, 1, 1)
+    return x.sub(mean).div(std)
+
+
+def capture(model, names):
+    store, hooks = {}, []
+    mods = dict(model.named_modules())
+
+    def mk(n):
+        def hook(_m, _inp, out):
+            o = out[0] if isinstance(out, tuple) else out
+            if hasattr(o, 'last_hidden_state'):
+                o = o.last_hidden_state
+            store[n] = o.detach().float()
+        return hook
+    for n in names:
+        hooks.append(mods[n].register_forward_hook(mk(n)))
+    return store, hooks
+
+
+def e2e_sync(B=2):
+    model = ref_import.build_reference_synchformer()
+    sd = synth.make_state_dict(SEED)
+    model.load_state_dict(sd, strict=True)
+    vis = rgb_frontend_ref(synth.make_video_u8(B, 14, SEED)).float()
+    aud = synth.make_spectrogram(B, 14, SEED)
+    tgt = synth.make_targets(B, 21, SEED)
+    v, a = 'vfeat_extractor', 'afeat_extractor'
+    names = [f'{v}.patch_embed_3d', f'{v}.blocks.0.timeattn', f'{v}.blocks.0.attn', f'{v}.blocks.0',
+             f'{v}.blocks.5', f'{v}.blocks.11', f'{v}.norm', f'{v}.spatial_attn_agg',
+             f'{a}.ast.embeddings', f'{a}.ast.encoder.layer.0', f'{a}.ast.encoder.layer.11', f'{a}.ast.layernorm',
+             f'{a}.freq_attn_agg', 'vproj', 'aproj', 'transformer.blocks.0', 'transformer.ln_f']
+    store, hooks = capture(model, names)
+    with torch.no_grad():
+        loss, logits = model(vis, aud, tgt)
+    for h in hooks:
+        h.remove()
+    out = dict(seed=np.int64(SEED), B=np.int64(B), logits=logits.numpy(), loss=loss.numpy(), targets=tgt.numpy())
+    for n, t in store.items():
+        key = n.replace('.', '__')
+        if n.startswith(v) and t.dim() == 3 and t.shape[1] in (1568, 1569):
+            rows = [r for r in TOK_V if r < t.shape[1]]
+            out[key] = t[[0, 13, -1]][:, rows].numpy()          # segments 0, 13 and last
+        elif n.startswith(a) and t.dim() == 3 and t.shape[1] == 74:
+            out[key] = t[[0, 13, -1]][:, TOK_A].numpy()
+        else:
+            out[key] = t.reshape(-1, t.shape[-1])[:64].numpy() if t.numel() > 200000 else t.numpy()
+        print(n, tuple(t.shape), '->', out[key].shape)
+    np.savez_compressed(HERE / f'e2e_sync_B{B}.npz', **out)
+    print('logits', logits, 'loss', loss)
+
+
+def e2e_syncability(B=1):
+    """configs/ft_synchability.yaml: S=13 segments, 184-token pos_emb, 2-way sync_head (sync_model.py:176-190)."""
+    model = ref_import.build_reference_synchformer(
+        n_segments_tokens=184, transformer_target='model.sync_model.GlobalTransformerWithSyncabilityHead')
+    sd = synth.make_state_dict(SEED, n_pos=184, n_out=2, head='sync_head')
+    ref_keys = list(model.state_dict().keys())
+    assert ref_keys == list(sd.keys()), set(ref_keys) ^ set(sd.keys())
+    model.load_state_dict(sd, strict=True)
+    vis = rgb_frontend_ref(synth.make_video_u8(B, 13, SEED)).float()
+    aud = synth.make_spectrogram(B, 13, SEED)
+    with torch.no_grad():
+        _, logits = model(vis, aud)
+    np.savez_compressed(HERE / f'e2e_syncability_B{B}.npz', seed=np.int64(SEED), B=np.int64(B), logits=logits.numpy())
+    print('syncability logits', logits)
+
+
+if __name__ == '__main__':
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ['sync', 'syncability']
+    if 'sync' in which:
+        e2e_sync(2)
+    if 'syncability' in which:
+        e2e_syncability(1)

@@ -1,0 +1,230 @@
+"""Per-kernel parity on the GPU: each `sf_*` entry point (called through the C ABI via synchformer_amd.ops)
+against a plain fp32 torch evaluation of the same op on the same (bf16-rounded) operands.
+Tolerances: outputs are bf16 (rel 2^-8) or fp32 sums of bf16 products; stated per test."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(t):
+    return t.bfloat16()
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def test_gemm_identity_asymmetric(gpu):
+    """A = I against an asymmetric W catches swapped fragment rows/cols (guide rule 16)."""
+    from synchformer_amd import ops
+    K = 128
+    a = torch.eye(K)
+    w = torch.arange(192 * K, dtype=torch.float32).reshape(192, K) % 251 - 125.0   # exactly representable in bf16
+    out = torch.empty(K, 192, device=gpu)
+    ops.gemm(_bf(a).to(gpu), _bf(w).to(gpu), None, out)
+    torch.testing.assert_close(out.cpu(), w.t().contiguous(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 768, 768), (128, 2304, 768), (1000, 768, 3072), (257, 3072, 768), (5, 21, 768),
+                                   (3, 2, 768), (1568 * 2, 768, 1536), (144, 768, 256)])
+def test_gemm_bias(gpu, M, N, K):
+    from synchformer_amd import ops
+    a, w, b = _bf(_rand(M, K, seed=1)), _bf(_rand(N, K, seed=2, scale=0.05)), _rand(N, seed=3)
+    ref = a.float() @ w.float().t() + b
+    out = torch.full((M + 3, N), 7.0, device=gpu)
+    ops.gemm(a.to(gpu), w.to(gpu), b.to(gpu), out, M=M)
+    torch.testing.assert_close(out[:M].cpu(), ref, rtol=1e-4, atol=2e-4)
+    assert (out[M:] == 7.0).all(), 'rows beyond M were written'
+    outb = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(a.to(gpu), w.to(gpu), b.to(gpu), outb)
+    torch.testing.assert_close(outb.float().cpu(), ref, rtol=1e-2, atol=1e-2)
+
+
+def test_gemm_gelu_residual_maps(gpu):
+    from synchformer_amd import ops
+    M, N, K = 400, 768, 768
+    a, w, b = _bf(_rand(M, K, seed=4)), _bf(_rand(N, K, seed=5, scale=0.05)), _rand(N, seed=6)
+    lin = a.float() @ w.float().t() + b
+    # GELU -> bf16
+    out = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(a.to(gpu), w.to(gpu), b.to(gpu), out, gelu=True)
+    torch.testing.assert_close(out.float().cpu(), torch.nn.functional.gelu(lin), rtol=1e-2, atol=1e-2)
+    # in-place fp32 residual
+    x = _rand(M, N, seed=7)
+    xd = x.to(gpu)
+    ops.gemm(a.to(gpu), w.to(gpu), b.to(gpu), xd, residual=xd)
+    torch.testing.assert_close(xd.cpu(), lin + x, rtol=1e-4, atol=3e-4)
+    # mapped output rows: 4 "sequences" of 100 rows dropped at offset 1 of 101-row sequences, residual from there too
+    cmap = ops.rowmap(100, 100, 101, 0, 1, 1)
+    y = _rand(4 * 101, N, seed=8)
+    yd = y.to(gpu)
+    ops.gemm(a.to(gpu), w.to(gpu), b.to(gpu), yd, residual=yd, c_map=cmap, r_map=cmap)
+    ref = y.clone().reshape(4, 101, N)
+    ref[:, 1:] += lin.reshape(4, 100, N)
+    torch.testing.assert_close(yd.cpu(), ref.reshape(-1, N), rtol=1e-4, atol=3e-4)
+
+
+@pytest.mark.parametrize('eps', [1e-12, 1e-6, 1e-5])
+def test_layernorm(gpu, eps):
+    from synchformer_amd import ops
+    rows = 1003
+    x = _rand(rows, 768, seed=9, scale=3.0) + 0.5
+    g, b = 1 + 0.1 * _rand(768, seed=10), 0.1 * _rand(768, seed=11)
+    ref = torch.nn.functional.layer_norm(x, (768,), g, b, eps)
+    out = torch.empty(rows, 768, device=gpu)
+    ops.layernorm(x.to(gpu), g.to(gpu), b.to(gpu), out, eps)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)
+    outb = torch.empty(rows, 768, device=gpu, dtype=torch.bfloat16)
+    ops.layernorm(x.to(gpu), g.to(gpu), b.to(gpu), outb, eps)
+    torch.testing.assert_close(outb.float().cpu(), ref, rtol=8e-3, atol=8e-3)
+
+
+def test_layernorm_maps_accumulate(gpu):
+    from synchformer_amd import ops
+    # drop-CLS + per-frame regroup exactly as the engine uses it: (2 seq x 1569) -> (2*8 x 197) rows 1..196
+    x = _rand(2 * 1569, 768, seed=12)
+    g, b = 1 + 0.1 * _rand(768, seed=13), 0.1 * _rand(768, seed=14)
+    z = torch.zeros(2 * 8 * 197, 768)
+    zd = z.to(gpu)
+    ops.layernorm(x.to(gpu), g.to(gpu), b.to(gpu), zd, 1e-6, rows=2 * 1568,
+                  in_map=ops.rowmap(1568, 1568, 1569, 0, 1, 1), out_map=ops.rowmap(1568, 196, 8 * 197, 197, 1, 1))
+    ref = torch.nn.functional.layer_norm(x.reshape(2, 1569, 768)[:, 1:], (768,), g, b, 1e-6).reshape(16, 196, 768)
+    got = zd.cpu().reshape(16, 197, 768)
+    torch.testing.assert_close(got[:, 1:], ref, rtol=1e-5, atol=1e-5)
+    assert (got[:, 0] == 0).all()
+    # transposing map (audio aggregator): (bs, fi, ti) -> (bs*6 + ti)*13 + 1 + fi, accumulate onto a table
+    xa = _rand(3 * 74, 768, seed=15)
+    base = _rand(3 * 6 * 13, 768, seed=16)
+    bd = base.to(gpu)
+    ops.layernorm(xa.to(gpu), g.to(gpu), b.to(gpu), bd, 1e-12, rows=3 * 72, in_map=ops.rowmap(72, 72, 74, 0, 1, 2),
+                  out_map=ops.rowmap(72, 6, 78, 1, 13, 1), accumulate=True)
+    ln = torch.nn.functional.layer_norm(xa.reshape(3, 74, 768)[:, 2:], (768,), g, b, 1e-12).reshape(3, 12, 6, 768)
+    ref = base.clone().reshape(3, 6, 13, 768)
+    ref[:, :, 1:] += ln.permute(0, 2, 1, 3)
+    torch.testing.assert_close(bd.cpu().reshape(3, 6, 13, 768), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_broadcast_gather(gpu):
+    from synchformer_amd import ops
+    table = _rand(5, 768, seed=17)
+    dst = torch.zeros(3 * 9, 768, device=gpu)
+    ops.broadcast_rows(dst, table.to(gpu), n_seq=3, dst_seq_rows=9)
+    got = dst.cpu().reshape(3, 9, 768)
+    assert (got[:, :5] == table).all() and (got[:, 5:] == 0).all()
+    x = _rand(4 * 197, 768, seed=18)
+    out = torch.empty(4, 768, device=gpu, dtype=torch.bfloat16)
+    ops.gather_rows(x.to(gpu), out, 4, in_map=ops.rowmap(1, 1, 197, 0, 0, 0))
+    torch.testing.assert_close(out.float().cpu(), x.reshape(4, 197, 768)[:, 0].bfloat16().float(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('dtype', [torch.uint8, torch.float16, torch.bfloat16, torch.float32])
+def test_im2col_video(gpu, dtype):
+    from synchformer_amd import ops, synth
+    from oracle import synchformer_cpu as O
+    u8 = synth.make_video_u8(1, 2, seed=5)[0]                 # (2, 16, 3, 224, 224)
+    if dtype == torch.uint8:
+        vid, ref_in = u8, O.rgb_frontend(u8)
+    else:
+        vid = O.rgb_frontend(u8).to(dtype)
+        ref_in = vid.float()
+    out = torch.empty(2 * 1568, 1536, device=gpu, dtype=torch.bfloat16)
+    ops.im2col_video(vid.contiguous().to(gpu), out)
+    x = ref_in.permute(0, 2, 1, 3, 4)                          # (N, C, T, H, W) as patch_embed_3d expects
+    ref = x.reshape(2, 3, 8, 2, 14, 16, 14, 16).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(2 * 1568, 1536)
+    torch.testing.assert_close(out.float().cpu(), ref.bfloat16().float(), rtol=0, atol=0)
+
+
+def test_im2col_spec(gpu):
+    from synchformer_amd import ops
+    spec = _rand(3, 128, 66, seed=19)
+    out = torch.empty(3 * 72, 256, device=gpu, dtype=torch.bfloat16)
+    ops.im2col_spec(spec.to(gpu), out)
+    ref = spec.unfold(1, 16, 10).unfold(2, 16, 10).reshape(3 * 72, 256)
+    torch.testing.assert_close(out.float().cpu(), ref.bfloat16().float(), rtol=0, atol=0)
+
+
+def _attn_ref(q, k, v, scale):
+    s = (q @ k.transpose(-1, -2)) * scale
+    return torch.softmax(s, -1) @ v
+
+
+def _divided_ref(qkv, mode, heads=12, frames=8, n=196):
+    """fp32 divided attention on packed (N, L, 3*768) projections (vit_helper.py:100-158 semantics), patches only."""
+    N, L, _ = qkv.shape
+    d = 64
+    t = qkv.reshape(N, L, 3, heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0], t[1], t[2]
+    def grp(x):
+        x = x[:, :, 1:].reshape(N, heads, frames, n, d)
+        return x.transpose(2, 3) if mode == 'time' else x
+    qg, kg, vg = grp(q), grp(k), grp(v)
+    G = qg.shape[2]
+    kc = k[:, :, :1].unsqueeze(2).expand(N, heads, G, 1, d)
+    vc = v[:, :, :1].unsqueeze(2).expand(N, heads, G, 1, d)
+    og = _attn_ref(qg, torch.cat([kc, kg], 3), torch.cat([vc, vg], 3), d ** -0.5)
+    if mode == 'time':
+        og = og.transpose(2, 3)
+    cls = _attn_ref(q[:, :, :1], k, v, d ** -0.5)
+    out = torch.cat([cls, og.reshape(N, heads, frames * n, d)], 2)
+    return out.transpose(1, 2).reshape(N, L, heads * d)
+
+
+@pytest.mark.parametrize('mode', ['time', 'space'])
+def test_divided_attention(gpu, mode):
+    from synchformer_amd import ops
+    N, L = 2, 1569
+    qkv = _bf(_rand(N * L, 2304, seed=20, scale=1.5))
+    ref = _divided_ref(qkv.float().reshape(N, L, 2304), mode)
+    qd = qkv.to(gpu)
+    out = torch.zeros(N * L, 768, device=gpu, dtype=torch.bfloat16)
+    q, k, v = qd[:, :768], qd[:, 768:1536], qd[:, 1536:]
+    if mode == 'time':
+        ops.attention(q, k, v, out, n_seq=N, seq_rows=L, n_groups=196, row0=1, group_stride=1, tok_stride=196, n_tok=8,
+                      cls_row=0, heads=12, head_dim=64, scale=0.125)
+    else:
+        ops.attention(q, k, v, out, n_seq=N, seq_rows=L, n_groups=8, row0=1, group_stride=196, tok_stride=1, n_tok=196,
+                      cls_row=0, heads=12, head_dim=64, scale=0.125)
+    ops.attention_cls(q, k, v, out, n_seq=N, q_seq_rows=L, q_row=0, kv_seq_rows=L, kv_row0=0, n_keys=L, out_seq_rows=L,
+                      out_row=0, heads=12, head_dim=64, scale=0.125)
+    torch.testing.assert_close(out.float().cpu().reshape(N, L, 768), ref, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize('L,heads,d', [(74, 12, 64), (198, 8, 96), (184, 8, 96), (13, 12, 64), (197, 12, 64), (17, 12, 64)])
+def test_full_attention(gpu, L, heads, d):
+    from synchformer_amd import ops
+    N, Dm = 3, heads * d
+    qkv = _bf(_rand(N * L, 3 * Dm, seed=21, scale=1.2))
+    t = qkv.float().reshape(N, L, 3, heads, d).permute(2, 0, 3, 1, 4)
+    ref = _attn_ref(t[0], t[1], t[2], 1 / math.sqrt(d)).transpose(1, 2).reshape(N, L, Dm)
+    qd = qkv.to(gpu)
+    out = torch.zeros(N * L, Dm, device=gpu, dtype=torch.bfloat16)
+    ops.attention(qd[:, :Dm], qd[:, Dm:2 * Dm], qd[:, 2 * Dm:], out, n_seq=N, seq_rows=L, n_groups=1, row0=0,
+                  group_stride=0, tok_stride=1, n_tok=L, cls_row=-1, heads=heads, head_dim=d, scale=1 / math.sqrt(d))
+    torch.testing.assert_close(out.float().cpu().reshape(N, L, Dm), ref, rtol=2e-2, atol=2e-2)
+    if d == 64:   # the CLS-only kernel must agree with row 0 of the full attention
+        oc = torch.zeros(N, Dm, device=gpu, dtype=torch.bfloat16)
+        ops.attention_cls(qd[:, :Dm], qd[:, Dm:2 * Dm], qd[:, 2 * Dm:], oc, n_seq=N, q_seq_rows=L, q_row=0, kv_seq_rows=L,
+                          kv_row0=0, n_keys=L, out_seq_rows=1, out_row=0, heads=heads, head_dim=d, scale=1 / math.sqrt(d))
+        torch.testing.assert_close(oc.float().cpu(), ref[:, 0], rtol=2e-2, atol=2e-2)
+
+
+def test_attention_sharp_softmax(gpu):
+    """Large-magnitude scores (trained-model regime): exercises max-subtraction and the online-softmax merges."""
+    from synchformer_amd import ops
+    N, L, heads, d = 2, 197, 12, 64
+    qkv = _bf(_rand(N * L, 2304, seed=22, scale=6.0))
+    t = qkv.float().reshape(N, L, 3, heads, d).permute(2, 0, 3, 1, 4)
+    ref = _attn_ref(t[0], t[1], t[2], 0.125).transpose(1, 2).reshape(N, L, 768)
+    qd = qkv.to(gpu)
+    out = torch.zeros(N * L, 768, device=gpu, dtype=torch.bfloat16)
+    ops.attention(qd[:, :768], qd[:, 768:1536], qd[:, 1536:], out, n_seq=N, seq_rows=L, n_groups=1, row0=0,
+                  group_stride=0, tok_stride=1, n_tok=L, cls_row=-1, heads=heads, head_dim=d, scale=0.125)
+    torch.testing.assert_close(out.float().cpu().reshape(N, L, 768), ref, rtol=3e-2, atol=6e-2)
+    oc = torch.zeros(N, 768, device=gpu, dtype=torch.bfloat16)
+    ops.attention_cls(qd[:, :768], qd[:, 768:1536], qd[:, 1536:], oc, n_seq=N, q_seq_rows=L, q_row=0, kv_seq_rows=L,
+                      kv_row0=0, n_keys=L, out_seq_rows=1, out_row=0, heads=heads, head_dim=d, scale=0.125)
+    torch.testing.assert_close(oc.float().cpu(), ref[:, 0], rtol=3e-2, atol=6e-2)
