@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""Headline benchmark: clips/sec of Synchformer offset prediction (14 x 0.64 s segments, 21 offset classes).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: batched offset inference, configs/sync.yaml model, random-init weights,
+synthetic 224x224 @ 25 fps uint8 frames + 128x66 log-mel spectrograms already resident in HBM.  One "step" = one
+full Synchformer.forward() (RGB front-end -> Motionformer -> AST -> sync transformer -> logits) over B clips per GPU.
+Multi-GPU: inference shards by clip with no data-path collective ("replicas only"): every rank runs
+its own B clips; value = all clips / max-over-ranks time (weak scaling).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the bf16 GEMM, timed live with HIP events on the
+launch stream) and `cpu_baseline` (the CPU oracle timed on this box's host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch  # noqa: E402
+
+FLOP_PER_CLIP = 5.725e12          # algorithmic forward FLOPs per 14-segment clip
+PEAK_BF16 = 2.5e15                # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=16, help='clips per GPU per step (configs/sync.yaml batch = 16)')
+    ap.add_argument('--seg-chunk', type=int, default=28)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    return ap.parse_args()
+
+
+class GemmTimer:
+    """Brackets every sf_gemm_bf16 launch with HIP events on the launch stream (= torch's current stream)."""
+
+    def __init__(self):
+        from synchformer_amd import ops
+        self.ops = ops
+        self.orig = ops.gemm
+        self.records = []
+        self.enabled = False
+
+    def __enter__(self):
+        def timed(a, w, bias, out, *, M=None, **kw):
+            if not self.enabled:
+                return self.orig(a, w, bias, out, M=M, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self.orig(a, w, bias, out, M=M, **kw)
+            e1.record()
+            m = a.shape[0] if M is None else M
+            self.records.append((e0, e1, 2.0 * m * w.shape[0] * w.shape[1]))
+            return r
+        self.ops.gemm = timed
+        return self
+
+    def __exit__(self, *a):
+        self.ops.gemm = self.orig
+
+    def summary(self):
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        return len(self.records), ms, fl
+
+
+def cpu_baseline(seconds_budget=25.0, max_threads=32):
+    """The CPU oracle (restatement of the reference, proven equal to it in the build container) timed on the host
+    cores of this box, fp32.  BOUNDED sample: the visual branch (97.6 % of the path's CPU time) is timed
+    on `k` of the 14 segments of one clip and scaled by 14/k (segments are independent and identical in cost); the audio
+    branch and the sync transformer are timed in full for the clip.  Threads are capped: beyond ~32 the 768-wide matmuls
+    of this path slow down on a many-core host (measured), so `cores` reports the threads actually used."""
+    from synchformer_amd import synth
+    from oracle import synchformer_cpu as O
+    threads = max(1, min(os.cpu_count() or 1, max_threads))
+    torch.set_num_threads(threads)
+    sd = synth.make_state_dict(1337)
+    vis = O.rgb_frontend(synth.make_video_u8(1, 14))
+    aud = synth.make_spectrogram(1, 14)
+    with torch.no_grad():
+        O.extract_vfeats(vis[:, :1], sd)                      # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        O.extract_vfeats(vis[:, :1], sd)
+        t1 = time.perf_counter() - t0
+        k = int(max(1, min(14, (seconds_budget - 2 * t1) // max(t1, 1e-3))))
+        t0 = time.perf_counter()
+        vf = O.extract_vfeats(vis[:, :k], sd, chunk=7)
+        t_vis = (time.perf_counter() - t0) * 14.0 / k
+        t0 = time.perf_counter()
+        af = O.extract_afeats(aud, sd)
+        v = O._lin(vf, sd, 'vproj')
+        O.global_transformer(torch.cat([v] * (14 // k + 1), 1)[:, :14].reshape(1, -1, 768), O._lin(af, sd, 'aproj').reshape(1, -1, 768), sd)
+        t_rest = time.perf_counter() - t0
+    total = t_vis + t_rest
+    return {'value': 1.0 / total, 'unit': 'clips/s', 'cores': threads, 'kind': 'port',
+            'sample': f'1 clip: visual branch on {k}/14 segments scaled x14/{k} ({t_vis:.1f} s/clip), audio branch + sync '
+                      f'transformer in full ({t_rest:.2f} s); fp32 torch CPU oracle; host has {os.cpu_count()} cpus'}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N > 1')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from synchformer_amd import synth
+    from synchformer_amd.engine import SynchformerEngine
+    B = args.batch
+    eng = SynchformerEngine(synth.make_state_dict(1337), dev, seg_chunk=args.seg_chunk)
+    vis = synth.make_video_u8(B, 14, seed=1337 + rank).to(dev)            # (B,14,16,3,224,224) uint8, HBM-resident
+    aud = synth.make_spectrogram(B, 14, seed=1337 + rank).to(dev)         # (B,14,1,128,66) fp32
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        logits = eng.forward(vis, aud)
+    with GemmTimer() as gt:
+        gt.enabled = (rank == 0) and not args.no_kernel_timing
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            logits = eng.forward(vis, aud)
+        barrier()
+        dt = time.perf_counter() - t0
+        n_gemm, gemm_ms, gemm_flop = gt.summary() if gt.enabled else (0, 0.0, 0.0)
+    assert torch.isfinite(logits).all()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    clips = B * world * args.steps
+    value = clips / dt
+    if rank == 0:
+        out = {
+            'metric': 'clips/sec (14-seg offset pred)', 'value': round(value, 3), 'unit': 'clips/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: batched offset inference, configs/sync.yaml model (237.5M params, '
+                                   'random-init), uint8 224x224 frames + 128x66 log-mel resident in HBM, full forward to 21-way logits',
+                       'clips_per_gpu': B, 'segments': 14, 'seg_chunk': args.seg_chunk, 'parallelism': f'replicas x{world}'},
+            'path_flop_per_clip': FLOP_PER_CLIP,
+            'path_mfma_frac': round(value * FLOP_PER_CLIP / (world * PEAK_BF16), 4),
+        }
+        if n_gemm:
+            ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16_128x128_kernel', 'achieved': round(ach, 1),
+                               'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': round(ach / (PEAK_BF16 / 1e12), 4),
+                               'traffic': None, 'launches': n_gemm // args.steps,
+                               'avg_launch_ms': round(gemm_ms / n_gemm, 4),
+                               'flop_per_launch': gemm_flop / n_gemm,
+                               'share_of_step_time': round(gemm_ms * 1e-3 / dt, 3)}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -44,6 +44,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64; import it FIRST so this library binds to the same HIP runtime instance
+    # (loading ours first would pull /opt/rocm's copy and leave the process with two runtimes that cannot see
+    # each other's allocations or streams).
+    import torch  # noqa: F401
     path = lib_path()
     if not path.exists():
         raise RuntimeError(f'{path} not found: the HIP extension is not built. There is no CPU fallback; run '

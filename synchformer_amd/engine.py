@@ -1,0 +1,336 @@
+"""Forward engine: Synchformer.forward() as a fixed schedule of libsynchformer_hip launches.
+
+Host side of the hot path.  It owns (1) weight preparation - bf16 GEMM operands,
+fp32 biases/LN parameters, fused q|k|v weights, and the positional tables with their CLS/DISTILL/OFF/MOD rows
+folded in - and (2) the launch order and workspace.  Every FLOP and every activation byte is produced by a
+kernel of the C ABI (`ops.*`); torch only allocates device memory and provides the stream.
+
+HBM layout (all row-major, 768-wide token matrices; one "sequence" = one 0.64 s segment):
+  X   fp32 (n*1569, 768)   residual stream of the visual branch (fp32 like the reference's autocast residual)
+  XN  bf16 (n*1576, 768)   LayerNorm output / attention output (GEMM A operands)
+  BIG bf16 (n*1576*3072)   qkv (.., 2304) | MLP hidden (.., 3072) | im2col patches (n*1568, 1536), time-shared
+  Z   fp32 (n*8*197, 768)  per-frame aggregator sequences [agg_cls; 196 patch tokens]
+Segments are processed `seg_chunk` at a time so that X/XN/BIG of a chunk stay L2/Infinity-Cache friendly and the
+workspace stays small; chunking changes nothing numerically (segments are independent until vproj/aproj,
+the reference's own `for_loop` switch, motionformer.py:200-207).
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+
+D = 768
+FF = 3072
+VIS_L = 1569          # 1 + 8*196 tokens per visual segment
+VIS_P = 1568
+AGG_V = 197           # agg cls + 196 patches per frame
+AUD_L = 74            # CLS + DISTILL + 12*6 patches
+AUD_P = 72
+AGG_A = 13            # agg cls + 12 frequency tokens per time step
+EPS_VIS, EPS_AST, EPS_SYNC = 1e-6, 1e-12, 1e-5
+
+
+class _Lin:
+    """bf16 weight (N, K) + fp32 bias (N,) on device."""
+    __slots__ = ('w', 'b')
+
+    def __init__(self, w, b, dev):
+        self.w = w.detach().to(dev, torch.bfloat16).contiguous()
+        self.b = b.detach().to(dev, torch.float32).contiguous() if b is not None else None
+
+
+class _LN:
+    __slots__ = ('g', 'b')
+
+    def __init__(self, sd, name, dev):
+        self.g = sd[name + '.weight'].detach().to(dev, torch.float32).contiguous()
+        self.b = sd[name + '.bias'].detach().to(dev, torch.float32).contiguous()
+
+
+class SynchformerEngine:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device='cuda:0', seg_chunk: int = 28):
+        self.dev = torch.device(device)
+        if self.dev.type != 'cuda':
+            raise RuntimeError('SynchformerEngine needs a HIP device; there is no CPU path in the product')
+        self.seg_chunk = seg_chunk
+        self._ws = {}
+        self.load_weights(state_dict)
+
+    # ------------------------------------------------------------------------------------------------
+    # weight preparation (one-off; not on the hot path)
+    # ------------------------------------------------------------------------------------------------
+    def load_weights(self, sd: Dict[str, torch.Tensor]):
+        dev = self.dev
+        f32 = lambda k: sd[k].detach().to(dev, torch.float32)
+        lin = lambda k: _Lin(sd[k + '.weight'], sd[k + '.bias'], dev)
+        v = 'vfeat_extractor'
+        self.v_pe = _Lin(sd[f'{v}.patch_embed_3d.proj.weight'].reshape(D, -1), sd[f'{v}.patch_embed_3d.proj.bias'], dev)
+        pos, temp = f32(f'{v}.pos_embed')[0], f32(f'{v}.temp_embed')[0]
+        body = (pos[1:].unsqueeze(0) + temp.unsqueeze(1)).reshape(-1, D)       # row f*196+n (vmb:248-254)
+        self.v_table = torch.cat([pos[:1] + f32(f'{v}.cls_token')[0], body], 0).contiguous()   # (1569, 768)
+        self.v_blocks = []
+        i = 0
+        while f'{v}.blocks.{i}.norm1.weight' in sd:
+            b = f'{v}.blocks.{i}'
+            self.v_blocks.append(dict(
+                norm1=_LN(sd, b + '.norm1', dev), norm2=_LN(sd, b + '.norm2', dev), norm3=_LN(sd, b + '.norm3', dev),
+                t_qkv=lin(b + '.timeattn.qkv'), t_proj=lin(b + '.timeattn.proj'),
+                s_qkv=lin(b + '.attn.qkv'), s_proj=lin(b + '.attn.proj'),
+                fc1=lin(b + '.mlp.fc1'), fc2=lin(b + '.mlp.fc2')))
+            i += 1
+        self.v_norm = _LN(sd, f'{v}.norm', dev)
+        self.v_agg = self._agg(sd, f'{v}.spatial_attn_agg')
+        a = 'afeat_extractor'
+        e = f'{a}.ast.embeddings'
+        self.a_pe = _Lin(sd[f'{e}.patch_embeddings.projection.weight'].reshape(D, -1),
+                         sd[f'{e}.patch_embeddings.projection.bias'], dev)
+        tab = f32(f'{e}.position_embeddings')[0].clone()
+        tab[0] += f32(f'{e}.cls_token')[0, 0]
+        tab[1] += f32(f'{e}.distillation_token')[0, 0]
+        self.a_table = tab.contiguous()                                          # (74, 768)
+        self.a_layers = []
+        i = 0
+        while f'{a}.ast.encoder.layer.{i}.layernorm_before.weight' in sd:
+            L = f'{a}.ast.encoder.layer.{i}'
+            att = L + '.attention.attention'
+            qkv_w = torch.cat([sd[f'{att}.{n}.weight'] for n in ('query', 'key', 'value')], 0)
+            qkv_b = torch.cat([sd[f'{att}.{n}.bias'] for n in ('query', 'key', 'value')], 0)
+            self.a_layers.append(dict(
+                ln1=_LN(sd, L + '.layernorm_before', dev), ln2=_LN(sd, L + '.layernorm_after', dev),
+                qkv=_Lin(qkv_w, qkv_b, dev), o=lin(L + '.attention.output.dense'),
+                fc1=lin(L + '.intermediate.dense'), fc2=lin(L + '.output.dense')))
+            i += 1
+        self.a_norm = _LN(sd, f'{a}.ast.layernorm', dev)
+        self.a_agg = self._agg(sd, f'{a}.freq_attn_agg')
+        self.vproj, self.aproj = lin('vproj'), lin('aproj')
+        t = 'transformer'
+        self.s_vln, self.s_aln = _LN(sd, f'{t}.vis_in_lnorm', dev), _LN(sd, f'{t}.aud_in_lnorm', dev)
+        self.s_pos = f32(f'{t}.pos_emb_cfg.pos_emb')[0].contiguous()
+        self.s_off, self.s_mod = f32(f'{t}.OFF_tok')[0, 0], f32(f'{t}.MOD_tok')[0, 0]
+        self._s_tables = {}
+        self.s_blocks = []
+        i = 0
+        while f'{t}.blocks.{i}.ln1.weight' in sd:
+            b = f'{t}.blocks.{i}'
+            qkv_w = torch.cat([sd[f'{b}.attn.{n}.weight'] for n in ('query', 'key', 'value')], 0)
+            qkv_b = torch.cat([sd[f'{b}.attn.{n}.bias'] for n in ('query', 'key', 'value')], 0)
+            self.s_blocks.append(dict(ln1=_LN(sd, b + '.ln1', dev), ln2=_LN(sd, b + '.ln2', dev),
+                                      qkv=_Lin(qkv_w, qkv_b, dev), proj=lin(b + '.attn.proj'),
+                                      fc1=lin(b + '.mlp.0'), fc2=lin(b + '.mlp.2')))
+            i += 1
+        self.s_heads = 8
+        self.s_lnf = _LN(sd, f'{t}.ln_f', dev)
+        head = 'off_head' if f'{t}.off_head.weight' in sd else 'sync_head'
+        self.s_head = lin(f'{t}.{head}')
+        self.n_out = self.s_head.w.shape[0]
+
+    def _agg(self, sd, p):
+        dev = self.dev
+        return dict(cls=sd[p + '.cls_token'].detach().to(dev, torch.float32).reshape(1, D).contiguous(),
+                    norm1=_LN(sd, p + '.norm1', dev), norm2=_LN(sd, p + '.norm2', dev),
+                    qkv=_Lin(sd[p + '.self_attn.in_proj_weight'], sd[p + '.self_attn.in_proj_bias'], dev),
+                    o=_Lin(sd[p + '.self_attn.out_proj.weight'], sd[p + '.self_attn.out_proj.bias'], dev),
+                    fc1=_Lin(sd[p + '.linear1.weight'], sd[p + '.linear1.bias'], dev),
+                    fc2=_Lin(sd[p + '.linear2.weight'], sd[p + '.linear2.bias'], dev))
+
+    def _sync_table(self, Sv: int, Sa: int):
+        key = (Sv, Sa)
+        if key not in self._s_tables:
+            L = 2 + Sv + Sa
+            if L > self.s_pos.shape[0]:
+                raise ValueError(f'sequence of {L} tokens exceeds pos_emb length {self.s_pos.shape[0]}')
+            tab = self.s_pos[:L].clone()
+            tab[0] += self.s_off
+            tab[1 + Sv] += self.s_mod
+            self._s_tables[key] = tab.contiguous()
+        return self._s_tables[key]
+
+    # ------------------------------------------------------------------------------------------------
+    # workspace
+    # ------------------------------------------------------------------------------------------------
+    def _buf(self, name, numel, dtype):
+        t = self._ws.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = torch.zeros(numel, device=self.dev, dtype=dtype)
+            self._ws[name] = t
+        return t[:numel]
+
+    # ------------------------------------------------------------------------------------------------
+    # shared sub-schedules
+    # ------------------------------------------------------------------------------------------------
+    def _agg_layer(self, Z, n_seq, L, agg, out, tag):
+        """BaseEncoderLayer (motionformer.py:301-334): Z fp32 (n_seq*L, 768) already holds [agg_cls; tokens].
+        Only output row 0 of each sequence is ever read (:332), so everything after K/V is computed for row 0 only."""
+        rows = n_seq * L
+        zn = self._buf('XN', rows * D, torch.bfloat16).view(rows, D)
+        qkv = self._buf('BIG', rows * 3 * D, torch.bfloat16).view(rows, 3 * D)
+        ops.layernorm(Z, agg['norm1'].g, agg['norm1'].b, zn, EPS_VIS)
+        ops.gemm(zn, agg['qkv'].w, agg['qkv'].b, qkv)
+        att = self._buf(tag + '_att', n_seq * D, torch.bfloat16).view(n_seq, D)
+        ops.attention_cls(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], att, n_seq=n_seq, q_seq_rows=L, q_row=0,
+                          kv_seq_rows=L, kv_row0=0, n_keys=L, out_seq_rows=1, out_row=0, heads=12, head_dim=64,
+                          scale=0.125)
+        y = self._buf(tag + '_y', n_seq * D, torch.float32).view(n_seq, D)
+        ops.gemm(att, agg['o'].w, agg['o'].b, y, residual=Z, r_map=ops.rowmap(1, 1, L, 0, 0, 0))
+        yn = self._buf(tag + '_yn', n_seq * D, torch.bfloat16).view(n_seq, D)
+        ops.layernorm(y, agg['norm2'].g, agg['norm2'].b, yn, EPS_VIS)
+        h = self._buf(tag + '_h', n_seq * FF, torch.bfloat16).view(n_seq, FF)
+        ops.gemm(yn, agg['fc1'].w, agg['fc1'].b, h, gelu=True)
+        ops.gemm(h, agg['fc2'].w, agg['fc2'].b, out, residual=y)
+        return out
+
+    def _encoder_layer(self, X, rows, xn, big, ln1, qkv, attn_fn, proj, ln2, fc1, fc2, eps):
+        """pre-LN transformer layer on the fp32 residual stream X (rows, 768): AST layer / sync Block."""
+        ops.layernorm(X, ln1.g, ln1.b, xn, eps, rows=rows)
+        q3 = big[:rows * 3 * D].view(rows, 3 * D)
+        ops.gemm(xn, qkv.w, qkv.b, q3, M=rows)
+        attn_fn(q3, xn)
+        ops.gemm(xn, proj.w, proj.b, X, M=rows, residual=X)
+        ops.layernorm(X, ln2.g, ln2.b, xn, eps, rows=rows)
+        h = big[:rows * FF].view(rows, FF)
+        ops.gemm(xn, fc1.w, fc1.b, h, M=rows, gelu=True)
+        ops.gemm(h, fc2.w, fc2.b, X, M=rows, residual=X)
+
+    # ------------------------------------------------------------------------------------------------
+    # visual branch
+    # ------------------------------------------------------------------------------------------------
+    def _visual_chunk(self, vid, out):
+        """vid (n, 16, 3, 224, 224) u8|f16|bf16|f32 on device -> out fp32 (n*8, 768).  a3-a9 of SURVEY §8a."""
+        n = vid.shape[0]
+        rows = n * VIS_L
+        X = self._buf('X', rows * D, torch.float32).view(rows, D)
+        xn = self._buf('XN', n * 8 * AGG_V * D, torch.bfloat16)[:rows * D].view(rows, D)
+        big = self._buf('BIG', n * 8 * AGG_V * FF, torch.bfloat16)
+        patches = big[:n * VIS_P * 1536].view(n * VIS_P, 1536)
+        ops.im2col_video(vid, patches)
+        ops.broadcast_rows(X, self.v_table, n_seq=n, dst_seq_rows=VIS_L)
+        tokmap = ops.rowmap(VIS_P, VIS_P, VIS_L, 0, 1, 1)
+        ops.gemm(patches, self.v_pe.w, self.v_pe.b, X, residual=X, c_map=tokmap, r_map=tokmap)
+        qkv = big[:rows * 3 * D].view(rows, 3 * D)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        hid = big[:rows * FF].view(rows, FF)
+
+        def divided(kind):
+            if kind == 'time':   # '(b n) f d' groups (vit_helper.py:343-344)
+                ops.attention(q, k, v, xn, n_seq=n, seq_rows=VIS_L, n_groups=196, row0=1, group_stride=1, tok_stride=196,
+                              n_tok=8, cls_row=0, heads=12, head_dim=64, scale=0.125)
+            else:                # '(b f) n d' groups (vit_helper.py:341-342)
+                ops.attention(q, k, v, xn, n_seq=n, seq_rows=VIS_L, n_groups=8, row0=1, group_stride=196, tok_stride=1,
+                              n_tok=196, cls_row=0, heads=12, head_dim=64, scale=0.125)
+            ops.attention_cls(q, k, v, xn, n_seq=n, q_seq_rows=VIS_L, q_row=0, kv_seq_rows=VIS_L, kv_row0=0,
+                              n_keys=VIS_L, out_seq_rows=VIS_L, out_row=0, heads=12, head_dim=64, scale=0.125)
+
+        for b in self.v_blocks:   # DividedSpaceTimeBlock.forward (vit_helper.py:364-376)
+            ops.layernorm(X, b['norm3'].g, b['norm3'].b, xn, EPS_VIS)
+            ops.gemm(xn, b['t_qkv'].w, b['t_qkv'].b, qkv)
+            divided('time')
+            ops.gemm(xn, b['t_proj'].w, b['t_proj'].b, X, residual=X)
+            ops.layernorm(X, b['norm1'].g, b['norm1'].b, xn, EPS_VIS)
+            ops.gemm(xn, b['s_qkv'].w, b['s_qkv'].b, qkv)
+            divided('space')
+            ops.gemm(xn, b['s_proj'].w, b['s_proj'].b, X, residual=X)
+            ops.layernorm(X, b['norm2'].g, b['norm2'].b, xn, EPS_VIS)
+            ops.gemm(xn, b['fc1'].w, b['fc1'].b, hid, gelu=True)
+            ops.gemm(hid, b['fc2'].w, b['fc2'].b, X, residual=X)
+        # drop CLS -> final norm -> per-frame sequences with the aggregator CLS in front (mf:231-232, 356-375)
+        Z = self._buf('Z', n * 8 * AGG_V * D, torch.float32).view(n * 8 * AGG_V, D)
+        ops.broadcast_rows(Z, self.v_agg['cls'], n_seq=n * 8, dst_seq_rows=AGG_V)
+        ops.layernorm(X, self.v_norm.g, self.v_norm.b, Z, EPS_VIS, rows=n * VIS_P,
+                      in_map=ops.rowmap(VIS_P, VIS_P, VIS_L, 0, 1, 1), out_map=ops.rowmap(VIS_P, 196, 8 * AGG_V, AGG_V, 1, 1))
+        self._agg_layer(Z, n * 8, AGG_V, self.v_agg, out, 'vagg')
+
+    def extract_vfeats(self, vis: torch.Tensor) -> torch.Tensor:
+        """vis (B, S, Tv=16, C=3, H, W) -> (B, S, 8, 768) fp32 (Synchformer.extract_vfeats, sync_model.py:72-80)."""
+        B, S = vis.shape[:2]
+        vid = vis.reshape(B * S, *vis.shape[2:])
+        if not vid.is_contiguous():
+            vid = vid.contiguous()
+        out = torch.empty(B * S * 8, D, device=self.dev, dtype=torch.float32)
+        for s0 in range(0, B * S, self.seg_chunk):
+            n = min(self.seg_chunk, B * S - s0)
+            self._visual_chunk(vid[s0:s0 + n], out[s0 * 8:(s0 + n) * 8])
+        return out.view(B, S, 8, D)
+
+    # ------------------------------------------------------------------------------------------------
+    # audio branch
+    # ------------------------------------------------------------------------------------------------
+    def extract_afeats(self, aud: torch.Tensor) -> torch.Tensor:
+        """aud (B, S, 1, F=128, Ta=66) fp32 -> (B, S, 6, 768) fp32 (sync_model.py:82-89, ast.py:137-201)."""
+        B, S, _, Fa, Ta = aud.shape
+        n = B * S
+        spec = aud.reshape(n, Fa, Ta).to(torch.float32)
+        if not spec.is_contiguous():
+            spec = spec.contiguous()
+        nf, nt = (Fa - 16) // 10 + 1, (Ta - 16) // 10 + 1
+        P, L = nf * nt, nf * nt + 2
+        if L != self.a_table.shape[0]:
+            raise ValueError(f'spectrogram gives {L} tokens but position table has {self.a_table.shape[0]}')
+        rows = n * L
+        X = self._buf('Xa', rows * D, torch.float32).view(rows, D)
+        agg_rows = n * nt * (nf + 1)
+        xn = self._buf('XN', max(rows, agg_rows) * D, torch.bfloat16)[:rows * D].view(rows, D)
+        big = self._buf('BIG', max(rows, agg_rows) * FF, torch.bfloat16)
+        patches = big[:n * P * 256].view(n * P, 256)
+        ops.im2col_spec(spec, patches)
+        ops.broadcast_rows(X, self.a_table, n_seq=n, dst_seq_rows=L)
+        tokmap = ops.rowmap(P, P, L, 0, 1, 2)
+        ops.gemm(patches, self.a_pe.w, self.a_pe.b, X, residual=X, c_map=tokmap, r_map=tokmap)
+
+        def full_attn(q3, o):
+            ops.attention(q3[:, :D], q3[:, D:2 * D], q3[:, 2 * D:], o, n_seq=n, seq_rows=L, n_groups=1, row0=0,
+                          group_stride=0, tok_stride=1, n_tok=L, cls_row=-1, heads=12, head_dim=64, scale=0.125)
+        for ly in self.a_layers:   # ASTLayer.forward (modeling_ast.py:294-322)
+            self._encoder_layer(X, rows, xn, big, ly['ln1'], ly['qkv'], full_attn, ly['o'], ly['ln2'], ly['fc1'], ly['fc2'],
+                                EPS_AST)
+        # final layernorm, drop CLS/DISTILL, regroup (fi, ti) -> per-time-step sequences (ast.py:232-236, 265-266)
+        La = nf + 1
+        Z = self._buf('Za', agg_rows * D, torch.float32).view(agg_rows, D)
+        ops.broadcast_rows(Z, self.a_agg['cls'], n_seq=n * nt, dst_seq_rows=La)
+        ops.layernorm(X, self.a_norm.g, self.a_norm.b, Z, EPS_AST, rows=n * P, in_map=ops.rowmap(P, P, L, 0, 1, 2),
+                      out_map=ops.rowmap(P, nt, nt * La, 1, La, 1))
+        out = torch.empty(n * nt, D, device=self.dev, dtype=torch.float32)
+        self._agg_layer(Z, n * nt, La, self.a_agg, out, 'aagg')
+        return out.view(B, S, nt, D)
+
+    # ------------------------------------------------------------------------------------------------
+    # sync transformer + top level
+    # ------------------------------------------------------------------------------------------------
+    def sync_transformer(self, vfeat: torch.Tensor, afeat: torch.Tensor) -> torch.Tensor:
+        """vproj/aproj (sync_model.py:55-56) + GlobalTransformer.forward (:150-173).  vfeat (B,S,tv,768), afeat (B,S,ta,768)
+        fp32 on device -> logits fp32 (B, n_out)."""
+        B = vfeat.shape[0]
+        Sv, Sa = vfeat.shape[1] * vfeat.shape[2], afeat.shape[1] * afeat.shape[2]
+        L = 2 + Sv + Sa
+        table = self._sync_table(Sv, Sa)
+        rows = B * L
+        X = self._buf('Xs', rows * D, torch.float32).view(rows, D)
+        xn = self._buf('XNs', rows * D, torch.bfloat16).view(rows, D)
+        big = self._buf('BIGs', rows * FF, torch.bfloat16)
+        ops.broadcast_rows(X, table, n_seq=B, dst_seq_rows=L)
+        for feat, proj, ln, n_tok, off in ((vfeat, self.vproj, self.s_vln, Sv, 1), (afeat, self.aproj, self.s_aln, Sa, 2 + Sv)):
+            f2 = feat.reshape(B * n_tok, D)
+            fb = xn[:B * n_tok]
+            ops.gather_rows(f2, fb, B * n_tok)
+            pr = self._buf('proj', B * n_tok * D, torch.float32).view(B * n_tok, D)
+            ops.gemm(fb, proj.w, proj.b, pr, M=B * n_tok)
+            ops.layernorm(pr, ln.g, ln.b, X, EPS_SYNC, out_map=ops.rowmap(n_tok, n_tok, L, 0, 1, off), accumulate=True)
+        hd = D // self.s_heads
+
+        def full_attn(q3, o):
+            ops.attention(q3[:, :D], q3[:, D:2 * D], q3[:, 2 * D:], o, n_seq=B, seq_rows=L, n_groups=1, row0=0,
+                          group_stride=0, tok_stride=1, n_tok=L, cls_row=-1, heads=self.s_heads, head_dim=hd,
+                          scale=1.0 / math.sqrt(hd))
+        for b in self.s_blocks:   # Block.forward (modules/transformer.py:93-97)
+            self._encoder_layer(X, rows, xn, big, b['ln1'], b['qkv'], full_attn, b['proj'], b['ln2'], b['fc1'], b['fc2'],
+                                EPS_SYNC)
+        cls = xn[:B]
+        ops.layernorm(X, self.s_lnf.g, self.s_lnf.b, cls, EPS_SYNC, rows=B, in_map=ops.rowmap(1, 1, L, 0, 0, 0))
+        logits = torch.empty(B, self.n_out, device=self.dev, dtype=torch.float32)
+        ops.gemm(cls, self.s_head.w, self.s_head.b, logits, M=B)
+        return logits
+
+    def forward(self, vis: torch.Tensor, aud: torch.Tensor) -> torch.Tensor:
+        """Synchformer.forward (sync_model.py:38-70) without the loss: logits (B, n_out) fp32."""
+        return self.sync_transformer(self.extract_vfeats(vis), self.extract_afeats(aud))

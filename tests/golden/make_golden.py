@@ -49,9 +49,11 @@ def capture(model, names):
     return store, hooks
 
 
-def e2e_sync(B=2):
+def e2e_sync(B=2, gain=1.0):
+    """gain=1: reference-like init scale.  gain=2: sharper attention / stronger input dependence (logit spread between
+    clips ~0.2 vs ~0.02), so an input-blind bug cannot hide inside the tolerance."""
     model = ref_import.build_reference_synchformer()
-    sd = synth.make_state_dict(SEED)
+    sd = synth.make_state_dict(SEED, gain=gain)
     model.load_state_dict(sd, strict=True)
     vis = rgb_frontend_ref(synth.make_video_u8(B, 14, SEED)).float()
     aud = synth.make_spectrogram(B, 14, SEED)
@@ -66,7 +68,7 @@ def e2e_sync(B=2):
         loss, logits = model(vis, aud, tgt)
     for h in hooks:
         h.remove()
-    out = dict(seed=np.int64(SEED), B=np.int64(B), logits=logits.numpy(), loss=loss.numpy(), targets=tgt.numpy())
+    out = dict(seed=np.int64(SEED), B=np.int64(B), gain=np.float64(gain), logits=logits.numpy(), loss=loss.numpy(), targets=tgt.numpy())
     for n, t in store.items():
         key = n.replace('.', '__')
         if n.startswith(v) and t.dim() == 3 and t.shape[1] in (1568, 1569):
@@ -77,7 +79,8 @@ def e2e_sync(B=2):
         else:
             out[key] = t.reshape(-1, t.shape[-1])[:64].numpy() if t.numel() > 200000 else t.numpy()
         print(n, tuple(t.shape), '->', out[key].shape)
-    np.savez_compressed(HERE / f'e2e_sync_B{B}.npz', **out)
+    tag = '' if gain == 1.0 else f'_gain{gain:g}'
+    np.savez_compressed(HERE / f'e2e_sync{tag}_B{B}.npz', **out)
     print('logits', logits, 'loss', loss)
 
 
@@ -99,8 +102,10 @@ def e2e_syncability(B=1):
 
 if __name__ == '__main__':
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['sync', 'syncability']
+    which = sys.argv[1:] or ['sync', 'sync_gain2', 'syncability']
     if 'sync' in which:
         e2e_sync(2)
+    if 'sync_gain2' in which:
+        e2e_sync(2, gain=2.0)
     if 'syncability' in which:
         e2e_syncability(1)
