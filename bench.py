@@ -36,7 +36,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=16, help='clips per GPU per step (configs/sync.yaml batch = 16)')
-    ap.add_argument('--seg-chunk', type=int, default=28)
+    ap.add_argument('--seg-chunk', type=int, default=27)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     return ap.parse_args()
@@ -75,11 +75,11 @@ class GemmTimer:
         return len(self.records), ms, fl
 
 
-def cpu_baseline(seconds_budget=25.0, max_threads=32):
+def cpu_baseline(seconds_budget=25.0, max_threads=16):
     """The CPU oracle (restatement of the reference, proven equal to it in the build container) timed on the host
     cores of this box, fp32.  BOUNDED sample: the visual branch (97.6 % of the path's CPU time) is timed
     on `k` of the 14 segments of one clip and scaled by 14/k (segments are independent and identical in cost); the audio
-    branch and the sync transformer are timed in full for the clip.  Threads are capped: beyond ~32 the 768-wide matmuls
+    branch and the sync transformer are timed in full for the clip.  Threads are capped: beyond ~16 the 768-wide matmuls
     of this path slow down on a many-core host (measured), so `cores` reports the threads actually used."""
     from synchformer_amd import synth
     from oracle import synchformer_cpu as O
@@ -165,7 +165,7 @@ def main():
         }
         if n_gemm:
             ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16_128x128_kernel', 'achieved': round(ach, 1),
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'sf_gemm_bf16 (gemm_bf16_persistent_kernel + gemm_bf16_kernel)', 'achieved': round(ach, 1),
                                'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': round(ach / (PEAK_BF16 / 1e12), 4),
                                'traffic': None, 'launches': n_gemm // args.steps,
                                'avg_launch_ms': round(gemm_ms / n_gemm, 4),

@@ -46,6 +46,10 @@ int sf_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
                  int c_dtype, int64_t ldc, const int64_t* c_map, const float* R, int64_t ldr, const int64_t* r_map,
                  int epilogue, int64_t M, int64_t N, int64_t K, void* stream);
 
+/* Tuning / test hook: force the GEMM tile configuration for subsequent sf_gemm_bf16 calls of this process
+ * (-1 = automatic choice by shape, 0 = 128x128x64 / 4 waves, 1 = 256x256x64 / 8 waves). */
+void sf_gemm_force_config(int cfg);
+
 /* y[omap(r), :] (=|+=) LayerNorm(x[imap(r), :]) * gamma + beta over 768 columns; x fp32, y bf16|fp32.
  * Replaces nn.LayerNorm at vit_helper.py:366-375, motionformer.py:232, modeling_ast.py:301,315,535,
  * sync_model.py:157,169, modules/transformer.py:94-95 and norm1/norm2 inside motionformer.py:329. */

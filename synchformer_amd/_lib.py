@@ -21,6 +21,7 @@ SIGNATURES = {
     'sf_last_error': [],
     'sf_build_info': [],
     'sf_gemm_bf16': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i64, _ptr, _ptr, _i64, _ptr, _i32, _i64, _i64, _i64, _ptr],
+    'sf_gemm_force_config': [_i32],
     'sf_layernorm768': [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i64, _ptr, _i32, _i64, _f32, _ptr],
     'sf_broadcast_rows768': [_ptr, _i64, _i64, _ptr, _i64, _i64, _ptr],
     'sf_gather_rows768': [_ptr, _i64, _ptr, _ptr, _i32, _i64, _i64, _ptr],
@@ -29,7 +30,7 @@ SIGNATURES = {
     'sf_attention': [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _ptr],
     'sf_attention_cls': [_ptr, _i64, _i32, _ptr, _ptr, _i64, _i64, _i32, _i32, _ptr, _i64, _i64, _i32, _i64, _i32, _i32, _f32, _ptr],
 }
-_RESTYPES = {'sf_last_error': C.c_char_p, 'sf_build_info': C.c_char_p}
+_RESTYPES = {'sf_last_error': C.c_char_p, 'sf_build_info': C.c_char_p, 'sf_gemm_force_config': None}
 
 _lib = None
 

@@ -49,15 +49,15 @@ __device__ __forceinline__ int64_t map_row(const RowMap& m, int64_t r) {
 
 // ---- bf16 <-> f32 ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {   // round-to-nearest-even, NaN kept quiet
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// f32 -> bf16, round-to-nearest-even with NaN preserved: gfx950 has the conversion in hardware
+// (v_cvt_pk_bf16_f32); the vector convert below is what makes hipcc select it.
+typedef __attribute__((ext_vector_type(2))) __bf16 sf_bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float sf_f32x2_t;
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const sf_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, sf_bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float f16_to_f32(uint16_t h) { return __half2float(__ushort_as_half(h)); }
 
 // ---- wave reductions ------------------------------------------------------------------------------------

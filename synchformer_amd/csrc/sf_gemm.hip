@@ -7,24 +7,26 @@
 // (modules/transformer.py:59-61,74,86-91), the aggregator layers, the two patch-embedding convolutions
 // (as patch-gather GEMMs), vproj/aproj and the offset head.
 //
-// Tile: 128 x 128 x 64, 256 threads = 4 waves in a 2 x 2 grid, each wave 64 x 64 = 4 x 4 fragments of
-// v_mfma_f32_16x16x32_bf16.  Operand tiles go HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per
-// wave-instruction = 8 rows x 128 B), double-buffered, one barrier per K-step.  LDS rows are 128 B; the
-// 16-byte chunk index is XOR-swizzled with (row & 7) so the ds_read_b128 fragment reads are conflict-free.
-// global_load_lds writes lane-linear, so the swizzle is applied to the per-lane SOURCE address and to the
-// read address (same involution), never to the LDS destination.
-// Epilogue: accumulators are transposed through (per-wave private) LDS so that bias / GELU / fp32 residual /
-// stores run on 16-byte row-contiguous pieces.
-// Workgroup -> tile mapping is XCD-aware: the 8 XCDs each walk a contiguous range of tiles, N fastest, so
-// an A row-panel is fetched from HBM once per XCD-local L2 and W stays L2/MALL-resident.
+// Structure (per workgroup = one BM x BN output tile):
+//   * operand tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave-instruction) into an
+//     NS-deep ring of BK-wide stages; NS-1 stages are kept in flight with COUNTED s_waitcnt vmcnt(N) and one raw
+//     s_barrier per K-step (never vmcnt(0) in the steady state) - with K as short as 768 the loop is bound by
+//     operand-delivery latency, not MFMA rate, unless several stages are outstanding (profiles/r01 notes).
+//   * LDS rows are BK*2 bytes; the 16-byte chunk index is XOR-swizzled so the ds_read_b128 fragment reads are
+//     bank-conflict-free.  LDS-DMA writes lane-linear, so the swizzle is applied to the per-lane SOURCE address
+//     and to the read address (same involution), never to the LDS destination.
+//   * every wave owns a (BM/WM) x 64 block of 16 x 16 fragments of v_mfma_f32_16x16x32_bf16 (fp32 accumulate).
+//   * epilogue: accumulators are transposed through per-wave private LDS so bias / erf-GELU / fp32 residual /
+//     stores run on 16-byte row-contiguous pieces (full 128/256-byte row segments per 16 lanes).
+//   * workgroup -> tile mapping is XCD-aware (block b runs on XCD b % 8): each XCD walks a contiguous range of
+//     tiles, N fastest, so an A row-panel is fetched once per XCD-local L2 and W stays L2/MALL-resident.
 #include "sf_common.h"
 #include "../../include/synchformer_hip.h"
 
-#define BM 128
-#define BN 128
-#define BK 64
-#define STAGE_BYTES (2 * BM * BK * 2)     // A tile + B tile, bf16
-#define EPI_LD 68                          // fp32 row stride of the epilogue staging tile (16-B aligned, padded)
+#ifndef SF_ABL
+#define SF_ABL 0   // tools/ablate_gemm.sh builds throwaway variants with -DSF_ABL=mask; the product build is 0
+#endif
+#define EPI_LD 68                          // fp32 row stride of the epilogue staging slab (64 cols + pad, 16-B aligned)
 
 struct GemmArgs {
   const bf16_t* A; int64_t lda;
@@ -43,12 +45,112 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst_wave_base
                                    (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
 }
 
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {   // LDS byte address of a __shared__ pointer
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+// Four LDS-DMA pieces (1 KiB each, consecutive in LDS from wave-uniform address `l0`) issued from inline asm, so
+// hipcc neither counts them nor guards later ds_reads with vmcnt(0) (it does for the builtin once the loop gets
+// complicated - that wait serialised prefetch and compute in the first persistent kernel).  Every wait for these
+// loads is a hand-placed counted s_waitcnt.  M0 (LDS destination base) is saved/restored inside the statement.
+__device__ __forceinline__ void dma4(const void* g0, const void* g1, const void* g2, const void* g3, uint32_t l0) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(l0)
+      : "memory", "scc");
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// Branch-free epilogue tail for one group of 16 rows x 64 cols per wave (4 float4 per lane, rows 4 apart):
+// + bias, erf-GELU, + fp32 residual, convert, store.  Row bounds come for free from the buffer descriptors
+// (num_records = M * ld * esz: rows >= M are dropped by the hardware range check), so there is no exec-mask
+// branching and hipcc keeps counted vmcnt waits: stores never wait for earlier stores, and the residual rows of
+// the NEXT group are already in flight (loaded before this group's stores were issued).
 template <bool OUT_BF16, bool GELU, bool HAS_RES>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_128x128_kernel(GemmArgs p) {
+__device__ __forceinline__ void epi_group_store(float4 (&v)[4], const float4& bias4, const float4 (&res)[4],
+                                                __amdgpu_buffer_rsrc_t rc, uint32_t coff, uint32_t cstep) {
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    float4 x = v[ps];
+    x.x += bias4.x; x.y += bias4.y; x.z += bias4.z; x.w += bias4.w;
+    if (GELU) { x.x = gelu_erf(x.x); x.y = gelu_erf(x.y); x.z = gelu_erf(x.z); x.w = gelu_erf(x.w); }
+    if (HAS_RES) { x.x += res[ps].x; x.y += res[ps].y; x.z += res[ps].z; x.w += res[ps].w; }
+    if (OUT_BF16) {
+      u32x2 o; o.x = pack_bf2(x.x, x.y); o.y = pack_bf2(x.z, x.w);
+      __builtin_amdgcn_raw_buffer_store_b64(o, rc, coff + ps * cstep, 0, 0);
+    } else {
+      u32x4 o;
+      o.x = __float_as_uint(x.x); o.y = __float_as_uint(x.y); o.z = __float_as_uint(x.z); o.w = __float_as_uint(x.w);
+      __builtin_amdgcn_raw_buffer_store_b128(o, rc, coff + ps * cstep, 0, 0);
+    }
+  }
+}
+__device__ __forceinline__ void epi_group_load_res(float4 (&res)[4], __amdgpu_buffer_rsrc_t rr, uint32_t roff, uint32_t rstep) {
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rr, roff + ps * rstep, 0, 0);
+    res[ps] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_barrier() {
+  // Counted wait for this wave's own LDS-DMA pieces, then the workgroup barrier.  The wait is the BUILTIN (gfx9
+  // encoding: vmcnt[3:0] | expcnt<<4 | lgkmcnt<<8 | vmcnt[5:4]<<14, other counters left at max) so that hipcc's
+  // waitcnt pass sees it and stops inserting its own conservative vmcnt(0) in the loop; the empty asm statements are
+  // compiler memory fences (the raw s_barrier builtin alone does not order LDS accesses for the compiler).
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// Tile configuration: BM x BN x BK block tile, NS-stage LDS ring, WM x WN waves, each wave (BM/WM) x 64 outputs.
+template <int BM_, int BN_, int WM_, int WN_, int BK_, int NS_, int WG_PER_CU_, bool PIPE_ = false>
+struct GemmCfg {
+  static constexpr bool PIPE = PIPE_;      // fragment register double-buffering one K-step ahead (needs BK 32, NS >= 4)
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_, NS = NS_;
+  static constexpr int NWAVES = WM * WN, THREADS = NWAVES * 64;
+  static constexpr int WT_M = BM / WM, WT_N = BN / WN;           // wave tile
+  static constexpr int FI = WT_M / 16, FJ = WT_N / 16;           // 16x16 fragments per wave
+  static constexpr int ROW_B = BK * 2;                            // bytes per LDS row
+  static constexpr int PIECE_ROWS = 1024 / ROW_B;                 // rows per 1-KiB LDS-DMA piece
+  static constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B, STAGE = A_BYTES + B_BYTES;
+  static constexpr int A_PIECES = BM / PIECE_ROWS / NWAVES, B_PIECES = BN / PIECE_ROWS / NWAVES;
+  static constexpr int PIECES = A_PIECES + B_PIECES;              // LDS-DMA instructions per thread per stage
+  static constexpr int LDS = NS * STAGE;
+  static constexpr int MIN_WAVES_PER_SIMD = WG_PER_CU_ * NWAVES / 4;
+  static_assert(BK == 32 || BK == 64, "BK must be 32 or 64");
+  static_assert(WT_N == 64, "epilogue assumes 64-column wave tiles");
+  static_assert(NWAVES * 32 * EPI_LD * 4 <= LDS, "epilogue slabs must fit in the operand LDS");
+  static_assert(FI % 2 == 0, "general epilogue walks 32-row halves");
+  static_assert(A_PIECES >= 1 && B_PIECES >= 1 && (NS - 2) * PIECES <= 63, "piece / vmcnt budget");
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static_assert(!PIPE_ || (BK_ == 32 && NS_ >= 4), "PIPE needs one k-step per stage and a 4-deep ring");
+};
+
+// byte offset inside a tile of the 16-byte chunk `c` (0 .. BK/8-1) of row `r`, XOR-swizzled.
+template <int BK>
+__device__ __forceinline__ int lds_chunk_off(int r, int c) {
+  if (BK == 64) return r * 128 + ((c ^ (r & 7)) << 4);          // 8 chunks/row, 2 rows per 256-B bank row
+  return r * 64 + ((c ^ ((r >> 2) & 3)) << 4);                   // 4 chunks/row, 4 rows per 256-B bank row
+}
+
+template <class Cfg, bool OUT_BF16, bool GELU, bool HAS_RES, bool FAST>
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES_PER_SIMD) void gemm_bf16_kernel(GemmArgs p) {
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, NS = Cfg::NS, FI = Cfg::FI, FJ = Cfg::FJ, P = Cfg::PIECES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  // ---- XCD-aware, bijective block -> tile remap (block b runs on XCD b % 8) -------------------------------
+  // ---- XCD-aware, bijective block -> tile remap ---------------------------------------------------------
   uint32_t vb;
   {
     const uint32_t nb = p.tiles_total, q = nb >> 3, r = nb & 7u, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
@@ -58,141 +160,449 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128x128_kernel(GemmArgs p) {
   const int64_t m0 = (int64_t)tm * BM;
   const int n0 = (int)tn * BN;
 
-  // ---- per-lane source pointers for the 4 + 4 LDS-DMA pieces this wave issues per stage -------------------
-  const int piece_row = lane >> 3;                              // row inside the 8-row piece
-  const int gchunk = (lane & 7) ^ piece_row;                    // source-side swizzle (row & 7 == piece_row)
-  const bf16_t* a_src[4];
-  const bf16_t* b_src[4];
+  // ---- per-lane source pointers for the LDS-DMA pieces this wave issues per stage -------------------------
+  constexpr int CPR = BK / 8;                                   // 16-byte chunks per row
+  const int piece_row = lane / CPR, pos = lane % CPR;           // LDS position (row, chunk slot) this lane fills
+  const int gchunk = (BK == 64) ? (pos ^ (piece_row & 7)) : (pos ^ ((piece_row >> 2) & 3));   // source-side swizzle
+  const bf16_t* a_src[Cfg::A_PIECES];
+  const bf16_t* b_src[Cfg::B_PIECES];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 8 + piece_row;
-    int64_t ar = m0 + row; if (ar > p.M - 1) ar = p.M - 1;      // clamp: tail rows re-read the last valid row
-    int br = n0 + row; if (br > p.N - 1) br = p.N - 1;
+  for (int i = 0; i < Cfg::A_PIECES; ++i) {
+    int64_t ar = m0 + (wave * Cfg::A_PIECES + i) * Cfg::PIECE_ROWS + piece_row;
+    if (ar > p.M - 1) ar = p.M - 1;                             // clamp: tail rows re-read the last valid row
     a_src[i] = p.A + ar * p.lda + gchunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < Cfg::B_PIECES; ++i) {
+    int br = n0 + (wave * Cfg::B_PIECES + i) * Cfg::PIECE_ROWS + piece_row;
+    if (br > p.N - 1) br = p.N - 1;
     b_src[i] = p.W + (int64_t)br * p.ldw + gchunk * 8;
   }
   auto stage = [&](int s, int kt) {
-    char* base = smem + s * STAGE_BYTES + (wave * 4) * 1024;
+    if ((SF_ABL & 2) && kt >= NS - 1) return;
+    char* abase = smem + s * Cfg::STAGE + (wave * Cfg::A_PIECES) * 1024;
+    char* bbase = smem + s * Cfg::STAGE + Cfg::A_BYTES + (wave * Cfg::B_PIECES) * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(a_src[i] + kt * BK, base + i * 1024);
+    for (int i = 0; i < Cfg::A_PIECES; ++i) glds16(a_src[i] + kt * BK, abase + i * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(b_src[i] + kt * BK, base + BM * BK * 2 + i * 1024);
+    for (int i = 0; i < Cfg::B_PIECES; ++i) glds16(b_src[i] + kt * BK, bbase + i * 1024);
   };
 
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int fr = lane & 15, fg = lane >> 4;
-  // byte offset of this lane's fragment row inside a tile + swizzled chunk offsets for k-step 0 / 1
-  const int a_row_off = (wm * 64 + fr) * 128, b_row_off = (wn * 64 + fr) * 128;
-  const int ch0 = ((fg) ^ (fr & 7)) * 16, ch1 = ((4 + fg) ^ (fr & 7)) * 16;
+  int a_off[BK / 32], b_off[BK / 32];                           // swizzled fragment offsets per 32-deep k-step
+#pragma unroll
+  for (int ks = 0; ks < BK / 32; ++ks) {
+    a_off[ks] = lds_chunk_off<BK>(wm * Cfg::WT_M + fr, ks * 4 + fg);   // (+ i*16 rows keeps row&7 / (row>>2)&3)
+    b_off[ks] = lds_chunk_off<BK>(wn * Cfg::WT_N + fr, ks * 4 + fg);
+  }
 
-  f32x4 acc[4][4];
+  f32x4 acc[FI][FJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const char* sa = smem + (kt & 1) * STAGE_BYTES;
-    const char* sb = sa + BM * BK * 2;
+  // ---- prologue: NS-1 stages in flight ---------------------------------------------------------------------
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int ch = ks ? ch1 : ch0;
-      bf16x8 a[4], b[4];
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) stage(s, s);
+  if constexpr (!Cfg::PIPE) {
+    int cur = 0, fill = NS - 1;                                 // ring slots: being computed / next to refill
+    for (int kt = 0; kt < nk; ++kt) {
+      // wait until tile kt has landed: only the (<= NS-2) younger stages may still be outstanding
+      const int ahead = min(NS - 2, nk - 1 - kt);
+      if (NS >= 4 && ahead >= 2) wait_vmcnt_barrier<2 * P>();
+      else if (NS >= 3 && ahead == 1) wait_vmcnt_barrier<P>();
+      else wait_vmcnt_barrier<0>();
+      // every wave has passed compute(kt-1): slot `fill` (== slot of tile kt-1) is free -> refill with tile kt+NS-1
+      if (kt + NS - 1 < nk) stage(fill, kt + NS - 1);
+      const char* sa = smem + cur * Cfg::STAGE;
+      const char* sb = sa + Cfg::A_BYTES;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 16 * 128 + ch);
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        bf16x8 a[FI], b[FJ];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 16 * 128 + ch);
+        for (int j = 0; j < FJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[ks] + j * 16 * Cfg::ROW_B);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sa + a_off[ks] + i * 16 * Cfg::ROW_B);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+          for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      cur = (cur + 1 == NS) ? 0 : cur + 1;
+      fill = (fill + 1 == NS) ? 0 : fill + 1;
     }
+  } else {
+    // Fragment-pipelined loop (BK = 32: one k-step per stage).  Iteration kt multiplies the fragments of tile kt that
+    // were read from LDS during iteration kt-1, while this iteration's ds_reads fetch tile kt+1: LDS latency hides
+    // under the MFMAs instead of alternating with them (the two waves of a SIMD run in lockstep behind the barrier).
+    // Barrier(kt) publishes tile kt+1 (each wave waited for its own DMA pieces) and retires every read of tile kt-1
+    // (consumed by the MFMAs of iteration kt-1), whose slot is refilled with tile kt+NS-1.
+    auto load_frags = [&](int slot, bf16x8 (&a)[FI], bf16x8 (&b)[FJ]) {
+      const char* sa = smem + slot * Cfg::STAGE;
+      const char* sb = sa + Cfg::A_BYTES;
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[0] + j * 16 * Cfg::ROW_B);
+#pragma unroll
+      for (int i = 0; i < FI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sa + a_off[0] + i * 16 * Cfg::ROW_B);
+    };
+    auto mma = [&](const bf16x8 (&a)[FI], const bf16x8 (&b)[FJ]) {
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    auto sync_for = [&](int tile) {   // make `tile` visible: younger stages (<= NS-3 of them) may stay in flight
+      const int ahead = min(NS - 3, nk - 1 - tile);
+      if (ahead >= 1) wait_vmcnt_barrier<P>(); else wait_vmcnt_barrier<0>();
+    };
+    static_assert(NS == 4, "sync_for() is written for a 4-deep ring");
+    bf16x8 a0[FI], b0[FJ], a1[FI], b1[FJ];
+    // tile 0
+    { const int ahead = min(NS - 2, nk - 1); if (ahead >= 2) wait_vmcnt_barrier<2 * P>(); else if (ahead == 1) wait_vmcnt_barrier<P>(); else wait_vmcnt_barrier<0>(); }
+    load_frags(0, a0, b0);
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {             // two tiles per trip so fragment buffers are statically named
+      sync_for(kt + 1);
+      if (kt + NS - 1 < nk) stage((kt + NS - 1) & (NS - 1), kt + NS - 1);
+      load_frags((kt + 1) & (NS - 1), a1, b1);
+      mma(a0, b0);
+      if (kt + 2 < nk) {
+        sync_for(kt + 2);
+        if (kt + NS < nk) stage((kt + NS) & (NS - 1), kt + NS);
+        load_frags((kt + 2) & (NS - 1), a0, b0);
+      }
+      mma(a1, b1);
+    }
+    if (kt < nk) mma(a0, b0);                  // odd tile count: last tile's fragments are already in a0/b0
   }
   __syncthreads();   // every wave is done reading operand tiles; LDS becomes per-wave epilogue scratch
 
-  // ---- epilogue: 2 passes of 32 rows x 64 cols through this wave's private LDS slab -----------------------
-  float* slab = reinterpret_cast<float*>(smem + wave * (32 * EPI_LD * 4));
-  const int ecol = (lane & 15) * 4;                 // 4 consecutive output columns per lane
-  const int gcol = n0 + wn * 64 + ecol;
-  const bool vec_ok = ((p.N & 3) == 0);
-  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias) {
-    if (vec_ok && gcol + 3 < p.N) bias4 = *reinterpret_cast<const float4*>(p.bias + gcol);
-    else {
-      if (gcol + 0 < p.N) bias4.x = p.bias[gcol + 0];
-      if (gcol + 1 < p.N) bias4.y = p.bias[gcol + 1];
-      if (gcol + 2 < p.N) bias4.z = p.bias[gcol + 2];
-      if (gcol + 3 < p.N) bias4.w = p.bias[gcol + 3];
-    }
+  if (SF_ABL & 8) {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sum == 1.2345e30f) reinterpret_cast<float*>(p.C)[0] = sum;
+    return;
   }
+  // ---- epilogue ----------------------------------------------------------------------------------------------
+  const int ecol = (lane & 15) * 4;                 // 4 consecutive output columns per lane
+  const int gcol = n0 + wn * Cfg::WT_N + ecol;
+  if constexpr (FAST) {
+    // identity row maps, N % 64 == 0, buffers < 4 GiB: branch-free groups of 16 rows through a 16-row LDS slab
+    if (n0 + wn * Cfg::WT_N < p.N) {               // wave-uniform (N % 64 == 0)
+      float* slab = reinterpret_cast<float*>(smem + wave * (16 * EPI_LD * 4));
+      const uint32_t esz = OUT_BF16 ? 2u : 4u;
+      const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, (short)0, (int)(uint32_t)(p.M * p.ldc * esz), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), (short)0, HAS_RES ? (int)(uint32_t)(p.M * p.ldr * 4) : 0, 0x00020000);
+      const int64_t row0 = m0 + wm * Cfg::WT_M + (lane >> 4);
+      const uint32_t coff0 = (uint32_t)(row0 * p.ldc + gcol) * esz, cstep = (uint32_t)(4 * p.ldc) * esz;
+      const uint32_t roff0 = (uint32_t)(row0 * p.ldr + gcol) * 4u, rstep = (uint32_t)(4 * p.ldr) * 4u;
+      float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + gcol);
+      float4 res[2][4];
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+      for (int ps = 0; ps < 4; ++ps) res[0][ps] = res[1][ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (HAS_RES) epi_group_load_res(res[0], rr, roff0, rstep);
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
+      for (int g = 0; g < FI; ++g) {
+        if (HAS_RES && g + 1 < FI) epi_group_load_res(res[(g + 1) & 1], rr, roff0 + (g + 1) * 4 * rstep, rstep);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < FJ; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) slab[(ii * 16 + fg * 4 + r) * EPI_LD + j * 16 + fr] = acc[half * 2 + ii][j][r];
+          for (int r = 0; r < 4; ++r) slab[(fg * 4 + r) * EPI_LD + j * 16 + fr] = acc[g][j][r];
+        float4 v[4];
 #pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-      const int lrow = pass * 4 + (lane >> 4);
-      float4 v = *reinterpret_cast<const float4*>(slab + lrow * EPI_LD + ecol);
-      const int64_t grow = m0 + wm * 64 + half * 32 + lrow;
-      if (grow >= p.M || gcol >= p.N) continue;
-      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-      if (GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-      const bool full = vec_ok && (gcol + 3 < p.N);
-      if (HAS_RES) {
-        const float* rp = p.R + map_row(p.rmap, grow) * p.ldr + gcol;
-        if (full) { const float4 t = *reinterpret_cast<const float4*>(rp); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-        else {
-          v.x += rp[0];
-          if (gcol + 1 < p.N) v.y += rp[1];
-          if (gcol + 2 < p.N) v.z += rp[2];
-          if (gcol + 3 < p.N) v.w += rp[3];
-        }
+        for (int ps = 0; ps < 4; ++ps) v[ps] = *reinterpret_cast<const float4*>(slab + (ps * 4 + (lane >> 4)) * EPI_LD + ecol);
+        if (!(SF_ABL & 1)) epi_group_store<OUT_BF16, GELU, HAS_RES>(v, bias4, res[g & 1], rc, coff0 + g * 4 * cstep, cstep);
+        else if (v[0].x == 1.2345e30f) epi_group_store<OUT_BF16, GELU, HAS_RES>(v, bias4, res[g & 1], rc, coff0, cstep);
       }
-      const int64_t crow = map_row(p.cmap, grow);
-      if (OUT_BF16) {
-        bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + gcol;
-        if (full) { uint2 o; o.x = pack_bf2(v.x, v.y); o.y = pack_bf2(v.z, v.w); *reinterpret_cast<uint2*>(cp) = o; }
-        else {
-          cp[0] = f2bf(v.x);
-          if (gcol + 1 < p.N) cp[1] = f2bf(v.y);
-          if (gcol + 2 < p.N) cp[2] = f2bf(v.z);
-          if (gcol + 3 < p.N) cp[3] = f2bf(v.w);
-        }
-      } else {
-        float* cp = reinterpret_cast<float*>(p.C) + crow * p.ldc + gcol;
-        if (full) *reinterpret_cast<float4*>(cp) = v;
-        else {
-          cp[0] = v.x;
-          if (gcol + 1 < p.N) cp[1] = v.y;
-          if (gcol + 2 < p.N) cp[2] = v.z;
-          if (gcol + 3 < p.N) cp[3] = v.w;
+    }
+  } else {
+    // general path (row maps, ragged N such as the 21-way / 2-way heads): per-row predicates, element-wise tails
+    float* slab = reinterpret_cast<float*>(smem + wave * (32 * EPI_LD * 4));
+    const bool vec = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!HAS_RES || (p.ldr & 3) == 0);
+    float bias_e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (p.bias && gcol + e < p.N) bias_e[e] = p.bias[gcol + e];
+#pragma unroll
+    for (int half = 0; half < FI / 2; ++half) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) slab[(ii * 16 + fg * 4 + r) * EPI_LD + j * 16 + fr] = acc[half * 2 + ii][j][r];
+      for (int pass = 0; pass < 8; ++pass) {
+        const int lrow = pass * 4 + (lane >> 4);
+        const float4 t = *reinterpret_cast<const float4*>(slab + lrow * EPI_LD + ecol);
+        const int64_t grow = m0 + wm * Cfg::WT_M + half * 32 + lrow;
+        if (grow < p.M && gcol < p.N) {
+          float vv[4] = {t.x + bias_e[0], t.y + bias_e[1], t.z + bias_e[2], t.w + bias_e[3]};
+          if (GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vv[e] = gelu_erf(vv[e]);
+          }
+          const int64_t crow = map_row(p.cmap, grow);
+          const int64_t rrow = HAS_RES ? map_row(p.rmap, grow) : 0;
+          if (vec && gcol + 3 < p.N) {
+            if (HAS_RES) {
+              const float4 rr4 = *reinterpret_cast<const float4*>(p.R + rrow * p.ldr + gcol);
+              vv[0] += rr4.x; vv[1] += rr4.y; vv[2] += rr4.z; vv[3] += rr4.w;
+            }
+            if (OUT_BF16) {
+              uint2 o; o.x = pack_bf2(vv[0], vv[1]); o.y = pack_bf2(vv[2], vv[3]);
+              *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + gcol) = o;
+            } else {
+              *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + crow * p.ldc + gcol) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (gcol + e < p.N) {
+                float o = vv[e];
+                if (HAS_RES) o += p.R[rrow * p.ldr + gcol + e];
+                if (OUT_BF16) reinterpret_cast<bf16_t*>(p.C)[crow * p.ldc + gcol + e] = f2bf(o);
+                else reinterpret_cast<float*>(p.C)[crow * p.ldc + gcol + e] = o;
+              }
+          }
         }
       }
     }
   }
 }
 
+// =========================================================================================================
+// Persistent 256 x 256 x 64 kernel on v_mfma_f32_32x32x16_bf16 - the big token GEMMs.
+// The ablation in profiles/r01_gemm_ablation.md shows a fixed ~7 us per output tile (workgroup launch, first-load
+// latency, epilogue) on top of ~15 us of MFMA work at K = 768.  So: ONE workgroup per CU walks many tiles, and the
+// first K-stage of the NEXT tile is put in flight (LDS-DMA into ring slot 0) before the current tile's epilogue
+// runs (which stages through slot 1's memory) - launch cost is paid once, load latency hides under the epilogue.
+// 32x32x16 fragments: same LDS bytes per FLOP as 16x16x32, 15 % higher MFMA peak (2.38 vs 2.08 PFLOP/s).
+//   A fragment: lane l holds row (l & 31), k = (l >> 5) * 8 .. +7 of the 16-deep step;  B likewise with n.
+//   C fragment: col = l & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5).
+// LDS rows are 128 B; chunk c of row r lives at slot c ^ ((r >> 1) & 7): 16 consecutive rows (and the 16-lane
+// groups ds_read_b128 is served in, for 32-row fragments) hit 16 distinct 16-byte slots of the 256-B bank row.
+// =========================================================================================================
+#define PBM 256
+#define PBN 256
+#define PBK 64
+#define P_STAGE (2 * PBM * PBK * 2)       // 64 KiB: A tile + B tile
+#define P_LDS (2 * P_STAGE)
+#define P_SLAB_ROWS 16
+#define P_SLAB_BYTES (P_SLAB_ROWS * EPI_LD * 4)
+
 template <bool OUT_BF16, bool GELU, bool HAS_RES>
-static int launch_gemm(const GemmArgs& a, hipStream_t s) {
-  auto kern = gemm_bf16_128x128_kernel<OUT_BF16, GELU, HAS_RES>;
+__global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;                      // 2 x 4 waves, wave tile 128 x 64
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // persistent schedule: block b sits on XCD b % 8; every XCD owns a contiguous tile range, N fastest
+  const uint32_t xcd = blockIdx.x & 7u, li = blockIdx.x >> 3, per_xcd_blocks = gridDim.x >> 3;
+  const uint32_t t8 = (p.tiles_total + 7u) >> 3;                // tiles per XCD (last XCD may own fewer)
+  const uint32_t t_begin = xcd * t8, t_end = min(t_begin + t8, p.tiles_total);
+
+  const int piece_row = lane >> 3, slot = lane & 7;
+  // fragment read offsets (bytes) inside a tile for k-step kk: row-dependent swizzle is lane-constant
+  const int sw = (l31 >> 1) & 7;
+  int frag_off[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) frag_off[kk] = l31 * 128 + (((kk * 2 + hi) ^ sw) << 4);
+  const int a_base = wm * 128 * 128, b_base = PBM * PBK * 2 + wn * 64 * 128;
+
+  const bf16_t* a_src[4];
+  const bf16_t* b_src[4];
+  auto set_tile = [&](uint32_t t, int64_t& m0, int& n0) {
+    const uint32_t tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+    m0 = (int64_t)tm * PBM; n0 = (int)tn * PBN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave * 4 + i) * 8 + piece_row;            // tile row this lane fills
+      const int gch = slot ^ ((row >> 1) & 7);                   // source-side swizzle
+      int64_t ar = m0 + row; if (ar > p.M - 1) ar = p.M - 1;
+      int br = n0 + row; if (br > p.N - 1) br = p.N - 1;
+      a_src[i] = p.A + ar * p.lda + gch * 8;
+      b_src[i] = p.W + (int64_t)br * p.ldw + gch * 8;
+    }
+  };
+  const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(lds_addr(smem) + (wave * 4) * 1024);
+  auto stage = [&](int s, int kt) {
+    const uint32_t l = lds_wave + s * P_STAGE;
+    dma4(a_src[0] + kt * PBK, a_src[1] + kt * PBK, a_src[2] + kt * PBK, a_src[3] + kt * PBK, l);
+    dma4(b_src[0] + kt * PBK, b_src[1] + kt * PBK, b_src[2] + kt * PBK, b_src[3] + kt * PBK, l + PBM * PBK * 2);
+  };
+
+  const int nk = p.K / PBK;
+  uint32_t t = t_begin + li;
+  if (t >= t_end) return;
+  int64_t m0; int n0;
+  set_tile(t, m0, n0);
+  stage(0, 0);
+  float* slab = reinterpret_cast<float*>(smem + P_STAGE + wave * P_SLAB_BYTES);
+  const int ecol = (lane & 15) * 4;
+  const uint32_t esz = OUT_BF16 ? 2u : 4u;
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, (short)0, (int)(uint32_t)(p.M * p.ldc * esz), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), (short)0, HAS_RES ? (int)(uint32_t)(p.M * p.ldr * 4) : 0, 0x00020000);
+  const uint32_t cstep = (uint32_t)(4 * p.ldc) * esz, rstep = (uint32_t)(4 * p.ldr) * 4u;
+
+  for (;;) {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      wait_vmcnt_barrier<0>();                                   // tile kt landed everywhere; slot (kt+1)&1 is free
+      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+      const char* sa = smem + (kt & 1) * P_STAGE + a_base;
+      const char* sb = smem + (kt & 1) * P_STAGE + b_base;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 a[4], b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * 128 + frag_off[kk]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sa + i * 32 * 128 + frag_off[kk]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    // all waves finished reading both slots -> slot 0 can take the next tile's first stage, slot 1 is epilogue scratch
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int64_t em0 = m0; const int en0 = n0;
+    const uint32_t tnext = t + per_xcd_blocks;
+    const bool more = tnext < t_end;
+    if (more) { set_tile(tnext, m0, n0); stage(0, 0); }
+
+    // ---- epilogue of tile (em0, en0): 8 branch-free groups of 16 rows x 64 cols through this wave's slab -------
+    if (en0 + wn * 64 < p.N) {                                   // wave-uniform (N % 64 == 0 on this path)
+      const int gcol = en0 + wn * 64 + ecol;
+      const int64_t row0 = em0 + wm * 128 + (lane >> 4);
+      const uint32_t coff0 = (uint32_t)(row0 * p.ldc + gcol) * esz, roff0 = (uint32_t)(row0 * p.ldr + gcol) * 4u;
+      float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + gcol);
+      float4 res[2][4];
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) res[0][ps] = res[1][ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (HAS_RES) epi_group_load_res(res[0], rr, roff0, rstep);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int i = g >> 1, q2 = g & 1;
+        if (HAS_RES && g + 1 < 8) epi_group_load_res(res[(g + 1) & 1], rr, roff0 + (g + 1) * 4 * rstep, rstep);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              slab[(qq * 8 + hi * 4 + r) * EPI_LD + j * 32 + l31] = acc[i][j][(q2 * 2 + qq) * 4 + r];
+        float4 v[4];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) v[ps] = *reinterpret_cast<const float4*>(slab + (ps * 4 + (lane >> 4)) * EPI_LD + ecol);
+        if (!(SF_ABL & 1)) epi_group_store<OUT_BF16, GELU, HAS_RES>(v, bias4, res[g & 1], rc, coff0 + g * 4 * cstep, cstep);
+        else if (v[0].x == 1.2345e30f) epi_group_store<OUT_BF16, GELU, HAS_RES>(v, bias4, res[g & 1], rc, coff0, cstep);
+      }
+    }
+    if (!more) break;
+    t = tnext;
+  }
+}
+
+template <bool OUT_BF16, bool GELU, bool HAS_RES>
+static int launch_gemm_persistent(GemmArgs a, hipStream_t s) {
+  auto kern = gemm_bf16_persistent_kernel<OUT_BF16, GELU, HAS_RES>;
+  static bool attr_set = false;
+  static int n_cu = 0;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+    if (e != hipSuccess) { sf_set_error("sf_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { sf_set_error("sf_gemm_bf16: device query failed"); return -1; }
+    n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const int64_t tiles_m = (a.M + PBM - 1) / PBM;
+  a.tiles_n = (uint32_t)((a.N + PBN - 1) / PBN);
+  const int64_t total = tiles_m * a.tiles_n;
+  if (total >= ((int64_t)1 << 31)) { sf_set_error("sf_gemm_bf16: too many tiles"); return -1; }
+  a.tiles_total = (uint32_t)total;
+  int64_t blocks = (n_cu / 8) * 8;                               // one workgroup per CU, a multiple of the 8 XCDs
+  const int64_t need = ((total + 7) / 8) * 8;
+  if (blocks > need) blocks = need;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), P_LDS, s, a);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+static int dispatch_gemm_persistent(const GemmArgs& a, bool out_bf16, bool gelu, bool res, hipStream_t s) {
+  if (out_bf16) {
+    if (gelu) return res ? launch_gemm_persistent<true, true, true>(a, s) : launch_gemm_persistent<true, true, false>(a, s);
+    return res ? launch_gemm_persistent<true, false, true>(a, s) : launch_gemm_persistent<true, false, false>(a, s);
+  }
+  if (gelu) return res ? launch_gemm_persistent<false, true, true>(a, s) : launch_gemm_persistent<false, true, false>(a, s);
+  return res ? launch_gemm_persistent<false, false, true>(a, s) : launch_gemm_persistent<false, false, false>(a, s);
+}
+
+//                 BM   BN  WM WN BK NS wg/CU
+typedef GemmCfg<128, 128, 2, 2, 64, 2, 2> Cfg0;   // 4 waves,  64 KiB: small-M GEMMs (AST, aggregators, sync, heads)
+typedef GemmCfg<256, 256, 2, 4, 64, 2, 1> Cfg1;   // 8 waves, 128 KiB, 2-stage
+typedef GemmCfg<256, 256, 2, 4, 32, 4, 1> Cfg2;   // 8 waves, 128 KiB, 4-stage ring of 32-deep steps (3 in flight)
+typedef GemmCfg<256, 128, 4, 2, 64, 3, 1> Cfg3;   // 8 waves, 144 KiB, 3-stage ring of 64-deep steps (2 in flight)
+typedef GemmCfg<128, 128, 2, 2, 32, 4, 2> Cfg4;   // 4 waves,  64 KiB, 4-stage ring, 2 workgroups/CU
+typedef GemmCfg<256, 256, 2, 4, 32, 4, 1, true> Cfg5;   // Cfg2 + fragment register double-buffering
+typedef GemmCfg<128, 128, 2, 2, 32, 4, 2, true> Cfg6;   // Cfg4 + fragment register double-buffering
+typedef GemmCfg<256, 128, 2, 2, 32, 3, 2> Cfg8;   // 4 waves x (128 x 64), 72 KiB, 2 workgroups/CU: epilogue overlaps the other WG's loop
+typedef GemmCfg<128, 256, 1, 4, 32, 3, 2> Cfg9;   // same, transposed block shape
+
+static int g_force_cfg = -1;   // tuning / test hook
+extern "C" void sf_gemm_force_config(int cfg) { g_force_cfg = cfg; }
+
+template <class Cfg, bool OUT_BF16, bool GELU, bool HAS_RES, bool FAST>
+static int launch_gemm(GemmArgs a, hipStream_t s) {
+  auto kern = gemm_bf16_kernel<Cfg, OUT_BF16, GELU, HAS_RES, FAST>;
   static bool attr_set = false;   // benign race: the attribute call is idempotent
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     if (e != hipSuccess) { sf_set_error("sf_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.tiles_total), dim3(256), 2 * STAGE_BYTES, s, a);
+  const int64_t tiles_m = (a.M + Cfg::BM - 1) / Cfg::BM;
+  a.tiles_n = (uint32_t)((a.N + Cfg::BN - 1) / Cfg::BN);
+  const int64_t total = tiles_m * a.tiles_n;
+  if (total >= ((int64_t)1 << 31)) { sf_set_error("sf_gemm_bf16: too many tiles"); return -1; }
+  a.tiles_total = (uint32_t)total;
+  hipLaunchKernelGGL(kern, dim3(a.tiles_total), dim3(Cfg::THREADS), Cfg::LDS, s, a);
   SF_LAUNCH_CHECK();
   return 0;
+}
+
+template <class Cfg>
+static int dispatch_gemm(const GemmArgs& a, bool out_bf16, bool gelu, bool res, bool fast, hipStream_t s) {
+  if (!fast) {   // general path (row maps / ragged N): the variants the model needs
+    if (gelu) { sf_set_error("sf_gemm_bf16: the GELU epilogue needs identity row maps and N %% 64 == 0"); return -1; }
+    if (out_bf16) return res ? launch_gemm<Cfg, true, false, true, false>(a, s) : launch_gemm<Cfg, true, false, false, false>(a, s);
+    return res ? launch_gemm<Cfg, false, false, true, false>(a, s) : launch_gemm<Cfg, false, false, false, false>(a, s);
+  }
+  if (out_bf16) {
+    if (gelu) return res ? launch_gemm<Cfg, true, true, true, true>(a, s) : launch_gemm<Cfg, true, true, false, true>(a, s);
+    return res ? launch_gemm<Cfg, true, false, true, true>(a, s) : launch_gemm<Cfg, true, false, false, true>(a, s);
+  }
+  if (gelu) return res ? launch_gemm<Cfg, false, true, true, true>(a, s) : launch_gemm<Cfg, false, true, false, true>(a, s);
+  return res ? launch_gemm<Cfg, false, false, true, true>(a, s) : launch_gemm<Cfg, false, false, false, true>(a, s);
 }
 
 extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, void* C,
@@ -201,30 +611,44 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
   SF_CHECK_ARG(A && W && C, "sf_gemm_bf16: null pointer");
   SF_CHECK_ARG(c_dtype == SF_BF16 || c_dtype == SF_F32, "sf_gemm_bf16: c_dtype must be bf16 or f32");
   SF_CHECK_ARG(epilogue == SF_EPI_NONE || epilogue == SF_EPI_GELU, "sf_gemm_bf16: bad epilogue %d", epilogue);
-  SF_CHECK_ARG(K > 0 && (K % BK) == 0, "sf_gemm_bf16: K=%lld must be a positive multiple of %d", (long long)K, BK);
+  SF_CHECK_ARG(K > 0 && (K % 64) == 0, "sf_gemm_bf16: K=%lld must be a positive multiple of 64", (long long)K);
   SF_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0, "sf_gemm_bf16: lda/ldw must be multiples of 8 elements (16 B)");
   SF_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "sf_gemm_bf16: A/W must be 16-byte aligned");
   SF_CHECK_ARG(M < ((int64_t)1 << 31) && N < ((int64_t)1 << 31), "sf_gemm_bf16: M, N must be < 2^31");
-  SF_CHECK_ARG(!(R && c_dtype == SF_BF16 && 0), "unreachable");
   if (M <= 0 || N <= 0) return 0;
-  if ((N % 4) == 0) {
-    SF_CHECK_ARG((ldc % 4) == 0 && (!R || (ldr % 4) == 0), "sf_gemm_bf16: ldc/ldr must be multiples of 4 when N %% 4 == 0");
-  }
+  // FAST epilogue: identity row maps, whole 64-column wave tiles, 16-byte aligned rows, and every byte offset of the
+  // (tile-padded) output / residual below 4 GiB (32-bit buffer offsets; rows >= M are dropped by the range check).
+  const int64_t m_pad = ((M + 255) / 256) * 256;
+  const bool fast = !c_map && !r_map && (N % 64) == 0 && (ldc % 4) == 0 && (!R || (ldr % 4) == 0) &&
+                    ((uintptr_t)C % 16) == 0 && (!R || ((uintptr_t)R % 16) == 0) && (!bias || ((uintptr_t)bias % 16) == 0) &&
+                    m_pad * ldc * 4 < ((int64_t)1 << 32) && (!R || m_pad * ldr * 4 < ((int64_t)1 << 32));
   GemmArgs a;
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldr;
   a.cmap = sf_rowmap(c_map); a.rmap = sf_rowmap(r_map);
   a.M = M; a.N = (int)N; a.K = (int)K;
-  const int64_t tiles_m = (M + BM - 1) / BM;
-  a.tiles_n = (uint32_t)((N + BN - 1) / BN);
-  const int64_t total = tiles_m * a.tiles_n;
-  SF_CHECK_ARG(total < ((int64_t)1 << 31), "sf_gemm_bf16: too many tiles");
-  a.tiles_total = (uint32_t)total;
+  a.tiles_n = 0; a.tiles_total = 0;
   hipStream_t s = (hipStream_t)stream;
-  const bool gelu = epilogue == SF_EPI_GELU, res = R != nullptr;
-  if (c_dtype == SF_BF16) {
-    if (gelu) return res ? launch_gemm<true, true, true>(a, s) : launch_gemm<true, true, false>(a, s);
-    return res ? launch_gemm<true, false, true>(a, s) : launch_gemm<true, false, false>(a, s);
+  const bool gelu = epilogue == SF_EPI_GELU, res = R != nullptr, obf = c_dtype == SF_BF16;
+  int cfg = g_force_cfg;
+  if (cfg < 0) {
+    // Measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_configs.md): the persistent 256x256 kernel wins on the
+    // big token GEMMs; the short-K fp32-residual projection (N = K = 768) is HBM-bound and prefers 2 workgroups/CU;
+    // everything small (AST, aggregators, sync transformer, heads) and every mapped/ragged GEMM takes the 128x128 kernel.
+    const bool big = fast && M >= 8192 && N >= 512;
+    cfg = !big ? 0 : ((res && K <= 1024) ? 0 : 7);
   }
-  if (gelu) return res ? launch_gemm<false, true, true>(a, s) : launch_gemm<false, true, false>(a, s);
-  return res ? launch_gemm<false, false, true>(a, s) : launch_gemm<false, false, false>(a, s);
+  switch (cfg) {
+    case 0: return dispatch_gemm<Cfg0>(a, obf, gelu, res, fast, s);
+    case 1: return dispatch_gemm<Cfg1>(a, obf, gelu, res, fast, s);
+    case 2: return dispatch_gemm<Cfg2>(a, obf, gelu, res, fast, s);
+    case 3: return dispatch_gemm<Cfg3>(a, obf, gelu, res, fast, s);
+    case 4: return dispatch_gemm<Cfg4>(a, obf, gelu, res, fast, s);
+    case 5: return dispatch_gemm<Cfg5>(a, obf, gelu, res, fast, s);
+    case 6: return dispatch_gemm<Cfg6>(a, obf, gelu, res, fast, s);
+    case 8: return dispatch_gemm<Cfg8>(a, obf, gelu, res, fast, s);
+    case 9: return dispatch_gemm<Cfg9>(a, obf, gelu, res, fast, s);
+    case 7: if (!fast) { sf_set_error("sf_gemm_bf16: config 7 needs N %% 64 == 0"); return -1; }
+            return dispatch_gemm_persistent(a, obf, gelu, res, s);
+    default: sf_set_error("sf_gemm_bf16: unknown tile config %d", cfg); return -1;
+  }
 }

@@ -18,21 +18,31 @@ def _rand(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
-def test_gemm_identity_asymmetric(gpu):
+def test_gemm_identity_asymmetric(gpu, gemm_cfg):
     """A = I against an asymmetric W catches swapped fragment rows/cols (guide rule 16)."""
     from synchformer_amd import ops
-    K = 128
+    K = 320
     a = torch.eye(K)
-    w = torch.arange(192 * K, dtype=torch.float32).reshape(192, K) % 251 - 125.0   # exactly representable in bf16
-    out = torch.empty(K, 192, device=gpu)
+    w = torch.arange(320 * K, dtype=torch.float32).reshape(320, K) % 251 - 125.0   # exactly representable in bf16
+    out = torch.empty(K, 320, device=gpu)
     ops.gemm(_bf(a).to(gpu), _bf(w).to(gpu), None, out)
     torch.testing.assert_close(out.cpu(), w.t().contiguous(), rtol=0, atol=0)
 
 
-@pytest.mark.parametrize('M,N,K', [(300, 768, 768), (128, 2304, 768), (1000, 768, 3072), (257, 3072, 768), (5, 21, 768),
+@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9], ids=['auto'] + [f'cfg{i}' for i in range(10)])
+def gemm_cfg(request, gpu):
+    from synchformer_amd import _lib
+    _lib.load().sf_gemm_force_config(request.param)
+    yield request.param
+    _lib.load().sf_gemm_force_config(-1)
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 768, 768), (9000, 768, 768), (8500, 2304, 768), (128, 2304, 768), (1000, 768, 3072), (257, 3072, 768), (5, 21, 768),
                                    (3, 2, 768), (1568 * 2, 768, 1536), (144, 768, 256)])
-def test_gemm_bias(gpu, M, N, K):
+def test_gemm_bias(gpu, gemm_cfg, M, N, K):
     from synchformer_amd import ops
+    if gemm_cfg == 7 and N % 64:
+        pytest.skip('persistent config serves N % 64 == 0 only')
     a, w, b = _bf(_rand(M, K, seed=1)), _bf(_rand(N, K, seed=2, scale=0.05)), _rand(N, seed=3)
     ref = a.float() @ w.float().t() + b
     out = torch.full((M + 3, N), 7.0, device=gpu)
@@ -44,8 +54,10 @@ def test_gemm_bias(gpu, M, N, K):
     torch.testing.assert_close(outb.float().cpu(), ref, rtol=1e-2, atol=1e-2)
 
 
-def test_gemm_gelu_residual_maps(gpu):
+def test_gemm_gelu_residual_maps(gpu, gemm_cfg):
     from synchformer_amd import ops
+    if gemm_cfg == 7:
+        pytest.skip('persistent config serves identity row maps only')
     M, N, K = 400, 768, 768
     a, w, b = _bf(_rand(M, K, seed=4)), _bf(_rand(N, K, seed=5, scale=0.05)), _rand(N, seed=6)
     lin = a.float() @ w.float().t() + b
