@@ -1,0 +1,11 @@
+"""synchformer_amd - MI355X-native hot path of v-iashin/Synchformer.
+
+    from synchformer_amd import Synchformer, instantiate_from_config, install_reference_aliases
+"""
+from .model import (AST, DoNothingBridge, GlobalTransformer, GlobalTransformerWithSyncabilityHead, MotionFormer,  # noqa: F401
+                    RandInitPositionalEncoding, Synchformer, get_obj_from_str, install_reference_aliases,
+                    instantiate_from_config, sync_yaml_model_config, uninstall_reference_aliases)
+
+__all__ = ['Synchformer', 'MotionFormer', 'AST', 'GlobalTransformer', 'GlobalTransformerWithSyncabilityHead',
+           'RandInitPositionalEncoding', 'DoNothingBridge', 'instantiate_from_config', 'get_obj_from_str',
+           'install_reference_aliases', 'uninstall_reference_aliases', 'sync_yaml_model_config']

@@ -1,0 +1,45 @@
+"""Multi-GPU plumbing for the inference path: one process per GPU, clips sharded by rank, NO data-path collective.
+
+Offset-prediction inference is embarrassingly parallel over clips ("replicas only"): every rank holds a full
+replica of the 475 MB bf16 weights and processes its own contiguous slice of the batch.  The only communication is
+control-plane: a barrier + MAX-reduce of the step time for honest throughput accounting, and an optional gather of the
+(B, 21) logits to rank 0.  Backend 'nccl' (= RCCL over xGMI on ROCm) on GPUs, 'gloo' in the CPU unit tests.
+"""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced split of `n_items` clips: the first (n % world) ranks get one extra."""
+    if world <= 0 or not 0 <= rank < world:
+        raise ValueError(f'bad rank/world {rank}/{world}')
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
+    """MAX-reduce a python float (step time) over the default process group; identity when not initialised."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device or 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_logits(local: torch.Tensor, n_total: int) -> Optional[torch.Tensor]:
+    """Gather per-rank logits (ragged first dim, shard_range order) to rank 0 -> (n_total, C); None on other ranks."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    pad = max(e - s for s, e in sizes)
+    buf = torch.zeros(pad, local.shape[1], dtype=local.dtype, device=local.device)
+    buf[:local.shape[0]] = local
+    out: List[torch.Tensor] = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, out, dst=0)
+    if rank != 0:
+        return None
+    return torch.cat([o[:e - s] for o, (s, e) in zip(out, sizes)], 0)

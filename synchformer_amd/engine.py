@@ -297,11 +297,21 @@ class SynchformerEngine:
     # ------------------------------------------------------------------------------------------------
     # sync transformer + top level
     # ------------------------------------------------------------------------------------------------
-    def sync_transformer(self, vfeat: torch.Tensor, afeat: torch.Tensor) -> torch.Tensor:
-        """vproj/aproj (sync_model.py:55-56) + GlobalTransformer.forward (:150-173).  vfeat (B,S,tv,768), afeat (B,S,ta,768)
-        fp32 on device -> logits fp32 (B, n_out)."""
-        B = vfeat.shape[0]
-        Sv, Sa = vfeat.shape[1] * vfeat.shape[2], afeat.shape[1] * afeat.shape[2]
+    def project(self, feat: torch.Tensor, which: str) -> torch.Tensor:
+        """vproj / aproj (sync_model.py:55-56): (B, S, t, 768) fp32 -> (B, S*t, 768) fp32."""
+        proj = self.vproj if which == 'v' else self.aproj
+        B, n_tok = feat.shape[0], feat.shape[1] * feat.shape[2]
+        f2 = feat.reshape(B * n_tok, D)
+        fb = self._buf('proj_in', B * n_tok * D, torch.bfloat16).view(B * n_tok, D)
+        ops.gather_rows(f2, fb, B * n_tok)
+        out = torch.empty(B * n_tok, D, device=self.dev, dtype=torch.float32)
+        ops.gemm(fb, proj.w, proj.b, out)
+        return out.view(B, n_tok, D)
+
+    def global_transformer(self, v: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
+        """GlobalTransformer.forward (sync_model.py:150-173).  v (B, Sv, 768), a (B, Sa, 768) fp32 on device (already
+        projected) -> logits fp32 (B, n_out)."""
+        B, Sv, Sa = v.shape[0], v.shape[1], a.shape[1]
         L = 2 + Sv + Sa
         table = self._sync_table(Sv, Sa)
         rows = B * L
@@ -309,13 +319,11 @@ class SynchformerEngine:
         xn = self._buf('XNs', rows * D, torch.bfloat16).view(rows, D)
         big = self._buf('BIGs', rows * FF, torch.bfloat16)
         ops.broadcast_rows(X, table, n_seq=B, dst_seq_rows=L)
-        for feat, proj, ln, n_tok, off in ((vfeat, self.vproj, self.s_vln, Sv, 1), (afeat, self.aproj, self.s_aln, Sa, 2 + Sv)):
+        for feat, ln, n_tok, off in ((v, self.s_vln, Sv, 1), (a, self.s_aln, Sa, 2 + Sv)):
             f2 = feat.reshape(B * n_tok, D)
-            fb = xn[:B * n_tok]
-            ops.gather_rows(f2, fb, B * n_tok)
-            pr = self._buf('proj', B * n_tok * D, torch.float32).view(B * n_tok, D)
-            ops.gemm(fb, proj.w, proj.b, pr, M=B * n_tok)
-            ops.layernorm(pr, ln.g, ln.b, X, EPS_SYNC, out_map=ops.rowmap(n_tok, n_tok, L, 0, 1, off), accumulate=True)
+            if not f2.is_contiguous():
+                f2 = f2.contiguous()
+            ops.layernorm(f2, ln.g, ln.b, X, EPS_SYNC, out_map=ops.rowmap(n_tok, n_tok, L, 0, 1, off), accumulate=True)
         hd = D // self.s_heads
 
         def full_attn(q3, o):
@@ -330,6 +338,10 @@ class SynchformerEngine:
         logits = torch.empty(B, self.n_out, device=self.dev, dtype=torch.float32)
         ops.gemm(cls, self.s_head.w, self.s_head.b, logits, M=B)
         return logits
+
+    def sync_transformer(self, vfeat: torch.Tensor, afeat: torch.Tensor) -> torch.Tensor:
+        """vproj/aproj + GlobalTransformer: segment features (B,S,tv,768) / (B,S,ta,768) fp32 -> logits (B, n_out)."""
+        return self.global_transformer(self.project(vfeat, 'v'), self.project(afeat, 'a'))
 
     def forward(self, vis: torch.Tensor, aud: torch.Tensor) -> torch.Tensor:
         """Synchformer.forward (sync_model.py:38-70) without the loss: logits (B, n_out) fp32."""

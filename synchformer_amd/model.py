@@ -1,0 +1,365 @@
+"""Drop-in host mirror of the reference's plugin interface for the hot path.
+
+The reference builds its model with `instantiate_from_config({'target': 'pkg.mod.Class', 'params': {...}})`
+(utils/utils.py:78-88) from configs/sync.yaml.  The classes below keep the reference's constructor signatures,
+attribute names (`vfeat_extractor`, `afeat_extractor`, `vproj`, `aproj`, `transformer.pos_emb_cfg.pos_emb`, ...) and
+the exact `state_dict()` schema (513 tensors for configs/sync.yaml), so `get_model`, `toggle_mode`,
+`load_state_dict(ckpt['model'])` and `model(vis, aud, targets)` in scripts/train_sync.py / example.py work unchanged once
+`target:` points here - or, without editing any yaml, after `synchformer_amd.install_reference_aliases()` has
+registered these classes under the reference's own dotted paths.
+
+All compute runs through libsynchformer_hip (synchformer_amd.engine); there is no CPU / eager fallback: calling
+forward on CPU tensors raises.  Out-of-scope options of the reference constructors (SparseSync-era bridges, S3D/ResNet
+extractors, joint/trajectory attention, token masks - SURVEY §2 rows 4b/5/6, §8f rank 2) raise NotImplementedError
+naming the option.
+"""
+import importlib
+import logging
+import sys
+import types
+from typing import Any, Mapping, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import synth
+from .engine import SynchformerEngine
+
+# reference dotted path -> class name in this module (nested `target:` strings of configs/*.yaml)
+_TARGET_ALIASES = {
+    'model.sync_model.Synchformer': 'Synchformer',
+    'model.sync_model.GlobalTransformer': 'GlobalTransformer',
+    'model.sync_model.GlobalTransformerWithSyncabilityHead': 'GlobalTransformerWithSyncabilityHead',
+    'model.modules.feat_extractors.visual.motionformer.MotionFormer': 'MotionFormer',
+    'model.modules.feat_extractors.audio.ast.AST': 'AST',
+    'model.modules.transformer.RandInitPositionalEncoding': 'RandInitPositionalEncoding',
+    'model.modules.bridges.DoNothingBridge': 'DoNothingBridge',
+}
+
+
+def get_obj_from_str(string: str):
+    """utils/utils.py:78-83, with the reference's hot-path classes resolved to this package."""
+    if string in _TARGET_ALIASES:
+        return globals()[_TARGET_ALIASES[string]]
+    module, cls = string.rsplit('.', 1)
+    return getattr(importlib.import_module(module), cls)
+
+
+def instantiate_from_config(config: Mapping[str, Any]):
+    """utils/utils.py:85-88 (same KeyError on a missing `target`)."""
+    if 'target' not in config:
+        raise KeyError('Expected key `target` to instantiate.')
+    return get_obj_from_str(config['target'])(**config.get('params', dict()))
+
+
+def install_reference_aliases():
+    """Register this module under the reference's dotted module paths (`model.sync_model`, ...), so an UNMODIFIED
+    configs/sync.yaml instantiates the HIP-backed classes (SURVEY §8b 'registering itself under the same dotted path')."""
+    me = sys.modules[__name__]
+    for path in {p.rsplit('.', 1)[0] for p in _TARGET_ALIASES}:
+        parts = path.split('.')
+        for i in range(1, len(parts) + 1):
+            name = '.'.join(parts[:i])
+            if name not in sys.modules:
+                sys.modules[name] = types.ModuleType(name)
+            if i > 1:
+                setattr(sys.modules['.'.join(parts[:i - 1])], parts[i - 1], sys.modules[name])
+        for ref_path, cls in _TARGET_ALIASES.items():
+            if ref_path.rsplit('.', 1)[0] == path:
+                setattr(sys.modules[path], ref_path.rsplit('.', 1)[1], getattr(me, cls))
+
+
+def uninstall_reference_aliases():
+    """Remove the alias modules again (they have no __file__), e.g. before importing the real reference in tests."""
+    for name in [n for n, m in sys.modules.items()
+                 if (n == 'model' or n.startswith('model.')) and getattr(m, '__file__', None) is None
+                 and not hasattr(m, '__path__')]:
+        del sys.modules[name]
+
+
+def _register_tree(root: torch.nn.Module, schema: Mapping[str, tuple], prefix: str, seed: int):
+    """Create nested containers + nn.Parameters so that root.state_dict() has exactly the reference's keys."""
+    for full, shape in schema.items():
+        if not full.startswith(prefix):
+            continue
+        parts = full[len(prefix):].split('.')
+        mod = root
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, torch.nn.Module())
+            mod = getattr(mod, p)
+        mod.register_parameter(parts[-1], torch.nn.Parameter(synth.fill_tensor(full, shape, seed)))
+
+
+class DoNothingBridge(torch.nn.Identity):
+    """model/modules/bridges.py:64-68."""
+
+    def __init__(self, in_features=None, out_features=None, **_):
+        super().__init__()
+
+
+class RandInitPositionalEncoding(torch.nn.Module):
+    """model/modules/transformer.py:120-130 (parameter holder; the add is folded into the engine's token table)."""
+
+    def __init__(self, block_shape: list, n_embd: int):
+        super().__init__()
+        self.block_shape, self.n_embd = block_shape, n_embd
+        self.pos_emb = torch.nn.Parameter(torch.randn(1, *block_shape, n_embd))
+
+    def forward(self, token_embeddings):
+        return token_embeddings + self.pos_emb
+
+
+class MotionFormer(torch.nn.Module):
+    """motionformer.py:24-272 (divided space-time, factorised spatial aggregation).  Parameter holder + standalone
+    feature extractor; inside `Synchformer` the engine reads these parameters directly."""
+
+    def __init__(self, extract_features: bool = False, ckpt_path: str = None, factorize_space_time: bool = None,
+                 agg_space_module: str = None, agg_time_module: str = None, add_global_repr: bool = True,
+                 agg_segments_module: str = None, max_segments: int = None, _seed: int = 0):
+        super().__init__()
+        if not extract_features or not factorize_space_time or agg_space_module != 'TransformerEncoderLayer':
+            raise NotImplementedError('only extract_features=True, factorize_space_time=True, '
+                                      "agg_space_module='TransformerEncoderLayer' (configs/sync.yaml) is built natively")
+        if agg_time_module is None or 'Identity' not in agg_time_module:
+            raise NotImplementedError(f'agg_time_module={agg_time_module!r}: only torch.nn.Identity (Stage-2 configs) so far')
+        if add_global_repr:
+            raise NotImplementedError('add_global_repr=True (global segment aggregation) is outside the hot path')
+        if ckpt_path is not None:
+            raise NotImplementedError('pretrained-checkpoint download/loading is out of scope; load a state_dict instead')
+        self.extract_features, self.factorize_space_time, self.add_global_repr = True, True, False
+        self.embed_dim, self.num_heads, self.temporal_resolution = 768, 12, 8
+        schema = synth.state_dict_schema()
+        _register_tree(self, schema, 'vfeat_extractor.', _seed)
+        self.patch_embed.requires_grad_(False)          # motionformer.py:177
+        logging.info(f'vfeat_extractor: {sum(p.numel() for p in self.parameters() if p.requires_grad):,}')
+
+    def forward(self, x, for_loop: bool = False, cont_mask: torch.Tensor = None):
+        """x (B, S, C, T, H, W) -> ((B, S, 8, 768), None)  (motionformer.py:182-223)."""
+        if cont_mask is not None:
+            raise NotImplementedError('cont_mask (token masking) is not implemented yet (SURVEY §8f rank 2)')
+        eng = _engine_for(self, 'vfeat_extractor.')
+        return eng.extract_vfeats(x.permute(0, 1, 3, 2, 4, 5).contiguous()), None
+
+
+class AST(torch.nn.Module):
+    """ast.py:13-250 (factorised frequency aggregation)."""
+
+    def __init__(self, extract_features: bool = False, ckpt_path: str = None, feat_type: str = None,
+                 max_spec_t: int = None, factorize_freq_time: bool = None, agg_freq_module: str = None,
+                 agg_time_module: str = None, add_global_repr: bool = True, agg_segments_module: str = None,
+                 max_segments: int = None, _seed: int = 0):
+        super().__init__()
+        if not extract_features or not factorize_freq_time or agg_freq_module != 'TransformerEncoderLayer':
+            raise NotImplementedError('only extract_features=True, factorize_freq_time=True, '
+                                      "agg_freq_module='TransformerEncoderLayer' (configs/sync.yaml) is built natively")
+        if agg_time_module is None or 'Identity' not in agg_time_module:
+            raise NotImplementedError(f'agg_time_module={agg_time_module!r}: only torch.nn.Identity (Stage-2 configs) so far')
+        if add_global_repr:
+            raise NotImplementedError('add_global_repr=True (global segment aggregation) is outside the hot path')
+        if ckpt_path is not None:
+            raise NotImplementedError('pretrained-checkpoint download/loading is out of scope; load a state_dict instead')
+        if max_spec_t != 66:
+            raise NotImplementedError('max_spec_t must be 66 (74-token position table, configs/sync.yaml:14)')
+        self.extract_features, self.max_spec_t, self.factorize_freq_time, self.add_global_repr = True, 66, True, False
+        self.feat_type = 'last_hidden_state'
+        _register_tree(self, synth.state_dict_schema(), 'afeat_extractor.', _seed)
+
+    def forward(self, x, for_loop: bool = False, cont_mask: torch.Tensor = None, **ast_kwargs):
+        """x (B, S, T, F) -> ((B, S, 6, 768), None)  (ast.py:137-176)."""
+        if cont_mask is not None:
+            raise NotImplementedError('cont_mask (token masking) is not implemented yet (SURVEY §8f rank 2)')
+        eng = _engine_for(self, 'afeat_extractor.')
+        B, S, T, Fq = x.shape
+        return eng.extract_afeats(x.permute(0, 1, 3, 2).reshape(B, S, 1, Fq, T)), None
+
+
+class GlobalTransformer(torch.nn.Module):
+    """sync_model.py:117-173.  Dropouts are inference-only no-ops here (the reference runs eval() for inference)."""
+    _head_name = 'off_head'
+
+    def __init__(self, tok_pdrop, embd_pdrop, resid_pdrop, attn_pdrop, n_layer, n_head, n_embd, pos_emb_cfg=None,
+                 off_head_cfg=None, _seed: int = 0):
+        super().__init__()
+        if n_embd != 768 or n_head != 8:
+            raise NotImplementedError('native sync transformer is built for n_embd=768, n_head=8 (configs/sync.yaml:44-46)')
+        if tok_pdrop and tok_pdrop > 0:
+            raise NotImplementedError('tok_pdrop > 0 (whole-token dropout) is not used by the three configs')
+        self.n_layer, self.n_head, self.n_embd = n_layer, n_head, n_embd
+        n_pos = pos_emb_cfg['params']['block_shape'][0] if pos_emb_cfg is not None else 198
+        n_out = off_head_cfg['params']['out_features'] if off_head_cfg is not None else 21
+        schema = synth.state_dict_schema(n_pos=n_pos, n_out=n_out, sync_depth=n_layer, head='off_head')
+        skip = ('transformer.pos_emb_cfg.', 'transformer.off_head.')
+        _register_tree(self, {k: v for k, v in schema.items() if not k.startswith(skip)}, 'transformer.', _seed)
+        if pos_emb_cfg is not None:
+            self.pos_emb_cfg = instantiate_from_config(pos_emb_cfg)
+            with torch.no_grad():
+                self.pos_emb_cfg.pos_emb.copy_(synth.fill_tensor('transformer.pos_emb_cfg.pos_emb', (1, n_pos, n_embd), _seed))
+        if off_head_cfg is not None:
+            self.off_head = instantiate_from_config(off_head_cfg)
+        _reorder_like(self, [k[len('transformer.'):] for k in schema])
+
+    def forward(self, v: torch.Tensor, a: torch.Tensor, targets=None, attempt_to_apply_heads=True):
+        if not attempt_to_apply_heads:
+            raise NotImplementedError('attempt_to_apply_heads=False is only used by subclasses of the reference')
+        eng = _engine_for(self, 'transformer.')
+        B = v.shape[0]
+        return eng.global_transformer(v.reshape(B, -1, self.n_embd).float(), a.reshape(B, -1, self.n_embd).float())
+
+
+class GlobalTransformerWithSyncabilityHead(GlobalTransformer):
+    """sync_model.py:176-190: off_head -> Identity, 2-way sync_head on token 0."""
+
+    def __init__(self, tok_pdrop, embd_pdrop, resid_pdrop, attn_pdrop, n_layer, n_head, n_embd, pos_emb_cfg=None,
+                 off_head_cfg=None, _seed: int = 0):
+        super().__init__(tok_pdrop, embd_pdrop, resid_pdrop, attn_pdrop, n_layer, n_head, n_embd, pos_emb_cfg, off_head_cfg,
+                         _seed)
+        self.off_head = torch.nn.Identity()
+        self.sync_head = torch.nn.Linear(n_embd, 2)
+        with torch.no_grad():
+            self.sync_head.weight.copy_(synth.fill_tensor('transformer.sync_head.weight', (2, n_embd), _seed))
+            self.sync_head.bias.copy_(synth.fill_tensor('transformer.sync_head.bias', (2,), _seed))
+
+
+def _reorder_like(mod: torch.nn.Module, order):
+    """state_dict() order follows registration order; make it the reference's (cosmetic: strict loading is by key)."""
+    want = [k.split('.')[0] for k in order]
+    seen, first = set(), []
+    for k in want:
+        if k not in seen:
+            seen.add(k)
+            first.append(k)
+    params = dict(mod._parameters)
+    mods = dict(mod._modules)
+    mod._parameters.clear()
+    mod._modules.clear()
+    for k in first:
+        if k in params:
+            mod._parameters[k] = params.pop(k)
+        elif k in mods:
+            mod._modules[k] = mods.pop(k)
+    mod._parameters.update(params)
+    mod._modules.update(mods)
+
+
+def _param_key(module: torch.nn.Module):
+    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+
+
+def _engine_for(module: torch.nn.Module, prefix: str) -> SynchformerEngine:
+    """Stand-alone use of a sub-module: build (and cache) an engine that only has this sub-module's weights real."""
+    key = _param_key(module)
+    cached = getattr(module, '_sf_engine', None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    dev = next(module.parameters()).device
+    if dev.type != 'cuda':
+        raise RuntimeError('synchformer_amd modules compute on a HIP device only (no CPU fallback); call .to("cuda") first')
+    n_pos, n_out, head = 198, 21, 'off_head'
+    own = {prefix + k: v for k, v in module.state_dict().items()}
+    if prefix == 'transformer.':
+        n_pos = own['transformer.pos_emb_cfg.pos_emb'].shape[1]
+        head = 'sync_head' if 'transformer.sync_head.weight' in own else 'off_head'
+        n_out = own[f'transformer.{head}.weight'].shape[0]
+    sd = synth.make_state_dict(0, n_pos=n_pos, n_out=n_out, head=head, sync_depth=len([k for k in own if k.endswith('ln1.weight')]) or 3)
+    sd.update(own)
+    eng = SynchformerEngine(sd, dev)
+    object.__setattr__(module, '_sf_engine', (key, eng))
+    return eng
+
+
+class Synchformer(torch.nn.Module):
+    """model/sync_model.py:23-114 - same constructor, forward contract and state-dict schema."""
+
+    def __init__(self, afeat_extractor, vfeat_extractor, aproj, vproj, transformer):
+        super().__init__()
+        self.vfeat_extractor = instantiate_from_config(vfeat_extractor)
+        self.afeat_extractor = instantiate_from_config(afeat_extractor)
+        self.vproj = instantiate_from_config(vproj)
+        self.aproj = instantiate_from_config(aproj)
+        self.transformer = instantiate_from_config(transformer)
+        for name in ('vproj', 'aproj'):
+            m = getattr(self, name)
+            if not isinstance(m, torch.nn.Linear) or m.in_features != 768 or m.out_features != 768:
+                raise NotImplementedError(f'{name}: only torch.nn.Linear(768, 768) (configs/sync.yaml:28-39) is built natively')
+            with torch.no_grad():
+                m.weight.copy_(synth.fill_tensor(f'{name}.weight', (768, 768), 0))
+                m.bias.copy_(synth.fill_tensor(f'{name}.bias', (768,), 0))
+        self._sf_engine = None
+        self.seg_chunk = 27
+
+    # -- engine cache ---------------------------------------------------------------------------------------
+    def _engine(self) -> SynchformerEngine:
+        key = _param_key(self)
+        if self._sf_engine is not None and self._sf_engine[0] == key:
+            return self._sf_engine[1]
+        dev = next(self.parameters()).device
+        if dev.type != 'cuda':
+            raise RuntimeError('Synchformer computes on a HIP device only (no CPU fallback); call .to("cuda") first')
+        eng = SynchformerEngine(self.state_dict(), dev, seg_chunk=self.seg_chunk)
+        self._sf_engine = (key, eng)
+        return eng
+
+    # -- reference API --------------------------------------------------------------------------------------
+    def forward(self, vis: torch.Tensor, aud: torch.Tensor, targets: torch.Tensor = None, for_loop=False,
+                vis_mask: torch.Tensor = None, aud_mask: torch.Tensor = None, loss_fn=None):
+        """vis (B, S, Tv, C, H, W) u8|f16|bf16|f32, aud (B, S, 1, F, Ta) -> (loss | None, logits)  (sync_model.py:38-70).
+        `for_loop` only trades memory for speed in the reference (bit-equal results); here segments are always
+        processed in `self.seg_chunk`-sized chunks."""
+        vis = self.extract_vfeats(vis, for_loop, vis_mask=vis_mask)
+        aud = self.extract_afeats(aud, for_loop, aud_mask=aud_mask)
+        logits = self._engine().sync_transformer(vis, aud)
+        return self.compute_loss(logits, targets, loss_fn), logits
+
+    def extract_vfeats(self, vis, for_loop, vis_mask=None):
+        if vis_mask is not None:
+            raise NotImplementedError('vis_mask (token masking) is not implemented yet (SURVEY §8f rank 2)')
+        return self._engine().extract_vfeats(vis)
+
+    def extract_afeats(self, aud, for_loop, aud_mask=None):
+        if aud_mask is not None:
+            raise NotImplementedError('aud_mask (token masking) is not implemented yet (SURVEY §8f rank 2)')
+        return self._engine().extract_afeats(aud)
+
+    def compute_loss(self, logits, targets, loss_fn: str = None):
+        loss = None
+        if targets is not None:
+            if loss_fn is None or loss_fn == 'cross_entropy':
+                loss = F.cross_entropy(logits, targets)
+            else:
+                raise NotImplementedError(f'Loss {loss_fn} not implemented')
+        return loss
+
+    def load_state_dict(self, sd: Mapping[str, Any], strict: bool = True):
+        """sync_model.py:101-114: a longer checkpoint pos_emb is trimmed, a shorter one is an error."""
+        if 'transformer.pos_emb_cfg.pos_emb' in sd:
+            weight_len = sd['transformer.pos_emb_cfg.pos_emb'].shape[1]
+            self_len = self.transformer.pos_emb_cfg.pos_emb.shape[1]
+            if weight_len > self_len:
+                sd = dict(sd)
+                sd['transformer.pos_emb_cfg.pos_emb'] = sd['transformer.pos_emb_cfg.pos_emb'][:, :self_len, :]
+                logging.warning(f'Trimming the state dict for pos emb from {weight_len} to {self_len}')
+            elif weight_len < self_len:
+                raise ValueError(f'Cant load state dict with shorter seq len ({weight_len} vs {self_len})')
+        self._sf_engine = None
+        return super().load_state_dict(sd, strict)
+
+
+def sync_yaml_model_config(n_pos: int = 198, num_off_cls: int = 21,
+                           transformer_target: str = 'model.sync_model.GlobalTransformer') -> dict:
+    """`configs/sync.yaml: model` with its `${...}` interpolations resolved (what OmegaConf hands to the reference)."""
+    n_embd = 768
+    return dict(target='model.sync_model.Synchformer', params=dict(
+        afeat_extractor=dict(target='model.modules.feat_extractors.audio.ast.AST', params=dict(
+            ckpt_path=None, extract_features=True, max_spec_t=66, factorize_freq_time=True,
+            agg_freq_module='TransformerEncoderLayer', agg_time_module='torch.nn.Identity', add_global_repr=False)),
+        vfeat_extractor=dict(target='model.modules.feat_extractors.visual.motionformer.MotionFormer', params=dict(
+            ckpt_path=None, extract_features=True, factorize_space_time=True, agg_space_module='TransformerEncoderLayer',
+            agg_time_module='torch.nn.Identity', add_global_repr=False)),
+        aproj=dict(target='torch.nn.Linear', params=dict(in_features=768, out_features=n_embd)),
+        vproj=dict(target='torch.nn.Linear', params=dict(in_features=768, out_features=n_embd)),
+        transformer=dict(target=transformer_target, params=dict(
+            n_layer=3, n_head=8, n_embd=n_embd, tok_pdrop=0.0, embd_pdrop=0.1, resid_pdrop=0.1, attn_pdrop=0.1,
+            pos_emb_cfg=dict(target='model.modules.transformer.RandInitPositionalEncoding',
+                             params=dict(block_shape=[n_pos], n_embd=n_embd)),
+            off_head_cfg=dict(target='torch.nn.Linear', params=dict(in_features=n_embd, out_features=num_off_cls))))))

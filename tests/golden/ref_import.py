@@ -39,6 +39,9 @@ def import_reference():
         return _imported
     if not reference_available():
         raise RuntimeError(f'reference not found at {REF}')
+    # alias modules installed by synchformer_amd.install_reference_aliases() would shadow the real `model` package
+    for name in [n for n, m in sys.modules.items() if (n == 'model' or n.startswith('model.')) and getattr(m, '__file__', None) is None and not hasattr(m, '__path__')]:
+        del sys.modules[name]
     for p in (str(REF), str(SHIMS)):
         if p not in sys.path:
             sys.path.insert(0, p)

@@ -99,3 +99,31 @@ def test_chunking_invariance(gpu):
     eng.seg_chunk = 2
     b = eng.extract_vfeats(u8.to(gpu)).clone()
     assert torch.equal(a, b)
+
+
+def test_dropin_module_matches_golden(gpu):
+    """The reference-shaped plugin path: instantiate_from_config(sync.yaml model) -> load_state_dict -> model(vis, aud, targets)
+    returns (loss, logits) like Synchformer.forward (sync_model.py:38-70); checked against the real reference's outputs."""
+    import synchformer_amd as sa
+    from synchformer_amd import synth
+    g = np.load(GOLD / 'e2e_sync_B2.npz')
+    model = sa.instantiate_from_config(sa.sync_yaml_model_config())
+    status = model.load_state_dict(synth.make_state_dict(1337), strict=True)
+    assert not status.missing_keys and not status.unexpected_keys
+    model = model.to(gpu).eval()
+    u8, aud = _inputs(2, 14)
+    tgt = torch.from_numpy(g['targets']).to(gpu)
+    with torch.no_grad():
+        loss, logits = model(u8.to(gpu), aud.to(gpu), tgt)
+    assert (logits.cpu() - torch.from_numpy(g['logits'])).abs().max().item() < 1.5e-2
+    assert abs(loss.item() - float(g['loss'])) < 1e-2
+    # fp16 frames, as the reference's RGBToHalfToZeroOne pipeline delivers them (dataset/transforms.py:653)
+    from oracle import synchformer_cpu as O
+    with torch.no_grad():
+        _, l16 = model(O.rgb_frontend(u8).half().to(gpu), aud.to(gpu))
+    assert (l16 - logits).abs().max().item() < 2e-3
+    # a weight update must invalidate the cached engine
+    with torch.no_grad():
+        model.transformer.off_head.bias.add_(1.0)
+        _, l2 = model(u8.to(gpu), aud.to(gpu))
+    assert (l2 - logits - 1.0).abs().max().item() < 1e-4
