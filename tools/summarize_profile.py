@@ -1,0 +1,61 @@
+"""Condense a tools/profile_bench.sh output directory into the small files kept under profiles/.
+    python tools/summarize_profile.py gpurun_out/prof_r01 profiles/r01_bench"""
+import collections
+import csv
+import json
+import shutil
+import sys
+from pathlib import Path
+
+src, dst = Path(sys.argv[1]), Path(sys.argv[2])
+dst.parent.mkdir(parents=True, exist_ok=True)
+shutil.copy(src / 'stats' / 'stats_kernel_stats.csv', f'{dst}_kernel_stats.csv')
+
+
+def short(name):
+    name = name.replace('void ', '')
+    return name.split('(')[0][:110]
+
+
+pmc = collections.defaultdict(lambda: collections.defaultdict(float))
+calls = collections.Counter()
+for d in sorted(src.glob('pmc_*')):
+    if not d.is_dir():
+        continue
+    f = d / f'{d.name[4:]}_counter_collection.csv'
+    seen = set()
+    for r in csv.DictReader(open(f)):
+        k = short(r['Kernel_Name'])
+        pmc[k][r['Counter_Name']] += float(r['Counter_Value'])
+        if d.name == 'pmc_sq' and (r['Dispatch_Id'], k) not in seen:
+            seen.add((r['Dispatch_Id'], k))
+            calls[k] += 1
+stats = list(csv.DictReader(open(src / 'stats' / 'stats_kernel_stats.csv')))
+bench = None
+for line in open(src / 'stats.log'):
+    if line.startswith('{"metric"'):
+        bench = json.loads(line)
+lines = [f'# rocprofv3 summary - {dst.name}', '',
+         'Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing`',
+         '(PMC counters from separate `--pmc` passes of the same command; 3 forward passes x 16 clips in every pass).', '']
+if bench:
+    lines += [f'bench line under the profiler: {bench["value"]} clips/s, {bench["ms_per_step"]} ms/step', '']
+lines += ['| kernel | calls | total ms | avg us | % |', '|---|---|---|---|---|']
+for r in stats[:14]:
+    lines.append(f'| `{short(r["Name"])}` | {r["Calls"]} | {float(r["TotalDurationNs"]) / 1e6:.1f} | {float(r["AverageNs"]) / 1e3:.1f} | {float(r["Percentage"]):.1f} |')
+lines += ['', 'PMC per kernel (summed over all dispatches of the run, then per launch).  FETCH_SIZE/WRITE_SIZE are in KiB as rocprofv3',
+          'reports them; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md §HBM) - the `fetch x2` column',
+          'applies that correction.  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD x 256 CU x GRBM_GUI_ACTIVE/8).', '',
+          '| kernel | launches | fetch MiB/launch (x2) | write MiB/launch | MFMA busy % | wait_any % | L2 hit % | LDS bank-conflict % |', '|---|---|---|---|---|---|---|---|']
+for k, c in sorted(pmc.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE', 0))[:9]:
+    n = max(calls[k], 1)
+    fetch = c.get('FETCH_SIZE', 0) * 2 / 1024 / n
+    write = c.get('WRITE_SIZE', 0) / 1024 / n
+    gui = c.get('GRBM_GUI_ACTIVE', 0) / 8
+    mfma = 100 * c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (1024 * gui) if gui else 0
+    wait = 100 * c.get('SQ_WAIT_ANY', 0) / c['SQ_WAVE_CYCLES'] if c.get('SQ_WAVE_CYCLES') else 0
+    hit = 100 * c.get('TCC_HIT_sum', 0) / max(c.get('TCC_HIT_sum', 0) + c.get('TCC_MISS_sum', 0), 1)
+    bank = 100 * c.get('SQ_LDS_BANK_CONFLICT', 0) / max(c.get('SQ_LDS_IDX_ACTIVE', 0), 1)
+    lines.append(f'| `{k[:70]}` | {n} | {fetch:.0f} | {write:.0f} | {mfma:.1f} | {wait:.1f} | {hit:.1f} | {bank:.1f} |')
+Path(f'{dst}_summary.md').write_text('\n'.join(lines) + '\n')
+print('\n'.join(lines))
