@@ -49,35 +49,38 @@ __global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t to
   unpack8(*reinterpret_cast<const uint4*>(p.q + (first + (int64_t)qtok * p.tok_stride) * p.ld + col), qf);
   const int has_cls = p.cls_row >= 0 ? 1 : 0;
   const int nk = p.n_tok + has_cls;
+  // all 2 x 9 key/value loads are issued before the first use (one memory round trip per wave)
+  uint4 kraw[9], vraw[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int jj = j < nk ? j : nk - 1;
+    const int64_t row = (has_cls && jj == 0) ? seq_base + p.cls_row : first + (int64_t)(jj - has_cls) * p.tok_stride;
+    kraw[j] = *reinterpret_cast<const uint4*>(p.k + row * p.ld + col);
+    vraw[j] = *reinterpret_cast<const uint4*>(p.v + row * p.ld + col);
+  }
+  const float sc = p.scale * 1.44269504088896f;                 // softmax in base 2: exp(x) = exp2(x * log2 e)
   float s[9];
   float m = -INFINITY;
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
-    s[j] = -INFINITY;
-    if (j < nk) {
-      const int64_t krow = (has_cls && j == 0) ? seq_base + p.cls_row : first + (int64_t)(j - has_cls) * p.tok_stride;
-      float kf[8];
-      unpack8(*reinterpret_cast<const uint4*>(p.k + krow * p.ld + col), kf);
-      float d = 0.f;
+    float kf[8];
+    unpack8(kraw[j], kf);
+    float d = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) d += qf[e] * kf[e];
-      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-      s[j] = d * p.scale;
-      m = fmaxf(m, s[j]);
-    }
+    for (int e = 0; e < 8; ++e) d += qf[e] * kf[e];
+    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+    s[j] = j < nk ? d * sc : -INFINITY;
+    m = fmaxf(m, s[j]);
   }
   float l = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
-    if (j < nk) {
-      const float e = __expf(s[j] - m);
-      l += e;
-      const int64_t vrow = (has_cls && j == 0) ? seq_base + p.cls_row : first + (int64_t)(j - has_cls) * p.tok_stride;
-      float vf[8];
-      unpack8(*reinterpret_cast<const uint4*>(p.v + vrow * p.ld + col), vf);
+    const float e = exp2f(s[j] - m);                             // 0 for the masked tail (s = -inf)
+    l += e;
+    float vf[8];
+    unpack8(vraw[j], vf);
 #pragma unroll
-      for (int t = 0; t < 8; ++t) o[t] += e * vf[t];
-    }
+    for (int t = 0; t < 8; ++t) o[t] += e * vf[t];
   }
   if (qi < p.n_tok) {
     const float inv = 1.0f / l;
@@ -180,12 +183,16 @@ __global__ __launch_bounds__(256) void attn_cls64_kernel(ClsArgs p) {
 // the V^T fragments are read from LDS with the same permutation (two 8-byte reads per fragment).
 // ======================================================================================================
 #define ATT_MAX_KT 13            // 13 x 16 = 208 keys / queries max
-#define ATT_VT_LD 232            // V^T row stride in keys (bf16): 464 B, conflict-free ds_read_b64 / ds_write_b32
+#define ATT_VT_LD 228            // V^T row stride in keys (bf16): 456 B = 114 dwords; 114 mod 32 = 18 -> the 16-lane groups
+                                 // of the (compiler-merged) ds_read2_b64 fragment reads cover all 32 banks exactly once
+#ifndef SF_ATT_ABL
+#define SF_ATT_ABL 0             // tools/ablate_attention.sh only: 1 skip stores, 2 skip P V, 4 skip softmax
+#endif
 
 template <int D>
 struct AttLds {
   static constexpr int K_LD = (D == 64) ? 128 : (D * 2 + 16);   // bytes per K row (D=64: XOR-swizzled 128 B rows)
-  static constexpr int K_BYTES = 224 * K_LD;
+  static constexpr int K_BYTES = 208 * K_LD;
   static constexpr int VT_BYTES = D * ATT_VT_LD * 2;
   static constexpr int TOTAL = K_BYTES + VT_BYTES;
 };
@@ -196,7 +203,7 @@ __device__ __forceinline__ int k_lds_off(int row, int chunk) {   // byte offset 
   return row * AttLds<D>::K_LD + (chunk << 4);
 }
 
-template <int D>
+template <int D, int NKT>
 __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_lds = smem;
@@ -210,7 +217,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
   const int64_t first = seq_base + p.row0 + (int64_t)g * p.group_stride;
   const int has_cls = p.cls_row >= 0 ? 1 : 0;
   const int nk = p.n_tok + has_cls, nq = p.n_tok;
-  const int nkt = (nk + 15) >> 4, nqt = (nq + 15) >> 4;
+  constexpr int nkt = NKT;                                       // key tiles (host guarantees ceil(nk/16) == NKT)
+  const int nqt = (nq + 15) >> 4;
   const int hcol = head * D;
   constexpr int CH = D / 8;          // 16-byte chunks per row
 
@@ -218,68 +226,99 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     return (has_cls && j == 0) ? seq_base + p.cls_row : first + (int64_t)(j - has_cls) * p.tok_stride;
   };
 
-  // ---- stage K: rows [0, nkt*16) (rows >= nk zero-filled) ------------------------------------------------
-  for (int idx = tid; idx < nkt * 16 * CH; idx += 256) {
-    const int row = idx / CH, ch = idx - row * CH;
-    uint4 val = make_uint4(0, 0, 0, 0);
-    if (row < nk) val = *reinterpret_cast<const uint4*>(p.k + key_row(row) * p.ld + hcol + ch * 8);
-    *reinterpret_cast<uint4*>(k_lds + k_lds_off<D>(row, ch)) = val;
+  // ---- all global loads of this workgroup are issued up front (Q fragments of this wave's query tiles, then the
+  // K rows and V row-pairs this thread stages), THEN written to LDS: one memory latency per workgroup instead of one per
+  // loop iteration (the first version's runtime-trip-count staging loops serialised load -> wait -> ds_write).
+  const int fr = lane & 15, fg = lane >> 4;
+  constexpr int MAXQ = (NKT + 3) / 4;                             // query tiles per wave (nq <= nk)
+  bf16x8 qf[MAXQ][D / 32];
+#pragma unroll
+  for (int t = 0; t < MAXQ; ++t) {
+    const int qt = wave + 4 * t;
+    int qi = qt * 16 + fr; if (qi > nq - 1) qi = nq - 1;          // clamp (also for tiles beyond nqt: harmless reload)
+    const bf16_t* qrow = p.q + (first + (int64_t)qi * p.tok_stride) * p.ld + hcol;
+#pragma unroll
+    for (int ks = 0; ks < D / 32; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 32 + fg * 8);
   }
-  // ---- stage V^T: vt[d][key], written as dwords holding keys (2*pp, 2*pp+1); keys in [nk, 32*ceil(nkt/2)) = 0 --
+  constexpr int K_IT = (NKT * 16 * CH + 255) / 256;               // 16-B K chunks per thread
+  uint4 kreg[K_IT];
+#pragma unroll
+  for (int it = 0; it < K_IT; ++it) {
+    const int idx = tid + it * 256, row = idx / CH, ch = idx - row * CH;
+    kreg[it] = make_uint4(0, 0, 0, 0);
+    if (row < nk) kreg[it] = *reinterpret_cast<const uint4*>(p.k + key_row(row) * p.ld + hcol + ch * 8);
+  }
+  // V^T: vt[d][key] written as dwords holding keys (2*pp, 2*pp+1); 32 consecutive pairs per half-wave -> conflict-free
+  // b32 stores; (pair, chunk) tasks: chunk = (wave*2 + half) + 8*c, pair = pp_l + 32*b
+  const int pp_l = lane & 31, half = lane >> 5;
+  constexpr int V_PB = (((NKT + 1) / 2) * 16 + 31) / 32;          // pair blocks (<= 4), CH/8 chunk rounds
+  constexpr int V_CR = (CH + 7) / 8;
+  uint4 vreg[V_PB][V_CR][2];
+#pragma unroll
+  for (int b = 0; b < V_PB; ++b)
+#pragma unroll
+    for (int c = 0; c < V_CR; ++c) {
+      const int pp = pp_l + 32 * b, ch = wave * 2 + half + 8 * c;
+      vreg[b][c][0] = make_uint4(0, 0, 0, 0); vreg[b][c][1] = make_uint4(0, 0, 0, 0);
+      if (ch < CH) {
+        if (2 * pp < nk) vreg[b][c][0] = *reinterpret_cast<const uint4*>(p.v + key_row(2 * pp) * p.ld + hcol + ch * 8);
+        if (2 * pp + 1 < nk) vreg[b][c][1] = *reinterpret_cast<const uint4*>(p.v + key_row(2 * pp + 1) * p.ld + hcol + ch * 8);
+      }
+    }
+#pragma unroll
+  for (int it = 0; it < K_IT; ++it) {
+    const int idx = tid + it * 256, row = idx / CH, ch = idx - row * CH;
+    if (row < nkt * 16) *reinterpret_cast<uint4*>(k_lds + k_lds_off<D>(row, ch)) = kreg[it];
+  }
   {
-    const int npairs = ((nkt + 1) >> 1) * 16;            // key pairs to cover all 32-key PV steps
-    const int pp_l = lane & 31, half = lane >> 5;        // 32 consecutive pairs per half-wave -> conflict-free b32 stores
-    for (int pbase = 0; pbase < npairs; pbase += 32) {
-      const int pp = pbase + pp_l;
-      for (int ch = wave * 2 + half; ch < CH; ch += 8) {
-        if (pp < npairs) {
-          uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
-          if (2 * pp < nk) v0 = *reinterpret_cast<const uint4*>(p.v + key_row(2 * pp) * p.ld + hcol + ch * 8);
-          if (2 * pp + 1 < nk) v1 = *reinterpret_cast<const uint4*>(p.v + key_row(2 * pp + 1) * p.ld + hcol + ch * 8);
-          const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, b[4] = {v1.x, v1.y, v1.z, v1.w};
+    const int npairs = ((nkt + 1) >> 1) * 16;                     // key pairs covering all 32-key PV steps (zero beyond nk)
+#pragma unroll
+    for (int b = 0; b < V_PB; ++b)
+#pragma unroll
+      for (int c = 0; c < V_CR; ++c) {
+        const int pp = pp_l + 32 * b, ch = wave * 2 + half + 8 * c;
+        if (ch < CH && pp < npairs) {
+          const uint32_t a4[4] = {vreg[b][c][0].x, vreg[b][c][0].y, vreg[b][c][0].z, vreg[b][c][0].w};
+          const uint32_t b4[4] = {vreg[b][c][1].x, vreg[b][c][1].y, vreg[b][c][1].z, vreg[b][c][1].w};
           uint32_t* dst = reinterpret_cast<uint32_t*>(vt_lds) + pp;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            dst[(ch * 8 + 2 * e) * (ATT_VT_LD / 2)] = (a[e] & 0xffffu) | (b[e] << 16);
-            dst[(ch * 8 + 2 * e + 1) * (ATT_VT_LD / 2)] = (a[e] >> 16) | (b[e] & 0xffff0000u);
+            dst[(ch * 8 + 2 * e) * (ATT_VT_LD / 2)] = (a4[e] & 0xffffu) | (b4[e] << 16);
+            dst[(ch * 8 + 2 * e + 1) * (ATT_VT_LD / 2)] = (a4[e] >> 16) | (b4[e] & 0xffff0000u);
           }
         }
       }
-    }
   }
   __syncthreads();
 
-  const int fr = lane & 15, fg = lane >> 4;
-  for (int qt = wave; qt < nqt; qt += 4) {
-    // ---- Q fragments (B operand of S^T): query qt*16 + fr, dims ks*32 + fg*8 .. +7 ------------------------
-    int qi = qt * 16 + fr; if (qi > nq - 1) qi = nq - 1;
-    const bf16_t* qrow = p.q + (first + (int64_t)qi * p.tok_stride) * p.ld + hcol;
-    bf16x8 qf[D / 32];
 #pragma unroll
-    for (int ks = 0; ks < D / 32; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 32 + fg * 8);
+  for (int t = 0; t < MAXQ; ++t) {
+    const int qt = wave + 4 * t;
+    if (qt >= nqt) break;
 
     // ---- S^T tiles -------------------------------------------------------------------------------------
-    f32x4 s[ATT_MAX_KT];
+    f32x4 s[NKT];
 #pragma unroll
-    for (int kt = 0; kt < ATT_MAX_KT; ++kt) {
+    for (int kt = 0; kt < NKT; ++kt) {
       s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (kt < nkt) {
+      {
 #pragma unroll
         for (int ks = 0; ks < D / 32; ++ks) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + k_lds_off<D>(kt * 16 + fr, ks * 4 + fg));
-          s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+          s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[kt], 0, 0, 0);
         }
       }
     }
-    // ---- softmax over keys for query column (lane & 15) ---------------------------------------------------
+    // ---- softmax (base 2, scale folded with log2 e) over keys for query column (lane & 15) ---------------------
+    const float sc2 = p.scale * 1.44269504088896f;
     float m = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < ATT_MAX_KT; ++kt)
-      if (kt < nkt) {
+    for (int kt = 0; kt < NKT; ++kt)
+      {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + fg * 4 + r;
-          const float v = (key < nk) ? s[kt][r] * p.scale : -INFINITY;
+          const float v = (key < nk) ? s[kt][r] * sc2 : -INFINITY;
           s[kt][r] = v;
           m = fmaxf(m, v);
         }
@@ -287,11 +326,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
     float l = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < ATT_MAX_KT; ++kt)
-      if (kt < nkt) {
+    for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float e = __expf(s[kt][r] - m); s[kt][r] = e; l += e; }
-      }
+      for (int r = 0; r < 4; ++r) { const float e = (SF_ATT_ABL & 4) ? s[kt][r] : exp2f(s[kt][r] - m); s[kt][r] = e; l += e; }
+    }
     l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
     const float linv = 1.0f / l;
 
@@ -300,14 +338,14 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 #pragma unroll
     for (int dt = 0; dt < D / 16; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kk = 0; kk < (ATT_MAX_KT + 1) / 2; ++kk) {
-      if (2 * kk < nkt) {
+    for (int kk = 0; kk < ((SF_ATT_ABL & 2) ? 1 : (NKT + 1) / 2); ++kk) {
+      {
         // A operand: slots 0..3 <- tile 2kk regs, slots 4..7 <- tile 2kk+1 regs (zero beyond nkt)
         union { bf16x8 v; uint32_t u[4]; } pa;
         pa.u[0] = pack_bf2(s[2 * kk][0], s[2 * kk][1]);
         pa.u[1] = pack_bf2(s[2 * kk][2], s[2 * kk][3]);
-        if (2 * kk + 1 < ATT_MAX_KT && 2 * kk + 1 < nkt) {
-          const int t1 = (2 * kk + 1 < ATT_MAX_KT) ? 2 * kk + 1 : 0;
+        if (2 * kk + 1 < NKT) {
+          const int t1 = (2 * kk + 1 < NKT) ? 2 * kk + 1 : 0;
           pa.u[2] = pack_bf2(s[t1][0], s[t1][1]);
           pa.u[3] = pack_bf2(s[t1][2], s[t1][3]);
         } else { pa.u[2] = 0; pa.u[3] = 0; }
@@ -317,27 +355,30 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
           union { bf16x8 v; uint2 h[2]; } vb;
           vb.h[0] = *reinterpret_cast<const uint2*>(vrow);
           vb.h[1] = *reinterpret_cast<const uint2*>(vrow + 16);
-          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa.v, vb.v, o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb.v, pa.v, o[dt], 0, 0, 0);   // O^T tile: (d, query)
         }
       }
     }
-    // ---- normalise + store: o[dt][r] is (query qt*16 + fg*4 + r, dim dt*16 + fr) ---------------------------
+    // ---- normalise + store.  The product was formed transposed (A = V^T fragment, B = P - the same registers serve
+    // as either operand), so o[dt][r] is (dim dt*16 + fg*4 + r, query qt*16 + fr): each lane owns 4 consecutive dims of
+    // ITS query row -> its own 1/l, and one 8-byte store per 16-dim tile.
+    const int qo = qt * 16 + fr;
+    if ((SF_ATT_ABL & 1) ? (linv == 1.2345e30f) : (qo < nq)) {
+      bf16_t* orow = p.out + (first + (int64_t)qo * p.tok_stride) * p.ldo + hcol + fg * 4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qo = qt * 16 + fg * 4 + r;
-      const float inv = __shfl(linv, fg * 4 + r, 64);        // lane (fg*4+r) holds query column fg*4+r of this tile
-      if (qo < nq) {
-        bf16_t* orow = p.out + (first + (int64_t)qo * p.tok_stride) * p.ldo + hcol + fr;
-#pragma unroll
-        for (int dt = 0; dt < D / 16; ++dt) orow[dt * 16] = f2bf(o[dt][r] * inv);
+      for (int dt = 0; dt < D / 16; ++dt) {
+        uint2 w;
+        w.x = pack_bf2(o[dt][0] * linv, o[dt][1] * linv);
+        w.y = pack_bf2(o[dt][2] * linv, o[dt][3] * linv);
+        *reinterpret_cast<uint2*>(orow + dt * 16) = w;
       }
     }
   }
 }
 
-template <int D>
+template <int D, int NKT>
 static int launch_attn_mfma(const AttnArgs& a, int64_t n_seq, hipStream_t s) {
-  auto kern = attn_mfma_kernel<D>;
+  auto kern = attn_mfma_kernel<D, NKT>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AttLds<D>::TOTAL);
@@ -348,6 +389,25 @@ static int launch_attn_mfma(const AttnArgs& a, int64_t n_seq, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), AttLds<D>::TOTAL, s, a);
   SF_LAUNCH_CHECK();
   return 0;
+}
+
+template <int D>
+static int dispatch_attn_mfma(const AttnArgs& a, int64_t n_seq, int nkt, hipStream_t s) {
+  switch (nkt) {   // exact key-tile counts keep the kernel free of per-tile guards
+    case 1: return launch_attn_mfma<D, 1>(a, n_seq, s);
+    case 2: return launch_attn_mfma<D, 2>(a, n_seq, s);
+    case 3: return launch_attn_mfma<D, 3>(a, n_seq, s);
+    case 4: return launch_attn_mfma<D, 4>(a, n_seq, s);
+    case 5: return launch_attn_mfma<D, 5>(a, n_seq, s);      // AST: 74 tokens
+    case 6: return launch_attn_mfma<D, 6>(a, n_seq, s);
+    case 7: return launch_attn_mfma<D, 7>(a, n_seq, s);
+    case 8: return launch_attn_mfma<D, 8>(a, n_seq, s);
+    case 9: return launch_attn_mfma<D, 9>(a, n_seq, s);
+    case 10: return launch_attn_mfma<D, 10>(a, n_seq, s);
+    case 11: return launch_attn_mfma<D, 11>(a, n_seq, s);
+    case 12: return launch_attn_mfma<D, 12>(a, n_seq, s);    // syncability: 184 tokens
+    default: return launch_attn_mfma<D, 13>(a, n_seq, s);    // space attention 197 keys, sync transformer 198 tokens
+  }
 }
 
 extern "C" int sf_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ldo,
@@ -372,7 +432,8 @@ extern "C" int sf_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, i
     SF_LAUNCH_CHECK();
     return 0;
   }
-  return head_dim == 64 ? launch_attn_mfma<64>(a, n_seq, s) : launch_attn_mfma<96>(a, n_seq, s);
+  const int nkt = (n_tok + (cls_row >= 0 ? 1 : 0) + 15) / 16;
+  return head_dim == 64 ? dispatch_attn_mfma<64>(a, n_seq, nkt, s) : dispatch_attn_mfma<96>(a, n_seq, nkt, s);
 }
 
 extern "C" int sf_attention_cls(const bf16_t* q, int64_t q_seq_rows, int q_row, const bf16_t* k, const bf16_t* v,
