@@ -94,6 +94,15 @@ int sf_attention_cls(const uint16_t* q, int64_t q_seq_rows, int q_row, const uin
                      int64_t kv_seq_rows, int kv_row0, int n_keys, uint16_t* out, int64_t ldo, int64_t out_seq_rows,
                      int out_row, int64_t n_seq, int heads, int head_dim, float scale, void* stream);
 
+/* Audio front-end (dataset/transforms.py:815-889; configs/sync.yaml:183-202): wave fp32 (n_seg, n_samples) ->
+ * out fp32 (n_seg, n_mels, pad_to) = ((log(mel(|STFT|^2) + 1e-6), right-padded with 0.0) - mean) / (2 std), the
+ * (S, 1, F, Ta) layout Synchformer.forward receives.  STFT: n_fft 1024, periodic Hann(400) centred in the frame, hop 160,
+ * center/reflect.  tw_cos/tw_sin: (400, 513) twiddles with the window folded in; fb: (513, n_mels) HTK mel filterbank;
+ * fb_lo/fb_hi: per-filter non-zero bin range; power_ws: fp32 workspace (n_seg * min(n_samples/hop+1, pad_to) * 513). */
+int sf_mel_frontend(const float* wave, int64_t n_seg, int n_samples, int hop, const float* tw_cos, const float* tw_sin,
+                    const float* fb, const int* fb_lo, const int* fb_hi, int n_mels, float* power_ws, float* out, int pad_to,
+                    float mean, float std, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,7 @@ SIGNATURES = {
     'sf_im2col_video': [_ptr, _i32, _ptr, _i64, _ptr],
     'sf_im2col_spec': [_ptr, _ptr, _i64, _i32, _i32, _ptr],
     'sf_attention': [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _ptr],
+    'sf_mel_frontend': [_ptr, _i64, _i32, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _i32, _f32, _f32, _ptr],
     'sf_attention_cls': [_ptr, _i64, _i32, _ptr, _ptr, _i64, _i64, _i32, _i32, _ptr, _i64, _i64, _i32, _i64, _i32, _i32, _f32, _ptr],
 }
 _RESTYPES = {'sf_last_error': C.c_char_p, 'sf_build_info': C.c_char_p, 'sf_gemm_force_config': None}

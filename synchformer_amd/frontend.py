@@ -1,0 +1,67 @@
+"""Device front-ends in front of Synchformer.forward.
+
+`MelFrontend` turns 16 kHz waveform segments into the normalised log-mel tensors the model consumes, on the GPU, via
+`sf_mel_frontend` (two fp32 kernels).  The tables it uploads - window-folded DFT twiddles and the HTK mel filterbank -
+are constants of the transform (torchaudio's documented MelSpectrogram defaults, dataset/transforms.py:815-823 with
+configs/sync.yaml:183-188), computed once here in float64.  The RGB front-end (a27) needs no module: uint8 frames are
+normalised inside `sf_im2col_video`.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+AST_MEAN, AST_STD = -4.2677393, 4.5689974        # configs/sync.yaml:196-197 (AudioNormalizeAST)
+
+
+def mel_filterbank(n_freqs=513, f_min=0.0, f_max=8000.0, n_mels=128, sample_rate=16000) -> np.ndarray:
+    """HTK-scale triangular filterbank without area normalisation, (n_freqs, n_mels) float32."""
+    freqs = np.linspace(0.0, sample_rate // 2, n_freqs)
+    to_mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)
+    pts = 700.0 * (10.0 ** (np.linspace(to_mel(f_min), to_mel(f_max), n_mels + 2) / 2595.0) - 1.0)
+    width = np.diff(pts)
+    slopes = pts[None, :] - freqs[:, None]
+    fb = np.maximum(0.0, np.minimum(-slopes[:, :-2] / width[:-1], slopes[:, 2:] / width[1:]))
+    return fb.astype(np.float32)
+
+
+class MelFrontend:
+    def __init__(self, device, sample_rate=16000, n_mels=128, pad_to=66, mean=AST_MEAN, std=AST_STD):
+        self.dev = torch.device(device)
+        if self.dev.type != 'cuda':
+            raise RuntimeError('MelFrontend runs on a HIP device only (no CPU fallback)')
+        self.n_mels, self.pad_to, self.mean, self.std, self.hop = n_mels, pad_to, float(mean), float(std), 160
+        win, n_fft, bins = 400, 1024, 513
+        n = np.arange(win)
+        hann = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / win)                      # periodic Hann
+        ang = 2.0 * np.pi * np.outer((n_fft - win) // 2 + n, np.arange(bins)) / n_fft
+        self.tw_cos = torch.from_numpy((hann[:, None] * np.cos(ang)).astype(np.float32)).to(self.dev)
+        self.tw_sin = torch.from_numpy((-hann[:, None] * np.sin(ang)).astype(np.float32)).to(self.dev)
+        fb = mel_filterbank(bins, 0.0, sample_rate / 2, n_mels, sample_rate)
+        nz = fb > 0
+        lo = np.where(nz.any(0), nz.argmax(0), 0).astype(np.int32)
+        hi = np.where(nz.any(0), bins - nz[::-1].argmax(0), 0).astype(np.int32)
+        self.fb = torch.from_numpy(fb).to(self.dev)
+        self.fb_lo, self.fb_hi = torch.from_numpy(lo).to(self.dev), torch.from_numpy(hi).to(self.dev)
+        self._ws = None
+
+    def __call__(self, wave: torch.Tensor) -> torch.Tensor:
+        """wave (..., n_samples) fp32 on device -> (..., 1, n_mels, pad_to) fp32 (PermuteStreams 'S F T -> S 1 F T')."""
+        if not wave.is_cuda:
+            raise RuntimeError('MelFrontend: expected a HIP device tensor (no CPU fallback exists)')
+        lead, n = wave.shape[:-1], wave.shape[-1]
+        w = wave.reshape(-1, n).to(torch.float32).contiguous()
+        n_seg = w.shape[0]
+        frames = min(n // self.hop + 1, self.pad_to)
+        need = n_seg * frames * 513
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, device=self.dev, dtype=torch.float32)
+        out = torch.empty(n_seg, self.n_mels, self.pad_to, device=self.dev, dtype=torch.float32)
+        rc = _lib.load().sf_mel_frontend(w.data_ptr(), n_seg, n, self.hop, self.tw_cos.data_ptr(), self.tw_sin.data_ptr(),
+                                         self.fb.data_ptr(), self.fb_lo.data_ptr(), self.fb_hi.data_ptr(), self.n_mels,
+                                         self._ws.data_ptr(), out.data_ptr(), self.pad_to, self.mean, self.std,
+                                         torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, 'sf_mel_frontend')
+        return out.reshape(*lead, 1, self.n_mels, self.pad_to)
