@@ -46,6 +46,14 @@ int sf_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
                  int c_dtype, int64_t ldc, const int64_t* c_map, const float* R, int64_t ldr, const int64_t* r_map,
                  int epilogue, int64_t M, int64_t N, int64_t K, void* stream);
 
+/* Strided-batched small GEMM (train step: attention backward).  For b0 < batch_outer, b1 < batch_inner:
+ * C[b0,b1] (M x N) = A[b0,b1] (M x K) * W[b0,b1]^T (N x K) + bias, X[b0,b1] = X + b0*sX0 + b1*sX1 (element strides).
+ * K % 32 == 0 (zero-pad the contraction dimension); any M, N; C bf16|fp32.  Backward of the matmuls at
+ * modules/transformer.py:67-70. */
+int sf_gemm_bf16_batched(const uint16_t* A, int64_t lda, int64_t sA0, int64_t sA1, const uint16_t* W, int64_t ldw, int64_t sW0,
+                         int64_t sW1, const float* bias, void* C, int c_dtype, int64_t ldc, int64_t sC0, int64_t sC1, int64_t M,
+                         int64_t N, int64_t K, int batch_outer, int batch_inner, void* stream);
+
 /* Tuning / test hook: force the GEMM tile configuration for subsequent sf_gemm_bf16 calls of this process
  * (-1 = automatic choice by shape, 0 = 128x128x64 / 4 waves, 1 = 256x256x64 / 8 waves). */
 void sf_gemm_force_config(int cfg);
@@ -102,6 +110,41 @@ int sf_attention_cls(const uint16_t* q, int64_t q_seq_rows, int q_row, const uin
 int sf_mel_frontend(const float* wave, int64_t n_seg, int n_samples, int hop, const float* tw_cos, const float* tw_sin,
                     const float* fb, const int* fb_lo, const int* fb_hi, int n_mels, float* power_ws, float* out, int pad_to,
                     float mean, float std, void* stream);
+
+/* ---- Stage-2 train step (scripts/train_sync.py:153-237, train_utils.py:373-386): backward of vproj/aproj + the sync
+ * transformer and the optimizer.  GEMM-shaped work reuses sf_gemm_bf16 / sf_gemm_bf16_batched on transposed copies. ---- */
+
+/* out[b][c][r] = in[b][r][c] (bf16), columns r in [R, R_pad) zero-filled; two-level batch strides in elements. */
+int sf_transpose_bf16(const uint16_t* in, int64_t ld_in, int64_t sI0, int64_t sI1, uint16_t* out, int64_t ld_out, int64_t sO0,
+                      int64_t sO1, int R, int C, int R_pad, int batch_outer, int batch_inner, void* stream);
+/* y = bf16(scale * x) for a (rows, cols) fp32 matrix, cols % 4 == 0. */
+int sf_cast_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int64_t rows, int cols, float scale, void* stream);
+/* P[r,:L] = softmax(scale * S[r,:L]) (bf16), P[r,L:L_pad] = 0; L <= 256 (attention probabilities, modules/transformer.py:67-69). */
+int sf_softmax_rows(const float* S, int64_t lds, uint16_t* P, int64_t ldp, int64_t rows, int L, int L_pad, float scale, void* stream);
+/* dS = scale * P * (dP - rowsum(P * dP)) (bf16, zero-padded): backward of the softmax + 1/sqrt(d) scaling. */
+int sf_softmax_bwd_rows(const uint16_t* P, int64_t ldp, const float* dP, int64_t lddp, uint16_t* dS, int64_t ldds, int64_t rows, int L,
+                        int L_pad, float scale, void* stream);
+/* LayerNorm(768) backward: dx[(dx_map)] (=|+=) ..., dgamma / dbeta (=|+=) column sums; statistics recomputed from x.
+ * workspace: fp32, 2 * 768 * ceil(rows / 4) elements. */
+int sf_layernorm768_bwd(const float* x, int64_t ldx, const int64_t* x_map, const float* gamma, const float* dy, int64_t lddy,
+                        const int64_t* dy_map, float* dx, int64_t lddx, const int64_t* dx_map, int accumulate_dx, float* dgamma,
+                        float* dbeta, int accumulate_dparams, float* workspace, int64_t rows, float eps, void* stream);
+/* out[c] (=|+=) sum_r x[r, c] (bias gradients); x fp32|bf16; workspace fp32 cols * ceil(rows / 64). */
+int sf_colsum(const void* x, int x_dtype, int64_t ldx, int64_t rows, int cols, float* out, int accumulate, float* workspace, void* stream);
+/* out[l, c] (=|+=) sum_b x[b*L + l, c]: gradient of the broadcast positional / token table. */
+int sf_seqsum(const float* x, int64_t ldx, int n_seq, int L, int cols, float* out, int accumulate, void* stream);
+/* act = gelu_erf(pre) / dpre = dact * gelu_erf'(pre) on bf16 pre-activations (n elements, n % 4 == 0). */
+int sf_gelu_fwd(const uint16_t* pre, uint16_t* act, int64_t n, void* stream);
+int sf_gelu_bwd(const uint16_t* pre, const float* dact, uint16_t* dpre, int64_t n, void* stream);
+/* loss = mean cross-entropy of (B, C) logits vs int64 targets (sync_model.py:95-96); dlogits (optional) scaled by grad_scale / B. */
+int sf_cross_entropy(const float* logits, int64_t ld, const int64_t* targets, int B, int C, float* loss, float* dlogits, int64_t ldd,
+                     float grad_scale, void* stream);
+/* norm_out[0] = ||g||_2 of a flat fp32 buffer (deterministic two-stage; workspace fp32 1024). */
+int sf_grad_norm(const float* g, int64_t n, float* norm_out, float* workspace, void* stream);
+/* clip_grad_norm_(max_norm, device-resident norm) + Adam(betas, eps, no weight decay) on flat fp32 buffers; also writes the
+ * bf16 copy of the updated parameters when p_bf16 != NULL.  step >= 1 is the Adam step count (bias correction). */
+int sf_adam_clip_step(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n, const float* norm, float max_norm,
+                      float lr, float beta1, float beta2, float eps, int step, void* stream);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,7 @@ SIGNATURES = {
     'sf_last_error': [],
     'sf_build_info': [],
     'sf_gemm_bf16': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i64, _ptr, _ptr, _i64, _ptr, _i32, _i64, _i64, _i64, _ptr],
+    'sf_gemm_bf16_batched': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _ptr, _ptr, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _ptr],
     'sf_gemm_force_config': [_i32],
     'sf_layernorm768': [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i64, _ptr, _i32, _i64, _f32, _ptr],
     'sf_broadcast_rows768': [_ptr, _i64, _i64, _ptr, _i64, _i64, _ptr],
@@ -29,6 +30,18 @@ SIGNATURES = {
     'sf_im2col_spec': [_ptr, _ptr, _i64, _i32, _i32, _ptr],
     'sf_attention': [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _ptr],
     'sf_mel_frontend': [_ptr, _i64, _i32, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _i32, _f32, _f32, _ptr],
+    'sf_transpose_bf16': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _ptr],
+    'sf_cast_bf16': [_ptr, _i64, _ptr, _i64, _i64, _i32, _f32, _ptr],
+    'sf_softmax_rows': [_ptr, _i64, _ptr, _i64, _i64, _i32, _i32, _f32, _ptr],
+    'sf_softmax_bwd_rows': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i32, _i32, _f32, _ptr],
+    'sf_layernorm768_bwd': [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i32, _ptr, _ptr, _i32, _ptr, _i64, _f32, _ptr],
+    'sf_colsum': [_ptr, _i32, _i64, _i64, _i32, _ptr, _i32, _ptr, _ptr],
+    'sf_seqsum': [_ptr, _i64, _i32, _i32, _i32, _ptr, _i32, _ptr],
+    'sf_gelu_fwd': [_ptr, _ptr, _i64, _ptr],
+    'sf_gelu_bwd': [_ptr, _ptr, _ptr, _i64, _ptr],
+    'sf_cross_entropy': [_ptr, _i64, _ptr, _i32, _i32, _ptr, _ptr, _i64, _f32, _ptr],
+    'sf_grad_norm': [_ptr, _i64, _ptr, _ptr, _ptr],
+    'sf_adam_clip_step': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _f32, _f32, _f32, _f32, _f32, _i32, _ptr],
     'sf_attention_cls': [_ptr, _i64, _i32, _ptr, _ptr, _i64, _i64, _i32, _i32, _ptr, _i64, _i64, _i32, _i64, _i32, _i32, _f32, _ptr],
 }
 _RESTYPES = {'sf_last_error': C.c_char_p, 'sf_build_info': C.c_char_p, 'sf_gemm_force_config': None}

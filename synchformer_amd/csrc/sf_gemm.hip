@@ -38,6 +38,9 @@ struct GemmArgs {
   int64_t M;
   int N, K;
   uint32_t tiles_n, tiles_total;
+  // strided batch (blockIdx.y = b0 * batch_inner + b1): element offsets added to A / W / C per batch index
+  int batch_inner;
+  int64_t sA0, sA1, sW0, sW1, sC0, sC1;
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst_wave_base) {
@@ -149,6 +152,13 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES_PER_SIMD) void gemm_bf
   constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, NS = Cfg::NS, FI = Cfg::FI, FJ = Cfg::FJ, P = Cfg::PIECES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (gridDim.y > 1) {                                          // strided batch: shift the operand bases (wave-uniform)
+    const int b0 = blockIdx.y / p.batch_inner, b1 = blockIdx.y - b0 * p.batch_inner;
+    p.A += b0 * p.sA0 + b1 * p.sA1;
+    p.W += b0 * p.sW0 + b1 * p.sW1;
+    const int64_t co = b0 * p.sC0 + b1 * p.sC1;
+    p.C = OUT_BF16 ? (void*)(reinterpret_cast<bf16_t*>(p.C) + co) : (void*)(reinterpret_cast<float*>(p.C) + co);
+  }
 
   // ---- XCD-aware, bijective block -> tile remap ---------------------------------------------------------
   uint32_t vb;
@@ -569,6 +579,7 @@ typedef GemmCfg<256, 128, 2, 2, 32, 3, 2> Cfg8;   // 4 waves x (128 x 64), 72 Ki
 typedef GemmCfg<128, 256, 1, 4, 32, 3, 2> Cfg9;   // same, transposed block shape
 
 static int g_force_cfg = -1;   // tuning / test hook
+static thread_local int64_t g_batch_count = 1;   // set by sf_gemm_bf16_batched around its launch
 extern "C" void sf_gemm_force_config(int cfg) { g_force_cfg = cfg; }
 
 template <class Cfg, bool OUT_BF16, bool GELU, bool HAS_RES, bool FAST>
@@ -585,7 +596,7 @@ static int launch_gemm(GemmArgs a, hipStream_t s) {
   const int64_t total = tiles_m * a.tiles_n;
   if (total >= ((int64_t)1 << 31)) { sf_set_error("sf_gemm_bf16: too many tiles"); return -1; }
   a.tiles_total = (uint32_t)total;
-  hipLaunchKernelGGL(kern, dim3(a.tiles_total), dim3(Cfg::THREADS), Cfg::LDS, s, a);
+  hipLaunchKernelGGL(kern, dim3(a.tiles_total, a.batch_inner > 0 ? (unsigned)g_batch_count : 1u), dim3(Cfg::THREADS), Cfg::LDS, s, a);
   SF_LAUNCH_CHECK();
   return 0;
 }
@@ -627,6 +638,7 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
   a.cmap = sf_rowmap(c_map); a.rmap = sf_rowmap(r_map);
   a.M = M; a.N = (int)N; a.K = (int)K;
   a.tiles_n = 0; a.tiles_total = 0;
+  a.batch_inner = 0; a.sA0 = a.sA1 = a.sW0 = a.sW1 = a.sC0 = a.sC1 = 0;
   hipStream_t s = (hipStream_t)stream;
   const bool gelu = epilogue == SF_EPI_GELU, res = R != nullptr, obf = c_dtype == SF_BF16;
   int cfg = g_force_cfg;
@@ -651,4 +663,33 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
             return dispatch_gemm_persistent(a, obf, gelu, res, s);
     default: sf_set_error("sf_gemm_bf16: unknown tile config %d", cfg); return -1;
   }
+}
+
+// Strided-batched small GEMM: for b0 < batch_outer, b1 < batch_inner
+//     C[b0,b1] (M x N) = A[b0,b1] (M x K) * W[b0,b1]^T (N x K) (+ bias)
+// with X[b0,b1] = X + b0 * sX0 + b1 * sX1 (element strides).  K % 32 == 0 (callers zero-pad the contraction dimension),
+// any M / N.  128 x 128 x 32 tiles, 4-stage ring.  Used by the attention backward of the Stage-2 train step: per
+// (clip, head) Q K^T, dO V^T, dS K, dS^T Q, P^T dO are 198 x 198 x 96-class products inside the packed (rows, 2304)
+// projection buffers.
+extern "C" int sf_gemm_bf16_batched(const bf16_t* A, int64_t lda, int64_t sA0, int64_t sA1, const bf16_t* W, int64_t ldw,
+                                    int64_t sW0, int64_t sW1, const float* bias, void* C, int c_dtype, int64_t ldc, int64_t sC0,
+                                    int64_t sC1, int64_t M, int64_t N, int64_t K, int batch_outer, int batch_inner,
+                                    void* stream) {
+  SF_CHECK_ARG(A && W && C, "sf_gemm_bf16_batched: null pointer");
+  SF_CHECK_ARG(c_dtype == SF_BF16 || c_dtype == SF_F32, "sf_gemm_bf16_batched: c_dtype must be bf16 or f32");
+  SF_CHECK_ARG(K > 0 && (K % 32) == 0, "sf_gemm_bf16_batched: K=%lld must be a positive multiple of 32", (long long)K);
+  SF_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0 && (sA0 % 8) == 0 && (sA1 % 8) == 0 && (sW0 % 8) == 0 && (sW1 % 8) == 0,
+               "sf_gemm_bf16_batched: lda/ldw/batch strides of A and W must be multiples of 8 elements (16 B)");
+  SF_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "sf_gemm_bf16_batched: A/W must be 16-byte aligned");
+  SF_CHECK_ARG(batch_outer >= 1 && batch_inner >= 1 && (int64_t)batch_outer * batch_inner < 65536, "sf_gemm_bf16_batched: bad batch");
+  if (M <= 0 || N <= 0) return 0;
+  GemmArgs a;
+  a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.C = C; a.ldc = ldc; a.R = nullptr; a.ldr = 0;
+  a.cmap = sf_rowmap(nullptr); a.rmap = sf_rowmap(nullptr);
+  a.M = M; a.N = (int)N; a.K = (int)K; a.tiles_n = 0; a.tiles_total = 0;
+  a.batch_inner = batch_inner; a.sA0 = sA0; a.sA1 = sA1; a.sW0 = sW0; a.sW1 = sW1; a.sC0 = sC0; a.sC1 = sC1;
+  g_batch_count = (int64_t)batch_outer * batch_inner;
+  const int rc = dispatch_gemm<Cfg4>(a, c_dtype == SF_BF16, false, false, /*fast=*/false, (hipStream_t)stream);
+  g_batch_count = 1;
+  return rc;
 }

@@ -1,0 +1,416 @@
+// Kernels of the Stage-2 train step: the backward of vproj/aproj + the 3-block sync
+// transformer (the only trainable part when the extractors are frozen, scripts/train_utils.py:199-204) and the fused
+// clip + Adam update (train_utils.py:373-386, :217-226).  All GEMM-shaped backward work (dgrad, wgrad, the five products of
+// the attention backward) goes through sf_gemm_bf16 / sf_gemm_bf16_batched on (zero-padded) transposed copies; this file
+// holds the bandwidth/latency-class pieces around them.  Activations here are (B*198, 768)-sized - a few MB - so the
+// kernels favour simplicity and determinism (no atomics: column reductions are two-stage).
+#include "sf_common.h"
+#include "../../include/synchformer_hip.h"
+
+// ------------------------------------------------------------------------------------------------------
+// Batched bf16 transpose with zero padding: out[b][c][r] = in[b][r][c] for r < R, 0 for R <= r < R_pad.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, int64_t ld_in, int64_t sI0, int64_t sI1,
+                                                              bf16_t* __restrict__ out, int64_t ld_out, int64_t sO0, int64_t sO1,
+                                                              int R, int C, int R_pad, int batch_inner) {
+  __shared__ bf16_t tile[32][33];
+  const int b0 = blockIdx.z / batch_inner, b1 = blockIdx.z - b0 * batch_inner;
+  in += b0 * sI0 + b1 * sI1;
+  out += b0 * sO0 + b1 * sO1;
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + i * 8, c = c0 + tx;
+    tile[ty + i * 8][tx] = (r < R && c < C) ? in[(int64_t)r * ld_in + c] : (bf16_t)0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + i * 8, r = r0 + tx;
+    if (c < C && r < R_pad) out[(int64_t)c * ld_out + r] = tile[tx][ty + i * 8];
+  }
+}
+
+extern "C" int sf_transpose_bf16(const bf16_t* in, int64_t ld_in, int64_t sI0, int64_t sI1, bf16_t* out, int64_t ld_out, int64_t sO0,
+                                 int64_t sO1, int R, int C, int R_pad, int batch_outer, int batch_inner, void* stream) {
+  SF_CHECK_ARG(in && out, "sf_transpose_bf16: null pointer");
+  SF_CHECK_ARG(R > 0 && C > 0 && R_pad >= R && batch_outer >= 1 && batch_inner >= 1, "sf_transpose_bf16: bad shape");
+  SF_CHECK_ARG((int64_t)batch_outer * batch_inner < 65536, "sf_transpose_bf16: too many batches");
+  dim3 grid((R_pad + 31) / 32, (C + 31) / 32, batch_outer * batch_inner);
+  hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, sI0, sI1, out, ld_out, sO0, sO1, R, C,
+                     R_pad, batch_inner);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// fp32 -> bf16 cast of a (rows, cols) matrix (cols % 4 == 0), optional scale.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ y, int64_t ldy,
+                                                         int64_t rows, int cols4, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols4) return;
+  const int64_t r = i / cols4; const int c = (int)(i - r * cols4) * 4;
+  const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+  uint2 o; o.x = pack_bf2(v.x * scale, v.y * scale); o.y = pack_bf2(v.z * scale, v.w * scale);
+  *reinterpret_cast<uint2*>(y + r * ldy + c) = o;
+}
+
+extern "C" int sf_cast_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int64_t rows, int cols, float scale, void* stream) {
+  SF_CHECK_ARG(x && y && (cols % 4) == 0 && (ldx % 4) == 0 && (ldy % 4) == 0, "sf_cast_bf16: bad arguments");
+  const int64_t n = rows * (cols / 4);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, cols / 4,
+                     scale);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Row softmax (attention probabilities recomputed for the backward): P[r, :L] = softmax(S[r, :L]) as bf16, P[r, L:L_pad] = 0.
+// One wave per row, L <= 256; `scale` (1/sqrt(d)) is applied to S first.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int64_t lds_, bf16_t* __restrict__ P, int64_t ldp,
+                                                            int64_t rows, int L, int L_pad, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float v[4], m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; v[i] = c < L ? S[r * lds_ + c] * scale : -INFINITY; m = fmaxf(m, v[i]); }
+  m = wave_max(m);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = __expf(v[i] - m); s += v[i]; }
+  const float inv = 1.0f / wave_sum(s);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; if (c < L_pad) P[r * ldp + c] = c < L ? f2bf(v[i] * inv) : (bf16_t)0; }
+}
+
+extern "C" int sf_softmax_rows(const float* S, int64_t lds_, uint16_t* P, int64_t ldp, int64_t rows, int L, int L_pad, float scale, void* stream) {
+  SF_CHECK_ARG(S && P && L >= 1 && L <= 256 && L_pad >= L && L_pad <= 256, "sf_softmax_rows: bad arguments");
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, lds_, P, ldp, rows, L, L_pad, scale);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// dS[r, c] = scale * P[r, c] * (dP[r, c] - sum_j P[r, j] dP[r, j])  (bf16, zero-padded to L_pad)
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const bf16_t* __restrict__ P, int64_t ldp, const float* __restrict__ dP,
+                                                                int64_t lddp, bf16_t* __restrict__ dS, int64_t ldds, int64_t rows, int L,
+                                                                int L_pad, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float p[4], g[4], dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    p[i] = c < L ? bf2f(P[r * ldp + c]) : 0.f;
+    g[i] = c < L ? dP[r * lddp + c] : 0.f;
+    dot += p[i] * g[i];
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; if (c < L_pad) dS[r * ldds + c] = c < L ? f2bf(scale * p[i] * (g[i] - dot)) : (bf16_t)0; }
+}
+
+extern "C" int sf_softmax_bwd_rows(const uint16_t* P, int64_t ldp, const float* dP, int64_t lddp, uint16_t* dS, int64_t ldds, int64_t rows,
+                                   int L, int L_pad, float scale, void* stream) {
+  SF_CHECK_ARG(P && dP && dS && L >= 1 && L <= 256 && L_pad >= L && L_pad <= 256, "sf_softmax_bwd_rows: bad arguments");
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P, ldp, dP, lddp, dS, ldds,
+                     rows, L, L_pad, scale);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// LayerNorm backward over 768 columns (statistics recomputed from x):
+//   dx[omap(r)] (=|+=) rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)),  xhat = (x[imap(r)] - mean) * rstd
+//   part[blk][0][c] = sum_rows dy*xhat (dgamma), part[blk][1][c] = sum_rows dy (dbeta), reduced by sf_colsum_partials.
+// One wave per row, 4 rows per block -> the block's 4 waves combine their per-column partials through LDS.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm768_bwd_kernel(const float* __restrict__ x, int64_t ldx, RowMap xmap, const float* __restrict__ gamma,
+                                                                const float* __restrict__ dy, int64_t lddy, RowMap dymap, float* __restrict__ dx,
+                                                                int64_t lddx, RowMap dxmap, int accumulate, float* __restrict__ part, int64_t rows,
+                                                                float eps) {
+  __shared__ float red[4][2][768];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  float4 dg[3], db[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i]; }
+  if (r < rows) {
+    const float* xr = x + map_row(xmap, r) * ldx;
+    const float* gr = dy + map_row(dymap, r) * lddy;
+    float4 v[3], g[3];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      v[i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
+      g[i] = *reinterpret_cast<const float4*>(gr + i * 256 + lane * 4);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) * (1.0f / 768);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / 768) + eps);
+    float a = 0.f, b = 0.f;   // sum(g*dy), sum(g*dy*xhat)
+    float4 gd[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float4 w = *reinterpret_cast<const float4*>(gamma + i * 256 + lane * 4);
+      v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;           // xhat
+      gd[i] = make_float4(w.x * g[i].x, w.y * g[i].y, w.z * g[i].z, w.w * g[i].w);
+      a += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
+      b += (gd[i].x * v[i].x + gd[i].y * v[i].y) + (gd[i].z * v[i].z + gd[i].w * v[i].w);
+      dg[i] = make_float4(g[i].x * v[i].x, g[i].y * v[i].y, g[i].z * v[i].z, g[i].w * v[i].w);
+      db[i] = g[i];
+    }
+    a = wave_sum(a) * (1.0f / 768); b = wave_sum(b) * (1.0f / 768);
+    float* dr = dx + map_row(dxmap, r) * lddx;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float4 o;
+      o.x = rstd * (gd[i].x - a - v[i].x * b); o.y = rstd * (gd[i].y - a - v[i].y * b);
+      o.z = rstd * (gd[i].z - a - v[i].z * b); o.w = rstd * (gd[i].w - a - v[i].w * b);
+      float* dp = dr + i * 256 + lane * 4;
+      if (accumulate) { const float4 t = *reinterpret_cast<const float4*>(dp); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+      *reinterpret_cast<float4*>(dp) = o;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    *reinterpret_cast<float4*>(&red[wave][0][i * 256 + lane * 4]) = dg[i];
+    *reinterpret_cast<float4*>(&red[wave][1][i * 256 + lane * 4]) = db[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * 768; c += 256) {
+    const int k = c / 768, col = c - k * 768;
+    part[((int64_t)blockIdx.x * 2 + k) * 768 + col] = (red[0][k][col] + red[1][k][col]) + (red[2][k][col] + red[3][k][col]);
+  }
+}
+
+// out[c] (=|+=) sum_p part[p * stride + c], c < cols  (second stage of the two-stage column reductions)
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part, int64_t n_part, int64_t stride, float* __restrict__ out,
+                                                               int cols, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int64_t p = 0; p < n_part; ++p) s += part[p * stride + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+extern "C" int sf_layernorm768_bwd(const float* x, int64_t ldx, const int64_t* x_map, const float* gamma, const float* dy, int64_t lddy,
+                                   const int64_t* dy_map, float* dx, int64_t lddx, const int64_t* dx_map, int accumulate_dx, float* dgamma,
+                                   float* dbeta, int accumulate_dparams, float* workspace, int64_t rows, float eps, void* stream) {
+  SF_CHECK_ARG(x && gamma && dy && dx && dgamma && dbeta && workspace, "sf_layernorm768_bwd: null pointer");
+  if (rows <= 0) return 0;
+  const int64_t nblk = (rows + 3) / 4;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(layernorm768_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, ldx, sf_rowmap(x_map), gamma, dy, lddy, sf_rowmap(dy_map), dx,
+                     lddx, sf_rowmap(dx_map), accumulate_dx, workspace, rows, eps);
+  SF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(3), dim3(256), 0, s, workspace, nblk, (int64_t)2 * 768, dgamma, 768, accumulate_dparams);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(3), dim3(256), 0, s, workspace + 768, nblk, (int64_t)2 * 768, dbeta, 768, accumulate_dparams);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Column sums (bias gradients) of a (rows, cols) fp32 | bf16 matrix -> fp32 (cols); and per-position sums over
+// sequences (positional-table gradient): out[l, c] = sum_b x[(b*L + l), c].
+// ------------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const void* __restrict__ x, int64_t ldx, int64_t rows, int cols, int rows_per_blk,
+                                                             float* __restrict__ part) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_blk, r1 = min(r0 + rows_per_blk, rows);
+  float s = 0.f;
+  for (int64_t r = r0; r < r1; ++r) s += BF16 ? bf2f(reinterpret_cast<const bf16_t*>(x)[r * ldx + c]) : reinterpret_cast<const float*>(x)[r * ldx + c];
+  part[(int64_t)blockIdx.y * cols + c] = s;
+}
+
+extern "C" int sf_colsum(const void* x, int x_dtype, int64_t ldx, int64_t rows, int cols, float* out, int accumulate, float* workspace,
+                         void* stream) {
+  SF_CHECK_ARG(x && out && workspace && (x_dtype == SF_F32 || x_dtype == SF_BF16), "sf_colsum: bad arguments");
+  if (rows <= 0 || cols <= 0) return 0;
+  const int rpb = 64;
+  const int64_t nblk = (rows + rpb - 1) / rpb;
+  SF_CHECK_ARG(nblk < 65536, "sf_colsum: too many rows");
+  dim3 grid((cols + 255) / 256, (unsigned)nblk);
+  hipStream_t s = (hipStream_t)stream;
+  if (x_dtype == SF_BF16) hipLaunchKernelGGL((colsum_stage1_kernel<true>), grid, dim3(256), 0, s, x, ldx, rows, cols, rpb, workspace);
+  else hipLaunchKernelGGL((colsum_stage1_kernel<false>), grid, dim3(256), 0, s, x, ldx, rows, cols, rpb, workspace);
+  SF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, workspace, nblk, (int64_t)cols, out, cols, accumulate);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void seqsum_kernel(const float* __restrict__ x, int64_t ldx, int n_seq, int L, int cols, float* __restrict__ out,
+                                                      int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)L * cols) return;
+  const int l = (int)(i / cols), c = (int)(i - (int64_t)l * cols);
+  float s = 0.f;
+  for (int b = 0; b < n_seq; ++b) s += x[((int64_t)b * L + l) * ldx + c];
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+extern "C" int sf_seqsum(const float* x, int64_t ldx, int n_seq, int L, int cols, float* out, int accumulate, void* stream) {
+  SF_CHECK_ARG(x && out && n_seq >= 1 && L >= 1 && cols >= 1, "sf_seqsum: bad arguments");
+  const int64_t n = (int64_t)L * cols;
+  hipLaunchKernelGGL(seqsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, n_seq, L, cols, out, accumulate);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// GELU (exact erf form) forward on a saved pre-activation, and its backward:
+//   act = gelu(pre);   dpre = dact * (Phi(pre) + pre * phi(pre)),  Phi = 0.5 (1 + erf(x / sqrt 2)), phi = exp(-x^2/2) / sqrt(2 pi)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ act, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const uint2 u = reinterpret_cast<const uint2*>(pre)[i];
+  uint2 o;
+  o.x = pack_bf2(gelu_erf(__uint_as_float(u.x << 16)), gelu_erf(__uint_as_float(u.x & 0xffff0000u)));
+  o.y = pack_bf2(gelu_erf(__uint_as_float(u.y << 16)), gelu_erf(__uint_as_float(u.y & 0xffff0000u)));
+  reinterpret_cast<uint2*>(act)[i] = o;
+}
+
+__device__ __forceinline__ float gelu_grad(float x) {
+  const float phi = 0.3989422804014327f * __expf(-0.5f * x * x);
+  const float cdf = erff(x * 0.70710678118654752f) * 0.5f + 0.5f;
+  return cdf + x * phi;
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ pre, const float* __restrict__ dact, bf16_t* __restrict__ dpre,
+                                                        int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const uint2 u = reinterpret_cast<const uint2*>(pre)[i];
+  const float4 g = reinterpret_cast<const float4*>(dact)[i];
+  uint2 o;
+  o.x = pack_bf2(g.x * gelu_grad(__uint_as_float(u.x << 16)), g.y * gelu_grad(__uint_as_float(u.x & 0xffff0000u)));
+  o.y = pack_bf2(g.z * gelu_grad(__uint_as_float(u.y << 16)), g.w * gelu_grad(__uint_as_float(u.y & 0xffff0000u)));
+  reinterpret_cast<uint2*>(dpre)[i] = o;
+}
+
+extern "C" int sf_gelu_fwd(const uint16_t* pre, uint16_t* act, int64_t n, void* stream) {
+  SF_CHECK_ARG(pre && act && (n % 4) == 0, "sf_gelu_fwd: bad arguments");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pre, act, n / 4);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sf_gelu_bwd(const uint16_t* pre, const float* dact, uint16_t* dpre, int64_t n, void* stream) {
+  SF_CHECK_ARG(pre && dact && dpre && (n % 4) == 0, "sf_gelu_bwd: bad arguments");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pre, dact, dpre, n / 4);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Cross-entropy over (B, C) logits with int64 class targets, mean reduction (F.cross_entropy, sync_model.py:95-96):
+//   loss = mean_b (logsumexp(z_b) - z_b[t_b]),   dlogits = (softmax(z) - onehot) * (grad_scale / B)
+// One workgroup, one wave per row in turn (B and C are tiny: 16 x 21).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void cross_entropy_kernel(const float* __restrict__ z, int64_t ldz, const int64_t* __restrict__ tgt, int B, int C,
+                                                            float* __restrict__ loss, float* __restrict__ dz, int64_t lddz, float grad_scale) {
+  const int lane = threadIdx.x;
+  float total = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, z[b * ldz + c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += __expf(z[b * ldz + c] - m);
+    s = wave_sum(s);
+    const int t = (int)tgt[b];
+    total += (m + logf(s)) - z[b * ldz + t];
+    if (dz)
+      for (int c = lane; c < C; c += 64) dz[b * lddz + c] = (__expf(z[b * ldz + c] - m) / s - (c == t ? 1.f : 0.f)) * (grad_scale / B);
+  }
+  if (lane == 0) *loss = total / B;
+}
+
+extern "C" int sf_cross_entropy(const float* logits, int64_t ld, const int64_t* targets, int B, int C, float* loss, float* dlogits, int64_t ldd,
+                                float grad_scale, void* stream) {
+  SF_CHECK_ARG(logits && targets && loss && B >= 1 && C >= 1, "sf_cross_entropy: bad arguments");
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, logits, ld, targets, B, C, loss, dlogits, ldd, grad_scale);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Fused gradient clipping + Adam over a flat fp32 parameter buffer (make_backward_and_optim_step, train_utils.py:373-386:
+// clip_grad_norm_(params, max_norm) then torch.optim.Adam(betas, eps, weight_decay 0); :217-226).
+//   stage 1: sum of squares of the flat gradient (two-stage, deterministic) -> norm_out[0] = ||g||_2
+//   stage 2: g *= min(1, max_norm / (norm + 1e-6));  m, v update;  p -= lr * mhat / (sqrt(vhat) + eps);  bf16 copy of p
+// The norm stays on the device (no host sync); bias corrections are passed in as scalars.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_stage1_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const float v = g[i]; s += v * v; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_stage2_kernel(const float* __restrict__ part, int n_part, float* __restrict__ norm_out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n_part; i += 256) s += part[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) norm_out[0] = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+}
+__global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                         bf16_t* __restrict__ p_bf16, int64_t n, const float* __restrict__ norm, float max_norm,
+                                                         float lr, float beta1, float beta2, float eps, float bc1, float bc2) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float coef = 1.0f;
+  if (max_norm > 0.f) coef = fminf(1.0f, max_norm / (norm[0] + 1e-6f));
+  const float gi = g[i] * coef;
+  const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+  const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  const float pi = p[i] - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+  p[i] = pi;
+  if (p_bf16) p_bf16[i] = f2bf(pi);
+}
+
+extern "C" int sf_grad_norm(const float* g, int64_t n, float* norm_out, float* workspace, void* stream) {
+  SF_CHECK_ARG(g && norm_out && workspace && n >= 0, "sf_grad_norm: bad arguments");
+  const int nblk = 1024;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sumsq_stage1_kernel, dim3(nblk), dim3(256), 0, s, g, n, workspace);
+  hipLaunchKernelGGL(sumsq_stage2_kernel, dim3(1), dim3(256), 0, s, workspace, nblk, norm_out);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sf_adam_clip_step(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n, const float* norm, float max_norm,
+                                 float lr, float beta1, float beta2, float eps, int step, void* stream) {
+  SF_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1 && (max_norm <= 0.f || norm), "sf_adam_clip_step: bad arguments");
+  if (n == 0) return 0;
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_clip_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, p_bf16, n, norm, max_norm, lr,
+                     beta1, beta2, eps, bc1, bc2);
+  SF_LAUNCH_CHECK();
+  return 0;
+}

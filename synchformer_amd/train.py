@@ -1,0 +1,351 @@
+"""Stage-2 train step on the HIP path (scripts/train_sync.py:153-237).
+
+With `is_trainable: False` extractors (configs/sync.yaml:7,19; train_utils.py:199-204) only vproj, aproj and the sync
+transformer train: 22,619,157 parameters.  `SyncTrainer` keeps them as ONE flat fp32 master buffer (+ flat grad, Adam m/v,
+bf16 operand copies), runs forward with saved activations, the hand-scheduled backward, an optional RCCL gradient
+all-reduce (one 90 MB bucket - the backward is 0.3 % of the step, there is nothing to overlap it with but the next step's
+frozen extractor forward) and the fused clip + Adam kernel.  Dropout: the reference trains with p = 0.1; this path
+implements p = 0 only (parity is exact only there; SURVEY §7 hard part (g)) and refuses otherwise.
+
+All compute is in libsynchformer_hip (GEMMs via sf_gemm_bf16 / sf_gemm_bf16_batched on transposed copies); torch provides
+memory, the stream and torch.distributed.
+"""
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib, ops, synth
+from .engine import D, FF, EPS_SYNC, SynchformerEngine
+
+_F32, _BF16 = 0, 1
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(rc, what):
+    _lib.check(rc, what)
+
+
+def transpose(inp: torch.Tensor, ld_in, sI0, sI1, out: torch.Tensor, ld_out, sO0, sO1, R, Cc, R_pad, b_outer=1, b_inner=1):
+    _chk(_lib.load().sf_transpose_bf16(inp.data_ptr(), ld_in, sI0, sI1, out.data_ptr(), ld_out, sO0, sO1, R, Cc, R_pad, b_outer, b_inner, _st()),
+         'sf_transpose_bf16')
+
+
+def cast_bf16(x: torch.Tensor, y: torch.Tensor, rows, cols, scale=1.0):
+    _chk(_lib.load().sf_cast_bf16(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), rows, cols, float(scale), _st()), 'sf_cast_bf16')
+
+
+def bgemm(a, lda, sA0, sA1, w, ldw, sW0, sW1, c, ldc, sC0, sC1, M, N, K, b_outer, b_inner):
+    _chk(_lib.load().sf_gemm_bf16_batched(a.data_ptr(), lda, sA0, sA1, w.data_ptr(), ldw, sW0, sW1, None, c.data_ptr(),
+                                          _BF16 if c.dtype == torch.bfloat16 else _F32, ldc, sC0, sC1, M, N, K, b_outer, b_inner, _st()),
+         'sf_gemm_bf16_batched')
+
+
+def ln_bwd(x, gamma, dy, dx, dgamma, dbeta, ws, rows, eps, *, x_map=None, dy_map=None, dx_map=None, acc_dx=False, acc_dp=False):
+    m = lambda t: (C.c_int64 * 6)(*t) if t is not None else None
+    _chk(_lib.load().sf_layernorm768_bwd(x.data_ptr(), x.stride(0), m(x_map), gamma.data_ptr(), dy.data_ptr(), dy.stride(0), m(dy_map),
+                                         dx.data_ptr(), dx.stride(0), m(dx_map), int(acc_dx), dgamma.data_ptr(), dbeta.data_ptr(), int(acc_dp),
+                                         ws.data_ptr(), rows, float(eps), _st()), 'sf_layernorm768_bwd')
+
+
+def colsum(x, rows, cols, out, ws, accumulate=False):
+    _chk(_lib.load().sf_colsum(x.data_ptr(), _BF16 if x.dtype == torch.bfloat16 else _F32, x.stride(0), rows, cols, out.data_ptr(), int(accumulate),
+                               ws.data_ptr(), _st()), 'sf_colsum')
+
+
+# trainable keys, in the reference's state-dict order (vproj, aproj, transformer.*)
+def trainable_keys(schema) -> List[str]:
+    return [k for k in schema if k.startswith(('vproj.', 'aproj.', 'transformer.'))]
+
+
+class SyncTrainer:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device='cuda:0', lr: float = 2e-6, betas=(0.9, 0.999), eps: float = 1e-7,
+                 max_clip_norm: float = 1.0, dropout: float = 0.0, seg_chunk: int = 27):
+        if dropout and dropout > 0:
+            raise NotImplementedError('the HIP train step implements dropout p = 0 only (embd/resid/attn_pdrop of configs/sync.yaml '
+                                      'must be set to 0.0); dropout masks are the next item (DESIGN.md §7)')
+        self.dev = torch.device(device)
+        self.engine = SynchformerEngine(state_dict, self.dev, seg_chunk=seg_chunk)       # frozen extractors (+ inference path)
+        self.lr, self.betas, self.eps, self.max_clip_norm = lr, betas, eps, max_clip_norm
+        self.keys = trainable_keys(state_dict)
+        sizes = [state_dict[k].numel() for k in self.keys]
+        self.n = sum(sizes)
+        self.flat_p = torch.empty(self.n, device=self.dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(self.n, device=self.dev, dtype=torch.float32)
+        self.flat_m = torch.zeros_like(self.flat_g)
+        self.flat_v = torch.zeros_like(self.flat_g)
+        self.flat_b = torch.empty(self.n, device=self.dev, dtype=torch.bfloat16)
+        self.p, self.g, self.b = {}, {}, {}
+        o = 0
+        for k, sz in zip(self.keys, sizes):
+            shp = state_dict[k].shape
+            self.p[k] = self.flat_p[o:o + sz].view(shp)
+            self.g[k] = self.flat_g[o:o + sz].view(shp)
+            self.b[k] = self.flat_b[o:o + sz].view(shp)
+            self.p[k].copy_(state_dict[k])
+            o += sz
+        self.flat_b.copy_(self.flat_p)
+        self.step_count = 0
+        self.n_blocks = len([k for k in self.keys if k.endswith('.ln1.weight')])
+        self.heads = 8
+        self.head_name = 'off_head' if 'transformer.off_head.weight' in self.p else 'sync_head'
+        self.n_out = self.p[f'transformer.{self.head_name}.weight'].shape[0]
+        self.norm = torch.zeros(1, device=self.dev, dtype=torch.float32)
+        self.loss = torch.zeros(1, device=self.dev, dtype=torch.float32)
+        self._ws: Dict[str, torch.Tensor] = {}
+        self._wT: Dict[str, torch.Tensor] = {}
+        self._refresh_transposed()
+
+    # ---- small helpers -----------------------------------------------------------------------------------
+    def _buf(self, name, shape, dtype, zero=False):
+        t = self._ws.get(name)
+        n = int(math.prod(shape))
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.zeros(n, device=self.dev, dtype=dtype)
+            self._ws[name] = t
+        v = t[:n].view(*shape)
+        if zero:
+            v.zero_()
+        return v
+
+    def _refresh_transposed(self):
+        """bf16 W^T copies (dgrad operands) of every 2-D trainable weight; called after each optimizer step."""
+        for k in self.keys:
+            w = self.b[k]
+            if w.dim() != 2 or not k.endswith('weight'):
+                continue
+            N, K = w.shape
+            n_pad = ((N + 63) // 64) * 64
+            t = self._wT.get(k)
+            if t is None:
+                t = torch.zeros(K, n_pad, device=self.dev, dtype=torch.bfloat16)
+                self._wT[k] = t
+            transpose(w, K, 0, 0, t, n_pad, 0, 0, N, K, n_pad)
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: v.detach().clone() for k, v in self.p.items()}
+
+    # ---- linear layer forward / backward -------------------------------------------------------------------
+    def _wb(self, name):
+        return self.b[name + '.weight'], self.p[name + '.bias']
+
+    def _lin_bwd(self, name, dy_b, x_b, M, *, need_dx=True, dx_out=None, tag=''):
+        """dy_b (M, N) bf16 (row stride may exceed N), x_b (M, K) bf16 saved input.  Fills g[W], g[b]; returns dx fp32 (M, K)."""
+        N, K = self.p[name + '.weight'].shape
+        m_pad = ((M + 63) // 64) * 64
+        ws = self._buf('colsum_ws', (N * ((M + 63) // 64),), torch.float32)
+        colsum(dy_b, M, N, self.g[name + '.bias'], ws)
+        dyT = self._buf('dyT', (N, m_pad), torch.bfloat16)
+        xT = self._buf('xT', (K, m_pad), torch.bfloat16)
+        transpose(dy_b, dy_b.stride(0), 0, 0, dyT, m_pad, 0, 0, M, N, m_pad)
+        transpose(x_b, x_b.stride(0), 0, 0, xT, m_pad, 0, 0, M, K, m_pad)
+        ops.gemm(dyT, xT, None, self.g[name + '.weight'], M=N)                       # dW = dy^T x
+        if not need_dx:
+            return None
+        wT = self._wT[name + '.weight']                                               # (K, n_pad)
+        dx = dx_out if dx_out is not None else self._buf('dx_' + tag, (M, K), torch.float32)
+        if wT.shape[1] != N:                                                           # ragged N (heads): zero-padded contraction
+            dyp = self._buf('dy_pad', (M, wT.shape[1]), torch.bfloat16, zero=True)
+            dyp[:, :N].copy_(dy_b[:M, :N])
+            ops.gemm(dyp, wT, None, dx, M=M)
+        else:
+            ops.gemm(dy_b, wT, None, dx, M=M)
+        return dx
+
+    # ---- forward with saved activations ----------------------------------------------------------------------
+    def _forward(self, vfeat, afeat):
+        B = vfeat.shape[0]
+        Sv, Sa = vfeat.shape[1] * vfeat.shape[2], afeat.shape[1] * afeat.shape[2]
+        L = 2 + Sv + Sa
+        M = B * L
+        sv = self.sv = dict(B=B, Sv=Sv, Sa=Sa, L=L, M=M)
+        # projections (vproj / aproj) on the frozen features
+        for tag, feat, n_tok in (('v', vfeat, Sv), ('a', afeat, Sa)):
+            fb = self._buf(f'{tag}_in', (B * n_tok, D), torch.bfloat16)
+            ops.gather_rows(feat.reshape(B * n_tok, D), fb, B * n_tok)
+            w, b = self._wb(f'{tag}proj')
+            pr = self._buf(f'{tag}_proj', (B * n_tok, D), torch.float32)
+            ops.gemm(fb, w, b, pr)
+            sv[f'{tag}_in'], sv[f'{tag}_proj'] = fb, pr
+        t = 'transformer'
+        table = self.p[f'{t}.pos_emb_cfg.pos_emb'][0, :L].clone()
+        table[0] += self.p[f'{t}.OFF_tok'][0, 0]
+        table[1 + Sv] += self.p[f'{t}.MOD_tok'][0, 0]
+        x = self._buf('x0', (M, D), torch.float32)
+        ops.broadcast_rows(x, table.contiguous(), n_seq=B, dst_seq_rows=L)
+        ops.layernorm(sv['v_proj'], self.p[f'{t}.vis_in_lnorm.weight'], self.p[f'{t}.vis_in_lnorm.bias'], x, EPS_SYNC,
+                      out_map=ops.rowmap(Sv, Sv, L, 0, 1, 1), accumulate=True)
+        ops.layernorm(sv['a_proj'], self.p[f'{t}.aud_in_lnorm.weight'], self.p[f'{t}.aud_in_lnorm.bias'], x, EPS_SYNC,
+                      out_map=ops.rowmap(Sa, Sa, L, 0, 1, 2 + Sv), accumulate=True)
+        hd = D // self.heads
+        sv['blocks'] = []
+        for i in range(self.n_blocks):
+            p = f'{t}.blocks.{i}'
+            s = dict(x=x)
+            s['h1'] = self._buf(f'h1_{i}', (M, D), torch.bfloat16)
+            ops.layernorm(x, self.p[p + '.ln1.weight'], self.p[p + '.ln1.bias'], s['h1'], EPS_SYNC)
+            s['qkv'] = self._buf(f'qkv_{i}', (M, 3 * D), torch.bfloat16)
+            for j, n in enumerate(('query', 'key', 'value')):                           # separate Linears, packed side by side
+                w, b = self._wb(f'{p}.attn.{n}')
+                ops.gemm(s['h1'], w, b, s['qkv'][:, j * D:(j + 1) * D])
+            s['att'] = self._buf(f'att_{i}', (M, D), torch.bfloat16)
+            q3 = s['qkv']
+            ops.attention(q3[:, :D], q3[:, D:2 * D], q3[:, 2 * D:], s['att'], n_seq=B, seq_rows=L, n_groups=1, row0=0, group_stride=0,
+                          tok_stride=1, n_tok=L, cls_row=-1, heads=self.heads, head_dim=hd, scale=1.0 / math.sqrt(hd))
+            w, b = self._wb(p + '.attn.proj')
+            s['x2'] = self._buf(f'x2_{i}', (M, D), torch.float32)
+            ops.gemm(s['att'], w, b, s['x2'], residual=x)
+            s['h2'] = self._buf(f'h2_{i}', (M, D), torch.bfloat16)
+            ops.layernorm(s['x2'], self.p[p + '.ln2.weight'], self.p[p + '.ln2.bias'], s['h2'], EPS_SYNC)
+            w, b = self._wb(p + '.mlp.0')
+            s['pre'] = self._buf(f'pre_{i}', (M, FF), torch.bfloat16)
+            ops.gemm(s['h2'], w, b, s['pre'])
+            s['act'] = self._buf(f'act_{i}', (M, FF), torch.bfloat16)
+            _chk(_lib.load().sf_gelu_fwd(s['pre'].data_ptr(), s['act'].data_ptr(), M * FF, _st()), 'sf_gelu_fwd')
+            w, b = self._wb(p + '.mlp.2')
+            x = self._buf(f'xo_{i}', (M, D), torch.float32)
+            ops.gemm(s['act'], w, b, x, residual=s['x2'])
+            sv['blocks'].append(s)
+        sv['x_last'] = x
+        cls = self._buf('cls_n', (B, D), torch.bfloat16)
+        ops.layernorm(x, self.p[f'{t}.ln_f.weight'], self.p[f'{t}.ln_f.bias'], cls, EPS_SYNC, rows=B, in_map=ops.rowmap(1, 1, L, 0, 0, 0))
+        sv['cls_n'] = cls
+        w, b = self._wb(f'{t}.{self.head_name}')
+        logits = self._buf('logits', (B, self.n_out), torch.float32)
+        ops.gemm(cls, w, b, logits, M=B)
+        return logits
+
+    # ---- attention backward: five strided-batched products per block -------------------------------------------
+    def _attn_bwd(self, qkv, dO_b, dqkv):
+        sv = self.sv
+        B, L, H = sv['B'], sv['L'], self.heads
+        hd = D // H
+        Lp = ((L + 31) // 32) * 32
+        scale = 1.0 / math.sqrt(hd)
+        ld3 = qkv.stride(0)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        S = self._buf('att_S', (B * H * L, Lp), torch.float32)
+        bgemm(q, ld3, L * ld3, hd, k, ld3, L * ld3, hd, S, Lp, H * L * Lp, L * Lp, L, L, hd, B, H)
+        P = self._buf('att_P', (B * H * L, Lp), torch.bfloat16)
+        _chk(_lib.load().sf_softmax_rows(S.data_ptr(), Lp, P.data_ptr(), Lp, B * H * L, L, Lp, scale, _st()), 'sf_softmax_rows')
+        dP = S                                                                          # reuse: S is dead once P exists
+        bgemm(dO_b, D, L * D, hd, v, ld3, L * ld3, hd, dP, Lp, H * L * Lp, L * Lp, L, L, hd, B, H)
+        dS = self._buf('att_dS', (B * H * L, Lp), torch.bfloat16)
+        _chk(_lib.load().sf_softmax_bwd_rows(P.data_ptr(), Lp, dP.data_ptr(), Lp, dS.data_ptr(), Lp, B * H * L, L, Lp, scale, _st()),
+             'sf_softmax_bwd_rows')
+        # transposed per-(clip, head) operands, contraction dimension zero-padded to Lp
+        kT = self._buf('att_kT', (B * H * hd, Lp), torch.bfloat16)
+        qT = self._buf('att_qT', (B * H * hd, Lp), torch.bfloat16)
+        dOT = self._buf('att_dOT', (B * H * hd, Lp), torch.bfloat16)
+        transpose(k, ld3, L * ld3, hd, kT, Lp, H * hd * Lp, hd * Lp, L, hd, Lp, B, H)
+        transpose(q, ld3, L * ld3, hd, qT, Lp, H * hd * Lp, hd * Lp, L, hd, Lp, B, H)
+        transpose(dO_b, D, L * D, hd, dOT, Lp, H * hd * Lp, hd * Lp, L, hd, Lp, B, H)
+        dST = self._buf('att_dST', (B * H * L, Lp), torch.bfloat16)
+        PT = self._buf('att_PT', (B * H * L, Lp), torch.bfloat16)
+        transpose(dS, Lp, H * L * Lp, L * Lp, dST, Lp, H * L * Lp, L * Lp, L, L, Lp, B, H)
+        transpose(P, Lp, H * L * Lp, L * Lp, PT, Lp, H * L * Lp, L * Lp, L, L, Lp, B, H)
+        dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
+        ldg = dqkv.stride(0)
+        bgemm(dS, Lp, H * L * Lp, L * Lp, kT, Lp, H * hd * Lp, hd * Lp, dq, ldg, L * ldg, hd, L, hd, Lp, B, H)     # dQ = dS K
+        bgemm(dST, Lp, H * L * Lp, L * Lp, qT, Lp, H * hd * Lp, hd * Lp, dk, ldg, L * ldg, hd, L, hd, Lp, B, H)    # dK = dS^T Q
+        bgemm(PT, Lp, H * L * Lp, L * Lp, dOT, Lp, H * hd * Lp, hd * Lp, dv, ldg, L * ldg, hd, L, hd, Lp, B, H)    # dV = P^T dO
+
+    # ---- backward ------------------------------------------------------------------------------------------------
+    def _backward(self, dlogits):
+        sv = self.sv
+        B, L, M, Sv, Sa = sv['B'], sv['L'], sv['M'], sv['Sv'], sv['Sa']
+        t = 'transformer'
+        lnws = self._buf('ln_ws', (2 * 768 * ((M + 3) // 4),), torch.float32)
+        # head: logits = cls_n W^T + b
+        dl_b = self._buf('dlogits_b', (B, 64), torch.bfloat16, zero=True)
+        dl_b[:, :self.n_out].copy_(dlogits)
+        head = f'{t}.{self.head_name}'
+        dcls = self._lin_bwd(head, dl_b[:, :self.n_out], sv['cls_n'], B, tag='cls')      # (B, 768) fp32
+        # ln_f on row 0 of each sequence; every other row of dX is zero
+        dx = self._buf('dx_a', (M, D), torch.float32, zero=True)
+        ln_bwd(sv['x_last'], self.p[f'{t}.ln_f.weight'], dcls, dx, self.g[f'{t}.ln_f.weight'], self.g[f'{t}.ln_f.bias'], lnws, B, EPS_SYNC,
+               x_map=ops.rowmap(1, 1, L, 0, 0, 0), dx_map=ops.rowmap(1, 1, L, 0, 0, 0))
+        dy_b = self._buf('dy_b', (M, FF), torch.bfloat16)
+        for i in reversed(range(self.n_blocks)):
+            p, s = f'{t}.blocks.{i}', sv['blocks'][i]
+            # y = x2 + act W2^T + b2
+            cast_bf16(dx, dy_b[:, :D], M, D)
+            dact = self._lin_bwd(p + '.mlp.2', dy_b[:, :D], s['act'], M, tag='act')       # (M, 3072) fp32
+            dpre = self._buf('dpre', (M, FF), torch.bfloat16)
+            _chk(_lib.load().sf_gelu_bwd(s['pre'].data_ptr(), dact.data_ptr(), dpre.data_ptr(), M * FF, _st()), 'sf_gelu_bwd')
+            dh2 = self._lin_bwd(p + '.mlp.0', dpre, s['h2'], M, tag='h')                   # (M, 768) fp32
+            # dx2 = dy + LN2'(dh2)
+            ln_bwd(s['x2'], self.p[p + '.ln2.weight'], dh2, dx, self.g[p + '.ln2.weight'], self.g[p + '.ln2.bias'], lnws, M, EPS_SYNC, acc_dx=True)
+            # x2 = x + att Wp^T + bp
+            cast_bf16(dx, dy_b[:, :D], M, D)
+            datt = self._lin_bwd(p + '.attn.proj', dy_b[:, :D], s['att'], M, tag='h')     # (M, 768) fp32
+            dO_b = self._buf('dO_b', (M, D), torch.bfloat16)
+            cast_bf16(datt, dO_b, M, D)
+            dqkv = self._buf('dqkv', (M, 3 * D), torch.bfloat16)
+            self._attn_bwd(s['qkv'], dO_b, dqkv)
+            dh1 = self._buf('dh1', (M, D), torch.float32)
+            for j, n in enumerate(('query', 'key', 'value')):
+                part = self._lin_bwd(f'{p}.attn.{n}', dqkv[:, j * D:(j + 1) * D], s['h1'], M, tag='h')
+                if j == 0:
+                    dh1.copy_(part)
+                else:
+                    dh1.add_(part)                                                          # torch elementwise add: 3 small launches / block
+            ln_bwd(s['x'], self.p[p + '.ln1.weight'], dh1, dx, self.g[p + '.ln1.weight'], self.g[p + '.ln1.bias'], lnws, M, EPS_SYNC, acc_dx=True)
+        # x0 = table + scatter(LN_v(pv)) + scatter(LN_a(pa))
+        gtab = self._buf('gtab', (L, D), torch.float32)
+        _chk(_lib.load().sf_seqsum(dx.data_ptr(), D, B, L, D, gtab.data_ptr(), 0, _st()), 'sf_seqsum')
+        gpos = self.g[f'{t}.pos_emb_cfg.pos_emb']
+        gpos.zero_()
+        gpos[0, :L].copy_(gtab)
+        self.g[f'{t}.OFF_tok'][0, 0].copy_(gtab[0])
+        self.g[f'{t}.MOD_tok'][0, 0].copy_(gtab[1 + Sv])
+        for tag, ln, n_tok, off in (('v', 'vis_in_lnorm', Sv, 1), ('a', 'aud_in_lnorm', Sa, 2 + Sv)):
+            dpr = self._buf('dproj', (B * n_tok, D), torch.float32)
+            ln_bwd(sv[f'{tag}_proj'], self.p[f'{t}.{ln}.weight'], dx, dpr, self.g[f'{t}.{ln}.weight'], self.g[f'{t}.{ln}.bias'], lnws, B * n_tok,
+                   EPS_SYNC, dy_map=ops.rowmap(n_tok, n_tok, L, 0, 1, off))
+            cast_bf16(dpr, dy_b[:B * n_tok, :D], B * n_tok, D)
+            self._lin_bwd(f'{tag}proj', dy_b[:B * n_tok, :D], sv[f'{tag}_in'], B * n_tok, need_dx=False)
+
+    # ---- public API ----------------------------------------------------------------------------------------------
+    def forward_backward(self, vfeat: torch.Tensor, afeat: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        """Segment features (B,S,tv,768)/(B,S,ta,768) fp32 + int64 targets -> loss (device scalar); fills the flat gradient."""
+        logits = self._forward(vfeat, afeat)
+        B = logits.shape[0]
+        dlogits = self._buf('dlogits', (B, self.n_out), torch.float32)
+        _chk(_lib.load().sf_cross_entropy(logits.data_ptr(), logits.stride(0), targets.data_ptr(), B, self.n_out, self.loss.data_ptr(),
+                                          dlogits.data_ptr(), dlogits.stride(0), 1.0, _st()), 'sf_cross_entropy')
+        self._backward(dlogits)
+        self.logits = logits
+        return self.loss
+
+    def allreduce_grads(self):
+        """DDP-equivalent gradient averaging: one flat 90 MB bucket over RCCL (C1 in SURVEY §2.2)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+            self.flat_g.div_(dist.get_world_size())
+
+    def optimizer_step(self, lr: Optional[float] = None):
+        """clip_grad_norm_(max_clip_norm) + Adam on the flat buffers (train_utils.py:373-386), then refresh operand copies."""
+        lib = _lib.load()
+        ws = self._buf('norm_ws', (1024,), torch.float32)
+        _chk(lib.sf_grad_norm(self.flat_g.data_ptr(), self.n, self.norm.data_ptr(), ws.data_ptr(), _st()), 'sf_grad_norm')
+        self.step_count += 1
+        _chk(lib.sf_adam_clip_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
+                                   self.flat_b.data_ptr(), self.n, self.norm.data_ptr(), float(self.max_clip_norm or 0.0),
+                                   float(self.lr if lr is None else lr), self.betas[0], self.betas[1], self.eps, self.step_count, _st()),
+             'sf_adam_clip_step')
+        self._refresh_transposed()
+
+    def train_step(self, vis: torch.Tensor, aud: torch.Tensor, targets: torch.Tensor, lr: Optional[float] = None) -> torch.Tensor:
+        """One Stage-2 iteration (train_sync.py:159-192): frozen extractors -> trainable forward/backward -> all-reduce -> clip+Adam."""
+        vf = self.engine.extract_vfeats(vis)
+        af = self.engine.extract_afeats(aud)
+        loss = self.forward_backward(vf, af, targets)
+        self.allreduce_grads()
+        self.optimizer_step(lr)
+        return loss

@@ -100,12 +100,49 @@ def e2e_syncability(B=1):
     print('syncability logits', logits)
 
 
+def train_grads(B=2):
+    """Stage-2 backward (train_utils.py:199-204: extractors frozen) of the REAL reference: CE loss + gradients of vproj, aproj and
+    the sync transformer, fed with the golden segment features, dropout disabled (eval()), fp32."""
+    g = np.load(HERE / f'e2e_sync_B{B}.npz')
+    model = ref_import.build_reference_synchformer()
+    model.load_state_dict(synth.make_state_dict(SEED), strict=True)
+    model.eval()
+    vf = torch.from_numpy(g['vfeat_extractor__spatial_attn_agg']).reshape(B, 14, 8, 768)
+    af = torch.from_numpy(g['afeat_extractor__freq_attn_agg']).reshape(B, 14, 6, 768)
+    tgt = torch.from_numpy(g['targets'])
+    train = [(n, p) for n, p in model.named_parameters() if n.startswith(('vproj.', 'aproj.', 'transformer.'))]
+    for p in model.parameters():
+        p.requires_grad_(False)
+    for _, p in train:
+        p.requires_grad_(True)
+    v, a = model.vproj(vf), model.aproj(af)
+    logits = model.transformer(v.view(B, -1, 768), a.view(B, -1, 768))
+    loss = model.compute_loss(logits, tgt)
+    loss.backward()
+    out = dict(loss=loss.detach().numpy(), logits=logits.detach().numpy())
+    keep = ('transformer.off_head.bias', 'transformer.off_head.weight', 'transformer.ln_f.weight', 'transformer.OFF_tok', 'transformer.MOD_tok',
+            'vproj.bias', 'aproj.bias', 'transformer.blocks.0.attn.query.bias', 'transformer.blocks.2.mlp.2.bias',
+            'transformer.blocks.1.ln1.weight', 'transformer.vis_in_lnorm.weight')
+    names, norms = [], []
+    for n, p in train:
+        names.append(n); norms.append(float(p.grad.norm()))
+        if n in keep:
+            out['grad__' + n.replace('.', '__')] = p.grad.numpy()
+    out['names'] = np.array(names); out['grad_norms'] = np.array(norms, dtype=np.float64)
+    out['grad__transformer__blocks__0__mlp__0__weight__rows0_4'] = dict(train)['transformer.blocks.0.mlp.0.weight'].grad[:4].numpy()
+    out['grad__transformer__pos_emb__rows0_4'] = dict(train)['transformer.pos_emb_cfg.pos_emb'].grad[0, :4].numpy()
+    np.savez_compressed(HERE / f'train_sync_B{B}_grads.npz', **out)
+    print('train loss', float(loss), 'total grad norm', float(np.sqrt((np.array(norms) ** 2).sum())))
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['sync', 'sync_gain2', 'syncability']
+    which = sys.argv[1:] or ['sync', 'sync_gain2', 'syncability', 'train']
     if 'sync' in which:
         e2e_sync(2)
     if 'sync_gain2' in which:
         e2e_sync(2, gain=2.0)
     if 'syncability' in which:
         e2e_syncability(1)
+    if 'train' in which:
+        train_grads(2)
