@@ -29,6 +29,14 @@ def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float
     return float(t.item())
 
 
+def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
+    """In-place mean all-reduce of a flat gradient bucket (DDP semantics: sum / world); identity without a process group."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
+    return flat
+
+
 def gather_logits(local: torch.Tensor, n_total: int) -> Optional[torch.Tensor]:
     """Gather per-rank logits (ragged first dim, shard_range order) to rank 0 -> (n_total, C); None on other ranks."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

@@ -186,6 +186,7 @@ class GlobalTransformer(torch.nn.Module):
         if tok_pdrop and tok_pdrop > 0:
             raise NotImplementedError('tok_pdrop > 0 (whole-token dropout) is not used by the three configs')
         self.n_layer, self.n_head, self.n_embd = n_layer, n_head, n_embd
+        self.pdrops = dict(embd_pdrop=embd_pdrop, resid_pdrop=resid_pdrop, attn_pdrop=attn_pdrop)
         n_pos = pos_emb_cfg['params']['block_shape'][0] if pos_emb_cfg is not None else 198
         n_out = off_head_cfg['params']['out_features'] if off_head_cfg is not None else 21
         schema = synth.state_dict_schema(n_pos=n_pos, n_out=n_out, sync_depth=n_layer, head='off_head')
@@ -290,6 +291,7 @@ class Synchformer(torch.nn.Module):
 
     # -- engine cache ---------------------------------------------------------------------------------------
     def _engine(self) -> SynchformerEngine:
+        # keyed on the FROZEN part only would be enough for training, but inference must also see updated sync weights
         key = _param_key(self)
         if self._sf_engine is not None and self._sf_engine[0] == key:
             return self._sf_engine[1]
@@ -308,8 +310,39 @@ class Synchformer(torch.nn.Module):
         processed in `self.seg_chunk`-sized chunks."""
         vis = self.extract_vfeats(vis, for_loop, vis_mask=vis_mask)
         aud = self.extract_afeats(aud, for_loop, aud_mask=aud_mask)
-        logits = self._engine().sync_transformer(vis, aud)
+        trainable = self._trainable_params()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in trainable.values()):
+            logits = self._train_forward(vis, aud, trainable)
+        else:
+            logits = self._engine().sync_transformer(vis, aud)
         return self.compute_loss(logits, targets, loss_fn), logits
+
+    # -- Stage-2 training (extractors frozen, train_utils.py:199-204) ---------------------------------------
+    def _trainable_params(self):
+        return {n: p for n, p in self.named_parameters() if n.startswith(('vproj.', 'aproj.', 'transformer.'))}
+
+    def _train_forward(self, vfeat, afeat, trainable):
+        from .train import SyncTrainer, SyncTrainFunction
+        if any(p.requires_grad for n, p in self.named_parameters() if n.startswith(('vfeat_extractor.', 'afeat_extractor.'))
+               and not n.startswith('vfeat_extractor.patch_embed.')):
+            raise NotImplementedError('only Stage-2 training with frozen extractors (is_trainable: False, configs/sync.yaml:7,19) has a '
+                                      'backward; requires_grad_(False) the extractors as scripts/train_utils.py:199-204 does')
+        if self.training and any(v and v > 0 for v in getattr(self.transformer, 'pdrops', {}).values()):
+            raise NotImplementedError('the HIP train step implements dropout p = 0 only: set embd_pdrop / resid_pdrop / attn_pdrop '
+                                      'to 0.0 in the transformer config (dropout masks: DESIGN.md §7)')
+        if any(not p.requires_grad for p in trainable.values()):
+            raise NotImplementedError('partially frozen sync transformer is not supported')
+        eng = self._engine()
+        tr = getattr(self, '_sf_trainer', None)
+        if tr is None or tr.engine is not eng:
+            tr = SyncTrainer(self.state_dict(), next(self.parameters()).device, engine=eng)
+            object.__setattr__(self, '_sf_trainer', tr)
+            object.__setattr__(self, '_sf_trainer_key', None)
+        key = tuple((p.data_ptr(), p._version) for p in trainable.values())
+        if key != self._sf_trainer_key:                      # an external optimizer moved the nn.Parameters
+            tr.load_params({k: p.detach() for k, p in trainable.items()})
+            object.__setattr__(self, '_sf_trainer_key', key)
+        return SyncTrainFunction.apply(tr, vfeat.detach(), afeat.detach(), *[trainable[k] for k in tr.keys])
 
     def extract_vfeats(self, vis, for_loop, vis_mask=None):
         if vis_mask is not None:

@@ -64,12 +64,12 @@ def trainable_keys(schema) -> List[str]:
 
 class SyncTrainer:
     def __init__(self, state_dict: Dict[str, torch.Tensor], device='cuda:0', lr: float = 2e-6, betas=(0.9, 0.999), eps: float = 1e-7,
-                 max_clip_norm: float = 1.0, dropout: float = 0.0, seg_chunk: int = 27):
+                 max_clip_norm: float = 1.0, dropout: float = 0.0, seg_chunk: int = 27, engine: Optional[SynchformerEngine] = None):
         if dropout and dropout > 0:
             raise NotImplementedError('the HIP train step implements dropout p = 0 only (embd/resid/attn_pdrop of configs/sync.yaml '
                                       'must be set to 0.0); dropout masks are the next item (DESIGN.md §7)')
         self.dev = torch.device(device)
-        self.engine = SynchformerEngine(state_dict, self.dev, seg_chunk=seg_chunk)       # frozen extractors (+ inference path)
+        self.engine = engine if engine is not None else SynchformerEngine(state_dict, self.dev, seg_chunk=seg_chunk)   # frozen extractors
         self.lr, self.betas, self.eps, self.max_clip_norm = lr, betas, eps, max_clip_norm
         self.keys = trainable_keys(state_dict)
         sizes = [state_dict[k].numel() for k in self.keys]
@@ -128,6 +128,13 @@ class SyncTrainer:
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         return {k: v.detach().clone() for k, v in self.p.items()}
+
+    def load_params(self, tensors: Dict[str, torch.Tensor]):
+        """Overwrite the fp32 master copy (e.g. from nn.Parameters an external optimizer updated) and refresh operand copies."""
+        for k in self.keys:
+            self.p[k].copy_(tensors[k])
+        self.flat_b.copy_(self.flat_p)
+        self._refresh_transposed()
 
     # ---- linear layer forward / backward -------------------------------------------------------------------
     def _wb(self, name):
@@ -324,10 +331,8 @@ class SyncTrainer:
 
     def allreduce_grads(self):
         """DDP-equivalent gradient averaging: one flat 90 MB bucket over RCCL (C1 in SURVEY §2.2)."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
-            self.flat_g.div_(dist.get_world_size())
+        from .dist import allreduce_mean_
+        allreduce_mean_(self.flat_g)
 
     def optimizer_step(self, lr: Optional[float] = None):
         """clip_grad_norm_(max_clip_norm) + Adam on the flat buffers (train_utils.py:373-386), then refresh operand copies."""
@@ -349,3 +354,20 @@ class SyncTrainer:
         self.allreduce_grads()
         self.optimizer_step(lr)
         return loss
+
+
+class SyncTrainFunction(torch.autograd.Function):
+    """autograd bridge: logits = f(frozen features; trainable params).  backward runs the HIP backward and hands the
+    per-parameter gradients to autograd, so `scaler.scale(loss).backward()`, DistributedDataParallel's reducer hooks and
+    torch.optim.Adam of the reference loop (train_utils.py:373-386) work on the module's nn.Parameters unchanged."""
+
+    @staticmethod
+    def forward(ctx, trainer: SyncTrainer, vfeat, afeat, *params):
+        ctx.trainer = trainer
+        return trainer._forward(vfeat, afeat).clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        tr = ctx.trainer
+        tr._backward(dlogits.contiguous().float())
+        return (None, None, None) + tuple(tr.g[k].clone() for k in tr.keys)

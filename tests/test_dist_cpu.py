@@ -18,11 +18,13 @@ def _worker(rank, world, port, n_clips, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        from synchformer_amd.dist import gather_logits, max_over_ranks, shard_range
+        from synchformer_amd.dist import allreduce_mean_, gather_logits, max_over_ranks, shard_range
         s, e = shard_range(n_clips, rank, world)
         # stand-in for the per-rank forward: logits row i = clip index i (so the gather order is checkable)
         local = torch.arange(s, e, dtype=torch.float32).unsqueeze(1).repeat(1, 21)
         t = max_over_ranks(0.5 + rank)
+        flat = allreduce_mean_(torch.full((1000,), float(rank + 1)))          # DDP gradient averaging on the flat bucket
+        assert torch.all(flat == 1.5)
         full = gather_logits(local, n_clips)
         dist.barrier()
         q.put((rank, (s, e), t, None if full is None else full[:, 0].tolist()))
