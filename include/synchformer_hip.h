@@ -96,6 +96,17 @@ int sf_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_
                  int64_t n_seq, int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok,
                  int cls_row, int heads, int head_dim, float scale, void* stream);
 
+/* sf_attention that ALSO emits, per (sequence, head, group), the partial softmax state (m, l, o[64]; base-2 domain, fp32, 66
+ * floats) of the CLS QUERY (row cls_row) over that group's keys - the CLS key itself counted in group 0 only - so the global
+ * CLS row of DividedAttention (vit_helper.py:126) costs no second pass over K/V.  Needs cls_row >= 0, head_dim 64 and a free
+ * query slot (n_tok <= 8 or n_tok % 16 != 0).  cls_partial: [n_seq][heads][n_groups][66]. */
+int sf_attention_cls_partial(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld, uint16_t* out, int64_t ldo,
+                             int64_t n_seq, int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok,
+                             int cls_row, int heads, int head_dim, float scale, float* cls_partial, void* stream);
+/* Merge those partials: out[seq*out_seq_rows + out_row, head*64 + d] = sum_p o_p[d] 2^(m_p-M) / sum_p l_p 2^(m_p-M). */
+int sf_attention_cls_combine(const float* partials, int n_part, uint16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row,
+                             int64_t n_seq, int heads, void* stream);
+
 /* One query row per sequence against n_keys consecutive rows (head_dim 64): the Motionformer CLS query
  * (vit_helper.py:126) and the only output row the aggregator layers ever read (motionformer.py:329-332). */
 int sf_attention_cls(const uint16_t* q, int64_t q_seq_rows, int q_row, const uint16_t* k, const uint16_t* v, int64_t ld,

@@ -19,6 +19,9 @@ struct AttnArgs {
   int64_t seq_rows;       // rows per sequence in q/k/v and out
   int n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads;
   float scale;
+  // optional: partial softmax state (m, l, o[64], base-2 domain) of the CLS QUERY over this group's keys,
+  // [seq][head][group][66] fp32 - merged by sf_attention_cls_combine into output row `cls_row` (vit_helper.py:126)
+  float* cls_part;
 };
 
 // ======================================================================================================
@@ -81,6 +84,40 @@ __global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t to
     unpack8(vraw[j], vf);
 #pragma unroll
     for (int t = 0; t < 8; ++t) o[t] += e * vf[t];
+  }
+  if (p.cls_part) {
+    // the CLS query's share of this group: keys 1..n_tok (plus the CLS key itself in group 0 only)
+    float qc[8];
+    unpack8(*reinterpret_cast<const uint4*>(p.q + (seq_base + p.cls_row) * p.ld + col), qc);
+    float cs[9], cm = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      float kf[8];
+      unpack8(kraw[j], kf);
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d += qc[e] * kf[e];
+      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+      const bool use = j < nk && !(j == 0 && g != 0);
+      cs[j] = use ? d * sc : -INFINITY;
+      cm = fmaxf(cm, cs[j]);
+    }
+    float cl = 0.f, co[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const float e = exp2f(cs[j] - cm);
+      cl += e;
+      float vf[8];
+      unpack8(vraw[j], vf);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) co[t] += e * vf[t];
+    }
+    if (qi == 0) {
+      float* part = p.cls_part + ((seq * p.heads + head) * p.n_groups + g) * 66;
+      if (sub == 0) { part[0] = cm; part[1] = cl; }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) part[2 + sub * 8 + t] = co[t];
+    }
   }
   if (qi < p.n_tok) {
     const float inv = 1.0f / l;
@@ -218,6 +255,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
   const int has_cls = p.cls_row >= 0 ? 1 : 0;
   const int nk = p.n_tok + has_cls, nq = p.n_tok;
   constexpr int nkt = NKT;                                       // key tiles (host guarantees ceil(nk/16) == NKT)
+  const bool do_cls = p.cls_part != nullptr;                      // host guarantees nq % 16 != 0 (a free query slot) and cls_row >= 0
   const int nqt = (nq + 15) >> 4;
   const int hcol = head * D;
   constexpr int CH = D / 8;          // 16-byte chunks per row
@@ -235,8 +273,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 #pragma unroll
   for (int t = 0; t < MAXQ; ++t) {
     const int qt = wave + 4 * t;
-    int qi = qt * 16 + fr; if (qi > nq - 1) qi = nq - 1;          // clamp (also for tiles beyond nqt: harmless reload)
-    const bf16_t* qrow = p.q + (first + (int64_t)qi * p.tok_stride) * p.ld + hcol;
+    int qi = qt * 16 + fr;
+    const bool is_cls_q = do_cls && qi == nq;                      // the free slot right after the last query holds the CLS query
+    if (qi > nq - 1) qi = nq - 1;                                  // clamp (also for tiles beyond nqt: harmless reload)
+    const bf16_t* qrow = is_cls_q ? p.q + (seq_base + p.cls_row) * p.ld + hcol
+                                  : p.q + (first + (int64_t)qi * p.tok_stride) * p.ld + hcol;
 #pragma unroll
     for (int ks = 0; ks < D / 32; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 32 + fg * 8);
   }
@@ -311,6 +352,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     }
     // ---- softmax (base 2, scale folded with log2 e) over keys for query column (lane & 15) ---------------------
     const float sc2 = p.scale * 1.44269504088896f;
+    const bool cls_slot = do_cls && (qt * 16 + fr == nq);            // this lane's query column is the CLS query
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
@@ -318,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + fg * 4 + r;
-          const float v = (key < nk) ? s[kt][r] * sc2 : -INFINITY;
+          const float v = (key < nk && !(cls_slot && key == 0 && g != 0)) ? s[kt][r] * sc2 : -INFINITY;
           s[kt][r] = v;
           m = fmaxf(m, v);
         }
@@ -363,6 +405,14 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     // as either operand), so o[dt][r] is (dim dt*16 + fg*4 + r, query qt*16 + fr): each lane owns 4 consecutive dims of
     // ITS query row -> its own 1/l, and one 8-byte store per 16-dim tile.
     const int qo = qt * 16 + fr;
+    if (cls_slot) {                                              // unnormalised partial of the CLS query over this group's keys
+      float* part = p.cls_part + ((seq * p.heads + head) * p.n_groups + g) * (D + 2);
+      if (fg == 0) { part[0] = m; part[1] = l; }
+#pragma unroll
+      for (int dt = 0; dt < D / 16; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[2 + dt * 16 + fg * 4 + r] = o[dt][r];
+    }
     if ((SF_ATT_ABL & 1) ? (linv == 1.2345e30f) : (qo < nq)) {
       bf16_t* orow = p.out + (first + (int64_t)qo * p.tok_stride) * p.ldo + hcol + fg * 4;
 #pragma unroll
@@ -410,9 +460,57 @@ static int dispatch_attn_mfma(const AttnArgs& a, int64_t n_seq, int nkt, hipStre
   }
 }
 
-extern "C" int sf_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ldo,
+// Merge the per-group partials of the CLS query: out[seq*out_seq_rows + out_row, head*64 + d] = sum_p o_p[d] 2^(m_p - M) / sum_p l_p 2^(m_p - M)
+__global__ __launch_bounds__(64) void attn_cls_combine64_kernel(const float* __restrict__ part, int n_part, bf16_t* __restrict__ out, int64_t ldo,
+                                                                 int64_t out_seq_rows, int out_row, int heads) {
+  const int head = blockIdx.x % heads, d = threadIdx.x;
+  const int64_t seq = blockIdx.x / heads;
+  const float* pp = part + (int64_t)blockIdx.x * n_part * 66;
+  float M = -INFINITY;
+  for (int i = 0; i < n_part; ++i) M = fmaxf(M, pp[i * 66]);
+  float L = 0.f, O = 0.f;
+  for (int i = 0; i < n_part; ++i) {
+    const float w = exp2f(pp[i * 66] - M);
+    L += pp[i * 66 + 1] * w;
+    O += pp[i * 66 + 2 + d] * w;
+  }
+  out[(seq * out_seq_rows + out_row) * ldo + head * 64 + d] = f2bf(O / L);
+}
+
+extern "C" int sf_attention_cls_combine(const float* partials, int n_part, uint16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row,
+                                        int64_t n_seq, int heads, void* stream) {
+  SF_CHECK_ARG(partials && out && n_part >= 1 && heads >= 1, "sf_attention_cls_combine: bad arguments");
+  if (n_seq <= 0) return 0;
+  hipLaunchKernelGGL(attn_cls_combine64_kernel, dim3((unsigned)(n_seq * heads)), dim3(64), 0, (hipStream_t)stream, partials, n_part, out, ldo,
+                     out_seq_rows, out_row, heads);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+static int attention_impl(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ldo, int64_t n_seq,
+                          int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok, int cls_row, int heads,
+                          int head_dim, float scale, float* cls_partial, void* stream);
+
+extern "C" int sf_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ldo, int64_t n_seq,
+                            int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok, int cls_row, int heads,
+                            int head_dim, float scale, void* stream) {
+  return attention_impl(q, k, v, ld, out, ldo, n_seq, seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim, scale,
+                        nullptr, stream);
+}
+
+// sf_attention + the CLS query's per-group partials ([n_seq][heads][n_groups][66] fp32), for sf_attention_cls_combine.
+extern "C" int sf_attention_cls_partial(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ldo, int64_t n_seq,
+                                        int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok, int cls_row,
+                                        int heads, int head_dim, float scale, float* cls_partial, void* stream) {
+  SF_CHECK_ARG(cls_partial && cls_row >= 0 && head_dim == 64, "sf_attention_cls_partial: needs a partial buffer, cls_row >= 0 and head_dim 64");
+  SF_CHECK_ARG(n_tok <= 8 || (n_tok % 16) != 0, "sf_attention_cls_partial: n_tok %% 16 == 0 leaves no free query slot");
+  return attention_impl(q, k, v, ld, out, ldo, n_seq, seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim, scale,
+                        cls_partial, stream);
+}
+
+static int attention_impl(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ldo,
                             int64_t n_seq, int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride,
-                            int n_tok, int cls_row, int heads, int head_dim, float scale, void* stream) {
+                            int n_tok, int cls_row, int heads, int head_dim, float scale, float* cls_partial, void* stream) {
   SF_CHECK_ARG(q && k && v && out, "sf_attention: null pointer");
   SF_CHECK_ARG(head_dim == 64 || head_dim == 96, "sf_attention: head_dim %d not supported (64, 96)", head_dim);
   SF_CHECK_ARG((ld % 8) == 0 && (ldo % 8) == 0, "sf_attention: ld/ldo must be multiples of 8 elements");
@@ -424,7 +522,7 @@ extern "C" int sf_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, i
   AttnArgs a;
   a.q = q; a.k = k; a.v = v; a.ld = ld; a.out = out; a.ldo = ldo; a.seq_rows = seq_rows;
   a.n_groups = n_groups; a.row0 = row0; a.group_stride = group_stride; a.tok_stride = tok_stride; a.n_tok = n_tok;
-  a.cls_row = cls_row; a.heads = heads; a.scale = scale;
+  a.cls_row = cls_row; a.heads = heads; a.scale = scale; a.cls_part = cls_partial;
   hipStream_t s = (hipStream_t)stream;
   if (head_dim == 64 && n_tok <= 8) {
     const int64_t units = n_seq * n_groups * heads;

@@ -632,7 +632,7 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
   const int64_t m_pad = ((M + 255) / 256) * 256;
   const bool fast = !c_map && !r_map && (N % 64) == 0 && (ldc % 4) == 0 && (!R || (ldr % 4) == 0) &&
                     ((uintptr_t)C % 16) == 0 && (!R || ((uintptr_t)R % 16) == 0) && (!bias || ((uintptr_t)bias % 16) == 0) &&
-                    m_pad * ldc * 4 < ((int64_t)1 << 32) && (!R || m_pad * ldr * 4 < ((int64_t)1 << 32));
+                    m_pad * ldc * (c_dtype == SF_BF16 ? 2 : 4) < ((int64_t)1 << 32) && (!R || m_pad * ldr * 4 < ((int64_t)1 << 32));
   GemmArgs a;
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldr;
   a.cmap = sf_rowmap(c_map); a.rmap = sf_rowmap(r_map);

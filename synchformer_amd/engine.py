@@ -15,6 +15,7 @@ workspace stays small; chunking changes nothing numerically (segments are indepe
 the reference's own `for_loop` switch, motionformer.py:200-207).
 """
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -50,7 +51,7 @@ class _LN:
 
 
 class SynchformerEngine:
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device='cuda:0', seg_chunk: int = 27):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device='cuda:0', seg_chunk: int = 112):
         self.dev = torch.device(device)
         if self.dev.type != 'cuda':
             raise RuntimeError('SynchformerEngine needs a HIP device; there is no CPU path in the product')
@@ -212,15 +213,29 @@ class SynchformerEngine:
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         hid = big[:rows * FF].view(rows, FF)
 
+        part = self._buf('cls_part', n * 12 * 196 * 66, torch.float32)
+
+        fuse_mode = os.environ.get('SF_CLS_FUSION', 'space')          # A/B switch: both | space | none (profiles/r01_notes.md)
+
         def divided(kind):
+            if fuse_mode == 'none' or (fuse_mode == 'space' and kind == 'time'):
+                kw = dict(n_groups=196, row0=1, group_stride=1, tok_stride=196, n_tok=8) if kind == 'time' else \
+                    dict(n_groups=8, row0=1, group_stride=196, tok_stride=1, n_tok=196)
+                ops.attention(q, k, v, xn, n_seq=n, seq_rows=VIS_L, cls_row=0, heads=12, head_dim=64, scale=0.125, **kw)
+                ops.attention_cls(q, k, v, xn, n_seq=n, q_seq_rows=VIS_L, q_row=0, kv_seq_rows=VIS_L, kv_row0=0, n_keys=VIS_L,
+                                  out_seq_rows=VIS_L, out_row=0, heads=12, head_dim=64, scale=0.125)
+                return
+            # patches attend [CLS; their group]; the CLS query's attention over ALL tokens (vit_helper.py:126) is accumulated as
+            # per-group partials inside the same kernels (no second pass over K/V) and merged by a tiny combine kernel
             if kind == 'time':   # '(b n) f d' groups (vit_helper.py:343-344)
-                ops.attention(q, k, v, xn, n_seq=n, seq_rows=VIS_L, n_groups=196, row0=1, group_stride=1, tok_stride=196,
-                              n_tok=8, cls_row=0, heads=12, head_dim=64, scale=0.125)
+                ops.attention_cls_partial(q, k, v, xn, part, n_seq=n, seq_rows=VIS_L, n_groups=196, row0=1, group_stride=1,
+                                          tok_stride=196, n_tok=8, cls_row=0, heads=12, head_dim=64, scale=0.125)
+                groups = 196
             else:                # '(b f) n d' groups (vit_helper.py:341-342)
-                ops.attention(q, k, v, xn, n_seq=n, seq_rows=VIS_L, n_groups=8, row0=1, group_stride=196, tok_stride=1,
-                              n_tok=196, cls_row=0, heads=12, head_dim=64, scale=0.125)
-            ops.attention_cls(q, k, v, xn, n_seq=n, q_seq_rows=VIS_L, q_row=0, kv_seq_rows=VIS_L, kv_row0=0,
-                              n_keys=VIS_L, out_seq_rows=VIS_L, out_row=0, heads=12, head_dim=64, scale=0.125)
+                ops.attention_cls_partial(q, k, v, xn, part, n_seq=n, seq_rows=VIS_L, n_groups=8, row0=1, group_stride=196,
+                                          tok_stride=1, n_tok=196, cls_row=0, heads=12, head_dim=64, scale=0.125)
+                groups = 8
+            ops.attention_cls_combine(part, xn, n_part=groups, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
 
         for b in self.v_blocks:   # DividedSpaceTimeBlock.forward (vit_helper.py:364-376)
             ops.layernorm(X, b['norm3'].g, b['norm3'].b, xn, EPS_VIS)

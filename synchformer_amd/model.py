@@ -287,7 +287,7 @@ class Synchformer(torch.nn.Module):
                 m.weight.copy_(synth.fill_tensor(f'{name}.weight', (768, 768), 0))
                 m.bias.copy_(synth.fill_tensor(f'{name}.bias', (768,), 0))
         self._sf_engine = None
-        self.seg_chunk = 27
+        self.seg_chunk = 112
 
     # -- engine cache ---------------------------------------------------------------------------------------
     def _engine(self) -> SynchformerEngine:

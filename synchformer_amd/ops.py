@@ -124,6 +124,26 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     return out
 
 
+def attention_cls_partial(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, *, n_seq: int,
+                          seq_rows: int, n_groups: int, row0: int, group_stride: int, tok_stride: int, n_tok: int, cls_row: int, heads: int,
+                          head_dim: int, scale: float):
+    """`attention` + per-group partials of the CLS query into `partials` (fp32, >= n_seq*heads*n_groups*66 elements)."""
+    assert q.dtype == k.dtype == v.dtype == out.dtype == torch.bfloat16 and partials.dtype == torch.float32
+    assert _ld(q) == _ld(k) == _ld(v) and partials.numel() >= n_seq * heads * n_groups * 66
+    rc = _lib.load().sf_attention_cls_partial(_dev(q, 'q'), _dev(k, 'k'), _dev(v, 'v'), _ld(q), _dev(out, 'out'), _ld(out), n_seq, seq_rows,
+                                              n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim, float(scale),
+                                              _dev(partials, 'partials'), _stream())
+    _lib.check(rc, 'sf_attention_cls_partial')
+    return out
+
+
+def attention_cls_combine(partials: torch.Tensor, out: torch.Tensor, *, n_part: int, n_seq: int, out_seq_rows: int, out_row: int, heads: int):
+    rc = _lib.load().sf_attention_cls_combine(_dev(partials, 'partials'), n_part, _dev(out, 'out'), _ld(out), out_seq_rows, out_row, n_seq, heads,
+                                              _stream())
+    _lib.check(rc, 'sf_attention_cls_combine')
+    return out
+
+
 def attention_cls(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, n_seq: int, q_seq_rows: int,
                   q_row: int, kv_seq_rows: int, kv_row0: int, n_keys: int, out_seq_rows: int, out_row: int, heads: int,
                   head_dim: int, scale: float):

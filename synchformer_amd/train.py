@@ -64,7 +64,7 @@ def trainable_keys(schema) -> List[str]:
 
 class SyncTrainer:
     def __init__(self, state_dict: Dict[str, torch.Tensor], device='cuda:0', lr: float = 2e-6, betas=(0.9, 0.999), eps: float = 1e-7,
-                 max_clip_norm: float = 1.0, dropout: float = 0.0, seg_chunk: int = 27, engine: Optional[SynchformerEngine] = None):
+                 max_clip_norm: float = 1.0, dropout: float = 0.0, seg_chunk: int = 112, engine: Optional[SynchformerEngine] = None):
         if dropout and dropout > 0:
             raise NotImplementedError('the HIP train step implements dropout p = 0 only (embd/resid/attn_pdrop of configs/sync.yaml '
                                       'must be set to 0.0); dropout masks are the next item (DESIGN.md §7)')

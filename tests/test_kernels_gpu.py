@@ -203,6 +203,17 @@ def test_divided_attention(gpu, mode):
     ops.attention_cls(q, k, v, out, n_seq=N, q_seq_rows=L, q_row=0, kv_seq_rows=L, kv_row0=0, n_keys=L, out_seq_rows=L,
                       out_row=0, heads=12, head_dim=64, scale=0.125)
     torch.testing.assert_close(out.float().cpu().reshape(N, L, 768), ref, rtol=2e-2, atol=2e-2)
+    # fused variant: CLS-query partials from the same kernel + combine must reproduce row 0 and leave the patches unchanged
+    out2 = torch.zeros_like(out)
+    groups = 196 if mode == 'time' else 8
+    part = torch.empty(N * 12 * groups * 66, device=gpu)
+    kw = dict(n_groups=196, row0=1, group_stride=1, tok_stride=196, n_tok=8) if mode == 'time' else \
+        dict(n_groups=8, row0=1, group_stride=196, tok_stride=1, n_tok=196)
+    ops.attention_cls_partial(q, k, v, out2, part, n_seq=N, seq_rows=L, cls_row=0, heads=12, head_dim=64, scale=0.125, **kw)
+    ops.attention_cls_combine(part, out2, n_part=groups, n_seq=N, out_seq_rows=L, out_row=0, heads=12)
+    o1, o2 = out.float().cpu().reshape(N, L, 768), out2.float().cpu().reshape(N, L, 768)
+    assert torch.equal(o1[:, 1:], o2[:, 1:])
+    torch.testing.assert_close(o2[:, 0], ref[:, 0], rtol=2e-2, atol=2e-2)
 
 
 @pytest.mark.parametrize('L,heads,d', [(74, 12, 64), (198, 8, 96), (184, 8, 96), (13, 12, 64), (197, 12, 64), (17, 12, 64)])
