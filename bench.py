@@ -39,6 +39,8 @@ def parse():
     ap.add_argument('--seg-chunk', type=int, default=112)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL over xGMI; default) | gloo (plumbing tests)')
+    ap.add_argument('--single-device', action='store_true', help='TEST ONLY: put every rank on cuda:0 (needs --dist-backend gloo)')
     ap.add_argument('--workload', choices=['infer', 'train'], default='infer',
                     help="infer = BASELINE configs[1] (headline metric); train = configs[2]: Stage-2 step, frozen extractors, "
                          "backward + RCCL gradient all-reduce + fused clip/Adam (dropout 0)")
@@ -119,11 +121,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N > 1')
+    if args.single_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from synchformer_amd import synth
     from synchformer_amd.engine import SynchformerEngine

@@ -403,9 +403,11 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES_PER_SIMD) void gemm_bf
 #define PBN 256
 #define PBK 64
 #define P_STAGE (2 * PBM * PBK * 2)       // 64 KiB: A tile + B tile
-#define P_LDS (2 * P_STAGE)
+#define P_EPI_LD 64                       // unpadded slab rows: conflict-free for the 32x32 C layout (32 consecutive lanes = 32 consecutive columns)
 #define P_SLAB_ROWS 16
-#define P_SLAB_BYTES (P_SLAB_ROWS * EPI_LD * 4)
+#define P_SLAB_BYTES (P_SLAB_ROWS * P_EPI_LD * 4)   // 4 KiB per wave
+#define P_LDS (2 * P_STAGE + 8 * P_SLAB_BYTES)      // 160 KiB: two ring slots + a private epilogue region, so BOTH slots of the
+                                                    // next tile can be in flight while this tile's epilogue runs
 
 template <bool OUT_BF16, bool GELU, bool HAS_RES>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p) {
@@ -455,12 +457,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p
   int64_t m0; int n0;
   set_tile(t, m0, n0);
   stage(0, 0);
-  float* slab = reinterpret_cast<float*>(smem + P_STAGE + wave * P_SLAB_BYTES);
+  float* slab = reinterpret_cast<float*>(smem + 2 * P_STAGE + wave * P_SLAB_BYTES);
   const int ecol = (lane & 15) * 4;
   const uint32_t esz = OUT_BF16 ? 2u : 4u;
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, (short)0, (int)(uint32_t)(p.M * p.ldc * esz), 0x00020000);
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), (short)0, HAS_RES ? (int)(uint32_t)(p.M * p.ldr * 4) : 0, 0x00020000);
   const uint32_t cstep = (uint32_t)(4 * p.ldc) * esz, rstep = (uint32_t)(4 * p.ldr) * 4u;
+  bool stage1_in_flight = false;
+  if (nk > 1) { stage(1, 1); stage1_in_flight = true; }
 
   for (;;) {
     f32x16 acc[4][2];
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p
 
     for (int kt = 0; kt < nk; ++kt) {
       wait_vmcnt_barrier<0>();                                   // tile kt landed everywhere; slot (kt+1)&1 is free
-      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+      if (kt + 1 < nk && !(kt == 0 && stage1_in_flight)) stage((kt + 1) & 1, kt + 1);
       const char* sa = smem + (kt & 1) * P_STAGE + a_base;
       const char* sb = smem + (kt & 1) * P_STAGE + b_base;
 #pragma unroll
@@ -496,7 +500,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p
     const int64_t em0 = m0; const int en0 = n0;
     const uint32_t tnext = t + per_xcd_blocks;
     const bool more = tnext < t_end;
-    if (more) { set_tile(tnext, m0, n0); stage(0, 0); }
+    stage1_in_flight = false;
+    if (more) { set_tile(tnext, m0, n0); stage(0, 0); if (nk > 1) { stage(1, 1); stage1_in_flight = true; } }
 
     // ---- epilogue of tile (em0, en0): 8 branch-free groups of 16 rows x 64 cols through this wave's slab -------
     if (en0 + wn * 64 < p.N) {                                   // wave-uniform (N % 64 == 0 on this path)
@@ -519,10 +524,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p
           for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              slab[(qq * 8 + hi * 4 + r) * EPI_LD + j * 32 + l31] = acc[i][j][(q2 * 2 + qq) * 4 + r];
+              slab[(qq * 8 + hi * 4 + r) * P_EPI_LD + j * 32 + l31] = acc[i][j][(q2 * 2 + qq) * 4 + r];
         float4 v[4];
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) v[ps] = *reinterpret_cast<const float4*>(slab + (ps * 4 + (lane >> 4)) * EPI_LD + ecol);
+        for (int ps = 0; ps < 4; ++ps) v[ps] = *reinterpret_cast<const float4*>(slab + (ps * 4 + (lane >> 4)) * P_EPI_LD + ecol);
         if (!(SF_ABL & 1)) epi_group_store<OUT_BF16, GELU, HAS_RES>(v, bias4, res[g & 1], rc, coff0 + g * 4 * cstep, cstep);
         else if (v[0].x == 1.2345e30f) epi_group_store<OUT_BF16, GELU, HAS_RES>(v, bias4, res[g & 1], rc, coff0, cstep);
       }
