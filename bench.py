@@ -43,7 +43,7 @@ def parse():
     ap.add_argument('--single-device', action='store_true', help='TEST ONLY: put every rank on cuda:0 (needs --dist-backend gloo)')
     ap.add_argument('--workload', choices=['infer', 'train'], default='infer',
                     help="infer = BASELINE configs[1] (headline metric); train = configs[2]: Stage-2 step, frozen extractors, "
-                         "backward + RCCL gradient all-reduce + fused clip/Adam (dropout 0)")
+                         "backward + RCCL gradient all-reduce + fused clip/Adam (dropout 0.1 as in sync.yaml)")
     return ap.parse_args()
 
 
@@ -137,7 +137,8 @@ def main():
     B = args.batch
     if args.workload == 'train':
         from synchformer_amd.train import SyncTrainer
-        trainer = SyncTrainer(synth.make_state_dict(1337), dev, lr=2e-6 * world, seg_chunk=args.seg_chunk)
+        trainer = SyncTrainer(synth.make_state_dict(1337), dev, lr=2e-6 * world, seg_chunk=args.seg_chunk, embd_pdrop=0.1, resid_pdrop=0.1,
+                              attn_pdrop=0.1, seed=1337 + rank)
         eng = trainer.engine
         targets = synth.make_targets(B, 21, seed=1337 + rank).to(dev)
         step_fn = lambda v, a: trainer.train_step(v, a, targets)
@@ -179,7 +180,7 @@ def main():
             'config': {'workload': ('BASELINE configs[1]: batched offset inference, configs/sync.yaml model (237.5M params, '
                                     'random-init), uint8 224x224 frames + 128x66 log-mel resident in HBM, full forward to 21-way logits')
                        if args.workload == 'infer' else
-                       ('BASELINE configs[2]: Stage-2 sync-module train step (configs/sync.yaml, dropout 0): frozen extractors forward, '
+                       ('BASELINE configs[2]: Stage-2 sync-module train step (configs/sync.yaml, embd/resid/attn dropout 0.1): frozen extractors forward, '
                         'backward of proj + sync transformer (22.6M params), flat 90 MB RCCL gradient all-reduce, fused clip+Adam'),
                        'clips_per_gpu': B, 'segments': 14, 'seg_chunk': args.seg_chunk,
                        'parallelism': f'replicas x{world}' if args.workload == 'infer' else f'dp{world}'},

@@ -150,6 +150,11 @@ int sf_gelu_bwd(const uint16_t* pre, const float* dact, uint16_t* dpre, int64_t 
 /* loss = mean cross-entropy of (B, C) logits vs int64 targets (sync_model.py:95-96); dlogits (optional) scaled by grad_scale / B. */
 int sf_cross_entropy(const float* logits, int64_t ld, const int64_t* targets, int B, int C, float* loss, float* dlogits, int64_t ldd,
                      float grad_scale, void* stream);
+/* y = dropout_p(x) (+ residual): keep(i) = hash(seed, i) >= p * 2^32 over the linear element index i, kept values scaled by
+ * 1/(1-p); x, y fp32|bf16 (same dtype), residual fp32 or NULL (fp32 x only).  The same (seed, shape) regenerates the mask in
+ * the backward.  Dropout sites: sync_model.py:166, modules/transformer.py:70,73,90. */
+int sf_dropout(const void* x, int dtype, int64_t ldx, const float* residual, int64_t ldr, void* y, int64_t ldy, int64_t rows, int cols,
+               float p, uint32_t seed, void* stream);
 /* norm_out[0] = ||g||_2 of a flat fp32 buffer (deterministic two-stage; workspace fp32 1024). */
 int sf_grad_norm(const float* g, int64_t n, float* norm_out, float* workspace, void* stream);
 /* clip_grad_norm_(max_norm, device-resident norm) + Adam(betas, eps, no weight decay) on flat fp32 buffers; also writes the

@@ -179,29 +179,40 @@ def ast_segments(x, sd, p='afeat_extractor', depth=None):
 # ----------------------------------------------------------------------------------------------------
 # Sync transformer + top level
 # ----------------------------------------------------------------------------------------------------
-def sync_block(x, sd, p, heads=8):
-    """Block / SelfAttention (modules/transformer.py:79-97, :31-76), eval mode (dropouts off)."""
+def sync_block(x, sd, p, heads=8, masks=None):
+    """Block / SelfAttention (modules/transformer.py:79-97, :31-76).  `masks` (tests only) = explicit dropout multipliers
+    {'attn': (N,h,L,L), 'proj': (N,L,D), 'mlp': (N,L,D)} (already scaled by 1/(1-p)) standing in for attn_drop / resid_drop /
+    the MLP's Dropout of train mode (:70, :73, :90); None = eval mode."""
     N, L, Dm = x.shape
     d = Dm // heads
+    masks = masks or {}
     y = _ln(x, sd, p + '.ln1', EPS_SYNC)
 
     def hd(name):
         return _lin(y, sd, f'{p}.attn.{name}').reshape(N, L, heads, d).transpose(1, 2)
-    a = _softmax_attn(hd('query'), hd('key'), hd('value'), 1.0 / math.sqrt(d))
-    x = x + _lin(a.transpose(1, 2).reshape(N, L, Dm), sd, p + '.attn.proj')
-    return x + _lin(_gelu(_lin(_ln(x, sd, p + '.ln2', EPS_SYNC), sd, p + '.mlp.0')), sd, p + '.mlp.2')
+    att = torch.softmax(torch.matmul(hd('query'), hd('key').transpose(-1, -2)) * (1.0 / math.sqrt(d)), dim=-1)
+    if 'attn' in masks:
+        att = att * masks['attn']
+    a = torch.matmul(att, hd('value'))
+    br = _lin(a.transpose(1, 2).reshape(N, L, Dm), sd, p + '.attn.proj')
+    x = x + (br * masks['proj'] if 'proj' in masks else br)
+    br = _lin(_gelu(_lin(_ln(x, sd, p + '.ln2', EPS_SYNC), sd, p + '.mlp.0')), sd, p + '.mlp.2')
+    return x + (br * masks['mlp'] if 'mlp' in masks else br)
 
 
-def global_transformer(v, a, sd, p='transformer', apply_head=True):
+def global_transformer(v, a, sd, p='transformer', apply_head=True, masks=None):
     """GlobalTransformer.forward (sync_model.py:150-173).  v (B, Sv, D), a (B, Sa, D) -> logits (B, n_cls)
     (or the ln_f output (B, 1+Sv+1+Sa, D) when apply_head is False)."""
     B = v.shape[0]
     v, a = _ln(v, sd, p + '.vis_in_lnorm', EPS_SYNC), _ln(a, sd, p + '.aud_in_lnorm', EPS_SYNC)
     x = torch.cat([sd[p + '.OFF_tok'].expand(B, 1, -1), v, sd[p + '.MOD_tok'].expand(B, 1, -1), a], 1)
     x = x + sd[p + '.pos_emb_cfg.pos_emb'][:, :x.shape[1]]
+    masks = masks or {}
+    if 'embd' in masks:                                               # self.drop(x) in train mode (sync_model.py:166)
+        x = x * masks['embd']
     i = 0
     while f'{p}.blocks.{i}.ln1.weight' in sd:
-        x = sync_block(x, sd, f'{p}.blocks.{i}')
+        x = sync_block(x, sd, f'{p}.blocks.{i}', masks=masks.get(i))
         i += 1
     x = _ln(x, sd, p + '.ln_f', EPS_SYNC)
     if not apply_head:

@@ -9,3 +9,6 @@ from .model import (AST, DoNothingBridge, GlobalTransformer, GlobalTransformerWi
 __all__ = ['Synchformer', 'MotionFormer', 'AST', 'GlobalTransformer', 'GlobalTransformerWithSyncabilityHead',
            'RandInitPositionalEncoding', 'DoNothingBridge', 'instantiate_from_config', 'get_obj_from_str',
            'install_reference_aliases', 'uninstall_reference_aliases', 'sync_yaml_model_config']
+
+from . import ops as _ops  # noqa: E402
+_ops.register_torch_ops()      # torch.ops.synchformer.* (dispatcher-visible leaf ops)

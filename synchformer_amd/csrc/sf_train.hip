@@ -414,3 +414,49 @@ extern "C" int sf_adam_clip_step(float* p, const float* g, float* m, float* v, u
   SF_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Dropout with a counter-based mask (no mask tensor is stored: backward regenerates it from (seed, element index)):
+//   keep(i) = hash(seed, i) >= p * 2^32;   y[i] = (keep ? x[i] / (1 - p) : 0) (+ r[i])
+// Sites of the reference's train mode: embd_pdrop on the assembled sequence (sync_model.py:166), resid_pdrop after the
+// attention projection and after the MLP (modules/transformer.py:73,90), attn_pdrop on the attention probabilities (:70).
+// The mask stream differs from torch's Philox stream, so parity with the reference under dropout is statistical; with the
+// masks read back from this kernel the oracle reproduces loss and gradients exactly (tests/test_train_gpu.py).
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t seed, uint32_t idx) {
+  uint32_t h = idx * 0x9E3779B1u ^ seed;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  h += seed * 0x27D4EB2Fu;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return h;
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void dropout_kernel(const void* __restrict__ x, int64_t ldx, const float* __restrict__ r, int64_t ldr,
+                                                       void* __restrict__ y, int64_t ldy, int64_t rows, int cols, uint32_t thresh, float keep_scale,
+                                                       uint32_t seed) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int64_t row = i / cols; const int c = (int)(i - row * cols);
+  const bool keep = mix32(seed, (uint32_t)i) >= thresh;
+  float v = BF16 ? bf2f(reinterpret_cast<const bf16_t*>(x)[row * ldx + c]) : reinterpret_cast<const float*>(x)[row * ldx + c];
+  v = keep ? v * keep_scale : 0.f;
+  if (r) v += r[row * ldr + c];
+  if (BF16) reinterpret_cast<bf16_t*>(y)[row * ldy + c] = f2bf(v);
+  else reinterpret_cast<float*>(y)[row * ldy + c] = v;
+}
+
+extern "C" int sf_dropout(const void* x, int dtype, int64_t ldx, const float* residual, int64_t ldr, void* y, int64_t ldy, int64_t rows,
+                          int cols, float p, uint32_t seed, void* stream) {
+  SF_CHECK_ARG(x && y && (dtype == SF_F32 || dtype == SF_BF16) && p >= 0.f && p < 1.f, "sf_dropout: bad arguments");
+  SF_CHECK_ARG(rows * (int64_t)cols < ((int64_t)1 << 32), "sf_dropout: more than 2^32 elements");
+  const int64_t n = rows * cols;
+  if (n <= 0) return 0;
+  const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+  const float ks = 1.0f / (1.0f - p);
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (dtype == SF_BF16) hipLaunchKernelGGL((dropout_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, residual, ldr, y, ldy, rows, cols, thresh, ks, seed);
+  else hipLaunchKernelGGL((dropout_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, residual, ldr, y, ldy, rows, cols, thresh, ks, seed);
+  SF_LAUNCH_CHECK();
+  return 0;
+}

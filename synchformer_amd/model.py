@@ -327,9 +327,7 @@ class Synchformer(torch.nn.Module):
                and not n.startswith('vfeat_extractor.patch_embed.')):
             raise NotImplementedError('only Stage-2 training with frozen extractors (is_trainable: False, configs/sync.yaml:7,19) has a '
                                       'backward; requires_grad_(False) the extractors as scripts/train_utils.py:199-204 does')
-        if self.training and any(v and v > 0 for v in getattr(self.transformer, 'pdrops', {}).values()):
-            raise NotImplementedError('the HIP train step implements dropout p = 0 only: set embd_pdrop / resid_pdrop / attn_pdrop '
-                                      'to 0.0 in the transformer config (dropout masks: DESIGN.md §7)')
+        pd = getattr(self.transformer, 'pdrops', {}) if self.transformer.training else {}
         if any(not p.requires_grad for p in trainable.values()):
             raise NotImplementedError('partially frozen sync transformer is not supported')
         eng = self._engine()
@@ -338,6 +336,7 @@ class Synchformer(torch.nn.Module):
             tr = SyncTrainer(self.state_dict(), next(self.parameters()).device, engine=eng)
             object.__setattr__(self, '_sf_trainer', tr)
             object.__setattr__(self, '_sf_trainer_key', None)
+        tr.embd_pdrop, tr.resid_pdrop, tr.attn_pdrop = (float(pd.get(k) or 0.0) for k in ('embd_pdrop', 'resid_pdrop', 'attn_pdrop'))
         key = tuple((p.data_ptr(), p._version) for p in trainable.values())
         if key != self._sf_trainer_key:                      # an external optimizer moved the nn.Parameters
             tr.load_params({k: p.detach() for k, p in trainable.items()})

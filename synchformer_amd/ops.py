@@ -154,3 +154,47 @@ def attention_cls(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.
                                       head_dim, float(scale), _stream())
     _lib.check(rc, 'sf_attention_cls')
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# PyTorch dispatcher registration (SURVEY §8b "custom-op contract"): the C-ABI launchers as `torch.ops.synchformer.*`
+# out-variant custom ops (device_types = "cuda", i.e. HIP on ROCm).  They mutate their `out` argument and return nothing,
+# which keeps them usable under torch.no_grad / autocast-free eager code and visible to the dispatcher; autograd for
+# training goes through synchformer_amd.train.SyncTrainFunction, not through these leaf ops.
+# ----------------------------------------------------------------------------------------------------------------------
+_registered = False
+
+
+def register_torch_ops():
+    global _registered
+    if _registered:
+        return
+    from torch.library import custom_op
+
+    @custom_op('synchformer::gemm_bf16', mutates_args=('out',), device_types='cuda')
+    def _gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, residual: Optional[torch.Tensor],
+              gelu: bool) -> None:
+        gemm(a, w, bias, out, residual=residual, gelu=gelu)
+
+    @custom_op('synchformer::layernorm768', mutates_args=('out',), device_types='cuda')
+    def _ln(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, eps: float) -> None:
+        layernorm(x, gamma, beta, out, eps)
+
+    @custom_op('synchformer::attention', mutates_args=('out',), device_types='cuda')
+    def _attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, n_seq: int, seq_rows: int, n_groups: int, row0: int,
+              group_stride: int, tok_stride: int, n_tok: int, cls_row: int, heads: int, head_dim: int, scale: float) -> None:
+        attention(q, k, v, out, n_seq=n_seq, seq_rows=seq_rows, n_groups=n_groups, row0=row0, group_stride=group_stride,
+                  tok_stride=tok_stride, n_tok=n_tok, cls_row=cls_row, heads=heads, head_dim=head_dim, scale=scale)
+
+    @custom_op('synchformer::attention_cls', mutates_args=('out',), device_types='cuda')
+    def _attn_cls(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, n_seq: int, q_seq_rows: int, q_row: int,
+                  kv_seq_rows: int, kv_row0: int, n_keys: int, out_seq_rows: int, out_row: int, heads: int, head_dim: int,
+                  scale: float) -> None:
+        attention_cls(q, k, v, out, n_seq=n_seq, q_seq_rows=q_seq_rows, q_row=q_row, kv_seq_rows=kv_seq_rows, kv_row0=kv_row0,
+                      n_keys=n_keys, out_seq_rows=out_seq_rows, out_row=out_row, heads=heads, head_dim=head_dim, scale=scale)
+
+    @custom_op('synchformer::im2col_video', mutates_args=('out',), device_types='cuda')
+    def _im2col(vid: torch.Tensor, out: torch.Tensor) -> None:
+        im2col_video(vid, out)
+
+    _registered = True

