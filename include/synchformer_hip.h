@@ -162,6 +162,15 @@ int sf_grad_norm(const float* g, int64_t n, float* norm_out, float* workspace, v
 int sf_adam_clip_step(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n, const float* norm, float max_norm,
                       float lr, float beta1, float beta2, float eps, int step, void* stream);
 
+/* ---- Stage-1 segment-level contrastive head (train_clip_src/open_clip/model.py:449-585) ------------------------------ */
+/* y[r, :768] = mean_j x[r*t + j, :768], then (normalize != 0) divided by max(||.||_2, 1e-12):  AveragePooling 'BS t D -> BS D'
+ * (motionformer.py:395-409, ast.py:87-88) and F.normalize (open_clip/model.py:530-531); fp32, row strides % 4 == 0. */
+int sf_meanpool_l2norm768(const float* x, int64_t ldx, int t, float* y, int64_t ldy, int normalize, int64_t n, void* stream);
+/* out[i, j] = scale * <a_i, b_j> for fp32 a (n, d), b (m, d), d % 16 == 0: sim = feat @ feat_all^T / logit_scale
+ * (open_clip/model.py:508-509); kept in fp32 because scale can be as large as 1 / 0.001. */
+int sf_similarity_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int n, int m, int d, float scale,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -251,6 +251,22 @@ def synchformer_forward(sd, vis, aud, targets=None, chunk=None):
     return loss, logits
 
 
+def avclip_forward(sd, vis, aud, logit_scale=0.07, vfeat_all=None, afeat_all=None, chunk=None):
+    """Stage-1 AVCLIP.forward with alpha = 0 (train_clip_src/open_clip/model.py:475-533): towers with
+    agg_time_module='AveragePooling' (mean over the t aggregated tokens, motionformer.py:139,246 / ast.py:88), DoNothingBridge
+    projections, F.normalize, sim = feat @ feat_all^T / logit_scale, eye(n, m) soft targets (:512-518), symmetric CE (:520-523).
+    `*_all` default to the local features (world_size == 1 / gather_for_loss False).  -> dict(vfeat, afeat, sim_v2a, sim_a2v, loss)."""
+    vfeat = F.normalize(extract_vfeats(vis, sd, chunk).mean(2).flatten(0, 1), dim=-1)      # (B*S, D)
+    afeat = F.normalize(extract_afeats(aud, sd).mean(2).flatten(0, 1), dim=-1)
+    vfeat_all = vfeat if vfeat_all is None else vfeat_all
+    afeat_all = afeat if afeat_all is None else afeat_all
+    sim_v2a = vfeat @ afeat_all.mT / logit_scale
+    sim_a2v = afeat @ vfeat_all.mT / logit_scale
+    tgt = torch.eye(*sim_v2a.shape, dtype=sim_v2a.dtype)
+    loss = (F.cross_entropy(sim_v2a, tgt) + F.cross_entropy(sim_a2v, tgt)) / 2
+    return dict(vfeat=vfeat, afeat=afeat, sim_v2a=sim_v2a, sim_a2v=sim_a2v, loss=loss)
+
+
 # ----------------------------------------------------------------------------------------------------
 # Deterministic input front-ends (dataset/transforms.py)
 # ----------------------------------------------------------------------------------------------------

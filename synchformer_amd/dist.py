@@ -51,3 +51,14 @@ def gather_logits(local: torch.Tensor, n_total: int) -> Optional[torch.Tensor]:
     if rank != 0:
         return None
     return torch.cat([o[:e - s] for o, (s, e) in zip(out, sizes)], 0)
+
+
+def all_gather_rows(local: torch.Tensor) -> torch.Tensor:
+    """Concatenate equally-shaped per-rank (n, D) embedding blocks in rank order -> (world * n, D): the forward half of
+    `torch.cat(torch.distributed.nn.all_gather(x))` in AVCLIP.forward (open_clip/model.py:489-491).  One all-gather of
+    n * 768 fp32 per modality per step (RCCL over xGMI on GPUs); identity without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    out = torch.empty(dist.get_world_size() * local.shape[0], *local.shape[1:], dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out

@@ -310,6 +310,41 @@ class SynchformerEngine:
         return out.view(B, S, nt, D)
 
     # ------------------------------------------------------------------------------------------------
+    # Stage-1 segment-level contrastive head (AVCLIP, train_clip_src/open_clip/model.py:449-585)
+    # ------------------------------------------------------------------------------------------------
+    def pool_segments(self, feat: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+        """(B, S, t, 768) aggregator outputs -> (B*S, 768): AveragePooling 'BS t D -> BS D' (motionformer.py:139, ast.py:88),
+        optionally followed by F.normalize (AVCLIP.encode_stream, open_clip/model.py:522-533)."""
+        B, S, t = feat.shape[:3]
+        f2 = feat.reshape(B * S * t, D)
+        if not f2.is_contiguous():
+            f2 = f2.contiguous()
+        out = torch.empty(B * S, D, device=self.dev, dtype=torch.float32)
+        return ops.meanpool_l2norm(f2, out, t, normalize)
+
+    def l2_normalize(self, x: torch.Tensor) -> torch.Tensor:
+        out = torch.empty_like(x)
+        return ops.meanpool_l2norm(x.contiguous(), out, 1, True)
+
+    def contrastive_loss(self, vfeat: torch.Tensor, afeat: torch.Tensor, vfeat_all: torch.Tensor, afeat_all: torch.Tensor,
+                         logit_scale: float, row_offset: int = 0):
+        """AVCLIP.compute_loss (open_clip/model.py:506-525) with alpha = 0: sim_v2a = vfeat @ afeat_all^T / scale (and a2v),
+        targets = eye(n, m) i.e. class `row_offset + i` for row i, loss = (CE(v2a) + CE(a2v)) / 2.
+        NOTE the reference's eye(n, m) puts the positive of LOCAL row i at column i even when features were gathered
+        from other ranks (row_offset stays 0 there, open_clip/model.py:516); `row_offset` is only for callers who want
+        the rank-aware diagonal.  Returns (loss (1,) fp32, sim_v2a, sim_a2v)."""
+        n, m = vfeat.shape[0], afeat_all.shape[0]
+        sim_v2a = torch.empty(n, m, device=self.dev, dtype=torch.float32)
+        sim_a2v = torch.empty(n, vfeat_all.shape[0], device=self.dev, dtype=torch.float32)
+        ops.similarity(vfeat, afeat_all, sim_v2a, 1.0 / logit_scale)
+        ops.similarity(afeat, vfeat_all, sim_a2v, 1.0 / logit_scale)
+        tgt = torch.arange(row_offset, row_offset + n, device=self.dev, dtype=torch.int64)
+        losses = torch.empty(2, device=self.dev, dtype=torch.float32)
+        ops.cross_entropy(sim_v2a, tgt, losses[0:1])
+        ops.cross_entropy(sim_a2v, tgt, losses[1:2])
+        return losses, sim_v2a, sim_a2v
+
+    # ------------------------------------------------------------------------------------------------
     # sync transformer + top level
     # ------------------------------------------------------------------------------------------------
     def project(self, feat: torch.Tensor, which: str) -> torch.Tensor:

@@ -34,6 +34,7 @@ _TARGET_ALIASES = {
     'model.modules.feat_extractors.audio.ast.AST': 'AST',
     'model.modules.transformer.RandInitPositionalEncoding': 'RandInitPositionalEncoding',
     'model.modules.bridges.DoNothingBridge': 'DoNothingBridge',
+    'model.modules.feat_extractors.train_clip_src.open_clip.model.AVCLIP': 'AVCLIP',
 }
 
 
@@ -110,6 +111,23 @@ class RandInitPositionalEncoding(torch.nn.Module):
         return token_embeddings + self.pos_emb
 
 
+def _parse_agg_time(agg_time_module) -> bool:
+    """True for 'AveragePooling' (Stage-1, configs/segment_avclip.yaml:21,33), False for torch.nn.Identity (Stage-2)."""
+    if agg_time_module == 'AveragePooling':
+        return True
+    if agg_time_module is not None and 'Identity' in agg_time_module:
+        return False
+    raise NotImplementedError(f"agg_time_module={agg_time_module!r}: 'AveragePooling' and 'torch.nn.Identity' are built natively; "
+                              "the temporal TransformerEncoderLayer aggregator is not used by the shipped configs")
+
+
+def _no_extractor_backward(module: torch.nn.Module):
+    """The extractors have a forward only (Stage-1 fine-tuning of the towers needs their backward: SURVEY §8 a22/a24, next)."""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise NotImplementedError(f'{type(module).__name__}: no backward through the HIP feature extractors yet - call under '
+                                  'torch.no_grad() or requires_grad_(False) the module (scripts/train_utils.py:199-204)')
+
+
 class MotionFormer(torch.nn.Module):
     """motionformer.py:24-272 (divided space-time, factorised spatial aggregation).  Parameter holder + standalone
     feature extractor; inside `Synchformer` the engine reads these parameters directly."""
@@ -121,8 +139,7 @@ class MotionFormer(torch.nn.Module):
         if not extract_features or not factorize_space_time or agg_space_module != 'TransformerEncoderLayer':
             raise NotImplementedError('only extract_features=True, factorize_space_time=True, '
                                       "agg_space_module='TransformerEncoderLayer' (configs/sync.yaml) is built natively")
-        if agg_time_module is None or 'Identity' not in agg_time_module:
-            raise NotImplementedError(f'agg_time_module={agg_time_module!r}: only torch.nn.Identity (Stage-2 configs) so far')
+        self.pool_time = _parse_agg_time(agg_time_module)
         if add_global_repr:
             raise NotImplementedError('add_global_repr=True (global segment aggregation) is outside the hot path')
         if ckpt_path is not None:
@@ -135,11 +152,16 @@ class MotionFormer(torch.nn.Module):
         logging.info(f'vfeat_extractor: {sum(p.numel() for p in self.parameters() if p.requires_grad):,}')
 
     def forward(self, x, for_loop: bool = False, cont_mask: torch.Tensor = None):
-        """x (B, S, C, T, H, W) -> ((B, S, 8, 768), None)  (motionformer.py:182-223)."""
+        """x (B, S, C, T, H, W) -> ((B, S, 8, 768), None), or ((B, S, 768), None) with agg_time_module='AveragePooling'
+        (motionformer.py:182-223)."""
         if cont_mask is not None:
             raise NotImplementedError('cont_mask (token masking) is not implemented yet (SURVEY §8f rank 2)')
+        _no_extractor_backward(self)
         eng = _engine_for(self, 'vfeat_extractor.')
-        return eng.extract_vfeats(x.permute(0, 1, 3, 2, 4, 5).contiguous()), None
+        feat = eng.extract_vfeats(x.permute(0, 1, 3, 2, 4, 5).contiguous())
+        if self.pool_time:
+            feat = eng.pool_segments(feat).view(feat.shape[0], feat.shape[1], -1)
+        return feat, None
 
 
 class AST(torch.nn.Module):
@@ -153,8 +175,7 @@ class AST(torch.nn.Module):
         if not extract_features or not factorize_freq_time or agg_freq_module != 'TransformerEncoderLayer':
             raise NotImplementedError('only extract_features=True, factorize_freq_time=True, '
                                       "agg_freq_module='TransformerEncoderLayer' (configs/sync.yaml) is built natively")
-        if agg_time_module is None or 'Identity' not in agg_time_module:
-            raise NotImplementedError(f'agg_time_module={agg_time_module!r}: only torch.nn.Identity (Stage-2 configs) so far')
+        self.pool_time = _parse_agg_time(agg_time_module)
         if add_global_repr:
             raise NotImplementedError('add_global_repr=True (global segment aggregation) is outside the hot path')
         if ckpt_path is not None:
@@ -166,12 +187,17 @@ class AST(torch.nn.Module):
         _register_tree(self, synth.state_dict_schema(), 'afeat_extractor.', _seed)
 
     def forward(self, x, for_loop: bool = False, cont_mask: torch.Tensor = None, **ast_kwargs):
-        """x (B, S, T, F) -> ((B, S, 6, 768), None)  (ast.py:137-176)."""
+        """x (B, S, T, F) -> ((B, S, 6, 768), None), or ((B, S, 768), None) with agg_time_module='AveragePooling'
+        (ast.py:137-176)."""
         if cont_mask is not None:
             raise NotImplementedError('cont_mask (token masking) is not implemented yet (SURVEY §8f rank 2)')
+        _no_extractor_backward(self)
         eng = _engine_for(self, 'afeat_extractor.')
         B, S, T, Fq = x.shape
-        return eng.extract_afeats(x.permute(0, 1, 3, 2).reshape(B, S, 1, Fq, T)), None
+        feat = eng.extract_afeats(x.permute(0, 1, 3, 2).reshape(B, S, 1, Fq, T))
+        if self.pool_time:
+            feat = eng.pool_segments(feat).view(B, S, -1)
+        return feat, None
 
 
 class GlobalTransformer(torch.nn.Module):
@@ -375,6 +401,113 @@ class Synchformer(torch.nn.Module):
                 raise ValueError(f'Cant load state dict with shorter seq len ({weight_len} vs {self_len})')
         self._sf_engine = None
         return super().load_state_dict(sd, strict)
+
+
+class AVCLIP(torch.nn.Module):
+    """Stage-1 segment-level audio-visual contrastive model (train_clip_src/open_clip/model.py:449-585,
+    configs/segment_avclip.yaml:4-46): same constructor, attribute names (`v_encoder`, `a_encoder`, `vproj`, `aproj`,
+    `logit_scale`) and output dict.  Forward / evaluation only: the towers have no backward yet, so calling it with
+    autograd enabled on trainable towers raises (SURVEY §8 a22/a24 are the next rows)."""
+
+    def __init__(self, n_embd: int, afeat_extractor, vfeat_extractor, aproj, vproj, init_scale: float = 0.07,
+                 clamp_scale_min: float = 0.001, clamp_scale_max: float = 0.5, gather_for_loss: bool = False):
+        super().__init__()
+        self.output_dict = True
+        self.n_embd = n_embd
+        self.v_encoder = instantiate_from_config(vfeat_extractor)
+        self.a_encoder = instantiate_from_config(afeat_extractor)
+        self.aproj = instantiate_from_config(aproj)
+        self.vproj = instantiate_from_config(vproj)
+        for name in ('vproj', 'aproj'):
+            if not isinstance(getattr(self, name), torch.nn.Identity):
+                raise NotImplementedError(f'{name}: only DoNothingBridge (configs/segment_avclip.yaml:37-46) is built natively')
+        if not (self.v_encoder.pool_time and self.a_encoder.pool_time):
+            raise NotImplementedError("AVCLIP needs agg_time_module='AveragePooling' towers (configs/segment_avclip.yaml:21,33)")
+        self.clamp_scale_min, self.clamp_scale_max = clamp_scale_min, clamp_scale_max
+        self.init_scale = init_scale
+        self.logit_scale = torch.nn.Parameter(torch.ones([]) * self.init_scale)
+        self.gather_for_loss = gather_for_loss
+        self._sf_engine = None
+        self.seg_chunk = 112
+
+    def _engine(self) -> SynchformerEngine:
+        key = _param_key(self)
+        if self._sf_engine is not None and self._sf_engine[0] == key:
+            return self._sf_engine[1]
+        dev = self.logit_scale.device
+        if dev.type != 'cuda':
+            raise RuntimeError('AVCLIP computes on a HIP device only (no CPU fallback); call .to("cuda") first')
+        sd = synth.make_state_dict(0)                       # vproj / aproj / transformer slots are unused by this model
+        sd.update({'vfeat_extractor.' + k: v for k, v in self.v_encoder.state_dict().items()})
+        sd.update({'afeat_extractor.' + k: v for k, v in self.a_encoder.state_dict().items()})
+        eng = SynchformerEngine(sd, dev, seg_chunk=self.seg_chunk)
+        self._sf_engine = (key, eng)
+        return eng
+
+    @torch.no_grad()
+    def clamp_logit_scales(self):
+        self.logit_scale.clamp_(self.clamp_scale_min, self.clamp_scale_max)
+        return (self.logit_scale, None)
+
+    def encode_streams(self, vis, aud, for_loop=False, do_norm=True):
+        """vis (B, S, C, Tv, H, W), aud (B, S, Ta, F) -> (B*S, D) visual, None, (B*S, D) audio, None (open_clip/model.py:515-520)."""
+        for tower in (self.v_encoder, self.a_encoder):
+            _no_extractor_backward(tower)
+        eng = self._engine()
+        B, S, Ta, Fq = aud.shape
+        vfeat = eng.pool_segments(eng.extract_vfeats(vis.permute(0, 1, 3, 2, 4, 5).contiguous()), normalize=do_norm)
+        afeat = eng.pool_segments(eng.extract_afeats(aud.permute(0, 1, 3, 2).reshape(B, S, 1, Fq, Ta)), normalize=do_norm)
+        return vfeat, None, afeat, None
+
+    def compute_loss(self, vfeat, afeat, vfeat_all, afeat_all, scale, alpha=0.0, vfeat_m=None, afeat_m=None):
+        """open_clip/model.py:506-512; `*_all` are passed TRANSPOSED (D, N) like the reference's call sites (`.mT`)."""
+        assert alpha == 0.0, f'alpha={alpha} not supported yet'
+        losses, sim_v2a, sim_a2v = self._engine().contrastive_loss(vfeat, afeat, vfeat_all.mT.contiguous(), afeat_all.mT.contiguous(),
+                                                                   float(scale))
+        return losses.mean(), (sim_v2a, sim_a2v)
+
+    def forward(self, vis: torch.Tensor, aud: torch.Tensor, alpha: float = 0.0, for_loop: bool = False, world_size=1):
+        """open_clip/model.py:475-504."""
+        assert alpha == 0.0, f'alpha={alpha} not supported yet'
+        logit_scales = self.clamp_logit_scales()
+        vfeat, _, afeat, _ = self.encode_streams(vis, aud, for_loop, do_norm=True)
+        if world_size > 1 and self.gather_for_loss:
+            from .dist import all_gather_rows
+            vfeat_all, afeat_all = all_gather_rows(vfeat), all_gather_rows(afeat)
+        else:
+            vfeat_all, afeat_all = vfeat, afeat
+        loss_avc, _ = self.compute_loss(vfeat, afeat, vfeat_all.mT, afeat_all.mT, self.logit_scale, alpha=0)
+        return {'rgb_features': (vfeat, None), 'audio_features': (afeat, None), 'logit_scales': logit_scales,
+                'losses': {'segment_contrastive_loss': loss_avc}}
+
+    def forward_for_logging(self, vis, aud, for_momentum=False, for_loop=False, do_norm=True):
+        """open_clip/model.py:535-567: features + the four similarity matrices + loss (zero-shot evaluation feeds on these)."""
+        eng = self._engine()
+        vfeat, _, afeat, _ = self.encode_streams(vis, aud, for_loop, do_norm)
+        out = {'segment_vfeat': vfeat.clone(), 'segment_afeat': afeat.clone()}
+        inv = 1.0 / float(self.logit_scale)
+        n = vfeat.shape[0]
+        for name, (x, y) in {'segment_sim_v2a': (vfeat, afeat), 'segment_sim_a2v': (afeat, vfeat), 'segment_sim_v2v': (vfeat, vfeat),
+                             'segment_sim_a2a': (afeat, afeat)}.items():
+            from . import ops
+            out[name] = ops.similarity(x, y, torch.empty(n, n, device=x.device, dtype=torch.float32), inv)
+        losses, _, _ = eng.contrastive_loss(vfeat, afeat, vfeat, afeat, float(self.logit_scale))
+        out['segment_contrastive_loss'] = losses.mean()
+        return out
+
+
+def avclip_yaml_model_config(gather_for_loss: bool = False) -> dict:
+    """`configs/segment_avclip.yaml: model` with its `${...}` interpolations resolved and ckpt_path: null."""
+    tower = dict(ckpt_path=None, extract_features=True, agg_time_module='AveragePooling', add_global_repr=False,
+                 agg_segments_module='AveragePooling', max_segments=14)
+    bridge = dict(target='model.modules.bridges.DoNothingBridge', params=dict(in_features=768, out_features=768))
+    return dict(target='model.modules.feat_extractors.train_clip_src.open_clip.model.AVCLIP', params=dict(
+        init_scale=0.07, clamp_scale_min=0.001, clamp_scale_max=0.5, n_embd=768, gather_for_loss=gather_for_loss,
+        afeat_extractor=dict(target='model.modules.feat_extractors.audio.ast.AST', params=dict(
+            max_spec_t=66, factorize_freq_time=True, agg_freq_module='TransformerEncoderLayer', **tower)),
+        vfeat_extractor=dict(target='model.modules.feat_extractors.visual.motionformer.MotionFormer', params=dict(
+            factorize_space_time=True, agg_space_module='TransformerEncoderLayer', **tower)),
+        aproj=bridge, vproj=bridge))
 
 
 def sync_yaml_model_config(n_pos: int = 198, num_off_cls: int = 21,

@@ -156,6 +156,32 @@ def attention_cls(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.
     return out
 
 
+def meanpool_l2norm(x: torch.Tensor, out: torch.Tensor, t: int, normalize: bool):
+    """x (n*t, 768) fp32 -> out (n, 768): mean over each run of t rows, then optional F.normalize (open_clip/model.py:530-531)."""
+    assert x.dtype == torch.float32 and out.dtype == torch.float32 and x.shape[0] == out.shape[0] * t
+    rc = _lib.load().sf_meanpool_l2norm768(_dev(x, 'x'), _ld(x), t, _dev(out, 'out'), _ld(out), int(bool(normalize)), out.shape[0], _stream())
+    _lib.check(rc, 'sf_meanpool_l2norm768')
+    return out
+
+
+def similarity(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: float):
+    """out (n, m) = scale * a (n, d) @ b (m, d)^T in fp32 (open_clip/model.py:508-509)."""
+    assert a.dtype == b.dtype == out.dtype == torch.float32 and a.shape[1] == b.shape[1]
+    rc = _lib.load().sf_similarity_f32(_dev(a, 'a'), _ld(a), _dev(b, 'b'), _ld(b), _dev(out, 'out'), _ld(out), a.shape[0], b.shape[0],
+                                       a.shape[1], float(scale), _stream())
+    _lib.check(rc, 'sf_similarity_f32')
+    return out
+
+
+def cross_entropy(logits: torch.Tensor, targets: torch.Tensor, loss: torch.Tensor):
+    """loss[0] = F.cross_entropy(logits, targets) (mean) for fp32 (B, C) logits and int64 class targets."""
+    assert logits.dtype == torch.float32 and targets.dtype == torch.int64 and loss.dtype == torch.float32
+    rc = _lib.load().sf_cross_entropy(_dev(logits, 'logits'), _ld(logits), _dev(targets, 'targets'), logits.shape[0], logits.shape[1],
+                                      _dev(loss, 'loss'), None, 0, 1.0, _stream())
+    _lib.check(rc, 'sf_cross_entropy')
+    return loss
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # PyTorch dispatcher registration (SURVEY §8b "custom-op contract"): the C-ABI launchers as `torch.ops.synchformer.*`
 # out-variant custom ops (device_types = "cuda", i.e. HIP on ROCm).  They mutate their `out` argument and return nothing,

@@ -135,9 +135,43 @@ def train_grads(B=2):
     print('train loss', float(loss), 'total grad norm', float(np.sqrt((np.array(norms) ** 2).sum())))
 
 
+def avclip(B=2, S=3, gain=2.0):
+    """Stage-1 towers (configs/segment_avclip.yaml: agg_time_module 'AveragePooling') run through the REAL MotionFormer / AST.
+    The AVCLIP class itself cannot be imported here (its package __init__ needs torchvision, absent from this image), so the
+    5-line head (F.normalize, sim / scale, eye targets, symmetric CE; open_clip/model.py:506-533) is applied to the real
+    tower outputs with plain torch below - the fixture marks which arrays are reference outputs and which are restated."""
+    ref = ref_import.import_reference()
+    tower = dict(ckpt_path=None, extract_features=True, agg_time_module='AveragePooling', add_global_repr=False,
+                 agg_segments_module='AveragePooling', max_segments=14)
+    with ref_import._cwd(ref_import.REF):
+        vt = ref['MotionFormer'](factorize_space_time=True, agg_space_module='TransformerEncoderLayer', **tower).eval()
+        at = ref['AST'](max_spec_t=66, factorize_freq_time=True, agg_freq_module='TransformerEncoderLayer', **tower).eval()
+    sd = synth.make_state_dict(SEED, gain=gain)
+    vsd = {k[len('vfeat_extractor.'):]: v for k, v in sd.items() if k.startswith('vfeat_extractor.')}
+    asd = {k[len('afeat_extractor.'):]: v for k, v in sd.items() if k.startswith('afeat_extractor.')}
+    assert list(vt.state_dict().keys()) == list(vsd.keys()) and list(at.state_dict().keys()) == list(asd.keys())
+    vt.load_state_dict(vsd, strict=True)
+    at.load_state_dict(asd, strict=True)
+    vis = rgb_frontend_ref(synth.make_video_u8(B, S, SEED)).float()           # (B, S, Tv, C, H, W)
+    aud = synth.make_spectrogram(B, S, SEED)                                   # (B, S, 1, F, Ta)
+    with torch.no_grad():
+        vseg, _ = vt(vis.permute(0, 1, 3, 2, 4, 5), False)                     # AVCLIP feeds (B, S, C, Tv, H, W)
+        aseg, _ = at(aud.squeeze(2).permute(0, 1, 3, 2), False)                # and (B, S, Ta, F)
+        vfeat = torch.nn.functional.normalize(vseg.flatten(0, 1), dim=-1)
+        afeat = torch.nn.functional.normalize(aseg.flatten(0, 1), dim=-1)
+        scale = 0.07
+        sim_v2a, sim_a2v = vfeat @ afeat.mT / scale, afeat @ vfeat.mT / scale
+        tgt = torch.eye(*sim_v2a.shape)
+        loss = (torch.nn.functional.cross_entropy(sim_v2a, tgt) + torch.nn.functional.cross_entropy(sim_a2v, tgt)) / 2
+    np.savez_compressed(HERE / f'avclip_towers_B{B}S{S}.npz', seed=np.int64(SEED), B=np.int64(B), S=np.int64(S), gain=np.float64(gain),
+                        logit_scale=np.float64(scale), ref_vseg=vseg.numpy(), ref_aseg=aseg.numpy(),
+                        restated_sim_v2a=sim_v2a.numpy(), restated_sim_a2v=sim_a2v.numpy(), restated_loss=loss.numpy())
+    print('avclip towers', tuple(vseg.shape), tuple(aseg.shape), 'loss', float(loss), 'sim spread', float(sim_v2a.max() - sim_v2a.min()))
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['sync', 'sync_gain2', 'syncability', 'train']
+    which = sys.argv[1:] or ['sync', 'sync_gain2', 'syncability', 'train', 'avclip']
     if 'sync' in which:
         e2e_sync(2)
     if 'sync_gain2' in which:
@@ -146,3 +180,5 @@ if __name__ == '__main__':
         e2e_syncability(1)
     if 'train' in which:
         train_grads(2)
+    if 'avclip' in which:
+        avclip(2, 3)

@@ -1,0 +1,91 @@
+"""Stage-1 (segment-level contrastive, AVCLIP) forward on the GPU through the drop-in class: towers with AveragePooling, F.normalize,
+fp32 similarity and symmetric cross-entropy, against (a) real-reference tower outputs (tests/golden/avclip_towers_B2S3.npz) and
+(b) torch fp32 restatements of the small head kernels.  Tolerances: pooled tower features relative RMS <= 1.5 % (bf16 GEMM
+operands, same bar as tests/test_e2e_gpu.py); cosine similarities |delta| <= 2e-3, i.e. 3e-2 after the 1/0.07 temperature."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / 'golden'
+
+
+def _rel_rms(a, b):
+    return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+
+
+@pytest.mark.parametrize('n,t', [(1, 1), (5, 8), (28, 6), (224, 8)])
+@pytest.mark.parametrize('normalize', [False, True])
+def test_meanpool_l2norm(gpu, n, t, normalize):
+    from synchformer_amd import ops
+    x = torch.randn(n * t, 768, device=gpu)
+    if normalize and n > 1:
+        x[t:2 * t] = 0                                             # zero vector: F.normalize's eps clamp
+    out = ops.meanpool_l2norm(x, torch.empty(n, 768, device=gpu), t, normalize)
+    ref = x.view(n, t, 768).double().mean(1)
+    if normalize:
+        ref = torch.nn.functional.normalize(ref, dim=-1)
+    assert (out.double() - ref).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize('n,m,d', [(1, 1, 16), (6, 6, 768), (28, 224, 768), (70, 130, 64), (224, 224, 768)])
+def test_similarity_f32(gpu, n, m, d):
+    from synchformer_amd import ops
+    a, b = torch.randn(n, d, device=gpu), torch.randn(m, d, device=gpu)
+    out = ops.similarity(a, b, torch.full((n, m), float('nan'), device=gpu), 1 / 0.07)
+    ref = (a.double() @ b.double().T) / 0.07
+    assert (out.double() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item() / 100)
+
+
+def _model(gpu, gain, gather=False):
+    import synchformer_amd as sa
+    from synchformer_amd import synth
+    m = sa.instantiate_from_config(sa.avclip_yaml_model_config(gather_for_loss=gather))
+    sd = synth.make_state_dict(1337, gain=gain)
+    own = {k.replace('vfeat_extractor.', 'v_encoder.').replace('afeat_extractor.', 'a_encoder.'): v for k, v in sd.items()
+           if k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}
+    own['logit_scale'] = torch.tensor(0.07)
+    m.load_state_dict(own, strict=True)
+    return m.to(gpu).eval()
+
+
+def test_avclip_forward_matches_reference_towers(gpu):
+    from synchformer_amd import synth
+    from oracle import synchformer_cpu as O
+    g = np.load(GOLD / 'avclip_towers_B2S3.npz')
+    B, S, gain = int(g['B']), int(g['S']), float(g['gain'])
+    m = _model(gpu, gain)
+    assert len(m.state_dict()) == 451
+    vis = O.rgb_frontend(synth.make_video_u8(B, S, 1337)).permute(0, 1, 3, 2, 4, 5).to(gpu)     # (B, S, C, Tv, H, W)
+    aud = synth.make_spectrogram(B, S, 1337).squeeze(2).permute(0, 1, 3, 2).contiguous().to(gpu)  # (B, S, Ta, F)
+    with pytest.raises(NotImplementedError, match='no backward'):
+        m(vis, aud)                                             # trainable towers + autograd on: loud, not silently detached
+    with torch.no_grad():
+        out = m(vis, aud)
+        log = m.forward_for_logging(vis, aud)
+        vseg, _ = m.v_encoder(vis)
+        aseg, _ = m.a_encoder(aud)
+    ev, ea = _rel_rms(vseg.cpu(), torch.from_numpy(g['ref_vseg'])), _rel_rms(aseg.cpu(), torch.from_numpy(g['ref_aseg']))
+    vfeat, afeat = out['rgb_features'][0].cpu(), out['audio_features'][0].cpu()
+    assert vfeat.shape == (B * S, 768) and out['rgb_features'][1] is None and out['logit_scales'][1] is None
+    assert (vfeat.norm(dim=-1) - 1).abs().max() < 1e-5
+    cos_ref = torch.from_numpy(g['restated_sim_v2a']) * float(g['logit_scale'])
+    dcos = (log['segment_sim_v2a'].cpu() * 0.07 - cos_ref).abs().max().item()
+    dloss = abs(float(out['losses']['segment_contrastive_loss']) - float(g['restated_loss']))
+    print(f'avclip: vseg relrms {ev:.4f} aseg relrms {ea:.4f} | cos max {dcos:.5f} | loss delta {dloss:.5f}')
+    assert ev < 1.5e-2 and ea < 1.5e-2
+    assert dcos < 2e-3 and dloss < 1e-2
+    assert torch.allclose(log['segment_sim_a2v'], log['segment_sim_v2a'].T, atol=1e-5)
+    assert abs(float(log['segment_contrastive_loss']) - float(out['losses']['segment_contrastive_loss'])) < 1e-6
+    # head kernels alone, fed the HIP features: exact fp32 restatement
+    sim = vfeat @ afeat.T / 0.07
+    tgt = torch.eye(B * S)
+    loss = (torch.nn.functional.cross_entropy(sim, tgt) + torch.nn.functional.cross_entropy(sim.T, tgt)) / 2
+    assert (log['segment_sim_v2a'].cpu() - sim).abs().max() < 1e-4
+    assert abs(float(loss) - float(out['losses']['segment_contrastive_loss'])) < 1e-5
+    # clamp_logit_scales (open_clip/model.py:569-572)
+    with torch.no_grad():
+        m.logit_scale.fill_(5.0)
+    assert float(m.clamp_logit_scales()[0].detach()) == 0.5

@@ -48,3 +48,31 @@ def test_two_rank_sharding_and_gather(n_clips):
     assert span0[0] == 0 and span0[1] == span1[0] and span1[1] == n_clips
     assert t0 == t1 == 1.5                                   # MAX over ranks
     assert full0 == [float(i) for i in range(n_clips)] and full1 is None
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from synchformer_amd.dist import all_gather_rows
+        local = torch.full((3, 768), float(rank)) + torch.arange(3.).unsqueeze(1)      # row i of rank r = r + i
+        full = all_gather_rows(local)
+        q.put((rank, tuple(full.shape), full[:, 0].tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_embedding_all_gather():
+    """AVCLIP gather_for_loss (open_clip/model.py:489-491): rank-ordered concatenation of the per-rank embedding blocks."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, shape, col in res:
+        assert shape == (6, 768) and col == [0., 1., 2., 1., 2., 3.]

@@ -81,3 +81,23 @@ def test_oracle_matches_real_reference(sd):
         assert (m.extract_vfeats(vis, for_loop=False) - O.extract_vfeats(vis, sd)).abs().max() < 1e-5
         assert (m.extract_afeats(aud, for_loop=False) - O.extract_afeats(aud, sd)).abs().max() < 1e-5
         assert (m.transformer(v, a) - O.global_transformer(v, a, sd)).abs().max() < 1e-5
+
+
+def test_oracle_avclip_matches_golden_towers():
+    """Stage-1 towers (AveragePooling) of the REAL reference + the contrastive head (fixture: tests/golden/make_golden.py avclip)."""
+    from synchformer_amd import synth
+    from oracle import synchformer_cpu as O
+    g = np.load(GOLD / 'avclip_towers_B2S3.npz')
+    B, S = int(g['B']), int(g['S'])
+    sd2 = synth.make_state_dict(1337, gain=float(g['gain']))
+    vis = O.rgb_frontend(synth.make_video_u8(B, S, 1337))
+    aud = synth.make_spectrogram(B, S, 1337)
+    with torch.no_grad():
+        out = O.avclip_forward(sd2, vis, aud, logit_scale=float(g['logit_scale']))
+        vseg = O.extract_vfeats(vis, sd2).mean(2)
+    assert (vseg - torch.from_numpy(g['ref_vseg'])).abs().max() < 2e-5
+    rv = torch.nn.functional.normalize(torch.from_numpy(g['ref_vseg']).flatten(0, 1), dim=-1)
+    ra = torch.nn.functional.normalize(torch.from_numpy(g['ref_aseg']).flatten(0, 1), dim=-1)
+    assert (out['vfeat'] - rv).abs().max() < 1e-5 and (out['afeat'] - ra).abs().max() < 1e-5
+    assert (out['sim_v2a'] - torch.from_numpy(g['restated_sim_v2a'])).abs().max() < 2e-4
+    assert abs(float(out['loss']) - float(g['restated_loss'])) < 1e-4
