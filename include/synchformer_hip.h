@@ -171,6 +171,25 @@ int sf_meanpool_l2norm768(const float* x, int64_t ldx, int t, float* y, int64_t 
 int sf_similarity_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int n, int m, int d, float scale,
                       void* stream);
 
+/* ---- feature-extractor backward helpers (Stage-1 training; the matmul-shaped parts reuse the GEMM entry points) ------------ */
+/* dst[dst_map(r), :cols] = src[src_map(r), :cols] for r < rows (bf16, cols % 8 == 0): builds / scatters the per-group
+ * sequences [CLS; group tokens] of divided space-time attention (vit_helper.py:100-158, 341-344). */
+int sf_copy_rows_bf16(const uint16_t* src, int64_t ld_src, const int64_t* src_map, uint16_t* dst, int64_t ld_dst, const int64_t* dst_map,
+                      int64_t rows, int cols, void* stream);
+/* out[s*out_seq_stride + c] (=|+=) sum_{g<G} in[s*in_seq_stride + g*in_group_stride + c]: the CLS row is a key/value of every
+ * group, so its dk|dv is the sum over groups (strides in elements). */
+int sf_reduce_groups_bf16(const uint16_t* in, int64_t in_seq_stride, int64_t in_group_stride, int G, uint16_t* out, int64_t out_seq_stride,
+                          int cols, int64_t n_seq, int accumulate, void* stream);
+/* Backward of sf_attention_cls (same addressing): dO row (seq*do_seq_rows + do_row) -> dq at the query row (=), dk / dv at the
+ * n_keys key rows (=|+=); head_dim 64, n_keys <= 2048. */
+int sf_attention_cls_bwd(const uint16_t* q, int64_t q_seq_rows, int q_row, const uint16_t* k, const uint16_t* v, int64_t ld,
+                         int64_t kv_seq_rows, int kv_row0, int n_keys, const uint16_t* dO, int64_t lddo, int64_t do_seq_rows, int do_row,
+                         uint16_t* dq, uint16_t* dk, uint16_t* dv, int64_t ldg, int64_t n_seq, int heads, int head_dim, float scale,
+                         int accumulate_kv, void* stream);
+/* Backward of sf_meanpool_l2norm768: dx[r*t + j, :] = d(mean -> normalize)/dx applied to dy[r, :] (x = the forward input). */
+int sf_meanpool_l2norm768_bwd(const float* x, int64_t ldx, int t, const float* dy, int64_t lddy, float* dx, int64_t lddx, int normalize,
+                              int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

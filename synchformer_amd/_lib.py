@@ -45,6 +45,11 @@ SIGNATURES = {
     'sf_adam_clip_step': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _f32, _f32, _f32, _f32, _f32, _i32, _ptr],
     'sf_meanpool_l2norm768': [_ptr, _i64, _i32, _ptr, _i64, _i32, _i64, _ptr],
     'sf_similarity_f32': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _i32, _i32, _i32, _f32, _ptr],
+    'sf_copy_rows_bf16': [_ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i32, _ptr],
+    'sf_reduce_groups_bf16': [_ptr, _i64, _i64, _i32, _ptr, _i64, _i32, _i64, _i32, _ptr],
+    'sf_attention_cls_bwd': [_ptr, _i64, _i32, _ptr, _ptr, _i64, _i64, _i32, _i32, _ptr, _i64, _i64, _i32, _ptr, _ptr, _ptr, _i64, _i64, _i32,
+                             _i32, _f32, _i32, _ptr],
+    'sf_meanpool_l2norm768_bwd': [_ptr, _i64, _i32, _ptr, _i64, _ptr, _i64, _i32, _i64, _ptr],
     'sf_attention_cls_partial': [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _ptr, _ptr],
     'sf_attention_cls_combine': [_ptr, _i32, _ptr, _i64, _i64, _i32, _i64, _i32, _ptr],
     'sf_attention_cls': [_ptr, _i64, _i32, _ptr, _ptr, _i64, _i64, _i32, _i32, _ptr, _i64, _i64, _i32, _i64, _i32, _i32, _f32, _ptr],

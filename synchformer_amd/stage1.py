@@ -1,0 +1,472 @@
+"""Stage-1 train step on the HIP path: segment-level audio-visual contrastive pre-training of BOTH feature extractors
+(train_clip_src/open_clip/model.py:449-585, train_clip_src/training/train.py:72-160,
+train_clip.py:268-278, configs/segment_avclip.yaml).
+
+`AVCLIPTrainer` keeps every trainable tensor of the two towers (+ logit_scale) in ONE flat fp32 master buffer with flat grad /
+Adam m, v / bf16 operand copies (FlatTrainer), runs the towers with saved activations (~26 MB per visual segment per block,
+sized for 288 GB of HBM: the reference's batch of 2 x 14 segments needs ~20 GB), the hand-scheduled backward, the flat-bucket
+gradient all-reduce and the fused clip + Adam step (AdamW with the config's weight_decay 0.0).
+
+Backward of divided space-time attention (vit_helper.py:100-158): each patch attends [CLS; its time or space group], the CLS
+query attends everything.  The group part is run as ordinary self-attention over GATHERED sequences [CLS; group] (bf16 row
+gather, sf_copy_rows_bf16) through the five strided-batched GEMMs of FlatTrainer.attn_bwd_seq; the zero dO row in the CLS slot
+makes the CLS "query" of a group inert.  dq|dk|dv rows are scattered back, the CLS key/value gradient is summed over groups
+(sf_reduce_groups_bf16) and the CLS-query part is added by sf_attention_cls_bwd.
+
+All compute is in libsynchformer_hip; torch provides memory, the stream, torch.distributed, and two host-side scalars
+(the logit_scale clamp and its gradient).
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib, ops, synth
+from .engine import AGG_A, AGG_V, AUD_L, AUD_P, D, EPS_AST, EPS_VIS, FF, VIS_L, VIS_P
+from .train import FlatTrainer, _chk, _st, cast_bf16, colsum, ln_bwd
+
+V, A = 'vfeat_extractor', 'afeat_extractor'
+H, HD = 12, 64
+
+
+def _m(t):
+    import ctypes as C
+    return (C.c_int64 * 6)(*t) if t is not None else None
+
+
+def copy_rows(src, dst, rows, cols, src_map=None, dst_map=None):
+    _chk(_lib.load().sf_copy_rows_bf16(src.data_ptr(), src.stride(0), _m(src_map), dst.data_ptr(), dst.stride(0), _m(dst_map), rows, cols, _st()),
+         'sf_copy_rows_bf16')
+
+
+def normalise_keys(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """AVCLIP checkpoints name the towers v_encoder / a_encoder (open_clip/model.py:460-461); Synchformer names them
+    vfeat_extractor / afeat_extractor (sync_model.py:27-28).  Internally the Synchformer names are used."""
+    out = {}
+    for k, v in sd.items():
+        if k.startswith('v_encoder.'):
+            k = V + k[len('v_encoder'):]
+        elif k.startswith('a_encoder.'):
+            k = A + k[len('a_encoder'):]
+        out[k] = v
+    return out
+
+
+def cosine_lr(step: int, base_lr: float, warmup: int, total_steps: int) -> float:
+    """train_clip_src/training/scheduler.py:9-10, 43-53 (configs/segment_avclip.yaml: lr_scheduler cosine, warmup 1000)."""
+    if step < warmup:
+        return base_lr * (step + 1) / warmup
+    return 0.5 * (1 + math.cos(math.pi * (step - warmup) / (total_steps - warmup))) * base_lr
+
+
+class AVCLIPTrainer(FlatTrainer):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device='cuda:0', lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
+                 max_clip_norm: float = 1.0, clamp_scale=(0.001, 0.5), init_scale: float = 0.07, gather_for_loss: bool = False):
+        sd = dict(normalise_keys(state_dict))
+        if 'logit_scale' not in sd:
+            sd['logit_scale'] = torch.tensor(init_scale)
+        keys = [k for k in sd if k.startswith((V + '.', A + '.')) and not k.startswith(V + '.patch_embed.')] + ['logit_scale']
+        self._init_flat(sd, keys, device, lr, betas, eps, max_clip_norm)
+        self.clamp_scale, self.gather_for_loss = clamp_scale, gather_for_loss
+        self.n_vblocks = len([k for k in keys if k.startswith(V + '.blocks.') and k.endswith('.norm1.weight')])
+        self.n_alayers = len([k for k in keys if k.endswith('.layernorm_before.weight')])
+
+    # ---- small launch helpers ---------------------------------------------------------------------------------------
+    def _ln(self, name):
+        return self.p[name + '.weight'], self.p[name + '.bias']
+
+    def _lnws(self, rows):
+        return self._buf('ln_ws', (2 * 768 * ((rows + 3) // 4),), torch.float32)
+
+    def _ln_bwd(self, x, name, dy, dx, rows, eps, **kw):
+        ln_bwd(x, self.p[name + '.weight'], dy, dx, self.g[name + '.weight'], self.g[name + '.bias'], self._lnws(rows), rows, eps, **kw)
+
+    def _gelu_fwd(self, pre, act):
+        _chk(_lib.load().sf_gelu_fwd(pre.data_ptr(), act.data_ptr(), pre.numel(), _st()), 'sf_gelu_fwd')
+
+    def _gelu_bwd(self, pre, dact, dpre):
+        _chk(_lib.load().sf_gelu_bwd(pre.data_ptr(), dact.data_ptr(), dpre.data_ptr(), pre.numel(), _st()), 'sf_gelu_bwd')
+
+    def _seqsum(self, x, n_seq, L, out):
+        _chk(_lib.load().sf_seqsum(x.data_ptr(), x.stride(0), n_seq, L, D, out.data_ptr(), 0, _st()), 'sf_seqsum')
+
+    def _mlp_fwd(self, s, x_in, h_name, fc1, fc2, rows, eps_name, eps, tag):
+        """h = LN(x_in); pre = fc1(h); act = gelu(pre); returns x_in + fc2(act).  Saves h, pre, act."""
+        s['h2'] = self._buf(f'{tag}_h2', (rows, D), torch.bfloat16)
+        ops.layernorm(x_in, *self._ln(eps_name), s['h2'], eps)
+        s['pre'] = self._buf(f'{tag}_pre', (rows, FF), torch.bfloat16)
+        ops.gemm(s['h2'], *self._wb(fc1), s['pre'])
+        s['act'] = self._buf(f'{tag}_act', (rows, FF), torch.bfloat16)
+        self._gelu_fwd(s['pre'], s['act'])
+        out = self._buf(f'{tag}_xo', (rows, D), torch.float32)
+        ops.gemm(s['act'], *self._wb(fc2), out, residual=x_in)
+        return out
+
+    def _mlp_bwd(self, s, dx, x_in, fc1, fc2, rows, ln_name, eps):
+        """dx (rows, 768) fp32 = gradient of the block output; adds the MLP branch's contribution through LN(x_in) into dx."""
+        dy_b = self._buf('dy_b', (rows, D), torch.bfloat16)
+        cast_bf16(dx, dy_b, rows, D)
+        dact = self._lin_bwd(fc2, dy_b, s['act'], rows, tag='act', dy_f32=dx)
+        dpre = self._buf('dpre', (rows, FF), torch.bfloat16)
+        self._gelu_bwd(s['pre'], dact, dpre)
+        dh = self._lin_bwd(fc1, dpre, s['h2'], rows, tag='h')
+        self._ln_bwd(x_in, ln_name, dh, dx, rows, eps, acc_dx=True)
+
+    # ---- divided space-time attention ---------------------------------------------------------------------------------
+    @staticmethod
+    def _group_maps(kind):
+        """Row maps between token order (seg, 1 + f*196 + p) and group-sequence order; logical row r runs over (seg, group, tok)."""
+        if kind == 'time':        # groups = spatial positions p, tokens = frames f  ('(b n) f d', vit_helper.py:343-344)
+            G, T = 196, 8
+            tok = ops.rowmap(VIS_P, T, VIS_L, 1, 196, 1)
+        else:                     # groups = frames f, tokens = positions p          ('(b f) n d', vit_helper.py:341-342)
+            G, T = 8, 196
+            tok = ops.rowmap(VIS_P, T, VIS_L, 196, 1, 1)
+        Lg = T + 1
+        grp = ops.rowmap(VIS_P, T, G * Lg, Lg, 1, 1)
+        cls_tok = ops.rowmap(G, G, VIS_L, 0, 0, 0)
+        cls_grp = ops.rowmap(G, G, G * Lg, 0, Lg, 0)
+        return G, T, Lg, tok, grp, cls_tok, cls_grp
+
+    def _divided_fwd(self, qkv, att, n, kind):
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        kw = dict(n_groups=196, row0=1, group_stride=1, tok_stride=196, n_tok=8) if kind == 'time' else \
+            dict(n_groups=8, row0=1, group_stride=196, tok_stride=1, n_tok=196)
+        ops.attention(q, k, v, att, n_seq=n, seq_rows=VIS_L, cls_row=0, heads=H, head_dim=HD, scale=0.125, **kw)
+        ops.attention_cls(q, k, v, att, n_seq=n, q_seq_rows=VIS_L, q_row=0, kv_seq_rows=VIS_L, kv_row0=0, n_keys=VIS_L,
+                          out_seq_rows=VIS_L, out_row=0, heads=H, head_dim=HD, scale=0.125)
+
+    def _attn_bwd_chunked(self, Gq, GdO, Gd, nseq, Lg):
+        step = max(1, 60000 // H)                                 # batched-GEMM grids take < 65536 (sequence, head) pairs
+        for s0 in range(0, nseq, step):
+            c = min(step, nseq - s0)
+            self.attn_bwd_seq(Gq[s0 * Lg:(s0 + c) * Lg], GdO[s0 * Lg:(s0 + c) * Lg], Gd[s0 * Lg:(s0 + c) * Lg], c, Lg, H, HD)
+
+    def _divided_bwd(self, qkv, dO_b, n, kind):
+        """qkv (n*1569, 2304) bf16 saved, dO_b (n*1569, 768) bf16 -> dqkv (n*1569, 2304) bf16."""
+        G, T, Lg, tok, grp, cls_tok, cls_grp = self._group_maps(kind)
+        nseq, rows_g, M = n * G, n * G * Lg, n * VIS_L
+        Gq = self._buf('g_qkv', (rows_g, 3 * D), torch.bfloat16)
+        copy_rows(qkv, Gq, n * VIS_P, 3 * D, tok, grp)
+        copy_rows(qkv, Gq, nseq, 3 * D, cls_tok, cls_grp)
+        GdO = self._buf('g_dO', (rows_g, D), torch.bfloat16, zero=True)       # CLS slots keep dO = 0
+        copy_rows(dO_b, GdO, n * VIS_P, D, tok, grp)
+        Gd = self._buf('g_dqkv', (rows_g, 3 * D), torch.bfloat16)
+        self._attn_bwd_chunked(Gq, GdO, Gd, nseq, Lg)
+        dqkv = self._buf('dqkv', (M, 3 * D), torch.bfloat16)
+        copy_rows(Gd, dqkv, n * VIS_P, 3 * D, grp, tok)
+        # the CLS row is a key / value of every group: its dk | dv is the sum over the groups' slot-0 rows
+        _chk(_lib.load().sf_reduce_groups_bf16(Gd[:, D:].data_ptr(), G * Lg * 3 * D, Lg * 3 * D, G, dqkv[:, D:].data_ptr(), VIS_L * 3 * D, 2 * D, n, 0,
+                                               _st()), 'sf_reduce_groups_bf16')
+        # CLS query over all 1569 tokens: dq of the CLS row (=), dk | dv of every row (+=)
+        self._cls_bwd(qkv, dO_b, dqkv, n, VIS_L, VIS_L, do_seq_rows=VIS_L, accumulate=True)
+        return dqkv
+
+    def _cls_bwd(self, qkv, dO_b, dqkv, n_seq, seq_rows, n_keys, do_seq_rows, accumulate):
+        _chk(_lib.load().sf_attention_cls_bwd(qkv.data_ptr(), seq_rows, 0, qkv[:, D:].data_ptr(), qkv[:, 2 * D:].data_ptr(), qkv.stride(0), seq_rows, 0,
+                                              n_keys, dO_b.data_ptr(), dO_b.stride(0), do_seq_rows, 0, dqkv.data_ptr(), dqkv[:, D:].data_ptr(),
+                                              dqkv[:, 2 * D:].data_ptr(), dqkv.stride(0), n_seq, H, HD, 0.125, int(accumulate), _st()),
+             'sf_attention_cls_bwd')
+
+    def _attn_branch_bwd(self, dx, rows, proj, att_saved, qkv_fn, h_saved, x_in, ln_name, eps, qkv_names):
+        """Common tail of an attention residual branch: dx -> proj backward -> attention backward (qkv_fn) -> qkv linear(s)
+        backward -> LN backward accumulated into dx."""
+        dy_b = self._buf('dy_b', (rows, D), torch.bfloat16)
+        cast_bf16(dx, dy_b, rows, D)
+        datt = self._lin_bwd(proj, dy_b, att_saved, rows, tag='h', dy_f32=dx)
+        dO_b = self._buf('dO_b', (rows, D), torch.bfloat16)
+        cast_bf16(datt, dO_b, rows, D)
+        dqkv = qkv_fn(dO_b)
+        if isinstance(qkv_names, str):                                        # one fused (2304, 768) projection
+            dh = self._lin_bwd(qkv_names, dqkv, h_saved, rows, tag='h')
+        else:                                                                 # separate query / key / value Linears
+            dh = self._buf('dx_qkvsum', (rows, D), torch.float32)
+            for j, nm in enumerate(qkv_names):
+                self._lin_bwd(nm, dqkv[:, j * D:(j + 1) * D], h_saved, rows, dx_out=dh, acc_dx=j > 0)
+        self._ln_bwd(x_in, ln_name, dh, dx, rows, eps, acc_dx=True)
+
+    # ---- aggregator layer (BaseEncoderLayer over nn.TransformerEncoderLayer, motionformer.py:301-334) -----------------
+    def _agg_fwd(self, Z, n_seq, L, p, tag):
+        rows = n_seq * L
+        s = dict(Z=Z, n_seq=n_seq, L=L)
+        s['zn'] = self._buf(f'{tag}_zn', (rows, D), torch.bfloat16)
+        ops.layernorm(Z, *self._ln(p + '.norm1'), s['zn'], EPS_VIS)
+        s['qkv'] = self._buf(f'{tag}_qkv', (rows, 3 * D), torch.bfloat16)
+        ops.gemm(s['zn'], self.b[p + '.self_attn.in_proj_weight'], self.p[p + '.self_attn.in_proj_bias'], s['qkv'])
+        q3 = s['qkv']
+        s['att'] = self._buf(f'{tag}_att', (n_seq, D), torch.bfloat16)
+        ops.attention_cls(q3[:, :D], q3[:, D:2 * D], q3[:, 2 * D:], s['att'], n_seq=n_seq, q_seq_rows=L, q_row=0, kv_seq_rows=L, kv_row0=0,
+                          n_keys=L, out_seq_rows=1, out_row=0, heads=H, head_dim=HD, scale=0.125)
+        s['y'] = self._buf(f'{tag}_y', (n_seq, D), torch.float32)
+        ops.gemm(s['att'], *self._wb(p + '.self_attn.out_proj'), s['y'], residual=Z, r_map=ops.rowmap(1, 1, L, 0, 0, 0))
+        out = self._mlp_fwd(s, s['y'], 'yn', p + '.linear1', p + '.linear2', n_seq, p + '.norm2', EPS_VIS, tag)
+        return out, s
+
+    def _agg_bwd(self, dout, s, p):
+        """dout (n_seq, 768) fp32 -> dZ (n_seq*L, 768) fp32 (gradient w.r.t. [agg_cls; tokens])."""
+        n_seq, L = s['n_seq'], s['L']
+        rows = n_seq * L
+        dy = self._buf('agg_dy', (n_seq, D), torch.float32)
+        dy.copy_(dout)
+        self._mlp_bwd(s, dy, s['y'], p + '.linear1', p + '.linear2', n_seq, p + '.norm2', EPS_VIS)
+        dy_b = self._buf('dy_b', (n_seq, D), torch.bfloat16)
+        cast_bf16(dy, dy_b, n_seq, D)
+        datt = self._lin_bwd(p + '.self_attn.out_proj', dy_b, s['att'], n_seq, tag='h', dy_f32=dy)
+        dO_b = self._buf('dO_b', (n_seq, D), torch.bfloat16)
+        cast_bf16(datt, dO_b, n_seq, D)
+        dqkv = self._buf('dqkv', (rows, 3 * D), torch.bfloat16, zero=True)   # dq of rows 1.. stays zero (only row 0 queries)
+        self._cls_bwd(s['qkv'], dO_b, dqkv, n_seq, L, L, do_seq_rows=1, accumulate=False)
+        dzn = self._lin_bwd(p + '.self_attn.in_proj', dqkv, s['zn'], rows, tag='h', wkey=p + '.self_attn.in_proj_weight',
+                            bkey=p + '.self_attn.in_proj_bias')
+        dZ = self._buf('agg_dZ', (rows, D), torch.float32, zero=True)
+        dZ.view(n_seq, L, D)[:, 0].copy_(dy)                                 # residual path of row 0 (data movement only)
+        self._ln_bwd(s['Z'], p + '.norm1', dzn, dZ, rows, EPS_VIS, acc_dx=True)
+        return dZ
+
+    # ---- visual tower -------------------------------------------------------------------------------------------------------
+    def _vis_table(self):
+        pos, temp = self.p[V + '.pos_embed'][0], self.p[V + '.temp_embed'][0]
+        body = (pos[1:].unsqueeze(0) + temp.unsqueeze(1)).reshape(-1, D)       # weight prep, as SynchformerEngine.load_weights
+        return torch.cat([pos[:1] + self.p[V + '.cls_token'][0], body], 0).contiguous()
+
+    def _fwd_visual(self, vid):
+        """vid (n, 16, 3, 224, 224) u8|f16|bf16|f32 -> aggregator outputs (n*8, 768) fp32 (saved state in self.sv_v)."""
+        n = vid.shape[0]
+        M = n * VIS_L
+        sv = self.sv_v = dict(n=n, blocks=[])
+        sv['patches'] = self._buf('v_patches', (n * VIS_P, 1536), torch.bfloat16)
+        ops.im2col_video(vid.contiguous(), sv['patches'])
+        x = self._buf('v_x0', (M, D), torch.float32)
+        ops.broadcast_rows(x, self._vis_table(), n_seq=n, dst_seq_rows=VIS_L)
+        tokmap = ops.rowmap(VIS_P, VIS_P, VIS_L, 0, 1, 1)
+        ops.gemm(sv['patches'], self.b[V + '.patch_embed_3d.proj.weight'].view(D, 1536), self.p[V + '.patch_embed_3d.proj.bias'], x, residual=x,
+                 c_map=tokmap, r_map=tokmap)
+        for i in range(self.n_vblocks):
+            p, t = f'{V}.blocks.{i}', f'v{i}'
+            s = dict(x=x)
+            for kind, ln, att, key in (('time', 'norm3', 'timeattn', 't'), ('space', 'norm1', 'attn', 's')):
+                s['h' + key] = self._buf(f'{t}_h{key}', (M, D), torch.bfloat16)
+                ops.layernorm(x, *self._ln(f'{p}.{ln}'), s['h' + key], EPS_VIS)
+                s['qkv' + key] = self._buf(f'{t}_qkv{key}', (M, 3 * D), torch.bfloat16)
+                ops.gemm(s['h' + key], *self._wb(f'{p}.{att}.qkv'), s['qkv' + key])
+                s['att' + key] = self._buf(f'{t}_att{key}', (M, D), torch.bfloat16)
+                self._divided_fwd(s['qkv' + key], s['att' + key], n, kind)
+                xn = self._buf(f'{t}_x{key}', (M, D), torch.float32)
+                ops.gemm(s['att' + key], *self._wb(f'{p}.{att}.proj'), xn, residual=x)
+                x = s['x' + key] = xn                                           # xt = after time attention, xs = after space attention
+            x = self._mlp_fwd(s, x, 'h2', p + '.mlp.fc1', p + '.mlp.fc2', M, p + '.norm2', EPS_VIS, t)
+            sv['blocks'].append(s)
+        sv['x_last'] = x
+        Z = self._buf('v_Z', (n * 8 * AGG_V, D), torch.float32)
+        ops.broadcast_rows(Z, self.p[V + '.spatial_attn_agg.cls_token'].view(1, D), n_seq=n * 8, dst_seq_rows=AGG_V)
+        sv['in_map'], sv['z_map'] = ops.rowmap(VIS_P, VIS_P, VIS_L, 0, 1, 1), ops.rowmap(VIS_P, 196, 8 * AGG_V, AGG_V, 1, 1)
+        ops.layernorm(x, *self._ln(V + '.norm'), Z, EPS_VIS, rows=n * VIS_P, in_map=sv['in_map'], out_map=sv['z_map'])
+        out, sv['agg'] = self._agg_fwd(Z, n * 8, AGG_V, V + '.spatial_attn_agg', 'vagg')
+        return out
+
+    def _bwd_visual(self, dout):
+        sv = self.sv_v
+        n = sv['n']
+        M = n * VIS_L
+        agg = V + '.spatial_attn_agg'
+        dZ = self._agg_bwd(dout, sv['agg'], agg)
+        gz = self._buf('gz', (AGG_V, D), torch.float32)
+        self._seqsum(dZ, n * 8, AGG_V, gz)
+        self.g[agg + '.cls_token'].view(D).copy_(gz[0])
+        dx = self._buf('v_dx', (M, D), torch.float32, zero=True)               # CLS rows are dropped before the final norm: grad 0
+        self._ln_bwd(sv['x_last'], V + '.norm', dZ, dx, n * VIS_P, EPS_VIS, x_map=sv['in_map'], dy_map=sv['z_map'], dx_map=sv['in_map'])
+        for i in reversed(range(self.n_vblocks)):
+            p, s = f'{V}.blocks.{i}', sv['blocks'][i]
+            self._mlp_bwd(s, dx, s['xs'], p + '.mlp.fc1', p + '.mlp.fc2', M, p + '.norm2', EPS_VIS)
+            self._attn_branch_bwd(dx, M, p + '.attn.proj', s['atts'], lambda dO, q=s['qkvs']: self._divided_bwd(q, dO, n, 'space'), s['hs'],
+                                  s['xt'], p + '.norm1', EPS_VIS, p + '.attn.qkv')
+            self._attn_branch_bwd(dx, M, p + '.timeattn.proj', s['attt'], lambda dO, q=s['qkvt']: self._divided_bwd(q, dO, n, 'time'), s['ht'],
+                                  s['x'], p + '.norm3', EPS_VIS, p + '.timeattn.qkv')
+        # token table: row 0 = cls_token + pos[0]; row 1 + f*196 + p = pos[1 + p] + temp[f]  (video_model_builder.py:248-254)
+        gtab = self._buf('gtab', (VIS_L, D), torch.float32)
+        self._seqsum(dx, n, VIS_L, gtab)
+        self.g[V + '.cls_token'].view(D).copy_(gtab[0])
+        gpos = self.g[V + '.pos_embed'][0]
+        gpos[0].copy_(gtab[0])
+        self._seqsum(gtab[1:], 8, 196, gpos[1:])                                # sum over frames
+        ws = self._buf('colsum_ws', (D * 4,), torch.float32)
+        for f in range(8):
+            colsum(gtab[1 + f * 196: 1 + (f + 1) * 196], 196, D, self.g[V + '.temp_embed'][0, f], ws)
+        dtok = self._buf('v_dtok', (n * VIS_P, D), torch.bfloat16)
+        ops.gather_rows(dx, dtok, n * VIS_P, in_map=sv['in_map'])
+        self._lin_bwd(V + '.patch_embed_3d.proj', dtok, sv['patches'], n * VIS_P, need_dx=False)
+
+    # ---- audio tower --------------------------------------------------------------------------------------------------------
+    def _aud_table(self, L):
+        e = A + '.ast.embeddings'
+        tab = self.p[e + '.position_embeddings'][0, :L].clone()
+        tab[0] += self.p[e + '.cls_token'][0, 0]
+        tab[1] += self.p[e + '.distillation_token'][0, 0]
+        return tab.contiguous()
+
+    def _fwd_audio(self, spec):
+        """spec (n, F=128, Ta=66) fp32 -> aggregator outputs (n*6, 768) fp32."""
+        n, Fa, Ta = spec.shape
+        nf, nt = (Fa - 16) // 10 + 1, (Ta - 16) // 10 + 1
+        P, L = nf * nt, nf * nt + 2
+        if (P, L, nf + 1) != (AUD_P, AUD_L, AGG_A):
+            raise ValueError(f'spectrogram {Fa}x{Ta} gives {L} tokens; this build trains the 128x66 / 74-token configuration')
+        M = n * L
+        sv = self.sv_a = dict(n=n, layers=[], nt=nt)
+        sv['patches'] = self._buf('a_patches', (n * P, 256), torch.bfloat16)
+        ops.im2col_spec(spec.contiguous().float(), sv['patches'])
+        x = self._buf('a_x0', (M, D), torch.float32)
+        ops.broadcast_rows(x, self._aud_table(L), n_seq=n, dst_seq_rows=L)
+        sv['tokmap'] = ops.rowmap(P, P, L, 0, 1, 2)
+        pe = A + '.ast.embeddings.patch_embeddings.projection'
+        ops.gemm(sv['patches'], self.b[pe + '.weight'].view(D, 256), self.p[pe + '.bias'], x, residual=x, c_map=sv['tokmap'], r_map=sv['tokmap'])
+        for i in range(self.n_alayers):
+            p, t = f'{A}.ast.encoder.layer.{i}', f'a{i}'
+            s = dict(x=x)
+            s['h1'] = self._buf(f'{t}_h1', (M, D), torch.bfloat16)
+            ops.layernorm(x, *self._ln(p + '.layernorm_before'), s['h1'], EPS_AST)
+            q3 = s['qkv'] = self._buf(f'{t}_qkv', (M, 3 * D), torch.bfloat16)
+            for j, nm in enumerate(('query', 'key', 'value')):
+                ops.gemm(s['h1'], *self._wb(f'{p}.attention.attention.{nm}'), q3[:, j * D:(j + 1) * D])
+            s['att'] = self._buf(f'{t}_att', (M, D), torch.bfloat16)
+            ops.attention(q3[:, :D], q3[:, D:2 * D], q3[:, 2 * D:], s['att'], n_seq=n, seq_rows=L, n_groups=1, row0=0, group_stride=0, tok_stride=1,
+                          n_tok=L, cls_row=-1, heads=H, head_dim=HD, scale=0.125)
+            s['x2'] = self._buf(f'{t}_x2', (M, D), torch.float32)
+            ops.gemm(s['att'], *self._wb(p + '.attention.output.dense'), s['x2'], residual=x)
+            x = self._mlp_fwd(s, s['x2'], 'h2', p + '.intermediate.dense', p + '.output.dense', M, p + '.layernorm_after', EPS_AST, t)
+            sv['layers'].append(s)
+        sv['x_last'] = x
+        La = AGG_A
+        Z = self._buf('a_Z', (n * nt * La, D), torch.float32)
+        ops.broadcast_rows(Z, self.p[A + '.freq_attn_agg.cls_token'].view(1, D), n_seq=n * nt, dst_seq_rows=La)
+        sv['z_map'] = ops.rowmap(P, nt, nt * La, 1, La, 1)
+        ops.layernorm(x, *self._ln(A + '.ast.layernorm'), Z, EPS_AST, rows=n * P, in_map=sv['tokmap'], out_map=sv['z_map'])
+        out, sv['agg'] = self._agg_fwd(Z, n * nt, La, A + '.freq_attn_agg', 'aagg')
+        return out
+
+    def _bwd_audio(self, dout):
+        sv = self.sv_a
+        n, nt = sv['n'], sv['nt']
+        L, P = AUD_L, AUD_P
+        M = n * L
+        agg = A + '.freq_attn_agg'
+        dZ = self._agg_bwd(dout, sv['agg'], agg)
+        gz = self._buf('gz', (AGG_V, D), torch.float32)
+        self._seqsum(dZ, n * nt, AGG_A, gz)
+        self.g[agg + '.cls_token'].view(D).copy_(gz[0])
+        dx = self._buf('a_dx', (M, D), torch.float32, zero=True)
+        self._ln_bwd(sv['x_last'], A + '.ast.layernorm', dZ, dx, n * P, EPS_AST, x_map=sv['tokmap'], dy_map=sv['z_map'], dx_map=sv['tokmap'])
+        for i in reversed(range(self.n_alayers)):
+            p, s = f'{A}.ast.encoder.layer.{i}', sv['layers'][i]
+            self._mlp_bwd(s, dx, s['x2'], p + '.intermediate.dense', p + '.output.dense', M, p + '.layernorm_after', EPS_AST)
+
+            def full_bwd(dO, q=s['qkv']):
+                dqkv = self._buf('dqkv', (M, 3 * D), torch.bfloat16)
+                self.attn_bwd_seq(q, dO, dqkv, n, L, H, HD)
+                return dqkv
+            self._attn_branch_bwd(dx, M, p + '.attention.output.dense', s['att'], full_bwd, s['h1'], s['x'], p + '.layernorm_before', EPS_AST,
+                                  [f'{p}.attention.attention.{nm}' for nm in ('query', 'key', 'value')])
+        e = A + '.ast.embeddings'
+        gtab = self._buf('gtab', (VIS_L, D), torch.float32)[:L]
+        self._seqsum(dx, n, L, gtab)
+        gpos = self.g[e + '.position_embeddings'][0]
+        gpos.zero_()
+        gpos[:L].copy_(gtab)
+        self.g[e + '.cls_token'].view(D).copy_(gtab[0])
+        self.g[e + '.distillation_token'].view(D).copy_(gtab[1])
+        dtok = self._buf('a_dtok', (n * P, D), torch.bfloat16)
+        ops.gather_rows(dx, dtok, n * P, in_map=sv['tokmap'])
+        self._lin_bwd(e + '.patch_embeddings.projection', dtok, sv['patches'], n * P, need_dx=False)
+
+    # ---- contrastive head ------------------------------------------------------------------------------------------------------
+    def _pool(self, x, t, n, tag):
+        out = self._buf(f'{tag}_feat', (n, D), torch.float32)
+        return ops.meanpool_l2norm(x, out, t, True)
+
+    def _pool_bwd(self, x, t, dfeat, n, tag):
+        dx = self._buf(f'{tag}_dpool', (n * t, D), torch.float32)
+        _chk(_lib.load().sf_meanpool_l2norm768_bwd(x.data_ptr(), x.stride(0), t, dfeat.data_ptr(), dfeat.stride(0), dx.data_ptr(), dx.stride(0), 1, n,
+                                                   _st()), 'sf_meanpool_l2norm768_bwd')
+        return dx
+
+    def _matmul_nt(self, a, bT_rows, out, scale):
+        """out (n, d) = scale * a (n, K) @ b (K, d), given b as its rows (K, d): sf_similarity_f32 wants both operands K-contiguous,
+        so the small fp32 operands are re-laid out (transposed, K padded to a multiple of 16) with torch copies - data movement only."""
+        n, K = a.shape
+        Kp = ((K + 15) // 16) * 16
+        ap = self._buf('head_a', (n, Kp), torch.float32, zero=True)
+        ap[:, :K].copy_(a)
+        bp = self._buf('head_b', (bT_rows.shape[1], Kp), torch.float32, zero=True)
+        bp[:, :K].copy_(bT_rows.t())
+        return ops.similarity(ap, bp, out, scale)
+
+    def _head(self, vfeat, afeat):
+        """AVCLIP.compute_loss (open_clip/model.py:506-525) + its backward -> (dvfeat, dafeat) fp32 (n, 768); fills g[logit_scale]."""
+        from .dist import all_gather_rows
+        n = vfeat.shape[0]
+        s = float(self.p['logit_scale'])                                        # host scalar (one sync per step)
+        world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+        gathered = self.gather_for_loss and world > 1
+        v_all, a_all = (all_gather_rows(vfeat), all_gather_rows(afeat)) if gathered else (vfeat, afeat)
+        m = v_all.shape[0]
+        sims = [self._buf(f'sim{i}', (n, m), torch.float32) for i in range(2)]
+        dsims = [self._buf(f'dsim{i}', (n, m), torch.float32) for i in range(2)]
+        ops.similarity(vfeat, a_all, sims[0], 1.0 / s)                          # sim_v2a
+        ops.similarity(afeat, v_all, sims[1], 1.0 / s)                          # sim_a2v
+        tgt = torch.arange(n, device=self.dev, dtype=torch.int64)              # eye(n, m) targets (open_clip/model.py:512-518)
+        losses = self._buf('losses', (2,), torch.float32)
+        for i in range(2):
+            _chk(_lib.load().sf_cross_entropy(sims[i].data_ptr(), m, tgt.data_ptr(), n, m, losses[i:i + 1].data_ptr(), dsims[i].data_ptr(), m, 0.5,
+                                              _st()), 'sf_cross_entropy')
+        self.losses = losses
+        # d logit_scale = -sum(dsim * sim) / s  (sim = <.,.> / s): host-side scalar reduction of two (n, m) products
+        self.g['logit_scale'].copy_(-((dsims[0] * sims[0]).sum() + (dsims[1] * sims[1]).sum()) / s)
+        dv = self._buf('dvfeat', (n, D), torch.float32)
+        da = self._buf('dafeat', (n, D), torch.float32)
+        dv_all = self._buf('dv_all', (m, D), torch.float32)
+        da_all = self._buf('da_all', (m, D), torch.float32)
+        self._matmul_nt(dsims[0], a_all, dv, 1.0 / s)                           # d sim_v2a / d vfeat
+        self._matmul_nt(dsims[1], v_all, da, 1.0 / s)                           # d sim_a2v / d afeat
+        self._matmul_nt(dsims[1].t(), afeat, dv_all, 1.0 / s)                   # d sim_a2v / d vfeat_all  (m, D)
+        self._matmul_nt(dsims[0].t(), vfeat, da_all, 1.0 / s)                   # d sim_v2a / d afeat_all
+        if gathered:                                                            # backward of all_gather = reduce-scatter (sum over ranks)
+            torch.distributed.all_reduce(dv_all)
+            torch.distributed.all_reduce(da_all)
+            r = torch.distributed.get_rank()
+            dv_all, da_all = dv_all[r * n:(r + 1) * n], da_all[r * n:(r + 1) * n]
+        ops_add = self._buf('head_sum', (2, n, D), torch.float32)
+        torch.add(dv, dv_all, out=ops_add[0])                                   # two (n, 768) adds
+        torch.add(da, da_all, out=ops_add[1])
+        return ops_add[0], ops_add[1]
+
+    # ---- public API ----------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def clamp_logit_scale(self):
+        self.p['logit_scale'].clamp_(*self.clamp_scale)                        # open_clip/model.py:569-572
+
+    @torch.no_grad()
+    def forward_backward(self, vis: torch.Tensor, aud: torch.Tensor) -> torch.Tensor:
+        """vis (B, S, Tv=16, C=3, H, W) (Synchformer layout) u8|float, aud (B, S, 1, F, Ta) fp32 -> loss (device scalar); fills flat_g."""
+        B, S = vis.shape[:2]
+        n = B * S
+        self.clamp_logit_scale()
+        self.flat_g.zero_()
+        vout = self._fwd_visual(vis.reshape(n, *vis.shape[2:]))
+        aout = self._fwd_audio(aud.reshape(n, aud.shape[-2], aud.shape[-1]))
+        self.vfeat, self.afeat = self._pool(vout, 8, n, 'v'), self._pool(aout, self.sv_a['nt'], n, 'a')
+        dv, da = self._head(self.vfeat, self.afeat)
+        self._bwd_visual(self._pool_bwd(vout, 8, dv, n, 'v'))
+        self._bwd_audio(self._pool_bwd(aout, self.sv_a['nt'], da, n, 'a'))
+        self.loss = self.losses.mean()
+        return self.loss
+
+    def train_step(self, vis: torch.Tensor, aud: torch.Tensor, lr: Optional[float] = None) -> torch.Tensor:
+        """One Stage-1 iteration (train_clip_src/training/train.py:103-154): forward, backward, DDP-mean all-reduce, clip + AdamW."""
+        loss = self.forward_backward(vis, aud)
+        self.allreduce_grads()
+        self.optimizer_step(lr)
+        return loss
+
+    def model_state_dict(self) -> Dict[str, torch.Tensor]:
+        """Checkpoint in the reference's AVCLIP key names (v_encoder. / a_encoder. / logit_scale)."""
+        return {k.replace(V + '.', 'v_encoder.').replace(A + '.', 'a_encoder.'): t.detach().clone() for k, t in self.p.items()}

@@ -70,16 +70,16 @@ def trainable_keys(schema) -> List[str]:
     return [k for k in schema if k.startswith(('vproj.', 'aproj.', 'transformer.'))]
 
 
-class SyncTrainer:
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device='cuda:0', lr: float = 2e-6, betas=(0.9, 0.999), eps: float = 1e-7,
-                 max_clip_norm: float = 1.0, embd_pdrop: float = 0.0, resid_pdrop: float = 0.0, attn_pdrop: float = 0.0, seed: int = 1337,
-                 seg_chunk: int = 112, engine: Optional[SynchformerEngine] = None):
-        self.embd_pdrop, self.resid_pdrop, self.attn_pdrop, self.seed = float(embd_pdrop or 0), float(resid_pdrop or 0), float(attn_pdrop or 0), seed
-        self.fwd_count = 0
+class FlatTrainer:
+    """Shared machinery of the HIP train steps: ONE flat fp32 master buffer for the trainable tensors (+ flat grad, Adam m / v,
+    bf16 operand copies and bf16 W^T copies for dgrad), linear / attention backward on the GEMM entry points, the flat-bucket
+    gradient all-reduce and the fused clip + Adam step."""
+    attn_pdrop = 0.0
+
+    def _init_flat(self, state_dict: Dict[str, torch.Tensor], keys: List[str], device, lr, betas, eps, max_clip_norm):
         self.dev = torch.device(device)
-        self.engine = engine if engine is not None else SynchformerEngine(state_dict, self.dev, seg_chunk=seg_chunk)   # frozen extractors
         self.lr, self.betas, self.eps, self.max_clip_norm = lr, betas, eps, max_clip_norm
-        self.keys = trainable_keys(state_dict)
+        self.keys = list(keys)
         sizes = [state_dict[k].numel() for k in self.keys]
         self.n = sum(sizes)
         self.flat_p = torch.empty(self.n, device=self.dev, dtype=torch.float32)
@@ -98,10 +98,6 @@ class SyncTrainer:
             o += sz
         self.flat_b.copy_(self.flat_p)
         self.step_count = 0
-        self.n_blocks = len([k for k in self.keys if k.endswith('.ln1.weight')])
-        self.heads = 8
-        self.head_name = 'off_head' if 'transformer.off_head.weight' in self.p else 'sync_head'
-        self.n_out = self.p[f'transformer.{self.head_name}.weight'].shape[0]
         self.norm = torch.zeros(1, device=self.dev, dtype=torch.float32)
         self.loss = torch.zeros(1, device=self.dev, dtype=torch.float32)
         self._ws: Dict[str, torch.Tensor] = {}
@@ -144,38 +140,115 @@ class SyncTrainer:
         self.flat_b.copy_(self.flat_p)
         self._refresh_transposed()
 
+    # ---- linear layer forward / backward -------------------------------------------------------------------
+    def _wb(self, name):
+        return self.b[name + '.weight'], self.p[name + '.bias']
+
+    def _lin_bwd(self, name, dy_b, x_b, M, *, need_dx=True, dx_out=None, tag='', wkey=None, bkey=None, acc_bias=False, acc_dx=False, dy_f32=None):
+        """dy_b (M, N) bf16 (row stride may exceed N), x_b (M, K) bf16 saved input.  Fills g[W], g[b]; returns dx fp32 (M, K).
+        `wkey` / `bkey` name tensors that do not follow the `<name>.weight` / `<name>.bias` convention (in_proj_weight, conv kernels)."""
+        wkey, bkey = wkey or name + '.weight', bkey or name + '.bias'
+        N = self.p[wkey].shape[0]
+        K = self.p[wkey].numel() // N
+        m_pad = ((M + 63) // 64) * 64
+        ws = self._buf('colsum_ws', (N * ((M + 63) // 64),), torch.float32)
+        colsum(dy_b if dy_f32 is None else dy_f32, M, N, self.g[bkey], ws, accumulate=acc_bias)   # fp32 dy when the caller has it
+        dyT = self._buf('dyT', (N, m_pad), torch.bfloat16)
+        xT = self._buf('xT', (K, m_pad), torch.bfloat16)
+        transpose(dy_b, dy_b.stride(0), 0, 0, dyT, m_pad, 0, 0, M, N, m_pad)
+        transpose(x_b, x_b.stride(0), 0, 0, xT, m_pad, 0, 0, M, K, m_pad)
+        ops.gemm(dyT, xT, None, self.g[wkey].view(N, K), M=N)                        # dW = dy^T x
+        if not need_dx:
+            return None
+        wT = self._wT[wkey]                                                           # (K, n_pad)
+        dx = dx_out if dx_out is not None else self._buf('dx_' + tag, (M, K), torch.float32)
+        if wT.shape[1] != N:                                                           # ragged N (heads): zero-padded contraction
+            dyp = self._buf('dy_pad', (M, wT.shape[1]), torch.bfloat16, zero=True)
+            dyp[:, :N].copy_(dy_b[:M, :N])
+            ops.gemm(dyp, wT, None, dx, M=M, residual=dx if acc_dx else None)
+        else:
+            ops.gemm(dy_b, wT, None, dx, M=M, residual=dx if acc_dx else None)
+        return dx
+
+    # ---- full self-attention backward over B contiguous sequences of L rows: five strided-batched products ----------------
+    def attn_bwd_seq(self, qkv, dO_b, dqkv, B, L, H, hd, P_saved=None, seed=None):
+        """qkv (B*L, 3*H*hd) bf16 = q | k | v side by side, dO_b (B*L, H*hd) bf16 -> dqkv (B*L, 3*H*hd) bf16 (all rows written).
+        softmax(q k^T / sqrt(hd)) is recomputed unless the (pre-dropout) probabilities were saved."""
+        D = H * hd
+        Lp = ((L + 31) // 32) * 32
+        scale = 1.0 / math.sqrt(hd)
+        ld3 = qkv.stride(0)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        S = self._buf('att_S', (B * H * L, Lp), torch.float32)
+        if P_saved is None:                                                             # recompute the probabilities
+            bgemm(q, ld3, L * ld3, hd, k, ld3, L * ld3, hd, S, Lp, H * L * Lp, L * Lp, L, L, hd, B, H)
+            P = self._buf('att_P', (B * H * L, Lp), torch.bfloat16)
+            _chk(_lib.load().sf_softmax_rows(S.data_ptr(), Lp, P.data_ptr(), Lp, B * H * L, L, Lp, scale, _st()), 'sf_softmax_rows')
+            Pv = P                                                                      # the matrix that multiplied V in the forward
+        else:                                                                           # attn dropout: P saved, drop(P) regenerated
+            P = P_saved
+            Pv = self._buf('att_Pd', (B * H * L, Lp), torch.bfloat16, zero=True)
+            dropout(P, Pv, B * H * L, L, self.attn_pdrop, seed)
+        dP = S                                                                          # reuse: S is dead once P exists
+        bgemm(dO_b, D, L * D, hd, v, ld3, L * ld3, hd, dP, Lp, H * L * Lp, L * Lp, L, L, hd, B, H)
+        if P_saved is not None:
+            dropout(dP, dP, B * H * L, L, self.attn_pdrop, seed)                         # d(drop(P)) -> dP through the same mask
+        dS = self._buf('att_dS', (B * H * L, Lp), torch.bfloat16)
+        _chk(_lib.load().sf_softmax_bwd_rows(P.data_ptr(), Lp, dP.data_ptr(), Lp, dS.data_ptr(), Lp, B * H * L, L, Lp, scale, _st()),
+             'sf_softmax_bwd_rows')
+        # transposed per-(clip, head) operands, contraction dimension zero-padded to Lp
+        kT = self._buf('att_kT', (B * H * hd, Lp), torch.bfloat16)
+        qT = self._buf('att_qT', (B * H * hd, Lp), torch.bfloat16)
+        dOT = self._buf('att_dOT', (B * H * hd, Lp), torch.bfloat16)
+        transpose(k, ld3, L * ld3, hd, kT, Lp, H * hd * Lp, hd * Lp, L, hd, Lp, B, H)
+        transpose(q, ld3, L * ld3, hd, qT, Lp, H * hd * Lp, hd * Lp, L, hd, Lp, B, H)
+        transpose(dO_b, D, L * D, hd, dOT, Lp, H * hd * Lp, hd * Lp, L, hd, Lp, B, H)
+        dST = self._buf('att_dST', (B * H * L, Lp), torch.bfloat16)
+        PT = self._buf('att_PT', (B * H * L, Lp), torch.bfloat16)
+        transpose(dS, Lp, H * L * Lp, L * Lp, dST, Lp, H * L * Lp, L * Lp, L, L, Lp, B, H)
+        transpose(Pv, Lp, H * L * Lp, L * Lp, PT, Lp, H * L * Lp, L * Lp, L, L, Lp, B, H)
+        dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
+        ldg = dqkv.stride(0)
+        bgemm(dS, Lp, H * L * Lp, L * Lp, kT, Lp, H * hd * Lp, hd * Lp, dq, ldg, L * ldg, hd, L, hd, Lp, B, H)     # dQ = dS K
+        bgemm(dST, Lp, H * L * Lp, L * Lp, qT, Lp, H * hd * Lp, hd * Lp, dk, ldg, L * ldg, hd, L, hd, Lp, B, H)    # dK = dS^T Q
+        bgemm(PT, Lp, H * L * Lp, L * Lp, dOT, Lp, H * hd * Lp, hd * Lp, dv, ldg, L * ldg, hd, L, hd, Lp, B, H)    # dV = P^T dO
+
+    def allreduce_grads(self):
+        """DDP-equivalent gradient averaging: one flat 90 MB bucket over RCCL (C1 in SURVEY §2.2)."""
+        from .dist import allreduce_mean_
+        allreduce_mean_(self.flat_g)
+
+    def optimizer_step(self, lr: Optional[float] = None):
+        """clip_grad_norm_(max_clip_norm) + Adam on the flat buffers (train_utils.py:373-386), then refresh operand copies."""
+        lib = _lib.load()
+        ws = self._buf('norm_ws', (1024,), torch.float32)
+        _chk(lib.sf_grad_norm(self.flat_g.data_ptr(), self.n, self.norm.data_ptr(), ws.data_ptr(), _st()), 'sf_grad_norm')
+        self.step_count += 1
+        _chk(lib.sf_adam_clip_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
+                                   self.flat_b.data_ptr(), self.n, self.norm.data_ptr(), float(self.max_clip_norm or 0.0),
+                                   float(self.lr if lr is None else lr), self.betas[0], self.betas[1], self.eps, self.step_count, _st()),
+             'sf_adam_clip_step')
+        self._refresh_transposed()
+
+
+class SyncTrainer(FlatTrainer):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device='cuda:0', lr: float = 2e-6, betas=(0.9, 0.999), eps: float = 1e-7,
+                 max_clip_norm: float = 1.0, embd_pdrop: float = 0.0, resid_pdrop: float = 0.0, attn_pdrop: float = 0.0, seed: int = 1337,
+                 seg_chunk: int = 112, engine: Optional[SynchformerEngine] = None):
+        self.embd_pdrop, self.resid_pdrop, self.attn_pdrop, self.seed = float(embd_pdrop or 0), float(resid_pdrop or 0), float(attn_pdrop or 0), seed
+        self.fwd_count = 0
+        self.engine = engine if engine is not None else SynchformerEngine(state_dict, torch.device(device), seg_chunk=seg_chunk)   # frozen extractors
+        self._init_flat(state_dict, trainable_keys(state_dict), device, lr, betas, eps, max_clip_norm)
+        self.n_blocks = len([k for k in self.keys if k.endswith('.ln1.weight')])
+        self.heads = 8
+        self.head_name = 'off_head' if 'transformer.off_head.weight' in self.p else 'sync_head'
+        self.n_out = self.p[f'transformer.{self.head_name}.weight'].shape[0]
+
     def _site_seed(self, site: int) -> int:
         """uint32 seed of dropout site `site` for the current forward pass (embd 0; block i: attn 1+3i, proj 2+3i, mlp 3+3i)."""
         h = (self.seed * 0x9E3779B1 + self.fwd_count * 0x85EBCA6B + site * 0xC2B2AE35 + 0x165667B1) & 0xFFFFFFFF
         h ^= h >> 15
         return (h * 0x2C1B3C6D) & 0xFFFFFFFF
-
-    # ---- linear layer forward / backward -------------------------------------------------------------------
-    def _wb(self, name):
-        return self.b[name + '.weight'], self.p[name + '.bias']
-
-    def _lin_bwd(self, name, dy_b, x_b, M, *, need_dx=True, dx_out=None, tag=''):
-        """dy_b (M, N) bf16 (row stride may exceed N), x_b (M, K) bf16 saved input.  Fills g[W], g[b]; returns dx fp32 (M, K)."""
-        N, K = self.p[name + '.weight'].shape
-        m_pad = ((M + 63) // 64) * 64
-        ws = self._buf('colsum_ws', (N * ((M + 63) // 64),), torch.float32)
-        colsum(dy_b, M, N, self.g[name + '.bias'], ws)
-        dyT = self._buf('dyT', (N, m_pad), torch.bfloat16)
-        xT = self._buf('xT', (K, m_pad), torch.bfloat16)
-        transpose(dy_b, dy_b.stride(0), 0, 0, dyT, m_pad, 0, 0, M, N, m_pad)
-        transpose(x_b, x_b.stride(0), 0, 0, xT, m_pad, 0, 0, M, K, m_pad)
-        ops.gemm(dyT, xT, None, self.g[name + '.weight'], M=N)                       # dW = dy^T x
-        if not need_dx:
-            return None
-        wT = self._wT[name + '.weight']                                               # (K, n_pad)
-        dx = dx_out if dx_out is not None else self._buf('dx_' + tag, (M, K), torch.float32)
-        if wT.shape[1] != N:                                                           # ragged N (heads): zero-padded contraction
-            dyp = self._buf('dy_pad', (M, wT.shape[1]), torch.bfloat16, zero=True)
-            dyp[:, :N].copy_(dy_b[:M, :N])
-            ops.gemm(dyp, wT, None, dx, M=M)
-        else:
-            ops.gemm(dy_b, wT, None, dx, M=M)
-        return dx
 
     # ---- forward with saved activations ----------------------------------------------------------------------
     def _forward(self, vfeat, afeat):
@@ -282,45 +355,7 @@ class SyncTrainer:
     # ---- attention backward: five strided-batched products per block -------------------------------------------
     def _attn_bwd(self, qkv, dO_b, dqkv, P_saved=None, seed=None):
         sv = self.sv
-        B, L, H = sv['B'], sv['L'], self.heads
-        hd = D // H
-        Lp = ((L + 31) // 32) * 32
-        scale = 1.0 / math.sqrt(hd)
-        ld3 = qkv.stride(0)
-        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
-        S = self._buf('att_S', (B * H * L, Lp), torch.float32)
-        if P_saved is None:                                                             # recompute the probabilities
-            bgemm(q, ld3, L * ld3, hd, k, ld3, L * ld3, hd, S, Lp, H * L * Lp, L * Lp, L, L, hd, B, H)
-            P = self._buf('att_P', (B * H * L, Lp), torch.bfloat16)
-            _chk(_lib.load().sf_softmax_rows(S.data_ptr(), Lp, P.data_ptr(), Lp, B * H * L, L, Lp, scale, _st()), 'sf_softmax_rows')
-            Pv = P                                                                      # the matrix that multiplied V in the forward
-        else:                                                                           # attn dropout: P saved, drop(P) regenerated
-            P = P_saved
-            Pv = self._buf('att_Pd', (B * H * L, Lp), torch.bfloat16, zero=True)
-            dropout(P, Pv, B * H * L, L, self.attn_pdrop, seed)
-        dP = S                                                                          # reuse: S is dead once P exists
-        bgemm(dO_b, D, L * D, hd, v, ld3, L * ld3, hd, dP, Lp, H * L * Lp, L * Lp, L, L, hd, B, H)
-        if P_saved is not None:
-            dropout(dP, dP, B * H * L, L, self.attn_pdrop, seed)                         # d(drop(P)) -> dP through the same mask
-        dS = self._buf('att_dS', (B * H * L, Lp), torch.bfloat16)
-        _chk(_lib.load().sf_softmax_bwd_rows(P.data_ptr(), Lp, dP.data_ptr(), Lp, dS.data_ptr(), Lp, B * H * L, L, Lp, scale, _st()),
-             'sf_softmax_bwd_rows')
-        # transposed per-(clip, head) operands, contraction dimension zero-padded to Lp
-        kT = self._buf('att_kT', (B * H * hd, Lp), torch.bfloat16)
-        qT = self._buf('att_qT', (B * H * hd, Lp), torch.bfloat16)
-        dOT = self._buf('att_dOT', (B * H * hd, Lp), torch.bfloat16)
-        transpose(k, ld3, L * ld3, hd, kT, Lp, H * hd * Lp, hd * Lp, L, hd, Lp, B, H)
-        transpose(q, ld3, L * ld3, hd, qT, Lp, H * hd * Lp, hd * Lp, L, hd, Lp, B, H)
-        transpose(dO_b, D, L * D, hd, dOT, Lp, H * hd * Lp, hd * Lp, L, hd, Lp, B, H)
-        dST = self._buf('att_dST', (B * H * L, Lp), torch.bfloat16)
-        PT = self._buf('att_PT', (B * H * L, Lp), torch.bfloat16)
-        transpose(dS, Lp, H * L * Lp, L * Lp, dST, Lp, H * L * Lp, L * Lp, L, L, Lp, B, H)
-        transpose(Pv, Lp, H * L * Lp, L * Lp, PT, Lp, H * L * Lp, L * Lp, L, L, Lp, B, H)
-        dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
-        ldg = dqkv.stride(0)
-        bgemm(dS, Lp, H * L * Lp, L * Lp, kT, Lp, H * hd * Lp, hd * Lp, dq, ldg, L * ldg, hd, L, hd, Lp, B, H)     # dQ = dS K
-        bgemm(dST, Lp, H * L * Lp, L * Lp, qT, Lp, H * hd * Lp, hd * Lp, dk, ldg, L * ldg, hd, L, hd, Lp, B, H)    # dK = dS^T Q
-        bgemm(PT, Lp, H * L * Lp, L * Lp, dOT, Lp, H * hd * Lp, hd * Lp, dv, ldg, L * ldg, hd, L, hd, Lp, B, H)    # dV = P^T dO
+        self.attn_bwd_seq(qkv, dO_b, dqkv, sv['B'], sv['L'], self.heads, D // self.heads, P_saved, seed)
 
     # ---- backward ------------------------------------------------------------------------------------------------
     def _backward(self, dlogits):
@@ -400,23 +435,6 @@ class SyncTrainer:
         self._backward(dlogits)
         self.logits = logits
         return self.loss
-
-    def allreduce_grads(self):
-        """DDP-equivalent gradient averaging: one flat 90 MB bucket over RCCL (C1 in SURVEY §2.2)."""
-        from .dist import allreduce_mean_
-        allreduce_mean_(self.flat_g)
-
-    def optimizer_step(self, lr: Optional[float] = None):
-        """clip_grad_norm_(max_clip_norm) + Adam on the flat buffers (train_utils.py:373-386), then refresh operand copies."""
-        lib = _lib.load()
-        ws = self._buf('norm_ws', (1024,), torch.float32)
-        _chk(lib.sf_grad_norm(self.flat_g.data_ptr(), self.n, self.norm.data_ptr(), ws.data_ptr(), _st()), 'sf_grad_norm')
-        self.step_count += 1
-        _chk(lib.sf_adam_clip_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
-                                   self.flat_b.data_ptr(), self.n, self.norm.data_ptr(), float(self.max_clip_norm or 0.0),
-                                   float(self.lr if lr is None else lr), self.betas[0], self.betas[1], self.eps, self.step_count, _st()),
-             'sf_adam_clip_step')
-        self._refresh_transposed()
 
     def train_step(self, vis: torch.Tensor, aud: torch.Tensor, targets: torch.Tensor, lr: Optional[float] = None) -> torch.Tensor:
         """One Stage-2 iteration (train_sync.py:159-192): frozen extractors -> trainable forward/backward -> all-reduce -> clip+Adam."""

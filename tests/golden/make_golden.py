@@ -169,9 +169,63 @@ def avclip(B=2, S=3, gain=2.0):
     print('avclip towers', tuple(vseg.shape), tuple(aseg.shape), 'loss', float(loss), 'sim spread', float(sim_v2a.max() - sim_v2a.min()))
 
 
+def _real_towers(gain):
+    ref = ref_import.import_reference()
+    tower = dict(ckpt_path=None, extract_features=True, agg_time_module='AveragePooling', add_global_repr=False,
+                 agg_segments_module='AveragePooling', max_segments=14)
+    with ref_import._cwd(ref_import.REF):
+        vt = ref['MotionFormer'](factorize_space_time=True, agg_space_module='TransformerEncoderLayer', **tower).eval()
+        at = ref['AST'](max_spec_t=66, factorize_freq_time=True, agg_freq_module='TransformerEncoderLayer', **tower).eval()
+    sd = synth.make_state_dict(SEED, gain=gain)
+    vt.load_state_dict({k[len('vfeat_extractor.'):]: v for k, v in sd.items() if k.startswith('vfeat_extractor.')}, strict=True)
+    at.load_state_dict({k[len('afeat_extractor.'):]: v for k, v in sd.items() if k.startswith('afeat_extractor.')}, strict=True)
+    return vt, at
+
+
+def avclip_grads(B=1, S=3, gain=2.0):
+    """Stage-1 backward through the REAL MotionFormer / AST towers (fp32 autograd, eval mode = no DropPath), with the AVCLIP head
+    restated as in `avclip` above: loss + per-parameter gradient norms + a few full gradients."""
+    vt, at = _real_towers(gain)
+    vis = rgb_frontend_ref(synth.make_video_u8(B, S, SEED)).float()
+    aud = synth.make_spectrogram(B, S, SEED)
+    scale = torch.tensor(0.07, requires_grad=True)
+    vseg, _ = vt(vis.permute(0, 1, 3, 2, 4, 5), False)
+    aseg, _ = at(aud.squeeze(2).permute(0, 1, 3, 2), False)
+    vfeat = torch.nn.functional.normalize(vseg.flatten(0, 1), dim=-1)
+    afeat = torch.nn.functional.normalize(aseg.flatten(0, 1), dim=-1)
+    sim_v2a, sim_a2v = vfeat @ afeat.mT / scale, afeat @ vfeat.mT / scale
+    tgt = torch.eye(*sim_v2a.shape)
+    loss = (torch.nn.functional.cross_entropy(sim_v2a, tgt) + torch.nn.functional.cross_entropy(sim_a2v, tgt)) / 2
+    loss.backward()
+    named = [('vfeat_extractor.' + n, p) for n, p in vt.named_parameters()] + [('afeat_extractor.' + n, p) for n, p in at.named_parameters()]
+    named = [(n, p) for n, p in named if p.grad is not None] + [('logit_scale', scale)]
+    keep = ('vfeat_extractor.cls_token', 'vfeat_extractor.temp_embed', 'vfeat_extractor.blocks.0.timeattn.qkv.bias', 'vfeat_extractor.blocks.0.norm3.weight',
+            'vfeat_extractor.blocks.11.attn.proj.bias', 'vfeat_extractor.blocks.5.mlp.fc2.bias', 'vfeat_extractor.norm.weight',
+            'vfeat_extractor.spatial_attn_agg.cls_token', 'vfeat_extractor.spatial_attn_agg.self_attn.in_proj_bias',
+            'vfeat_extractor.patch_embed_3d.proj.bias', 'afeat_extractor.ast.embeddings.cls_token', 'afeat_extractor.ast.embeddings.position_embeddings',
+            'afeat_extractor.ast.encoder.layer.0.attention.attention.query.bias', 'afeat_extractor.ast.encoder.layer.11.output.dense.bias',
+            'afeat_extractor.ast.layernorm.weight', 'afeat_extractor.freq_attn_agg.linear1.bias', 'afeat_extractor.ast.embeddings.patch_embeddings.projection.bias')
+    out = dict(seed=np.int64(SEED), B=np.int64(B), S=np.int64(S), gain=np.float64(gain), loss=loss.detach().numpy(), logit_scale_grad=scale.grad.numpy())
+    names, norms = [], []
+    for n, p in named:
+        names.append(n); norms.append(float(p.grad.norm()))
+        if n in keep:
+            out['grad__' + n.replace('.', '__')] = p.grad.numpy()
+    out['names'] = np.array(names); out['grad_norms'] = np.array(norms, dtype=np.float64)
+    d = dict(named)
+    out['gradrows__vfeat_extractor__blocks__0__timeattn__qkv__weight'] = d['vfeat_extractor.blocks.0.timeattn.qkv.weight'].grad[[0, 768, 1536, 2303]].numpy()
+    out['gradrows__vfeat_extractor__blocks__6__attn__qkv__weight'] = d['vfeat_extractor.blocks.6.attn.qkv.weight'].grad[[0, 768, 1536, 2303]].numpy()
+    out['gradrows__vfeat_extractor__blocks__11__mlp__fc1__weight'] = d['vfeat_extractor.blocks.11.mlp.fc1.weight'].grad[[0, 1000, 2000, 3071]].numpy()
+    out['gradrows__afeat_extractor__ast__encoder__layer__3__attention__attention__key__weight'] = \
+        d['afeat_extractor.ast.encoder.layer.3.attention.attention.key.weight'].grad[[0, 768 // 2, 767]].numpy()
+    np.savez_compressed(HERE / f'avclip_grads_B{B}S{S}.npz', **out)
+    print('avclip grads: loss', float(loss), 'total grad norm', float(np.sqrt((np.array(norms) ** 2).sum())), 'n tensors', len(names),
+          'dscale', float(scale.grad))
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['sync', 'sync_gain2', 'syncability', 'train', 'avclip']
+    which = sys.argv[1:] or ['sync', 'sync_gain2', 'syncability', 'train', 'avclip', 'avclip_grads']
     if 'sync' in which:
         e2e_sync(2)
     if 'sync_gain2' in which:
@@ -182,3 +236,5 @@ if __name__ == '__main__':
         train_grads(2)
     if 'avclip' in which:
         avclip(2, 3)
+    if 'avclip_grads' in which:
+        avclip_grads(1, 3)
