@@ -41,7 +41,7 @@ def parse():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL over xGMI; default) | gloo (plumbing tests)')
     ap.add_argument('--single-device', action='store_true', help='TEST ONLY: put every rank on cuda:0 (needs --dist-backend gloo)')
-    ap.add_argument('--workload', choices=['infer', 'train'], default='infer',
+    ap.add_argument('--workload', choices=['infer', 'train', 'stage1'], default='infer',
                     help="infer = BASELINE configs[1] (headline metric); train = configs[2]: Stage-2 step, frozen extractors, "
                          "backward + RCCL gradient all-reduce + fused clip/Adam (dropout 0.1 as in sync.yaml)")
     return ap.parse_args()
@@ -142,6 +142,12 @@ def main():
         eng = trainer.engine
         targets = synth.make_targets(B, 21, seed=1337 + rank).to(dev)
         step_fn = lambda v, a: trainer.train_step(v, a, targets)
+    elif args.workload == 'stage1':
+        # Stage-1 AVCLIP train step (configs/segment_avclip.yaml: base_batch_size 2 clips x 14 segments per GPU, both towers trainable)
+        from synchformer_amd.stage1 import AVCLIPTrainer
+        sd = {k: v for k, v in synth.make_state_dict(1337).items() if k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}
+        trainer = AVCLIPTrainer(sd, dev, lr=1e-4)
+        step_fn = lambda v, a: trainer.train_step(v, a).reshape(1)
     else:
         eng = SynchformerEngine(synth.make_state_dict(1337), dev, seg_chunk=args.seg_chunk)
         step_fn = eng.forward
@@ -173,19 +179,24 @@ def main():
     value = clips / dt
     if rank == 0:
         out = {
-            'metric': 'clips/sec (14-seg offset pred)' if args.workload == 'infer' else 'clips/sec (Stage-2 train step, 14 segments)',
+            'metric': {'infer': 'clips/sec (14-seg offset pred)', 'train': 'clips/sec (Stage-2 train step, 14 segments)',
+                       'stage1': 'clips/sec (Stage-1 AVCLIP train step, 14 segments)'}[args.workload],
             'value': round(value, 3), 'unit': 'clips/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': ('BASELINE configs[1]: batched offset inference, configs/sync.yaml model (237.5M params, '
                                     'random-init), uint8 224x224 frames + 128x66 log-mel resident in HBM, full forward to 21-way logits')
                        if args.workload == 'infer' else
+                       ('Stage-1 segment-level contrastive train step (configs/segment_avclip.yaml): forward with saved activations + backward of '
+                        'both towers (214.8M params), symmetric InfoNCE over B*14 segments, flat gradient all-reduce, fused clip+AdamW')
+                       if args.workload == 'stage1' else
                        ('BASELINE configs[2]: Stage-2 sync-module train step (configs/sync.yaml, embd/resid/attn dropout 0.1): frozen extractors forward, '
                         'backward of proj + sync transformer (22.6M params), flat 90 MB RCCL gradient all-reduce, fused clip+Adam'),
                        'clips_per_gpu': B, 'segments': 14, 'seg_chunk': args.seg_chunk,
                        'parallelism': f'replicas x{world}' if args.workload == 'infer' else f'dp{world}'},
-            'path_flop_per_clip': FLOP_PER_CLIP,
-            'path_mfma_frac': round(value * FLOP_PER_CLIP / (world * PEAK_BF16), 4),
+            # stage1: forward + dgrad + wgrad of every linear ~ 3x the forward FLOPs (attention backward ~2.5x; approximate)
+            'path_flop_per_clip': FLOP_PER_CLIP * (3 if args.workload == 'stage1' else 1),
+            'path_mfma_frac': round(value * FLOP_PER_CLIP * (3 if args.workload == 'stage1' else 1) / (world * PEAK_BF16), 4),
         }
         if n_gemm:
             ach = gemm_flop / (gemm_ms * 1e-3) / 1e12

@@ -130,19 +130,21 @@ extern "C" int sf_softmax_bwd_rows(const uint16_t* P, int64_t ldp, const float* 
 // LayerNorm backward over 768 columns (statistics recomputed from x):
 //   dx[omap(r)] (=|+=) rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)),  xhat = (x[imap(r)] - mean) * rstd
 //   part[blk][0][c] = sum_rows dy*xhat (dgamma), part[blk][1][c] = sum_rows dy (dbeta), reduced by sf_colsum_partials.
-// One wave per row, 4 rows per block -> the block's 4 waves combine their per-column partials through LDS.
+// One wave per row, 4 * rpw rows per block (each wave walks rpw rows, keeping its dgamma / dbeta partials in registers) -> the
+// block's 4 waves combine their per-column partials through LDS.
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm768_bwd_kernel(const float* __restrict__ x, int64_t ldx, RowMap xmap, const float* __restrict__ gamma,
                                                                 const float* __restrict__ dy, int64_t lddy, RowMap dymap, float* __restrict__ dx,
                                                                 int64_t lddx, RowMap dxmap, int accumulate, float* __restrict__ part, int64_t rows,
-                                                                float eps) {
+                                                                float eps, int rpw) {
   __shared__ float red[4][2][768];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
   float4 dg[3], db[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) { dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i]; }
-  if (r < rows) {
+  for (int it = 0; it < rpw; ++it) {
+    const int64_t r = ((int64_t)blockIdx.x * rpw + it) * 4 + wave;
+    if (r >= rows) break;
     const float* xr = x + map_row(xmap, r) * ldx;
     const float* gr = dy + map_row(dymap, r) * lddy;
     float4 v[3], g[3];
@@ -170,8 +172,8 @@ __global__ __launch_bounds__(256) void layernorm768_bwd_kernel(const float* __re
       gd[i] = make_float4(w.x * g[i].x, w.y * g[i].y, w.z * g[i].z, w.w * g[i].w);
       a += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
       b += (gd[i].x * v[i].x + gd[i].y * v[i].y) + (gd[i].z * v[i].z + gd[i].w * v[i].w);
-      dg[i] = make_float4(g[i].x * v[i].x, g[i].y * v[i].y, g[i].z * v[i].z, g[i].w * v[i].w);
-      db[i] = g[i];
+      dg[i].x += g[i].x * v[i].x; dg[i].y += g[i].y * v[i].y; dg[i].z += g[i].z * v[i].z; dg[i].w += g[i].w * v[i].w;
+      db[i].x += g[i].x; db[i].y += g[i].y; db[i].z += g[i].z; db[i].w += g[i].w;
     }
     a = wave_sum(a) * (1.0f / 768); b = wave_sum(b) * (1.0f / 768);
     float* dr = dx + map_row(dxmap, r) * lddx;
@@ -200,11 +202,17 @@ __global__ __launch_bounds__(256) void layernorm768_bwd_kernel(const float* __re
 // out[c] (=|+=) sum_p part[p * stride + c], c < cols  (second stage of the two-stage column reductions)
 __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part, int64_t n_part, int64_t stride, float* __restrict__ out,
                                                                int cols, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;       // 64 columns x 4 interleaved row lanes per block
   float s = 0.f;
-  for (int64_t p = 0; p < n_part; ++p) s += part[p * stride + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < cols)
+    for (int64_t p = g; p < n_part; p += 4) s += part[p * stride + c];
+  red[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (g == 0 && c < cols) {
+    s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    out[c] = accumulate ? out[c] + s : s;
+  }
 }
 
 extern "C" int sf_layernorm768_bwd(const float* x, int64_t ldx, const int64_t* x_map, const float* gamma, const float* dy, int64_t lddy,
@@ -212,13 +220,14 @@ extern "C" int sf_layernorm768_bwd(const float* x, int64_t ldx, const int64_t* x
                                    float* dbeta, int accumulate_dparams, float* workspace, int64_t rows, float eps, void* stream) {
   SF_CHECK_ARG(x && gamma && dy && dx && dgamma && dbeta && workspace, "sf_layernorm768_bwd: null pointer");
   if (rows <= 0) return 0;
-  const int64_t nblk = (rows + 3) / 4;
+  const int rpw = rows >= 16384 ? 8 : (rows >= 4096 ? 2 : 1);      // keep >= 1k blocks in flight, <= ~1.4k partial rows at Stage-1 sizes
+  const int64_t nblk = (rows + 4 * rpw - 1) / (4 * rpw);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(layernorm768_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, ldx, sf_rowmap(x_map), gamma, dy, lddy, sf_rowmap(dy_map), dx,
-                     lddx, sf_rowmap(dx_map), accumulate_dx, workspace, rows, eps);
+                     lddx, sf_rowmap(dx_map), accumulate_dx, workspace, rows, eps, rpw);
   SF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3(3), dim3(256), 0, s, workspace, nblk, (int64_t)2 * 768, dgamma, 768, accumulate_dparams);
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3(3), dim3(256), 0, s, workspace + 768, nblk, (int64_t)2 * 768, dbeta, 768, accumulate_dparams);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(12), dim3(256), 0, s, workspace, nblk, (int64_t)2 * 768, dgamma, 768, accumulate_dparams);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(12), dim3(256), 0, s, workspace + 768, nblk, (int64_t)2 * 768, dbeta, 768, accumulate_dparams);
   SF_LAUNCH_CHECK();
   return 0;
 }
@@ -242,7 +251,7 @@ extern "C" int sf_colsum(const void* x, int x_dtype, int64_t ldx, int64_t rows, 
                          void* stream) {
   SF_CHECK_ARG(x && out && workspace && (x_dtype == SF_F32 || x_dtype == SF_BF16), "sf_colsum: bad arguments");
   if (rows <= 0 || cols <= 0) return 0;
-  const int rpb = 64;
+  const int rpb = rows >= 16384 ? 256 : 64;       // workspace contract (cols * ceil(rows / 64)) is an upper bound
   const int64_t nblk = (rows + rpb - 1) / rpb;
   SF_CHECK_ARG(nblk < 65536, "sf_colsum: too many rows");
   dim3 grid((cols + 255) / 256, (unsigned)nblk);
@@ -250,7 +259,7 @@ extern "C" int sf_colsum(const void* x, int x_dtype, int64_t ldx, int64_t rows, 
   if (x_dtype == SF_BF16) hipLaunchKernelGGL((colsum_stage1_kernel<true>), grid, dim3(256), 0, s, x, ldx, rows, cols, rpb, workspace);
   else hipLaunchKernelGGL((colsum_stage1_kernel<false>), grid, dim3(256), 0, s, x, ldx, rows, cols, rpb, workspace);
   SF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, workspace, nblk, (int64_t)cols, out, cols, accumulate);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, workspace, nblk, (int64_t)cols, out, cols, accumulate);
   SF_LAUNCH_CHECK();
   return 0;
 }

@@ -406,8 +406,10 @@ class Synchformer(torch.nn.Module):
 class AVCLIP(torch.nn.Module):
     """Stage-1 segment-level audio-visual contrastive model (train_clip_src/open_clip/model.py:449-585,
     configs/segment_avclip.yaml:4-46): same constructor, attribute names (`v_encoder`, `a_encoder`, `vproj`, `aproj`,
-    `logit_scale`) and output dict.  Forward / evaluation only: the towers have no backward yet, so calling it with
-    autograd enabled on trainable towers raises (SURVEY §8 a22/a24 are the next rows)."""
+    `logit_scale`) and output dict.  Under torch.no_grad() it is the evaluation / zero-shot path; with autograd enabled the
+    step runs on synchformer_amd.stage1.AVCLIPTrainer (HIP forward with saved activations + HIP backward) and the returned loss
+    carries the parameter gradients through an autograd bridge, so `backward(total_loss, scaler)`, clip_grad_norm_, AdamW and
+    DistributedDataParallel of train_clip_src/training/train.py:103-154 run unchanged."""
 
     def __init__(self, n_embd: int, afeat_extractor, vfeat_extractor, aproj, vproj, init_scale: float = 0.07,
                  clamp_scale_min: float = 0.001, clamp_scale_max: float = 0.5, gather_for_loss: bool = False):
@@ -470,6 +472,8 @@ class AVCLIP(torch.nn.Module):
         """open_clip/model.py:475-504."""
         assert alpha == 0.0, f'alpha={alpha} not supported yet'
         logit_scales = self.clamp_logit_scales()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._train_forward(vis, aud, logit_scales)
         vfeat, _, afeat, _ = self.encode_streams(vis, aud, for_loop, do_norm=True)
         if world_size > 1 and self.gather_for_loss:
             from .dist import all_gather_rows
@@ -479,6 +483,33 @@ class AVCLIP(torch.nn.Module):
         loss_avc, _ = self.compute_loss(vfeat, afeat, vfeat_all.mT, afeat_all.mT, self.logit_scale, alpha=0)
         return {'rgb_features': (vfeat, None), 'audio_features': (afeat, None), 'logit_scales': logit_scales,
                 'losses': {'segment_contrastive_loss': loss_avc}}
+
+    # -- Stage-1 training (both towers trainable, configs/segment_avclip.yaml:13,25) ----------------------------
+    def _named_trainables(self):
+        named = [('vfeat_extractor.' + n, p) for n, p in self.v_encoder.named_parameters()]
+        named += [('afeat_extractor.' + n, p) for n, p in self.a_encoder.named_parameters()] + [('logit_scale', self.logit_scale)]
+        return {n: p for n, p in named if not n.startswith('vfeat_extractor.patch_embed.')}
+
+    def _train_forward(self, vis, aud, logit_scales):
+        from .stage1 import AVCLIPTrainer, AVCLIPTrainFunction
+        named = self._named_trainables()
+        if any(not p.requires_grad for p in named.values()):
+            raise NotImplementedError('partially frozen AVCLIP (lock_rgb / lock_audio) is not supported: train all of it or none')
+        tr = getattr(self, '_sf_trainer', None)
+        if tr is None:
+            tr = AVCLIPTrainer({k: p.detach() for k, p in named.items()}, self.logit_scale.device,
+                               clamp_scale=(self.clamp_scale_min, self.clamp_scale_max), gather_for_loss=self.gather_for_loss)
+            assert tr.keys == list(named), 'parameter order mismatch'
+            object.__setattr__(self, '_sf_trainer', tr)
+            object.__setattr__(self, '_sf_trainer_key', None)
+        key = tuple((p.data_ptr(), p._version) for p in named.values())
+        if key != self._sf_trainer_key:                                      # an external optimizer moved the nn.Parameters
+            tr.load_params({k: p.detach() for k, p in named.items()})
+            object.__setattr__(self, '_sf_trainer_key', key)
+        B, S, Ta, Fq = aud.shape
+        loss = AVCLIPTrainFunction.apply(tr, vis.permute(0, 1, 3, 2, 4, 5), aud.permute(0, 1, 3, 2).reshape(B, S, 1, Fq, Ta), *named.values())
+        return {'rgb_features': (tr.vfeat.clone(), None), 'audio_features': (tr.afeat.clone(), None), 'logit_scales': logit_scales,
+                'losses': {'segment_contrastive_loss': loss}}
 
     def forward_for_logging(self, vis, aud, for_momentum=False, for_loop=False, do_norm=True):
         """open_clip/model.py:535-567: features + the four similarity matrices + loss (zero-shot evaluation feeds on these)."""

@@ -470,3 +470,20 @@ class AVCLIPTrainer(FlatTrainer):
     def model_state_dict(self) -> Dict[str, torch.Tensor]:
         """Checkpoint in the reference's AVCLIP key names (v_encoder. / a_encoder. / logit_scale)."""
         return {k.replace(V + '.', 'v_encoder.').replace(A + '.', 'a_encoder.'): t.detach().clone() for k, t in self.p.items()}
+
+
+class AVCLIPTrainFunction(torch.autograd.Function):
+    """autograd bridge for the drop-in `AVCLIP` module: the forward runs the whole HIP step (forward + backward, the loss is a
+    scalar so its parameter gradients are known up to the incoming scale), the backward hands `grad_output * dloss/dparam` to
+    autograd - GradScaler's scaled loss, DistributedDataParallel's reducer hooks and torch.optim.AdamW then work on the
+    module's nn.Parameters unchanged (train_clip_src/training/train.py:143-154)."""
+
+    @staticmethod
+    def forward(ctx, trainer: AVCLIPTrainer, vis, aud, *params):
+        ctx.trainer = trainer
+        return trainer.forward_backward(vis, aud).clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        tr = ctx.trainer
+        return (None, None, None) + tuple(tr.g[k] * gout for k in tr.keys)

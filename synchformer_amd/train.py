@@ -153,11 +153,22 @@ class FlatTrainer:
         m_pad = ((M + 63) // 64) * 64
         ws = self._buf('colsum_ws', (N * ((M + 63) // 64),), torch.float32)
         colsum(dy_b if dy_f32 is None else dy_f32, M, N, self.g[bkey], ws, accumulate=acc_bias)   # fp32 dy when the caller has it
+        # dW = dy^T x: an (N, K) output is only (N/128)*(K/128) tiles (36 for a 768x768 weight) however long the M contraction is,
+        # so for long M the contraction is split into `split` chunks run as one batched GEMM (fills the 256 CUs) and summed after
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        split = max(1, min(32, 768 // tiles)) if M >= 8192 else 1
+        kc = ((m_pad // split + 63) // 64) * 64
+        m_pad = kc * split if split > 1 else m_pad
         dyT = self._buf('dyT', (N, m_pad), torch.bfloat16)
         xT = self._buf('xT', (K, m_pad), torch.bfloat16)
         transpose(dy_b, dy_b.stride(0), 0, 0, dyT, m_pad, 0, 0, M, N, m_pad)
         transpose(x_b, x_b.stride(0), 0, 0, xT, m_pad, 0, 0, M, K, m_pad)
-        ops.gemm(dyT, xT, None, self.g[wkey].view(N, K), M=N)                        # dW = dy^T x
+        if split > 1:
+            part = self._buf('wgrad_part', (split * N, K), torch.float32)
+            bgemm(dyT, m_pad, kc, 0, xT, m_pad, kc, 0, part, K, N * K, 0, N, K, kc, split, 1)
+            _chk(_lib.load().sf_seqsum(part.data_ptr(), K, split, N, K, self.g[wkey].data_ptr(), 0, _st()), 'sf_seqsum')
+        else:
+            ops.gemm(dyT, xT, None, self.g[wkey].view(N, K), M=N)
         if not need_dx:
             return None
         wT = self._wT[wkey]                                                           # (K, n_pad)

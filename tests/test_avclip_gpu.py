@@ -61,7 +61,7 @@ def test_avclip_forward_matches_reference_towers(gpu):
     vis = O.rgb_frontend(synth.make_video_u8(B, S, 1337)).permute(0, 1, 3, 2, 4, 5).to(gpu)     # (B, S, C, Tv, H, W)
     aud = synth.make_spectrogram(B, S, 1337).squeeze(2).permute(0, 1, 3, 2).contiguous().to(gpu)  # (B, S, Ta, F)
     with pytest.raises(NotImplementedError, match='no backward'):
-        m(vis, aud)                                             # trainable towers + autograd on: loud, not silently detached
+        m.encode_streams(vis, aud)                              # feature extraction with autograd on: loud, not silently detached
     with torch.no_grad():
         out = m(vis, aud)
         log = m.forward_for_logging(vis, aud)

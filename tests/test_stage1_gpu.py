@@ -209,3 +209,103 @@ def test_avclip_train_steps_reduce_loss(gpu):
     assert 0.001 <= float(tr.p['logit_scale']) <= 0.5
     ck = tr.model_state_dict()
     assert 'logit_scale' in ck and any(k.startswith('v_encoder.blocks.0.') for k in ck) and len(ck) == 451 - 2
+
+
+def test_avclip_dropin_training_loop(gpu):
+    """The reference's Stage-1 loop body (train_clip_src/training/train.py:103-154) on the drop-in module: scaled loss.backward(),
+    unscale, clip_grad_norm_, torch.optim.AdamW - gradients arrive on the nn.Parameters through the autograd bridge."""
+    import synchformer_amd as sa
+    from synchformer_amd import synth
+    from oracle import synchformer_cpu as O
+    m = sa.instantiate_from_config(sa.avclip_yaml_model_config())
+    sd = synth.make_state_dict(1337, gain=2.0)
+    own = {k.replace('vfeat_extractor.', 'v_encoder.').replace('afeat_extractor.', 'a_encoder.'): v for k, v in sd.items()
+           if k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}
+    own['logit_scale'] = torch.tensor(0.07)
+    m.load_state_dict(own, strict=True)
+    m = m.to(gpu).train()
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    B, S = 2, 2
+    vis = O.rgb_frontend(synth.make_video_u8(B, S, 1337)).permute(0, 1, 3, 2, 4, 5).contiguous().to(gpu)      # (B, S, C, Tv, H, W)
+    aud = synth.make_spectrogram(B, S, 1337).squeeze(2).permute(0, 1, 3, 2).contiguous().to(gpu)               # (B, S, Ta, F)
+    losses = []
+    for it in range(4):
+        opt.zero_grad()
+        out = m(vis, aud)
+        loss = sum(out['losses'].values())
+        (loss * 1024.0).backward()                                            # GradScaler-style scaled loss
+        if it == 0:
+            tr = m._sf_trainer
+            g_mod = getattr(m.v_encoder.blocks, '3').attn.qkv.weight.grad / 1024.0
+            assert torch.allclose(g_mod, tr.g['vfeat_extractor.blocks.3.attn.qkv.weight'], rtol=1e-5, atol=1e-9)
+            assert m.v_encoder.patch_embed.proj.weight.grad is None
+            assert out['rgb_features'][0].shape == (B * S, 768)
+        for p in params:
+            p.grad.div_(1024.0)                                               # scaler.unscale_
+        torch.nn.utils.clip_grad_norm_(params, 1.0, norm_type=2.0)
+        opt.step()
+        losses.append(float(loss.detach()))
+    print('drop-in stage-1 losses', [f'{x:.4f}' for x in losses])
+    assert losses[-1] < losses[0] - 1e-3
+    with torch.no_grad():                                                     # eval path sees the updated weights
+        ev = m(vis, aud)
+    assert float(ev['losses']['segment_contrastive_loss']) < losses[0]
+
+
+def _gather_head_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from synchformer_amd import synth
+        from synchformer_amd.stage1 import AVCLIPTrainer
+        sd = {k: v for k, v in synth.make_state_dict(1337).items() if k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}
+        tr = AVCLIPTrainer(sd, 'cuda:0', gather_for_loss=True)
+        n = 4
+        g = torch.Generator().manual_seed(7)
+        v_all = torch.nn.functional.normalize(torch.randn(world * n, 768, generator=g), dim=-1)
+        a_all = torch.nn.functional.normalize(v_all + 0.7 * torch.randn(world * n, 768, generator=g), dim=-1)
+        dv, da = tr._head(v_all[rank * n:(rank + 1) * n].cuda(), a_all[rank * n:(rank + 1) * n].cuda())
+        q.put((rank, dv.cpu(), da.cpu(), float(tr.losses.mean()), float(tr.g['logit_scale'])))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gathered_contrastive_head_two_ranks(gpu):
+    """gather_for_loss=True with world_size 2 (two processes sharing the one GPU, gloo): forward all-gather of the embeddings
+    and the sum-over-ranks backward of torch.distributed.nn.all_gather (open_clip/model.py:489-494) against single-process autograd."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    world, n = 2, 4
+    procs = [ctx.Process(target=_gather_head_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(7)
+    v_all = torch.nn.functional.normalize(torch.randn(world * n, 768, generator=g), dim=-1)
+    a_all = torch.nn.functional.normalize(v_all + 0.7 * torch.randn(world * n, 768, generator=g), dim=-1)
+    vr, ar = v_all.clone().requires_grad_(True), a_all.clone().requires_grad_(True)
+    scales = [torch.tensor(0.07, requires_grad=True) for _ in range(world)]
+    tgt = torch.eye(n, world * n)
+    rank_losses = []
+    for r in range(world):                                                    # each rank: local rows vs ALL columns, eye(n, m) targets
+        s1 = vr[r * n:(r + 1) * n] @ ar.T / scales[r]
+        s2 = ar[r * n:(r + 1) * n] @ vr.T / scales[r]
+        rank_losses.append((torch.nn.functional.cross_entropy(s1, tgt) + torch.nn.functional.cross_entropy(s2, tgt)) / 2)
+    sum(rank_losses).backward()
+    for r, dv, da, loss, dscale in res:
+        assert abs(loss - float(rank_losses[r])) < 1e-5
+        assert (dv - vr.grad[r * n:(r + 1) * n]).abs().max() < 1e-5 * max(1.0, vr.grad.abs().max().item())
+        assert (da - ar.grad[r * n:(r + 1) * n]).abs().max() < 1e-5 * max(1.0, ar.grad.abs().max().item())
+        assert abs(dscale - float(scales[r].grad)) < 1e-4 * abs(float(scales[r].grad))
