@@ -21,6 +21,7 @@
 //   * workgroup -> tile mapping is XCD-aware (block b runs on XCD b % 8): each XCD walks a contiguous range of
 //     tiles, N fastest, so an A row-panel is fetched once per XCD-local L2 and W stays L2/MALL-resident.
 #include "sf_common.h"
+#include <stdlib.h>
 #include "../../include/synchformer_hip.h"
 
 #ifndef SF_ABL
@@ -69,6 +70,33 @@ __device__ __forceinline__ void dma4(const void* g0, const void* g1, const void*
       : "memory", "scc");
 }
 
+__device__ __forceinline__ void dma4_nt(const void* g0, const void* g1, const void* g2, const void* g3, uint32_t l0) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off nt\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off nt\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(l0)
+      : "memory", "scc");
+}
+
+// cache-policy bits of the epilogue's buffer ops (aux operand: bit 0 sc0/glc, bit 1 nt/slc, bit 4 sc1)
+// Outputs are written once and the fp32 residual is read once: marked non-temporal (nt) so that they do not evict the weight matrix
+// (3.5-4.7 MB against a 4 MB L2 per XCD) and the A panels the other column tiles of the same rows are about to read.  Measured on
+// M = 175,728: qkv 891 -> 950 TFLOP/s, fc1+GELU 717 -> 744, proj+residual 563 -> 618 (profiles/r01_gemm_configs.md).
+#ifndef SF_EPI_STORE_AUX
+#define SF_EPI_STORE_AUX 2
+#endif
+#ifndef SF_EPI_LOAD_AUX
+#define SF_EPI_LOAD_AUX 2
+#endif
+#ifndef SF_A_NT
+#define SF_A_NT 0      // 1: stream the A operand (activations) through L2 with the nt hint as well
+#endif
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
@@ -88,18 +116,18 @@ __device__ __forceinline__ void epi_group_store(float4 (&v)[4], const float4& bi
     if (HAS_RES) { x.x += res[ps].x; x.y += res[ps].y; x.z += res[ps].z; x.w += res[ps].w; }
     if (OUT_BF16) {
       u32x2 o; o.x = pack_bf2(x.x, x.y); o.y = pack_bf2(x.z, x.w);
-      __builtin_amdgcn_raw_buffer_store_b64(o, rc, coff + ps * cstep, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(o, rc, coff + ps * cstep, 0, SF_EPI_STORE_AUX);
     } else {
       u32x4 o;
       o.x = __float_as_uint(x.x); o.y = __float_as_uint(x.y); o.z = __float_as_uint(x.z); o.w = __float_as_uint(x.w);
-      __builtin_amdgcn_raw_buffer_store_b128(o, rc, coff + ps * cstep, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(o, rc, coff + ps * cstep, 0, SF_EPI_STORE_AUX);
     }
   }
 }
 __device__ __forceinline__ void epi_group_load_res(float4 (&res)[4], __amdgpu_buffer_rsrc_t rr, uint32_t roff, uint32_t rstep) {
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
-    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rr, roff + ps * rstep, 0, 0);
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rr, roff + ps * rstep, 0, SF_EPI_LOAD_AUX);
     res[ps] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
   }
 }
@@ -447,7 +475,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p
   const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(lds_addr(smem) + (wave * 4) * 1024);
   auto stage = [&](int s, int kt) {
     const uint32_t l = lds_wave + s * P_STAGE;
-    dma4(a_src[0] + kt * PBK, a_src[1] + kt * PBK, a_src[2] + kt * PBK, a_src[3] + kt * PBK, l);
+    if (SF_A_NT) dma4_nt(a_src[0] + kt * PBK, a_src[1] + kt * PBK, a_src[2] + kt * PBK, a_src[3] + kt * PBK, l);
+    else dma4(a_src[0] + kt * PBK, a_src[1] + kt * PBK, a_src[2] + kt * PBK, a_src[3] + kt * PBK, l);
     dma4(b_src[0] + kt * PBK, b_src[1] + kt * PBK, b_src[2] + kt * PBK, b_src[3] + kt * PBK, l + PBM * PBK * 2);
   };
 
