@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--workload', choices=['infer', 'train', 'stage1'], default='infer',
                     help="infer = BASELINE configs[1] (headline metric); train = configs[2]: Stage-2 step, frozen extractors, "
                          "backward + RCCL gradient all-reduce + fused clip/Adam (dropout 0.1 as in sync.yaml)")
+    ap.add_argument('--graph', action='store_true', help='replay the forward as one captured HIP graph (infer workload only)')
     return ap.parse_args()
 
 
@@ -159,10 +160,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.graph:
+        assert args.workload == 'infer', '--graph serves the inference workload'
+        step_fn = eng.capture(vis, aud)
     for _ in range(args.warmup):
         logits = step_fn(vis, aud)
     with GemmTimer() as gt:
-        gt.enabled = (rank == 0) and not args.no_kernel_timing
+        gt.enabled = (rank == 0) and not args.no_kernel_timing and not args.graph
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -192,7 +196,7 @@ def main():
                        if args.workload == 'stage1' else
                        ('BASELINE configs[2]: Stage-2 sync-module train step (configs/sync.yaml, embd/resid/attn dropout 0.1): frozen extractors forward, '
                         'backward of proj + sync transformer (22.6M params), flat 90 MB RCCL gradient all-reduce, fused clip+Adam'),
-                       'clips_per_gpu': B, 'segments': 14, 'seg_chunk': args.seg_chunk,
+                       'clips_per_gpu': B, 'segments': 14, 'seg_chunk': args.seg_chunk, 'hip_graph': bool(args.graph),
                        'parallelism': f'replicas x{world}' if args.workload == 'infer' else f'dp{world}'},
             # stage1: forward + dgrad + wgrad of every linear ~ 3x the forward FLOPs (attention backward ~2.5x; approximate)
             'path_flop_per_clip': FLOP_PER_CLIP * (3 if args.workload == 'stage1' else 1),

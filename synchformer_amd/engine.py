@@ -396,3 +396,32 @@ class SynchformerEngine:
     def forward(self, vis: torch.Tensor, aud: torch.Tensor) -> torch.Tensor:
         """Synchformer.forward (sync_model.py:38-70) without the loss: logits (B, n_out) fp32."""
         return self.sync_transformer(self.extract_vfeats(vis), self.extract_afeats(aud))
+
+    # ------------------------------------------------------------------------------------------------
+    # HIP-graph replay of the whole forward (launch-bound regimes: single-clip latency, small batches)
+    # ------------------------------------------------------------------------------------------------
+    def capture(self, vis: torch.Tensor, aud: torch.Tensor):
+        """Capture forward() for THESE input shapes / dtypes into one HIP graph (the schedule is a fixed sequence of ~900 launches
+        with no host decisions in it) and return `run(vis, aud) -> logits`.  Replay removes the per-launch host cost (ctypes +
+        hipLaunchKernel, ~5 us each), which is what bounds a single-clip forward.  The returned logits tensor is reused by every
+        replay: copy it out before the next call if it must survive."""
+        static_vis, static_aud = vis.clone(), aud.clone()
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):                                # warm-up off the capture: workspaces, lazy function attributes
+            for _ in range(2):
+                self.forward(static_vis, static_aud)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = self.forward(static_vis, static_aud)
+
+        def run(v: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
+            if v.shape != static_vis.shape or a.shape != static_aud.shape or v.dtype != static_vis.dtype:
+                raise ValueError('captured graph serves one input shape/dtype; capture again for another')
+            static_vis.copy_(v, non_blocking=True)
+            static_aud.copy_(a, non_blocking=True)
+            graph.replay()
+            return static_out
+        run.graph = graph
+        return run

@@ -127,3 +127,18 @@ def test_dropin_module_matches_golden(gpu):
         model.transformer.off_head.bias.add_(1.0)
         _, l2 = model(u8.to(gpu), aud.to(gpu))
     assert (l2 - logits - 1.0).abs().max().item() < 1e-4
+
+
+def test_graph_replay_matches_eager(gpu):
+    """engine.capture(): the whole forward as one HIP graph; replay on new inputs must reproduce the eager launches bit for bit."""
+    from synchformer_amd import synth
+    eng, _ = _engine(gpu, gain=2.0)
+    u8a, auda = synth.make_video_u8(1, 3, 11), synth.make_spectrogram(1, 3, 11)
+    u8b, audb = synth.make_video_u8(1, 3, 12), synth.make_spectrogram(1, 3, 12)
+    run = eng.capture(u8a.to(gpu), auda.to(gpu))
+    for u8, aud in ((u8b, audb), (u8a, auda)):
+        got = run(u8.to(gpu), aud.to(gpu)).clone()
+        ref = eng.forward(u8.to(gpu), aud.to(gpu))
+        assert torch.equal(got, ref)
+    with pytest.raises(ValueError):
+        run(synth.make_video_u8(2, 3, 1).to(gpu), synth.make_spectrogram(2, 3, 1).to(gpu))
