@@ -190,6 +190,17 @@ int sf_attention_cls_bwd(const uint16_t* q, int64_t q_seq_rows, int q_row, const
 int sf_meanpool_l2norm768_bwd(const float* x, int64_t ldx, int t, const float* dy, int64_t lddy, float* dx, int64_t lddx, int normalize,
                               int64_t n, void* stream);
 
+/* ---- device-side segmenting (dataset/transforms.py:402-500 GenerateMultipleSegments; SURVEY §8f "next" rank 1) ------------------
+ * The segments of a clip overlap by 50 % (step_size_seg 0.5): instead of materialising (S, 16, C, H, W) / (S, n_samples) copies on
+ * the host and shipping 1.8x the bytes over PCIe, the two front-end gathers read the segment windows straight from the clip:
+ * segment (clip, s) = frames [frame0 + s*seg_stride, +16) of vid (n_clips, clip_frames, 3, 224, 224), and samples
+ * [sample0 + s*seg_stride, +n_samples) of wave (n_clips, clip_samples).  Reflect padding of the STFT stays inside a segment. */
+int sf_im2col_video_clips(const void* vid, int dtype, int64_t n_clips, int64_t clip_frames, int frame0, int seg_stride, int n_seg,
+                          uint16_t* out, void* stream);
+int sf_mel_frontend_clips(const float* wave, int64_t n_clips, int64_t clip_samples, int64_t sample0, int64_t seg_stride, int n_seg,
+                          int n_samples, int hop, const float* tw_cos, const float* tw_sin, const float* fb, const int* fb_lo,
+                          const int* fb_hi, int n_mels, float* power_ws, float* out, int pad_to, float mean, float std, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -195,7 +195,7 @@ __device__ __forceinline__ void load16(const void* p, float* f) {
 
 template <int DT>
 __global__ __launch_bounds__(256) void im2col_video_kernel(const void* __restrict__ vid, bf16_t* __restrict__ out,
-                                                            int64_t total_runs) {
+                                                            int64_t total_runs, int n_seg_clip, int64_t clip_frames, int frame0, int seg_stride) {
   // run index = (((n*8 + f)*2 + dt)*3 + c)*224*14 + (h*16+dh)*14 + w   (walks memory order of `vid` per frame)
   const int64_t run = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (run >= total_runs) return;
@@ -206,7 +206,10 @@ __global__ __launch_bounds__(256) void im2col_video_kernel(const void* __restric
   const int dt = (int)(t % 2); t /= 2;
   const int f = (int)(t % 8);
   const int64_t n = t / 8;
-  const int64_t src = ((((n * 16 + (f * 2 + dt)) * 3 + c) * 224 + y) * 224) + w * 16;
+  // segment n = (clip, s): its 16 frames start at frame clip * clip_frames + frame0 + s * seg_stride of the frame-major input
+  const int64_t clip = n / n_seg_clip, sidx = n - clip * n_seg_clip;
+  const int64_t frame = clip * clip_frames + frame0 + sidx * seg_stride + (f * 2 + dt);
+  const int64_t src = (((frame * 3 + c) * 224 + y) * 224) + w * 16;
   const int esz = (DT == SF_F32) ? 4 : (DT == SF_U8 ? 1 : 2);
   float v[16];
   load16<DT>(reinterpret_cast<const char*>(vid) + src * esz, v);
@@ -220,19 +223,35 @@ __global__ __launch_bounds__(256) void im2col_video_kernel(const void* __restric
   dst[0] = o0; dst[1] = o1;
 }
 
-extern "C" int sf_im2col_video(const void* vid, int dtype, bf16_t* out, int64_t n_seg, void* stream) {
-  SF_CHECK_ARG(vid && out, "sf_im2col_video: null pointer");
-  SF_CHECK_ARG(dtype >= 0 && dtype <= 3, "sf_im2col_video: bad dtype %d", dtype);
+static int launch_im2col_video(const void* vid, int dtype, bf16_t* out, int64_t n_seg, int n_seg_clip, int64_t clip_frames, int frame0, int seg_stride,
+                               hipStream_t s) {
   const int64_t total = n_seg * 16 * 3 * 224 * 14;
   if (total <= 0) return 0;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
-  hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
-    case SF_F32: hipLaunchKernelGGL((im2col_video_kernel<SF_F32>), grid, block, 0, s, vid, out, total); break;
-    case SF_BF16: hipLaunchKernelGGL((im2col_video_kernel<SF_BF16>), grid, block, 0, s, vid, out, total); break;
-    case SF_F16: hipLaunchKernelGGL((im2col_video_kernel<SF_F16>), grid, block, 0, s, vid, out, total); break;
-    default: hipLaunchKernelGGL((im2col_video_kernel<SF_U8>), grid, block, 0, s, vid, out, total); break;
+    case SF_F32: hipLaunchKernelGGL((im2col_video_kernel<SF_F32>), grid, block, 0, s, vid, out, total, n_seg_clip, clip_frames, frame0, seg_stride); break;
+    case SF_BF16: hipLaunchKernelGGL((im2col_video_kernel<SF_BF16>), grid, block, 0, s, vid, out, total, n_seg_clip, clip_frames, frame0, seg_stride); break;
+    case SF_F16: hipLaunchKernelGGL((im2col_video_kernel<SF_F16>), grid, block, 0, s, vid, out, total, n_seg_clip, clip_frames, frame0, seg_stride); break;
+    default: hipLaunchKernelGGL((im2col_video_kernel<SF_U8>), grid, block, 0, s, vid, out, total, n_seg_clip, clip_frames, frame0, seg_stride); break;
   }
+  return 0;
+}
+
+extern "C" int sf_im2col_video(const void* vid, int dtype, bf16_t* out, int64_t n_seg, void* stream) {
+  SF_CHECK_ARG(vid && out, "sf_im2col_video: null pointer");
+  SF_CHECK_ARG(dtype >= 0 && dtype <= 3, "sf_im2col_video: bad dtype %d", dtype);
+  launch_im2col_video(vid, dtype, out, n_seg, 1, 16, 0, 0, (hipStream_t)stream);       // every segment is its own 16-frame "clip"
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sf_im2col_video_clips(const void* vid, int dtype, int64_t n_clips, int64_t clip_frames, int frame0, int seg_stride, int n_seg,
+                                     bf16_t* out, void* stream) {
+  SF_CHECK_ARG(vid && out, "sf_im2col_video_clips: null pointer");
+  SF_CHECK_ARG(dtype >= 0 && dtype <= 3, "sf_im2col_video_clips: bad dtype %d", dtype);
+  SF_CHECK_ARG(n_seg >= 1 && frame0 >= 0 && seg_stride >= 0 && frame0 + (int64_t)(n_seg - 1) * seg_stride + 16 <= clip_frames,
+               "sf_im2col_video_clips: segments [%d + s*%d, +16) do not fit %lld frames", frame0, seg_stride, (long long)clip_frames);
+  launch_im2col_video(vid, dtype, out, n_clips * n_seg, n_seg, clip_frames, frame0, seg_stride, (hipStream_t)stream);
   SF_LAUNCH_CHECK();
   return 0;
 }

@@ -197,15 +197,19 @@ class SynchformerEngine:
     # ------------------------------------------------------------------------------------------------
     # visual branch
     # ------------------------------------------------------------------------------------------------
-    def _visual_chunk(self, vid, out):
-        """vid (n, 16, 3, 224, 224) u8|f16|bf16|f32 on device -> out fp32 (n*8, 768).  a3-a9 of SURVEY §8a."""
-        n = vid.shape[0]
+    def _visual_chunk(self, vid, out, clip_seg=None):
+        """vid (n, 16, 3, 224, 224) u8|f16|bf16|f32 on device -> out fp32 (n*8, 768).  a3-a9 of SURVEY §8a.
+        With clip_seg = (frame0, seg_stride, n_seg), vid is (clips, T, 3, 224, 224) and the segments are read in place."""
+        n = vid.shape[0] if clip_seg is None else vid.shape[0] * clip_seg[2]
         rows = n * VIS_L
         X = self._buf('X', rows * D, torch.float32).view(rows, D)
         xn = self._buf('XN', n * 8 * AGG_V * D, torch.bfloat16)[:rows * D].view(rows, D)
         big = self._buf('BIG', n * 8 * AGG_V * FF, torch.bfloat16)
         patches = big[:n * VIS_P * 1536].view(n * VIS_P, 1536)
-        ops.im2col_video(vid, patches)
+        if clip_seg is None:
+            ops.im2col_video(vid, patches)
+        else:
+            ops.im2col_video_clips(vid, patches, *clip_seg)
         ops.broadcast_rows(X, self.v_table, n_seq=n, dst_seq_rows=VIS_L)
         tokmap = ops.rowmap(VIS_P, VIS_P, VIS_L, 0, 1, 1)
         ops.gemm(patches, self.v_pe.w, self.v_pe.b, X, residual=X, c_map=tokmap, r_map=tokmap)
@@ -396,6 +400,33 @@ class SynchformerEngine:
     def forward(self, vis: torch.Tensor, aud: torch.Tensor) -> torch.Tensor:
         """Synchformer.forward (sync_model.py:38-70) without the loss: logits (B, n_out) fp32."""
         return self.sync_transformer(self.extract_vfeats(vis), self.extract_afeats(aud))
+
+    # ------------------------------------------------------------------------------------------------
+    # whole clips in, segmenting on the device (SURVEY §8f rank 1)
+    # ------------------------------------------------------------------------------------------------
+    def extract_vfeats_clips(self, frames: torch.Tensor, v_start: int, v_stride: int, n_seg: int) -> torch.Tensor:
+        """frames (B, T, 3, 224, 224) u8|float on device -> (B, n_seg, 8, 768): segment s = frames [v_start + s*v_stride, +16), read
+        straight from the clip by the patch gather (the 50 %-overlapping segments are never materialised)."""
+        B = frames.shape[0]
+        frames = frames.contiguous()
+        out = torch.empty(B * n_seg * 8, D, device=self.dev, dtype=torch.float32)
+        per = max(1, self.seg_chunk // n_seg)                                 # clips per chunk
+        for b0 in range(0, B, per):
+            nb = min(per, B - b0)
+            self._visual_chunk(frames[b0:b0 + nb], out[b0 * n_seg * 8:(b0 + nb) * n_seg * 8], clip_seg=(v_start, v_stride, n_seg))
+        return out.view(B, n_seg, 8, D)
+
+    def forward_clips(self, frames: torch.Tensor, wave: torch.Tensor, mel, v_fps: int = 25, a_fps: int = 16000, n_segments: int = 14,
+                      segment_size_vframes: int = 16, step_size_seg: float = 0.5) -> torch.Tensor:
+        """Un-segmented clips -> logits: frames (B, T, 3, 224, 224) uint8 (after the spatial crop), wave (B, n_samples) fp32 16 kHz,
+        `mel` a synchformer_amd.frontend.MelFrontend.  Equivalent to GenerateMultipleSegments -> RGBToHalfToZeroOne -> RGBNormalize ->
+        AudioMelSpectrogram -> AudioLog -> PadOrTruncate -> AudioNormalizeAST -> PermuteStreams -> Synchformer.forward
+        (configs/sync.yaml:222-249, sync_model.py:38-70) with is_start_random False."""
+        from .frontend import segment_ranges
+        r = segment_ranges(frames.shape[1], wave.shape[1], v_fps, a_fps, segment_size_vframes, n_segments, step_size_seg)
+        aud = mel.segments(wave, r['a_start'], r['a_stride'], r['n_segments'], r['a_size'])
+        vf = self.extract_vfeats_clips(frames, r['v_start'], r['v_stride'], r['n_segments'])
+        return self.sync_transformer(vf, self.extract_afeats(aud))
 
     # ------------------------------------------------------------------------------------------------
     # HIP-graph replay of the whole forward (launch-bound regimes: single-clip latency, small batches)

@@ -27,6 +27,26 @@ def mel_filterbank(n_freqs=513, f_min=0.0, f_max=8000.0, n_mels=128, sample_rate
     return fb.astype(np.float32)
 
 
+def segment_ranges(v_len_frames: int, a_len_frames: int, v_fps: int = 25, a_fps: int = 16000, segment_size_vframes: int = 16,
+                   n_segments: int = 14, step_size_seg: float = 0.5) -> dict:
+    """GenerateMultipleSegments with is_start_random=False, audio_jitter_sec=0 (dataset/transforms.py:421-500; configs/sync.yaml:222-227):
+    equally spaced, 50 %-overlapping segments taken from the middle of the clip.  Returns the start / stride of the video (frames)
+    and audio (samples) windows instead of materialising them."""
+    seg_a = int(segment_size_vframes / v_fps * a_fps)                          # sec2frames(frames2sec(.)) (:431, :12-16)
+    stride_v, stride_a = int(step_size_seg * segment_size_vframes), int(step_size_seg * seg_a)
+    n_max = min((v_len_frames - segment_size_vframes) // stride_v + 1, (a_len_frames - seg_a) // stride_a + 1)      # (:436-439)
+    n_seg = n_max if n_segments is None else n_segments
+    if n_seg > n_max:
+        raise ValueError(f'cant make {n_seg} segs of len {segment_size_vframes} in a vid of len {v_len_frames}')     # (:442-444)
+    seg_seq_len = n_seg * step_size_seg + (1 - step_size_seg)                 # (:467-469)
+    v_start = (v_len_frames - int(seg_seq_len * segment_size_vframes)) // 2   # (:472-476)
+    a_start = int(v_start / v_fps * a_fps)                                    # (:477)
+    if a_start + (n_seg - 1) * stride_a + seg_a > a_len_frames:
+        raise ValueError('audio ranges out of bounds')                        # (:497)
+    return dict(n_segments=n_seg, v_start=v_start, v_stride=stride_v, v_size=segment_size_vframes, a_start=a_start, a_stride=stride_a,
+                a_size=seg_a)
+
+
 class MelFrontend:
     def __init__(self, device, sample_rate=16000, n_mels=128, pad_to=66, mean=AST_MEAN, std=AST_STD):
         self.dev = torch.device(device)
@@ -65,3 +85,23 @@ class MelFrontend:
                                          torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, 'sf_mel_frontend')
         return out.reshape(*lead, 1, self.n_mels, self.pad_to)
+
+
+    def segments(self, wave: torch.Tensor, a_start: int, a_stride: int, n_seg: int, a_size: int) -> torch.Tensor:
+        """wave (B, clip_samples) fp32 on device -> (B, n_seg, 1, n_mels, pad_to): the log-mel of every overlapping segment window
+        [a_start + s*a_stride, +a_size), read in place from the clip (no (B, S, a_size) copy)."""
+        if not wave.is_cuda:
+            raise RuntimeError('MelFrontend: expected a HIP device tensor (no CPU fallback exists)')
+        w = wave.to(torch.float32).contiguous()
+        B, clip = w.shape
+        frames = min(a_size // self.hop + 1, self.pad_to)
+        need = B * n_seg * frames * 513
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, device=self.dev, dtype=torch.float32)
+        out = torch.empty(B * n_seg, self.n_mels, self.pad_to, device=self.dev, dtype=torch.float32)
+        rc = _lib.load().sf_mel_frontend_clips(w.data_ptr(), B, clip, a_start, a_stride, n_seg, a_size, self.hop, self.tw_cos.data_ptr(),
+                                               self.tw_sin.data_ptr(), self.fb.data_ptr(), self.fb_lo.data_ptr(), self.fb_hi.data_ptr(),
+                                               self.n_mels, self._ws.data_ptr(), out.data_ptr(), self.pad_to, self.mean, self.std,
+                                               torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, 'sf_mel_frontend_clips')
+        return out.reshape(B, n_seg, 1, self.n_mels, self.pad_to)

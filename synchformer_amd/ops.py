@@ -101,6 +101,16 @@ def im2col_video(vid: torch.Tensor, out: torch.Tensor):
     return out
 
 
+def im2col_video_clips(vid: torch.Tensor, out: torch.Tensor, frame0: int, seg_stride: int, n_seg: int):
+    """vid (n_clips, T, 3, 224, 224) u8|f16|bf16|f32 -> out bf16 (n_clips*n_seg*1568, 1536): segment (clip, s) = frames
+    [frame0 + s*seg_stride, +16) of the clip, read in place (GenerateMultipleSegments on the device, dataset/transforms.py:450-451)."""
+    assert vid.is_contiguous() and vid.dim() == 5 and tuple(vid.shape[2:]) == (3, 224, 224)
+    rc = _lib.load().sf_im2col_video_clips(_dev(vid, 'vid'), _DT[vid.dtype], vid.shape[0], vid.shape[1], frame0, seg_stride, n_seg,
+                                           _dev(out, 'out'), _stream())
+    _lib.check(rc, 'sf_im2col_video_clips')
+    return out
+
+
 def im2col_spec(spec: torch.Tensor, out: torch.Tensor):
     """spec fp32 (n_seg, F, Ta) contiguous -> out bf16 (n_seg*nf*nt, 256)."""
     assert spec.is_contiguous() and spec.dtype == torch.float32 and spec.dim() == 3

@@ -147,3 +147,21 @@ def test_shard_range():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+def test_segment_ranges_follow_generate_multiple_segments():
+    """dataset/transforms.py:421-500 with is_start_random False / no jitter, worked by hand from its formulas:
+    seg_a = int(16/25*16000) = 10240, strides 8 frames / 5120 samples, sequence length int(7.5*16) = 120 frames,
+    v_start = (v_len - 120) // 2, a_start = int(v_start / 25 * 16000)."""
+    from synchformer_amd.frontend import segment_ranges
+    r = segment_ranges(125, 80000)                       # the 5-s evaluation crop (configs/sync.yaml: crop_len_sec 5)
+    assert (r['n_segments'], r['v_start'], r['v_stride'], r['a_start'], r['a_stride'], r['a_size']) == (14, 2, 8, 1280, 5120, 10240)
+    assert r['v_start'] + 13 * 8 + 16 <= 125 and r['a_start'] + 13 * 5120 + 10240 <= 80000
+    r = segment_ranges(250, 160000)
+    assert (r['v_start'], r['a_start']) == (65, 41600)
+    r = segment_ranges(120, 76800, n_segments=None)      # n_segments None -> as many as fit (:436-440)
+    assert r['n_segments'] == 14 and r['v_start'] == 0
+    r = segment_ranges(125, 80000, n_segments=13)        # syncability fine-tuning uses 13 (configs/ft_synchability.yaml)
+    assert r['v_start'] == (125 - int(7.0 * 16)) // 2 == 6
+    with pytest.raises(ValueError):
+        segment_ranges(100, 80000)                       # cannot fit 14 half-overlapping 16-frame segments in 100 frames

@@ -31,3 +31,28 @@ def test_mel_filterbank_host_table_matches_oracle():
     from synchformer_amd.frontend import mel_filterbank
     from oracle import synchformer_cpu as O
     torch.testing.assert_close(torch.from_numpy(mel_filterbank()), O.mel_filterbank(), rtol=1e-6, atol=1e-7)
+
+
+def test_device_side_segmenting_matches_host_slicing(gpu):
+    """forward_clips (segments read in place from the clip by sf_im2col_video_clips / sf_mel_frontend_clips) must equal the
+    reference's order of operations: slice overlapping segments on the host (GenerateMultipleSegments), then forward."""
+    from synchformer_amd import synth
+    from synchformer_amd.engine import SynchformerEngine
+    from synchformer_amd.frontend import MelFrontend, segment_ranges
+    eng = SynchformerEngine(synth.make_state_dict(1337, gain=2.0), gpu, seg_chunk=14)
+    mel = MelFrontend(gpu)
+    B, T, n_samp = 3, 125, 80000
+    g = torch.Generator().manual_seed(5)
+    frames = torch.randint(0, 256, (B, T, 3, 224, 224), generator=g, dtype=torch.uint8)
+    wave = synth.make_wave(B, 1, 5, n=n_samp).reshape(B, n_samp)
+    r = segment_ranges(T, n_samp)
+    vis = torch.stack([torch.stack([frames[b, r['v_start'] + s * 8: r['v_start'] + s * 8 + 16] for s in range(14)]) for b in range(B)])
+    aw = torch.stack([torch.stack([wave[b, r['a_start'] + s * 5120: r['a_start'] + s * 5120 + 10240] for s in range(14)]) for b in range(B)])
+    ref_aud = mel(aw.to(gpu))                                                  # (B, 14, 1, 128, 66)
+    got_aud = mel.segments(wave.to(gpu), r['a_start'], r['a_stride'], 14, r['a_size'])
+    assert torch.equal(ref_aud, got_aud)
+    ref = eng.forward(vis.to(gpu), ref_aud)
+    got = eng.forward_clips(frames.to(gpu), wave.to(gpu), mel)
+    assert torch.equal(ref, got)
+    with pytest.raises(RuntimeError, match='do not fit'):
+        mel.segments(wave[:, :70000].to(gpu), r['a_start'], r['a_stride'], 14, r['a_size'])
