@@ -112,7 +112,10 @@ __device__ __forceinline__ void epi_group_store(float4 (&v)[4], const float4& bi
   for (int ps = 0; ps < 4; ++ps) {
     float4 x = v[ps];
     x.x += bias4.x; x.y += bias4.y; x.z += bias4.z; x.w += bias4.w;
-    if (GELU) { x.x = gelu_erf(x.x); x.y = gelu_erf(x.y); x.z = gelu_erf(x.z); x.w = gelu_erf(x.w); }
+    if (GELU) {
+      const sf_f32x2_t g0 = gelu_erf2(sf_f32x2_t{x.x, x.y}), g1 = gelu_erf2(sf_f32x2_t{x.z, x.w});
+      x.x = g0.x; x.y = g0.y; x.z = g1.x; x.w = g1.y;
+    }
     if (HAS_RES) { x.x += res[ps].x; x.y += res[ps].y; x.z += res[ps].z; x.w += res[ps].w; }
     if (OUT_BF16) {
       u32x2 o; o.x = pack_bf2(x.x, x.y); o.y = pack_bf2(x.z, x.w);
