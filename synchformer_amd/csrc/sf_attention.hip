@@ -230,8 +230,9 @@ __global__ __launch_bounds__(256) void attn_cls64_kernel(ClsArgs p) {
 // the V^T fragments are read from LDS with the same permutation (two 8-byte reads per fragment).
 // ======================================================================================================
 #define ATT_MAX_KT 13            // 13 x 16 = 208 keys / queries max
-#define ATT_VT_LD 228            // V^T row stride in keys (bf16): 456 B = 114 dwords; 114 mod 32 = 18 -> the 16-lane groups
-                                 // of the (compiler-merged) ds_read2_b64 fragment reads cover all 32 banks exactly once
+#define ATT_VT_LD 212            // V^T row stride in keys (bf16): 424 B = 106 dwords; 16 consecutive rows start 106 dwords apart ->
+                                 // banks {0,42,20,62,...} (mod 64), all even and distinct: the 8-byte fragment reads of a 16-lane group are
+                                 // conflict-free.  212 (not 228) keeps K + V^T at 53,760 B so THREE workgroups fit the 160 KiB LDS of a CU.
 #ifndef SF_ATT_ABL
 #define SF_ATT_ABL 0             // tools/ablate_attention.sh only: 1 skip stores, 2 skip P V, 4 skip softmax
 #endif
@@ -251,7 +252,7 @@ __device__ __forceinline__ int k_lds_off(int row, int chunk) {   // byte offset 
 }
 
 template <int D, int NKT>
-__global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_lds = smem;
   bf16_t* vt_lds = reinterpret_cast<bf16_t*>(smem + AttLds<D>::K_BYTES);
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 #pragma unroll
       for (int c = 0; c < V_CR; ++c) {
         const int pp = pp_l + 32 * b, ch = wave * 2 + half + 8 * c;
-        if (ch < CH && pp < npairs) {
+        if (ch < CH && pp < npairs && pp < ATT_VT_LD / 2) {
           const uint32_t a4[4] = {vreg[b][c][0].x, vreg[b][c][0].y, vreg[b][c][0].z, vreg[b][c][0].w};
           const uint32_t b4[4] = {vreg[b][c][1].x, vreg[b][c][1].y, vreg[b][c][1].z, vreg[b][c][1].w};
           uint32_t* dst = reinterpret_cast<uint32_t*>(vt_lds) + pp;
@@ -406,7 +407,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
           const bf16_t* vrow = vt_lds + (dt * 16 + fr) * ATT_VT_LD + kk * 32 + fg * 4;
           union { bf16x8 v; uint2 h[2]; } vb;
           vb.h[0] = *reinterpret_cast<const uint2*>(vrow);
-          vb.h[1] = *reinterpret_cast<const uint2*>(vrow + 16);
+          vb.h[1] = make_uint2(0u, 0u);
+          if (2 * kk + 1 < NKT) vb.h[1] = *reinterpret_cast<const uint2*>(vrow + 16);   // no 14th key tile: P is zero there, skip the read
           o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb.v, pa.v, o[dt], 0, 0, 0);   // O^T tile: (d, query)
         }
       }
