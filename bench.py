@@ -36,7 +36,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=16, help='clips per GPU per step (configs/sync.yaml batch = 16)')
-    ap.add_argument('--seg-chunk', type=int, default=112)
+    ap.add_argument('--seg-chunk', type=int, default=224)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL over xGMI; default) | gloo (plumbing tests)')

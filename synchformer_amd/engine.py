@@ -51,7 +51,7 @@ class _LN:
 
 
 class SynchformerEngine:
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device='cuda:0', seg_chunk: int = 112):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device='cuda:0', seg_chunk: int = 224):
         self.dev = torch.device(device)
         if self.dev.type != 'cuda':
             raise RuntimeError('SynchformerEngine needs a HIP device; there is no CPU path in the product')

@@ -313,7 +313,7 @@ class Synchformer(torch.nn.Module):
                 m.weight.copy_(synth.fill_tensor(f'{name}.weight', (768, 768), 0))
                 m.bias.copy_(synth.fill_tensor(f'{name}.bias', (768,), 0))
         self._sf_engine = None
-        self.seg_chunk = 112
+        self.seg_chunk = 224
 
     # -- engine cache ---------------------------------------------------------------------------------------
     def _engine(self) -> SynchformerEngine:
@@ -430,7 +430,7 @@ class AVCLIP(torch.nn.Module):
         self.logit_scale = torch.nn.Parameter(torch.ones([]) * self.init_scale)
         self.gather_for_loss = gather_for_loss
         self._sf_engine = None
-        self.seg_chunk = 112
+        self.seg_chunk = 224
 
     def _engine(self) -> SynchformerEngine:
         key = _param_key(self)
