@@ -201,6 +201,21 @@ int sf_mel_frontend_clips(const float* wave, int64_t n_clips, int64_t clip_sampl
                           int n_samples, int hop, const float* tw_cos, const float* tw_sin, const float* fb, const int* fb_lo,
                           const int* fb_hi, int n_mels, float* power_ws, float* out, int pad_to, float mean, float std, void* stream);
 
+/* ---- token masks (Synchformer.forward(vis_mask=, aud_mask=), sync_model.py:38-89) -------------------------------
+ * content_keep: bool bytes shaped like the input ((n,16,3,224,224) / (n,F,Ta)), 1 = kept.  tok_keep[n*L + t] = 0 iff the masked
+ * elements of token t's patch meet filter-0 weights of both signs or a zero weight (the reference's inf -> NaN trick,
+ * video_model_builder.py:185-201, modeling_ast.py:515-530); w0_sign = sign of filter 0 per patch element (int8), CLS/DISTILL kept. */
+int sf_token_mask_video(const uint8_t* content_keep, int64_t n_seg, const int8_t* w0_sign, uint8_t* tok_keep, void* stream);
+int sf_token_mask_spec(const uint8_t* content_keep, int64_t n_seg, int F, int Ta, const int8_t* w0_sign, uint8_t* tok_keep, void* stream);
+/* sf_attention / sf_attention_cls with a key mask: key_keep[row] == 0 gives K/V row `row` (same row indexing as k) a score of -inf
+ * (qkv_attn tok_mask, vit_helper.py:34-42; ASTSelfAttention, modeling_ast.py:160-163; aggregators' src_mask, motionformer.py:308-329). */
+int sf_attention_masked(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld, uint16_t* out, int64_t ldo, int64_t n_seq,
+                        int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok, int cls_row, int heads,
+                        int head_dim, float scale, const uint8_t* key_keep, void* stream);
+int sf_attention_cls_masked(const uint16_t* q, int64_t q_seq_rows, int q_row, const uint16_t* k, const uint16_t* v, int64_t ld,
+                            int64_t kv_seq_rows, int kv_row0, int n_keys, uint16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row,
+                            int64_t n_seq, int heads, int head_dim, float scale, const uint8_t* key_keep, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,10 +36,26 @@ def _gelu(x):
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
-def _softmax_attn(q, k, v, scale):
-    """softmax(q k^T * scale) v over the last two dims; q (..., Nq, d), k/v (..., Nk, d)."""
+def _softmax_attn(q, k, v, scale, key_keep=None):
+    """softmax(q k^T * scale) v over the last two dims; q (..., Nq, d), k/v (..., Nk, d).  key_keep (..., Nk) bool broadcastable
+    to the batch dims: keys with False get -inf before the softmax (qkv_attn, vit_helper.py:34-42; modeling_ast.py:160-163)."""
     s = torch.matmul(q, k.transpose(-1, -2)) * scale
+    if key_keep is not None:
+        s = s.masked_fill(~key_keep.unsqueeze(-2), float('-inf'))
     return torch.matmul(torch.softmax(s, dim=-1), v)
+
+
+def token_mask_from_content(patches_keep, w0):
+    """The reference's NaN trick (video_model_builder.py:185-201, modeling_ast.py:515-530): an indicator (1 = kept, inf = masked
+    content) is pushed through the patch embedding; a token is MASKED iff output channel 0 is NaN, i.e. iff the masked elements
+    of its patch meet filter-0 weights of both signs (inf - inf) or a zero weight (inf * 0).  A patch whose masked elements all
+    meet same-sign weights gives +-inf, which is not NaN: that token stays.
+    patches_keep (N, P, K) bool content mask gathered like the patches; w0 (K,) = filter 0.  -> (N, P) bool, True = keep."""
+    m = ~patches_keep
+    pos = (m & (w0 > 0)).any(-1)
+    neg = (m & (w0 < 0)).any(-1)
+    zero = (m & (w0 == 0)).any(-1)
+    return ~((pos & neg) | zero)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -66,7 +82,7 @@ def vis_pos_table(sd, p, frames=8):
     return torch.cat([pos[:1], body.reshape(frames * n, -1)], 0)   # (1 + f*n, D)
 
 
-def divided_attention(x, sd, p, mode, heads=12, frames=8):
+def divided_attention(x, sd, p, mode, heads=12, frames=8, tok_keep=None):
     """DividedAttention.forward + qkv_attn (vit_helper.py:100-158, :34-42).
     x (N, 1+f*n, D).  CLS query attends all tokens; patch (f, n) attends [CLS] + its group:
     mode 'time' -> same n over all f; mode 'space' -> same f over all n.  q is scaled by d^-0.5 first (:113)."""
@@ -75,7 +91,8 @@ def divided_attention(x, sd, p, mode, heads=12, frames=8):
     n = (L - 1) // frames
     qkv = _lin(x, sd, p + '.qkv').reshape(N, L, 3, heads, d).permute(2, 0, 3, 1, 4)   # (3, N, h, L, d)
     q, k, v = qkv[0] * (d ** -0.5), qkv[1], qkv[2]
-    out_cls = _softmax_attn(q[:, :, :1], k, v, 1.0)                                   # (N, h, 1, d)
+    kk_all = None if tok_keep is None else tok_keep.unsqueeze(1)                       # (N, 1, L): same mask for every head (:107-110)
+    out_cls = _softmax_attn(q[:, :, :1], k, v, 1.0, kk_all)                           # (N, h, 1, d)
 
     def grp(t):  # patches (N, h, f*n, d) -> groups
         t = t[:, :, 1:].reshape(N, heads, frames, n, d)
@@ -84,7 +101,12 @@ def divided_attention(x, sd, p, mode, heads=12, frames=8):
     G = qg.shape[2]
     kc = k[:, :, :1].unsqueeze(2).expand(N, heads, G, 1, d)
     vc = v[:, :, :1].unsqueeze(2).expand(N, heads, G, 1, d)
-    og = _softmax_attn(qg, torch.cat([kc, kg], 3), torch.cat([vc, vg], 3), 1.0)
+    gk = None
+    if tok_keep is not None:                                                          # mask rearranged like the keys (:136-141)
+        mg = tok_keep[:, 1:].reshape(N, frames, n)
+        mg = mg.transpose(1, 2) if mode == 'time' else mg                              # (N, G, T)
+        gk = torch.cat([tok_keep[:, :1].unsqueeze(1).expand(N, G, 1), mg], 2).unsqueeze(1)   # (N, 1, G, 1+T)
+    og = _softmax_attn(qg, torch.cat([kc, kg], 3), torch.cat([vc, vg], 3), 1.0, gk)
     if mode == 'time':
         og = og.transpose(2, 3)
     out = torch.cat([out_cls, og.reshape(N, heads, frames * n, d)], 2)                # (N, h, L, d)
@@ -92,15 +114,15 @@ def divided_attention(x, sd, p, mode, heads=12, frames=8):
     return _lin(out, sd, p + '.proj')
 
 
-def divided_block(x, sd, p):
+def divided_block(x, sd, p, tok_keep=None):
     """DividedSpaceTimeBlock.forward (vit_helper.py:364-376); DropPath is identity in eval."""
-    x = x + divided_attention(_ln(x, sd, p + '.norm3', EPS_VIS), sd, p + '.timeattn', 'time')
-    x = x + divided_attention(_ln(x, sd, p + '.norm1', EPS_VIS), sd, p + '.attn', 'space')
+    x = x + divided_attention(_ln(x, sd, p + '.norm3', EPS_VIS), sd, p + '.timeattn', 'time', tok_keep=tok_keep)
+    x = x + divided_attention(_ln(x, sd, p + '.norm1', EPS_VIS), sd, p + '.attn', 'space', tok_keep=tok_keep)
     h = _gelu(_lin(_ln(x, sd, p + '.norm2', EPS_VIS), sd, p + '.mlp.fc1'))           # Mlp (vit_helper.py:379-398)
     return x + _lin(h, sd, p + '.mlp.fc2')
 
 
-def agg_encoder_layer_cls(tokens, sd, p, heads=12):
+def agg_encoder_layer_cls(tokens, sd, p, heads=12, keep=None):
     """BaseEncoderLayer.forward (motionformer.py:301-334) over nn.TransformerEncoderLayer(norm_first=True,
     GELU, eps 1e-6, dropout 0): prepend the aggregator's cls_token, one pre-norm encoder layer, return row 0.
     tokens (N, L, D) -> (N, D)."""
@@ -110,26 +132,37 @@ def agg_encoder_layer_cls(tokens, sd, p, heads=12):
     y = _ln(z, sd, p + '.norm1', EPS_VIS)
     qkv = F.linear(y, sd[p + '.self_attn.in_proj_weight'], sd[p + '.self_attn.in_proj_bias'])
     qkv = qkv.reshape(N, L + 1, 3, heads, d).permute(2, 0, 3, 1, 4)
-    a = _softmax_attn(qkv[0], qkv[1], qkv[2], d ** -0.5).transpose(1, 2).reshape(N, L + 1, Dm)
+    kk = None                                                       # keep (N, L) bool: [cls = keep; tokens] as key mask (mf:308-317)
+    if keep is not None:
+        kk = torch.cat([torch.ones(N, 1, dtype=torch.bool), keep], 1).unsqueeze(1)
+    a = _softmax_attn(qkv[0], qkv[1], qkv[2], d ** -0.5, kk).transpose(1, 2).reshape(N, L + 1, Dm)
     z = z + _lin(a, sd, p + '.self_attn.out_proj')
     z = z + _lin(_gelu(_lin(_ln(z, sd, p + '.norm2', EPS_VIS), sd, p + '.linear1')), sd, p + '.linear2')
     return z[:, 0]
 
 
-def motionformer_segments(x, sd, p='vfeat_extractor', depth=None):
+def motionformer_segments(x, sd, p='vfeat_extractor', depth=None, cont_keep=None):
     """MotionFormer.forward_segments (motionformer.py:225-252) with forward_features
     (video_model_builder.py:174-274).  x (N, 3, 16, 224, 224) -> (N, 8, 768)."""
     N = x.shape[0]
     tok = patch_embed_3d(x, sd[p + '.patch_embed_3d.proj.weight'], sd[p + '.patch_embed_3d.proj.bias'])
+    tok_keep = None
+    if cont_keep is not None:                                          # cont_keep (N, 3, 16, 224, 224) bool, True = kept content
+        w = sd[p + '.patch_embed_3d.proj.weight']
+        pt, ph, pw = w.shape[2:]
+        C, T, H, W = cont_keep.shape[1:]
+        pk = cont_keep.reshape(N, C, T // pt, pt, H // ph, ph, W // pw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(N, -1, C * pt * ph * pw)
+        tok_keep = torch.cat([torch.ones(N, 1, dtype=torch.bool), token_mask_from_content(pk, w[0].reshape(-1))], 1)   # CLS kept (vmb:223-225)
     x = torch.cat([sd[p + '.cls_token'].expand(N, 1, -1), tok], 1) + vis_pos_table(sd, p)
     i = 0
     while f'{p}.blocks.{i}.norm1.weight' in sd and (depth is None or i < depth):
-        x = divided_block(x, sd, f'{p}.blocks.{i}')
+        x = divided_block(x, sd, f'{p}.blocks.{i}', tok_keep)
         i += 1
     x = _ln(x[:, 1:], sd, p + '.norm', EPS_VIS)                       # drop CLS, final norm (mf:231-232)
     frames = 8
     per_frame = x.reshape(N * frames, x.shape[1] // frames, -1)       # '(BS t) (h w) D' (mf:361)
-    return agg_encoder_layer_cls(per_frame, sd, p + '.spatial_attn_agg').reshape(N, frames, -1)
+    keep = None if tok_keep is None else tok_keep[:, 1:].reshape(N * frames, -1)      # (mf:237-243, 365-366)
+    return agg_encoder_layer_cls(per_frame, sd, p + '.spatial_attn_agg', keep=keep).reshape(N, frames, -1)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -144,7 +177,7 @@ def ast_patch_embed(x, w, b, stride=10):
     return win.reshape(N, nf * nt, 256) @ w.reshape(w.shape[0], 256).t() + b
 
 
-def ast_layer(x, sd, p, heads=12):
+def ast_layer(x, sd, p, heads=12, tok_keep=None):
     """ASTLayer.forward (modeling_ast.py:294-322) with ASTSelfAttention (:139-184): scores / sqrt(d)."""
     N, L, Dm = x.shape
     d = Dm // heads
@@ -152,13 +185,13 @@ def ast_layer(x, sd, p, heads=12):
 
     def hd(name):
         return _lin(y, sd, f'{p}.attention.attention.{name}').reshape(N, L, heads, d).transpose(1, 2)
-    a = _softmax_attn(hd('query'), hd('key'), hd('value'), 1.0 / math.sqrt(d))
+    a = _softmax_attn(hd('query'), hd('key'), hd('value'), 1.0 / math.sqrt(d), None if tok_keep is None else tok_keep.unsqueeze(1))
     h = x + _lin(a.transpose(1, 2).reshape(N, L, Dm), sd, p + '.attention.output.dense')
     m = _gelu(_lin(_ln(h, sd, p + '.layernorm_after', EPS_AST), sd, p + '.intermediate.dense'))
     return h + _lin(m, sd, p + '.output.dense')
 
 
-def ast_segments(x, sd, p='afeat_extractor', depth=None):
+def ast_segments(x, sd, p='afeat_extractor', depth=None, cont_keep=None):
     """AST.forward_segments (ast.py:178-201) with ASTModel.forward (modeling_ast.py:488-555).
     x (N, Ta=66, F=128) -> (N, 6, 768)."""
     N = x.shape[0]
@@ -166,14 +199,21 @@ def ast_segments(x, sd, p='afeat_extractor', depth=None):
     tok = ast_patch_embed(x, sd[e + '.patch_embeddings.projection.weight'], sd[e + '.patch_embeddings.projection.bias'])
     x = torch.cat([sd[e + '.cls_token'].expand(N, 1, -1), sd[e + '.distillation_token'].expand(N, 1, -1), tok], 1)
     x = x + sd[e + '.position_embeddings'][:, :x.shape[1]]
+    tok_keep = None
+    if cont_keep is not None:                                          # cont_keep (N, Ta, F) bool (ast.py:142, modeling_ast.py:515-530)
+        w = sd[e + '.patch_embeddings.projection.weight']
+        win = cont_keep.transpose(1, 2).unfold(1, 16, 10).unfold(2, 16, 10)          # (N, nf, nt, 16, 16) like ast_patch_embed
+        pk = win.reshape(N, -1, 256)
+        tok_keep = torch.cat([torch.ones(N, 2, dtype=torch.bool), token_mask_from_content(pk, w[0].reshape(-1))], 1)   # CLS, DISTILL kept
     i = 0
     while f'{p}.ast.encoder.layer.{i}.layernorm_before.weight' in sd and (depth is None or i < depth):
-        x = ast_layer(x, sd, f'{p}.ast.encoder.layer.{i}')
+        x = ast_layer(x, sd, f'{p}.ast.encoder.layer.{i}', tok_keep=tok_keep)
         i += 1
     x = _ln(x, sd, p + '.ast.layernorm', EPS_AST)[:, 2:]             # drop CLS+DISTILL (ast.py:232-233)
     nf, nt = 12, x.shape[1] // 12
     per_t = x.reshape(N, nf, nt, -1).transpose(1, 2).reshape(N * nt, nf, -1)   # (BS*t, f, D) (ast.py:265-266)
-    return agg_encoder_layer_cls(per_t, sd, p + '.freq_attn_agg').reshape(N, nt, -1)
+    keep = None if tok_keep is None else tok_keep[:, 2:].reshape(N, nf, nt).transpose(1, 2).reshape(N * nt, nf)   # (ast.py:188-193, 269-271)
+    return agg_encoder_layer_cls(per_t, sd, p + '.freq_attn_agg', keep=keep).reshape(N, nt, -1)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -221,30 +261,35 @@ def global_transformer(v, a, sd, p='transformer', apply_head=True, masks=None):
     return _lin(x[:, 0], sd, f'{p}.{head}')
 
 
-def extract_vfeats(vis, sd, chunk=None):
+def extract_vfeats(vis, sd, chunk=None, vis_mask=None):
     """Synchformer.extract_vfeats (sync_model.py:72-80) + MotionFormer.forward (motionformer.py:182-223).
     vis (B, S, Tv, C, H, W) -> (B, S, 8, 768).  `chunk` bounds CPU memory (segments per pass); results are
     identical to one pass (the reference's own for_loop switch, motionformer.py:200-207)."""
     B, S = vis.shape[:2]
     x = vis.permute(0, 1, 3, 2, 4, 5).reshape(B * S, vis.shape[3], vis.shape[2], *vis.shape[4:]).float()
     chunk = chunk or x.shape[0]
-    out = torch.cat([motionformer_segments(x[i:i + chunk], sd) for i in range(0, x.shape[0], chunk)], 0)
+    m = None                                                           # vis_mask: same shape as vis, True = kept (sync_model.py:75-76)
+    if vis_mask is not None:
+        m = vis_mask.permute(0, 1, 3, 2, 4, 5).reshape(x.shape).bool()
+    out = torch.cat([motionformer_segments(x[i:i + chunk], sd, cont_keep=None if m is None else m[i:i + chunk])
+                     for i in range(0, x.shape[0], chunk)], 0)
     return out.reshape(B, S, *out.shape[1:])
 
 
-def extract_afeats(aud, sd):
+def extract_afeats(aud, sd, aud_mask=None):
     """Synchformer.extract_afeats (sync_model.py:82-89) + AST.forward (ast.py:137-176).
     aud (B, S, 1, F, Ta) -> (B, S, 6, 768)."""
     B, S, _, Fa, Ta = aud.shape
     x = aud.reshape(B * S, Fa, Ta).transpose(1, 2).float()            # (BS, Ta, F)
-    out = ast_segments(x, sd)
+    m = None if aud_mask is None else aud_mask.reshape(B * S, Fa, Ta).transpose(1, 2).bool()     # (sync_model.py:85-86)
+    out = ast_segments(x, sd, cont_keep=m)
     return out.reshape(B, S, *out.shape[1:])
 
 
-def synchformer_forward(sd, vis, aud, targets=None, chunk=None):
+def synchformer_forward(sd, vis, aud, targets=None, chunk=None, vis_mask=None, aud_mask=None):
     """Synchformer.forward (sync_model.py:38-70) -> (loss | None, logits)."""
-    v = _lin(extract_vfeats(vis, sd, chunk), sd, 'vproj')
-    a = _lin(extract_afeats(aud, sd), sd, 'aproj')
+    v = _lin(extract_vfeats(vis, sd, chunk, vis_mask), sd, 'vproj')
+    a = _lin(extract_afeats(aud, sd, aud_mask), sd, 'aproj')
     B = v.shape[0]
     logits = global_transformer(v.reshape(B, -1, v.shape[-1]), a.reshape(B, -1, a.shape[-1]), sd)
     loss = F.cross_entropy(logits, targets) if targets is not None else None   # compute_loss (sm:91-99)

@@ -22,6 +22,8 @@ struct AttnArgs {
   // optional: partial softmax state (m, l, o[64], base-2 domain) of the CLS QUERY over this group's keys,
   // [seq][head][group][66] fp32 - merged by sf_attention_cls_combine into output row `cls_row` (vit_helper.py:126)
   float* cls_part;
+  // optional key mask (vis_mask / aud_mask token masks, vit_helper.py:34-42): key_keep[row] == 0 -> that K/V row gets -inf
+  const uint8_t* key_keep;
 };
 
 // ======================================================================================================
@@ -73,12 +75,14 @@ __global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t to
   const int nk = p.n_tok + has_cls;
   // all 2 x 9 key/value loads are issued before the first use (one memory round trip per wave)
   uint4 kraw[9], vraw[9];
+  uint32_t keep_bits = 0x1ffu;
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
     const int jj = j < nk ? j : nk - 1;
     const int64_t row = (has_cls && jj == 0) ? seq_base + p.cls_row : first + (int64_t)(jj - has_cls) * p.tok_stride;
     kraw[j] = *reinterpret_cast<const uint4*>(p.k + row * p.ld + col);
     vraw[j] = *reinterpret_cast<const uint4*>(p.v + row * p.ld + col);
+    if (p.key_keep && p.key_keep[row] == 0) keep_bits &= ~(1u << j);
   }
   const float sc = p.scale * 1.44269504088896f;                 // softmax in base 2: exp(x) = exp2(x * log2 e)
   float s[9];
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t to
   for (int j = 0; j < 9; ++j) {
     float d = dot8_bf16(qraw, kraw[j]);
     d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-    s[j] = j < nk ? d * sc : -INFINITY;
+    s[j] = (j < nk && ((keep_bits >> j) & 1u)) ? d * sc : -INFINITY;
     m = fmaxf(m, s[j]);
   }
   float l = 0.f;
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t to
     for (int j = 0; j < 9; ++j) {
       float d = dot8_bf16(qc, kraw[j]);
       d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-      const bool use = j < nk && !(j == 0 && g != 0);
+      const bool use = j < nk && ((keep_bits >> j) & 1u) && !(j == 0 && g != 0);
       cs[j] = use ? d * sc : -INFINITY;
       cm = fmaxf(cm, cs[j]);
     }
@@ -151,6 +155,7 @@ struct ClsArgs {
   int64_t kv_seq_rows; int kv_row0, n_keys;
   bf16_t* out; int64_t ldo; int64_t out_seq_rows; int out_row;
   int heads; float scale;
+  const uint8_t* key_keep;   // optional, indexed by K/V row
 };
 
 __global__ __launch_bounds__(256) void attn_cls64_kernel(ClsArgs p) {
@@ -165,6 +170,7 @@ __global__ __launch_bounds__(256) void attn_cls64_kernel(ClsArgs p) {
   const int64_t kv0 = seq * p.kv_seq_rows + p.kv_row0;
   float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int j = wave * 8 + slot; j < p.n_keys; j += 32) {
+    if (p.key_keep && p.key_keep[kv0 + j] == 0) continue;        // masked key: contributes nothing (the 8 lanes of a slot agree)
     float kf[8], vf[8];
     unpack8(*reinterpret_cast<const uint4*>(p.k + (kv0 + j) * p.ld + col), kf);
     unpack8(*reinterpret_cast<const uint4*>(p.v + (kv0 + j) * p.ld + col), vf);
@@ -242,7 +248,8 @@ struct AttLds {
   static constexpr int K_LD = (D == 64) ? 128 : (D * 2 + 16);   // bytes per K row (D=64: XOR-swizzled 128 B rows)
   static constexpr int K_BYTES = 208 * K_LD;
   static constexpr int VT_BYTES = D * ATT_VT_LD * 2;
-  static constexpr int TOTAL = K_BYTES + VT_BYTES;
+  static constexpr int MASK_BYTES = 208;                          // one keep-flag byte per key slot (used only with a key mask)
+  static constexpr int TOTAL = K_BYTES + VT_BYTES + MASK_BYTES;
 };
 
 template <int D>
@@ -322,6 +329,8 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
     const int idx = tid + it * 256, row = idx / CH, ch = idx - row * CH;
     if (row < nkt * 16) *reinterpret_cast<uint4*>(k_lds + k_lds_off<D>(row, ch)) = kreg[it];
   }
+  uint8_t* m_lds = reinterpret_cast<uint8_t*>(smem + AttLds<D>::K_BYTES + AttLds<D>::VT_BYTES);
+  if (p.key_keep && tid < 208) m_lds[tid] = tid < nk ? p.key_keep[key_row(tid)] : (uint8_t)0;
   {
     const int npairs = ((nkt + 1) >> 1) * 16;                     // key pairs covering all 32-key PV steps (zero beyond nk)
 #pragma unroll
@@ -364,6 +373,9 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
     // ---- softmax (base 2, scale folded with log2 e) over keys for query column (lane & 15) ---------------------
     const float sc2 = p.scale * 1.44269504088896f;
     const bool cls_slot = do_cls && (qt * 16 + fr == nq);            // this lane's query column is the CLS query
+    uint32_t kflags[NKT];                                            // keep flags of keys kt*16 + fg*4 + 0..3 (one dword)
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) kflags[kt] = p.key_keep ? *reinterpret_cast<const uint32_t*>(m_lds + kt * 16 + fg * 4) : 0x01010101u;
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
@@ -371,7 +383,8 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + fg * 4 + r;
-          const float v = (key < nk && !(cls_slot && key == 0 && g != 0)) ? s[kt][r] * sc2 : -INFINITY;
+          const bool kept = !p.key_keep || ((kflags[kt] >> (8 * r)) & 0xffu);
+          const float v = (key < nk && kept && !(cls_slot && key == 0 && g != 0)) ? s[kt][r] * sc2 : -INFINITY;
           s[kt][r] = v;
           m = fmaxf(m, v);
         }
@@ -501,7 +514,7 @@ extern "C" int sf_attention_cls_combine(const float* partials, int n_part, uint1
 
 static int attention_impl(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ldo, int64_t n_seq,
                           int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok, int cls_row, int heads,
-                          int head_dim, float scale, float* cls_partial, void* stream);
+                          int head_dim, float scale, float* cls_partial, void* stream, const uint8_t* key_keep = nullptr);
 
 extern "C" int sf_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ldo, int64_t n_seq,
                             int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok, int cls_row, int heads,
@@ -522,7 +535,8 @@ extern "C" int sf_attention_cls_partial(const bf16_t* q, const bf16_t* k, const 
 
 static int attention_impl(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ldo,
                             int64_t n_seq, int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride,
-                            int n_tok, int cls_row, int heads, int head_dim, float scale, float* cls_partial, void* stream) {
+                            int n_tok, int cls_row, int heads, int head_dim, float scale, float* cls_partial, void* stream,
+                            const uint8_t* key_keep) {
   SF_CHECK_ARG(q && k && v && out, "sf_attention: null pointer");
   SF_CHECK_ARG(head_dim == 64 || head_dim == 96, "sf_attention: head_dim %d not supported (64, 96)", head_dim);
   SF_CHECK_ARG((ld % 8) == 0 && (ldo % 8) == 0, "sf_attention: ld/ldo must be multiples of 8 elements");
@@ -534,7 +548,7 @@ static int attention_impl(const bf16_t* q, const bf16_t* k, const bf16_t* v, int
   AttnArgs a;
   a.q = q; a.k = k; a.v = v; a.ld = ld; a.out = out; a.ldo = ldo; a.seq_rows = seq_rows;
   a.n_groups = n_groups; a.row0 = row0; a.group_stride = group_stride; a.tok_stride = tok_stride; a.n_tok = n_tok;
-  a.cls_row = cls_row; a.heads = heads; a.scale = scale; a.cls_part = cls_partial;
+  a.cls_row = cls_row; a.heads = heads; a.scale = scale; a.cls_part = cls_partial; a.key_keep = key_keep;
   hipStream_t s = (hipStream_t)stream;
   if (head_dim == 64 && n_tok <= 8) {
     const int64_t units = n_seq * n_groups * heads;
@@ -546,10 +560,35 @@ static int attention_impl(const bf16_t* q, const bf16_t* k, const bf16_t* v, int
   return head_dim == 64 ? dispatch_attn_mfma<64>(a, n_seq, nkt, s) : dispatch_attn_mfma<96>(a, n_seq, nkt, s);
 }
 
+extern "C" int sf_attention_masked(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ldo, int64_t n_seq,
+                                   int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok, int cls_row,
+                                   int heads, int head_dim, float scale, const uint8_t* key_keep, void* stream) {
+  return attention_impl(q, k, v, ld, out, ldo, n_seq, seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim, scale,
+                        nullptr, stream, key_keep);
+}
+
+static int attention_cls_impl(const bf16_t* q, int64_t q_seq_rows, int q_row, const bf16_t* k, const bf16_t* v, int64_t ld, int64_t kv_seq_rows,
+                              int kv_row0, int n_keys, bf16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row, int64_t n_seq, int heads,
+                              int head_dim, float scale, const uint8_t* key_keep, void* stream);
+
 extern "C" int sf_attention_cls(const bf16_t* q, int64_t q_seq_rows, int q_row, const bf16_t* k, const bf16_t* v,
                                 int64_t ld, int64_t kv_seq_rows, int kv_row0, int n_keys, bf16_t* out, int64_t ldo,
                                 int64_t out_seq_rows, int out_row, int64_t n_seq, int heads, int head_dim, float scale,
                                 void* stream) {
+  return attention_cls_impl(q, q_seq_rows, q_row, k, v, ld, kv_seq_rows, kv_row0, n_keys, out, ldo, out_seq_rows, out_row, n_seq, heads, head_dim,
+                            scale, nullptr, stream);
+}
+
+extern "C" int sf_attention_cls_masked(const bf16_t* q, int64_t q_seq_rows, int q_row, const bf16_t* k, const bf16_t* v, int64_t ld,
+                                       int64_t kv_seq_rows, int kv_row0, int n_keys, bf16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row,
+                                       int64_t n_seq, int heads, int head_dim, float scale, const uint8_t* key_keep, void* stream) {
+  return attention_cls_impl(q, q_seq_rows, q_row, k, v, ld, kv_seq_rows, kv_row0, n_keys, out, ldo, out_seq_rows, out_row, n_seq, heads, head_dim,
+                            scale, key_keep, stream);
+}
+
+static int attention_cls_impl(const bf16_t* q, int64_t q_seq_rows, int q_row, const bf16_t* k, const bf16_t* v, int64_t ld, int64_t kv_seq_rows,
+                              int kv_row0, int n_keys, bf16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row, int64_t n_seq, int heads,
+                              int head_dim, float scale, const uint8_t* key_keep, void* stream) {
   SF_CHECK_ARG(q && k && v && out, "sf_attention_cls: null pointer");
   SF_CHECK_ARG(head_dim == 64, "sf_attention_cls: head_dim %d not supported (64)", head_dim);
   SF_CHECK_ARG((ld % 8) == 0 && (ldo % 8) == 0 && n_keys >= 1, "sf_attention_cls: bad shape");
@@ -557,7 +596,7 @@ extern "C" int sf_attention_cls(const bf16_t* q, int64_t q_seq_rows, int q_row, 
   ClsArgs a;
   a.q = q; a.q_seq_rows = q_seq_rows; a.q_row = q_row; a.k = k; a.v = v; a.ld = ld; a.kv_seq_rows = kv_seq_rows;
   a.kv_row0 = kv_row0; a.n_keys = n_keys; a.out = out; a.ldo = ldo; a.out_seq_rows = out_seq_rows; a.out_row = out_row;
-  a.heads = heads; a.scale = scale;
+  a.heads = heads; a.scale = scale; a.key_keep = key_keep;
   hipLaunchKernelGGL(attn_cls64_kernel, dim3((unsigned)(n_seq * heads)), dim3(256), 0, (hipStream_t)stream, a);
   SF_LAUNCH_CHECK();
   return 0;

@@ -288,3 +288,77 @@ extern "C" int sf_im2col_spec(const float* spec, bf16_t* out, int64_t n_seg, int
   SF_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Token masks from content masks: the reference pushes an indicator (1 = kept, inf = masked content) through the patch embedding and
+// masks a token iff output channel 0 is NaN (video_model_builder.py:185-201, modeling_ast.py:515-530), i.e. iff the masked elements
+// of its patch meet filter-0 weights of BOTH signs (inf - inf) or a zero weight (inf * 0).  w0_sign[k] in {+1, -1, 0} is the sign of
+// filter 0 at patch element k (same K order as the im2col gathers).  One wave per token; tok_keep[n*L + t] = 1 keeps the token;
+// the CLS (and DISTILL) rows are always kept (video_model_builder.py:223-225).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void token_mask_video_kernel(const uint8_t* __restrict__ keep, const int8_t* __restrict__ w0_sign,
+                                                                uint8_t* __restrict__ tok_keep, int64_t n_tok_total) {
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (t >= n_tok_total) return;
+  const int64_t n = t / 1569;
+  const int tok = (int)(t - n * 1569);
+  if (tok == 0) { if (lane == 0) tok_keep[t] = 1; return; }
+  const int f = (tok - 1) / 196, hw = (tok - 1) % 196, h = hw / 14, w = hw % 14;
+  int flags = 0;                                                   // bit0: +, bit1: -, bit2: zero weight among the masked elements
+  for (int e = lane; e < 1536 / 16; e += 64) {                    // e = ((c*2 + dt)*16 + dh): one 16-pixel run each
+    const int dh = e & 15, dt = (e >> 4) & 1, c = e >> 5;
+    const uint8_t* src = keep + ((((n * 16 + (f * 2 + dt)) * 3 + c) * 224 + (h * 16 + dh)) * 224) + w * 16;
+    const uint4 m = *reinterpret_cast<const uint4*>(src);
+    const uint32_t mw[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (((mw[i >> 2] >> (8 * (i & 3))) & 0xffu) == 0) {
+        const int sgn = w0_sign[e * 16 + i];
+        flags |= sgn > 0 ? 1 : (sgn < 0 ? 2 : 4);
+      }
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) flags |= __shfl_xor(flags, off, 64);
+  if (lane == 0) tok_keep[t] = (((flags & 3) == 3) || (flags & 4)) ? 0 : 1;
+}
+
+extern "C" int sf_token_mask_video(const uint8_t* content_keep, int64_t n_seg, const int8_t* w0_sign, uint8_t* tok_keep, void* stream) {
+  SF_CHECK_ARG(content_keep && w0_sign && tok_keep && ((uintptr_t)content_keep % 16) == 0, "sf_token_mask_video: bad arguments");
+  if (n_seg <= 0) return 0;
+  const int64_t total = n_seg * 1569;
+  hipLaunchKernelGGL(token_mask_video_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, content_keep, w0_sign, tok_keep,
+                     total);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void token_mask_spec_kernel(const uint8_t* __restrict__ keep, const int8_t* __restrict__ w0_sign,
+                                                               uint8_t* __restrict__ tok_keep, int64_t n_tok_total, int F, int Ta, int nf, int nt) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;      // tiny: one thread per token
+  if (t >= n_tok_total) return;
+  const int L = nf * nt + 2;
+  const int64_t n = t / L;
+  const int tok = (int)(t - n * L);
+  if (tok < 2) { tok_keep[t] = 1; return; }
+  const int fi = (tok - 2) / nt, ti = (tok - 2) % nt;
+  int flags = 0;
+  for (int df = 0; df < 16; ++df)
+    for (int dtc = 0; dtc < 16; ++dtc)
+      if (keep[(n * F + fi * 10 + df) * Ta + ti * 10 + dtc] == 0) {
+        const int sgn = w0_sign[df * 16 + dtc];
+        flags |= sgn > 0 ? 1 : (sgn < 0 ? 2 : 4);
+      }
+  tok_keep[t] = (((flags & 3) == 3) || (flags & 4)) ? 0 : 1;
+}
+
+extern "C" int sf_token_mask_spec(const uint8_t* content_keep, int64_t n_seg, int F, int Ta, const int8_t* w0_sign, uint8_t* tok_keep, void* stream) {
+  SF_CHECK_ARG(content_keep && w0_sign && tok_keep && F >= 16 && Ta >= 16, "sf_token_mask_spec: bad arguments");
+  if (n_seg <= 0) return 0;
+  const int nf = (F - 16) / 10 + 1, nt = (Ta - 16) / 10 + 1;
+  const int64_t total = n_seg * (nf * nt + 2);
+  hipLaunchKernelGGL(token_mask_spec_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, content_keep, w0_sign,
+                     tok_keep, total, F, Ta, nf, nt);
+  SF_LAUNCH_CHECK();
+  return 0;
+}

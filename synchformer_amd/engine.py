@@ -68,6 +68,8 @@ class SynchformerEngine:
         lin = lambda k: _Lin(sd[k + '.weight'], sd[k + '.bias'], dev)
         v = 'vfeat_extractor'
         self.v_pe = _Lin(sd[f'{v}.patch_embed_3d.proj.weight'].reshape(D, -1), sd[f'{v}.patch_embed_3d.proj.bias'], dev)
+        # sign of filter 0 per patch element: the reference's inf -> NaN token-mask rule (video_model_builder.py:185-201)
+        self.v_w0_sign = torch.sign(f32(f'{v}.patch_embed_3d.proj.weight')[0].reshape(-1)).to(torch.int8).contiguous()
         pos, temp = f32(f'{v}.pos_embed')[0], f32(f'{v}.temp_embed')[0]
         body = (pos[1:].unsqueeze(0) + temp.unsqueeze(1)).reshape(-1, D)       # row f*196+n (vmb:248-254)
         self.v_table = torch.cat([pos[:1] + f32(f'{v}.cls_token')[0], body], 0).contiguous()   # (1569, 768)
@@ -87,6 +89,7 @@ class SynchformerEngine:
         e = f'{a}.ast.embeddings'
         self.a_pe = _Lin(sd[f'{e}.patch_embeddings.projection.weight'].reshape(D, -1),
                          sd[f'{e}.patch_embeddings.projection.bias'], dev)
+        self.a_w0_sign = torch.sign(f32(f'{e}.patch_embeddings.projection.weight')[0].reshape(-1)).to(torch.int8).contiguous()
         tab = f32(f'{e}.position_embeddings')[0].clone()
         tab[0] += f32(f'{e}.cls_token')[0, 0]
         tab[1] += f32(f'{e}.distillation_token')[0, 0]
@@ -161,7 +164,7 @@ class SynchformerEngine:
     # ------------------------------------------------------------------------------------------------
     # shared sub-schedules
     # ------------------------------------------------------------------------------------------------
-    def _agg_layer(self, Z, n_seq, L, agg, out, tag):
+    def _agg_layer(self, Z, n_seq, L, agg, out, tag, key_keep=None):
         """BaseEncoderLayer (motionformer.py:301-334): Z fp32 (n_seq*L, 768) already holds [agg_cls; tokens].
         Only output row 0 of each sequence is ever read (:332), so everything after K/V is computed for row 0 only."""
         rows = n_seq * L
@@ -172,7 +175,7 @@ class SynchformerEngine:
         att = self._buf(tag + '_att', n_seq * D, torch.bfloat16).view(n_seq, D)
         ops.attention_cls(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], att, n_seq=n_seq, q_seq_rows=L, q_row=0,
                           kv_seq_rows=L, kv_row0=0, n_keys=L, out_seq_rows=1, out_row=0, heads=12, head_dim=64,
-                          scale=0.125)
+                          scale=0.125, key_keep=key_keep)
         y = self._buf(tag + '_y', n_seq * D, torch.float32).view(n_seq, D)
         ops.gemm(att, agg['o'].w, agg['o'].b, y, residual=Z, r_map=ops.rowmap(1, 1, L, 0, 0, 0))
         yn = self._buf(tag + '_yn', n_seq * D, torch.bfloat16).view(n_seq, D)
@@ -197,7 +200,7 @@ class SynchformerEngine:
     # ------------------------------------------------------------------------------------------------
     # visual branch
     # ------------------------------------------------------------------------------------------------
-    def _visual_chunk(self, vid, out, clip_seg=None):
+    def _visual_chunk(self, vid, out, clip_seg=None, keep=None):
         """vid (n, 16, 3, 224, 224) u8|f16|bf16|f32 on device -> out fp32 (n*8, 768).  a3-a9 of SURVEY §8a.
         With clip_seg = (frame0, seg_stride, n_seg), vid is (clips, T, 3, 224, 224) and the segments are read in place."""
         n = vid.shape[0] if clip_seg is None else vid.shape[0] * clip_seg[2]
@@ -220,14 +223,18 @@ class SynchformerEngine:
         part = self._buf('cls_part', n * 12 * 196 * 66, torch.float32)
 
         fuse_mode = os.environ.get('SF_CLS_FUSION', 'space')          # A/B switch: both | space | none (profiles/r01_notes.md)
+        tok_keep = None
+        if keep is not None:                                            # content mask (n, 16, 3, 224, 224) bool -> token keep flags
+            tok_keep = ops.token_mask_video(keep, self.v_w0_sign, torch.empty(rows, device=self.dev, dtype=torch.uint8))
+            fuse_mode = 'none'                                          # the fused CLS partials are not built for masks
 
         def divided(kind):
             if fuse_mode == 'none' or (fuse_mode == 'space' and kind == 'time'):
                 kw = dict(n_groups=196, row0=1, group_stride=1, tok_stride=196, n_tok=8) if kind == 'time' else \
                     dict(n_groups=8, row0=1, group_stride=196, tok_stride=1, n_tok=196)
-                ops.attention(q, k, v, xn, n_seq=n, seq_rows=VIS_L, cls_row=0, heads=12, head_dim=64, scale=0.125, **kw)
+                ops.attention(q, k, v, xn, n_seq=n, seq_rows=VIS_L, cls_row=0, heads=12, head_dim=64, scale=0.125, key_keep=tok_keep, **kw)
                 ops.attention_cls(q, k, v, xn, n_seq=n, q_seq_rows=VIS_L, q_row=0, kv_seq_rows=VIS_L, kv_row0=0, n_keys=VIS_L,
-                                  out_seq_rows=VIS_L, out_row=0, heads=12, head_dim=64, scale=0.125)
+                                  out_seq_rows=VIS_L, out_row=0, heads=12, head_dim=64, scale=0.125, key_keep=tok_keep)
                 return
             # patches attend [CLS; their group]; the CLS query's attention over ALL tokens (vit_helper.py:126) is accumulated as
             # per-group partials inside the same kernels (no second pass over K/V) and merged by a tiny combine kernel
@@ -258,25 +265,37 @@ class SynchformerEngine:
         ops.broadcast_rows(Z, self.v_agg['cls'], n_seq=n * 8, dst_seq_rows=AGG_V)
         ops.layernorm(X, self.v_norm.g, self.v_norm.b, Z, EPS_VIS, rows=n * VIS_P,
                       in_map=ops.rowmap(VIS_P, VIS_P, VIS_L, 0, 1, 1), out_map=ops.rowmap(VIS_P, 196, 8 * AGG_V, AGG_V, 1, 1))
-        self._agg_layer(Z, n * 8, AGG_V, self.v_agg, out, 'vagg')
+        zkeep = None
+        if tok_keep is not None:                                        # per-frame key mask [agg cls = keep; 196 patches] (motionformer.py:237-243, 308-317)
+            zkeep = torch.ones(n * 8, AGG_V, device=self.dev, dtype=torch.uint8)
+            zkeep[:, 1:] = tok_keep.view(n, VIS_L)[:, 1:].reshape(n * 8, 196)
+            zkeep = zkeep.reshape(-1)
+        self._agg_layer(Z, n * 8, AGG_V, self.v_agg, out, 'vagg', key_keep=zkeep)
 
-    def extract_vfeats(self, vis: torch.Tensor) -> torch.Tensor:
-        """vis (B, S, Tv=16, C=3, H, W) -> (B, S, 8, 768) fp32 (Synchformer.extract_vfeats, sync_model.py:72-80)."""
+    def extract_vfeats(self, vis: torch.Tensor, vis_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """vis (B, S, Tv=16, C=3, H, W) -> (B, S, 8, 768) fp32 (Synchformer.extract_vfeats, sync_model.py:72-80).
+        vis_mask: optional bool tensor shaped like vis, False = masked content (token masks, sync_model.py:75-76)."""
         B, S = vis.shape[:2]
         vid = vis.reshape(B * S, *vis.shape[2:])
         if not vid.is_contiguous():
             vid = vid.contiguous()
+        keep = None
+        if vis_mask is not None:
+            if vis_mask.shape != vis.shape:
+                raise ValueError(f'vis_mask {tuple(vis_mask.shape)} must have the shape of vis {tuple(vis.shape)}')
+            keep = vis_mask.to(self.dev).to(torch.bool).reshape(vid.shape).contiguous()
         out = torch.empty(B * S * 8, D, device=self.dev, dtype=torch.float32)
         for s0 in range(0, B * S, self.seg_chunk):
             n = min(self.seg_chunk, B * S - s0)
-            self._visual_chunk(vid[s0:s0 + n], out[s0 * 8:(s0 + n) * 8])
+            self._visual_chunk(vid[s0:s0 + n], out[s0 * 8:(s0 + n) * 8], keep=None if keep is None else keep[s0:s0 + n])
         return out.view(B, S, 8, D)
 
     # ------------------------------------------------------------------------------------------------
     # audio branch
     # ------------------------------------------------------------------------------------------------
-    def extract_afeats(self, aud: torch.Tensor) -> torch.Tensor:
-        """aud (B, S, 1, F=128, Ta=66) fp32 -> (B, S, 6, 768) fp32 (sync_model.py:82-89, ast.py:137-201)."""
+    def extract_afeats(self, aud: torch.Tensor, aud_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """aud (B, S, 1, F=128, Ta=66) fp32 -> (B, S, 6, 768) fp32 (sync_model.py:82-89, ast.py:137-201).
+        aud_mask: optional bool tensor shaped like aud, False = masked content (sync_model.py:85-86)."""
         B, S, _, Fa, Ta = aud.shape
         n = B * S
         spec = aud.reshape(n, Fa, Ta).to(torch.float32)
@@ -297,9 +316,14 @@ class SynchformerEngine:
         tokmap = ops.rowmap(P, P, L, 0, 1, 2)
         ops.gemm(patches, self.a_pe.w, self.a_pe.b, X, residual=X, c_map=tokmap, r_map=tokmap)
 
+        tok_keep = None
+        if aud_mask is not None:
+            keep = aud_mask.to(self.dev).to(torch.bool).reshape(n, Fa, Ta)
+            tok_keep = ops.token_mask_spec(keep, self.a_w0_sign, torch.empty(rows, device=self.dev, dtype=torch.uint8))
+
         def full_attn(q3, o):
             ops.attention(q3[:, :D], q3[:, D:2 * D], q3[:, 2 * D:], o, n_seq=n, seq_rows=L, n_groups=1, row0=0,
-                          group_stride=0, tok_stride=1, n_tok=L, cls_row=-1, heads=12, head_dim=64, scale=0.125)
+                          group_stride=0, tok_stride=1, n_tok=L, cls_row=-1, heads=12, head_dim=64, scale=0.125, key_keep=tok_keep)
         for ly in self.a_layers:   # ASTLayer.forward (modeling_ast.py:294-322)
             self._encoder_layer(X, rows, xn, big, ly['ln1'], ly['qkv'], full_attn, ly['o'], ly['ln2'], ly['fc1'], ly['fc2'],
                                 EPS_AST)
@@ -310,7 +334,12 @@ class SynchformerEngine:
         ops.layernorm(X, self.a_norm.g, self.a_norm.b, Z, EPS_AST, rows=n * P, in_map=ops.rowmap(P, P, L, 0, 1, 2),
                       out_map=ops.rowmap(P, nt, nt * La, 1, La, 1))
         out = torch.empty(n * nt, D, device=self.dev, dtype=torch.float32)
-        self._agg_layer(Z, n * nt, La, self.a_agg, out, 'aagg')
+        zkeep = None
+        if tok_keep is not None:                                        # per-time-step key mask [agg cls = keep; 12 frequency tokens] (ast.py:188-193, 269-271)
+            zkeep = torch.ones(n * nt, La, device=self.dev, dtype=torch.uint8)
+            zkeep[:, 1:] = tok_keep.view(n, L)[:, 2:].reshape(n, nf, nt).transpose(1, 2).reshape(n * nt, nf)
+            zkeep = zkeep.reshape(-1)
+        self._agg_layer(Z, n * nt, La, self.a_agg, out, 'aagg', key_keep=zkeep)
         return out.view(B, S, nt, D)
 
     # ------------------------------------------------------------------------------------------------
@@ -397,9 +426,10 @@ class SynchformerEngine:
         """vproj/aproj + GlobalTransformer: segment features (B,S,tv,768) / (B,S,ta,768) fp32 -> logits (B, n_out)."""
         return self.global_transformer(self.project(vfeat, 'v'), self.project(afeat, 'a'))
 
-    def forward(self, vis: torch.Tensor, aud: torch.Tensor) -> torch.Tensor:
+    def forward(self, vis: torch.Tensor, aud: torch.Tensor, vis_mask: Optional[torch.Tensor] = None,
+                aud_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Synchformer.forward (sync_model.py:38-70) without the loss: logits (B, n_out) fp32."""
-        return self.sync_transformer(self.extract_vfeats(vis), self.extract_afeats(aud))
+        return self.sync_transformer(self.extract_vfeats(vis, vis_mask), self.extract_afeats(aud, aud_mask))
 
     # ------------------------------------------------------------------------------------------------
     # whole clips in, segmenting on the device (SURVEY §8f rank 1)

@@ -10,7 +10,7 @@ registered these classes under the reference's own dotted paths.
 
 All compute runs through libsynchformer_hip (synchformer_amd.engine); there is no CPU / eager fallback: calling
 forward on CPU tensors raises.  Out-of-scope options of the reference constructors (SparseSync-era bridges, S3D/ResNet
-extractors, joint/trajectory attention, token masks - SURVEY §2 rows 4b/5/6, §8f rank 2) raise NotImplementedError
+extractors, joint/trajectory attention - SURVEY §2 rows 4b/5/6) raise NotImplementedError
 naming the option.
 """
 import importlib
@@ -154,11 +154,12 @@ class MotionFormer(torch.nn.Module):
     def forward(self, x, for_loop: bool = False, cont_mask: torch.Tensor = None):
         """x (B, S, C, T, H, W) -> ((B, S, 8, 768), None), or ((B, S, 768), None) with agg_time_module='AveragePooling'
         (motionformer.py:182-223)."""
-        if cont_mask is not None:
-            raise NotImplementedError('cont_mask (token masking) is not implemented yet (SURVEY §8f rank 2)')
+        if cont_mask is not None and for_loop:
+            raise AssertionError('cont_mask is not supported with for_loop=True')       # motionformer.py:201
         _no_extractor_backward(self)
         eng = _engine_for(self, 'vfeat_extractor.')
-        feat = eng.extract_vfeats(x.permute(0, 1, 3, 2, 4, 5).contiguous())
+        feat = eng.extract_vfeats(x.permute(0, 1, 3, 2, 4, 5).contiguous(),
+                                  None if cont_mask is None else cont_mask.permute(0, 1, 3, 2, 4, 5).contiguous())
         if self.pool_time:
             feat = eng.pool_segments(feat).view(feat.shape[0], feat.shape[1], -1)
         return feat, None
@@ -189,12 +190,13 @@ class AST(torch.nn.Module):
     def forward(self, x, for_loop: bool = False, cont_mask: torch.Tensor = None, **ast_kwargs):
         """x (B, S, T, F) -> ((B, S, 6, 768), None), or ((B, S, 768), None) with agg_time_module='AveragePooling'
         (ast.py:137-176)."""
-        if cont_mask is not None:
-            raise NotImplementedError('cont_mask (token masking) is not implemented yet (SURVEY §8f rank 2)')
+        if cont_mask is not None and for_loop:
+            raise AssertionError('cont_mask is not supported with for_loop=True')       # ast.py:153
         _no_extractor_backward(self)
         eng = _engine_for(self, 'afeat_extractor.')
         B, S, T, Fq = x.shape
-        feat = eng.extract_afeats(x.permute(0, 1, 3, 2).reshape(B, S, 1, Fq, T))
+        feat = eng.extract_afeats(x.permute(0, 1, 3, 2).reshape(B, S, 1, Fq, T),
+                                  None if cont_mask is None else cont_mask.permute(0, 1, 3, 2).reshape(B, S, 1, Fq, T))
         if self.pool_time:
             feat = eng.pool_segments(feat).view(B, S, -1)
         return feat, None
@@ -370,14 +372,15 @@ class Synchformer(torch.nn.Module):
         return SyncTrainFunction.apply(tr, vfeat.detach(), afeat.detach(), *[trainable[k] for k in tr.keys])
 
     def extract_vfeats(self, vis, for_loop, vis_mask=None):
-        if vis_mask is not None:
-            raise NotImplementedError('vis_mask (token masking) is not implemented yet (SURVEY §8f rank 2)')
-        return self._engine().extract_vfeats(vis)
+        """vis_mask: bool, shaped like vis, 0 = masked content (sync_model.py:72-80); like the reference, not with for_loop=True."""
+        if vis_mask is not None and for_loop:
+            raise AssertionError('cont_mask is not supported with for_loop=True')       # motionformer.py:201
+        return self._engine().extract_vfeats(vis, vis_mask)
 
     def extract_afeats(self, aud, for_loop, aud_mask=None):
-        if aud_mask is not None:
-            raise NotImplementedError('aud_mask (token masking) is not implemented yet (SURVEY §8f rank 2)')
-        return self._engine().extract_afeats(aud)
+        if aud_mask is not None and for_loop:
+            raise AssertionError('cont_mask is not supported with for_loop=True')       # ast.py:153
+        return self._engine().extract_afeats(aud, aud_mask)
 
     def compute_loss(self, logits, targets, loss_fn: str = None):
         loss = None

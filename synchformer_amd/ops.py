@@ -123,13 +123,20 @@ def im2col_spec(spec: torch.Tensor, out: torch.Tensor):
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, n_seq: int, seq_rows: int,
               n_groups: int, row0: int, group_stride: int, tok_stride: int, n_tok: int, cls_row: int, heads: int,
-              head_dim: int, scale: float):
-    """q/k/v: column-slice views (rows, heads*head_dim) of a packed bf16 projection; see include/synchformer_hip.h."""
+              head_dim: int, scale: float, key_keep: Optional[torch.Tensor] = None):
+    """q/k/v: column-slice views (rows, heads*head_dim) of a packed bf16 projection; see include/synchformer_hip.h.
+    key_keep: optional uint8 (rows,) token mask, 0 = that K/V row is masked out for every query."""
     assert q.dtype == k.dtype == v.dtype == out.dtype == torch.bfloat16
     assert _ld(q) == _ld(k) == _ld(v)
-    rc = _lib.load().sf_attention(_dev(q, 'q'), _dev(k, 'k'), _dev(v, 'v'), _ld(q), _dev(out, 'out'), _ld(out), n_seq,
-                                  seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim,
-                                  float(scale), _stream())
+    if key_keep is None:
+        rc = _lib.load().sf_attention(_dev(q, 'q'), _dev(k, 'k'), _dev(v, 'v'), _ld(q), _dev(out, 'out'), _ld(out), n_seq,
+                                      seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim,
+                                      float(scale), _stream())
+    else:
+        assert key_keep.dtype == torch.uint8 and key_keep.is_contiguous()
+        rc = _lib.load().sf_attention_masked(_dev(q, 'q'), _dev(k, 'k'), _dev(v, 'v'), _ld(q), _dev(out, 'out'), _ld(out), n_seq,
+                                             seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim,
+                                             float(scale), _dev(key_keep, 'key_keep'), _stream())
     _lib.check(rc, 'sf_attention')
     return out
 
@@ -156,13 +163,35 @@ def attention_cls_combine(partials: torch.Tensor, out: torch.Tensor, *, n_part: 
 
 def attention_cls(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, n_seq: int, q_seq_rows: int,
                   q_row: int, kv_seq_rows: int, kv_row0: int, n_keys: int, out_seq_rows: int, out_row: int, heads: int,
-                  head_dim: int, scale: float):
+                  head_dim: int, scale: float, key_keep: Optional[torch.Tensor] = None):
     assert q.dtype == k.dtype == v.dtype == out.dtype == torch.bfloat16
     assert _ld(q) == _ld(k) == _ld(v)
-    rc = _lib.load().sf_attention_cls(_dev(q, 'q'), q_seq_rows, q_row, _dev(k, 'k'), _dev(v, 'v'), _ld(q), kv_seq_rows,
-                                      kv_row0, n_keys, _dev(out, 'out'), _ld(out), out_seq_rows, out_row, n_seq, heads,
-                                      head_dim, float(scale), _stream())
+    if key_keep is None:
+        rc = _lib.load().sf_attention_cls(_dev(q, 'q'), q_seq_rows, q_row, _dev(k, 'k'), _dev(v, 'v'), _ld(q), kv_seq_rows,
+                                          kv_row0, n_keys, _dev(out, 'out'), _ld(out), out_seq_rows, out_row, n_seq, heads,
+                                          head_dim, float(scale), _stream())
+    else:
+        assert key_keep.dtype == torch.uint8 and key_keep.is_contiguous()
+        rc = _lib.load().sf_attention_cls_masked(_dev(q, 'q'), q_seq_rows, q_row, _dev(k, 'k'), _dev(v, 'v'), _ld(q), kv_seq_rows,
+                                                 kv_row0, n_keys, _dev(out, 'out'), _ld(out), out_seq_rows, out_row, n_seq, heads,
+                                                 head_dim, float(scale), _dev(key_keep, 'key_keep'), _stream())
     _lib.check(rc, 'sf_attention_cls')
+    return out
+
+
+def token_mask_video(content_keep: torch.Tensor, w0_sign: torch.Tensor, out: torch.Tensor):
+    """content_keep (n, 16, 3, 224, 224) bool|uint8 (True = kept) -> out uint8 (n*1569,) token keep flags (CLS kept)."""
+    m = content_keep.contiguous().view(torch.uint8)
+    rc = _lib.load().sf_token_mask_video(_dev(m, 'mask'), m.shape[0], _dev(w0_sign, 'w0_sign'), _dev(out, 'out'), _stream())
+    _lib.check(rc, 'sf_token_mask_video')
+    return out
+
+
+def token_mask_spec(content_keep: torch.Tensor, w0_sign: torch.Tensor, out: torch.Tensor):
+    """content_keep (n, F, Ta) bool|uint8 -> out uint8 (n*74,) token keep flags (CLS, DISTILL kept)."""
+    m = content_keep.contiguous().view(torch.uint8)
+    rc = _lib.load().sf_token_mask_spec(_dev(m, 'mask'), m.shape[0], m.shape[1], m.shape[2], _dev(w0_sign, 'w0_sign'), _dev(out, 'out'), _stream())
+    _lib.check(rc, 'sf_token_mask_spec')
     return out
 
 

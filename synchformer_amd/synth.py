@@ -133,6 +133,31 @@ def make_spectrogram(B: int, S: int = 14, seed: int = 1337, F: int = 128, Ta: in
     return torch.from_numpy(0.5 * g.standard_normal(size=(B, S, 1, F, Ta), dtype=np.float32))
 
 
+def make_masks(B: int, S: int = 14, seed: int = 1337, T: int = 16, H: int = 224, W: int = 224, F: int = 128, Ta: int = 66):
+    """Deterministic content masks for Synchformer.forward(vis_mask=, aud_mask=) (True = kept): per segment a few boxes that are NOT
+    aligned to the 16-pixel patch grid and span some frames (all channels), plus isolated single elements - those exercise the
+    reference's NaN-trick quirk (one masked element meets one filter weight: +-inf, not NaN, so the token stays).
+    -> vis_mask (B, S, T, 3, H, W) bool, aud_mask (B, S, 1, F, Ta) bool."""
+    g = _rng(seed, f'masks{B}x{S}')
+    vm = np.ones((B, S, T, 3, H, W), dtype=bool)
+    am = np.ones((B, S, 1, F, Ta), dtype=bool)
+    for b in range(B):
+        for s in range(S):
+            for _ in range(3):
+                t0, t1 = sorted(g.integers(0, T + 1, size=2))
+                y0, x0 = g.integers(0, H - 40), g.integers(0, W - 40)
+                h, w = g.integers(8, 90), g.integers(8, 90)
+                vm[b, s, t0:max(t1, t0 + 1), :, y0:y0 + h, x0:x0 + w] = False
+            for _ in range(4):                                            # isolated pixels (single channel, single frame)
+                vm[b, s, g.integers(0, T), g.integers(0, 3), g.integers(0, H), g.integers(0, W)] = False
+            for _ in range(2):
+                f0, a0 = g.integers(0, F - 20), g.integers(0, Ta - 10)
+                am[b, s, 0, f0:f0 + g.integers(4, 40), a0:a0 + g.integers(3, 25)] = False
+            for _ in range(3):
+                am[b, s, 0, g.integers(0, F), g.integers(0, Ta)] = False
+    return torch.from_numpy(vm), torch.from_numpy(am)
+
+
 def make_targets(B: int, n_cls: int = 21, seed: int = 1337) -> torch.Tensor:
     g = _rng(seed, f'targets{B}')
     return torch.from_numpy(g.integers(0, n_cls, size=(B,), dtype=np.int64))

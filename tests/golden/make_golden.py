@@ -223,9 +223,39 @@ def avclip_grads(B=1, S=3, gain=2.0):
           'dscale', float(scale.grad))
 
 
+def e2e_masked(B=1, S=2, gain=2.0):
+    """Synchformer.forward with vis_mask / aud_mask (sync_model.py:38-89; token masks via the NaN trick) through the REAL reference."""
+    n_pos = 2 + S * 14
+    model = ref_import.build_reference_synchformer(n_segments_tokens=n_pos)
+    model.load_state_dict(synth.make_state_dict(SEED, gain=gain, n_pos=n_pos), strict=True)
+    vis = rgb_frontend_ref(synth.make_video_u8(B, S, SEED)).float()
+    aud = synth.make_spectrogram(B, S, SEED)
+    vm, am = synth.make_masks(B, S, SEED)
+    names = ['vfeat_extractor.spatial_attn_agg', 'afeat_extractor.freq_attn_agg', 'vfeat_extractor.blocks.0', 'afeat_extractor.ast.encoder.layer.0']
+    store, hooks = capture(model, names)
+    with torch.no_grad():
+        _, logits = model(vis, aud, vis_mask=vm, aud_mask=am)
+        _, logits_nomask = model(vis, aud)
+    for h in hooks:
+        h.remove()
+    out = dict(seed=np.int64(SEED), B=np.int64(B), S=np.int64(S), gain=np.float64(gain), logits=logits.numpy(), logits_nomask=logits_nomask.numpy())
+    # hooks fired twice: `store` holds the UNMASKED pass; rerun for the masked one
+    store, hooks = capture(model, names)
+    with torch.no_grad():
+        model(vis, aud, vis_mask=vm, aud_mask=am)
+    for h in hooks:
+        h.remove()
+    out['vfeat'] = store['vfeat_extractor.spatial_attn_agg'].numpy()
+    out['afeat'] = store['afeat_extractor.freq_attn_agg'].numpy()
+    out['vblock0_rows'] = store['vfeat_extractor.blocks.0'][:, TOK_V].numpy()
+    out['ablock0_rows'] = store['afeat_extractor.ast.encoder.layer.0'][:, TOK_A].numpy()
+    np.savez_compressed(HERE / f'e2e_masked_B{B}S{S}.npz', **out)
+    print('masked logits', logits, 'unmasked', logits_nomask, 'max diff', float((logits - logits_nomask).abs().max()))
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['sync', 'sync_gain2', 'syncability', 'train', 'avclip', 'avclip_grads']
+    which = sys.argv[1:] or ['sync', 'sync_gain2', 'syncability', 'train', 'avclip', 'avclip_grads', 'masked']
     if 'sync' in which:
         e2e_sync(2)
     if 'sync_gain2' in which:
@@ -238,3 +268,5 @@ if __name__ == '__main__':
         avclip(2, 3)
     if 'avclip_grads' in which:
         avclip_grads(1, 3)
+    if 'masked' in which:
+        e2e_masked(1, 2)

@@ -142,3 +142,49 @@ def test_graph_replay_matches_eager(gpu):
         assert torch.equal(got, ref)
     with pytest.raises(ValueError):
         run(synth.make_video_u8(2, 3, 1).to(gpu), synth.make_spectrogram(2, 3, 1).to(gpu))
+
+
+def test_token_masks_match_reference_golden(gpu):
+    """Synchformer.forward(vis_mask=, aud_mask=): NaN-trick token masks + key masking in every tower attention, against the REAL
+    reference (tests/golden/e2e_masked_B1S2.npz) and the oracle's token masks bit for bit."""
+    from synchformer_amd import ops, synth
+    from synchformer_amd.engine import SynchformerEngine
+    from oracle import synchformer_cpu as O
+    g = np.load(GOLD / 'e2e_masked_B1S2.npz')
+    B, S, gain = int(g['B']), int(g['S']), float(g['gain'])
+    sd = synth.make_state_dict(1337, gain=gain, n_pos=2 + S * 14)
+    eng = SynchformerEngine(sd, gpu)
+    u8, aud = _inputs(B, S)
+    vm, am = synth.make_masks(B, S, 1337)
+    # token masks: exact
+    n = B * S
+    tk = ops.token_mask_video(vm.reshape(n, 16, 3, 224, 224).to(gpu), eng.v_w0_sign, torch.empty(n * 1569, device=gpu, dtype=torch.uint8)).cpu()
+    w = sd['vfeat_extractor.patch_embed_3d.proj.weight']
+    keep = vm.reshape(n, 16, 3, 224, 224).permute(0, 2, 1, 3, 4)                       # (n, C, T, H, W)
+    pk = keep.reshape(n, 3, 8, 2, 14, 16, 14, 16).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(n, 1568, 1536)
+    ref_tk = torch.cat([torch.ones(n, 1, dtype=torch.bool), O.token_mask_from_content(pk, w[0].reshape(-1))], 1)
+    assert torch.equal(tk.view(n, 1569).bool(), ref_tk)
+    assert 0 < int((~ref_tk).sum()) < ref_tk.numel() // 2
+    vf = eng.extract_vfeats(u8.to(gpu), vm.to(gpu)).cpu()
+    af = eng.extract_afeats(aud.to(gpu), am.to(gpu)).cpu()
+    logits = eng.forward(u8.to(gpu), aud.to(gpu), vm.to(gpu), am.to(gpu)).cpu()
+    ev = _rel_rms(vf.reshape(-1, 768), torch.from_numpy(g['vfeat']).reshape(-1, 768))
+    ea = _rel_rms(af.reshape(-1, 768), torch.from_numpy(g['afeat']).reshape(-1, 768))
+    dl = (logits - torch.from_numpy(g['logits'])).abs().max().item()
+    dn = (logits - torch.from_numpy(g['logits_nomask'])).abs().max().item()
+    print(f'masked: vfeat relrms {ev:.4f} afeat relrms {ea:.4f} logits max {dl:.5f} (distance to the unmasked logits {dn:.3f})')
+    assert ev < 1.5e-2 and ea < 1.5e-2 and dl < 4e-2 and dn > 0.1
+    # an all-ones mask must be a no-op, bit for bit (against the same un-fused CLS schedule the masked path uses)
+    import os
+    ones_v, ones_a = torch.ones_like(vm), torch.ones_like(am)
+    got = eng.forward(u8.to(gpu), aud.to(gpu), ones_v.to(gpu), ones_a.to(gpu))
+    old = os.environ.get('SF_CLS_FUSION')
+    os.environ['SF_CLS_FUSION'] = 'none'
+    try:
+        ref = eng.forward(u8.to(gpu), aud.to(gpu))
+    finally:
+        if old is None:
+            del os.environ['SF_CLS_FUSION']
+        else:
+            os.environ['SF_CLS_FUSION'] = old
+    assert torch.equal(got, ref)

@@ -101,3 +101,23 @@ def test_oracle_avclip_matches_golden_towers():
     assert (out['vfeat'] - rv).abs().max() < 1e-5 and (out['afeat'] - ra).abs().max() < 1e-5
     assert (out['sim_v2a'] - torch.from_numpy(g['restated_sim_v2a'])).abs().max() < 2e-4
     assert abs(float(out['loss']) - float(g['restated_loss'])) < 1e-4
+
+
+def test_oracle_token_masks_match_golden():
+    """vis_mask / aud_mask (NaN-trick token masks, key masking in every attention) against the REAL reference (make_golden.py masked)."""
+    from synchformer_amd import synth
+    from oracle import synchformer_cpu as O
+    g = np.load(GOLD / 'e2e_masked_B1S2.npz')
+    B, S = int(g['B']), int(g['S'])
+    sdm = synth.make_state_dict(1337, gain=float(g['gain']), n_pos=2 + S * 14)
+    vis = O.rgb_frontend(synth.make_video_u8(B, S, 1337))
+    aud = synth.make_spectrogram(B, S, 1337)
+    vm, am = synth.make_masks(B, S, 1337)
+    with torch.no_grad():
+        vf = O.extract_vfeats(vis, sdm, vis_mask=vm)
+        af = O.extract_afeats(aud, sdm, aud_mask=am)
+        _, logits = O.synchformer_forward(sdm, vis, aud, vis_mask=vm, aud_mask=am)
+    assert (vf.reshape(-1, 768) - torch.from_numpy(g['vfeat']).reshape(-1, 768)).abs().max() < 5e-5
+    assert (af.reshape(-1, 768) - torch.from_numpy(g['afeat']).reshape(-1, 768)).abs().max() < 5e-5
+    assert (logits - torch.from_numpy(g['logits'])).abs().max() < 5e-5
+    assert (torch.from_numpy(g['logits']) - torch.from_numpy(g['logits_nomask'])).abs().max() > 0.1     # the masks matter
