@@ -142,12 +142,14 @@ class MotionFormer(torch.nn.Module):
         self.pool_time = _parse_agg_time(agg_time_module)
         if add_global_repr:
             raise NotImplementedError('add_global_repr=True (global segment aggregation) is outside the hot path')
-        if ckpt_path is not None:
-            raise NotImplementedError('pretrained-checkpoint download/loading is out of scope; load a state_dict instead')
+        self.ckpt_path = ckpt_path
         self.extract_features, self.factorize_space_time, self.add_global_repr = True, True, False
         self.embed_dim, self.num_heads, self.temporal_resolution = 768, 12, 8
         schema = synth.state_dict_schema()
         _register_tree(self, schema, 'vfeat_extractor.', _seed)
+        if ckpt_path is not None:                       # ssv2_divided_224_16x4.pyth or a Stage-1 *.pt (motionformer.py:52-80, 109-116, 156-173)
+            from .checkpoint import init_motionformer
+            init_motionformer(self, ckpt_path)
         self.patch_embed.requires_grad_(False)          # motionformer.py:177
         logging.info(f'vfeat_extractor: {sum(p.numel() for p in self.parameters() if p.requires_grad):,}')
 
@@ -179,13 +181,15 @@ class AST(torch.nn.Module):
         self.pool_time = _parse_agg_time(agg_time_module)
         if add_global_repr:
             raise NotImplementedError('add_global_repr=True (global segment aggregation) is outside the hot path')
-        if ckpt_path is not None:
-            raise NotImplementedError('pretrained-checkpoint download/loading is out of scope; load a state_dict instead')
+        self.ckpt_path = ckpt_path
         if max_spec_t != 66:
             raise NotImplementedError('max_spec_t must be 66 (74-token position table, configs/sync.yaml:14)')
         self.extract_features, self.max_spec_t, self.factorize_freq_time, self.add_global_repr = True, 66, True, False
         self.feat_type = 'last_hidden_state'
         _register_tree(self, synth.state_dict_schema(), 'afeat_extractor.', _seed)
+        if ckpt_path is not None:                       # HF AST weights (local) or a Stage-1 *.pt (ast.py:49-53, 113-131, 240-245)
+            from .checkpoint import init_ast
+            init_ast(self, ckpt_path)
 
     def forward(self, x, for_loop: bool = False, cont_mask: torch.Tensor = None, **ast_kwargs):
         """x (B, S, T, F) -> ((B, S, 6, 768), None), or ((B, S, 768), None) with agg_time_module='AveragePooling'

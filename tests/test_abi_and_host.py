@@ -124,7 +124,9 @@ def test_module_mirror_schema_and_api():
     with pytest.raises(NotImplementedError):
         sa.MotionFormer(extract_features=True, factorize_space_time=True, agg_space_module='AveragePooling',
                         agg_time_module='torch.nn.Identity', add_global_repr=False)
-    with pytest.raises(NotImplementedError, match='vis_mask'):
+    with pytest.raises(AssertionError, match='for_loop'):                      # masks + for_loop: refused like the reference (motionformer.py:201)
+        m.extract_vfeats(torch.zeros(1), True, vis_mask=torch.ones(1))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
         m.extract_vfeats(torch.zeros(1), False, vis_mask=torch.ones(1))
     sa.install_reference_aliases()
     try:
@@ -165,3 +167,49 @@ def test_segment_ranges_follow_generate_multiple_segments():
     assert r['v_start'] == (125 - int(7.0 * 16)) // 2 == 6
     with pytest.raises(ValueError):
         segment_ranges(100, 80000)                       # cannot fit 14 half-overlapping 16-frame segments in 100 frames
+
+
+def test_checkpoint_adapters(tmp_path):
+    """The four checkpoint formats the reference's constructors read, built synthetically."""
+    import torch
+    import synchformer_amd as sa
+    from synchformer_amd import checkpoint as ck, synth
+    sd = synth.make_state_dict(3)
+    vsd = {k[len('vfeat_extractor.'):]: v for k, v in sd.items() if k.startswith('vfeat_extractor.')}
+    asd = {k[len('afeat_extractor.'):]: v for k, v in sd.items() if k.startswith('afeat_extractor.')}
+    tower = dict(extract_features=True, agg_time_module='torch.nn.Identity', add_global_repr=False)
+    # (1) released / Stage-2 checkpoint: ckpt['model'] (possibly saved from a DDP wrapper)
+    torch.save({'model': {'module.' + k: v for k, v in sd.items()}, 'epoch': 3}, tmp_path / 'sync.pt')
+    m = sa.instantiate_from_config(sa.sync_yaml_model_config())
+    m.load_state_dict(ck.synchformer_state(ck.load_file(tmp_path / 'sync.pt')))
+    assert torch.equal(m.transformer.off_head.weight, sd['transformer.off_head.weight'])
+    # (2) Stage-1 AVCLIP checkpoint -> both towers; the time aggregator of another config is "unexpected", as in the reference
+    s1 = {'module.v_encoder.' + k: v for k, v in vsd.items()}
+    s1.update({'module.a_encoder.' + k: v for k, v in asd.items()})
+    s1['module.v_encoder.temp_attn_agg.cls_token'] = torch.zeros(1, 1, 768)
+    s1['module.logit_scale'] = torch.tensor(0.05)
+    torch.save({'state_dict': s1, 'epoch': 1}, tmp_path / 'epoch_best.pt')
+    v = sa.MotionFormer(ckpt_path=str(tmp_path / 'epoch_best.pt'), factorize_space_time=True, agg_space_module='TransformerEncoderLayer', **tower)
+    a = sa.AST(ckpt_path=str(tmp_path / 'epoch_best.pt'), max_spec_t=66, factorize_freq_time=True, agg_freq_module='TransformerEncoderLayer', **tower)
+    assert torch.equal(getattr(v.blocks, '7').attn.qkv.weight, vsd['blocks.7.attn.qkv.weight'])
+    assert torch.equal(a.freq_attn_agg.linear1.weight, asd['freq_attn_agg.linear1.weight'])
+    # (3) the original Motionformer .pyth: model_state with a classification head the extractor does not have
+    pyth = {k: v for k, v in vsd.items() if not k.startswith('spatial_attn_agg.')}
+    pyth['head.weight'], pyth['head.bias'] = torch.zeros(174, 768), torch.zeros(174)
+    torch.save({'model_state': pyth, 'cfg': 'x'}, tmp_path / ck.MFORMER_DIVIDED)
+    v2 = sa.MotionFormer(ckpt_path=str(tmp_path / ck.MFORMER_DIVIDED), factorize_space_time=True, agg_space_module='TransformerEncoderLayer', **tower)
+    assert torch.equal(v2.pos_embed, vsd['pos_embed']) and not v2.patch_embed.proj.weight.requires_grad
+    with pytest.raises(NotImplementedError):
+        torch.save({'model_state': pyth}, tmp_path / 'ssv2_joint_224_16x4.pyth')
+        sa.MotionFormer(ckpt_path=str(tmp_path / 'ssv2_joint_224_16x4.pyth'), factorize_space_time=True, agg_space_module='TransformerEncoderLayer', **tower)
+    # (4) HF AST: audio_spectrogram_transformer.* keys, 1214 position rows -> first 74, classifier ignored
+    hf = {'audio_spectrogram_transformer.' + k[len('ast.'):]: v for k, v in asd.items() if k.startswith('ast.')}
+    long_pos = torch.randn(1, 1214, 768)
+    hf['audio_spectrogram_transformer.embeddings.position_embeddings'] = long_pos
+    hf['classifier.dense.weight'] = torch.zeros(527, 768)
+    (tmp_path / 'hf_ast').mkdir()
+    torch.save(hf, tmp_path / 'hf_ast' / 'pytorch_model.bin')
+    a2 = sa.AST(ckpt_path=str(tmp_path / 'hf_ast'), max_spec_t=66, factorize_freq_time=True, agg_freq_module='TransformerEncoderLayer', **tower)
+    assert torch.equal(a2.ast.embeddings.position_embeddings, long_pos[:, :74])
+    with pytest.raises(FileNotFoundError):
+        sa.AST(ckpt_path=ck.HF_AST_NAME, max_spec_t=66, factorize_freq_time=True, agg_freq_module='TransformerEncoderLayer', **tower)
