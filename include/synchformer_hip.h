@@ -216,6 +216,11 @@ int sf_attention_cls_masked(const uint16_t* q, int64_t q_seq_rows, int q_row, co
                             int64_t kv_seq_rows, int kv_row0, int n_keys, uint16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row,
                             int64_t n_seq, int heads, int head_dim, float scale, const uint8_t* key_keep, void* stream);
 
+/* Stage-1 zero-shot sync check (shift_and_get_preds, train_clip_src/training/train.py:549-579): G = audio-to-video segment similarity
+ * (n_clips*S x n_clips*S, fp32, clip-major); per clip, window sims are W-long diagonal sums of its S x S block;
+ * preds_a[b, j] = argmax_i, preds_v[b, i] = argmax_j over the S - W + 1 (<= 32) shifts. */
+int sf_shift_window_preds(const float* G, int64_t ldg, int n_clips, int S, int W, int64_t* preds_a, int64_t* preds_v, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

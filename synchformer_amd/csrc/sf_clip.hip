@@ -96,3 +96,43 @@ extern "C" int sf_similarity_f32(const float* a, int64_t lda, const float* b, in
   SF_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Stage-1 zero-shot synchronisation check (shift_and_get_preds, train_clip_src/training/train.py:549-579): for every clip the
+// similarity of window i of A with window j of V, sim[i, j] = sum_{w < W} <a[i+w], v[j+w]>, is a W-long diagonal sum of the
+// clip's S x S block of the audio-to-video segment similarity matrix G (rows = audio segments, cols = video segments).
+//   preds_a[b, j] = argmax_i sim[i, j]   (torch.argmax(sim, dim=-2)),   preds_v[b, i] = argmax_j sim[i, j]   (dim=-1)
+// One workgroup per clip; n = S - W + 1 <= 32 shifts.  First maximum wins, like torch.argmax.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shift_window_preds_kernel(const float* __restrict__ G, int64_t ldg, int S, int W, int64_t* __restrict__ preds_a,
+                                                                  int64_t* __restrict__ preds_v) {
+  __shared__ float sim[32][33];
+  const int b = blockIdx.x, n = S - W + 1;
+  const float* g = G + ((int64_t)b * S) * ldg + (int64_t)b * S;           // this clip's diagonal block
+  for (int e = threadIdx.x; e < n * n; e += 256) {
+    const int i = e / n, j = e - i * n;
+    float acc = 0.f;
+    for (int w = 0; w < W; ++w) acc += g[(int64_t)(i + w) * ldg + (j + w)];
+    sim[i][j] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < n) {                                                  // column argmax -> preds_a
+    const int j = threadIdx.x;
+    int best = 0;
+    for (int i = 1; i < n; ++i) if (sim[i][j] > sim[best][j]) best = i;
+    preds_a[(int64_t)b * n + j] = best;
+  } else if (threadIdx.x >= 64 && threadIdx.x < 64 + n) {                 // row argmax -> preds_v
+    const int i = threadIdx.x - 64;
+    int best = 0;
+    for (int j = 1; j < n; ++j) if (sim[i][j] > sim[i][best]) best = j;
+    preds_v[(int64_t)b * n + i] = best;
+  }
+}
+
+extern "C" int sf_shift_window_preds(const float* G, int64_t ldg, int n_clips, int S, int W, int64_t* preds_a, int64_t* preds_v, void* stream) {
+  SF_CHECK_ARG(G && preds_a && preds_v && n_clips >= 1 && W >= 1 && W <= S && S - W + 1 <= 32 && ldg >= (int64_t)n_clips * S,
+               "sf_shift_window_preds: bad arguments (1 <= W <= S, S - W + 1 <= 32)");
+  hipLaunchKernelGGL(shift_window_preds_kernel, dim3((unsigned)n_clips), dim3(256), 0, (hipStream_t)stream, G, ldg, S, W, preds_a, preds_v);
+  SF_LAUNCH_CHECK();
+  return 0;
+}

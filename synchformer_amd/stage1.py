@@ -472,6 +472,38 @@ class AVCLIPTrainer(FlatTrainer):
         return {k.replace(V + '.', 'v_encoder.').replace(A + '.', 'a_encoder.'): t.detach().clone() for k, t in self.p.items()}
 
 
+def shift_and_get_preds(a: torch.Tensor, v: torch.Tensor, W: int):
+    """a, v (B, S, D) fp32 segment embeddings on the device -> (preds_a, preds_v) int64 (B, S - W + 1): for every W-segment window
+    of A the index of the most similar window of V and vice versa (train_clip_src/training/train.py:549-579).  The window
+    similarity is a diagonal sum of the per-clip segment similarity, so one fp32 similarity launch + one tiny kernel do it."""
+    assert a.shape == v.shape, f'{a.shape} != {v.shape}'
+    B, S, Dm = a.shape
+    n = S - W + 1
+    G = torch.empty(B * S, B * S, device=a.device, dtype=torch.float32)
+    ops.similarity(a.reshape(B * S, Dm).contiguous().float(), v.reshape(B * S, Dm).contiguous().float(), G, 1.0)
+    pa = torch.empty(B, n, device=a.device, dtype=torch.int64)
+    pv = torch.empty(B, n, device=a.device, dtype=torch.int64)
+    _chk(_lib.load().sf_shift_window_preds(G.data_ptr(), G.stride(0), B, S, W, pa.data_ptr(), pv.data_ptr(), _st()), 'sf_shift_window_preds')
+    return pa, pv
+
+
+@torch.no_grad()
+def eval_one_example(model, rgb: torch.Tensor, audio: torch.Tensor, win: int = 8):
+    """eval_one_example (train_clip_src/training/train.py:405-444) on the drop-in AVCLIP: contrastive loss from
+    `forward_for_logging` + the shifted-window zero-shot precision (configs/segment_avclip.yaml: run_shifted_win_val_winsize 8).
+    rgb (B, S, C, Tv, H, W), audio (B, S, Ta, F) -> (losses, metrics) dicts of device scalars."""
+    assert not model.training, 'Model should be in eval mode.'
+    B, S = rgb.shape[:2]
+    out = model.forward_for_logging(rgb, audio, for_momentum=False, for_loop=False, do_norm=True)
+    assert win < S, f'Win size ({win}) should be < than the number of segments.'
+    pa, pv = shift_and_get_preds(out['segment_afeat'].view(B, S, -1), out['segment_vfeat'].view(B, S, -1), win)
+    n = pa.shape[-1]
+    gt = torch.arange(n, device=pa.device).view(1, n)                       # get_gt (:581-592)
+    prec_a, prec_v = (pa == gt).sum(-1) / n, (pv == gt).sum(-1) / n         # calc_cls_metrics (:594-613)
+    metrics = {'precision_a': prec_a.mean(), 'precision_v': prec_v.mean(), 'precision': ((prec_a + prec_v) / 2).mean()}
+    return {'segment_contrastive_loss': out['segment_contrastive_loss']}, metrics
+
+
 class AVCLIPTrainFunction(torch.autograd.Function):
     """autograd bridge for the drop-in `AVCLIP` module: the forward runs the whole HIP step (forward + backward, the loss is a
     scalar so its parameter gradients are known up to the incoming scale), the backward hands `grad_output * dloss/dparam` to

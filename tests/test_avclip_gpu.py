@@ -89,3 +89,30 @@ def test_avclip_forward_matches_reference_towers(gpu):
     with torch.no_grad():
         m.logit_scale.fill_(5.0)
     assert float(m.clamp_logit_scales()[0].detach()) == 0.5
+
+
+@pytest.mark.parametrize('B,S,W', [(1, 14, 8), (3, 14, 8), (2, 9, 1), (2, 6, 5)])
+def test_shift_and_get_preds(gpu, B, S, W):
+    """Zero-shot shifted-window predictions against the reference's unfold + matmul + argmax formulation (training/train.py:549-579)."""
+    from synchformer_amd.stage1 import shift_and_get_preds
+    torch.manual_seed(B * 100 + S)
+    a = torch.nn.functional.normalize(torch.randn(B, S, 768), dim=-1)
+    v = torch.nn.functional.normalize(a + 0.8 * torch.randn(B, S, 768), dim=-1)
+    pa, pv = shift_and_get_preds(a.to(gpu), v.to(gpu), W)
+    af = a.unfold(-2, W, 1).contiguous().view(B, S - W + 1, -1)
+    vf = v.unfold(-2, W, 1).contiguous().view(B, S - W + 1, -1)
+    sim = af.double() @ vf.double().mT
+    assert torch.equal(pa.cpu(), torch.argmax(sim, dim=-2)) and torch.equal(pv.cpu(), torch.argmax(sim, dim=-1))
+
+
+def test_eval_one_example(gpu):
+    from synchformer_amd import synth
+    from synchformer_amd.stage1 import eval_one_example
+    from oracle import synchformer_cpu as O
+    m = _model(gpu, 2.0)
+    B, S = 1, 10
+    vis = O.rgb_frontend(synth.make_video_u8(B, S, 1337)).permute(0, 1, 3, 2, 4, 5).to(gpu)
+    aud = synth.make_spectrogram(B, S, 1337).squeeze(2).permute(0, 1, 3, 2).contiguous().to(gpu)
+    losses, metrics = eval_one_example(m, vis, aud, win=8)
+    assert torch.isfinite(losses['segment_contrastive_loss']) and 0.0 <= float(metrics['precision']) <= 1.0
+    assert abs(float(metrics['precision']) - (float(metrics['precision_a']) + float(metrics['precision_v'])) / 2) < 1e-6
