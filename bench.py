@@ -67,7 +67,10 @@ class GemmTimer:
             r = self.orig(a, w, bias, out, M=M, **kw)
             e1.record()
             m = a.shape[0] if M is None else M
-            self.records.append((e0, e1, 2.0 * m * w.shape[0] * w.shape[1]))
+            n, k = w.shape
+            res = kw.get('residual')
+            nbytes = m * k * 2 + n * k * 2 + m * n * out.element_size() + (m * n * 4 if res is not None else 0)   # A + W + C (+ R), each once
+            self.records.append((e0, e1, 2.0 * m * n * k, nbytes))
             return r
         self.ops.gemm = timed
         return self
@@ -76,9 +79,21 @@ class GemmTimer:
         self.ops.gemm = self.orig
 
     def summary(self):
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
-        fl = sum(f for _, _, f in self.records)
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        fl = sum(r[2] for r in self.records)
+        self.bytes = sum(r[3] for r in self.records)
         return len(self.records), ms, fl
+
+
+def pmc_traffic():
+    """HBM bytes per sf_gemm_bf16 launch from the committed PMC passes of this same command (tools/profile_bench.sh ->
+    profiles/r01_bench_roofline.json; counters cannot be read from inside the benchmark process).  None if absent."""
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_bench_roofline.json')
+    try:
+        with open(f) as fh:
+            return round(json.load(fh)['traffic_bytes_per_launch'])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(seconds_budget=25.0, max_threads=16):
@@ -206,7 +221,8 @@ def main():
             ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
             out['roofline'] = {'bound': 'mfma', 'kernel': 'sf_gemm_bf16 (gemm_bf16_persistent_kernel + gemm_bf16_kernel)', 'achieved': round(ach, 1),
                                'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': round(ach / (PEAK_BF16 / 1e12), 4),
-                               'traffic': None, 'launches': n_gemm // args.steps,
+                               'traffic': pmc_traffic(), 'algorithmic_bytes_per_launch': round(gt.bytes / n_gemm),
+                               'launches': n_gemm // args.steps,
                                'avg_launch_ms': round(gemm_ms / n_gemm, 4),
                                'flop_per_launch': gemm_flop / n_gemm,
                                'share_of_step_time': round(gemm_ms * 1e-3 / dt, 3)}

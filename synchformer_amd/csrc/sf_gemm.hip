@@ -726,7 +726,9 @@ extern "C" int sf_gemm_bf16_batched(const bf16_t* A, int64_t lda, int64_t sA0, i
   a.M = M; a.N = (int)N; a.K = (int)K; a.tiles_n = 0; a.tiles_total = 0;
   a.batch_inner = batch_inner; a.sA0 = sA0; a.sA1 = sA1; a.sW0 = sW0; a.sW1 = sW1; a.sC0 = sC0; a.sC1 = sC1;
   g_batch_count = (int64_t)batch_outer * batch_inner;
-  const int rc = dispatch_gemm<Cfg4>(a, c_dtype == SF_BF16, false, false, /*fast=*/false, (hipStream_t)stream);
+  // 64-deep stages when the contraction allows it (the split-K weight-gradient products of the train steps: K = chunks of 64 rows)
+  const int rc = (K % 64 == 0 && K >= 512) ? dispatch_gemm<Cfg0>(a, c_dtype == SF_BF16, false, false, /*fast=*/false, (hipStream_t)stream)
+                                           : dispatch_gemm<Cfg4>(a, c_dtype == SF_BF16, false, false, /*fast=*/false, (hipStream_t)stream);
   g_batch_count = 1;
   return rc;
 }
