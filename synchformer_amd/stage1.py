@@ -264,7 +264,7 @@ class AVCLIPTrainer(FlatTrainer):
         out, sv['agg'] = self._agg_fwd(Z, n * 8, AGG_V, V + '.spatial_attn_agg', 'vagg')
         return out
 
-    def _bwd_visual(self, dout):
+    def _bwd_visual(self, dout, on_ready=None):
         sv = self.sv_v
         n = sv['n']
         M = n * VIS_L
@@ -275,6 +275,8 @@ class AVCLIPTrainer(FlatTrainer):
         self.g[agg + '.cls_token'].view(D).copy_(gz[0])
         dx = self._buf('v_dx', (M, D), torch.float32, zero=True)               # CLS rows are dropped before the final norm: grad 0
         self._ln_bwd(sv['x_last'], V + '.norm', dZ, dx, n * VIS_P, EPS_VIS, x_map=sv['in_map'], dy_map=sv['z_map'], dx_map=sv['in_map'])
+        if on_ready:
+            on_ready(self._key_range(V + '.norm.', V + '.spatial_attn_agg.'))
         for i in reversed(range(self.n_vblocks)):
             p, s = f'{V}.blocks.{i}', sv['blocks'][i]
             self._mlp_bwd(s, dx, s['xs'], p + '.mlp.fc1', p + '.mlp.fc2', M, p + '.norm2', EPS_VIS)
@@ -282,6 +284,8 @@ class AVCLIPTrainer(FlatTrainer):
                                   s['xt'], p + '.norm1', EPS_VIS, p + '.attn.qkv')
             self._attn_branch_bwd(dx, M, p + '.timeattn.proj', s['attt'], lambda dO, q=s['qkvt']: self._divided_bwd(q, dO, n, 'time'), s['ht'],
                                   s['x'], p + '.norm3', EPS_VIS, p + '.timeattn.qkv')
+            if on_ready and i % 3 == 0:                                        # blocks i .. i+2 are final: one ~92 MB bucket
+                on_ready(self._key_range(*[f'{V}.blocks.{j}.' for j in range(i, min(i + 3, self.n_vblocks))]))
         # token table: row 0 = cls_token + pos[0]; row 1 + f*196 + p = pos[1 + p] + temp[f]  (video_model_builder.py:248-254)
         gtab = self._buf('gtab', (VIS_L, D), torch.float32)
         self._seqsum(dx, n, VIS_L, gtab)
@@ -295,6 +299,8 @@ class AVCLIPTrainer(FlatTrainer):
         dtok = self._buf('v_dtok', (n * VIS_P, D), torch.bfloat16)
         ops.gather_rows(dx, dtok, n * VIS_P, in_map=sv['in_map'])
         self._lin_bwd(V + '.patch_embed_3d.proj', dtok, sv['patches'], n * VIS_P, need_dx=False)
+        if on_ready:
+            on_ready(self._key_range(V + '.cls_token', V + '.pos_embed', V + '.temp_embed', V + '.patch_embed_3d.'))
 
     # ---- audio tower --------------------------------------------------------------------------------------------------------
     def _aud_table(self, L):
@@ -445,7 +451,7 @@ class AVCLIPTrainer(FlatTrainer):
         self.p['logit_scale'].clamp_(*self.clamp_scale)                        # open_clip/model.py:569-572
 
     @torch.no_grad()
-    def forward_backward(self, vis: torch.Tensor, aud: torch.Tensor) -> torch.Tensor:
+    def forward_backward(self, vis: torch.Tensor, aud: torch.Tensor, on_ready=None) -> torch.Tensor:
         """vis (B, S, Tv=16, C=3, H, W) (Synchformer layout) u8|float, aud (B, S, 1, F, Ta) fp32 -> loss (device scalar); fills flat_g."""
         B, S = vis.shape[:2]
         n = B * S
@@ -455,15 +461,42 @@ class AVCLIPTrainer(FlatTrainer):
         aout = self._fwd_audio(aud.reshape(n, aud.shape[-2], aud.shape[-1]))
         self.vfeat, self.afeat = self._pool(vout, 8, n, 'v'), self._pool(aout, self.sv_a['nt'], n, 'a')
         dv, da = self._head(self.vfeat, self.afeat)
-        self._bwd_visual(self._pool_bwd(vout, 8, dv, n, 'v'))
-        self._bwd_audio(self._pool_bwd(aout, self.sv_a['nt'], da, n, 'a'))
+        self._bwd_audio(self._pool_bwd(aout, self.sv_a['nt'], da, n, 'a'))      # the short tower first: its bucket travels under the long one
+        if on_ready:
+            on_ready(self._key_range(A + '.', 'logit_scale'))
+        self._bwd_visual(self._pool_bwd(vout, 8, dv, n, 'v'), on_ready)
         self.loss = self.losses.mean()
         return self.loss
 
+    def _key_range(self, *prefixes):
+        """[lo, hi) of the flat buffers covered by the keys starting with any of `prefixes` (they are contiguous by construction)."""
+        if not hasattr(self, '_offsets'):
+            self._offsets, o = {}, 0
+            for k in self.keys:
+                self._offsets[k] = (o, o + self.p[k].numel())
+                o += self.p[k].numel()
+        spans = [self._offsets[k] for k in self.keys if k.startswith(tuple(prefixes))]
+        lo, hi = min(a for a, _ in spans), max(b for _, b in spans)
+        assert sum(b - a for a, b in spans) == hi - lo, f'{prefixes}: not contiguous'
+        return lo, hi
+
     def train_step(self, vis: torch.Tensor, aud: torch.Tensor, lr: Optional[float] = None) -> torch.Tensor:
-        """One Stage-1 iteration (train_clip_src/training/train.py:103-154): forward, backward, DDP-mean all-reduce, clip + AdamW."""
-        loss = self.forward_backward(vis, aud)
-        self.allreduce_grads()
+        """One Stage-1 iteration (train_clip_src/training/train.py:103-154): forward, backward, DDP-mean all-reduce, clip + AdamW.
+        With a process group the 859 MB of gradients leave in 7 buckets while the backward is still running: the audio
+        tower + logit_scale right after its (short) backward, then norm/aggregator, four 3-block groups in reverse order and the token
+        tables of the visual tower as they become final; RCCL runs them on its own stream behind an event on the compute stream."""
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        handles = []
+
+        def reduce_range(span):
+            if world > 1:
+                handles.append(dist.all_reduce(self.flat_g[span[0]:span[1]], async_op=True))
+        loss = self.forward_backward(vis, aud, on_ready=reduce_range)
+        for h in handles:
+            h.wait()
+        if world > 1:
+            self.flat_g.div_(world)                                            # DDP semantics: mean over ranks
         self.optimizer_step(lr)
         return loss
 

@@ -309,3 +309,49 @@ def test_gathered_contrastive_head_two_ranks(gpu):
         assert (dv - vr.grad[r * n:(r + 1) * n]).abs().max() < 1e-5 * max(1.0, vr.grad.abs().max().item())
         assert (da - ar.grad[r * n:(r + 1) * n]).abs().max() < 1e-5 * max(1.0, ar.grad.abs().max().item())
         assert abs(dscale - float(scales[r].grad)) < 1e-4 * abs(float(scales[r].grad))
+
+
+def _bucketed_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from synchformer_amd import synth
+        from synchformer_amd.stage1 import AVCLIPTrainer
+        sd = {k: v for k, v in synth.make_state_dict(1337, gain=2.0).items() if k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}
+        tr = AVCLIPTrainer(sd, 'cuda:0')
+        vis = synth.make_video_u8(1, 2, 100 + rank).cuda()
+        aud = synth.make_spectrogram(1, 2, 100 + rank).cuda()
+        tr.forward_backward(vis, aud)                                        # local gradients, no communication
+        g_mean = tr.flat_g.clone()
+        dist.all_reduce(g_mean)
+        g_mean /= world
+        p_before = tr.flat_p.clone()
+        tr.train_step(vis, aud, lr=0.0)                                      # bucketed async all-reduce under the backward; lr 0 keeps p
+        same_g = bool(torch.equal(tr.flat_g, g_mean))
+        same_p = bool(torch.equal(tr.flat_p, p_before))
+        q.put((rank, same_g, same_p, float(tr.flat_g.norm())))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_two_ranks(gpu):
+    """train_step's 7 gradient buckets (launched while the backward runs) must equal one mean all-reduce of the whole flat buffer."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucketed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(r[1] and r[2] for r in res), res
+    assert res[0][3] == res[1][3] and res[0][3] > 0                          # identical averaged gradients on both ranks
