@@ -373,28 +373,37 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
     // ---- softmax (base 2, scale folded with log2 e) over keys for query column (lane & 15) ---------------------
     const float sc2 = p.scale * 1.44269504088896f;
     const bool cls_slot = do_cls && (qt * 16 + fr == nq);            // this lane's query column is the CLS query
-    uint32_t kflags[NKT];                                            // keep flags of keys kt*16 + fg*4 + 0..3 (one dword)
+    // Masking touches only what can be invalid: the last key tile (keys >= nk), key 0 for the CLS-query slot outside group 0, and -
+    // on the masked entry points only - the token keep flags.  The scale is folded into the exponent: exp2(s*sc2 - m*sc2), so the
+    // row maximum is taken on the raw scores (sc2 > 0) and each score costs max + fma + v_exp + add.
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) kflags[kt] = p.key_keep ? *reinterpret_cast<const uint32_t*>(m_lds + kt * 16 + fg * 4) : 0x01010101u;
+    for (int r = 0; r < 4; ++r)
+      if ((NKT - 1) * 16 + fg * 4 + r >= nk) s[NKT - 1][r] = -INFINITY;
+    if (cls_slot && g != 0 && fg == 0) s[0][0] = -INFINITY;
+    if (p.key_keep) {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        const uint32_t fl = *reinterpret_cast<const uint32_t*>(m_lds + kt * 16 + fg * 4);   // keep flags of keys kt*16 + fg*4 + 0..3
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (((fl >> (8 * r)) & 0xffu) == 0) s[kt][r] = -INFINITY;
+      }
+    }
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
-      {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + fg * 4 + r;
-          const bool kept = !p.key_keep || ((kflags[kt] >> (8 * r)) & 0xffu);
-          const float v = (key < nk && kept && !(cls_slot && key == 0 && g != 0)) ? s[kt][r] * sc2 : -INFINITY;
-          s[kt][r] = v;
-          m = fmaxf(m, v);
-        }
-      }
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
     m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float msc = m * sc2;
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const float e = (SF_ATT_ABL & 4) ? s[kt][r] : exp2f(s[kt][r] - m); s[kt][r] = e; l += e; }
+      for (int r = 0; r < 4; ++r) {
+        const float e = (SF_ATT_ABL & 4) ? s[kt][r] : __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc2, -msc));   // -inf -> 0
+        s[kt][r] = e; l += e;
+      }
     }
     l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
     const float linv = 1.0f / l;
@@ -432,7 +441,7 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
     const int qo = qt * 16 + fr;
     if (cls_slot) {                                              // unnormalised partial of the CLS query over this group's keys
       float* part = p.cls_part + ((seq * p.heads + head) * p.n_groups + g) * (D + 2);
-      if (fg == 0) { part[0] = m; part[1] = l; }
+      if (fg == 0) { part[0] = msc; part[1] = l; }
 #pragma unroll
       for (int dt = 0; dt < D / 16; ++dt)
 #pragma unroll
