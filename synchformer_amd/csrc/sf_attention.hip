@@ -75,14 +75,21 @@ __global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t to
   const int nk = p.n_tok + has_cls;
   // all 2 x 9 key/value loads are issued before the first use (one memory round trip per wave)
   uint4 kraw[9], vraw[9];
-  uint32_t keep_bits = 0x1ffu;
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
     const int jj = j < nk ? j : nk - 1;
     const int64_t row = (has_cls && jj == 0) ? seq_base + p.cls_row : first + (int64_t)(jj - has_cls) * p.tok_stride;
     kraw[j] = *reinterpret_cast<const uint4*>(p.k + row * p.ld + col);
     vraw[j] = *reinterpret_cast<const uint4*>(p.v + row * p.ld + col);
-    if (p.key_keep && p.key_keep[row] == 0) keep_bits &= ~(1u << j);
+  }
+  uint32_t keep_bits = 0x1ffu;                                   // token keep flags of the 9 key slots (masked entry point only)
+  if (p.key_keep) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int jj = j < nk ? j : nk - 1;
+      const int64_t row = (has_cls && jj == 0) ? seq_base + p.cls_row : first + (int64_t)(jj - has_cls) * p.tok_stride;
+      if (p.key_keep[row] == 0) keep_bits &= ~(1u << j);
+    }
   }
   const float sc = p.scale * 1.44269504088896f;                 // softmax in base 2: exp(x) = exp2(x * log2 e)
   float s[9];
@@ -91,8 +98,16 @@ __global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t to
   for (int j = 0; j < 9; ++j) {
     float d = dot8_bf16(qraw, kraw[j]);
     d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-    s[j] = (j < nk && ((keep_bits >> j) & 1u)) ? d * sc : -INFINITY;
+    s[j] = j < nk ? d * sc : -INFINITY;
     m = fmaxf(m, s[j]);
+  }
+  if (keep_bits != 0x1ffu) {                                     // wave-uniform: only groups that actually contain a masked key
+    m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      if (!((keep_bits >> j) & 1u)) s[j] = -INFINITY;
+      m = fmaxf(m, s[j]);
+    }
   }
   float l = 0.f;
   sf_f32x2_t o[4];
