@@ -65,6 +65,15 @@ def colsum(x, rows, cols, out, ws, accumulate=False):
                                ws.data_ptr(), _st()), 'sf_colsum')
 
 
+def constant_with_warmup_lr(step: int, base_lr: float, warmup: int = 1000) -> float:
+    """Stage-2 schedule `constant_with_warmup` (scripts/train_utils.py:236-246; configs/sync.yaml lr_scheduler): torch's
+    SequentialLR([LinearLR(start_factor 1/100, total_iters warmup), ConstantLR(factor 1)], milestones [warmup]) as a function of the
+    number of optimizer steps already taken: factor 0.01 + 0.99 * step / warmup, then 1."""
+    if step >= warmup:
+        return base_lr
+    return base_lr * (0.01 + 0.99 * step / warmup)
+
+
 # trainable keys, in the reference's state-dict order (vproj, aproj, transformer.*)
 def trainable_keys(schema) -> List[str]:
     return [k for k in schema if k.startswith(('vproj.', 'aproj.', 'transformer.'))]

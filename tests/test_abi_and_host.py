@@ -213,3 +213,25 @@ def test_checkpoint_adapters(tmp_path):
     assert torch.equal(a2.ast.embeddings.position_embeddings, long_pos[:, :74])
     with pytest.raises(FileNotFoundError):
         sa.AST(ckpt_path=ck.HF_AST_NAME, max_spec_t=66, factorize_freq_time=True, agg_freq_module='TransformerEncoderLayer', **tower)
+
+
+def test_lr_schedules_match_torch_and_open_clip():
+    """Stage-2 `constant_with_warmup` against torch's own SequentialLR (train_utils.py:236-246); Stage-1 cosine against the formulas of
+    train_clip_src/training/scheduler.py:9-10, 43-53."""
+    import math
+    import torch
+    from torch.optim import lr_scheduler
+    from synchformer_amd.stage1 import cosine_lr, normalise_keys
+    from synchformer_amd.train import constant_with_warmup_lr
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=2e-6)
+    sched = lr_scheduler.SequentialLR(opt, schedulers=[lr_scheduler.LinearLR(opt, start_factor=1 / 100, total_iters=50),
+                                                       lr_scheduler.ConstantLR(opt, factor=1)], milestones=[50])
+    for step in range(80):
+        assert abs(opt.param_groups[0]['lr'] - constant_with_warmup_lr(step, 2e-6, 50)) < 1e-15, step
+        opt.step()
+        sched.step()
+    assert cosine_lr(0, 1e-4, 1000, 10000) == 1e-4 / 1000 and cosine_lr(999, 1e-4, 1000, 10000) == 1e-4
+    assert abs(cosine_lr(5500, 1e-4, 1000, 10000) - 0.5e-4) < 1e-12 and abs(cosine_lr(10000, 1e-4, 1000, 10000)) < 1e-12
+    assert abs(cosine_lr(3250, 1e-4, 1000, 10000) - 0.5 * (1 + math.cos(math.pi * 0.25)) * 1e-4) < 1e-12
+    got = set(normalise_keys({'v_encoder.norm.weight': 1, 'a_encoder.ast.x': 2, 'logit_scale': 3}))
+    assert got == {'vfeat_extractor.norm.weight', 'afeat_extractor.ast.x', 'logit_scale'}
