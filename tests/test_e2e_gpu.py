@@ -188,3 +188,25 @@ def test_token_masks_match_reference_golden(gpu):
         else:
             os.environ['SF_CLS_FUSION'] = old
     assert torch.equal(got, ref)
+
+
+def test_dropin_module_forward_with_masks(gpu):
+    """Synchformer.forward(vis, aud, targets, vis_mask=, aud_mask=) on the drop-in module == the engine path, loss included."""
+    import synchformer_amd as sa
+    from synchformer_amd import synth
+    B, S = 1, 2
+    m = sa.instantiate_from_config(sa.sync_yaml_model_config(n_pos=2 + S * 14))
+    sd = synth.make_state_dict(1337, gain=2.0, n_pos=2 + S * 14)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(gpu).eval()
+    u8, aud = _inputs(B, S)
+    vm, am = synth.make_masks(B, S, 1337)
+    tgt = synth.make_targets(B, 21, 1337).to(gpu)
+    with torch.no_grad():
+        loss, logits = m(u8.to(gpu), aud.to(gpu), tgt, vis_mask=vm.to(gpu), aud_mask=am.to(gpu))
+        _, plain = m(u8.to(gpu), aud.to(gpu))
+    ref = m._engine().forward(u8.to(gpu), aud.to(gpu), vm.to(gpu), am.to(gpu))
+    assert torch.equal(logits, ref) and (logits - plain).abs().max() > 0.05
+    assert abs(float(loss) - float(torch.nn.functional.cross_entropy(ref, tgt))) < 1e-6
+    with pytest.raises(AssertionError, match='for_loop'):
+        m(u8.to(gpu), aud.to(gpu), for_loop=True, vis_mask=vm.to(gpu))
