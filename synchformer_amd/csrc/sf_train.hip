@@ -200,17 +200,30 @@ __global__ __launch_bounds__(256) void layernorm768_bwd_kernel(const float* __re
 }
 
 // out[c] (=|+=) sum_p part[p * stride + c], c < cols  (second stage of the two-stage column reductions)
-__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part, int64_t n_part, int64_t stride, float* __restrict__ out,
-                                                               int cols, int accumulate) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;       // 64 columns x 4 interleaved row lanes per block
-  float s = 0.f;
-  if (c < cols)
-    for (int64_t p = g; p < n_part; p += 4) s += part[p * stride + c];
-  red[g][threadIdx.x & 63] = s;
+__global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __restrict__ part, int64_t n_part, int64_t stride, float* __restrict__ out,
+                                                                int cols, int accumulate) {
+  // 64 columns x 16 interleaved row lanes per workgroup, four independent partial sums per thread: enough loads in flight that the
+  // second stage of the column reductions is not a chain of dependent L2 round trips (it was 9 % of the Stage-1 train step)
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    int64_t p = g;
+    for (; p + 48 < n_part; p += 64) {
+      s0 += part[p * stride + c];
+      s1 += part[(p + 16) * stride + c];
+      s2 += part[(p + 32) * stride + c];
+      s3 += part[(p + 48) * stride + c];
+    }
+    for (; p < n_part; p += 16) s0 += part[p * stride + c];
+  }
+  red[g][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (g == 0 && c < cols) {
-    s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i][cl];
     out[c] = accumulate ? out[c] + s : s;
   }
 }
@@ -226,8 +239,8 @@ extern "C" int sf_layernorm768_bwd(const float* x, int64_t ldx, const int64_t* x
   hipLaunchKernelGGL(layernorm768_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, ldx, sf_rowmap(x_map), gamma, dy, lddy, sf_rowmap(dy_map), dx,
                      lddx, sf_rowmap(dx_map), accumulate_dx, workspace, rows, eps, rpw);
   SF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3(12), dim3(256), 0, s, workspace, nblk, (int64_t)2 * 768, dgamma, 768, accumulate_dparams);
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3(12), dim3(256), 0, s, workspace + 768, nblk, (int64_t)2 * 768, dbeta, 768, accumulate_dparams);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(12), dim3(1024), 0, s, workspace, nblk, (int64_t)2 * 768, dgamma, 768, accumulate_dparams);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(12), dim3(1024), 0, s, workspace + 768, nblk, (int64_t)2 * 768, dbeta, 768, accumulate_dparams);
   SF_LAUNCH_CHECK();
   return 0;
 }
@@ -259,7 +272,7 @@ extern "C" int sf_colsum(const void* x, int x_dtype, int64_t ldx, int64_t rows, 
   if (x_dtype == SF_BF16) hipLaunchKernelGGL((colsum_stage1_kernel<true>), grid, dim3(256), 0, s, x, ldx, rows, cols, rpb, workspace);
   else hipLaunchKernelGGL((colsum_stage1_kernel<false>), grid, dim3(256), 0, s, x, ldx, rows, cols, rpb, workspace);
   SF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, workspace, nblk, (int64_t)cols, out, cols, accumulate);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((cols + 63) / 64), dim3(1024), 0, s, workspace, nblk, (int64_t)cols, out, cols, accumulate);
   SF_LAUNCH_CHECK();
   return 0;
 }
