@@ -221,6 +221,13 @@ int sf_attention_cls_masked(const uint16_t* q, int64_t q_seq_rows, int q_row, co
  * preds_a[b, j] = argmax_i, preds_v[b, i] = argmax_j over the S - W + 1 (<= 32) shifts. */
 int sf_shift_window_preds(const float* G, int64_t ldg, int n_clips, int S, int W, int64_t* preds_a, int64_t* preds_v, void* stream);
 
+/* Backward of sf_attention for tiny groups (n_tok <= 8, head_dim 64: Motionformer time attention, vit_helper.py:343-344): same
+ * addressing as the forward; dq | dk | dv rows of the group's tokens are written (=), the CLS key's dk | dv of every (seq, group) goes to
+ * cls_part (n_seq * n_groups, 2 * heads * 64) bf16 for sf_reduce_groups_bf16. */
+int sf_attention_tiny_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld, const uint16_t* dO, int64_t lddo, uint16_t* dq,
+                          uint16_t* dk, uint16_t* dv, int64_t ldg, uint16_t* cls_part, int64_t n_seq, int64_t seq_rows, int n_groups, int row0,
+                          int group_stride, int tok_stride, int n_tok, int cls_row, int heads, int head_dim, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,6 +157,139 @@ __global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t to
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Backward of the tiny-group attention above (Motionformer time attention in the Stage-1 train step): one wave per (seq, group, head),
+// n_tok <= 8 queries against [CLS key; n_tok keys].  Phase 1 is query-major like the forward (lane = (query, 8-dim slice)): recompute
+// p = softmax(q k^T * scale), dp = dO v^T, ds = p (dp - sum_j p dp) scale, and dq = ds k.  Phase 2 is key-major (lane = (key, slice)):
+// dk_j = sum_i ds_ij q_i, dv_j = sum_i p_ij dO_i, with q, dO, ds, p exchanged through 2.6 KB of wave-private LDS.  Token keys write
+// their dk | dv rows directly (a token belongs to exactly one group); the CLS key's share goes to cls_part[(seq, group)][k|v][head*64+d]
+// and is summed over groups by sf_reduce_groups_bf16.
+// ------------------------------------------------------------------------------------------------------
+struct AttnBwdArgs {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; int64_t ld;
+  const bf16_t* dO; int64_t lddo;
+  bf16_t* dq; bf16_t* dk; bf16_t* dv; int64_t ldg;
+  bf16_t* cls_part;                       // (n_seq * n_groups, 2 * heads * 64)
+  int64_t seq_rows;
+  int n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads;
+  float scale;
+};
+
+__global__ __launch_bounds__(256) void attn_tiny64_bwd_kernel(AttnBwdArgs p, int64_t total_units) {
+  __shared__ __attribute__((aligned(16))) bf16_t q_l[4][8][64], do_l[4][8][64];
+  __shared__ float ds_l[4][8][12], p_l[4][8][12];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wv;
+  if (unit >= total_units) return;
+  const int head = (int)(unit % p.heads);
+  const int64_t sg = unit / p.heads;
+  const int g = (int)(sg % p.n_groups);
+  const int64_t seq = sg / p.n_groups;
+  const int qi = lane >> 3, sub = lane & 7;
+  const int64_t seq_base = seq * p.seq_rows;
+  const int64_t first = seq_base + p.row0 + (int64_t)g * p.group_stride;
+  const int col = head * 64 + sub * 8;
+  const bool q_valid = qi < p.n_tok;
+  const int qtok = q_valid ? qi : p.n_tok - 1;
+  const int64_t qrow = first + (int64_t)qtok * p.tok_stride;
+  const uint4 qraw = *reinterpret_cast<const uint4*>(p.q + qrow * p.ld + col);
+  const uint4 doraw = *reinterpret_cast<const uint4*>(p.dO + qrow * p.lddo + col);
+  const int has_cls = p.cls_row >= 0 ? 1 : 0;
+  const int nk = p.n_tok + has_cls;
+  uint4 kraw[9], vraw[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int jj = j < nk ? j : nk - 1;
+    const int64_t row = (has_cls && jj == 0) ? seq_base + p.cls_row : first + (int64_t)(jj - has_cls) * p.tok_stride;
+    kraw[j] = *reinterpret_cast<const uint4*>(p.k + row * p.ld + col);
+    vraw[j] = *reinterpret_cast<const uint4*>(p.v + row * p.ld + col);
+  }
+  *reinterpret_cast<uint4*>(&q_l[wv][qi][sub * 8]) = qraw;
+  *reinterpret_cast<uint4*>(&do_l[wv][qi][sub * 8]) = doraw;
+  // ---- phase 1: probabilities, dp, ds, dq ---------------------------------------------------------------------------------
+  const float sc2 = p.scale * 1.44269504088896f;
+  float s[9], dp[9], m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    float d = dot8_bf16(qraw, kraw[j]), e = dot8_bf16(doraw, vraw[j]);
+    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+    e += __shfl_xor(e, 1, 64); e += __shfl_xor(e, 2, 64); e += __shfl_xor(e, 4, 64);
+    s[j] = j < nk ? d * sc2 : -INFINITY;
+    dp[j] = e;
+    m = fmaxf(m, s[j]);
+  }
+  float l = 0.f;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) { s[j] = __builtin_amdgcn_exp2f(s[j] - m); l += s[j]; }
+  const float linv = q_valid ? 1.0f / l : 0.f;                   // idle query lanes contribute nothing to dk / dv
+  float delta = 0.f;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) { s[j] *= linv; delta += s[j] * dp[j]; }
+  sf_f32x2_t dqa[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dqa[i] = sf_f32x2_t{0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const float ds = s[j] * (dp[j] - delta) * p.scale;
+    axpy8_bf16(dqa, ds, kraw[j]);
+    if (sub == 0) { ds_l[wv][qi][j] = ds; p_l[wv][qi][j] = s[j]; }
+  }
+  if (q_valid) {
+    uint4 w;
+    w.x = pack_bf2(dqa[0].x, dqa[0].y); w.y = pack_bf2(dqa[1].x, dqa[1].y);
+    w.z = pack_bf2(dqa[2].x, dqa[2].y); w.w = pack_bf2(dqa[3].x, dqa[3].y);
+    *reinterpret_cast<uint4*>(p.dq + qrow * p.ldg + col) = w;
+  }
+  // ---- phase 2: key-major.  lane (kj = lane >> 3, sub) owns key kj; key 8 is done by the kj == 0 lanes in a second pass ---------
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int j = pass == 0 ? qi : 8;
+    if (j >= nk || (pass == 1 && qi != 0)) continue;
+    sf_f32x2_t dka[4], dva[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dka[i] = sf_f32x2_t{0.f, 0.f}; dva[i] = sf_f32x2_t{0.f, 0.f}; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint4 qv = *reinterpret_cast<const uint4*>(&q_l[wv][i][sub * 8]);
+      const uint4 dv_ = *reinterpret_cast<const uint4*>(&do_l[wv][i][sub * 8]);
+      axpy8_bf16(dka, ds_l[wv][i][j], qv);
+      axpy8_bf16(dva, p_l[wv][i][j], dv_);
+    }
+    uint4 wk, wvv;
+    wk.x = pack_bf2(dka[0].x, dka[0].y); wk.y = pack_bf2(dka[1].x, dka[1].y); wk.z = pack_bf2(dka[2].x, dka[2].y); wk.w = pack_bf2(dka[3].x, dka[3].y);
+    wvv.x = pack_bf2(dva[0].x, dva[0].y); wvv.y = pack_bf2(dva[1].x, dva[1].y); wvv.z = pack_bf2(dva[2].x, dva[2].y); wvv.w = pack_bf2(dva[3].x, dva[3].y);
+    if (has_cls && j == 0) {
+      bf16_t* cp = p.cls_part + (seq * p.n_groups + g) * (int64_t)(2 * p.heads * 64);
+      *reinterpret_cast<uint4*>(cp + col) = wk;
+      *reinterpret_cast<uint4*>(cp + p.heads * 64 + col) = wvv;
+    } else {
+      const int64_t row = first + (int64_t)(j - has_cls) * p.tok_stride;
+      *reinterpret_cast<uint4*>(p.dk + row * p.ldg + col) = wk;
+      *reinterpret_cast<uint4*>(p.dv + row * p.ldg + col) = wvv;
+    }
+  }
+}
+
+extern "C" int sf_attention_tiny_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const bf16_t* dO, int64_t lddo, bf16_t* dq, bf16_t* dk,
+                                     bf16_t* dv, int64_t ldg, bf16_t* cls_part, int64_t n_seq, int64_t seq_rows, int n_groups, int row0,
+                                     int group_stride, int tok_stride, int n_tok, int cls_row, int heads, int head_dim, float scale, void* stream) {
+  SF_CHECK_ARG(q && k && v && dO && dq && dk && dv, "sf_attention_tiny_bwd: null pointer");
+  SF_CHECK_ARG(head_dim == 64 && n_tok >= 1 && n_tok <= 8 && (cls_row < 0 || cls_part), "sf_attention_tiny_bwd: head_dim 64, n_tok <= 8, cls_part with cls_row");
+  SF_CHECK_ARG((ld % 8) == 0 && (lddo % 8) == 0 && (ldg % 8) == 0 && n_groups >= 1 && heads >= 1, "sf_attention_tiny_bwd: bad strides / counts");
+  if (n_seq <= 0) return 0;
+  AttnBwdArgs a;
+  a.q = q; a.k = k; a.v = v; a.ld = ld; a.dO = dO; a.lddo = lddo; a.dq = dq; a.dk = dk; a.dv = dv; a.ldg = ldg; a.cls_part = cls_part;
+  a.seq_rows = seq_rows; a.n_groups = n_groups; a.row0 = row0; a.group_stride = group_stride; a.tok_stride = tok_stride; a.n_tok = n_tok;
+  a.cls_row = cls_row; a.heads = heads; a.scale = scale;
+  const int64_t units = n_seq * n_groups * heads;
+  hipLaunchKernelGGL(attn_tiny64_bwd_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, units);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
 // ======================================================================================================
 // (2) one query row per sequence against n_keys rows (D = 64): the Motionformer CLS query (1569 keys) and the
 // aggregator layers, whose encoder output is only ever read at row 0 (motionformer.py:332, ast.py:274-277).

@@ -146,6 +146,16 @@ class AVCLIPTrainer(FlatTrainer):
         """qkv (n*1569, 2304) bf16 saved, dO_b (n*1569, 768) bf16 -> dqkv (n*1569, 2304) bf16."""
         G, T, Lg, tok, grp, cls_tok, cls_grp = self._group_maps(kind)
         nseq, rows_g, M = n * G, n * G * Lg, n * VIS_L
+        if kind == 'time':                                                     # 8 queries x 9 keys per group: the dedicated VALU kernel
+            dqkv = self._buf('dqkv', (M, 3 * D), torch.bfloat16)
+            part = self._buf('cls_kv_part', (nseq, 2 * D), torch.bfloat16)
+            _chk(_lib.load().sf_attention_tiny_bwd(qkv.data_ptr(), qkv[:, D:].data_ptr(), qkv[:, 2 * D:].data_ptr(), qkv.stride(0), dO_b.data_ptr(),
+                                                   dO_b.stride(0), dqkv.data_ptr(), dqkv[:, D:].data_ptr(), dqkv[:, 2 * D:].data_ptr(), dqkv.stride(0),
+                                                   part.data_ptr(), n, VIS_L, 196, 1, 1, 196, 8, 0, H, HD, 0.125, _st()), 'sf_attention_tiny_bwd')
+            _chk(_lib.load().sf_reduce_groups_bf16(part.data_ptr(), G * 2 * D, 2 * D, G, dqkv[:, D:].data_ptr(), VIS_L * 3 * D, 2 * D, n, 0, _st()),
+                 'sf_reduce_groups_bf16')
+            self._cls_bwd(qkv, dO_b, dqkv, n, VIS_L, VIS_L, do_seq_rows=VIS_L, accumulate=True)
+            return dqkv
         Gq = self._buf('g_qkv', (rows_g, 3 * D), torch.bfloat16)
         copy_rows(qkv, Gq, n * VIS_P, 3 * D, tok, grp)
         copy_rows(qkv, Gq, nseq, 3 * D, cls_tok, cls_grp)
