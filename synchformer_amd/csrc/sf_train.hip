@@ -32,14 +32,54 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
   }
 }
 
+// 64 x 64 tiles, 16-byte global accesses on both sides (the 32 x 32 / 2-byte kernel above moves 64 B per wavefront row and was 20 % of
+// the Stage-1 train step).  Needs C % 8 == 0, 16-byte aligned rows on both sides and R_pad % 8 == 0; everything else takes the kernel above.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel64(const bf16_t* __restrict__ in, int64_t ld_in, int64_t sI0, int64_t sI1,
+                                                                bf16_t* __restrict__ out, int64_t ld_out, int64_t sO0, int64_t sO1,
+                                                                int R, int C, int R_pad, int batch_inner) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];      // 144-B rows: 16-B aligned stores, 36-dword stride for the column gathers
+  const int b0 = blockIdx.z / batch_inner, b1 = blockIdx.z - b0 * batch_inner;
+  in += b0 * sI0 + b1 * sI1;
+  out += b0 * sO0 + b1 * sO1;
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = threadIdx.x + i * 256, row = idx >> 3, ch = idx & 7;
+    const int r = r0 + row, c = c0 + ch * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (r < R && c < C) v = *reinterpret_cast<const uint4*>(in + (int64_t)r * ld_in + c);
+    *reinterpret_cast<uint4*>(&tile[row][ch * 8]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = threadIdx.x + i * 256, oc = idx & 63, rch = idx >> 6;     // lanes of a wave walk the output rows: conflict-light LDS gathers
+    const int c = c0 + oc, r = r0 + rch * 8;
+    if (c < C && r < R_pad) {
+      uint32_t w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (uint32_t)tile[rch * 8 + 2 * e][oc] | ((uint32_t)tile[rch * 8 + 2 * e + 1][oc] << 16);
+      *reinterpret_cast<uint4*>(out + (int64_t)c * ld_out + r) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
 extern "C" int sf_transpose_bf16(const bf16_t* in, int64_t ld_in, int64_t sI0, int64_t sI1, bf16_t* out, int64_t ld_out, int64_t sO0,
                                  int64_t sO1, int R, int C, int R_pad, int batch_outer, int batch_inner, void* stream) {
   SF_CHECK_ARG(in && out, "sf_transpose_bf16: null pointer");
   SF_CHECK_ARG(R > 0 && C > 0 && R_pad >= R && batch_outer >= 1 && batch_inner >= 1, "sf_transpose_bf16: bad shape");
   SF_CHECK_ARG((int64_t)batch_outer * batch_inner < 65536, "sf_transpose_bf16: too many batches");
-  dim3 grid((R_pad + 31) / 32, (C + 31) / 32, batch_outer * batch_inner);
-  hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, sI0, sI1, out, ld_out, sO0, sO1, R, C,
-                     R_pad, batch_inner);
+  const bool wide = (C % 8) == 0 && (R_pad % 8) == 0 && (ld_in % 8) == 0 && (ld_out % 8) == 0 && (sI0 % 8) == 0 && (sI1 % 8) == 0 &&
+                    (sO0 % 8) == 0 && (sO1 % 8) == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0;
+  if (wide) {
+    dim3 grid((R_pad + 63) / 64, (C + 63) / 64, batch_outer * batch_inner);
+    hipLaunchKernelGGL(transpose_bf16_kernel64, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, sI0, sI1, out, ld_out, sO0, sO1, R, C,
+                       R_pad, batch_inner);
+  } else {
+    dim3 grid((R_pad + 31) / 32, (C + 31) / 32, batch_outer * batch_inner);
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, sI0, sI1, out, ld_out, sO0, sO1, R, C,
+                       R_pad, batch_inner);
+  }
   SF_LAUNCH_CHECK();
   return 0;
 }
