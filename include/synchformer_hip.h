@@ -228,6 +228,9 @@ int sf_attention_tiny_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* 
                           uint16_t* dk, uint16_t* dv, int64_t ldg, uint16_t* cls_part, int64_t n_seq, int64_t seq_rows, int n_groups, int row0,
                           int group_stride, int tok_stride, int n_tok, int cls_row, int heads, int head_dim, float scale, void* stream);
 
+/* out[r] (=|+=) sum_c x[r, c] for a bf16 (rows, cols) matrix (cols % 8 == 0): bias gradients from the transposed gradient copy. */
+int sf_rowsum_bf16(const uint16_t* x, int64_t ldx, int rows, int64_t cols, float* out, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -317,6 +317,31 @@ extern "C" int sf_colsum(const void* x, int x_dtype, int64_t ldx, int64_t rows, 
   return 0;
 }
 
+// out[r] (=|+=) sum_c x[r, c] for a bf16 (rows, cols) matrix, cols % 8 == 0: bias gradients read off the TRANSPOSED gradient copy the
+// weight-gradient GEMM needs anyway (row r of dy^T = column r of dy) - contiguous 16-byte reads, one wave per row, no second stage.
+__global__ __launch_bounds__(256) void rowsum_bf16_kernel(const bf16_t* __restrict__ x, int64_t ldx, int rows, int64_t cols, float* __restrict__ out,
+                                                           int accumulate) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const bf16_t* xr = x + (int64_t)r * ldx;
+  float s0 = 0.f, s1 = 0.f;
+  for (int64_t c = (int64_t)lane * 8; c < cols; c += 512) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xr + c);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s0 += __uint_as_float(w[e] << 16); s1 += __uint_as_float(w[e] & 0xffff0000u); }
+  }
+  const float s = wave_sum(s0 + s1);
+  if (lane == 0) out[r] = accumulate ? out[r] + s : s;
+}
+
+extern "C" int sf_rowsum_bf16(const uint16_t* x, int64_t ldx, int rows, int64_t cols, float* out, int accumulate, void* stream) {
+  SF_CHECK_ARG(x && out && rows >= 1 && cols >= 8 && (cols % 8) == 0 && (ldx % 8) == 0 && ((uintptr_t)x % 16) == 0, "sf_rowsum_bf16: bad arguments");
+  hipLaunchKernelGGL(rowsum_bf16_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols, out, accumulate);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void seqsum_kernel(const float* __restrict__ x, int64_t ldx, int n_seq, int L, int cols, float* __restrict__ out,
                                                       int accumulate) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -160,8 +160,9 @@ class FlatTrainer:
         N = self.p[wkey].shape[0]
         K = self.p[wkey].numel() // N
         m_pad = ((M + 63) // 64) * 64
-        ws = self._buf('colsum_ws', (N * ((M + 63) // 64),), torch.float32)
-        colsum(dy_b if dy_f32 is None else dy_f32, M, N, self.g[bkey], ws, accumulate=acc_bias)   # fp32 dy when the caller has it
+        if dy_f32 is not None:                                                       # fp32 gradient at hand: sum that (cancellation-prone biases)
+            ws = self._buf('colsum_ws', (N * ((M + 63) // 64),), torch.float32)
+            colsum(dy_f32, M, N, self.g[bkey], ws, accumulate=acc_bias)
         # dW = dy^T x: an (N, K) output is only (N/128)*(K/128) tiles (36 for a 768x768 weight) however long the M contraction is,
         # so for long M the contraction is split into `split` chunks run as one batched GEMM (fills the 256 CUs) and summed after
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
@@ -172,6 +173,8 @@ class FlatTrainer:
         xT = self._buf('xT', (K, m_pad), torch.bfloat16)
         transpose(dy_b, dy_b.stride(0), 0, 0, dyT, m_pad, 0, 0, M, N, m_pad)
         transpose(x_b, x_b.stride(0), 0, 0, xT, m_pad, 0, 0, M, K, m_pad)
+        if dy_f32 is None:                                                           # bias gradient = row sums of dy^T (zero-padded columns add 0)
+            _chk(_lib.load().sf_rowsum_bf16(dyT.data_ptr(), m_pad, N, m_pad, self.g[bkey].data_ptr(), int(acc_bias), _st()), 'sf_rowsum_bf16')
         if split > 1:
             part = self._buf('wgrad_part', (split * N, K), torch.float32)
             bgemm(dyT, m_pad, kc, 0, xT, m_pad, kc, 0, part, K, N * K, 0, N, K, kc, split, 1)
