@@ -231,6 +231,12 @@ int sf_attention_tiny_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* 
 /* out[r] (=|+=) sum_c x[r, c] for a bf16 (rows, cols) matrix (cols % 8 == 0): bias gradients from the transposed gradient copy. */
 int sf_rowsum_bf16(const uint16_t* x, int64_t ldx, int rows, int64_t cols, float* out, int accumulate, void* stream);
 
+/* Fused backward of sf_attention for groups of up to 208 keys, head_dim 64 (Motionformer space attention, AST): same addressing and
+ * outputs as sf_attention_tiny_bwd; scores / probabilities are recomputed, nothing but dq | dk | dv (and cls_part) touches HBM. */
+int sf_attention_group_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld, const uint16_t* dO, int64_t lddo, uint16_t* dq,
+                           uint16_t* dk, uint16_t* dv, int64_t ldg, uint16_t* cls_part, int64_t n_seq, int64_t seq_rows, int n_groups, int row0,
+                           int group_stride, int tok_stride, int n_tok, int cls_row, int heads, int head_dim, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

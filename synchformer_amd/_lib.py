@@ -60,6 +60,8 @@ SIGNATURES = {
     'sf_attention_tiny_bwd': [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                               _i32, _f32, _ptr],
     'sf_rowsum_bf16': [_ptr, _i64, _i32, _i64, _ptr, _i32, _ptr],
+    'sf_attention_group_bwd': [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                               _i32, _f32, _ptr],
     'sf_attention_cls_partial': [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _ptr, _ptr],
     'sf_attention_cls_combine': [_ptr, _i32, _ptr, _i64, _i64, _i32, _i64, _i32, _ptr],
     'sf_attention_cls': [_ptr, _i64, _i32, _ptr, _ptr, _i64, _i64, _i32, _i32, _ptr, _i64, _i64, _i32, _i64, _i32, _i32, _f32, _ptr],

@@ -290,6 +290,240 @@ extern "C" int sf_attention_tiny_bwd(const bf16_t* q, const bf16_t* k, const bf1
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Fused backward of the grouped attention for up to 208 keys, head_dim 64 (Motionformer space attention: 196 queries x [CLS; 196 keys];
+// AST: 74 x 74).  One 256-thread workgroup per (seq, group, head); K, V, Q, dO rows of the group are staged once in LDS (row-major,
+// 144-byte rows).  Everything runs on v_mfma_f32_16x16x16_bf16, whose C layout (lane: column l & 15, rows (l >> 4)*4 + r) IS its A / B
+// operand layout (lane: row l & 15, k = (l >> 4)*4 + e): a probability tile computed as S^T = K Q^T is directly the A operand
+// "rows = query, k = key" of dQ = dS K, and the same tile computed as S = Q K^T is directly the A operand "rows = key, k = query" of
+// dK = dS^T Q and dV = P^T dO - so P and dS never go through LDS; computing the score / dP tiles twice (once per layout) is cheaper
+// than transposing them.  B operands that contract over keys or queries are column fragments of the row-major LDS copies (four
+// 2-byte reads).
+//   pass 1 (query tiles over the waves): softmax statistics per query (max, 1/sum, delta = sum_j p dp) -> LDS, and dQ;
+//   pass 2 (key tiles over the waves):   dK and dV, with p = exp2(s*c - m) / l rebuilt from the statistics.
+// The CLS key's dk | dv share goes to cls_part like in the tiny-group kernel.
+// ------------------------------------------------------------------------------------------------------
+#define GB_LD 72                 // bf16 per LDS row: 64 + 8 pad (144 B: 8-byte aligned fragments, 36-dword stride)
+#define GB_ROWS 208
+#define GB_MAT (GB_ROWS * GB_LD * 2)                       // 29,952 B per staged matrix
+#define GB_LDS (4 * GB_MAT + GB_ROWS * 3 * 4 + 4 * 16 * GB_LD * 2)
+
+__device__ __forceinline__ bf16x4 gb_row_frag(const bf16_t* X, int row, int k0) { return *reinterpret_cast<const bf16x4*>(X + row * GB_LD + k0); }
+__device__ __forceinline__ bf16x4 gb_col_frag(const bf16_t* X, int row0, int col) {
+  bf16x4 f;
+  f[0] = (short)X[(row0 + 0) * GB_LD + col]; f[1] = (short)X[(row0 + 1) * GB_LD + col];
+  f[2] = (short)X[(row0 + 2) * GB_LD + col]; f[3] = (short)X[(row0 + 3) * GB_LD + col];
+  return f;
+}
+__device__ __forceinline__ bf16x4 gb_pack(const f32x4& v) {
+  union { bf16x4 f; uint32_t u[2]; } r;
+  r.u[0] = pack_bf2(v[0], v[1]); r.u[1] = pack_bf2(v[2], v[3]);
+  return r.f;
+}
+
+__global__ __launch_bounds__(256) void attn_group_bwd_kernel(AttnBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Kr = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Vr = Kr + GB_ROWS * GB_LD;
+  bf16_t* Qr = Vr + GB_ROWS * GB_LD;
+  bf16_t* Dr = Qr + GB_ROWS * GB_LD;                          // dO
+  float* stats = reinterpret_cast<float*>(smem + 4 * GB_MAT);   // [208][3]: m (base-2 domain), 1/l, delta
+  bf16_t* outl = reinterpret_cast<bf16_t*>(smem + 4 * GB_MAT + GB_ROWS * 3 * 4);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int64_t unit = blockIdx.x;
+  const int head = (int)(unit % p.heads);
+  const int64_t sg = unit / p.heads;
+  const int g = (int)(sg % p.n_groups);
+  const int64_t seq = sg / p.n_groups;
+  const int64_t seq_base = seq * p.seq_rows;
+  const int64_t first = seq_base + p.row0 + (int64_t)g * p.group_stride;
+  const int has_cls = p.cls_row >= 0 ? 1 : 0;
+  const int nk = p.n_tok + has_cls, nq = p.n_tok;
+  const int nkt = (nk + 15) >> 4, nqt = (nq + 15) >> 4;
+  const int hcol = head * 64;
+  auto key_row = [&](int j) -> int64_t { return (has_cls && j == 0) ? seq_base + p.cls_row : first + (int64_t)(j - has_cls) * p.tok_stride; };
+  auto tok_row = [&](int i) -> int64_t { return first + (int64_t)i * p.tok_stride; };
+
+  // ---- stage K, V (key rows) and Q, dO (query rows): 208 rows x 8 chunks of 16 B each, zero beyond the valid rows -------------
+  for (int idx = tid; idx < GB_ROWS * 8; idx += 256) {
+    const int row = idx >> 3, ch = idx & 7;
+    uint4 kk = make_uint4(0, 0, 0, 0), vv = kk, qq = kk, dd = kk;
+    if (row < nk) {
+      const int64_t r = key_row(row);
+      kk = *reinterpret_cast<const uint4*>(p.k + r * p.ld + hcol + ch * 8);
+      vv = *reinterpret_cast<const uint4*>(p.v + r * p.ld + hcol + ch * 8);
+    }
+    if (row < nq) {
+      const int64_t r = tok_row(row);
+      qq = *reinterpret_cast<const uint4*>(p.q + r * p.ld + hcol + ch * 8);
+      dd = *reinterpret_cast<const uint4*>(p.dO + r * p.lddo + hcol + ch * 8);
+    }
+    // 144-byte rows are only 8-byte aligned at odd rows: store as two 8-byte halves
+    uint2* dk_ = reinterpret_cast<uint2*>(Kr + row * GB_LD + ch * 8); dk_[0] = make_uint2(kk.x, kk.y); dk_[1] = make_uint2(kk.z, kk.w);
+    uint2* dv_ = reinterpret_cast<uint2*>(Vr + row * GB_LD + ch * 8); dv_[0] = make_uint2(vv.x, vv.y); dv_[1] = make_uint2(vv.z, vv.w);
+    uint2* dq_ = reinterpret_cast<uint2*>(Qr + row * GB_LD + ch * 8); dq_[0] = make_uint2(qq.x, qq.y); dq_[1] = make_uint2(qq.z, qq.w);
+    uint2* dd_ = reinterpret_cast<uint2*>(Dr + row * GB_LD + ch * 8); dd_[0] = make_uint2(dd.x, dd.y); dd_[1] = make_uint2(dd.z, dd.w);
+  }
+  __syncthreads();
+  const float sc2 = p.scale * 1.44269504088896f;
+  bf16_t* myout = outl + wave * 16 * GB_LD;
+
+  // ---- pass 1: per query tile - statistics and dQ.  Tiles are S^T: lane's query = qt*16 + lr, its keys = kt*16 + lg*4 + r ---------
+  for (int qt = wave; qt < nqt; qt += 4) {
+    f32x4 sT[13], dpT[13];
+    bf16x4 qf[4], df[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { qf[ks] = gb_row_frag(Qr, qt * 16 + lr, ks * 16 + lg * 4); df[ks] = gb_row_frag(Dr, qt * 16 + lr, ks * 16 + lg * 4); }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 13; ++kt) {
+      sT[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dpT[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kt < nkt) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          sT[kt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb_row_frag(Kr, kt * 16 + lr, ks * 16 + lg * 4), qf[ks], sT[kt], 0, 0, 0);
+          dpT[kt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb_row_frag(Vr, kt * 16 + lr, ks * 16 + lg * 4), df[ks], dpT[kt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (kt * 16 + lg * 4 + r >= nk) sT[kt][r] = -INFINITY;
+        m = fmaxf(m, sT[kt][r]);
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float msc = m * sc2;
+    float l = 0.f, delta = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 13; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(sT[kt][r], sc2, -msc));      // -inf -> 0
+        sT[kt][r] = e; l += e; delta += e * dpT[kt][r];
+      }
+    l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+    delta += __shfl_xor(delta, 16, 64); delta += __shfl_xor(delta, 32, 64);
+    const float linv = 1.0f / l;
+    delta *= linv;
+    if (lg == 0) { float* st = stats + (qt * 16 + lr) * 3; st[0] = msc; st[1] = linv; st[2] = delta; }
+    // dS tiles (rows = query, k = key) and dQ = dS K
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 13; ++kt) {
+      if (kt < nkt) {
+        f32x4 ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[r] = sT[kt][r] * linv * (dpT[kt][r] - delta) * p.scale;
+        const bf16x4 dsf = gb_pack(ds);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsf, gb_col_frag(Kr, kt * 16 + lg * 4, dt * 16 + lr), dq[dt], 0, 0, 0);
+      }
+    }
+    // dq[dt][r] = dQ[query qt*16 + lg*4 + r][d = dt*16 + lr] -> staging -> 16-byte row stores
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) myout[(lg * 4 + r) * GB_LD + dt * 16 + lr] = f2bf(dq[dt][r]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = lane + i * 64, row = idx >> 3, ch = idx & 7, qi = qt * 16 + row;
+      if (qi < nq) {
+        const uint2* sp = reinterpret_cast<const uint2*>(myout + row * GB_LD + ch * 8);
+        const uint2 a = sp[0], b = sp[1];
+        *reinterpret_cast<uint4*>(p.dq + tok_row(qi) * p.ldg + hcol + ch * 8) = make_uint4(a.x, a.y, b.x, b.y);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  __syncthreads();                                             // statistics of every query are in LDS
+
+  // ---- pass 2: per key tile - dK, dV.  Tiles are S: lane's key = kt*16 + lr, its queries = qt*16 + lg*4 + r ----------------------
+  for (int kt = wave; kt < nkt; kt += 4) {
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    bf16x4 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { kf[ks] = gb_row_frag(Kr, kt * 16 + lr, ks * 16 + lg * 4); vf[ks] = gb_row_frag(Vr, kt * 16 + lr, ks * 16 + lg * 4); }
+    const bool key_ok = kt * 16 + lr < nk;
+    for (int qt = 0; qt < nqt; ++qt) {
+      f32x4 s2 = f32x4{0.f, 0.f, 0.f, 0.f}, dp2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb_row_frag(Qr, qt * 16 + lr, ks * 16 + lg * 4), kf[ks], s2, 0, 0, 0);
+        dp2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb_row_frag(Dr, qt * 16 + lr, ks * 16 + lg * 4), vf[ks], dp2, 0, 0, 0);
+      }
+      f32x4 pp, ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = qt * 16 + lg * 4 + r;
+        const float* st = stats + qi * 3;
+        const float pr = (key_ok && qi < nq) ? __builtin_amdgcn_exp2f(fmaf(s2[r], sc2, -st[0])) * st[1] : 0.f;
+        pp[r] = pr;
+        ds[r] = pr * (dp2[r] - st[2]) * p.scale;
+      }
+      const bf16x4 pf = gb_pack(pp), dsf = gb_pack(ds);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pf, gb_col_frag(Dr, qt * 16 + lg * 4, dt * 16 + lr), dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsf, gb_col_frag(Qr, qt * 16 + lg * 4, dt * 16 + lr), dk[dt], 0, 0, 0);
+      }
+    }
+    // dk[dt][r] = dK[key kt*16 + lg*4 + r][d = dt*16 + lr]: two staging rounds (dk, then dv)
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) myout[(lg * 4 + r) * GB_LD + dt * 16 + lr] = f2bf(which == 0 ? dk[dt][r] : dv[dt][r]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = lane + i * 64, row = idx >> 3, ch = idx & 7, kj = kt * 16 + row;
+        if (kj < nk) {
+          const uint2* sp = reinterpret_cast<const uint2*>(myout + row * GB_LD + ch * 8);
+          const uint2 a = sp[0], b = sp[1];
+          bf16_t* dst;
+          if (has_cls && kj == 0) dst = p.cls_part + (seq * p.n_groups + g) * (int64_t)(2 * p.heads * 64) + which * p.heads * 64 + hcol + ch * 8;
+          else dst = (which == 0 ? p.dk : p.dv) + key_row(kj) * p.ldg + hcol + ch * 8;
+          *reinterpret_cast<uint4*>(dst) = make_uint4(a.x, a.y, b.x, b.y);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+}
+
+extern "C" int sf_attention_group_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const bf16_t* dO, int64_t lddo, bf16_t* dq,
+                                      bf16_t* dk, bf16_t* dv, int64_t ldg, bf16_t* cls_part, int64_t n_seq, int64_t seq_rows, int n_groups, int row0,
+                                      int group_stride, int tok_stride, int n_tok, int cls_row, int heads, int head_dim, float scale, void* stream) {
+  SF_CHECK_ARG(q && k && v && dO && dq && dk && dv, "sf_attention_group_bwd: null pointer");
+  SF_CHECK_ARG(head_dim == 64 && n_tok >= 1 && n_tok + (cls_row >= 0 ? 1 : 0) <= GB_ROWS && (cls_row < 0 || cls_part),
+               "sf_attention_group_bwd: head_dim 64, n_tok (+1) <= 208, cls_part with cls_row");
+  SF_CHECK_ARG((ld % 8) == 0 && (lddo % 8) == 0 && (ldg % 8) == 0 && n_groups >= 1 && heads >= 1, "sf_attention_group_bwd: bad strides / counts");
+  if (n_seq <= 0) return 0;
+  AttnBwdArgs a;
+  a.q = q; a.k = k; a.v = v; a.ld = ld; a.dO = dO; a.lddo = lddo; a.dq = dq; a.dk = dk; a.dv = dv; a.ldg = ldg; a.cls_part = cls_part;
+  a.seq_rows = seq_rows; a.n_groups = n_groups; a.row0 = row0; a.group_stride = group_stride; a.tok_stride = tok_stride; a.n_tok = n_tok;
+  a.cls_row = cls_row; a.heads = heads; a.scale = scale;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_group_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS);
+    if (e != hipSuccess) { sf_set_error("sf_attention_group_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  const int64_t units = n_seq * n_groups * heads;
+  SF_CHECK_ARG(units < ((int64_t)1 << 31), "sf_attention_group_bwd: too many groups");
+  hipLaunchKernelGGL(attn_group_bwd_kernel, dim3((unsigned)units), dim3(256), GB_LDS, (hipStream_t)stream, a);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
 // ======================================================================================================
 // (2) one query row per sequence against n_keys rows (D = 64): the Motionformer CLS query (1569 keys) and the
 // aggregator layers, whose encoder output is only ever read at row 0 (motionformer.py:332, ast.py:274-277).

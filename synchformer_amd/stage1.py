@@ -68,6 +68,7 @@ class AVCLIPTrainer(FlatTrainer):
         keys = [k for k in sd if k.startswith((V + '.', A + '.')) and not k.startswith(V + '.patch_embed.')] + ['logit_scale']
         self._init_flat(sd, keys, device, lr, betas, eps, max_clip_norm)
         self.clamp_scale, self.gather_for_loss = clamp_scale, gather_for_loss
+        self.fused_attn_bwd = True          # False: the gathered batched-GEMM attention backward (kept as a cross-check)
         self.n_vblocks = len([k for k in keys if k.startswith(V + '.blocks.') and k.endswith('.norm1.weight')])
         self.n_alayers = len([k for k in keys if k.endswith('.layernorm_before.weight')])
 
@@ -146,12 +147,16 @@ class AVCLIPTrainer(FlatTrainer):
         """qkv (n*1569, 2304) bf16 saved, dO_b (n*1569, 768) bf16 -> dqkv (n*1569, 2304) bf16."""
         G, T, Lg, tok, grp, cls_tok, cls_grp = self._group_maps(kind)
         nseq, rows_g, M = n * G, n * G * Lg, n * VIS_L
-        if kind == 'time':                                                     # 8 queries x 9 keys per group: the dedicated VALU kernel
+        if self.fused_attn_bwd:
+            # dedicated kernels: 8 x 9 time groups on VALU, 196 x 197 space groups fused on v_mfma_f32_16x16x16_bf16 (scores recomputed,
+            # nothing but dq | dk | dv touches HBM); the CLS key's dk | dv of every group is summed by sf_reduce_groups_bf16
             dqkv = self._buf('dqkv', (M, 3 * D), torch.bfloat16)
             part = self._buf('cls_kv_part', (nseq, 2 * D), torch.bfloat16)
-            _chk(_lib.load().sf_attention_tiny_bwd(qkv.data_ptr(), qkv[:, D:].data_ptr(), qkv[:, 2 * D:].data_ptr(), qkv.stride(0), dO_b.data_ptr(),
-                                                   dO_b.stride(0), dqkv.data_ptr(), dqkv[:, D:].data_ptr(), dqkv[:, 2 * D:].data_ptr(), dqkv.stride(0),
-                                                   part.data_ptr(), n, VIS_L, 196, 1, 1, 196, 8, 0, H, HD, 0.125, _st()), 'sf_attention_tiny_bwd')
+            geo = (196, 1, 1, 196, 8) if kind == 'time' else (8, 1, 196, 1, 196)          # n_groups, row0, group_stride, tok_stride, n_tok
+            fn = _lib.load().sf_attention_tiny_bwd if kind == 'time' else _lib.load().sf_attention_group_bwd
+            _chk(fn(qkv.data_ptr(), qkv[:, D:].data_ptr(), qkv[:, 2 * D:].data_ptr(), qkv.stride(0), dO_b.data_ptr(), dO_b.stride(0), dqkv.data_ptr(),
+                    dqkv[:, D:].data_ptr(), dqkv[:, 2 * D:].data_ptr(), dqkv.stride(0), part.data_ptr(), n, VIS_L, *geo, 0, H, HD, 0.125, _st()),
+                 'sf_attention_*_bwd')
             _chk(_lib.load().sf_reduce_groups_bf16(part.data_ptr(), G * 2 * D, 2 * D, G, dqkv[:, D:].data_ptr(), VIS_L * 3 * D, 2 * D, n, 0, _st()),
                  'sf_reduce_groups_bf16')
             self._cls_bwd(qkv, dO_b, dqkv, n, VIS_L, VIS_L, do_seq_rows=VIS_L, accumulate=True)
@@ -378,7 +383,13 @@ class AVCLIPTrainer(FlatTrainer):
 
             def full_bwd(dO, q=s['qkv']):
                 dqkv = self._buf('dqkv', (M, 3 * D), torch.bfloat16)
-                self.attn_bwd_seq(q, dO, dqkv, n, L, H, HD)
+                if self.fused_attn_bwd:                                      # one 74 x 74 "group" per (segment, head), no CLS slot
+                    _chk(_lib.load().sf_attention_group_bwd(q.data_ptr(), q[:, D:].data_ptr(), q[:, 2 * D:].data_ptr(), q.stride(0), dO.data_ptr(),
+                                                            dO.stride(0), dqkv.data_ptr(), dqkv[:, D:].data_ptr(), dqkv[:, 2 * D:].data_ptr(),
+                                                            dqkv.stride(0), None, n, L, 1, 0, 0, 1, L, -1, H, HD, 0.125, _st()),
+                         'sf_attention_group_bwd')
+                else:
+                    self.attn_bwd_seq(q, dO, dqkv, n, L, H, HD)
                 return dqkv
             self._attn_branch_bwd(dx, M, p + '.attention.output.dense', s['att'], full_bwd, s['h1'], s['x'], p + '.layernorm_before', EPS_AST,
                                   [f'{p}.attention.attention.{nm}' for nm in ('query', 'key', 'value')])

@@ -355,3 +355,54 @@ def test_bucketed_gradient_allreduce_two_ranks(gpu):
         assert p.exitcode == 0
     assert all(r[1] and r[2] for r in res), res
     assert res[0][3] == res[1][3] and res[0][3] > 0                          # identical averaged gradients on both ranks
+
+
+def _group_attn_ref(qkv, dO, n, n_groups, n_tok, row0, group_stride, tok_stride, cls_row, L, heads=12):
+    """fp32 autograd reference of grouped attention: token i of group g at row row0 + g*group_stride + i*tok_stride attends
+    [CLS row (if any); the n_tok tokens of its group].  Returns d(qkv) from upstream dO (zero rows for the CLS query)."""
+    Dm = 768
+    x = qkv.float().view(n, L, 3, heads, 64).clone().requires_grad_(True)
+    idx = torch.tensor([[row0 + g * group_stride + i * tok_stride for i in range(n_tok)] for g in range(n_groups)])   # (G, T)
+    q = x[:, idx, 0]                                  # (n, G, T, H, 64)
+    k, v = x[:, idx, 1], x[:, idx, 2]
+    if cls_row >= 0:
+        kc = x[:, cls_row, 1][:, None, None].expand(n, n_groups, 1, heads, 64)
+        vc = x[:, cls_row, 2][:, None, None].expand(n, n_groups, 1, heads, 64)
+        k, v = torch.cat([kc, k], 2), torch.cat([vc, v], 2)
+    s = torch.einsum('ngihd,ngjhd->nghij', q, k) * 0.125
+    o = torch.einsum('nghij,ngjhd->ngihd', torch.softmax(s, -1), v)           # (n, G, T, H, 64)
+    go = dO.float().view(n, L, heads, 64)[:, idx]
+    o.backward(go)
+    return x.grad.view(n * L, 3 * Dm)
+
+
+@pytest.mark.parametrize('case', ['space', 'ast', 'time'])
+def test_attention_group_bwd(gpu, case):
+    """Fused MFMA backward (space / AST shapes) and the tiny-group VALU backward (time) against fp32 autograd of the same attention."""
+    n, Dm = 2, 768
+    if case == 'space':
+        L, kw, fn = 1569, dict(n_groups=8, row0=1, group_stride=196, tok_stride=1, n_tok=196, cls_row=0), 'sf_attention_group_bwd'
+    elif case == 'time':
+        L, kw, fn = 1569, dict(n_groups=196, row0=1, group_stride=1, tok_stride=196, n_tok=8, cls_row=0), 'sf_attention_tiny_bwd'
+    else:
+        L, kw, fn = 74, dict(n_groups=1, row0=0, group_stride=0, tok_stride=1, n_tok=74, cls_row=-1), 'sf_attention_group_bwd'
+    torch.manual_seed(3)
+    qkv = (torch.randn(n * L, 3 * Dm, device=gpu) * 0.8).bfloat16()
+    dO = (torch.randn(n * L, Dm, device=gpu) * 0.5).bfloat16()
+    dqkv = torch.zeros(n * L, 3 * Dm, device=gpu, dtype=torch.bfloat16)
+    part = torch.zeros(n * kw['n_groups'], 2 * Dm, device=gpu, dtype=torch.bfloat16)
+    rc = getattr(_lib(), fn)(qkv.data_ptr(), qkv[:, Dm:].data_ptr(), qkv[:, 2 * Dm:].data_ptr(), 3 * Dm, dO.data_ptr(), Dm, dqkv.data_ptr(),
+                             dqkv[:, Dm:].data_ptr(), dqkv[:, 2 * Dm:].data_ptr(), 3 * Dm, part.data_ptr(), n, L, kw['n_groups'], kw['row0'],
+                             kw['group_stride'], kw['tok_stride'], kw['n_tok'], kw['cls_row'], 12, 64, 0.125, _st())
+    assert rc == 0, _lib().sf_last_error()
+    if kw['cls_row'] >= 0:                                                   # CLS key / value gradient: sum over the groups
+        G = kw['n_groups']
+        rc = _lib().sf_reduce_groups_bf16(part.data_ptr(), G * 2 * Dm, 2 * Dm, G, dqkv[:, Dm:].data_ptr(), L * 3 * Dm, 2 * Dm, n, 0, _st())
+        assert rc == 0
+    ref = _group_attn_ref(qkv.cpu(), dO.cpu(), n, L=L, **kw)
+    got = dqkv.float().cpu()
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    print(f'{case}: max err {err:.4f} (scale {scale:.3f}), rel-L2 {rel:.4f}')
+    assert rel < 1.5e-2 and err < 3e-2 * scale
