@@ -292,7 +292,7 @@ extern "C" int sf_attention_tiny_bwd(const bf16_t* q, const bf16_t* k, const bf1
 
 // ------------------------------------------------------------------------------------------------------
 // Fused backward of the grouped attention for up to 208 keys, head_dim 64 (Motionformer space attention: 196 queries x [CLS; 196 keys];
-// AST: 74 x 74).  One 256-thread workgroup per (seq, group, head); K, V, Q, dO rows of the group are staged once in LDS (row-major,
+// AST: 74 x 74).  One 512-thread workgroup per (seq, group, head); K, V, Q, dO rows of the group are staged once in LDS (row-major,
 // 144-byte rows).  Everything runs on v_mfma_f32_16x16x16_bf16, whose C layout (lane: column l & 15, rows (l >> 4)*4 + r) IS its A / B
 // operand layout (lane: row l & 15, k = (l >> 4)*4 + e): a probability tile computed as S^T = K Q^T is directly the A operand
 // "rows = query, k = key" of dQ = dS K, and the same tile computed as S = Q K^T is directly the A operand "rows = key, k = query" of
@@ -306,7 +306,8 @@ extern "C" int sf_attention_tiny_bwd(const bf16_t* q, const bf16_t* k, const bf1
 #define GB_LD 72                 // bf16 per LDS row: 64 + 8 pad (144 B: 8-byte aligned fragments, 36-dword stride)
 #define GB_ROWS 208
 #define GB_MAT (GB_ROWS * GB_LD * 2)                       // 29,952 B per staged matrix
-#define GB_LDS (4 * GB_MAT + GB_ROWS * 3 * 4 + 4 * 16 * GB_LD * 2)
+#define GB_WAVES 8                // two waves per SIMD: the fragment reads are dependent LDS round trips, a second wave hides them
+#define GB_LDS (4 * GB_MAT + GB_ROWS * 3 * 4 + GB_WAVES * 16 * GB_LD * 2)
 
 __device__ __forceinline__ bf16x4 gb_row_frag(const bf16_t* X, int row, int k0) { return *reinterpret_cast<const bf16x4*>(X + row * GB_LD + k0); }
 __device__ __forceinline__ bf16x4 gb_col_frag(const bf16_t* X, int row0, int col) {
@@ -321,7 +322,7 @@ __device__ __forceinline__ bf16x4 gb_pack(const f32x4& v) {
   return r.f;
 }
 
-__global__ __launch_bounds__(256) void attn_group_bwd_kernel(AttnBwdArgs p) {
+__global__ __launch_bounds__(GB_WAVES * 64) void attn_group_bwd_kernel(AttnBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* Kr = reinterpret_cast<bf16_t*>(smem);
   bf16_t* Vr = Kr + GB_ROWS * GB_LD;
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256) void attn_group_bwd_kernel(AttnBwdArgs p) {
   auto tok_row = [&](int i) -> int64_t { return first + (int64_t)i * p.tok_stride; };
 
   // ---- stage K, V (key rows) and Q, dO (query rows): 208 rows x 8 chunks of 16 B each, zero beyond the valid rows -------------
-  for (int idx = tid; idx < GB_ROWS * 8; idx += 256) {
+  for (int idx = tid; idx < GB_ROWS * 8; idx += GB_WAVES * 64) {
     const int row = idx >> 3, ch = idx & 7;
     uint4 kk = make_uint4(0, 0, 0, 0), vv = kk, qq = kk, dd = kk;
     if (row < nk) {
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256) void attn_group_bwd_kernel(AttnBwdArgs p) {
   bf16_t* myout = outl + wave * 16 * GB_LD;
 
   // ---- pass 1: per query tile - statistics and dQ.  Tiles are S^T: lane's query = qt*16 + lr, its keys = kt*16 + lg*4 + r ---------
-  for (int qt = wave; qt < nqt; qt += 4) {
+  for (int qt = wave; qt < nqt; qt += GB_WAVES) {
     f32x4 sT[13], dpT[13];
     bf16x4 qf[4], df[4];
 #pragma unroll
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(256) void attn_group_bwd_kernel(AttnBwdArgs p) {
   __syncthreads();                                             // statistics of every query are in LDS
 
   // ---- pass 2: per key tile - dK, dV.  Tiles are S: lane's key = kt*16 + lr, its queries = qt*16 + lg*4 + r ----------------------
-  for (int kt = wave; kt < nkt; kt += 4) {
+  for (int kt = wave; kt < nkt; kt += GB_WAVES) {
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -519,7 +520,7 @@ extern "C" int sf_attention_group_bwd(const bf16_t* q, const bf16_t* k, const bf
   }
   const int64_t units = n_seq * n_groups * heads;
   SF_CHECK_ARG(units < ((int64_t)1 << 31), "sf_attention_group_bwd: too many groups");
-  hipLaunchKernelGGL(attn_group_bwd_kernel, dim3((unsigned)units), dim3(256), GB_LDS, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(attn_group_bwd_kernel, dim3((unsigned)units), dim3(GB_WAVES * 64), GB_LDS, (hipStream_t)stream, a);
   SF_LAUNCH_CHECK();
   return 0;
 }
