@@ -406,3 +406,21 @@ def test_attention_group_bwd(gpu, case):
     rel = ((got - ref).norm() / ref.norm()).item()
     print(f'{case}: max err {err:.4f} (scale {scale:.3f}), rel-L2 {rel:.4f}')
     assert rel < 1.5e-2 and err < 3e-2 * scale
+
+
+@pytest.mark.parametrize('kind', ['time', 'space'])
+def test_divided_bwd_fused_vs_gathered(gpu, kind):
+    """The dedicated attention-backward kernels against the gathered batched-GEMM formulation of the same trainer (two independent
+    implementations of the divided space-time attention backward, CLS key / CLS query handling included)."""
+    sd, tr, _, _ = _setup(gpu, 1, 1, 1.0)
+    n = 2
+    torch.manual_seed(11)
+    qkv = (torch.randn(n * 1569, 2304, device=gpu) * 0.7).bfloat16()
+    dO = (torch.randn(n * 1569, 768, device=gpu) * 0.3).bfloat16()
+    tr.fused_attn_bwd = True
+    a = tr._divided_bwd(qkv, dO, n, kind).float().clone()
+    tr.fused_attn_bwd = False
+    b = tr._divided_bwd(qkv, dO, n, kind).float().clone()
+    rel = ((a - b).norm() / b.norm()).item()
+    print(f'{kind}: fused vs gathered rel-L2 {rel:.4f}')
+    assert rel < 1.5e-2
