@@ -696,7 +696,19 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
     // big token GEMMs; the short-K fp32-residual projection (N = K = 768) is HBM-bound and prefers 2 workgroups/CU;
     // everything small (AST, aggregators, sync transformer, heads) and every mapped/ragged GEMM takes the 128x128 kernel.
     const bool big = fast && M >= 8192 && N >= 512;
-    cfg = !big ? 0 : ((res && K <= 1024) ? 0 : 7);
+    cfg = 0;
+    if (big && !(res && K <= 1024)) {
+      // Tile-round quantisation decides between the persistent 256x256 kernel (one workgroup per CU, ~8 % faster per tile pair when
+      // the chip is full) and the 128x128 kernel (two per CU): e.g. fc2 of a single clip is 86 x 3 = 258 big tiles = TWO rounds of
+      // 256 CUs at 50 % fill, but 1032 small tiles = 2.02 rounds of 512 slots.  Pick the better filled one (measured, M = 21,966 /
+      // 43,932: fc2 600 -> 803 / 766 -> 917 TFLOP/s; the 16-clip batch keeps the persistent kernel everywhere).
+      static int n_cu = 0;
+      if (!n_cu) { int dev = 0; hipDeviceProp_t prop; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256; }
+      const double t7 = (double)((M + 255) / 256) * (double)((N + 255) / 256), t0 = (double)((M + 127) / 128) * (double)((N + 127) / 128);
+      const double r7 = (double)(int64_t)((t7 + n_cu - 1) / n_cu), r0 = (double)(int64_t)((t0 + 2 * n_cu - 1) / (2 * n_cu));
+      const double e7 = t7 / (r7 * n_cu), e0 = t0 / (r0 * 2 * n_cu);
+      cfg = (e7 * 1.08 >= e0) ? 7 : 0;
+    }
   }
   switch (cfg) {
     case 0: return dispatch_gemm<Cfg0>(a, obf, gelu, res, fast, s);
