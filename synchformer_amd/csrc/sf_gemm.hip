@@ -39,6 +39,7 @@ struct GemmArgs {
   int64_t M;
   int N, K;
   uint32_t tiles_n, tiles_total;
+  uint32_t nchunk;   // persistent kernel: column tiles per sweep (0 = all)
   // strided batch (blockIdx.y = b0 * batch_inner + b1): element offsets added to A / W / C per batch index
   int batch_inner;
   int64_t sA0, sA1, sW0, sW1, sC0, sC1;
@@ -452,8 +453,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p
 
   // persistent schedule: block b sits on XCD b % 8; every XCD owns a contiguous tile range, N fastest
   const uint32_t xcd = blockIdx.x & 7u, li = blockIdx.x >> 3, per_xcd_blocks = gridDim.x >> 3;
-  const uint32_t t8 = (p.tiles_total + 7u) >> 3;                // tiles per XCD (last XCD may own fewer)
-  const uint32_t t_begin = xcd * t8, t_end = min(t_begin + t8, p.tiles_total);
+  // every XCD owns a contiguous range of 256-row panels and sweeps it once per CHUNK of `nchunk` column tiles (N fastest inside
+  // a chunk): the weight slice of a chunk (nchunk * 256 rows of W) stays L2-resident for the whole sweep
+  const uint32_t tiles_m = p.tiles_total / p.tiles_n;
+  const uint32_t mp8 = (tiles_m + 7u) >> 3;
+  const uint32_t mp0 = min(xcd * mp8, tiles_m), mp1 = min(mp0 + mp8, tiles_m), n_mp = mp1 - mp0;
+  const uint32_t gchunk = p.nchunk ? min(p.nchunk, p.tiles_n) : p.tiles_n;
+  const uint32_t n_chunks = (p.tiles_n + gchunk - 1) / gchunk, chunk_tiles = n_mp * gchunk;
+  const uint32_t t_begin = 0, t_end = n_mp * p.tiles_n;           // local tile index inside this XCD's range
 
   const int piece_row = lane >> 3, slot = lane & 7;
   // fragment read offsets (bytes) inside a tile for k-step kk: row-dependent swizzle is lane-constant
@@ -466,7 +473,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p
   const bf16_t* a_src[4];
   const bf16_t* b_src[4];
   auto set_tile = [&](uint32_t t, int64_t& m0, int& n0) {
-    const uint32_t tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+    const uint32_t c = min(t / chunk_tiles, n_chunks - 1), r = t - c * chunk_tiles;
+    const uint32_t gw = (c == n_chunks - 1) ? p.tiles_n - c * gchunk : gchunk;
+    const uint32_t tm = mp0 + r / gw, tn = c * gchunk + r % gw;
     m0 = (int64_t)tm * PBM; n0 = (int)tn * PBN;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -599,6 +608,14 @@ static int launch_gemm_persistent(GemmArgs a, hipStream_t s) {
   const int64_t total = tiles_m * a.tiles_n;
   if (total >= ((int64_t)1 << 31)) { sf_set_error("sf_gemm_bf16: too many tiles"); return -1; }
   a.tiles_total = (uint32_t)total;
+  // Column-chunked sweeps keep the weight slice of a sweep (nchunk * 256 * K bf16) within ~2.4 MB of the XCD's 4 MB L2, so that the
+  // streamed A panels and outputs stop evicting it: PMC on M = 351,456 - qkv 1912 -> 1132 MiB fetched per launch (518 algorithmic),
+  // fc1 5604 -> 1167, and +2-4 % speed (profiles/r01_gemm_configs.md).  Only for short K: with K = 3072 an A panel is 1.5 MB and
+  // re-reading it per sweep costs more than it saves (fc2 already fetches its algorithmic bytes).  SF_GEMM_NCHUNK overrides (experiments).
+  static int env_chunk = -2;
+  if (env_chunk == -2) { const char* e = getenv("SF_GEMM_NCHUNK"); env_chunk = e ? atoi(e) : -1; }
+  if (env_chunk >= 0) a.nchunk = (uint32_t)env_chunk;
+  else a.nchunk = a.K <= 1024 ? (uint32_t)(2400000 / (512 * a.K) > 0 ? 2400000 / (512 * a.K) : 1) : 0u;
   int64_t blocks = (n_cu / 8) * 8;                               // one workgroup per CU, a multiple of the 8 XCDs
   const int64_t need = ((total + 7) / 8) * 8;
   if (blocks > need) blocks = need;
@@ -686,7 +703,7 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldr;
   a.cmap = sf_rowmap(c_map); a.rmap = sf_rowmap(r_map);
   a.M = M; a.N = (int)N; a.K = (int)K;
-  a.tiles_n = 0; a.tiles_total = 0;
+  a.tiles_n = 0; a.tiles_total = 0; a.nchunk = 0;
   a.batch_inner = 0; a.sA0 = a.sA1 = a.sW0 = a.sW1 = a.sC0 = a.sC1 = 0;
   hipStream_t s = (hipStream_t)stream;
   const bool gelu = epilogue == SF_EPI_GELU, res = R != nullptr, obf = c_dtype == SF_BF16;
@@ -747,7 +764,7 @@ extern "C" int sf_gemm_bf16_batched(const bf16_t* A, int64_t lda, int64_t sA0, i
   GemmArgs a;
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.C = C; a.ldc = ldc; a.R = nullptr; a.ldr = 0;
   a.cmap = sf_rowmap(nullptr); a.rmap = sf_rowmap(nullptr);
-  a.M = M; a.N = (int)N; a.K = (int)K; a.tiles_n = 0; a.tiles_total = 0;
+  a.M = M; a.N = (int)N; a.K = (int)K; a.tiles_n = 0; a.tiles_total = 0; a.nchunk = 0;
   a.batch_inner = batch_inner; a.sA0 = sA0; a.sA1 = sA1; a.sW0 = sW0; a.sW1 = sW1; a.sC0 = sC0; a.sC1 = sC1;
   g_batch_count = (int64_t)batch_outer * batch_inner;
   // 64-deep stages when the contraction allows it (the split-K weight-gradient products of the train steps: K = chunks of 64 rows)
