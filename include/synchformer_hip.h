@@ -54,8 +54,9 @@ int sf_gemm_bf16_batched(const uint16_t* A, int64_t lda, int64_t sA0, int64_t sA
                          int64_t sW1, const float* bias, void* C, int c_dtype, int64_t ldc, int64_t sC0, int64_t sC1, int64_t M,
                          int64_t N, int64_t K, int batch_outer, int batch_inner, void* stream);
 
-/* Tuning / test hook: force the GEMM tile configuration for subsequent sf_gemm_bf16 calls of this process
- * (-1 = automatic choice by shape, 0 = 128x128x64 / 4 waves, 1 = 256x256x64 / 8 waves). */
+/* Tuning / test hook (process-global, not for production threads): force the GEMM tile configuration of subsequent sf_gemm_bf16
+ * calls.  -1 = automatic choice by shape (default); 0 = 128x128x64, 4 waves, two workgroups per CU; 7 = persistent 256x256x64,
+ * 8 waves, v_mfma_f32_32x32x16_bf16; 1-6, 8, 9 = the other tilings measured in profiles/r01_gemm_configs.md (tools/bench_gemm.py). */
 void sf_gemm_force_config(int cfg);
 
 /* y[omap(r), :] (=|+=) LayerNorm(x[imap(r), :]) * gamma + beta over 768 columns; x fp32, y bf16|fp32.
