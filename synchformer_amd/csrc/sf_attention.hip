@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t to
   for (int i = 0; i < 4; ++i) o[i] = sf_f32x2_t{0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
-    const float e = exp2f(s[j] - m);                             // 0 for the masked tail (s = -inf)
+    const float e = __builtin_amdgcn_exp2f(s[j] - m);                             // 0 for the masked tail (s = -inf)
     l += e;
     axpy8_bf16(o, e, vraw[j]);
   }
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t to
     for (int i = 0; i < 4; ++i) co[i] = sf_f32x2_t{0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-      const float e = exp2f(cs[j] - cm);
+      const float e = __builtin_amdgcn_exp2f(cs[j] - cm);
       cl += e;
       axpy8_bf16(co, e, vraw[j]);
     }
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(64) void attn_cls_combine64_kernel(const float* __r
   for (int i = 0; i < n_part; ++i) M = fmaxf(M, pp[i * 66]);
   float L = 0.f, O = 0.f;
   for (int i = 0; i < n_part; ++i) {
-    const float w = exp2f(pp[i * 66] - M);
+    const float w = __builtin_amdgcn_exp2f(pp[i * 66] - M);
     L += pp[i * 66 + 1] * w;
     O += pp[i * 66 + 2 + d] * w;
   }
