@@ -57,9 +57,16 @@ __device__ __forceinline__ void axpy8_bf16(sf_f32x2_t (&o)[4], float e, const ui
   }
 }
 
-__global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t total_units) {
-  const int lane = threadIdx.x & 63;
-  const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // (seq, group, head), head fastest
+// K/V (and the CLS query) are fetched ONCE per wave - lane (r, sub) loads 16 bytes of token r - and shared through 2.4 KB of
+// wave-private LDS; every query lane then reads key j's slice back with a broadcasting ds_read_b128.  Compared with each query
+// lane loading all 9 keys itself (18 vector loads per wave that are 8x redundant across lanes and 72 live registers) this is 4
+// vector loads and ~70 VGPRs, i.e. 7 waves per SIMD instead of 3: the kernel is bound by bytes in flight, not by VALU.
+#define TINY_SLOTS 9
+template <bool PART>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void attn_tiny64_kernel(AttnArgs p, int64_t total_units) {
+  __shared__ __attribute__((aligned(16))) uint4 lds_k[4][TINY_SLOTS][8], lds_v[4][TINY_SLOTS][8], lds_qc[4][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;                   // (seq, group, head), head fastest
   if (unit >= total_units) return;
   const int head = (int)(unit % p.heads);
   const int64_t sg = unit / p.heads;
@@ -69,34 +76,36 @@ __global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t to
   const int64_t seq_base = seq * p.seq_rows;
   const int64_t first = seq_base + p.row0 + (int64_t)g * p.group_stride;
   const int col = head * 64 + sub * 8;
-  const int qtok = qi < p.n_tok ? qi : p.n_tok - 1;                      // idle lanes shadow the last query
-  const uint4 qraw = *reinterpret_cast<const uint4*>(p.q + (first + (int64_t)qtok * p.tok_stride) * p.ld + col);
   const int has_cls = p.cls_row >= 0 ? 1 : 0;
   const int nk = p.n_tok + has_cls;
-  // all 2 x 9 key/value loads are issued before the first use (one memory round trip per wave)
-  uint4 kraw[9], vraw[9];
-#pragma unroll
-  for (int j = 0; j < 9; ++j) {
-    const int jj = j < nk ? j : nk - 1;
-    const int64_t row = (has_cls && jj == 0) ? seq_base + p.cls_row : first + (int64_t)(jj - has_cls) * p.tok_stride;
-    kraw[j] = *reinterpret_cast<const uint4*>(p.k + row * p.ld + col);
-    vraw[j] = *reinterpret_cast<const uint4*>(p.v + row * p.ld + col);
+  const int qtok = qi < p.n_tok ? qi : p.n_tok - 1;                      // idle lanes shadow the last token
+  const int64_t my_row = first + (int64_t)qtok * p.tok_stride;
+  const uint4 qraw = *reinterpret_cast<const uint4*>(p.q + my_row * p.ld + col);
+  const uint4 kraw = *reinterpret_cast<const uint4*>(p.k + my_row * p.ld + col);
+  const uint4 vraw = *reinterpret_cast<const uint4*>(p.v + my_row * p.ld + col);
+  if (has_cls && qi < (PART ? 3 : 2)) {                                  // lanes 0-7: CLS key, 8-15: CLS value, 16-23: CLS query
+    const bf16_t* src = qi == 0 ? p.k : (qi == 1 ? p.v : p.q);
+    const uint4 c = *reinterpret_cast<const uint4*>(src + (seq_base + p.cls_row) * p.ld + col);
+    if (qi == 0) lds_k[wave][0][sub] = c; else if (qi == 1) lds_v[wave][0][sub] = c; else lds_qc[wave][sub] = c;
   }
+  if (qi < p.n_tok) { lds_k[wave][has_cls + qi][sub] = kraw; lds_v[wave][has_cls + qi][sub] = vraw; }
   uint32_t keep_bits = 0x1ffu;                                   // token keep flags of the 9 key slots (masked entry point only)
   if (p.key_keep) {
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
+    for (int j = 0; j < TINY_SLOTS; ++j) {
       const int jj = j < nk ? j : nk - 1;
       const int64_t row = (has_cls && jj == 0) ? seq_base + p.cls_row : first + (int64_t)(jj - has_cls) * p.tok_stride;
       if (p.key_keep[row] == 0) keep_bits &= ~(1u << j);
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const float sc = p.scale * 1.44269504088896f;                 // softmax in base 2: exp(x) = exp2(x * log2 e)
-  float s[9];
+  float s[TINY_SLOTS];
   float m = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < 9; ++j) {
-    float d = dot8_bf16(qraw, kraw[j]);
+  for (int j = 0; j < TINY_SLOTS; ++j) {
+    const uint4 kk = lds_k[wave][j < nk ? j : nk - 1][sub];
+    float d = dot8_bf16(qraw, kk);
     d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
     s[j] = j < nk ? d * sc : -INFINITY;
     m = fmaxf(m, s[j]);
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t to
   if (keep_bits != 0x1ffu) {                                     // wave-uniform: only groups that actually contain a masked key
     m = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
+    for (int j = 0; j < TINY_SLOTS; ++j) {
       if (!((keep_bits >> j) & 1u)) s[j] = -INFINITY;
       m = fmaxf(m, s[j]);
     }
@@ -114,39 +123,10 @@ __global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t to
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = sf_f32x2_t{0.f, 0.f};
 #pragma unroll
-  for (int j = 0; j < 9; ++j) {
+  for (int j = 0; j < TINY_SLOTS; ++j) {
     const float e = __builtin_amdgcn_exp2f(s[j] - m);                             // 0 for the masked tail (s = -inf)
     l += e;
-    axpy8_bf16(o, e, vraw[j]);
-  }
-  if (p.cls_part) {
-    // the CLS query's share of this group: keys 1..n_tok (plus the CLS key itself in group 0 only)
-    const uint4 qc = *reinterpret_cast<const uint4*>(p.q + (seq_base + p.cls_row) * p.ld + col);
-    float cs[9], cm = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      float d = dot8_bf16(qc, kraw[j]);
-      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-      const bool use = j < nk && ((keep_bits >> j) & 1u) && !(j == 0 && g != 0);
-      cs[j] = use ? d * sc : -INFINITY;
-      cm = fmaxf(cm, cs[j]);
-    }
-    float cl = 0.f;
-    sf_f32x2_t co[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) co[i] = sf_f32x2_t{0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const float e = __builtin_amdgcn_exp2f(cs[j] - cm);
-      cl += e;
-      axpy8_bf16(co, e, vraw[j]);
-    }
-    if (qi == 0) {
-      float* part = p.cls_part + ((seq * p.heads + head) * p.n_groups + g) * 66;
-      if (sub == 0) { part[0] = cm; part[1] = cl; }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { part[2 + sub * 8 + 2 * t] = co[t].x; part[2 + sub * 8 + 2 * t + 1] = co[t].y; }
-    }
+    axpy8_bf16(o, e, lds_v[wave][j < nk ? j : nk - 1][sub]);
   }
   if (qi < p.n_tok) {
     const float inv = 1.0f / l;
@@ -154,6 +134,46 @@ __global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t to
     w.x = pack_bf2(o[0].x * inv, o[0].y * inv); w.y = pack_bf2(o[1].x * inv, o[1].y * inv);
     w.z = pack_bf2(o[2].x * inv, o[2].y * inv); w.w = pack_bf2(o[3].x * inv, o[3].y * inv);
     *reinterpret_cast<uint4*>(p.out + (first + (int64_t)qi * p.tok_stride) * p.ldo + col) = w;
+  }
+  if (PART) {
+    // the CLS query's share of this group: keys 1..n_tok (plus the CLS key itself in group 0 only).  Row group qi scores ITS token
+    // (k/v are the registers it loaded), the softmax state and the weighted values are then reduced across the eight row groups.
+    const uint4 qc = lds_qc[wave][sub];
+    float d = dot8_bf16(qc, lds_k[wave][has_cls + qtok][sub]);          // this row group's own token, back from LDS (keeps registers low)
+    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+    const float cs = (qi < p.n_tok && ((keep_bits >> (has_cls + qi)) & 1u)) ? d * sc : -INFINITY;
+    float c0 = -INFINITY;
+    if (has_cls && g == 0 && (keep_bits & 1u)) {                              // wave-uniform
+      float d0 = dot8_bf16(qc, lds_k[wave][0][sub]);
+      d0 += __shfl_xor(d0, 1, 64); d0 += __shfl_xor(d0, 2, 64); d0 += __shfl_xor(d0, 4, 64);
+      c0 = d0 * sc;
+    }
+    float cm = cs;
+    cm = fmaxf(cm, __shfl_xor(cm, 8, 64)); cm = fmaxf(cm, __shfl_xor(cm, 16, 64)); cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+    cm = fmaxf(cm, c0);
+    const float e = __builtin_amdgcn_exp2f(cs - cm);
+    float cl = e;
+    sf_f32x2_t co[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) co[i] = sf_f32x2_t{0.f, 0.f};
+    axpy8_bf16(co, e, lds_v[wave][has_cls + qtok][sub]);
+#pragma unroll
+    for (int sh = 8; sh < 64; sh <<= 1) {
+      cl += __shfl_xor(cl, sh, 64);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { co[i].x += __shfl_xor(co[i].x, sh, 64); co[i].y += __shfl_xor(co[i].y, sh, 64); }
+    }
+    if (c0 != -INFINITY) {                                                     // wave-uniform
+      const float e0 = __builtin_amdgcn_exp2f(c0 - cm);
+      cl += e0;
+      axpy8_bf16(co, e0, lds_v[wave][0][sub]);
+    }
+    if (qi == 0) {
+      float* part = p.cls_part + ((seq * p.heads + head) * p.n_groups + g) * 66;
+      if (sub == 0) { part[0] = cm; part[1] = cl; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { part[2 + sub * 8 + 2 * t] = co[t].x; part[2 + sub * 8 + 2 * t + 1] = co[t].y; }
+    }
   }
 }
 
@@ -623,7 +643,7 @@ __global__ __launch_bounds__(256) void attn_cls64_kernel(ClsArgs p) {
                                  // banks {0,42,20,62,...} (mod 64), all even and distinct: the 8-byte fragment reads of a 16-lane group are
                                  // conflict-free.  212 (not 228) keeps K + V^T at 53,760 B so THREE workgroups fit the 160 KiB LDS of a CU.
 #ifndef SF_ATT_ABL
-#define SF_ATT_ABL 0             // tools/ablate_attention.sh only: 1 skip stores, 2 skip P V, 4 skip softmax
+#define SF_ATT_ABL 0             // tools/ablate_attention.sh only: 1 skip stores, 2 skip P V, 4 skip softmax, 8 one query tile per wave
 #endif
 
 template <int D>
@@ -670,10 +690,15 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
   // loop iteration (the first version's runtime-trip-count staging loops serialised load -> wait -> ds_write).
   const int fr = lane & 15, fg = lane >> 4;
   constexpr int MAXQ = (NKT + 3) / 4;                             // query tiles per wave (nq <= nk)
+  // Query tile qt goes to wave (qt - rot) & 3.  With 13 tiles one wave gets four and the others three; wave w of every workgroup sits on
+  // SIMD w, so without the rotation SIMD 0 of each CU would carry 4/3 of the work of the others.  rot differs between workgroups that
+  // share a CU whichever way the dispatcher fills it (neighbouring ids of one XCD, or ids 32 apart).
+  const int xw = blockIdx.x >> 3;
+  const int wq = (wave + xw + (xw >> 5)) & 3;
   bf16x8 qf[MAXQ][D / 32];
 #pragma unroll
   for (int t = 0; t < MAXQ; ++t) {
-    const int qt = wave + 4 * t;
+    const int qt = wq + 4 * t;
     int qi = qt * 16 + fr;
     const bool is_cls_q = do_cls && qi == nq;                      // the free slot right after the last query holds the CLS query
     if (qi > nq - 1) qi = nq - 1;                                  // clamp (also for tiles beyond nqt: harmless reload)
@@ -737,8 +762,8 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
 
 #pragma unroll
   for (int t = 0; t < MAXQ; ++t) {
-    const int qt = wave + 4 * t;
-    if (qt >= nqt) break;
+    const int qt = wq + 4 * t;
+    if (qt >= nqt || ((SF_ATT_ABL & 8) && t >= 1)) break;
 
     // ---- S^T tiles -------------------------------------------------------------------------------------
     f32x4 s[NKT];
@@ -944,7 +969,8 @@ static int attention_impl(const bf16_t* q, const bf16_t* k, const bf16_t* v, int
   hipStream_t s = (hipStream_t)stream;
   if (head_dim == 64 && n_tok <= 8) {
     const int64_t units = n_seq * n_groups * heads;
-    hipLaunchKernelGGL(attn_tiny64_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a, units);
+    if (cls_partial) hipLaunchKernelGGL(attn_tiny64_kernel<true>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a, units);
+    else hipLaunchKernelGGL(attn_tiny64_kernel<false>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, a, units);
     SF_LAUNCH_CHECK();
     return 0;
   }
