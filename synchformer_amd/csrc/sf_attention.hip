@@ -639,20 +639,20 @@ __global__ __launch_bounds__(256) void attn_cls64_kernel(ClsArgs p) {
 // the V^T fragments are read from LDS with the same permutation (two 8-byte reads per fragment).
 // ======================================================================================================
 #define ATT_MAX_KT 13            // 13 x 16 = 208 keys / queries max
-#define ATT_VT_LD 212            // V^T row stride in keys (bf16): 424 B = 106 dwords; 16 consecutive rows start 106 dwords apart ->
-                                 // banks {0,42,20,62,...} (mod 64), all even and distinct: the 8-byte fragment reads of a 16-lane group are
-                                 // conflict-free.  212 (not 228) keeps K + V^T at 53,760 B so THREE workgroups fit the 160 KiB LDS of a CU.
 #ifndef SF_ATT_ABL
 #define SF_ATT_ABL 0             // tools/ablate_attention.sh only: 1 skip stores, 2 skip P V, 4 skip softmax, 8 one query tile per wave
 #endif
+
+typedef short att_s4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) att_s4 att_lds_s4;
 
 template <int D>
 struct AttLds {
   static constexpr int K_LD = (D == 64) ? 128 : (D * 2 + 16);   // bytes per K row (D=64: XOR-swizzled 128 B rows)
   static constexpr int K_BYTES = 208 * K_LD;
-  static constexpr int VT_BYTES = D * ATT_VT_LD * 2;
+  static constexpr int V_BYTES = K_BYTES;                         // V is staged row-major exactly like K; the P V operand is read with ds_read_b64_tr_b16
   static constexpr int MASK_BYTES = 208;                          // one keep-flag byte per key slot (used only with a key mask)
-  static constexpr int TOTAL = K_BYTES + VT_BYTES + MASK_BYTES;
+  static constexpr int TOTAL = K_BYTES + V_BYTES + MASK_BYTES;    // D = 64: 53,456 B -> three workgroups per CU
 };
 
 template <int D>
@@ -665,7 +665,7 @@ template <int D, int NKT>
 __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_lds = smem;
-  bf16_t* vt_lds = reinterpret_cast<bf16_t*>(smem + AttLds<D>::K_BYTES);
+  char* v_lds = smem + AttLds<D>::K_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int head = blockIdx.x % p.heads;
   const int64_t sg = blockIdx.x / p.heads;
@@ -683,6 +683,18 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
 
   auto key_row = [&](int j) -> int64_t {
     return (has_cls && j == 0) ? seq_base + p.cls_row : first + (int64_t)(j - has_cls) * p.tok_stride;
+  };
+  // Addressing: everything this workgroup touches lies inside ONE sequence, so rows are addressed as 32-bit element offsets from the
+  // (wave-uniform, scalar) sequence base - one 24-bit multiply per row instead of 64-bit multiply-adds (the prologue was ~30 % of the
+  // VALU time of a wave, a quarter of it quarter-rate integer multiplies).  The host checks seq_rows * ld < 2^31 and ld < 2^24.
+  const bf16_t* qb = p.q + seq_base * p.ld + hcol;
+  const bf16_t* kb = p.k + seq_base * p.ld + hcol;
+  const bf16_t* vb_ = p.v + seq_base * p.ld + hcol;
+  const uint32_t ld32 = (uint32_t)p.ld;
+  const int rel_first = p.row0 + g * p.group_stride;              // first token row of the group, relative to the sequence
+  auto key_off = [&](int j) -> uint32_t {                         // element offset of key/value row j (callers clamp j to nk - 1)
+    const int r = (has_cls && j == 0) ? p.cls_row : rel_first + __mul24(j - has_cls, p.tok_stride);
+    return __umul24((uint32_t)r, ld32);
   };
 
   // ---- all global loads of this workgroup are issued up front (Q fragments of this wave's query tiles, then the
@@ -702,10 +714,9 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
     int qi = qt * 16 + fr;
     const bool is_cls_q = do_cls && qi == nq;                      // the free slot right after the last query holds the CLS query
     if (qi > nq - 1) qi = nq - 1;                                  // clamp (also for tiles beyond nqt: harmless reload)
-    const bf16_t* qrow = is_cls_q ? p.q + (seq_base + p.cls_row) * p.ld + hcol
-                                  : p.q + (first + (int64_t)qi * p.tok_stride) * p.ld + hcol;
+    const uint32_t qoff = __umul24((uint32_t)(is_cls_q ? p.cls_row : rel_first + __mul24(qi, p.tok_stride)), ld32) + fg * 8;
 #pragma unroll
-    for (int ks = 0; ks < D / 32; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 32 + fg * 8);
+    for (int ks = 0; ks < D / 32; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8*>(qb + qoff + ks * 32);
   }
   constexpr int K_IT = (NKT * 16 * CH + 255) / 256;               // 16-B K chunks per thread
   uint4 kreg[K_IT];
@@ -713,50 +724,40 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
   for (int it = 0; it < K_IT; ++it) {
     const int idx = tid + it * 256, row = idx / CH, ch = idx - row * CH;
     kreg[it] = make_uint4(0, 0, 0, 0);
-    if (row < nk) kreg[it] = *reinterpret_cast<const uint4*>(p.k + key_row(row) * p.ld + hcol + ch * 8);
+    if (row < nk) kreg[it] = *reinterpret_cast<const uint4*>(kb + key_off(row) + ch * 8);
   }
-  // V^T: vt[d][key] written as dwords holding keys (2*pp, 2*pp+1); 32 consecutive pairs per half-wave -> conflict-free
-  // b32 stores; (pair, chunk) tasks: chunk = (wave*2 + half) + 8*c, pair = pp_l + 32*b
-  const int pp_l = lane & 31, half = lane >> 5;
-  constexpr int V_PB = (((NKT + 1) / 2) * 16 + 31) / 32;          // pair blocks (<= 4), CH/8 chunk rounds
-  constexpr int V_CR = (CH + 7) / 8;
-  uint4 vreg[V_PB][V_CR][2];
+  // V rows are fetched and staged exactly like K rows (whole 128-byte rows per 8 lanes; zero beyond nk, because P = 0 there must meet
+  // finite values).  The first version transposed V in registers (each wave fetched a 32-byte slice of every row - four 32-byte
+  // requests per cache line - and wrote V^T with 64 ds_write_b32 per thread).
+  uint4 vreg[K_IT];
 #pragma unroll
-  for (int b = 0; b < V_PB; ++b)
-#pragma unroll
-    for (int c = 0; c < V_CR; ++c) {
-      const int pp = pp_l + 32 * b, ch = wave * 2 + half + 8 * c;
-      vreg[b][c][0] = make_uint4(0, 0, 0, 0); vreg[b][c][1] = make_uint4(0, 0, 0, 0);
-      if (ch < CH) {
-        if (2 * pp < nk) vreg[b][c][0] = *reinterpret_cast<const uint4*>(p.v + key_row(2 * pp) * p.ld + hcol + ch * 8);
-        if (2 * pp + 1 < nk) vreg[b][c][1] = *reinterpret_cast<const uint4*>(p.v + key_row(2 * pp + 1) * p.ld + hcol + ch * 8);
-      }
-    }
+  for (int it = 0; it < K_IT; ++it) {
+    const int idx = tid + it * 256, row = idx / CH, ch = idx - row * CH;
+    vreg[it] = make_uint4(0, 0, 0, 0);
+    if (row < nk) vreg[it] = *reinterpret_cast<const uint4*>(vb_ + key_off(row) + ch * 8);
+  }
 #pragma unroll
   for (int it = 0; it < K_IT; ++it) {
     const int idx = tid + it * 256, row = idx / CH, ch = idx - row * CH;
     if (row < nkt * 16) *reinterpret_cast<uint4*>(k_lds + k_lds_off<D>(row, ch)) = kreg[it];
   }
-  uint8_t* m_lds = reinterpret_cast<uint8_t*>(smem + AttLds<D>::K_BYTES + AttLds<D>::VT_BYTES);
+  uint8_t* m_lds = reinterpret_cast<uint8_t*>(smem + AttLds<D>::K_BYTES + AttLds<D>::V_BYTES);
   if (p.key_keep && tid < 208) m_lds[tid] = tid < nk ? p.key_keep[key_row(tid)] : (uint8_t)0;
+#pragma unroll
+  for (int it = 0; it < K_IT; ++it) {
+    const int idx = tid + it * 256, row = idx / CH, ch = idx - row * CH;
+    if (row < nkt * 16) *reinterpret_cast<uint4*>(v_lds + k_lds_off<D>(row, ch)) = vreg[it];
+  }
+  // P V operand: the A fragment of v_mfma_f32_16x16x32_bf16 is V^T (16 dims x 32 key slots), lane (fr, fg) holding dim dt*16 + fr of key
+  // slots fg*8 .. +7 = keys 32 kk + 4 fg + {0..3} and 32 kk + 16 + 4 fg + {0..3} (the order P comes out of the S^T tiles in).
+  // ds_read_b64_tr_b16 transposes a 4 x 16 block inside each 16-lane group: lane i receives element (i & 3) of lanes (i >> 2) + 4 j,
+  // j = 0..3, so lane (fr, fg) points at the 8 bytes V[key 32 kk + 4 fg + (fr >> 2)][dt*16 + 4 (fr & 3) .. +3] and gets back
+  // V[32 kk + 4 fg + 0..3][dt*16 + fr].  (key & 7) is lane-constant, so the swizzled chunk offsets are computed once per dim tile.
+  int v_off[D / 16];
   {
-    const int npairs = ((nkt + 1) >> 1) * 16;                     // key pairs covering all 32-key PV steps (zero beyond nk)
+    const int krow = fg * 4 + (fr >> 2), c1 = (fr & 3) >> 1, hb = (fr & 1) * 8;
 #pragma unroll
-    for (int b = 0; b < V_PB; ++b)
-#pragma unroll
-      for (int c = 0; c < V_CR; ++c) {
-        const int pp = pp_l + 32 * b, ch = wave * 2 + half + 8 * c;
-        if (ch < CH && pp < npairs && pp < ATT_VT_LD / 2) {
-          const uint32_t a4[4] = {vreg[b][c][0].x, vreg[b][c][0].y, vreg[b][c][0].z, vreg[b][c][0].w};
-          const uint32_t b4[4] = {vreg[b][c][1].x, vreg[b][c][1].y, vreg[b][c][1].z, vreg[b][c][1].w};
-          uint32_t* dst = reinterpret_cast<uint32_t*>(vt_lds) + pp;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            dst[(ch * 8 + 2 * e) * (ATT_VT_LD / 2)] = (a4[e] & 0xffffu) | (b4[e] << 16);
-            dst[(ch * 8 + 2 * e + 1) * (ATT_VT_LD / 2)] = (a4[e] >> 16) | (b4[e] & 0xffff0000u);
-          }
-        }
-      }
+    for (int dt = 0; dt < D / 16; ++dt) v_off[dt] = k_lds_off<D>(krow, dt * 2 + c1) + hb;
   }
   __syncthreads();
 
@@ -834,11 +835,11 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
         } else { pa.u[2] = 0; pa.u[3] = 0; }
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt) {
-          const bf16_t* vrow = vt_lds + (dt * 16 + fr) * ATT_VT_LD + kk * 32 + fg * 4;
-          union { bf16x8 v; uint2 h[2]; } vb;
-          vb.h[0] = *reinterpret_cast<const uint2*>(vrow);
-          vb.h[1] = make_uint2(0u, 0u);
-          if (2 * kk + 1 < NKT) vb.h[1] = *reinterpret_cast<const uint2*>(vrow + 16);   // no 14th key tile: P is zero there, skip the read
+          union { bf16x8 v; att_s4 h[2]; } vb;
+          vb.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4*)(v_lds + v_off[dt] + kk * 32 * AttLds<D>::K_LD));
+          vb.h[1] = att_s4{0, 0, 0, 0};
+          if (2 * kk + 1 < NKT)                                                       // no 14th key tile: P is zero there, skip the read
+            vb.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4*)(v_lds + v_off[dt] + (kk * 32 + 16) * AttLds<D>::K_LD));
           o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb.v, pa.v, o[dt], 0, 0, 0);   // O^T tile: (d, query)
         }
       }
@@ -856,7 +857,7 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
         for (int r = 0; r < 4; ++r) part[2 + dt * 16 + fg * 4 + r] = o[dt][r];
     }
     if ((SF_ATT_ABL & 1) ? (linv == 1.2345e30f) : (qo < nq)) {
-      bf16_t* orow = p.out + (first + (int64_t)qo * p.tok_stride) * p.ldo + hcol + fg * 4;
+      bf16_t* orow = p.out + seq_base * p.ldo + hcol + (__umul24((uint32_t)(rel_first + __mul24(qo, p.tok_stride)), (uint32_t)p.ldo) + fg * 4);
 #pragma unroll
       for (int dt = 0; dt < D / 16; ++dt) {
         uint2 w;
@@ -961,6 +962,8 @@ static int attention_impl(const bf16_t* q, const bf16_t* k, const bf16_t* v, int
                "sf_attention: pointers must be 16-byte aligned");
   SF_CHECK_ARG(n_tok >= 1 && n_tok + (cls_row >= 0 ? 1 : 0) <= ATT_MAX_KT * 16, "sf_attention: n_tok %d out of range", n_tok);
   SF_CHECK_ARG(n_groups >= 1 && heads >= 1, "sf_attention: bad group/head count");
+  SF_CHECK_ARG(seq_rows >= 1 && seq_rows < (1 << 24) && ld < (1 << 24) && ldo < (1 << 24) && seq_rows * ld < ((int64_t)1 << 31) && seq_rows * ldo < ((int64_t)1 << 31),
+               "sf_attention: a sequence must span < 2^31 elements (32-bit row offsets inside a sequence)");
   if (n_seq <= 0) return 0;
   AttnArgs a;
   a.q = q; a.k = k; a.v = v; a.ld = ld; a.out = out; a.ldo = ldo; a.seq_rows = seq_rows;
