@@ -317,8 +317,8 @@ extern "C" int sf_attention_tiny_bwd(const bf16_t* q, const bf16_t* k, const bf1
 // operand layout (lane: row l & 15, k = (l >> 4)*4 + e): a probability tile computed as S^T = K Q^T is directly the A operand
 // "rows = query, k = key" of dQ = dS K, and the same tile computed as S = Q K^T is directly the A operand "rows = key, k = query" of
 // dK = dS^T Q and dV = P^T dO - so P and dS never go through LDS; computing the score / dP tiles twice (once per layout) is cheaper
-// than transposing them.  B operands that contract over keys or queries are column fragments of the row-major LDS copies (four
-// 2-byte reads).
+// than transposing them.  B operands that contract over keys or queries are column fragments of the row-major LDS copies, read
+// with ds_read_b64_tr_b16.
 //   pass 1 (query tiles over the waves): softmax statistics per query (max, 1/sum, delta = sum_j p dp) -> LDS, and dQ;
 //   pass 2 (key tiles over the waves):   dK and dV, with p = exp2(s*c - m) / l rebuilt from the statistics.
 // The CLS key's dk | dv share goes to cls_part like in the tiny-group kernel.
@@ -330,11 +330,14 @@ extern "C" int sf_attention_tiny_bwd(const bf16_t* q, const bf16_t* k, const bf1
 #define GB_LDS (4 * GB_MAT + GB_ROWS * 3 * 4 + GB_WAVES * 16 * GB_LD * 2)
 
 __device__ __forceinline__ bf16x4 gb_row_frag(const bf16_t* X, int row, int k0) { return *reinterpret_cast<const bf16x4*>(X + row * GB_LD + k0); }
-__device__ __forceinline__ bf16x4 gb_col_frag(const bf16_t* X, int row0, int col) {
-  bf16x4 f;
-  f[0] = (short)X[(row0 + 0) * GB_LD + col]; f[1] = (short)X[(row0 + 1) * GB_LD + col];
-  f[2] = (short)X[(row0 + 2) * GB_LD + col]; f[3] = (short)X[(row0 + 3) * GB_LD + col];
-  return f;
+// Column fragment X[row0 + 0..3][col0 + lr] of a row-major LDS matrix (lane = 16*lg + lr; row0 is the same for the 16 lanes of a group)
+// with ONE ds_read_b64_tr_b16: the lane points at the 8 bytes X[row0 + (lr >> 2)][col0 + 4*(lr & 3) .. +3] and the hardware hands lane i
+// element (i & 3) of lanes (i >> 2) + 4 j (was: four 2-byte reads + packing per fragment).
+typedef short gb_s4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4 gb_col_frag(const bf16_t* X, int row0, int col0, int lr) {
+  const bf16_t* src = X + (row0 + (lr >> 2)) * GB_LD + col0 + (lr & 3) * 4;
+  const gb_s4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gb_s4*)src);
+  return __builtin_bit_cast(bf16x4, r);
 }
 __device__ __forceinline__ bf16x4 gb_pack(const f32x4& v) {
   union { bf16x4 f; uint32_t u[2]; } r;
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(GB_WAVES * 64) void attn_group_bwd_kernel(AttnBwdAr
         const bf16x4 dsf = gb_pack(ds);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
-          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsf, gb_col_frag(Kr, kt * 16 + lg * 4, dt * 16 + lr), dq[dt], 0, 0, 0);
+          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsf, gb_col_frag(Kr, kt * 16 + lg * 4, dt * 16, lr), dq[dt], 0, 0, 0);
       }
     }
     // dq[dt][r] = dQ[query qt*16 + lg*4 + r][d = dt*16 + lr] -> staging -> 16-byte row stores
@@ -491,8 +494,8 @@ __global__ __launch_bounds__(GB_WAVES * 64) void attn_group_bwd_kernel(AttnBwdAr
       const bf16x4 pf = gb_pack(pp), dsf = gb_pack(ds);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pf, gb_col_frag(Dr, qt * 16 + lg * 4, dt * 16 + lr), dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsf, gb_col_frag(Qr, qt * 16 + lg * 4, dt * 16 + lr), dk[dt], 0, 0, 0);
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pf, gb_col_frag(Dr, qt * 16 + lg * 4, dt * 16, lr), dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsf, gb_col_frag(Qr, qt * 16 + lg * 4, dt * 16, lr), dk[dt], 0, 0, 0);
       }
     }
     // dk[dt][r] = dK[key kt*16 + lg*4 + r][d = dt*16 + lr]: two staging rounds (dk, then dv)
