@@ -57,101 +57,110 @@ extern "C" int sf_reduce_groups_bf16(const uint16_t* in, int64_t in_seq_stride, 
 //   s_j = scale <q, k_j>, p = softmax(s), o = sum_j p_j v_j
 //   dp_j = <dO, v_j>, ds_j = p_j (dp_j - sum_i p_i dp_i)
 //   dq = scale sum_j ds_j k_j        dk_j (=|+=) scale ds_j q        dv_j (=|+=) p_j dO
+// Eight lanes per key: lane (key slot = tid >> 3, chunk = tid & 7) owns 8 of the 64 head dims, so every K / V / dK / dV row is touched as
+// one whole 128-byte line by 8 neighbouring lanes (the first version ran one THREAD per key: every 16-byte load of a wave hit 64
+// different cache lines, eight times over, and each thread carried a 64-register dq accumulator).  Scores use v_dot2c_f32_bf16.
 #define CLSB_MAX_KEYS 2048
-__global__ __launch_bounds__(256) void attention_cls_bwd_kernel(const bf16_t* __restrict__ q, int64_t q_seq_rows, int q_row, const bf16_t* __restrict__ k,
-                                                                const bf16_t* __restrict__ v, int64_t ld, int64_t kv_seq_rows, int kv_row0, int n_keys,
-                                                                const bf16_t* __restrict__ dO, int64_t lddo, int64_t do_seq_rows, int do_row,
-                                                                bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t ldg,
-                                                                int heads, float scale, int accumulate_kv) {
-  __shared__ float qs[64], dos[64], s_l[CLSB_MAX_KEYS], dp_l[CLSB_MAX_KEYS], red[8], dq_part[4][64];
+#define CLSB_THREADS 512
+typedef __attribute__((ext_vector_type(2))) __bf16 clsb_bf2;
+__device__ __forceinline__ float clsb_dot8(const uint4& a, const uint4& b) {
+  float d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(clsb_bf2, a.x), __builtin_bit_cast(clsb_bf2, b.x), 0.f, false);
+  d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(clsb_bf2, a.y), __builtin_bit_cast(clsb_bf2, b.y), d, false);
+  d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(clsb_bf2, a.z), __builtin_bit_cast(clsb_bf2, b.z), d, false);
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(clsb_bf2, a.w), __builtin_bit_cast(clsb_bf2, b.w), d, false);
+}
+__device__ __forceinline__ void clsb_unpack8(const uint4& u, float* f) {
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+
+__global__ __launch_bounds__(CLSB_THREADS) void attention_cls_bwd_kernel(const bf16_t* __restrict__ q, int64_t q_seq_rows, int q_row, const bf16_t* __restrict__ k,
+                                                                         const bf16_t* __restrict__ v, int64_t ld, int64_t kv_seq_rows, int kv_row0, int n_keys,
+                                                                         const bf16_t* __restrict__ dO, int64_t lddo, int64_t do_seq_rows, int do_row,
+                                                                         bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t ldg,
+                                                                         int heads, float scale, int accumulate_kv) {
+  constexpr int NW = CLSB_THREADS / 64, KSLOTS = CLSB_THREADS / 8;
+  __shared__ float s_l[CLSB_MAX_KEYS], dp_l[CLSB_MAX_KEYS], red[2 * NW], dq_part[NW][64];
   const int seq = blockIdx.x / heads, h = blockIdx.x % heads;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ks = tid >> 3, ch = tid & 7;
   const int64_t qr = (int64_t)seq * q_seq_rows + q_row;
   const int64_t kr0 = (int64_t)seq * kv_seq_rows + kv_row0;
-  if (tid < 64) qs[tid] = bf2f(q[qr * ld + h * 64 + tid]);
-  else if (tid < 128) dos[tid - 64] = bf2f(dO[((int64_t)seq * do_seq_rows + do_row) * lddo + h * 64 + (tid - 64)]);
-  __syncthreads();
-  // pass 1: scores and dp, thread per key
+  const uint4 qraw = *(const uint4*)(q + qr * ld + h * 64 + ch * 8);                                        // this lane's 8 dims of q and dO
+  const uint4 doraw = *(const uint4*)(dO + ((int64_t)seq * do_seq_rows + do_row) * lddo + h * 64 + ch * 8);
+  // pass 1: scores and dp
   float mx = -INFINITY;
-  for (int j = tid; j < n_keys; j += 256) {
-    const bf16_t* kp = k + (kr0 + j) * ld + h * 64;
-    const bf16_t* vp = v + (kr0 + j) * ld + h * 64;
-    float s = 0.f, dp = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const uint4 kk = *(const uint4*)(kp + c * 8), vv = *(const uint4*)(vp + c * 8);
-      const uint32_t kw[4] = {kk.x, kk.y, kk.z, kk.w}, vw[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        s += qs[c * 8 + 2 * e] * __uint_as_float(kw[e] << 16) + qs[c * 8 + 2 * e + 1] * __uint_as_float(kw[e] & 0xffff0000u);
-        dp += dos[c * 8 + 2 * e] * __uint_as_float(vw[e] << 16) + dos[c * 8 + 2 * e + 1] * __uint_as_float(vw[e] & 0xffff0000u);
-      }
-    }
+  for (int j = ks; j < n_keys; j += KSLOTS) {
+    const uint4 kk = *(const uint4*)(k + (kr0 + j) * ld + h * 64 + ch * 8), vv = *(const uint4*)(v + (kr0 + j) * ld + h * 64 + ch * 8);
+    float s = clsb_dot8(qraw, kk), dp = clsb_dot8(doraw, vv);
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    dp += __shfl_xor(dp, 1, 64); dp += __shfl_xor(dp, 2, 64); dp += __shfl_xor(dp, 4, 64);
     s *= scale;
-    s_l[j] = s; dp_l[j] = dp;
+    if (ch == 0) { s_l[j] = s; dp_l[j] = dp; }
     mx = fmaxf(mx, s);
   }
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
   __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  mx = red[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
   float sum = 0.f, pd = 0.f;
-  for (int j = tid; j < n_keys; j += 256) {
+  for (int j = tid; j < n_keys; j += CLSB_THREADS) {
     const float p = __expf(s_l[j] - mx);
     s_l[j] = p;
     sum += p; pd += p * dp_l[j];
   }
   sum = wave_sum(sum); pd = wave_sum(pd);
-  __syncthreads();                                   // everyone has read red[0..3]
-  if (lane == 0) { red[wave] = sum; red[4 + wave] = pd; }
+  __syncthreads();                                   // everyone has read red[0..NW)
+  if (lane == 0) { red[wave] = sum; red[NW + wave] = pd; }
   __syncthreads();
-  const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
-  const float Dsum = ((red[4] + red[5]) + (red[6] + red[7])) * inv;      // sum_i p_i dp_i
-  // pass 2: per-key gradients; dq partials in registers
-  float dqa[64];
+  float tot = 0.f, totd = 0.f;
 #pragma unroll
-  for (int d = 0; d < 64; ++d) dqa[d] = 0.f;
-  for (int j = tid; j < n_keys; j += 256) {
+  for (int w = 0; w < NW; ++w) { tot += red[w]; totd += red[NW + w]; }
+  const float inv = 1.0f / tot;
+  const float Dsum = totd * inv;                                         // sum_i p_i dp_i
+  // pass 2: per-key gradients; this lane's 8 dims of dq accumulate over its keys
+  float qf[8], dof[8], dqa[8];
+  clsb_unpack8(qraw, qf); clsb_unpack8(doraw, dof);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dqa[e] = 0.f;
+  for (int j = ks; j < n_keys; j += KSLOTS) {
     const float p = s_l[j] * inv;
     const float ds = p * (dp_l[j] - Dsum) * scale;
-    const bf16_t* kp = k + (kr0 + j) * ld + h * 64;
-    bf16_t* dkp = dk + (kr0 + j) * ldg + h * 64;
-    bf16_t* dvp = dv + (kr0 + j) * ldg + h * 64;
+    const uint4 kk = *(const uint4*)(k + (kr0 + j) * ld + h * 64 + ch * 8);
+    bf16_t* dkp = dk + (kr0 + j) * ldg + h * 64 + ch * 8;
+    bf16_t* dvp = dv + (kr0 + j) * ldg + h * 64 + ch * 8;
+    float kf[8], gk[8], gv[8];
+    clsb_unpack8(kk, kf);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const uint4 kk = *(const uint4*)(kp + c * 8);
-      const uint32_t kw[4] = {kk.x, kk.y, kk.z, kk.w};
-      float gk[8], gv[8];
+    for (int e = 0; e < 8; ++e) { dqa[e] += ds * kf[e]; gk[e] = ds * qf[e]; gv[e] = p * dof[e]; }
+    if (accumulate_kv) {
+      float ok[8], ov[8];
+      clsb_unpack8(*(const uint4*)dkp, ok); clsb_unpack8(*(const uint4*)dvp, ov);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        dqa[c * 8 + 2 * e] += ds * __uint_as_float(kw[e] << 16);
-        dqa[c * 8 + 2 * e + 1] += ds * __uint_as_float(kw[e] & 0xffff0000u);
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { gk[e] = ds * qs[c * 8 + e]; gv[e] = p * dos[c * 8 + e]; }
-      if (accumulate_kv) {
-        const uint4 ok = *(const uint4*)(dkp + c * 8), ov = *(const uint4*)(dvp + c * 8);
-        const uint32_t okw[4] = {ok.x, ok.y, ok.z, ok.w}, ovw[4] = {ov.x, ov.y, ov.z, ov.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          gk[2 * e] += __uint_as_float(okw[e] << 16); gk[2 * e + 1] += __uint_as_float(okw[e] & 0xffff0000u);
-          gv[2 * e] += __uint_as_float(ovw[e] << 16); gv[2 * e + 1] += __uint_as_float(ovw[e] & 0xffff0000u);
-        }
-      }
-      uint4 wk, wv;
-      wk.x = pack_bf2(gk[0], gk[1]); wk.y = pack_bf2(gk[2], gk[3]); wk.z = pack_bf2(gk[4], gk[5]); wk.w = pack_bf2(gk[6], gk[7]);
-      wv.x = pack_bf2(gv[0], gv[1]); wv.y = pack_bf2(gv[2], gv[3]); wv.z = pack_bf2(gv[4], gv[5]); wv.w = pack_bf2(gv[6], gv[7]);
-      *(uint4*)(dkp + c * 8) = wk;
-      *(uint4*)(dvp + c * 8) = wv;
+      for (int e = 0; e < 8; ++e) { gk[e] += ok[e]; gv[e] += ov[e]; }
     }
+    uint4 wk, wv;
+    wk.x = pack_bf2(gk[0], gk[1]); wk.y = pack_bf2(gk[2], gk[3]); wk.z = pack_bf2(gk[4], gk[5]); wk.w = pack_bf2(gk[6], gk[7]);
+    wv.x = pack_bf2(gv[0], gv[1]); wv.y = pack_bf2(gv[2], gv[3]); wv.z = pack_bf2(gv[4], gv[5]); wv.w = pack_bf2(gv[6], gv[7]);
+    *(uint4*)dkp = wk;
+    *(uint4*)dvp = wv;
   }
 #pragma unroll
-  for (int d = 0; d < 64; ++d) {
-    const float t = wave_sum(dqa[d]);
-    if (lane == 0) dq_part[wave][d] = t;
+  for (int e = 0; e < 8; ++e) {                                           // over the 8 key slots of the wave that share this chunk
+    float t = dqa[e];
+    t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+    if (lane < 8) dq_part[wave][ch * 8 + e] = t;
   }
   __syncthreads();
-  if (tid < 64) dq[qr * ldg + h * 64 + tid] = f2bf((dq_part[0][tid] + dq_part[1][tid]) + (dq_part[2][tid] + dq_part[3][tid]));
+  if (tid < 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += dq_part[w][tid];
+    dq[qr * ldg + h * 64 + tid] = f2bf(t);
+  }
 }
 
 extern "C" int sf_attention_cls_bwd(const uint16_t* q, int64_t q_seq_rows, int q_row, const uint16_t* k, const uint16_t* v, int64_t ld,
@@ -159,9 +168,9 @@ extern "C" int sf_attention_cls_bwd(const uint16_t* q, int64_t q_seq_rows, int q
                                     uint16_t* dq, uint16_t* dk, uint16_t* dv, int64_t ldg, int64_t n_seq, int heads, int head_dim, float scale,
                                     int accumulate_kv, void* stream) {
   SF_CHECK_ARG(q && k && v && dO && dq && dk && dv && head_dim == 64 && n_keys >= 1 && n_keys <= CLSB_MAX_KEYS && heads >= 1 && n_seq >= 1 &&
-                   ld % 8 == 0 && ldg % 8 == 0 && n_seq * heads < (1ll << 31),
+                   ld % 8 == 0 && ldg % 8 == 0 && lddo % 8 == 0 && n_seq * heads < (1ll << 31),
                "sf_attention_cls_bwd: bad arguments (head_dim 64, n_keys <= %d, strides %% 8 == 0)", CLSB_MAX_KEYS);
-  hipLaunchKernelGGL(attention_cls_bwd_kernel, dim3((unsigned)(n_seq * heads)), dim3(256), 0, (hipStream_t)stream, q, q_seq_rows, q_row, k, v, ld,
+  hipLaunchKernelGGL(attention_cls_bwd_kernel, dim3((unsigned)(n_seq * heads)), dim3(CLSB_THREADS), 0, (hipStream_t)stream, q, q_seq_rows, q_row, k, v, ld,
                      kv_seq_rows, kv_row0, n_keys, dO, lddo, do_seq_rows, do_row, dq, dk, dv, ldg, heads, scale, accumulate_kv);
   SF_LAUNCH_CHECK();
   return 0;
