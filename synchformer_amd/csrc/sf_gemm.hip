@@ -768,7 +768,13 @@ extern "C" int sf_gemm_bf16_batched(const bf16_t* A, int64_t lda, int64_t sA0, i
   a.batch_inner = batch_inner; a.sA0 = sA0; a.sA1 = sA1; a.sW0 = sW0; a.sW1 = sW1; a.sC0 = sC0; a.sC1 = sC1;
   g_batch_count = (int64_t)batch_outer * batch_inner;
   // 64-deep stages when the contraction allows it (the split-K weight-gradient products of the train steps: K = chunks of 64 rows)
-  const int rc = (K % 64 == 0 && K >= 512) ? dispatch_gemm<Cfg0>(a, c_dtype == SF_BF16, false, false, /*fast=*/false, (hipStream_t)stream)
+  // the branch-free buffer-op epilogue also serves batches whose per-batch output is a whole number of 64-column wave tiles (the split-K
+  // weight-gradient partials): the batch offset is folded into the base pointer inside the kernel
+  const int64_t m_pad = ((M + 255) / 256) * 256;
+  const int esz = c_dtype == SF_BF16 ? 2 : 4;
+  const bool fast = (N % 64) == 0 && (ldc % 4) == 0 && ((uintptr_t)C % 16) == 0 && (sC0 * esz) % 16 == 0 && (sC1 * esz) % 16 == 0 &&
+                    (!bias || ((uintptr_t)bias % 16) == 0) && m_pad * ldc * esz < ((int64_t)1 << 32);
+  const int rc = (K % 64 == 0 && K >= 512) ? dispatch_gemm<Cfg0>(a, c_dtype == SF_BF16, false, false, fast, (hipStream_t)stream)
                                            : dispatch_gemm<Cfg4>(a, c_dtype == SF_BF16, false, false, /*fast=*/false, (hipStream_t)stream);
   g_batch_count = 1;
   return rc;
