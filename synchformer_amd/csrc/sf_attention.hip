@@ -63,7 +63,7 @@ __device__ __forceinline__ void axpy8_bf16(sf_f32x2_t (&o)[4], float e, const ui
 // vector loads and ~70 VGPRs, i.e. 7 waves per SIMD instead of 3: the kernel is bound by bytes in flight, not by VALU.
 #define TINY_SLOTS 9
 template <bool PART>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void attn_tiny64_kernel(AttnArgs p, int64_t total_units) {
+__global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t total_units) {
   __shared__ __attribute__((aligned(16))) uint4 lds_k[4][TINY_SLOTS][8], lds_v[4][TINY_SLOTS][8], lds_qc[4][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t unit = (int64_t)blockIdx.x * 4 + wave;                   // (seq, group, head), head fastest
@@ -170,9 +170,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     }
     if (qi == 0) {
       float* part = p.cls_part + ((seq * p.heads + head) * p.n_groups + g) * 66;
-      if (sub == 0) { part[0] = cm; part[1] = cl; }
+      if (sub == 0) *reinterpret_cast<float2*>(part) = make_float2(cm, cl);            // 66-float records are 8-byte aligned
 #pragma unroll
-      for (int t = 0; t < 4; ++t) { part[2 + sub * 8 + 2 * t] = co[t].x; part[2 + sub * 8 + 2 * t + 1] = co[t].y; }
+      for (int t = 0; t < 4; ++t) *reinterpret_cast<float2*>(part + 2 + sub * 8 + 2 * t) = make_float2(co[t].x, co[t].y);
     }
   }
 }
