@@ -54,6 +54,13 @@ int sf_gemm_bf16_batched(const uint16_t* A, int64_t lda, int64_t sA0, int64_t sA
                          int64_t sW1, const float* bias, void* C, int c_dtype, int64_t ldc, int64_t sC0, int64_t sC1, int64_t M,
                          int64_t N, int64_t K, int batch_outer, int batch_inner, void* stream);
 
+/* Split-K weight-gradient product of the train steps (autograd of every nn.Linear on the path: dW = dY^T X, e.g. the qkv / proj / fc1 / fc2
+ * layers of vit_helper.py:87-141 and modeling_ast.py:199-330): part[s] (N x K, fp32) = sum over token rows m in chunk s of dY[m,:]^T X[m,:],
+ * chunk s = rows [s*kc, min((s+1)*kc, M)).  dY (M x N) and X (M x K) are the row-major bf16 activations as they are - no transposed copies.
+ * N % 128 == 0, K % 128 == 0, kc % 64 == 0, split*kc >= M.  The caller sums the `split` partials (sf_seqsum). */
+int sf_gemm_tn_splitk(const uint16_t* dY, int64_t ldy, const uint16_t* X, int64_t ldx, float* part, int64_t M, int64_t N, int64_t K,
+                      int split, int64_t kc, void* stream);
+
 /* Tuning / test hook (process-global, not for production threads): force the GEMM tile configuration of subsequent sf_gemm_bf16
  * calls.  -1 = automatic choice by shape (default); 0 = 128x128x64, 4 waves, two workgroups per CU; 7 = persistent 256x256x64,
  * 8 waves, v_mfma_f32_32x32x16_bf16; 1-6, 8, 9 = the other tilings measured in profiles/r01_gemm_configs.md (tools/bench_gemm.py). */

@@ -779,3 +779,159 @@ extern "C" int sf_gemm_bf16_batched(const bf16_t* A, int64_t lda, int64_t sA0, i
   g_batch_count = 1;
   return rc;
 }
+
+// =========================================================================================================
+// Split-K "TN" weight-gradient GEMM (train steps):   part[s][i][j] = sum_{m in chunk s} dY[m][i] * X[m][j]
+// Both operands are the ROW-MAJOR activations as the backward pass holds them (rows = tokens = the contraction index), so no
+// transposed copies are made (the first version transposed dY and X per linear layer: 12 % of the Stage-1 step).  A stage is 64 token
+// rows x 128 columns of each operand, LDS-DMA'd as whole 256-byte rows; the MFMA operands - 8 consecutive tokens of one column per
+// lane - are gathered with ds_read_b64_tr_b16, the 4 x 16 transposing LDS read: lane (fr, fg) points at the 8 bytes
+// T[k0 + 8 fg + 4 h + (fr >> 2)][c0 + 4 (fr & 3) .. +3] and receives T[k0 + 8 fg + 4 h + 0..3][c0 + fr] (h = 0, 1 -> the 8 k values).
+// 16-byte chunk c of token row k sits at chunk c ^ swz(k), swz(k) = 2 ((k & 3) | ((k >> 3) & 1) << 2): the 8 rows a 32-lane half
+// reads land on 8 different 32-byte bank groups, and the permutation is applied on the SOURCE side of the lane-linear LDS-DMA.
+// 128 x 128 output tile, 4 waves (64 x 64 each), two 64-row stages in flight, 2 workgroups per CU; rows beyond M read a zero page.
+// =========================================================================================================
+struct TnArgs {
+  const bf16_t* A; int64_t lda;        // dY (M, N): output rows i index its columns
+  const bf16_t* B; int64_t ldb;        // X  (M, K): output columns j index its columns
+  float* C; int64_t ldc, sC;           // part (split, N, K) fp32
+  int64_t M;                           // valid token rows
+  int kc;                              // token rows per split chunk (multiple of 64)
+  uint32_t tiles_n;                    // column tiles (K / 128)
+};
+#define TN_BK 64
+#define TN_STAGE (2 * TN_BK * 256)     // 32 KiB: A rows + B rows
+__device__ __attribute__((aligned(256))) const uint32_t g_tn_zero_page[64] = {0};
+
+typedef short tn_s4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ tn_s4 tn_tr_read(const char* lds) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s4*)lds);
+}
+__device__ __forceinline__ int tn_swz(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 1; }
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_splitk_kernel(TnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t tm = blockIdx.x / p.tiles_n, tn = blockIdx.x - tm * p.tiles_n;
+  const int i0 = (int)tm * 128, j0 = (int)tn * 128;
+  const int64_t row_base = (int64_t)blockIdx.y * p.kc;
+  const int64_t left = p.M - row_base;
+  const int valid = left < p.kc ? (int)(left > 0 ? left : 0) : p.kc;      // token rows of this chunk that exist
+  const int nk = (valid + TN_BK - 1) / TN_BK;
+
+  // LDS-DMA pieces: piece q = 4 token rows x 256 B; wave w issues pieces 4w .. 4w+3 of A and of B
+  const int prow = lane >> 4, pos = lane & 15;
+  const bf16_t* a_src[4];
+  const bf16_t* b_src[4];
+  int krow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    krow[i] = (wave * 4 + i) * 4 + prow;
+    const int gch = pos ^ tn_swz(krow[i]);
+    a_src[i] = p.A + (row_base + krow[i]) * p.lda + i0 + gch * 8;
+    b_src[i] = p.B + (row_base + krow[i]) * p.ldb + j0 + gch * 8;
+  }
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_tn_zero_page) + pos * 8;
+  auto stage = [&](int s, int kt) {
+    char* abase = smem + s * TN_STAGE + (wave * 4) * 1024;
+    char* bbase = abase + TN_BK * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = kt * TN_BK + krow[i] < valid;
+      glds16(ok ? a_src[i] + (int64_t)kt * TN_BK * p.lda : zero, abase + i * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = kt * TN_BK + krow[i] < valid;
+      glds16(ok ? b_src[i] + (int64_t)kt * TN_BK * p.ldb : zero, bbase + i * 1024);
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  int a_off[4], b_off[4];
+  {
+    const int kl = fg * 8 + (fr >> 2), sw = tn_swz(kl), c1 = (fr & 3) >> 1, hb = (fr & 1) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a_off[i] = kl * 256 + (((wm * 8 + 2 * i + c1) ^ sw) << 4) + hb;
+      b_off[i] = kl * 256 + (((wn * 8 + 2 * i + c1) ^ sw) << 4) + hb + TN_BK * 256;
+    }
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt_barrier<0>();                                     // tile kt has landed; every wave is past compute(kt-1)
+    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    const char* st = smem + (kt & 1) * TN_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        union { bf16x8 v; tn_s4 h[2]; } ua, ub;
+        ua.h[0] = tn_tr_read(st + a_off[i] + (ks * 32) * 256);
+        ua.h[1] = tn_tr_read(st + a_off[i] + (ks * 32 + 4) * 256);
+        ub.h[0] = tn_tr_read(st + b_off[i] + (ks * 32) * 256);
+        ub.h[1] = tn_tr_read(st + b_off[i] + (ks * 32 + 4) * 256);
+        a[i] = ua.v; b[i] = ub.v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();                                               // operand LDS becomes per-wave epilogue scratch
+
+  // epilogue: 16-row groups through a per-wave slab -> 16-byte row stores
+  float* slab = reinterpret_cast<float*>(smem + wave * (16 * EPI_LD * 4));
+  float* cbase = p.C + (int64_t)blockIdx.y * p.sC + (int64_t)(i0 + wm * 64) * p.ldc + j0 + wn * 64;
+  const int ecol = (lane & 15) * 4;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(fg * 4 + r) * EPI_LD + j * 16 + fr] = acc[g][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int lrow = ps * 4 + (lane >> 4);
+      const float4 v = *reinterpret_cast<const float4*>(slab + lrow * EPI_LD + ecol);
+      *reinterpret_cast<float4*>(cbase + (int64_t)(g * 16 + lrow) * p.ldc + ecol) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// part (split, N, K) fp32 <- per-chunk dY^T X; chunk s covers token rows [s*kc, min((s+1)*kc, M)).  The caller sums the chunks (sf_seqsum).
+extern "C" int sf_gemm_tn_splitk(const bf16_t* dY, int64_t ldy, const bf16_t* X, int64_t ldx, float* part, int64_t M, int64_t N, int64_t K,
+                                 int split, int64_t kc, void* stream) {
+  SF_CHECK_ARG(dY && X && part, "sf_gemm_tn_splitk: null pointer");
+  SF_CHECK_ARG(M >= 1 && N >= 128 && K >= 128 && (N % 128) == 0 && (K % 128) == 0, "sf_gemm_tn_splitk: N=%lld and K=%lld must be multiples of 128",
+               (long long)N, (long long)K);
+  SF_CHECK_ARG(split >= 1 && split < 65536 && kc >= 64 && (kc % 64) == 0 && kc < ((int64_t)1 << 30) && (int64_t)split * kc >= M,
+               "sf_gemm_tn_splitk: split * kc must cover M, kc %% 64 == 0");
+  SF_CHECK_ARG((ldy % 8) == 0 && (ldx % 8) == 0 && ((uintptr_t)dY % 16) == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)part % 16) == 0,
+               "sf_gemm_tn_splitk: operands must be 16-byte aligned with row strides %% 8 == 0");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_splitk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE);
+    if (e != hipSuccess) { sf_set_error("sf_gemm_tn_splitk: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  TnArgs a;
+  a.A = dY; a.lda = ldy; a.B = X; a.ldb = ldx; a.C = part; a.ldc = K; a.sC = N * K; a.M = M; a.kc = (int)kc;
+  a.tiles_n = (uint32_t)(K / 128);
+  const int64_t tiles = (N / 128) * (K / 128);
+  SF_CHECK_ARG(tiles < ((int64_t)1 << 31), "sf_gemm_tn_splitk: too many tiles");
+  hipLaunchKernelGGL(gemm_tn_splitk_kernel, dim3((unsigned)tiles, (unsigned)split), dim3(256), 2 * TN_STAGE, (hipStream_t)stream, a);
+  SF_LAUNCH_CHECK();
+  return 0;
+}

@@ -13,6 +13,7 @@ memory, the stream and torch.distributed.
 """
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -107,6 +108,7 @@ class FlatTrainer:
             o += sz
         self.flat_b.copy_(self.flat_p)
         self.step_count = 0
+        self.tn_wgrad = os.environ.get('SF_TN_WGRAD', '1') != '0'      # weight gradients straight from row-major operands (sf_gemm_tn_splitk)
         self.norm = torch.zeros(1, device=self.dev, dtype=torch.float32)
         self.loss = torch.zeros(1, device=self.dev, dtype=torch.float32)
         self._ws: Dict[str, torch.Tensor] = {}
@@ -168,6 +170,16 @@ class FlatTrainer:
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
         split = max(1, min(32, 768 // tiles)) if M >= 8192 else 1
         kc = ((m_pad // split + 63) // 64) * 64
+        if self.tn_wgrad and N % 128 == 0 and K % 128 == 0 and M >= 8192 and dy_b.stride(0) % 8 == 0 and x_b.stride(0) % 8 == 0:
+            # dW straight from the row-major gradient / saved input (ds_read_b64_tr_b16 operand reads): no transposed copies
+            if dy_f32 is None:
+                ws = self._buf('colsum_ws', (N * ((M + 63) // 64),), torch.float32)
+                colsum(dy_b, M, N, self.g[bkey], ws, accumulate=acc_bias)
+            part = self._buf('wgrad_part', (split * N, K), torch.float32)
+            _chk(_lib.load().sf_gemm_tn_splitk(dy_b.data_ptr(), dy_b.stride(0), x_b.data_ptr(), x_b.stride(0), part.data_ptr(), M, N, K, split, kc,
+                                               _st()), 'sf_gemm_tn_splitk')
+            _chk(_lib.load().sf_seqsum(part.data_ptr(), K, split, N, K, self.g[wkey].data_ptr(), 0, _st()), 'sf_seqsum')
+            return self._lin_dgrad(dy_b, M, N, K, wkey, need_dx, dx_out, tag, acc_dx)
         m_pad = kc * split if split > 1 else m_pad
         dyT = self._buf('dyT', (N, m_pad), torch.bfloat16)
         xT = self._buf('xT', (K, m_pad), torch.bfloat16)
@@ -181,6 +193,9 @@ class FlatTrainer:
             _chk(_lib.load().sf_seqsum(part.data_ptr(), K, split, N, K, self.g[wkey].data_ptr(), 0, _st()), 'sf_seqsum')
         else:
             ops.gemm(dyT, xT, None, self.g[wkey].view(N, K), M=N)
+        return self._lin_dgrad(dy_b, M, N, K, wkey, need_dx, dx_out, tag, acc_dx)
+
+    def _lin_dgrad(self, dy_b, M, N, K, wkey, need_dx, dx_out, tag, acc_dx):
         if not need_dx:
             return None
         wT = self._wT[wkey]                                                           # (K, n_pad)

@@ -61,6 +61,25 @@ def test_batched_gemm(gpu):
     torch.testing.assert_close(S.cpu().reshape(B, H, L, 224)[..., :L], ref, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize('M,N,K,split,kc', [(1000, 128, 256, 4, 256), (4321, 768, 384, 7, 640), (200, 256, 128, 1, 256), (130, 128, 128, 3, 64)])
+def test_tn_splitk_weight_gradient_gemm(gpu, M, N, K, split, kc):
+    """part[s] = dY[chunk s]^T X[chunk s] from the ROW-MAJOR operands (ds_read_b64_tr_b16 operand reads); ragged last chunk, chunks past M
+    are zero, operands are column slices of wider buffers.  bf16 inputs, fp32 accumulation: compared with fp64 torch on the same bf16 values."""
+    from synchformer_amd import _lib
+    g = torch.Generator().manual_seed(M + N)
+    dyw = torch.randn(M, N + 64, generator=g).bfloat16()
+    xw = torch.randn(M, K + 8, generator=g).bfloat16()
+    dy, x = dyw.to(gpu)[:, 64:], xw.to(gpu)[:, :K]
+    part = torch.full((split, N, K), float('nan'), device=gpu)
+    _lib.check(_lib.load().sf_gemm_tn_splitk(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), part.data_ptr(), M, N, K, split, kc,
+                                             torch.cuda.current_stream().cuda_stream), 'sf_gemm_tn_splitk')
+    got = part.cpu().double()
+    for s_ in range(split):
+        lo, hi = min(M, s_ * kc), min(M, (s_ + 1) * kc)
+        ref = dyw[lo:hi, 64:].double().T @ xw[lo:hi, :K].double()
+        torch.testing.assert_close(got[s_], ref, rtol=1e-4, atol=2e-3)
+
+
 def test_layernorm_gelu_ce_backward(gpu):
     from synchformer_amd import train as T, _lib, ops
     lib = _lib.load()
