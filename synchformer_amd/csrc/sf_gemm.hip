@@ -812,7 +812,14 @@ __device__ __forceinline__ int tn_swz(int k) { return ((k & 3) | (((k >> 3) & 1)
 __global__ __launch_bounds__(256, 2) void gemm_tn_splitk_kernel(TnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t tm = blockIdx.x / p.tiles_n, tn = blockIdx.x - tm * p.tiles_n;
+  // XCD-aware bijective remap (as in gemm_bf16_kernel): the workgroups an XCD receives (ids x, x+8, ...) cover a CONTIGUOUS range of
+  // tiles, so neighbouring tiles - which share their dY columns (same tm) - hit the same L2
+  uint32_t vb;
+  {
+    const uint32_t nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const uint32_t tm = vb / p.tiles_n, tn = vb - tm * p.tiles_n;
   const int i0 = (int)tm * 128, j0 = (int)tn * 128;
   const int64_t row_base = (int64_t)blockIdx.y * p.kc;
   const int64_t left = p.M - row_base;
@@ -832,19 +839,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_splitk_kernel(TnArgs p) {
     b_src[i] = p.B + (row_base + krow[i]) * p.ldb + j0 + gch * 8;
   }
   const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_tn_zero_page) + pos * 8;
+  const int64_t a_step = (int64_t)TN_BK * p.lda, b_step = (int64_t)TN_BK * p.ldb;
+  // stage() is called with kt = 0, 1, 2, ... in order: the source pointers simply advance by 64 token rows per call; only the last
+  // k-tile of a chunk can contain rows beyond `valid` (they read the zero page instead)
   auto stage = [&](int s, int kt) {
     char* abase = smem + s * TN_STAGE + (wave * 4) * 1024;
     char* bbase = abase + TN_BK * 256;
+    const int lim = valid - kt * TN_BK;                          // rows of this k-tile that exist (>= 64 except in the last one); branch-free
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = kt * TN_BK + krow[i] < valid;
-      glds16(ok ? a_src[i] + (int64_t)kt * TN_BK * p.lda : zero, abase + i * 1024);
-    }
+    for (int i = 0; i < 4; ++i) glds16(krow[i] < lim ? a_src[i] : zero, abase + i * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = kt * TN_BK + krow[i] < valid;
-      glds16(ok ? b_src[i] + (int64_t)kt * TN_BK * p.ldb : zero, bbase + i * 1024);
-    }
+    for (int i = 0; i < 4; ++i) glds16(krow[i] < lim ? b_src[i] : zero, bbase + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a_src[i] += a_step; b_src[i] += b_step; }
   };
 
   const int wm = wave >> 1, wn = wave & 1;

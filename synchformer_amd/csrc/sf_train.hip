@@ -300,6 +300,44 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const void* __restri
   part[(int64_t)blockIdx.y * cols + c] = s;
 }
 
+// Vector variant: a block covers rows_per_blk rows x 8 sixteen-byte column chunks (64 bf16 / 32 fp32 columns); 8 neighbouring lanes read one
+// whole 128-byte line of a row, 32 row lanes stride the rows (the scalar kernel above moves 2 or 4 bytes per lane per load).
+template <bool BF16>
+__global__ __launch_bounds__(256) void colsum_stage1_vec_kernel(const void* __restrict__ x, int64_t ldx, int64_t rows, int cols, int rows_per_blk,
+                                                                 float* __restrict__ part) {
+  constexpr int E = BF16 ? 8 : 4;                                 // elements per 16-byte chunk
+  __shared__ float red[4][8 * 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rl = tid >> 3, ch = tid & 7;
+  const int c0 = blockIdx.x * (8 * E) + ch * E;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_blk, r1 = min(r0 + rows_per_blk, rows);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int64_t r = r0 + rl; r < r1; r += 32) {
+    if (BF16) {
+      const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(x) + r * ldx + c0);
+      const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc[2 * i] += __uint_as_float(w[i] << 16); acc[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u); }
+    } else {
+      const float4 u = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + r * ldx + c0);
+      acc[0] += u.x; acc[1] += u.y; acc[2] += u.z; acc[3] += u.w;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {                                   // over the 8 row lanes of the wave that share this chunk
+    float t = acc[e];
+    t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+    if (lane < 8) red[wave][ch * 8 + e] = t;
+  }
+  __syncthreads();
+  if (tid < 8 * E) {
+    const int cch = tid / E, e = tid - cch * E;
+    part[(int64_t)blockIdx.y * cols + blockIdx.x * (8 * E) + tid] = (red[0][cch * 8 + e] + red[1][cch * 8 + e]) + (red[2][cch * 8 + e] + red[3][cch * 8 + e]);
+  }
+}
+
 extern "C" int sf_colsum(const void* x, int x_dtype, int64_t ldx, int64_t rows, int cols, float* out, int accumulate, float* workspace,
                          void* stream) {
   SF_CHECK_ARG(x && out && workspace && (x_dtype == SF_F32 || x_dtype == SF_BF16), "sf_colsum: bad arguments");
@@ -309,7 +347,12 @@ extern "C" int sf_colsum(const void* x, int x_dtype, int64_t ldx, int64_t rows, 
   SF_CHECK_ARG(nblk < 65536, "sf_colsum: too many rows");
   dim3 grid((cols + 255) / 256, (unsigned)nblk);
   hipStream_t s = (hipStream_t)stream;
-  if (x_dtype == SF_BF16) hipLaunchKernelGGL((colsum_stage1_kernel<true>), grid, dim3(256), 0, s, x, ldx, rows, cols, rpb, workspace);
+  const int cw = x_dtype == SF_BF16 ? 64 : 32, esz = x_dtype == SF_BF16 ? 2 : 4;
+  if ((cols % cw) == 0 && ((uintptr_t)x % 16) == 0 && (ldx * esz) % 16 == 0) {
+    dim3 vgrid(cols / cw, (unsigned)nblk);
+    if (x_dtype == SF_BF16) hipLaunchKernelGGL((colsum_stage1_vec_kernel<true>), vgrid, dim3(256), 0, s, x, ldx, rows, cols, rpb, workspace);
+    else hipLaunchKernelGGL((colsum_stage1_vec_kernel<false>), vgrid, dim3(256), 0, s, x, ldx, rows, cols, rpb, workspace);
+  } else if (x_dtype == SF_BF16) hipLaunchKernelGGL((colsum_stage1_kernel<true>), grid, dim3(256), 0, s, x, ldx, rows, cols, rpb, workspace);
   else hipLaunchKernelGGL((colsum_stage1_kernel<false>), grid, dim3(256), 0, s, x, ldx, rows, cols, rpb, workspace);
   SF_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_partials_kernel, dim3((cols + 63) / 64), dim3(1024), 0, s, workspace, nblk, (int64_t)cols, out, cols, accumulate);

@@ -66,6 +66,22 @@ def colsum(x, rows, cols, out, ws, accumulate=False):
                                ws.data_ptr(), _st()), 'sf_colsum')
 
 
+def _wgrad_split(tiles: int, slots: int = 512) -> int:
+    """Number of contraction chunks for a weight gradient with `tiles` 128x128 output tiles: the smallest split whose tiles * split
+    workgroups fill whole rounds of the 512 resident workgroup slots (256 CUs x 2) to >= 94 % - e.g. 36 tiles -> 14 (504 workgroups),
+    108 -> 9 (972), 144 -> 7 (1008).  Measured (tools/bench_wgrad.py, M = 43,932): 92 -> 77 us, 247 -> 211 us, 352 -> 261 us against the
+    earlier min(32, 768 // tiles) rule."""
+    best, best_eff = 1, 0.0
+    for s_ in range(2, 33):
+        n = tiles * s_
+        eff = n / (((n + slots - 1) // slots) * slots)
+        if eff >= 0.94:
+            return s_
+        if eff > best_eff:
+            best, best_eff = s_, eff
+    return best
+
+
 def constant_with_warmup_lr(step: int, base_lr: float, warmup: int = 1000) -> float:
     """Stage-2 schedule `constant_with_warmup` (scripts/train_utils.py:236-246; configs/sync.yaml lr_scheduler): torch's
     SequentialLR([LinearLR(start_factor 1/100, total_iters warmup), ConstantLR(factor 1)], milestones [warmup]) as a function of the
@@ -168,7 +184,7 @@ class FlatTrainer:
         # dW = dy^T x: an (N, K) output is only (N/128)*(K/128) tiles (36 for a 768x768 weight) however long the M contraction is,
         # so for long M the contraction is split into `split` chunks run as one batched GEMM (fills the 256 CUs) and summed after
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        split = max(1, min(32, 768 // tiles)) if M >= 8192 else 1
+        split = _wgrad_split(tiles) if M >= 8192 else 1
         kc = ((m_pad // split + 63) // 64) * 64
         if self.tn_wgrad and N % 128 == 0 and K % 128 == 0 and M >= 8192 and dy_b.stride(0) % 8 == 0 and x_b.stride(0) % 8 == 0:
             # dW straight from the row-major gradient / saved input (ds_read_b64_tr_b16 operand reads): no transposed copies
