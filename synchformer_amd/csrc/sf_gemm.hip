@@ -783,13 +783,14 @@ extern "C" int sf_gemm_bf16_batched(const bf16_t* A, int64_t lda, int64_t sA0, i
 // =========================================================================================================
 // Split-K "TN" weight-gradient GEMM (train steps):   part[s][i][j] = sum_{m in chunk s} dY[m][i] * X[m][j]
 // Both operands are the ROW-MAJOR activations as the backward pass holds them (rows = tokens = the contraction index), so no
-// transposed copies are made (the first version transposed dY and X per linear layer: 12 % of the Stage-1 step).  A stage is 64 token
+// transposed copies are made (the first version transposed dY and X per linear layer: 12 % of the Stage-1 step).  A stage is 32 token
 // rows x 128 columns of each operand, LDS-DMA'd as whole 256-byte rows; the MFMA operands - 8 consecutive tokens of one column per
 // lane - are gathered with ds_read_b64_tr_b16, the 4 x 16 transposing LDS read: lane (fr, fg) points at the 8 bytes
 // T[k0 + 8 fg + 4 h + (fr >> 2)][c0 + 4 (fr & 3) .. +3] and receives T[k0 + 8 fg + 4 h + 0..3][c0 + fr] (h = 0, 1 -> the 8 k values).
 // 16-byte chunk c of token row k sits at chunk c ^ swz(k), swz(k) = 2 ((k & 3) | ((k >> 3) & 1) << 2): the 8 rows a 32-lane half
 // reads land on 8 different 32-byte bank groups, and the permutation is applied on the SOURCE side of the lane-linear LDS-DMA.
-// 128 x 128 output tile, 4 waves (64 x 64 each), two 64-row stages in flight, 2 workgroups per CU; rows beyond M read a zero page.
+// 128 x 128 output tile, 4 waves (64 x 64 each), a 4-slot ring of 32-row stages (three in flight), 2 workgroups per CU; rows beyond M read a
+// zero page.
 // =========================================================================================================
 struct TnArgs {
   const bf16_t* A; int64_t lda;        // dY (M, N): output rows i index its columns
@@ -799,8 +800,10 @@ struct TnArgs {
   int kc;                              // token rows per split chunk (multiple of 64)
   uint32_t tiles_n;                    // column tiles (K / 128)
 };
-#define TN_BK 64
-#define TN_STAGE (2 * TN_BK * 256)     // 32 KiB: A rows + B rows
+#define TN_BK 32                       // token rows per stage: one 32-deep MFMA k-step
+#define TN_NS 4                        // ring slots: three stages in flight while one is being multiplied
+#define TN_STAGE (2 * TN_BK * 256)     // 16 KiB: A rows + B rows
+#define TN_LDS (TN_NS * TN_STAGE)      // 64 KiB -> two workgroups per CU
 __device__ __attribute__((aligned(256))) const uint32_t g_tn_zero_page[64] = {0};
 
 typedef short tn_s4 __attribute__((ext_vector_type(4)));
@@ -826,43 +829,43 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_splitk_kernel(TnArgs p) {
   const int valid = left < p.kc ? (int)(left > 0 ? left : 0) : p.kc;      // token rows of this chunk that exist
   const int nk = (valid + TN_BK - 1) / TN_BK;
 
-  // LDS-DMA pieces: piece q = 4 token rows x 256 B; wave w issues pieces 4w .. 4w+3 of A and of B
+  // LDS-DMA pieces: piece q = 4 token rows x 256 B; wave w issues pieces 2w, 2w+1 of A and of B per stage.  The loop is bound by the
+  // latency of these loads (a 64-row, 2-slot version spent ~60 % of its time in the vmcnt(0) before the barrier), hence the 4-slot ring.
   const int prow = lane >> 4, pos = lane & 15;
-  const bf16_t* a_src[4];
-  const bf16_t* b_src[4];
-  int krow[4];
+  const bf16_t* a_src[2];
+  const bf16_t* b_src[2];
+  int krow[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    krow[i] = (wave * 4 + i) * 4 + prow;
+  for (int i = 0; i < 2; ++i) {
+    krow[i] = (wave * 2 + i) * 4 + prow;
     const int gch = pos ^ tn_swz(krow[i]);
     a_src[i] = p.A + (row_base + krow[i]) * p.lda + i0 + gch * 8;
     b_src[i] = p.B + (row_base + krow[i]) * p.ldb + j0 + gch * 8;
   }
   const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_tn_zero_page) + pos * 8;
   const int64_t a_step = (int64_t)TN_BK * p.lda, b_step = (int64_t)TN_BK * p.ldb;
-  // stage() is called with kt = 0, 1, 2, ... in order: the source pointers simply advance by 64 token rows per call; only the last
-  // k-tile of a chunk can contain rows beyond `valid` (they read the zero page instead)
-  auto stage = [&](int s, int kt) {
-    char* abase = smem + s * TN_STAGE + (wave * 4) * 1024;
-    char* bbase = abase + TN_BK * 256;
-    const int lim = valid - kt * TN_BK;                          // rows of this k-tile that exist (>= 64 except in the last one); branch-free
+  // stage() is called with kt = 0, 1, 2, ... in order: the source pointers advance by 32 token rows per call; rows beyond `valid`
+  // (last k-tile of a ragged chunk) read the zero page.  The four pieces of a wave (A rows 8w..8w+7, then B rows 8w..8w+7) are
+  // consecutive in LDS and issued from inline asm (dma4): hipcc puts a vmcnt(0) in front of the fragment reads when it sees the
+  // global_load_lds builtin in this loop, which serialises prefetch and compute; the waits below are the hand-counted ones.
+  const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 4096);
+  auto stage = [&](int slot, int kt) {
+    const int lim = valid - kt * TN_BK;
+    dma4(krow[0] < lim ? a_src[0] : zero, krow[1] < lim ? a_src[1] : zero, krow[0] < lim ? b_src[0] : zero, krow[1] < lim ? b_src[1] : zero,
+         lds_wave + slot * TN_STAGE);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(krow[i] < lim ? a_src[i] : zero, abase + i * 1024);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(krow[i] < lim ? b_src[i] : zero, bbase + i * 1024);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { a_src[i] += a_step; b_src[i] += b_step; }
+    for (int i = 0; i < 2; ++i) { a_src[i] += a_step; b_src[i] += b_step; }
   };
 
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fg = lane >> 4;
-  int a_off[4], b_off[4];
+  int a_off[4], b_off[4];                                         // token row k of a stage lives at (k >> 3) * 4096 + (k & 7) * 256 (A) / + 2048 (B)
   {
-    const int kl = fg * 8 + (fr >> 2), sw = tn_swz(kl), c1 = (fr & 3) >> 1, hb = (fr & 1) * 8;
+    const int sw = tn_swz(fg * 8 + (fr >> 2)), c1 = (fr & 3) >> 1, hb = (fr & 1) * 8, rb = fg * 4096 + (fr >> 2) * 256;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      a_off[i] = kl * 256 + (((wm * 8 + 2 * i + c1) ^ sw) << 4) + hb;
-      b_off[i] = kl * 256 + (((wn * 8 + 2 * i + c1) ^ sw) << 4) + hb + TN_BK * 256;
+      a_off[i] = rb + (((wm * 8 + 2 * i + c1) ^ sw) << 4) + hb;
+      b_off[i] = rb + (((wn * 8 + 2 * i + c1) ^ sw) << 4) + hb + 2048;
     }
   }
   f32x4 acc[4][4];
@@ -871,28 +874,30 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_splitk_kernel(TnArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (nk > 0) stage(0, 0);
+#pragma unroll
+  for (int s_ = 0; s_ < TN_NS - 1; ++s_)
+    if (s_ < nk) stage(s_, s_);
   for (int kt = 0; kt < nk; ++kt) {
-    wait_vmcnt_barrier<0>();                                     // tile kt has landed; every wave is past compute(kt-1)
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const char* st = smem + (kt & 1) * TN_STAGE;
+    // tile kt has landed when at most the (<= 2) younger stages are outstanding (4 LDS-DMA instructions per thread per stage)
+    const int ahead = min(TN_NS - 2, nk - 1 - kt);
+    if (ahead >= 2) wait_vmcnt_barrier<8>(); else if (ahead == 1) wait_vmcnt_barrier<4>(); else wait_vmcnt_barrier<0>();
+    // every wave is past compute(kt-1): its slot is free -> refill with tile kt+3
+    if (kt + TN_NS - 1 < nk) stage((kt + TN_NS - 1) & (TN_NS - 1), kt + TN_NS - 1);
+    const char* st = smem + (kt & (TN_NS - 1)) * TN_STAGE;
+    bf16x8 a[4], b[4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        union { bf16x8 v; tn_s4 h[2]; } ua, ub;
-        ua.h[0] = tn_tr_read(st + a_off[i] + (ks * 32) * 256);
-        ua.h[1] = tn_tr_read(st + a_off[i] + (ks * 32 + 4) * 256);
-        ub.h[0] = tn_tr_read(st + b_off[i] + (ks * 32) * 256);
-        ub.h[1] = tn_tr_read(st + b_off[i] + (ks * 32 + 4) * 256);
-        a[i] = ua.v; b[i] = ub.v;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    for (int i = 0; i < 4; ++i) {
+      union { bf16x8 v; tn_s4 h[2]; } ua, ub;
+      ua.h[0] = tn_tr_read(st + a_off[i]);
+      ua.h[1] = tn_tr_read(st + a_off[i] + 4 * 256);
+      ub.h[0] = tn_tr_read(st + b_off[i]);
+      ub.h[1] = tn_tr_read(st + b_off[i] + 4 * 256);
+      a[i] = ua.v; b[i] = ub.v;
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
   }
   __syncthreads();                                               // operand LDS becomes per-wave epilogue scratch
 
@@ -929,7 +934,7 @@ extern "C" int sf_gemm_tn_splitk(const bf16_t* dY, int64_t ldy, const bf16_t* X,
                "sf_gemm_tn_splitk: operands must be 16-byte aligned with row strides %% 8 == 0");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_splitk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_splitk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS);
     if (e != hipSuccess) { sf_set_error("sf_gemm_tn_splitk: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
@@ -938,7 +943,7 @@ extern "C" int sf_gemm_tn_splitk(const bf16_t* dY, int64_t ldy, const bf16_t* X,
   a.tiles_n = (uint32_t)(K / 128);
   const int64_t tiles = (N / 128) * (K / 128);
   SF_CHECK_ARG(tiles < ((int64_t)1 << 31), "sf_gemm_tn_splitk: too many tiles");
-  hipLaunchKernelGGL(gemm_tn_splitk_kernel, dim3((unsigned)tiles, (unsigned)split), dim3(256), 2 * TN_STAGE, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(gemm_tn_splitk_kernel, dim3((unsigned)tiles, (unsigned)split), dim3(256), TN_LDS, (hipStream_t)stream, a);
   SF_LAUNCH_CHECK();
   return 0;
 }
