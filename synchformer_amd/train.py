@@ -184,9 +184,10 @@ class FlatTrainer:
         # dW = dy^T x: an (N, K) output is only (N/128)*(K/128) tiles (36 for a 768x768 weight) however long the M contraction is,
         # so for long M the contraction is split into `split` chunks run as one batched GEMM (fills the 256 CUs) and summed after
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        split = _wgrad_split(tiles) if M >= 8192 else 1
+        tn = self.tn_wgrad and N % 128 == 0 and K % 128 == 0 and M >= 512 and dy_b.stride(0) % 8 == 0 and x_b.stride(0) % 8 == 0
+        split = _wgrad_split(tiles) if M >= 8192 else (max(1, min(_wgrad_split(tiles), m_pad // 128)) if tn else 1)   # short M: >= 128 rows per chunk
         kc = ((m_pad // split + 63) // 64) * 64
-        if self.tn_wgrad and N % 128 == 0 and K % 128 == 0 and M >= 8192 and dy_b.stride(0) % 8 == 0 and x_b.stride(0) % 8 == 0:
+        if tn:
             # dW straight from the row-major gradient / saved input (ds_read_b64_tr_b16 operand reads): no transposed copies
             if dy_f32 is None:
                 ws = self._buf('colsum_ws', (N * ((M + 63) // 64),), torch.float32)
