@@ -155,6 +155,8 @@ int sf_seqsum(const float* x, int64_t ldx, int n_seq, int L, int cols, float* ou
 /* act = gelu_erf(pre) / dpre = dact * gelu_erf'(pre) on bf16 pre-activations (n elements, n % 4 == 0). */
 int sf_gelu_fwd(const uint16_t* pre, uint16_t* act, int64_t n, void* stream);
 int sf_gelu_bwd(const uint16_t* pre, const float* dact, uint16_t* dpre, int64_t n, void* stream);
+/* sf_gelu_bwd with the incoming gradient in bf16 (n % 8 == 0, 16-byte aligned pointers). */
+int sf_gelu_bwd_bf16(const uint16_t* pre, const uint16_t* dact, uint16_t* dpre, int64_t n, void* stream);
 /* loss = mean cross-entropy of (B, C) logits vs int64 targets (sync_model.py:95-96); dlogits (optional) scaled by grad_scale / B. */
 int sf_cross_entropy(const float* logits, int64_t ld, const int64_t* targets, int B, int C, float* loss, float* dlogits, int64_t ldd,
                      float grad_scale, void* stream);

@@ -435,6 +435,30 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
   reinterpret_cast<uint2*>(dpre)[i] = o;
 }
 
+// same with the incoming gradient in bf16 (the fc2 input gradient written in bf16 by the dgrad GEMM: half the bytes of the fp32 round trip)
+__global__ __launch_bounds__(256) void gelu_bwd_bf16_kernel(const bf16_t* __restrict__ pre, const bf16_t* __restrict__ dact, bf16_t* __restrict__ dpre,
+                                                             int64_t n8) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const uint4 u = reinterpret_cast<const uint4*>(pre)[i], g = reinterpret_cast<const uint4*>(dact)[i];
+  const uint32_t uw[4] = {u.x, u.y, u.z, u.w}, gw[4] = {g.x, g.y, g.z, g.w};
+  uint32_t ow[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    ow[e] = pack_bf2(__uint_as_float(gw[e] << 16) * gelu_grad(__uint_as_float(uw[e] << 16)),
+                     __uint_as_float(gw[e] & 0xffff0000u) * gelu_grad(__uint_as_float(uw[e] & 0xffff0000u)));
+  reinterpret_cast<uint4*>(dpre)[i] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+}
+
+extern "C" int sf_gelu_bwd_bf16(const uint16_t* pre, const uint16_t* dact, uint16_t* dpre, int64_t n, void* stream) {
+  SF_CHECK_ARG(pre && dact && dpre && (n % 8) == 0 && ((uintptr_t)pre % 16) == 0 && ((uintptr_t)dact % 16) == 0 && ((uintptr_t)dpre % 16) == 0,
+               "sf_gelu_bwd_bf16: bad arguments (n %% 8 == 0, 16-byte aligned)");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(gelu_bwd_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pre, dact, dpre, n / 8);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int sf_gelu_fwd(const uint16_t* pre, uint16_t* act, int64_t n, void* stream) {
   SF_CHECK_ARG(pre && act && (n % 4) == 0, "sf_gelu_fwd: bad arguments");
   if (n <= 0) return 0;

@@ -86,7 +86,10 @@ class AVCLIPTrainer(FlatTrainer):
         _chk(_lib.load().sf_gelu_fwd(pre.data_ptr(), act.data_ptr(), pre.numel(), _st()), 'sf_gelu_fwd')
 
     def _gelu_bwd(self, pre, dact, dpre):
-        _chk(_lib.load().sf_gelu_bwd(pre.data_ptr(), dact.data_ptr(), dpre.data_ptr(), pre.numel(), _st()), 'sf_gelu_bwd')
+        if dact.dtype == torch.bfloat16:
+            _chk(_lib.load().sf_gelu_bwd_bf16(pre.data_ptr(), dact.data_ptr(), dpre.data_ptr(), pre.numel(), _st()), 'sf_gelu_bwd_bf16')
+        else:
+            _chk(_lib.load().sf_gelu_bwd(pre.data_ptr(), dact.data_ptr(), dpre.data_ptr(), pre.numel(), _st()), 'sf_gelu_bwd')
 
     def _seqsum(self, x, n_seq, L, out):
         _chk(_lib.load().sf_seqsum(x.data_ptr(), x.stride(0), n_seq, L, D, out.data_ptr(), 0, _st()), 'sf_seqsum')
@@ -107,7 +110,7 @@ class AVCLIPTrainer(FlatTrainer):
         """dx (rows, 768) fp32 = gradient of the block output; adds the MLP branch's contribution through LN(x_in) into dx."""
         dy_b = self._buf('dy_b', (rows, D), torch.bfloat16)
         cast_bf16(dx, dy_b, rows, D)
-        dact = self._lin_bwd(fc2, dy_b, s['act'], rows, tag='act', dy_f32=dx)
+        dact = self._lin_bwd(fc2, dy_b, s['act'], rows, tag='act', dy_f32=dx, dx_dtype=torch.bfloat16)   # consumed by the bf16 GELU backward only
         dpre = self._buf('dpre', (rows, FF), torch.bfloat16)
         self._gelu_bwd(s['pre'], dact, dpre)
         dh = self._lin_bwd(fc1, dpre, s['h2'], rows, tag='h')
@@ -188,9 +191,7 @@ class AVCLIPTrainer(FlatTrainer):
         backward -> LN backward accumulated into dx."""
         dy_b = self._buf('dy_b', (rows, D), torch.bfloat16)
         cast_bf16(dx, dy_b, rows, D)
-        datt = self._lin_bwd(proj, dy_b, att_saved, rows, tag='h', dy_f32=dx)
-        dO_b = self._buf('dO_b', (rows, D), torch.bfloat16)
-        cast_bf16(datt, dO_b, rows, D)
+        dO_b = self._lin_bwd(proj, dy_b, att_saved, rows, tag='h', dy_f32=dx, dx_dtype=torch.bfloat16)     # attention output gradient, bf16 for the attention backward
         dqkv = qkv_fn(dO_b)
         if isinstance(qkv_names, str):                                        # one fused (2304, 768) projection
             dh = self._lin_bwd(qkv_names, dqkv, h_saved, rows, tag='h')
@@ -226,9 +227,7 @@ class AVCLIPTrainer(FlatTrainer):
         self._mlp_bwd(s, dy, s['y'], p + '.linear1', p + '.linear2', n_seq, p + '.norm2', EPS_VIS)
         dy_b = self._buf('dy_b', (n_seq, D), torch.bfloat16)
         cast_bf16(dy, dy_b, n_seq, D)
-        datt = self._lin_bwd(p + '.self_attn.out_proj', dy_b, s['att'], n_seq, tag='h', dy_f32=dy)
-        dO_b = self._buf('dO_b', (n_seq, D), torch.bfloat16)
-        cast_bf16(datt, dO_b, n_seq, D)
+        dO_b = self._lin_bwd(p + '.self_attn.out_proj', dy_b, s['att'], n_seq, tag='h', dy_f32=dy, dx_dtype=torch.bfloat16)
         dqkv = self._buf('dqkv', (rows, 3 * D), torch.bfloat16, zero=True)   # dq of rows 1.. stays zero (only row 0 queries)
         self._cls_bwd(s['qkv'], dO_b, dqkv, n_seq, L, L, do_seq_rows=1, accumulate=False)
         dzn = self._lin_bwd(p + '.self_attn.in_proj', dqkv, s['zn'], rows, tag='h', wkey=p + '.self_attn.in_proj_weight',

@@ -171,9 +171,11 @@ class FlatTrainer:
     def _wb(self, name):
         return self.b[name + '.weight'], self.p[name + '.bias']
 
-    def _lin_bwd(self, name, dy_b, x_b, M, *, need_dx=True, dx_out=None, tag='', wkey=None, bkey=None, acc_bias=False, acc_dx=False, dy_f32=None):
+    def _lin_bwd(self, name, dy_b, x_b, M, *, need_dx=True, dx_out=None, tag='', wkey=None, bkey=None, acc_bias=False, acc_dx=False, dy_f32=None,
+                 dx_dtype=torch.float32):
         """dy_b (M, N) bf16 (row stride may exceed N), x_b (M, K) bf16 saved input.  Fills g[W], g[b]; returns dx fp32 (M, K).
-        `wkey` / `bkey` name tensors that do not follow the `<name>.weight` / `<name>.bias` convention (in_proj_weight, conv kernels)."""
+        `wkey` / `bkey` name tensors that do not follow the `<name>.weight` / `<name>.bias` convention (in_proj_weight, conv kernels).
+        dx_dtype=torch.bfloat16 lets the dgrad GEMM write dx in bf16 when the only consumer is a bf16 kernel (no fp32 round trip + cast)."""
         wkey, bkey = wkey or name + '.weight', bkey or name + '.bias'
         N = self.p[wkey].shape[0]
         K = self.p[wkey].numel() // N
@@ -196,7 +198,7 @@ class FlatTrainer:
             _chk(_lib.load().sf_gemm_tn_splitk(dy_b.data_ptr(), dy_b.stride(0), x_b.data_ptr(), x_b.stride(0), part.data_ptr(), M, N, K, split, kc,
                                                _st()), 'sf_gemm_tn_splitk')
             _chk(_lib.load().sf_seqsum(part.data_ptr(), K, split, N, K, self.g[wkey].data_ptr(), 0, _st()), 'sf_seqsum')
-            return self._lin_dgrad(dy_b, M, N, K, wkey, need_dx, dx_out, tag, acc_dx)
+            return self._lin_dgrad(dy_b, M, N, K, wkey, need_dx, dx_out, tag, acc_dx, dx_dtype)
         m_pad = kc * split if split > 1 else m_pad
         dyT = self._buf('dyT', (N, m_pad), torch.bfloat16)
         xT = self._buf('xT', (K, m_pad), torch.bfloat16)
@@ -210,13 +212,14 @@ class FlatTrainer:
             _chk(_lib.load().sf_seqsum(part.data_ptr(), K, split, N, K, self.g[wkey].data_ptr(), 0, _st()), 'sf_seqsum')
         else:
             ops.gemm(dyT, xT, None, self.g[wkey].view(N, K), M=N)
-        return self._lin_dgrad(dy_b, M, N, K, wkey, need_dx, dx_out, tag, acc_dx)
+        return self._lin_dgrad(dy_b, M, N, K, wkey, need_dx, dx_out, tag, acc_dx, dx_dtype)
 
-    def _lin_dgrad(self, dy_b, M, N, K, wkey, need_dx, dx_out, tag, acc_dx):
+    def _lin_dgrad(self, dy_b, M, N, K, wkey, need_dx, dx_out, tag, acc_dx, dx_dtype=torch.float32):
         if not need_dx:
             return None
         wT = self._wT[wkey]                                                           # (K, n_pad)
-        dx = dx_out if dx_out is not None else self._buf('dx_' + tag, (M, K), torch.float32)
+        assert dx_dtype == torch.float32 or (dx_out is None and not acc_dx)
+        dx = dx_out if dx_out is not None else self._buf('dx_' + tag + ('_b' if dx_dtype == torch.bfloat16 else ''), (M, K), dx_dtype)
         if wT.shape[1] != N:                                                           # ragged N (heads): zero-padded contraction
             dyp = self._buf('dy_pad', (M, wT.shape[1]), torch.bfloat16, zero=True)
             dyp[:, :N].copy_(dy_b[:M, :N])
