@@ -29,7 +29,7 @@ for N, K in [(768, 768), (2304, 768), (3072, 768), (768, 3072)]:
     x = torch.randn(M, K, device=dev).bfloat16()
     tiles = (N // 128) * (K // 128)
     flop = 2.0 * M * N * K
-    for split in sorted({max(1, min(32, 768 // tiles)), 7, 9, 14}):
+    for split in sorted({T._wgrad_split(tiles), max(1, min(32, 768 // tiles))}):   # the trainer's fill-aware choice vs the first rule
         m_pad = ((M + 63) // 64) * 64
         kc = ((m_pad // split + 63) // 64) * 64
         part = torch.empty(split * N, K, device=dev)
