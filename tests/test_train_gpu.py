@@ -61,6 +61,60 @@ def test_batched_gemm(gpu):
     torch.testing.assert_close(S.cpu().reshape(B, H, L, 224)[..., :L], ref, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize('rows,cols,dtype', [(20000, 768, torch.bfloat16), (1000, 3072, torch.bfloat16), (777, 96, torch.float32),
+                                             (20000, 768, torch.float32), (300, 21, torch.float32), (300, 72, torch.bfloat16)])
+def test_colsum_vector_and_scalar_paths(gpu, rows, cols, dtype):
+    """sf_colsum: 16-byte vector kernel (cols % 64 == 0 for bf16 / % 32 for fp32) and the scalar kernel for ragged widths; overwrite and
+    accumulate; the input is a column slice of a wider buffer (row stride > cols)."""
+    from synchformer_amd import train as T
+    g = torch.Generator().manual_seed(rows + cols)
+    wide = torch.randn(rows, cols + 64, generator=g).to(dtype)
+    x = wide.to(gpu)[:, 64:]
+    ref = wide[:, 64:].double().sum(0)
+    ws = torch.empty(cols * ((rows + 63) // 64), device=gpu)
+    o = torch.full((cols,), 3.0, device=gpu)
+    T.colsum(x, rows, cols, o, ws)
+    torch.testing.assert_close(o.cpu().double(), ref, rtol=1e-4, atol=2e-3)
+    T.colsum(x, rows, cols, o, ws, accumulate=True)
+    torch.testing.assert_close(o.cpu().double(), 2 * ref, rtol=1e-4, atol=4e-3)
+
+
+def test_attention_cls_backward_matches_autograd(gpu):
+    """sf_attention_cls_bwd (8 lanes per key row): one query row per (sequence, head) against n_keys keys, dk/dv overwrite and accumulate."""
+    from synchformer_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    n_seq, L, H, hd = 3, 197, 12, 64
+    Dm = H * hd
+    qkv = (torch.randn(n_seq * L, 3 * Dm, generator=g) * 0.7).bfloat16()
+    dO = torch.randn(n_seq, Dm, generator=g).bfloat16()
+    qd, dOd = qkv.to(gpu), dO.to(gpu)
+    dqkv = torch.zeros(n_seq * L, 3 * Dm, device=gpu, dtype=torch.bfloat16)
+    base = (torch.randn(n_seq * L, 3 * Dm, generator=g) * 0.1).bfloat16()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(buf, accumulate):
+        _lib.check(_lib.load().sf_attention_cls_bwd(qd.data_ptr(), L, 0, qd[:, Dm:].data_ptr(), qd[:, 2 * Dm:].data_ptr(), 3 * Dm, L, 0, L,
+                                                    dOd.data_ptr(), Dm, 1, 0, buf.data_ptr(), buf[:, Dm:].data_ptr(), buf[:, 2 * Dm:].data_ptr(),
+                                                    3 * Dm, n_seq, H, hd, 0.125, int(accumulate), st), 'sf_attention_cls_bwd')
+    run(dqkv, False)
+    x = qkv.float().reshape(n_seq, L, 3, H, hd).requires_grad_(True)
+    q0 = x[:, 0, 0]                                                           # (n_seq, H, hd): the CLS query
+    k, v = x[:, :, 1], x[:, :, 2]                                             # (n_seq, L, H, hd)
+    att = torch.softmax(torch.einsum('bhd,blhd->bhl', q0, k) * 0.125, -1)
+    out = torch.einsum('bhl,blhd->bhd', att, v)
+    out.backward(dO.float().reshape(n_seq, H, hd))
+    ref = x.grad.reshape(n_seq * L, 3 * Dm)
+    got = dqkv.float().cpu()
+    rows0 = torch.arange(n_seq) * L
+    for name, sl in (('dq', slice(0, Dm)), ('dk', slice(Dm, 2 * Dm)), ('dv', slice(2 * Dm, 3 * Dm))):
+        a, b = (got[rows0, sl], ref[rows0, sl]) if name == 'dq' else (got[:, sl], ref[:, sl])
+        assert _rel(a, b) < 1e-2, (name, _rel(a, b))
+    acc = base.to(gpu).clone()
+    run(acc, True)                                                            # dk / dv accumulate onto what is there; dq is always overwritten
+    want = base.float()[:, Dm:] + ref[:, Dm:]
+    assert _rel(acc.float().cpu()[:, Dm:], want) < 1e-2
+
+
 @pytest.mark.parametrize('M,N,K,split,kc', [(1000, 128, 256, 4, 256), (4321, 768, 384, 7, 640), (200, 256, 128, 1, 256), (130, 128, 128, 3, 64)])
 def test_tn_splitk_weight_gradient_gemm(gpu, M, N, K, split, kc):
     """part[s] = dY[chunk s]^T X[chunk s] from the ROW-MAJOR operands (ds_read_b64_tr_b16 operand reads); ragged last chunk, chunks past M
