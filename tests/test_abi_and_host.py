@@ -235,3 +235,26 @@ def test_lr_schedules_match_torch_and_open_clip():
     assert abs(cosine_lr(3250, 1e-4, 1000, 10000) - 0.5 * (1 + math.cos(math.pi * 0.25)) * 1e-4) < 1e-12
     got = set(normalise_keys({'v_encoder.norm.weight': 1, 'a_encoder.ast.x': 2, 'logit_scale': 3}))
     assert got == {'vfeat_extractor.norm.weight', 'afeat_extractor.ast.x', 'logit_scale'}
+
+
+def test_postprocess_grid_and_topk_match_reference_semantics():
+    """class grid / quantisation / top-k read-out (transforms.py:221-239, example.py:38-56): 21 classes on [-2, 2], argmin snapping,
+    softmax probabilities in descending order."""
+    import numpy as np
+    from synchformer_amd.postprocess import class_grid, quantize_offset, topk_offsets
+    grid = class_grid(-2.0, 2.0, 21)
+    assert grid.dtype == torch.float32 and grid.numel() == 21
+    assert torch.equal(grid, torch.from_numpy(np.linspace(-2.0, 2.0, 21)).float())          # the reference builds it with numpy.linspace
+    assert quantize_offset(grid, 1.6) == (float(grid[18]), 18) and quantize_offset(grid, -2.0)[1] == 0 and quantize_offset(grid, 0.09)[1] == 10
+    ext = class_grid(-2.0, 2.0, 21, add_extreme_offset=True, seg_size_vframes=16, n_segments=14, step_size_seg=0.5, vfps=25.0)
+    assert ext.numel() == 22 and abs(float(ext[-1]) - (14 - 0.5 * 13) * 16 / 25.0) < 1e-6
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(2, 21, generator=g) * 3
+    top = topk_offsets(logits, grid, k=5)
+    probs = torch.softmax(logits, -1)
+    for b in range(2):
+        assert [t[3] for t in top[b]] == torch.topk(logits[b], 5).indices.tolist()
+        assert all(abs(t[0] - float(probs[b, t[3]])) < 1e-6 and abs(t[2] - float(grid[t[3]])) < 1e-6 for t in top[b])
+        assert top[b][0][0] >= top[b][1][0] >= top[b][4][0]
+    with pytest.raises(ValueError):
+        class_grid(-1, 1, 2)
