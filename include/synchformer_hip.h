@@ -148,6 +148,10 @@ int sf_softmax_bwd_rows(const uint16_t* P, int64_t ldp, const float* dP, int64_t
 int sf_layernorm768_bwd(const float* x, int64_t ldx, const int64_t* x_map, const float* gamma, const float* dy, int64_t lddy,
                         const int64_t* dy_map, float* dx, int64_t lddx, const int64_t* dx_map, int accumulate_dx, float* dgamma,
                         float* dbeta, int accumulate_dparams, float* workspace, int64_t rows, float eps, void* stream);
+/* sf_layernorm768_bwd with the incoming gradient dy in bf16 (lddy % 4 == 0, 8-byte aligned rows). */
+int sf_layernorm768_bwd_bf16(const float* x, int64_t ldx, const int64_t* x_map, const float* gamma, const uint16_t* dy, int64_t lddy,
+                        const int64_t* dy_map, float* dx, int64_t lddx, const int64_t* dx_map, int accumulate_dx, float* dgamma,
+                        float* dbeta, int accumulate_dparams, float* workspace, int64_t rows, float eps, void* stream);
 /* out[c] (=|+=) sum_r x[r, c] (bias gradients); x fp32|bf16; workspace fp32 cols * ceil(rows / 64). */
 int sf_colsum(const void* x, int x_dtype, int64_t ldx, int64_t rows, int cols, float* out, int accumulate, float* workspace, void* stream);
 /* out[l, c] (=|+=) sum_b x[b*L + l, c]: gradient of the broadcast positional / token table. */

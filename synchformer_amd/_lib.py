@@ -36,6 +36,7 @@ SIGNATURES = {
     'sf_softmax_rows': [_ptr, _i64, _ptr, _i64, _i64, _i32, _i32, _f32, _ptr],
     'sf_softmax_bwd_rows': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i32, _i32, _f32, _ptr],
     'sf_layernorm768_bwd': [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i32, _ptr, _ptr, _i32, _ptr, _i64, _f32, _ptr],
+    'sf_layernorm768_bwd_bf16': [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i32, _ptr, _ptr, _i32, _ptr, _i64, _f32, _ptr],
     'sf_colsum': [_ptr, _i32, _i64, _i64, _i32, _ptr, _i32, _ptr, _ptr],
     'sf_seqsum': [_ptr, _i64, _i32, _i32, _i32, _ptr, _i32, _ptr],
     'sf_gelu_fwd': [_ptr, _ptr, _i64, _ptr],

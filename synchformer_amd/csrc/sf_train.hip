@@ -173,8 +173,9 @@ extern "C" int sf_softmax_bwd_rows(const uint16_t* P, int64_t ldp, const float* 
 // One wave per row, 4 * rpw rows per block (each wave walks rpw rows, keeping its dgamma / dbeta partials in registers) -> the
 // block's 4 waves combine their per-column partials through LDS.
 // ------------------------------------------------------------------------------------------------------
+template <bool DY_BF16>
 __global__ __launch_bounds__(256) void layernorm768_bwd_kernel(const float* __restrict__ x, int64_t ldx, RowMap xmap, const float* __restrict__ gamma,
-                                                                const float* __restrict__ dy, int64_t lddy, RowMap dymap, float* __restrict__ dx,
+                                                                const void* __restrict__ dy, int64_t lddy, RowMap dymap, float* __restrict__ dx,
                                                                 int64_t lddx, RowMap dxmap, int accumulate, float* __restrict__ part, int64_t rows,
                                                                 float eps, int rpw) {
   __shared__ float red[4][2][768];
@@ -186,13 +187,18 @@ __global__ __launch_bounds__(256) void layernorm768_bwd_kernel(const float* __re
     const int64_t r = ((int64_t)blockIdx.x * rpw + it) * 4 + wave;
     if (r >= rows) break;
     const float* xr = x + map_row(xmap, r) * ldx;
-    const float* gr = dy + map_row(dymap, r) * lddy;
+    const int64_t gro = map_row(dymap, r) * lddy;
     float4 v[3], g[3];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       v[i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
-      g[i] = *reinterpret_cast<const float4*>(gr + i * 256 + lane * 4);
+      if (DY_BF16) {                                               // incoming gradient in bf16 (written so by the dgrad GEMM): 8-byte loads
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(dy) + gro + i * 256 + lane * 4);
+        g[i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+      } else {
+        g[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy) + gro + i * 256 + lane * 4);
+      }
       s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) * (1.0f / 768);
@@ -268,21 +274,38 @@ __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __re
   }
 }
 
-extern "C" int sf_layernorm768_bwd(const float* x, int64_t ldx, const int64_t* x_map, const float* gamma, const float* dy, int64_t lddy,
-                                   const int64_t* dy_map, float* dx, int64_t lddx, const int64_t* dx_map, int accumulate_dx, float* dgamma,
-                                   float* dbeta, int accumulate_dparams, float* workspace, int64_t rows, float eps, void* stream) {
+static int layernorm768_bwd_impl(const float* x, int64_t ldx, const int64_t* x_map, const float* gamma, const void* dy, bool dy_bf16, int64_t lddy,
+                                 const int64_t* dy_map, float* dx, int64_t lddx, const int64_t* dx_map, int accumulate_dx, float* dgamma,
+                                 float* dbeta, int accumulate_dparams, float* workspace, int64_t rows, float eps, void* stream) {
   SF_CHECK_ARG(x && gamma && dy && dx && dgamma && dbeta && workspace, "sf_layernorm768_bwd: null pointer");
   if (rows <= 0) return 0;
   const int rpw = rows >= 16384 ? 8 : (rows >= 4096 ? 2 : 1);      // keep >= 1k blocks in flight, <= ~1.4k partial rows at Stage-1 sizes
   const int64_t nblk = (rows + 4 * rpw - 1) / (4 * rpw);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(layernorm768_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, ldx, sf_rowmap(x_map), gamma, dy, lddy, sf_rowmap(dy_map), dx,
-                     lddx, sf_rowmap(dx_map), accumulate_dx, workspace, rows, eps, rpw);
+  if (dy_bf16) hipLaunchKernelGGL(layernorm768_bwd_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, x, ldx, sf_rowmap(x_map), gamma, dy, lddy,
+                                  sf_rowmap(dy_map), dx, lddx, sf_rowmap(dx_map), accumulate_dx, workspace, rows, eps, rpw);
+  else hipLaunchKernelGGL(layernorm768_bwd_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, x, ldx, sf_rowmap(x_map), gamma, dy, lddy,
+                          sf_rowmap(dy_map), dx, lddx, sf_rowmap(dx_map), accumulate_dx, workspace, rows, eps, rpw);
   SF_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_partials_kernel, dim3(12), dim3(1024), 0, s, workspace, nblk, (int64_t)2 * 768, dgamma, 768, accumulate_dparams);
   hipLaunchKernelGGL(colsum_partials_kernel, dim3(12), dim3(1024), 0, s, workspace + 768, nblk, (int64_t)2 * 768, dbeta, 768, accumulate_dparams);
   SF_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int sf_layernorm768_bwd(const float* x, int64_t ldx, const int64_t* x_map, const float* gamma, const float* dy, int64_t lddy,
+                                   const int64_t* dy_map, float* dx, int64_t lddx, const int64_t* dx_map, int accumulate_dx, float* dgamma,
+                                   float* dbeta, int accumulate_dparams, float* workspace, int64_t rows, float eps, void* stream) {
+  return layernorm768_bwd_impl(x, ldx, x_map, gamma, dy, false, lddy, dy_map, dx, lddx, dx_map, accumulate_dx, dgamma, dbeta, accumulate_dparams,
+                               workspace, rows, eps, stream);
+}
+
+extern "C" int sf_layernorm768_bwd_bf16(const float* x, int64_t ldx, const int64_t* x_map, const float* gamma, const uint16_t* dy, int64_t lddy,
+                                        const int64_t* dy_map, float* dx, int64_t lddx, const int64_t* dx_map, int accumulate_dx, float* dgamma,
+                                        float* dbeta, int accumulate_dparams, float* workspace, int64_t rows, float eps, void* stream) {
+  SF_CHECK_ARG((lddy % 4) == 0 && ((uintptr_t)dy % 8) == 0, "sf_layernorm768_bwd_bf16: dy rows must be 8-byte aligned");
+  return layernorm768_bwd_impl(x, ldx, x_map, gamma, dy, true, lddy, dy_map, dx, lddx, dx_map, accumulate_dx, dgamma, dbeta, accumulate_dparams,
+                               workspace, rows, eps, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -113,7 +113,7 @@ class AVCLIPTrainer(FlatTrainer):
         dact = self._lin_bwd(fc2, dy_b, s['act'], rows, tag='act', dy_f32=dx, dx_dtype=torch.bfloat16)   # consumed by the bf16 GELU backward only
         dpre = self._buf('dpre', (rows, FF), torch.bfloat16)
         self._gelu_bwd(s['pre'], dact, dpre)
-        dh = self._lin_bwd(fc1, dpre, s['h2'], rows, tag='h')
+        dh = self._lin_bwd(fc1, dpre, s['h2'], rows, tag='h', dx_dtype=torch.bfloat16)                      # read once, by the LN backward
         self._ln_bwd(x_in, ln_name, dh, dx, rows, eps, acc_dx=True)
 
     # ---- divided space-time attention ---------------------------------------------------------------------------------
@@ -194,7 +194,7 @@ class AVCLIPTrainer(FlatTrainer):
         dO_b = self._lin_bwd(proj, dy_b, att_saved, rows, tag='h', dy_f32=dx, dx_dtype=torch.bfloat16)     # attention output gradient, bf16 for the attention backward
         dqkv = qkv_fn(dO_b)
         if isinstance(qkv_names, str):                                        # one fused (2304, 768) projection
-            dh = self._lin_bwd(qkv_names, dqkv, h_saved, rows, tag='h')
+            dh = self._lin_bwd(qkv_names, dqkv, h_saved, rows, tag='h', dx_dtype=torch.bfloat16)
         else:                                                                 # separate query / key / value Linears
             dh = self._buf('dx_qkvsum', (rows, D), torch.float32)
             for j, nm in enumerate(qkv_names):

@@ -49,9 +49,9 @@ def bgemm(a, lda, sA0, sA1, w, ldw, sW0, sW1, c, ldc, sC0, sC1, M, N, K, b_outer
 
 def ln_bwd(x, gamma, dy, dx, dgamma, dbeta, ws, rows, eps, *, x_map=None, dy_map=None, dx_map=None, acc_dx=False, acc_dp=False):
     m = lambda t: (C.c_int64 * 6)(*t) if t is not None else None
-    _chk(_lib.load().sf_layernorm768_bwd(x.data_ptr(), x.stride(0), m(x_map), gamma.data_ptr(), dy.data_ptr(), dy.stride(0), m(dy_map),
-                                         dx.data_ptr(), dx.stride(0), m(dx_map), int(acc_dx), dgamma.data_ptr(), dbeta.data_ptr(), int(acc_dp),
-                                         ws.data_ptr(), rows, float(eps), _st()), 'sf_layernorm768_bwd')
+    fn = _lib.load().sf_layernorm768_bwd_bf16 if dy.dtype == torch.bfloat16 else _lib.load().sf_layernorm768_bwd
+    _chk(fn(x.data_ptr(), x.stride(0), m(x_map), gamma.data_ptr(), dy.data_ptr(), dy.stride(0), m(dy_map), dx.data_ptr(), dx.stride(0), m(dx_map),
+            int(acc_dx), dgamma.data_ptr(), dbeta.data_ptr(), int(acc_dp), ws.data_ptr(), rows, float(eps), _st()), 'sf_layernorm768_bwd')
 
 
 def dropout(x, y, rows, cols, p, seed, residual=None):
