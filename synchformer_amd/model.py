@@ -340,8 +340,11 @@ class Synchformer(torch.nn.Module):
         """vis (B, S, Tv, C, H, W) u8|f16|bf16|f32, aud (B, S, 1, F, Ta) -> (loss | None, logits)  (sync_model.py:38-70).
         `for_loop` only trades memory for speed in the reference (bit-equal results); here segments are always
         processed in `self.seg_chunk`-sized chunks."""
-        vis = self.extract_vfeats(vis, for_loop, vis_mask=vis_mask)
-        aud = self.extract_afeats(aud, for_loop, aud_mask=aud_mask)
+        if aud_mask is not None and for_loop:
+            raise AssertionError('cont_mask is not supported with for_loop=True')       # ast.py:153
+        vis_in = vis
+        # the two extractors are independent (sync_model.py:45-52): the audio tower runs on a second stream next to the visual one
+        vis, aud = self._engine().both_towers(lambda: self.extract_vfeats(vis_in, for_loop, vis_mask=vis_mask), aud, aud_mask)
         trainable = self._trainable_params()
         if torch.is_grad_enabled() and any(p.requires_grad for p in trainable.values()):
             logits = self._train_forward(vis, aud, trainable)

@@ -496,8 +496,7 @@ class SyncTrainer(FlatTrainer):
 
     def train_step(self, vis: torch.Tensor, aud: torch.Tensor, targets: torch.Tensor, lr: Optional[float] = None) -> torch.Tensor:
         """One Stage-2 iteration (train_sync.py:159-192): frozen extractors -> trainable forward/backward -> all-reduce -> clip+Adam."""
-        vf = self.engine.extract_vfeats(vis)
-        af = self.engine.extract_afeats(aud)
+        vf, af = self.engine.both_towers(lambda: self.engine.extract_vfeats(vis), aud)
         loss = self.forward_backward(vf, af, targets)
         self.allreduce_grads()
         self.optimizer_step(lr)
