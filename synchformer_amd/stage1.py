@@ -17,6 +17,7 @@ All compute is in libsynchformer_hip; torch provides memory, the stream, torch.d
 (the logit_scale clamp and its gradient).
 """
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -69,6 +70,8 @@ class AVCLIPTrainer(FlatTrainer):
         self._init_flat(sd, keys, device, lr, betas, eps, max_clip_norm)
         self.clamp_scale, self.gather_for_loss = clamp_scale, gather_for_loss
         self.fused_attn_bwd = True          # False: the gathered batched-GEMM attention backward (kept as a cross-check)
+        self.two_streams = os.environ.get('SF_STAGE1_TWO_STREAMS', '1') != '0'   # audio tower next to the visual one (forward_backward)
+        self._side = None
         self.n_vblocks = len([k for k in keys if k.startswith(V + '.blocks.') and k.endswith('.norm1.weight')])
         self.n_alayers = len([k for k in keys if k.endswith('.layernorm_before.weight')])
 
@@ -477,14 +480,46 @@ class AVCLIPTrainer(FlatTrainer):
         n = B * S
         self.clamp_logit_scale()
         self.flat_g.zero_()
+        aud3 = aud.reshape(n, aud.shape[-2], aud.shape[-1])
+        if not self.two_streams:
+            vout = self._fwd_visual(vis.reshape(n, *vis.shape[2:]))
+            aout = self._fwd_audio(aud3)
+            self.vfeat, self.afeat = self._pool(vout, 8, n, 'v'), self._pool(aout, self.sv_a['nt'], n, 'a')
+            dv, da = self._head(self.vfeat, self.afeat)
+            self._bwd_audio(self._pool_bwd(aout, self.sv_a['nt'], da, n, 'a'))      # the short tower first: its bucket travels under the long one
+            if on_ready:
+                on_ready(self._key_range(A + '.', 'logit_scale'))
+            self._bwd_visual(self._pool_bwd(vout, 8, dv, n, 'v'), on_ready)
+            self.loss = self.losses.mean()
+            return self.loss
+        # The towers only meet in the contrastive head: the audio tower (2,072 token rows - small, latency-bound launches) runs its forward
+        # and its backward on a second stream next to the visual tower, with its own workspaces (`_ws_prefix`).
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+            self._ev = [torch.cuda.Event() for _ in range(4)]
+        main, side = torch.cuda.current_stream(), self._side
+        self._ev[0].record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(self._ev[0])
+            self._ws_prefix = 'a:'
+            aout = self._fwd_audio(aud3)
+            self._ws_prefix = ''
+            self._ev[1].record(side)
         vout = self._fwd_visual(vis.reshape(n, *vis.shape[2:]))
-        aout = self._fwd_audio(aud.reshape(n, aud.shape[-2], aud.shape[-1]))
+        main.wait_event(self._ev[1])
         self.vfeat, self.afeat = self._pool(vout, 8, n, 'v'), self._pool(aout, self.sv_a['nt'], n, 'a')
         dv, da = self._head(self.vfeat, self.afeat)
-        self._bwd_audio(self._pool_bwd(aout, self.sv_a['nt'], da, n, 'a'))      # the short tower first: its bucket travels under the long one
-        if on_ready:
-            on_ready(self._key_range(A + '.', 'logit_scale'))
+        self._ev[2].record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(self._ev[2])
+            self._ws_prefix = 'a:'
+            self._bwd_audio(self._pool_bwd(aout, self.sv_a['nt'], da, n, 'a'))
+            self._ws_prefix = ''
+            if on_ready:
+                on_ready(self._key_range(A + '.', 'logit_scale'))                  # issued from the side stream: the collective waits for THIS tower
+            self._ev[3].record(side)
         self._bwd_visual(self._pool_bwd(vout, 8, dv, n, 'v'), on_ready)
+        main.wait_event(self._ev[3])
         self.loss = self.losses.mean()
         return self.loss
 

@@ -124,6 +124,7 @@ class FlatTrainer:
             o += sz
         self.flat_b.copy_(self.flat_p)
         self.step_count = 0
+        self._ws_prefix = ''
         self.tn_wgrad = os.environ.get('SF_TN_WGRAD', '1') != '0'      # weight gradients straight from row-major operands (sf_gemm_tn_splitk)
         self.norm = torch.zeros(1, device=self.dev, dtype=torch.float32)
         self.loss = torch.zeros(1, device=self.dev, dtype=torch.float32)
@@ -133,6 +134,7 @@ class FlatTrainer:
 
     # ---- small helpers -----------------------------------------------------------------------------------
     def _buf(self, name, shape, dtype, zero=False):
+        name = self._ws_prefix + name                                     # per-stream workspaces (Stage-1 runs its two towers concurrently)
         t = self._ws.get(name)
         n = int(math.prod(shape))
         if t is None or t.numel() < n or t.dtype != dtype:
