@@ -514,10 +514,12 @@ __global__ __launch_bounds__(64) void cross_entropy_kernel(const float* __restri
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += __expf(z[b * ldz + c] - m);
     s = wave_sum(s);
-    const int t = (int)tgt[b];
-    total += (m + logf(s)) - z[b * ldz + t];
+    const int64_t t64 = tgt[b];
+    const bool ok = t64 >= 0 && t64 < C;            // a target outside [0, C) (an ignore_index, a class of another grid): NaN loss, zero gradient row -
+    const int t = ok ? (int)t64 : 0;                //   never an out-of-bounds read (F.cross_entropy raises; a kernel cannot)
+    total += ok ? (m + logf(s)) - z[b * ldz + t] : __builtin_nanf("");
     if (dz)
-      for (int c = lane; c < C; c += 64) dz[b * lddz + c] = (__expf(z[b * ldz + c] - m) / s - (c == t ? 1.f : 0.f)) * (grad_scale / B);
+      for (int c = lane; c < C; c += 64) dz[b * lddz + c] = ok ? (__expf(z[b * ldz + c] - m) / s - (c == t ? 1.f : 0.f)) * (grad_scale / B) : 0.f;
   }
   if (lane == 0) *loss = total / B;
 }

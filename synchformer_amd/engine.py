@@ -65,6 +65,11 @@ class SynchformerEngine:
     # weight preparation (one-off; not on the hot path)
     # ------------------------------------------------------------------------------------------------
     def load_weights(self, sd: Dict[str, torch.Tensor]):
+        self.load_tower_weights(sd)
+        self.load_sync_weights(sd)
+
+    def load_tower_weights(self, sd: Dict[str, torch.Tensor]):
+        """The two feature extractors (214.8M parameters; frozen in Stage-2 training, train_utils.py:199-204)."""
         dev = self.dev
         f32 = lambda k: sd[k].detach().to(dev, torch.float32)
         lin = lambda k: _Lin(sd[k + '.weight'], sd[k + '.bias'], dev)
@@ -110,6 +115,13 @@ class SynchformerEngine:
             i += 1
         self.a_norm = _LN(sd, f'{a}.ast.layernorm', dev)
         self.a_agg = self._agg(sd, f'{a}.freq_attn_agg')
+
+    def load_sync_weights(self, sd: Dict[str, torch.Tensor]):
+        """vproj / aproj / sync transformer (22.6M parameters: the part Stage-2 trains).  Cheap enough to refresh after every
+        optimizer step of an external optimizer without touching the tower operands or the workspaces."""
+        dev = self.dev
+        f32 = lambda k: sd[k].detach().to(dev, torch.float32)
+        lin = lambda k: _Lin(sd[k + '.weight'], sd[k + '.bias'], dev)
         self.vproj, self.aproj = lin('vproj'), lin('aproj')
         t = 'transformer'
         self.s_vln, self.s_aln = _LN(sd, f'{t}.vis_in_lnorm', dev), _LN(sd, f'{t}.aud_in_lnorm', dev)

@@ -20,7 +20,6 @@ import types
 from typing import Any, Mapping, Optional
 
 import torch
-import torch.nn.functional as F
 
 from . import synth
 from .engine import SynchformerEngine
@@ -78,8 +77,40 @@ def uninstall_reference_aliases():
         del sys.modules[name]
 
 
-def _register_tree(root: torch.nn.Module, schema: Mapping[str, tuple], prefix: str, seed: int):
-    """Create nested containers + nn.Parameters so that root.state_dict() has exactly the reference's keys."""
+_NORM_PARTS = ('norm', 'ln1', 'ln2', 'ln_f', 'lnorm', 'layernorm')
+
+
+def _reference_init(full: str, shape) -> torch.Tensor:
+    """One freshly initialised tensor by the reference's rules, drawn from torch's global RNG (so torch.manual_seed governs it):
+    sync transformer - Linear N(0, 0.02), zero biases, LayerNorm 1 / 0 (sync_model.py:13-20), OFF/MOD tokens and the position table
+    torch.randn (sync_model.py:129-130, modules/transformer.py:127); feature extractors - Linear / conv trunc_normal(std 0.02), zero
+    biases, LayerNorm 1 / 0, trunc_normal(0.02) cls / position tables (video_model_builder.py:71-83,151-158, motionformer.py:288-299,
+    336-343, modeling_ast.py:397-409), zeros for `temp_embed` and the AST tokens / position table (vmb:83, modeling_ast.py:65-71).
+    Differences kept on purpose: nn.MultiheadAttention's xavier in_proj of the aggregators is drawn as trunc_normal(0.02) like every other
+    Linear there (motionformer.py:299 re-initialises the nn.Linear members only), and `patch_embed_3d.proj` is not zero-initialised
+    (vmb:61 zeroes it, which makes a from-scratch visual tower input-independent; every shipped config loads it from a checkpoint)."""
+    leaf = full.rsplit('.', 1)[-1]
+    t = torch.empty(tuple(shape), dtype=torch.float32)
+    in_sync = full.startswith('transformer.')
+    is_norm = any(p in part for part in full.split('.')[:-1] for p in _NORM_PARTS) and leaf in ('weight', 'bias')
+    if is_norm:
+        return t.fill_(1.0 if leaf == 'weight' else 0.0)
+    if leaf in ('OFF_tok', 'MOD_tok') or full.endswith('pos_emb_cfg.pos_emb'):
+        return t.normal_()
+    if leaf in ('temp_embed', 'distillation_token', 'position_embeddings') or (leaf == 'cls_token' and '.ast.' in full):
+        return t.zero_()
+    if leaf in ('cls_token', 'pos_embed', 'pos_emb'):
+        return torch.nn.init.trunc_normal_(t, std=0.02)
+    if leaf.endswith('bias'):
+        return t.zero_()
+    if len(shape) >= 2:
+        return t.normal_(0.0, 0.02) if in_sync else torch.nn.init.trunc_normal_(t, std=0.02)
+    return t.zero_()
+
+
+def _register_tree(root: torch.nn.Module, schema: Mapping[str, tuple], prefix: str, seed: Optional[int]):
+    """Create nested containers + nn.Parameters so that root.state_dict() has exactly the reference's keys.  seed None (default):
+    the reference's initialisation rules on torch's RNG; an int: the deterministic synthetic fill of synchformer_amd.synth (tests, benches)."""
     for full, shape in schema.items():
         if not full.startswith(prefix):
             continue
@@ -89,7 +120,7 @@ def _register_tree(root: torch.nn.Module, schema: Mapping[str, tuple], prefix: s
             if not hasattr(mod, p):
                 mod.add_module(p, torch.nn.Module())
             mod = getattr(mod, p)
-        mod.register_parameter(parts[-1], torch.nn.Parameter(synth.fill_tensor(full, shape, seed)))
+        mod.register_parameter(parts[-1], torch.nn.Parameter(_reference_init(full, shape) if seed is None else synth.fill_tensor(full, shape, seed)))
 
 
 class DoNothingBridge(torch.nn.Identity):
@@ -134,7 +165,7 @@ class MotionFormer(torch.nn.Module):
 
     def __init__(self, extract_features: bool = False, ckpt_path: str = None, factorize_space_time: bool = None,
                  agg_space_module: str = None, agg_time_module: str = None, add_global_repr: bool = True,
-                 agg_segments_module: str = None, max_segments: int = None, _seed: int = 0):
+                 agg_segments_module: str = None, max_segments: int = None, _seed: Optional[int] = None):
         super().__init__()
         if not extract_features or not factorize_space_time or agg_space_module != 'TransformerEncoderLayer':
             raise NotImplementedError('only extract_features=True, factorize_space_time=True, '
@@ -173,7 +204,7 @@ class AST(torch.nn.Module):
     def __init__(self, extract_features: bool = False, ckpt_path: str = None, feat_type: str = None,
                  max_spec_t: int = None, factorize_freq_time: bool = None, agg_freq_module: str = None,
                  agg_time_module: str = None, add_global_repr: bool = True, agg_segments_module: str = None,
-                 max_segments: int = None, _seed: int = 0):
+                 max_segments: int = None, _seed: Optional[int] = None):
         super().__init__()
         if not extract_features or not factorize_freq_time or agg_freq_module != 'TransformerEncoderLayer':
             raise NotImplementedError('only extract_features=True, factorize_freq_time=True, '
@@ -211,7 +242,7 @@ class GlobalTransformer(torch.nn.Module):
     _head_name = 'off_head'
 
     def __init__(self, tok_pdrop, embd_pdrop, resid_pdrop, attn_pdrop, n_layer, n_head, n_embd, pos_emb_cfg=None,
-                 off_head_cfg=None, _seed: int = 0):
+                 off_head_cfg=None, _seed: Optional[int] = None):
         super().__init__()
         if n_embd != 768 or n_head != 8:
             raise NotImplementedError('native sync transformer is built for n_embd=768, n_head=8 (configs/sync.yaml:44-46)')
@@ -225,11 +256,16 @@ class GlobalTransformer(torch.nn.Module):
         skip = ('transformer.pos_emb_cfg.', 'transformer.off_head.')
         _register_tree(self, {k: v for k, v in schema.items() if not k.startswith(skip)}, 'transformer.', _seed)
         if pos_emb_cfg is not None:
-            self.pos_emb_cfg = instantiate_from_config(pos_emb_cfg)
-            with torch.no_grad():
-                self.pos_emb_cfg.pos_emb.copy_(synth.fill_tensor('transformer.pos_emb_cfg.pos_emb', (1, n_pos, n_embd), _seed))
+            self.pos_emb_cfg = instantiate_from_config(pos_emb_cfg)      # torch.randn, modules/transformer.py:127
+            if _seed is not None:
+                with torch.no_grad():
+                    self.pos_emb_cfg.pos_emb.copy_(synth.fill_tensor('transformer.pos_emb_cfg.pos_emb', (1, n_pos, n_embd), _seed))
         if off_head_cfg is not None:
             self.off_head = instantiate_from_config(off_head_cfg)
+            with torch.no_grad():                                         # self.apply(init_weights), sync_model.py:147
+                for nm, p_ in self.off_head.named_parameters():
+                    key = 'transformer.off_head.' + nm
+                    p_.copy_(_reference_init(key, p_.shape) if _seed is None else synth.fill_tensor(key, p_.shape, _seed))
         _reorder_like(self, [k[len('transformer.'):] for k in schema])
 
     def forward(self, v: torch.Tensor, a: torch.Tensor, targets=None, attempt_to_apply_heads=True):
@@ -244,14 +280,40 @@ class GlobalTransformerWithSyncabilityHead(GlobalTransformer):
     """sync_model.py:176-190: off_head -> Identity, 2-way sync_head on token 0."""
 
     def __init__(self, tok_pdrop, embd_pdrop, resid_pdrop, attn_pdrop, n_layer, n_head, n_embd, pos_emb_cfg=None,
-                 off_head_cfg=None, _seed: int = 0):
+                 off_head_cfg=None, _seed: Optional[int] = None):
         super().__init__(tok_pdrop, embd_pdrop, resid_pdrop, attn_pdrop, n_layer, n_head, n_embd, pos_emb_cfg, off_head_cfg,
                          _seed)
         self.off_head = torch.nn.Identity()
         self.sync_head = torch.nn.Linear(n_embd, 2)
-        with torch.no_grad():
-            self.sync_head.weight.copy_(synth.fill_tensor('transformer.sync_head.weight', (2, n_embd), _seed))
-            self.sync_head.bias.copy_(synth.fill_tensor('transformer.sync_head.bias', (2,), _seed))
+        with torch.no_grad():                                             # self.apply(init_weights), sync_model.py:185
+            for nm, p_ in self.sync_head.named_parameters():
+                key = 'transformer.sync_head.' + nm
+                p_.copy_(_reference_init(key, p_.shape) if _seed is None else synth.fill_tensor(key, p_.shape, _seed))
+
+
+class _CrossEntropyFunction(torch.autograd.Function):
+    """F.cross_entropy(logits, targets) (mean reduction) on sf_cross_entropy: loss and dlogits come out of one launch."""
+
+    @staticmethod
+    def forward(ctx, logits, targets):
+        from . import ops
+        z = logits.detach().float().contiguous()
+        loss = torch.empty(1, device=z.device, dtype=torch.float32)
+        dz = torch.empty_like(z)
+        ops.cross_entropy(z, targets.to(torch.int64).contiguous(), loss, dz)
+        ctx.save_for_backward(dz)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        return dz * g, None
+
+
+def _cross_entropy(logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+    if targets.dtype not in (torch.int64, torch.int32) or targets.dim() != 1:
+        raise NotImplementedError('cross_entropy: class-index targets of shape (B,) only (scripts/train_sync.py:171)')
+    return _CrossEntropyFunction.apply(logits, targets)
 
 
 def _reorder_like(mod: torch.nn.Module, order):
@@ -315,23 +377,33 @@ class Synchformer(torch.nn.Module):
             m = getattr(self, name)
             if not isinstance(m, torch.nn.Linear) or m.in_features != 768 or m.out_features != 768:
                 raise NotImplementedError(f'{name}: only torch.nn.Linear(768, 768) (configs/sync.yaml:28-39) is built natively')
-            with torch.no_grad():
-                m.weight.copy_(synth.fill_tensor(f'{name}.weight', (768, 768), 0))
-                m.bias.copy_(synth.fill_tensor(f'{name}.bias', (768,), 0))
+            # nn.Linear's own default initialisation stays, as in the reference (sync_model.py:33-34 never re-initialises the bridges)
         self._sf_engine = None
         self.seg_chunk = 224
 
     # -- engine cache ---------------------------------------------------------------------------------------
-    def _engine(self) -> SynchformerEngine:
-        # keyed on the FROZEN part only would be enough for training, but inference must also see updated sync weights
-        key = _param_key(self)
-        if self._sf_engine is not None and self._sf_engine[0] == key:
-            return self._sf_engine[1]
+    def _split_keys(self):
+        frozen, sync = [], []
+        for n, p in self.named_parameters():
+            (sync if n.startswith(('vproj.', 'aproj.', 'transformer.')) else frozen).append((p.data_ptr(), p._version))
+        return tuple(frozen), tuple(sync)
+
+    def _engine(self, need_sync: bool = True) -> SynchformerEngine:
+        """The engine is keyed on the EXTRACTOR parameters only (214.8M weights, the multi-GB workspaces): an optimizer step on
+        vproj / aproj / the sync transformer (Stage-2 training, train_utils.py:199-204) refreshes just those 22.6M operand copies in
+        place, and only when the inference path (`need_sync`) is about to read them - the train step has its own copies."""
+        k_frozen, k_sync = self._split_keys()
+        if self._sf_engine is not None and self._sf_engine[0] == k_frozen:
+            eng = self._sf_engine[1]
+            if need_sync and self._sf_engine[2] != k_sync:
+                eng.load_sync_weights({k: v for k, v in self.state_dict().items() if k.startswith(('vproj.', 'aproj.', 'transformer.'))})
+                self._sf_engine = (k_frozen, eng, k_sync)
+            return eng
         dev = next(self.parameters()).device
         if dev.type != 'cuda':
             raise RuntimeError('Synchformer computes on a HIP device only (no CPU fallback); call .to("cuda") first')
         eng = SynchformerEngine(self.state_dict(), dev, seg_chunk=self.seg_chunk)
-        self._sf_engine = (key, eng)
+        self._sf_engine = (k_frozen, eng, k_sync)
         return eng
 
     # -- reference API --------------------------------------------------------------------------------------
@@ -344,9 +416,10 @@ class Synchformer(torch.nn.Module):
             raise AssertionError('cont_mask is not supported with for_loop=True')       # ast.py:153
         vis_in = vis
         # the two extractors are independent (sync_model.py:45-52): the audio tower runs on a second stream next to the visual one
-        vis, aud = self._engine().both_towers(lambda: self.extract_vfeats(vis_in, for_loop, vis_mask=vis_mask), aud, aud_mask)
         trainable = self._trainable_params()
-        if torch.is_grad_enabled() and any(p.requires_grad for p in trainable.values()):
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in trainable.values())
+        vis, aud = self._engine(need_sync=not training).both_towers(lambda: self.extract_vfeats(vis_in, for_loop, vis_mask=vis_mask), aud, aud_mask)
+        if training:
             logits = self._train_forward(vis, aud, trainable)
         else:
             logits = self._engine().sync_transformer(vis, aud)
@@ -365,12 +438,13 @@ class Synchformer(torch.nn.Module):
         pd = getattr(self.transformer, 'pdrops', {}) if self.transformer.training else {}
         if any(not p.requires_grad for p in trainable.values()):
             raise NotImplementedError('partially frozen sync transformer is not supported')
-        eng = self._engine()
+        eng = self._engine(need_sync=False)
         tr = getattr(self, '_sf_trainer', None)
-        if tr is None or tr.engine is not eng:
+        if tr is None:                                       # ONE trainer per module: its forward counter seeds the dropout masks of each step
             tr = SyncTrainer(self.state_dict(), next(self.parameters()).device, engine=eng)
             object.__setattr__(self, '_sf_trainer', tr)
             object.__setattr__(self, '_sf_trainer_key', None)
+        tr.engine = eng
         tr.embd_pdrop, tr.resid_pdrop, tr.attn_pdrop = (float(pd.get(k) or 0.0) for k in ('embd_pdrop', 'resid_pdrop', 'attn_pdrop'))
         key = tuple((p.data_ptr(), p._version) for p in trainable.values())
         if key != self._sf_trainer_key:                      # an external optimizer moved the nn.Parameters
@@ -382,18 +456,18 @@ class Synchformer(torch.nn.Module):
         """vis_mask: bool, shaped like vis, 0 = masked content (sync_model.py:72-80); like the reference, not with for_loop=True."""
         if vis_mask is not None and for_loop:
             raise AssertionError('cont_mask is not supported with for_loop=True')       # motionformer.py:201
-        return self._engine().extract_vfeats(vis, vis_mask)
+        return self._engine(need_sync=False).extract_vfeats(vis, vis_mask)
 
     def extract_afeats(self, aud, for_loop, aud_mask=None):
         if aud_mask is not None and for_loop:
             raise AssertionError('cont_mask is not supported with for_loop=True')       # ast.py:153
-        return self._engine().extract_afeats(aud, aud_mask)
+        return self._engine(need_sync=False).extract_afeats(aud, aud_mask)
 
     def compute_loss(self, logits, targets, loss_fn: str = None):
         loss = None
         if targets is not None:
             if loss_fn is None or loss_fn == 'cross_entropy':
-                loss = F.cross_entropy(logits, targets)
+                loss = _cross_entropy(logits, targets)
             else:
                 raise NotImplementedError(f'Loss {loss_fn} not implemented')
         return loss
@@ -410,6 +484,7 @@ class Synchformer(torch.nn.Module):
             elif weight_len < self_len:
                 raise ValueError(f'Cant load state dict with shorter seq len ({weight_len} vs {self_len})')
         self._sf_engine = None
+        object.__setattr__(self, '_sf_trainer_key', None)      # the train step re-reads its parameter copies (the trainer and its dropout counter stay)
         return super().load_state_dict(sd, strict)
 
 

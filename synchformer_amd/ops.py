@@ -212,11 +212,14 @@ def similarity(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: float
     return out
 
 
-def cross_entropy(logits: torch.Tensor, targets: torch.Tensor, loss: torch.Tensor):
-    """loss[0] = F.cross_entropy(logits, targets) (mean) for fp32 (B, C) logits and int64 class targets."""
+def cross_entropy(logits: torch.Tensor, targets: torch.Tensor, loss: torch.Tensor, dlogits: torch.Tensor = None):
+    """loss[0] = F.cross_entropy(logits, targets) (mean) for fp32 (B, C) logits and int64 class targets; optionally
+    dlogits = d loss / d logits in the same launch.  A target outside [0, C) gives a NaN loss (and a zero dlogits row)."""
     assert logits.dtype == torch.float32 and targets.dtype == torch.int64 and loss.dtype == torch.float32
+    assert dlogits is None or (dlogits.dtype == torch.float32 and dlogits.shape == logits.shape)
     rc = _lib.load().sf_cross_entropy(_dev(logits, 'logits'), _ld(logits), _dev(targets, 'targets'), logits.shape[0], logits.shape[1],
-                                      _dev(loss, 'loss'), None, 0, 1.0, _stream())
+                                      _dev(loss, 'loss'), _dev(dlogits, 'dlogits') if dlogits is not None else None,
+                                      _ld(dlogits) if dlogits is not None else 0, 1.0, _stream())
     _lib.check(rc, 'sf_cross_entropy')
     return loss
 

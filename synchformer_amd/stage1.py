@@ -601,9 +601,15 @@ class AVCLIPTrainFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, trainer: AVCLIPTrainer, vis, aud, *params):
         ctx.trainer = trainer
-        return trainer.forward_backward(vis, aud).clone()
+        loss = trainer.forward_backward(vis, aud).clone()
+        trainer.generation = ctx.generation = getattr(trainer, 'generation', 0) + 1
+        return loss
 
     @staticmethod
     def backward(ctx, gout):
         tr = ctx.trainer
+        if ctx.generation != tr.generation:
+            # the gradients live in the trainer's ONE flat buffer: a later grad-enabled forward has overwritten them
+            raise RuntimeError('AVCLIP: backward() of a loss whose gradients were overwritten by a later grad-enabled forward of the same '
+                               'module; call backward() before the next forward (or run that forward under torch.no_grad())')
         return (None, None, None) + tuple(tr.g[k] * gout for k in tr.keys)

@@ -513,10 +513,16 @@ class SyncTrainFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, trainer: SyncTrainer, vfeat, afeat, *params):
         ctx.trainer = trainer
-        return trainer._forward(vfeat, afeat).clone()
+        logits = trainer._forward(vfeat, afeat).clone()
+        trainer.generation = ctx.generation = getattr(trainer, 'generation', 0) + 1
+        return logits
 
     @staticmethod
     def backward(ctx, dlogits):
         tr = ctx.trainer
+        if ctx.generation != tr.generation:
+            # the saved activations live in the trainer's shared workspaces: a later grad-enabled forward has overwritten them
+            raise RuntimeError('Synchformer: backward() through a forward whose saved activations were overwritten by a later grad-enabled '
+                               'forward of the same module; call backward() before the next forward (or run that forward under torch.no_grad())')
         tr._backward(dlogits.contiguous().float())
         return (None, None, None) + tuple(tr.g[k].clone() for k in tr.keys)
