@@ -61,6 +61,16 @@ int sf_gemm_bf16_batched(const uint16_t* A, int64_t lda, int64_t sA0, int64_t sA
 int sf_gemm_tn_splitk(const uint16_t* dY, int64_t ldy, const uint16_t* X, int64_t ldx, float* part, int64_t M, int64_t N, int64_t K,
                       int split, int64_t kc, void* stream);
 
+/* Full-row projection fused with the residual add and the NEXT LayerNorm (N = 768 fixed):
+ *   X[m,:] = A[m,:] W^T + bias + R[m,:]  (fp32; X may alias R),   Y[m,:] = LayerNorm(X[m,:]) * gamma + beta  (bf16; Y may alias A).
+ * A: M x K bf16, W: 768 x K bf16, K % 32 == 0; R / X / Y below 4 GiB.  One workgroup owns 128 complete rows, so the fp32 residual
+ * stream is read once and written once per sub-layer and the separate sf_layernorm768 launch disappears.  Replaces, inside
+ * DividedSpaceTimeBlock.forward (vit_helper.py:364-376), `x + temporal_fc/proj(...)` -> norm1, `x + proj(attn(...))` -> norm2 and
+ * `x + mlp.fc2(...)` -> the next block's norm3. */
+int sf_gemm_res_ln768(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, const float* R, int64_t ldr,
+                      float* X, int64_t ldx, const float* gamma, const float* beta, float eps, uint16_t* Y, int64_t ldy, int64_t M,
+                      int64_t K, void* stream);
+
 /* Tuning / test hook (process-global, not for production threads): force the GEMM tile configuration of subsequent sf_gemm_bf16
  * calls.  -1 = automatic choice by shape (default); 0 = 128x128x64, 4 waves, two workgroups per CU; 7 = persistent 256x256x64,
  * 8 waves, v_mfma_f32_32x32x16_bf16; 1-6, 8, 9 = the other tilings measured in profiles/r01_gemm_configs.md (tools/bench_gemm.py). */

@@ -1,0 +1,422 @@
+// Full-row projection GEMM fused with the residual add AND the next LayerNorm, for gfx950 (MI355X):
+//     X[m, :] = A[m, :] * W^T + bias + R[m, :]        (fp32 residual stream, 768 columns; X may alias R)
+//     Y[m, :] = LayerNorm(X[m, :]) * gamma + beta     (bf16: the A operand of the NEXT sub-layer's GEMM; Y may alias A)
+// This is `x = x + proj(attn(norm(x)))` / `x = x + mlp(norm(x))` followed by the norm that opens the next sub-layer of a
+// DividedSpaceTimeBlock (vit_helper.py:364-376: temporal proj -> norm1, spatial proj -> norm2, fc2 -> norm3 of the next block).
+//
+// Why a kernel of its own: with K = N = 768 the un-fused pair is HBM-bound twice - the GEMM epilogue reads and writes the fp32
+// stream (2 x 1.08 GB per launch at 224 segments), then sf_layernorm768 reads the same 1.08 GB again to write 0.54 GB of bf16
+// (profiles/r01_bench_summary.md: 13 % + 8 % of the inference step).  LayerNorm needs whole rows, so one workgroup owns BM = 128
+// complete rows: a 128 x 768 fp32 accumulator tile = 393 KB, i.e. three quarters of the CU's register file - 8 waves as 2 (M) x 4 (N),
+// each holding a 64 x 192 block as 2 x 6 fragments of v_mfma_f32_32x32x16_bf16 (192 accumulator registers per lane).  The epilogue adds
+// bias + residual, writes X once, reduces the row statistics in registers (16-lane DPP row sums, then 4 partials per row through LDS)
+// and writes the normalised bf16 rows: the stream is read once and written once, and the separate LayerNorm launch disappears.
+//
+// Main loop: K-steps of 32 (a stage = 128 x 32 of A + 768 x 32 of W = 56 KiB; two ring slots = 112 KiB), operands HBM/L2 -> LDS by LDS-DMA
+// (global_load_lds_dwordx4 from inline asm, SGPR base + 32-bit lane offset: 7 pieces of 1 KiB per wave per stage), one counted wait +
+// raw s_barrier per K-step, the refill of the other slot issued behind the first MFMA cluster.  LDS rows are 64 B; 16-byte chunk c of row r
+// sits at slot c ^ ((r >> 2) & 3) (applied to the SOURCE address of the lane-linear DMA and to the fragment reads): the 16-lane groups a
+// ds_read_b128 is served in then touch 16 distinct slots of the 256-byte bank row.
+// The workgroups are persistent (one per CU, tile t = block + k * grid): the next tile's first two stages are put in flight before the
+// epilogue runs, so the epilogue's HBM traffic and the next main loop's first operand loads overlap.
+#include "sf_common.h"
+#include <stdlib.h>
+#include "../../include/synchformer_hip.h"
+
+#define RL_BM 128
+#define RL_N 768
+#define RL_BK 32
+#define RL_A_BYTES (RL_BM * RL_BK * 2)                 // 8 KiB
+#define RL_B_BYTES (RL_N * RL_BK * 2)                  // 48 KiB
+#define RL_STAGE (RL_A_BYTES + RL_B_BYTES)             // 56 KiB
+#define RL_SLAB_OFF (2 * RL_STAGE)                     // per-wave 16 x 64 fp32 transposition slabs
+#define RL_SLAB_BYTES 4096
+#define RL_STAT_OFF (RL_SLAB_OFF + 8 * RL_SLAB_BYTES)  // [128 rows][4 column waves] partial sums, twice (mean pass, variance pass)
+#define RL_STAT_BYTES (RL_BM * 4 * 4)
+#define RL_PARAM_OFF (RL_STAT_OFF + 2 * RL_STAT_BYTES) // bias | gamma | beta (768 floats each), staged once per workgroup
+#define RL_LDS (RL_PARAM_OFF + 3 * RL_N * 4)           // 157 KiB
+#define RL_RING_WAVE 12288                             // residual landing ring inside the (idle) operand slots: 3 steps x 4 KiB per wave
+
+#ifndef SF_RL_STORE_AUX
+#define SF_RL_STORE_AUX 2     // nt: written once, consumed by a later launch
+#endif
+#ifndef SF_RL_LOAD_AUX
+#define SF_RL_LOAD_AUX 2
+#endif
+
+typedef __attribute__((ext_vector_type(4))) unsigned int rl_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int rl_u32x2;
+
+struct ResLnArgs {
+  const bf16_t* A; int64_t lda;
+  const bf16_t* W; int64_t ldw;
+  const float* bias;
+  const float* R; int64_t ldr;
+  float* X; int64_t ldx;
+  const float* gamma; const float* beta;
+  bf16_t* Y; int64_t ldy;
+  int64_t M;
+  int K;
+  float eps;
+  uint32_t tiles;
+};
+
+// One stage of LDS-DMA for this wave: its A piece (16 rows) and its six W pieces (96 rows), 1 KiB each.  SGPR base + 32-bit VGPR byte offset
+// (zero-extended); M0 = LDS destination of the piece.  Issued from inline asm so that hipcc neither counts these loads nor guards later
+// ds_reads with vmcnt(0); every wait for them is a hand-placed counted s_waitcnt.  M0 is saved / restored inside the statement.
+__device__ __forceinline__ void rl_dma7(uint32_t voff_a, const void* sa, uint32_t voff_b, const void* sb0, const void* sb1, const void* sb2,
+                                        const void* sb3, const void* sb4, const void* sb5, uint32_t lds_a, uint32_t lds_b) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %10\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+      "s_mov_b32 m0, %11\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %7\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %8\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %9\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff_a), "v"(voff_b), "s"(sa), "s"(sb0), "s"(sb1), "s"(sb2), "s"(sb3), "s"(sb4), "s"(sb5), "s"(lds_a), "s"(lds_b)
+      : "memory", "scc");
+}
+
+// Four 1-KiB pieces of the fp32 residual (4 rows x 64 columns each) -> consecutive KiB of this wave's landing ring; `nt`: read once.
+__device__ __forceinline__ void rl_dma_r4(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, const void* sbase, uint32_t lds) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5 nt\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5 nt\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5 nt\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5 nt\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(lds)
+      : "memory", "scc");
+}
+
+__device__ __forceinline__ uint32_t rl_lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+template <int N>
+__device__ __forceinline__ void rl_wait_vmcnt_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4); every lane of the row ends with the total
+__device__ __forceinline__ float rl_row16_sum(float v) {
+  int t;
+  t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true);  v += __int_as_float(t);   // quad_perm [1,0,3,2]
+  t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true);  v += __int_as_float(t);   // quad_perm [2,3,0,1]
+  t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true); v += __int_as_float(t);   // row_half_mirror
+  t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true); v += __int_as_float(t);   // row_mirror
+  return v;
+}
+
+// ABL: ablation mask of the measurement builds (tools/bench_gemm_ln.py, SF_RL_ABL): 1 = no residual loads, 2 = no X stores, 4 = no Y stores,
+// 8 = no operand refills after the first two stages.  The product instantiation is ABL = 0.
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;                        // 2 x 4 waves, wave tile 64 x 192
+  // ---- LDS-DMA addressing: lane i of a piece fills (row i >> 2, slot i & 3) with source chunk slot ^ ((row >> 2) & 3) ----
+  const int prow = lane >> 2, pslot = lane & 3;
+  const int pchunk = pslot ^ ((prow >> 2) & 3);
+  const uint32_t voff_b0 = (uint32_t)(prow * p.ldw * 2 + pchunk * 16);
+  const char* wbase = reinterpret_cast<const char*>(p.W) + (int64_t)(wave * 96) * p.ldw * 2;
+  const int64_t wstep = (int64_t)16 * p.ldw * 2;
+  const void* sb0 = wbase; const void* sb1 = wbase + wstep; const void* sb2 = wbase + 2 * wstep;
+  const void* sb3 = wbase + 3 * wstep; const void* sb4 = wbase + 4 * wstep; const void* sb5 = wbase + 5 * wstep;
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(rl_lds_addr(smem));
+  const uint32_t lds_a_w = lds0 + wave * 1024, lds_b_w = lds0 + RL_A_BYTES + wave * 6 * 1024;
+
+  // fragment read offsets (bytes) inside an operand tile for the two 16-deep k-steps of a stage
+  int frag_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) frag_off[ks] = (lane & 31) * 64 + (((ks * 2 + (lane >> 5)) ^ (((lane & 31) >> 2) & 3)) << 4);
+  const int a_base = wm * 64 * 64, b_base = RL_A_BYTES + wn * 192 * 64;
+
+  const int nk = p.K / RL_BK;
+  uint32_t t = blockIdx.x;
+  if (t >= p.tiles) return;
+
+  int64_t m0 = (int64_t)t * RL_BM;
+  const void* sa; uint32_t voff_a0;
+  auto set_tile = [&](int64_t mm) {
+    sa = reinterpret_cast<const char*>(p.A) + mm * p.lda * 2;
+    int64_t r = wave * 16 + prow;
+    const int64_t last = p.M - 1 - mm;                           // tail tile: rows beyond M re-read the last valid row (their outputs are dropped)
+    if (r > last) r = last;
+    voff_a0 = (uint32_t)(r * p.lda * 2 + pchunk * 16);
+  };
+  auto stage = [&](int slot, int kt) {
+    rl_dma7(voff_a0 + kt * (RL_BK * 2), sa, voff_b0 + kt * (RL_BK * 2), sb0, sb1, sb2, sb3, sb4, sb5, lds_a_w + slot * RL_STAGE,
+            lds_b_w + slot * RL_STAGE);
+  };
+  set_tile(m0);
+  stage(0, 0);
+  bool stage1_in_flight = false;
+  if (nk > 1) { stage(1, 1); stage1_in_flight = true; }
+
+  float* stat = reinterpret_cast<float*>(smem + RL_STAT_OFF);
+  float* prm = reinterpret_cast<float*>(smem + RL_PARAM_OFF);     // the epilogue reads bias / gamma / beta from LDS: a global load there would make
+  for (int i = tid; i < RL_N; i += 512) {                          // hipcc wait vmcnt(0), i.e. for every residual piece still in flight
+    prm[i] = p.bias ? p.bias[i] : 0.f;
+    prm[RL_N + i] = p.gamma[i];
+    prm[2 * RL_N + i] = p.beta[i];
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), (short)0, (int)(uint32_t)(p.M * p.ldr * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(p.X, (short)0, (int)(uint32_t)(p.M * p.ldx * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.Y, (short)0, (int)(uint32_t)(p.M * p.ldy * 2), 0x00020000);
+
+  for (;;) {
+    f32x16 acc[2][6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      rl_wait_vmcnt_barrier<0>();                                  // stage kt landed everywhere; slot (kt+1)&1 is free
+      const bool refill = kt + 1 < nk && !(kt == 0 && stage1_in_flight) && !(ABL & 8);
+      const char* st = smem + (kt & 1) * RL_STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 a[2], b[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) b[j] = *reinterpret_cast<const bf16x8*>(st + b_base + j * 32 * 64 + frag_off[ks]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 32 * 64 + frag_off[ks]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        if (ks == 0 && refill) {                                   // the refill's 7 LDS-DMA issues ride behind the first MFMA cluster
+          __builtin_amdgcn_sched_barrier(0);
+          stage((kt + 1) & 1, kt + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // every wave is done with both slots -> they take the next tile's first two stages while this tile's epilogue runs
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int64_t em0 = m0;
+    const uint32_t tnext = t + gridDim.x;
+    const bool more = tnext < p.tiles;
+
+    // ---- epilogue, pass 1: x = acc + bias + residual, kept in registers in row-contiguous form ----------------------------------------
+    // step s = c * 4 + g: 16-row group g (of 4) x 64-column chunk c (of 3) goes through this wave's slab; afterwards lane (lr, ecol) holds
+    // rows g*16 + ps*4 + lr (ps < 4), columns c*64 + ecol .. +3 of the wave tile.  The residual rows arrive by LDS-DMA in exactly that
+    // lane order (piece ps of a step = 4 rows x 256 B, lane i <- row i >> 4, 16 bytes at column (i & 15) * 4), three steps = 12 KiB per wave
+    // in flight in the idle operand slots: no registers are spent on prefetch depth, and this pass issues no other vector-memory
+    // operation, so the counted vmcnt waits below cover exactly these pieces (the X stores come after the pass: loads and stores complete
+    // out of order with respect to each other, a counted wait over a mix would not be safe).
+    // Every lane-derived quantity is re-derived here from an opaque copy of the thread id: computed up front, hipcc keeps ~10 of them
+    // live across the main loop, where the 192 accumulators + 32 fragment registers leave no room (they spilled into the k-loop).
+    int etid = threadIdx.x;
+    asm volatile("" : "+v"(etid));
+    const int elane = etid & 63, l31 = elane & 31, hi = elane >> 5, lr = elane >> 4, ecol = (elane & 15) * 4;
+    const int gcol0 = wn * 192 + ecol;                             // + c * 64
+    float* slab = reinterpret_cast<float*>(smem + RL_SLAB_OFF + wave * RL_SLAB_BYTES);
+    const char* ring = smem + wave * RL_RING_WAVE + elane * 16;
+    const uint32_t ring_lds = lds0 + wave * RL_RING_WAVE;
+    int64_t rrow0 = em0 + wm * 64;                                  // tail tile: rows beyond M re-read row M - 1 (their outputs are dropped)
+    if (rrow0 > p.M - 1) rrow0 = p.M - 1;
+    const int64_t rleft = p.M - 1 - rrow0;
+    const int rlast = rleft < 63 ? (int)rleft : 63;
+    const void* rbase = reinterpret_cast<const char*>(p.R) + rrow0 * p.ldr * 4;
+    auto issue_res = [&](int s) {
+      if (ABL & 1) return;
+      const int c = s >> 2, g = s & 3;
+      uint32_t vo[4];
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        int rl = g * 16 + ps * 4 + lr;
+        if (rl > rlast) rl = rlast;
+        vo[ps] = (uint32_t)(rl * (int)p.ldr + gcol0 + c * 64) * 4u;
+      }
+      rl_dma_r4(vo[0], vo[1], vo[2], vo[3], rbase, ring_lds + (s % 3) * 4096);
+    };
+    issue_res(0); issue_res(1); issue_res(2);
+    float4 xr[4][3][4];
+#pragma unroll
+    for (int s = 0; s < 12; ++s) {
+      const int c = s >> 2, g = s & 3, i = g >> 1, q2 = g & 1;
+      const float4 bias4 = *reinterpret_cast<const float4*>(prm + gcol0 + c * 64);
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) slab[(qq * 8 + hi * 4 + r) * 64 + jj * 32 + l31] = acc[i][2 * c + jj][(q2 * 2 + qq) * 4 + r];
+      if (!(ABL & 1)) {                                             // step s has landed: only the (<= 2) younger steps may be outstanding
+        if (s <= 9) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (s == 10) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        float4 v = *reinterpret_cast<const float4*>(slab + (ps * 4 + lr) * 64 + ecol);
+        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(ABL & 1)) rv = *reinterpret_cast<const float4*>(ring + (s % 3) * 4096 + ps * 1024);
+        v.x = (v.x + bias4.x) + rv.x; v.y = (v.y + bias4.y) + rv.y; v.z = (v.z + bias4.z) + rv.z; v.w = (v.w + bias4.w) + rv.w;
+        xr[g][c][ps] = v;
+      }
+      if (s + 3 < 12) {                                             // this step's ring slot has been read back: refill it with step s + 3
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_res(s + 3);
+      }
+    }
+    // ---- X (fp32 stream) out: 48 row-contiguous 16-byte stores per lane, nothing waits for them --------------------------------------
+    const int64_t row0 = em0 + wm * 64 + lr;
+    const uint32_t xoff0 = (uint32_t)(row0 * p.ldx + gcol0) * 4u, xstep = (uint32_t)(4 * p.ldx) * 4u;
+    if (!(ABL & 2)) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float4 v = xr[g][c][ps];
+            rl_u32x4 o;
+            o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y); o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rx, xoff0 + (uint32_t)(g * 4 + ps) * xstep + (uint32_t)c * 256u, 0, SF_RL_STORE_AUX);
+          }
+    }
+
+    // ---- pass 2: row sums (16-lane DPP sums, then the 4 column waves' partials through LDS) --------------------------------------
+    const int srow0 = (wm * 64 + lr) * 4;                           // stat index of (g = 0, ps = 0); + (g * 16 + ps * 4) * 4
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        float sres = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sres += (xr[g][c][ps].x + xr[g][c][ps].y) + (xr[g][c][ps].z + xr[g][c][ps].w);
+        sres = rl_row16_sum(sres);
+        if ((elane & 15) == 0) stat[srow0 + (g * 16 + ps * 4) * 4 + wn] = sres;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // raw barrier: __syncthreads() would also drain the 48 stores in flight
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // every wave is past its residual ring: the operand slots take the next tile's first two stages while the rest of the epilogue runs
+    stage1_in_flight = false;
+    if (more) {
+      m0 = (int64_t)tnext * RL_BM;
+      set_tile(m0);
+      stage(0, 0);
+      if (nk > 1) { stage(1, 1); stage1_in_flight = true; }
+    }
+    // ---- pass 3: centred second moments (the mean of a row is re-derived from its 4 partials where it is needed: no 32 live registers) ----
+    float* stat2 = stat + RL_BM * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const float4 q = *reinterpret_cast<const float4*>(stat + srow0 + (g * 16 + ps * 4) * 4);
+        const float mu = ((q.x + q.y) + (q.z + q.w)) * (1.0f / RL_N);
+        float sres = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float4 v = xr[g][c][ps];
+          const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+          sres += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        sres = rl_row16_sum(sres);
+        if ((elane & 15) == 0) stat2[srow0 + (g * 16 + ps * 4) * 4 + wn] = sres;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // ---- pass 4: normalise, scale, shift, bf16, store ------------------------------------------------------------------------------
+    const uint32_t yoff0 = (uint32_t)(row0 * p.ldy + gcol0) * 2u, ystep = (uint32_t)(4 * p.ldy) * 2u;
+    float4 gm[3], bt[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      gm[c] = *reinterpret_cast<const float4*>(prm + RL_N + gcol0 + c * 64);
+      bt[c] = *reinterpret_cast<const float4*>(prm + 2 * RL_N + gcol0 + c * 64);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const float4 q = *reinterpret_cast<const float4*>(stat + srow0 + (g * 16 + ps * 4) * 4);
+        const float4 q2 = *reinterpret_cast<const float4*>(stat2 + srow0 + (g * 16 + ps * 4) * 4);
+        const float mu = ((q.x + q.y) + (q.z + q.w)) * (1.0f / RL_N);
+        const float rs = rsqrtf(((q2.x + q2.y) + (q2.z + q2.w)) * (1.0f / RL_N) + p.eps);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float4 v = xr[g][c][ps];
+          rl_u32x2 o;
+          o.x = pack_bf2((v.x - mu) * rs * gm[c].x + bt[c].x, (v.y - mu) * rs * gm[c].y + bt[c].y);
+          o.y = pack_bf2((v.z - mu) * rs * gm[c].z + bt[c].z, (v.w - mu) * rs * gm[c].w + bt[c].w);
+          if (!(ABL & 4) || o.x == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b64(o, ry, yoff0 + (uint32_t)(g * 4 + ps) * ystep + (uint32_t)c * 128u, 0, SF_RL_STORE_AUX);
+        }
+      }
+    if (!more) break;
+    t = tnext;
+  }
+}
+
+extern "C" int sf_gemm_res_ln768(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* R, int64_t ldr,
+                                 float* X, int64_t ldx, const float* gamma, const float* beta, float eps, bf16_t* Y, int64_t ldy, int64_t M,
+                                 int64_t K, void* stream) {
+  SF_CHECK_ARG(A && W && R && X && gamma && beta && Y, "sf_gemm_res_ln768: null pointer");
+  SF_CHECK_ARG(K > 0 && (K % RL_BK) == 0 && K < (1 << 20), "sf_gemm_res_ln768: K=%lld must be a positive multiple of 32", (long long)K);
+  SF_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0 && lda >= K && ldw >= K, "sf_gemm_res_ln768: lda/ldw must be >= K and multiples of 8 elements");
+  SF_CHECK_ARG((ldr % 4) == 0 && (ldx % 4) == 0 && (ldy % 4) == 0 && ldr >= RL_N && ldx >= RL_N && ldy >= RL_N,
+               "sf_gemm_res_ln768: ldr/ldx/ldy must be >= 768 and multiples of 4 elements");
+  SF_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)R % 16) == 0 && ((uintptr_t)X % 16) == 0 &&
+                   ((uintptr_t)Y % 8) == 0 && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0),
+               "sf_gemm_res_ln768: operands must be 16-byte aligned");
+  if (M <= 0) return 0;
+  const int64_t m_pad = ((M + RL_BM - 1) / RL_BM) * RL_BM;
+  // 32-bit byte offsets: buffer descriptors for R / X / Y (rows >= M are dropped by the hardware range check) and the lane offsets of the
+  // LDS-DMA (16 rows of A or W plus the k offset)
+  SF_CHECK_ARG(m_pad * ldr * 4 < ((int64_t)1 << 32) && m_pad * ldx * 4 < ((int64_t)1 << 32) && m_pad * ldy * 2 < ((int64_t)1 << 32),
+               "sf_gemm_res_ln768: R / X / Y must stay below 4 GiB");
+  SF_CHECK_ARG(128 * lda * 2 + K * 2 < ((int64_t)1 << 31) && 16 * ldw * 2 + K * 2 < ((int64_t)1 << 31), "sf_gemm_res_ln768: row strides too large");
+  static bool attr_set = false;
+  static int n_cu = 0;
+  if (!attr_set) {
+    const void* kerns[] = {(const void*)gemm_res_ln768_kernel<0>, (const void*)gemm_res_ln768_kernel<1>, (const void*)gemm_res_ln768_kernel<15>};
+    for (const void* k : kerns) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS);
+      if (e != hipSuccess) { sf_set_error("sf_gemm_res_ln768: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { sf_set_error("sf_gemm_res_ln768: device query failed"); return -1; }
+    n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  ResLnArgs a;
+  a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.R = R; a.ldr = ldr; a.X = X; a.ldx = ldx; a.gamma = gamma; a.beta = beta;
+  a.Y = Y; a.ldy = ldy; a.M = M; a.K = (int)K; a.eps = eps;
+  const int64_t tiles = m_pad / RL_BM;
+  SF_CHECK_ARG(tiles < ((int64_t)1 << 31), "sf_gemm_res_ln768: too many tiles");
+  a.tiles = (uint32_t)tiles;
+  const int64_t blocks = tiles < n_cu ? tiles : n_cu;              // one persistent workgroup per CU
+  static int abl = -1;
+  if (abl < 0) { const char* e = getenv("SF_RL_ABL"); abl = e ? atoi(e) : 0; }
+  switch (abl) {
+    case 0: hipLaunchKernelGGL(gemm_res_ln768_kernel<0>, dim3((unsigned)blocks), dim3(512), RL_LDS, (hipStream_t)stream, a); break;
+    case 1: hipLaunchKernelGGL(gemm_res_ln768_kernel<1>, dim3((unsigned)blocks), dim3(512), RL_LDS, (hipStream_t)stream, a); break;
+    case 15: hipLaunchKernelGGL(gemm_res_ln768_kernel<15>, dim3((unsigned)blocks), dim3(512), RL_LDS, (hipStream_t)stream, a); break;
+    default: sf_set_error("sf_gemm_res_ln768: unknown SF_RL_ABL %d", abl); return -1;
+  }
+  SF_LAUNCH_CHECK();
+  return 0;
+}

@@ -58,6 +58,8 @@ class SynchformerEngine:
         self.seg_chunk = seg_chunk
         self._ws = {}
         self.audio_side_stream = os.environ.get('SF_AUDIO_SIDE_STREAM', '1') != '0'
+        self.fuse_ln = os.environ.get('SF_FUSE_LN', '1') != '0'            # A/B switches of the full-row GEMM + residual + LayerNorm kernel
+        self.fuse_ln_fc2 = os.environ.get('SF_FUSE_LN_FC2', '0') != '0'   # K = 3072: the persistent 256x256 kernel + separate LayerNorm is faster (profiles/r02_gemm_ln.md)
         self._a_side = None
         self.load_weights(state_dict)
 
@@ -263,18 +265,37 @@ class SynchformerEngine:
                 groups = 8
             ops.attention_cls_combine(part, xn, n_part=groups, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
 
-        for b in self.v_blocks:   # DividedSpaceTimeBlock.forward (vit_helper.py:364-376)
-            ops.layernorm(X, b['norm3'].g, b['norm3'].b, xn, EPS_VIS)
+        # DividedSpaceTimeBlock.forward (vit_helper.py:364-376).  With `fuse_ln` every residual GEMM also emits the LayerNorm that opens the next
+        # sub-layer (sf_gemm_res_ln768: the fp32 stream is read and written once per sub-layer, no separate LayerNorm launch); the last block's
+        # fc2 stays un-fused because the norm after it is the row-mapped final norm below.
+        fuse_ln = self.fuse_ln and rows >= 128 * 64
+        nb = len(self.v_blocks)
+        for bi, b in enumerate(self.v_blocks):
+            if bi == 0 or not fuse_ln:
+                ops.layernorm(X, b['norm3'].g, b['norm3'].b, xn, EPS_VIS)
             ops.gemm(xn, b['t_qkv'].w, b['t_qkv'].b, qkv)
             divided('time')
-            ops.gemm(xn, b['t_proj'].w, b['t_proj'].b, X, residual=X)
-            ops.layernorm(X, b['norm1'].g, b['norm1'].b, xn, EPS_VIS)
+            if fuse_ln:
+                ops.gemm_res_ln(xn, b['t_proj'].w, b['t_proj'].b, X, b['norm1'].g, b['norm1'].b, xn, EPS_VIS)
+            else:
+                ops.gemm(xn, b['t_proj'].w, b['t_proj'].b, X, residual=X)
+                ops.layernorm(X, b['norm1'].g, b['norm1'].b, xn, EPS_VIS)
             ops.gemm(xn, b['s_qkv'].w, b['s_qkv'].b, qkv)
             divided('space')
-            ops.gemm(xn, b['s_proj'].w, b['s_proj'].b, X, residual=X)
-            ops.layernorm(X, b['norm2'].g, b['norm2'].b, xn, EPS_VIS)
+            if fuse_ln:
+                ops.gemm_res_ln(xn, b['s_proj'].w, b['s_proj'].b, X, b['norm2'].g, b['norm2'].b, xn, EPS_VIS)
+            else:
+                ops.gemm(xn, b['s_proj'].w, b['s_proj'].b, X, residual=X)
+                ops.layernorm(X, b['norm2'].g, b['norm2'].b, xn, EPS_VIS)
             ops.gemm(xn, b['fc1'].w, b['fc1'].b, hid, gelu=True)
-            ops.gemm(hid, b['fc2'].w, b['fc2'].b, X, residual=X)
+            if fuse_ln and self.fuse_ln_fc2 and bi + 1 < nb:
+                nx = self.v_blocks[bi + 1]['norm3']
+                ops.gemm_res_ln(hid, b['fc2'].w, b['fc2'].b, X, nx.g, nx.b, xn, EPS_VIS)
+            else:
+                ops.gemm(hid, b['fc2'].w, b['fc2'].b, X, residual=X)
+                if fuse_ln and bi + 1 < nb:
+                    nx = self.v_blocks[bi + 1]['norm3']
+                    ops.layernorm(X, nx.g, nx.b, xn, EPS_VIS)
         # drop CLS -> final norm -> per-frame sequences with the aggregator CLS in front (mf:231-232, 356-375)
         Z = self._buf('Z', n * 8 * AGG_V * D, torch.float32).view(n * 8 * AGG_V, D)
         ops.broadcast_rows(Z, self.v_agg['cls'], n_seq=n * 8, dst_seq_rows=AGG_V)

@@ -65,6 +65,22 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     return out
 
 
+def gemm_res_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                y: torch.Tensor, eps: float, *, M: Optional[int] = None, residual: Optional[torch.Tensor] = None):
+    """x[m] = a[m] @ w.T + bias + residual[m] (fp32, in place when residual is None or x), y[m] = LayerNorm(x[m]) * gamma + beta (bf16).
+    a (>= M, K) bf16, w (768, K) bf16; y may be the buffer `a` lives in (each 128-row tile reads its A rows before it writes them)."""
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dtype == torch.float32 and y.dtype == torch.bfloat16
+    assert w.shape[0] == 768 and a.shape[1] == w.shape[1] and x.shape[1] == 768 and y.shape[1] == 768
+    M = a.shape[0] if M is None else M
+    r = x if residual is None else residual
+    assert r.dtype == torch.float32
+    rc = _lib.load().sf_gemm_res_ln768(_dev(a, 'a'), _ld(a), _dev(w, 'w'), _ld(w), _dev(bias, 'bias') if bias is not None else None,
+                                       _dev(r, 'residual'), _ld(r), _dev(x, 'x'), _ld(x), _dev(gamma, 'gamma'), _dev(beta, 'beta'), float(eps),
+                                       _dev(y, 'y'), _ld(y), M, w.shape[1], _stream())
+    _lib.check(rc, 'sf_gemm_res_ln768')
+    return x, y
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, eps: float, *,
               rows: Optional[int] = None, in_map: RowMap = None, out_map: RowMap = None, accumulate: bool = False):
     assert x.dtype == torch.float32 and x.shape[1] == 768 and out.shape[1] == 768

@@ -266,3 +266,48 @@ def test_torch_ops_registered(gpu):
     torch.testing.assert_close(y.cpu(), torch.nn.functional.layer_norm(x, (768,)), rtol=1e-5, atol=1e-5)
     with pytest.raises((RuntimeError, NotImplementedError)):
         torch.ops.synchformer.layernorm768(x, torch.ones(768), torch.zeros(768), torch.empty(10, 768), 1e-5)   # CPU: no kernel
+
+
+@pytest.mark.parametrize('M,K', [(1, 768), (127, 768), (128, 768), (1000, 768), (4500, 3072), (40000, 768), (33000, 3072)])
+def test_gemm_res_ln(gpu, M, K):
+    """sf_gemm_res_ln768 (full-row GEMM + bias + fp32 residual + the next LayerNorm) against fp32 torch on the same bf16 operands and
+    against the un-fused HIP pair (sf_gemm_bf16 + sf_layernorm768).  X: fp32 sums of bf16 products (rtol 1e-4); Y: bf16 (2^-8 relative)
+    of a LayerNorm output of magnitude <= ~4.  M = 40000 / 33000 give 313 / 258 row tiles: more than the 256 persistent workgroups, so the
+    tile loop with its next-tile prefetch, and the ragged last tile, are exercised; A rows beyond M are poisoned."""
+    from synchformer_amd import ops
+    a, w = _bf(_rand(M + 5, K, seed=1)), _bf(_rand(768, K, seed=2, scale=0.05))
+    a[M:] = float('nan')
+    b, r = _rand(768, seed=3), _rand(M, 768, seed=4, scale=2.0) + 0.5
+    gam, bet = 1.0 + 0.1 * _rand(768, seed=5), 0.1 * _rand(768, seed=6)
+    eps = 1e-6
+    x_ref = a[:M].float() @ w.float().t() + b + r
+    y_ref = torch.nn.functional.layer_norm(x_ref, (768,), gam, bet, eps)
+    x = torch.full((M + 3, 768), 7.0, device=gpu)
+    x[:M] = r.to(gpu)
+    y = torch.full((M + 3, 768), 3.0, device=gpu, dtype=torch.bfloat16)
+    ops.gemm_res_ln(a.to(gpu), w.to(gpu), b.to(gpu), x, gam.to(gpu), bet.to(gpu), y, eps, M=M)
+    torch.testing.assert_close(x[:M].cpu(), x_ref, rtol=1e-4, atol=3e-4)
+    torch.testing.assert_close(y[:M].float().cpu(), y_ref, rtol=1e-2, atol=1e-2)
+    assert (x[M:] == 7.0).all() and (y[M:] == 3.0).all(), 'rows beyond M were written'
+    # the un-fused pair on the same operands: same fp32 X up to summation order, same bf16 Y up to one rounding
+    x2 = torch.empty(M, 768, device=gpu)
+    x2.copy_(r)
+    y2 = torch.empty(M, 768, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(a.to(gpu), w.to(gpu), b.to(gpu), x2, M=M, residual=x2)
+    ops.layernorm(x2, gam.to(gpu), bet.to(gpu), y2, eps)
+    torch.testing.assert_close(x[:M], x2, rtol=1e-5, atol=2e-5)
+    assert ((y[:M].float() - y2.float()).abs() <= 2.0 ** -7 * y2.float().abs() + 1e-6).all()
+
+
+def test_gemm_res_ln_in_place_operand(gpu):
+    """Y aliasing A (the engine's XN buffer holds the attention output going in and the normalised rows coming out) and X aliasing R."""
+    from synchformer_amd import ops
+    M, K = 36000, 768
+    a, w = _bf(_rand(M, K, seed=11)).to(gpu), _bf(_rand(768, K, seed=12, scale=0.05)).to(gpu)
+    b, r = _rand(768, seed=13).to(gpu), _rand(M, 768, seed=14).to(gpu)
+    gam, bet = (1.0 + 0.1 * _rand(768, seed=15)).to(gpu), (0.1 * _rand(768, seed=16)).to(gpu)
+    x0, y0 = r.clone(), torch.empty(M, 768, device=gpu, dtype=torch.bfloat16)
+    ops.gemm_res_ln(a, w, b, x0, gam, bet, y0, 1e-6)
+    x1, buf = r.clone(), a.clone()
+    ops.gemm_res_ln(buf, w, b, x1, gam, bet, buf, 1e-6)
+    assert torch.equal(x0, x1) and torch.equal(y0, buf)
