@@ -72,11 +72,27 @@ class GemmTimer:
             nbytes = m * k * 2 + n * k * 2 + m * n * out.element_size() + (m * n * 4 if res is not None else 0)   # A + W + C (+ R), each once
             self.records.append((e0, e1, 2.0 * m * n * k, nbytes))
             return r
+        def timed_ln(a, w, bias, x, gamma, beta, y, eps, *, M=None, residual=None):
+            # the full-row GEMM + residual + LayerNorm launches are GEMM launches of the same family (sf_gemm_res_ln768)
+            if not self.enabled:
+                return self.orig_ln(a, w, bias, x, gamma, beta, y, eps, M=M, residual=residual)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self.orig_ln(a, w, bias, x, gamma, beta, y, eps, M=M, residual=residual)
+            e1.record()
+            m = a.shape[0] if M is None else M
+            n, k = w.shape
+            nbytes = m * k * 2 + n * k * 2 + m * n * (4 + 4 + 2)                       # A + W + R read, X + Y written, each once
+            self.records.append((e0, e1, 2.0 * m * n * k, nbytes))
+            return r
         self.ops.gemm = timed
+        self.orig_ln = self.ops.gemm_res_ln
+        self.ops.gemm_res_ln = timed_ln
         return self
 
     def __exit__(self, *a):
         self.ops.gemm = self.orig
+        self.ops.gemm_res_ln = self.orig_ln
 
     def summary(self):
         ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
@@ -238,7 +254,7 @@ def main():
         }
         if n_gemm:
             ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'sf_gemm_bf16 (gemm_bf16_persistent_kernel + gemm_bf16_kernel)', 'achieved': round(ach, 1),
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'sf_gemm_bf16 + sf_gemm_res_ln768 (gemm_bf16_persistent_kernel, gemm_bf16_kernel, gemm_res_ln768_kernel)', 'achieved': round(ach, 1),
                                'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': round(ach / (PEAK_BF16 / 1e12), 4),
                                'traffic': pmc_traffic(), 'algorithmic_bytes_per_launch': round(gt.bytes / n_gemm),
                                'launches': n_gemm // args.steps,

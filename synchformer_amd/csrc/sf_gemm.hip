@@ -98,6 +98,9 @@ __device__ __forceinline__ void dma4_nt(const void* g0, const void* g1, const vo
 #ifndef SF_DMA_SPREAD
 #define SF_DMA_SPREAD 1   // 1 (measured +1-2.6 %): issue the next stage's LDS-DMA behind the first two MFMA clusters instead of right after the barrier
 #endif
+#ifndef SF_KROT
+#define SF_KROT 0      // (measured neutral on every shape: profiles/r02_gemm_ln.md) persistent kernel: workgroup i of an XCD walks its k-loop starting at k-tile (i * SF_KROT) % nk (0 = every workgroup starts at 0)
+#endif
 #ifndef SF_A_NT
 #define SF_A_NT 0      // 1: stream the A operand (activations) through L2 with the nt hint as well
 #endif
@@ -488,14 +491,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p
     }
   };
   const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(lds_addr(smem) + (wave * 4) * 1024);
-  auto stage = [&](int s, int kt) {
+  // k-loop rotation: the 32 workgroups of an XCD run in near lockstep (same tile shape, same start), so without it they all ask the XCD's L2
+  // for the SAME operand lines at the same moment (the A panel shared by the column tiles of a row panel, the W rows shared by everything) and
+  // queue on those lines' channels.  Starting every workgroup at a different k-tile spreads the requests over the whole k-extent of the
+  // operands; the sum over k is the same set of products in a rotated order (fp32 accumulation: last-bit differences between tilings).
+  const int nk = p.K / PBK;
+  const int krot = SF_KROT ? (int)((li * (uint32_t)SF_KROT) % (uint32_t)nk) : 0;
+  auto kmap = [&](int kt) { const int k = kt + krot; return k >= nk ? k - nk : k; };
+  auto stage = [&](int s, int kt_) {
+    const int kt = kmap(kt_);
     const uint32_t l = lds_wave + s * P_STAGE;
     if (SF_A_NT) dma4_nt(a_src[0] + kt * PBK, a_src[1] + kt * PBK, a_src[2] + kt * PBK, a_src[3] + kt * PBK, l);
     else dma4(a_src[0] + kt * PBK, a_src[1] + kt * PBK, a_src[2] + kt * PBK, a_src[3] + kt * PBK, l);
     dma4(b_src[0] + kt * PBK, b_src[1] + kt * PBK, b_src[2] + kt * PBK, b_src[3] + kt * PBK, l + PBM * PBK * 2);
   };
 
-  const int nk = p.K / PBK;
   uint32_t t = t_begin + li;
   if (t >= t_end) return;
   int64_t m0; int n0;
@@ -539,7 +549,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p
         if (SF_DMA_SPREAD && refill && kk < 2) {                 // the refill's 8 LDS-DMA issues ride behind the first two MFMA clusters
           __builtin_amdgcn_sched_barrier(0);
           const uint32_t l = lds_wave + ((kt + 1) & 1) * P_STAGE;
-          const int ko = (kt + 1) * PBK;
+          const int ko = kmap(kt + 1) * PBK;
           if (kk == 0) dma4(a_src[0] + ko, a_src[1] + ko, a_src[2] + ko, a_src[3] + ko, l);
           else dma4(b_src[0] + ko, b_src[1] + ko, b_src[2] + ko, b_src[3] + ko, l + PBM * PBK * 2);
           __builtin_amdgcn_sched_barrier(0);

@@ -40,6 +40,12 @@
 #ifndef SF_RL_STORE_AUX
 #define SF_RL_STORE_AUX 2     // nt: written once, consumed by a later launch
 #endif
+#ifndef SF_RL_SPREAD
+#define SF_RL_SPREAD 1        // 1: one LDS-DMA piece behind every third MFMA of the k-step; 0: all seven behind the first MFMA cluster
+#endif
+#ifndef SF_RL_KROT
+#define SF_RL_KROT 1          // workgroup i of an XCD starts its k-loop at k-step (i * SF_RL_KROT) % nk instead of 0 (see below); 0 = off
+#endif
 #ifndef SF_RL_LOAD_AUX
 #define SF_RL_LOAD_AUX 2
 #endif
@@ -80,6 +86,13 @@ __device__ __forceinline__ void rl_dma7(uint32_t voff_a, const void* sa, uint32_
       : "=&s"(keep)
       : "v"(voff_a), "v"(voff_b), "s"(sa), "s"(sb0), "s"(sb1), "s"(sb2), "s"(sb3), "s"(sb4), "s"(sb5), "s"(lds_a), "s"(lds_b)
       : "memory", "scc");
+}
+
+// One piece (SF_RL_SPREAD: the refill's seven pieces are issued one at a time between MFMAs instead of back to back).
+__device__ __forceinline__ void rl_dma1(uint32_t voff, const void* sbase, uint32_t lds) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
 
 // Four 1-KiB pieces of the fp32 residual (4 rows x 64 columns each) -> consecutive KiB of this wave's landing ring; `nt`: read once.
@@ -157,7 +170,13 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
     if (r > last) r = last;
     voff_a0 = (uint32_t)(r * p.lda * 2 + pchunk * 16);
   };
-  auto stage = [&](int slot, int kt) {
+  // k-loop rotation: the 32 workgroups of an XCD (block b sits on XCD b % 8) run in near lockstep, so without it they all ask the XCD's L2 for
+  // the SAME 48 KiB of W at the same moment and queue on those lines; starting every workgroup at a different k-step spreads the requests
+  // over all of W (proj 815 -> 724 us, fc2 2050 -> 1940 us at 224 segments).  Same products, rotated fp32 summation order.
+  const int krot = SF_RL_KROT ? (int)(((blockIdx.x >> 3) * (uint32_t)SF_RL_KROT) % (uint32_t)nk) : 0;
+  auto kmap = [&](int kt) { int k = kt + krot; return k >= nk ? k - nk : k; };
+  auto stage = [&](int slot, int kt_) {
+    const int kt = kmap(kt_);
     rl_dma7(voff_a0 + kt * (RL_BK * 2), sa, voff_b0 + kt * (RL_BK * 2), sb0, sb1, sb2, sb3, sb4, sb5, lds_a_w + slot * RL_STAGE,
             lds_b_w + slot * RL_STAGE);
   };
@@ -198,14 +217,36 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
         for (int j = 0; j < 6; ++j) b[j] = *reinterpret_cast<const bf16x8*>(st + b_base + j * 32 * 64 + frag_off[ks]);
 #pragma unroll
         for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 32 * 64 + frag_off[ks]);
+        if (SF_RL_SPREAD) {
+          // the vector-memory path takes ~16 cycles per 1-KiB piece and the issuing wave is held while it queues: seven back-to-back issues by
+          // all eight waves right after the barrier leave the matrix pipe idle, one piece every third MFMA does not
+          const uint32_t ko = kmap(kt + 1) * (RL_BK * 2), la = lds_a_w + ((kt + 1) & 1) * RL_STAGE, lb = lds_b_w + ((kt + 1) & 1) * RL_STAGE;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        if (ks == 0 && refill) {                                   // the refill's 7 LDS-DMA issues ride behind the first MFMA cluster
-          __builtin_amdgcn_sched_barrier(0);
-          stage((kt + 1) & 1, kt + 1);
-          __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 6; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+              if ((j == 1 || j == 4) && !(ks == 1 && i == 1 && j == 4)) {
+                const int piece = ks * 4 + i * 2 + (j == 4);          // 0 .. 6: A, W0 .. W5
+                __builtin_amdgcn_sched_barrier(0);
+                if (refill) {
+                  if (piece == 0) rl_dma1(voff_a0 + ko, sa, la);
+                  else rl_dma1(voff_b0 + ko, piece == 1 ? sb0 : piece == 2 ? sb1 : piece == 3 ? sb2 : piece == 4 ? sb3 : piece == 5 ? sb4 : sb5,
+                               lb + (piece - 1) * 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          if (ks == 0 && refill) {                                   // the refill's 7 LDS-DMA issues ride behind the first MFMA cluster
+            __builtin_amdgcn_sched_barrier(0);
+            stage((kt + 1) & 1, kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
     }

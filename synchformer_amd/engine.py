@@ -59,7 +59,7 @@ class SynchformerEngine:
         self._ws = {}
         self.audio_side_stream = os.environ.get('SF_AUDIO_SIDE_STREAM', '1') != '0'
         self.fuse_ln = os.environ.get('SF_FUSE_LN', '1') != '0'            # A/B switches of the full-row GEMM + residual + LayerNorm kernel
-        self.fuse_ln_fc2 = os.environ.get('SF_FUSE_LN_FC2', '0') != '0'   # K = 3072: the persistent 256x256 kernel + separate LayerNorm is faster (profiles/r02_gemm_ln.md)
+        self.fuse_ln_fc2 = os.environ.get('SF_FUSE_LN_FC2', '1') != '0'   # K = 3072: 1932 us fused vs 1708 + 277 us (profiles/r02_gemm_ln.md)
         self._a_side = None
         self.load_weights(state_dict)
 

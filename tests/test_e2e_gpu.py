@@ -101,6 +101,41 @@ def test_chunking_invariance(gpu):
     assert torch.equal(a, b)
 
 
+def test_benchmarked_geometry_parity(gpu):
+    """The launch geometry bench.py times - 16 clips x 14 segments = 224 segments in ONE chunk (351,456 token rows: X 1.08 GB, qkv / hidden
+    buffers 1.6 / 2.2 GB, 32-bit buffer offsets close to their 4 GiB limit; configs/sync.yaml:63 batch 16) - against the same inputs run
+    14 segments at a time, for both the fused (sf_gemm_res_ln768) and the un-fused schedule, and clips 0-1 against the REAL reference's
+    golden outputs (e2e_sync_B2.npz).  Bitwise equality between chunkings is not a property of the path: sf_gemm_bf16 picks its tile
+    configuration (256x256 on 32x32x16 MFMA / 128x128 on 16x16x32) by M, and the fused kernel rotates its k-loop per workgroup, so fp32
+    summation orders differ, and a last-bit fp32 difference that flips one bf16 rounding (ulp 4e-3 at 1.0) propagates through the 12 blocks.
+    Bars: features (std 0.44) within 2e-2 and logits within 8e-3 absolute between any two schedules (measured 8e-3 / 3e-3; an addressing
+    fault in the big geometry is an O(0.5) error on at least one segment), and the golden bars of test_golden_sync_logits_and_features."""
+    from synchformer_amd import synth
+    g = np.load(GOLD / 'e2e_sync_B2.npz')
+    eng, _ = _engine(gpu)
+    u8 = torch.cat([synth.make_video_u8(2, 14, 1337), synth.make_video_u8(14, 14, 4242)]).to(gpu)     # clips 0-1 = the golden's inputs
+    aud = torch.cat([synth.make_spectrogram(2, 14, 1337), synth.make_spectrogram(14, 14, 4242)]).to(gpu)
+    res = {}
+    for fuse in (False, True):
+        eng.fuse_ln = fuse
+        for chunk in (224, 14):
+            eng.seg_chunk = chunk
+            vf = eng.extract_vfeats(u8)
+            af = eng.extract_afeats(aud)
+            res[fuse, chunk] = (vf.clone(), af.clone(), eng.sync_transformer(vf, af).clone())
+    ref = res[False, 14]
+    for key, out in res.items():
+        d = [(a - b).abs().max().item() for a, b in zip(out, ref)]
+        print(f'fuse_ln {key[0]} seg_chunk {key[1]}: max |delta| vs un-fused/14: vfeat {d[0]:.2e} afeat {d[1]:.2e} logits {d[2]:.2e}')
+        assert d[0] < 2e-2 and d[1] < 2e-2 and d[2] < 8e-3, (key, d)
+        assert all(torch.isfinite(t).all() for t in out)
+    vf, af, logits = (t.cpu() for t in res[True, 224])
+    gv = torch.from_numpy(g['vfeat_extractor__spatial_attn_agg']).reshape(2, 14, 8, 768)
+    ga = torch.from_numpy(g['afeat_extractor__freq_attn_agg']).reshape(2, 14, 6, 768)
+    assert _rel_rms(vf[:2], gv) < 1.5e-2 and _rel_rms(af[:2], ga) < 1.5e-2
+    assert (logits[:2] - torch.from_numpy(g['logits'])).abs().max().item() < 1.5e-2
+
+
 def test_dropin_module_matches_golden(gpu):
     """The reference-shaped plugin path: instantiate_from_config(sync.yaml model) -> load_state_dict -> model(vis, aud, targets)
     returns (loss, logits) like Synchformer.forward (sync_model.py:38-70); checked against the real reference's outputs."""
