@@ -133,7 +133,7 @@ __device__ __forceinline__ float rl_row16_sum(float v) {
 }
 
 // ABL: ablation mask of the measurement builds (tools/bench_gemm_ln.py, SF_RL_ABL): 1 = no residual loads, 2 = no X stores, 4 = no Y stores,
-// 8 = no operand refills after the first two stages.  The product instantiation is ABL = 0.
+// 8 = no operand refills after the first two stages, 16 = no MFMAs, 32 = only half of the W pieces are refilled.  The product instantiation is ABL = 0.
 template <int ABL>
 __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -225,11 +225,14 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-              if ((j == 1 || j == 4) && !(ks == 1 && i == 1 && j == 4)) {
-                const int piece = ks * 4 + i * 2 + (j == 4);          // 0 .. 6: A, W0 .. W5
+              if (!(ABL & 16)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+              else if (i == 0 && j == 0) acc[0][0][0] += (float)a[0][0] + (float)b[0][0];   // ablation: operands stay live, no matrix work
+              const bool slot_now = SF_RL_SPREAD == 2 ? ((ks == 0 && (j == 0 || j == 2 || j == 4)) || (ks == 1 && i == 0 && j == 0))
+                                                      : ((j == 1 || j == 4) && !(ks == 1 && i == 1 && j == 4));
+              if (slot_now) {
+                const int piece = SF_RL_SPREAD == 2 ? (ks == 1 ? 6 : i * 3 + (j >> 1)) : ks * 4 + i * 2 + (j == 4);   // 0 .. 6: A, W0 .. W5
                 __builtin_amdgcn_sched_barrier(0);
-                if (refill) {
+                if (refill && !((ABL & 32) && (piece & 1) == 0 && piece > 0)) {
                   if (piece == 0) rl_dma1(voff_a0 + ko, sa, la);
                   else rl_dma1(voff_b0 + ko, piece == 1 ? sb0 : piece == 2 ? sb1 : piece == 3 ? sb2 : piece == 4 ? sb3 : piece == 5 ? sb4 : sb5,
                                lb + (piece - 1) * 1024);
@@ -433,7 +436,8 @@ extern "C" int sf_gemm_res_ln768(const bf16_t* A, int64_t lda, const bf16_t* W, 
   static bool attr_set = false;
   static int n_cu = 0;
   if (!attr_set) {
-    const void* kerns[] = {(const void*)gemm_res_ln768_kernel<0>, (const void*)gemm_res_ln768_kernel<1>, (const void*)gemm_res_ln768_kernel<15>};
+    const void* kerns[] = {(const void*)gemm_res_ln768_kernel<0>, (const void*)gemm_res_ln768_kernel<1>, (const void*)gemm_res_ln768_kernel<15>,
+                           (const void*)gemm_res_ln768_kernel<17>, (const void*)gemm_res_ln768_kernel<33>, (const void*)gemm_res_ln768_kernel<49>};
     for (const void* k : kerns) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS);
       if (e != hipSuccess) { sf_set_error("sf_gemm_res_ln768: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -449,13 +453,18 @@ extern "C" int sf_gemm_res_ln768(const bf16_t* A, int64_t lda, const bf16_t* W, 
   const int64_t tiles = m_pad / RL_BM;
   SF_CHECK_ARG(tiles < ((int64_t)1 << 31), "sf_gemm_res_ln768: too many tiles");
   a.tiles = (uint32_t)tiles;
-  const int64_t blocks = tiles < n_cu ? tiles : n_cu;              // one persistent workgroup per CU
-  static int abl = -1;
+  int64_t blocks = tiles < n_cu ? tiles : n_cu;                    // one persistent workgroup per CU
+  static int abl = -1, max_blocks = -1;
+  if (max_blocks < 0) { const char* e = getenv("SF_RL_BLOCKS"); max_blocks = e ? atoi(e) : 0; }   // measurement hook: fewer resident workgroups
+  if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
   if (abl < 0) { const char* e = getenv("SF_RL_ABL"); abl = e ? atoi(e) : 0; }
   switch (abl) {
     case 0: hipLaunchKernelGGL(gemm_res_ln768_kernel<0>, dim3((unsigned)blocks), dim3(512), RL_LDS, (hipStream_t)stream, a); break;
     case 1: hipLaunchKernelGGL(gemm_res_ln768_kernel<1>, dim3((unsigned)blocks), dim3(512), RL_LDS, (hipStream_t)stream, a); break;
     case 15: hipLaunchKernelGGL(gemm_res_ln768_kernel<15>, dim3((unsigned)blocks), dim3(512), RL_LDS, (hipStream_t)stream, a); break;
+    case 17: hipLaunchKernelGGL(gemm_res_ln768_kernel<17>, dim3((unsigned)blocks), dim3(512), RL_LDS, (hipStream_t)stream, a); break;
+    case 33: hipLaunchKernelGGL(gemm_res_ln768_kernel<33>, dim3((unsigned)blocks), dim3(512), RL_LDS, (hipStream_t)stream, a); break;
+    case 49: hipLaunchKernelGGL(gemm_res_ln768_kernel<49>, dim3((unsigned)blocks), dim3(512), RL_LDS, (hipStream_t)stream, a); break;
     default: sf_set_error("sf_gemm_res_ln768: unknown SF_RL_ABL %d", abl); return -1;
   }
   SF_LAUNCH_CHECK();
