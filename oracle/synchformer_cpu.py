@@ -312,6 +312,17 @@ def avclip_forward(sd, vis, aud, logit_scale=0.07, vfeat_all=None, afeat_all=Non
     return dict(vfeat=vfeat, afeat=afeat, sim_v2a=sim_v2a, sim_a2v=sim_a2v, loss=loss)
 
 
+def shift_and_get_preds(a, v, W):
+    """Stage-1 zero-shot read-out (train_clip_src/training/train.py:549-579): a, v (B, S, D) -> (preds_a, preds_v) int64 (B, S - W + 1): every
+    W-segment window of A against every window of V (window similarity = sum of its W segment dot products), argmax along each axis.
+    Pinned to the real function's outputs by tests/golden/shift_preds.npz."""
+    B, S, D = a.shape
+    n = S - W + 1
+    g = torch.einsum('bsd,btd->bst', a.float(), v.float())                                   # per-clip segment similarity
+    sim = torch.stack([torch.stack([sum(g[:, i + w, j + w] for w in range(W)) for j in range(n)], -1) for i in range(n)], -2)   # (B, n, n)
+    return torch.argmax(sim, dim=-2), torch.argmax(sim, dim=-1)
+
+
 # ----------------------------------------------------------------------------------------------------
 # Deterministic input front-ends (dataset/transforms.py)
 # ----------------------------------------------------------------------------------------------------
@@ -328,7 +339,8 @@ def _hz_to_mel_htk(f):
 
 def mel_filterbank(n_freqs=513, f_min=0.0, f_max=8000.0, n_mels=128, sample_rate=16000):
     """torchaudio.functional.melscale_fbanks(norm=None, mel_scale='htk') restated from its documented
-    algorithm (torchaudio is not in this image; PARITY UNPINNED - SURVEY §8c).  -> (n_freqs, n_mels)."""
+    algorithm (torchaudio is not in this image; checked against an independent per-filter evaluation of the HTK triangles in
+    tests/test_oracle_cpu.py::test_mel_frontend_independent_numpy_scipy).  -> (n_freqs, n_mels)."""
     all_freqs = torch.linspace(0, sample_rate // 2, n_freqs, dtype=torch.float64)
     m_pts = torch.linspace(_hz_to_mel_htk(torch.tensor(f_min, dtype=torch.float64)),
                            _hz_to_mel_htk(torch.tensor(f_max, dtype=torch.float64)), n_mels + 2, dtype=torch.float64)
@@ -345,7 +357,9 @@ def mel_frontend(wave, pad_to=66, mean=-4.2677393, std=4.5689974):
     (dataset/transforms.py:815-889; params sync.yaml:183-202): MelSpectrogram(sr 16000, win 400, hop 160,
     n_fft 1024, n_mels 128; torchaudio defaults: periodic Hann zero-padded to n_fft, center+reflect, power 2,
     htk, norm None, f_max sr/2) -> log(x+1e-6) -> right-pad time to 66 with 0 -> (x-mean)/(2*std).
-    wave (..., n) fp32 -> (..., 1, 128, 66).  PARITY UNPINNED (torchaudio absent)."""
+    wave (..., n) fp32 -> (..., 1, 128, 66).  torchaudio is absent from every image of this build, so this is pinned indirectly: torch.stft IS the
+    primitive torchaudio's Spectrogram calls with these arguments, and tests/test_oracle_cpu.py::test_mel_frontend_independent_numpy_scipy
+    checks the whole chain against a numpy / scipy implementation that shares no code with it (2e-4)."""
     lead = wave.shape[:-1]
     w = wave.reshape(-1, wave.shape[-1]).float()
     win = torch.hann_window(400, periodic=True, dtype=torch.float32)

@@ -135,38 +135,122 @@ def train_grads(B=2):
     print('train loss', float(loss), 'total grad norm', float(np.sqrt((np.array(norms) ** 2).sum())))
 
 
-def avclip(B=2, S=3, gain=2.0):
-    """Stage-1 towers (configs/segment_avclip.yaml: agg_time_module 'AveragePooling') run through the REAL MotionFormer / AST.
-    The AVCLIP class itself cannot be imported here (its package __init__ needs torchvision, absent from this image), so the
-    5-line head (F.normalize, sim / scale, eye targets, symmetric CE; open_clip/model.py:506-533) is applied to the real
-    tower outputs with plain torch below - the fixture marks which arrays are reference outputs and which are restated."""
-    ref = ref_import.import_reference()
-    tower = dict(ckpt_path=None, extract_features=True, agg_time_module='AveragePooling', add_global_repr=False,
-                 agg_segments_module='AveragePooling', max_segments=14)
+def _real_avclip(gain, gather_for_loss=False):
+    """The REAL AVCLIP (train_clip_src/open_clip/model.py:449-585) built from configs/segment_avclip.yaml's model section (interpolations
+    resolved, ckpt_path null) with the synthetic weights loaded into its two towers."""
+    import synchformer_amd as sa
+    ref = ref_import.import_reference_avclip()
+    cfg = sa.avclip_yaml_model_config(gather_for_loss=gather_for_loss)['params']
     with ref_import._cwd(ref_import.REF):
-        vt = ref['MotionFormer'](factorize_space_time=True, agg_space_module='TransformerEncoderLayer', **tower).eval()
-        at = ref['AST'](max_spec_t=66, factorize_freq_time=True, agg_freq_module='TransformerEncoderLayer', **tower).eval()
+        m = ref['AVCLIP'](**cfg).eval()
     sd = synth.make_state_dict(SEED, gain=gain)
-    vsd = {k[len('vfeat_extractor.'):]: v for k, v in sd.items() if k.startswith('vfeat_extractor.')}
-    asd = {k[len('afeat_extractor.'):]: v for k, v in sd.items() if k.startswith('afeat_extractor.')}
-    assert list(vt.state_dict().keys()) == list(vsd.keys()) and list(at.state_dict().keys()) == list(asd.keys())
-    vt.load_state_dict(vsd, strict=True)
-    at.load_state_dict(asd, strict=True)
+    own = {'v_encoder.' + k[len('vfeat_extractor.'):]: v for k, v in sd.items() if k.startswith('vfeat_extractor.')}
+    own.update({'a_encoder.' + k[len('afeat_extractor.'):]: v for k, v in sd.items() if k.startswith('afeat_extractor.')})
+    own['logit_scale'] = m.logit_scale.detach().clone()
+    assert set(own) == set(m.state_dict()), set(own) ^ set(m.state_dict())
+    m.load_state_dict(own, strict=True)
+    return m
+
+
+def avclip(B=2, S=3, gain=2.0):
+    """Stage-1 `AVCLIP` (configs/segment_avclip.yaml) - the REAL class: forward() (loss with local features), forward_for_logging() (the four
+    similarity matrices + loss), and compute_loss() fed with features 'gathered' from two ranks, which pins the reference's eye(n, m) target
+    convention under gather_for_loss (open_clip/model.py:489-512: the positive of local row i is column i on EVERY rank)."""
+    m = _real_avclip(gain)
     vis = rgb_frontend_ref(synth.make_video_u8(B, S, SEED)).float()           # (B, S, Tv, C, H, W)
     aud = synth.make_spectrogram(B, S, SEED)                                   # (B, S, 1, F, Ta)
+    v_in, a_in = vis.permute(0, 1, 3, 2, 4, 5), aud.squeeze(2).permute(0, 1, 3, 2)   # AVCLIP is fed (B, S, C, Tv, H, W) / (B, S, Ta, F)
     with torch.no_grad():
-        vseg, _ = vt(vis.permute(0, 1, 3, 2, 4, 5), False)                     # AVCLIP feeds (B, S, C, Tv, H, W)
-        aseg, _ = at(aud.squeeze(2).permute(0, 1, 3, 2), False)                # and (B, S, Ta, F)
-        vfeat = torch.nn.functional.normalize(vseg.flatten(0, 1), dim=-1)
-        afeat = torch.nn.functional.normalize(aseg.flatten(0, 1), dim=-1)
-        scale = 0.07
-        sim_v2a, sim_a2v = vfeat @ afeat.mT / scale, afeat @ vfeat.mT / scale
-        tgt = torch.eye(*sim_v2a.shape)
-        loss = (torch.nn.functional.cross_entropy(sim_v2a, tgt) + torch.nn.functional.cross_entropy(sim_a2v, tgt)) / 2
+        vseg, _ = m.v_encoder(v_in, False)
+        aseg, _ = m.a_encoder(a_in, False)
+        out = m(v_in, a_in)
+        log = m.forward_for_logging(v_in, a_in)
+        vfeat, afeat = out['rgb_features'][0], out['audio_features'][0]
+        # two "ranks" of one clip each (n = S rows per rank, m = 2 S gathered columns): what forward() computes per rank when
+        # world_size == 2 and gather_for_loss (torch.distributed.nn.all_gather concatenates in rank order)
+        n = S
+        gath = {}
+        for r in range(2):
+            loss_r, (s_v2a, s_a2v) = m.compute_loss(vfeat[r * n:(r + 1) * n], afeat[r * n:(r + 1) * n], vfeat.mT, afeat.mT, m.logit_scale, alpha=0)
+            gath[f'gathered_loss_rank{r}'] = loss_r.numpy()
+            gath[f'gathered_sim_v2a_rank{r}'] = s_v2a.numpy()
+        # clamp_logit_scales (open_clip/model.py:569-572): a scale outside [clamp_scale_min, clamp_scale_max] is clamped in place by forward()
+        m.logit_scale.data.fill_(0.9)
+        clamped_hi = float(m(v_in, a_in)['logit_scales'][0])
+        m.logit_scale.data.fill_(1e-5)
+        out_lo = m(v_in, a_in)
     np.savez_compressed(HERE / f'avclip_towers_B{B}S{S}.npz', seed=np.int64(SEED), B=np.int64(B), S=np.int64(S), gain=np.float64(gain),
-                        logit_scale=np.float64(scale), ref_vseg=vseg.numpy(), ref_aseg=aseg.numpy(),
-                        restated_sim_v2a=sim_v2a.numpy(), restated_sim_a2v=sim_a2v.numpy(), restated_loss=loss.numpy())
-    print('avclip towers', tuple(vseg.shape), tuple(aseg.shape), 'loss', float(loss), 'sim spread', float(sim_v2a.max() - sim_v2a.min()))
+                        logit_scale=np.float64(0.07), ref_vseg=vseg.numpy(), ref_aseg=aseg.numpy(),
+                        ref_vfeat=vfeat.numpy(), ref_afeat=afeat.numpy(), ref_loss=out['losses']['segment_contrastive_loss'].numpy(),
+                        ref_sim_v2a=log['segment_sim_v2a'].numpy(), ref_sim_a2v=log['segment_sim_a2v'].numpy(),
+                        ref_sim_v2v=log['segment_sim_v2v'].numpy(), ref_sim_a2a=log['segment_sim_a2a'].numpy(),
+                        ref_logging_loss=log['segment_contrastive_loss'].numpy(), clamped_hi=np.float64(clamped_hi),
+                        clamped_lo=np.float64(float(out_lo['logit_scales'][0])), loss_at_clamped_lo=out_lo['losses']['segment_contrastive_loss'].numpy(),
+                        **gath)
+    print('avclip (real class)', tuple(vseg.shape), tuple(aseg.shape), 'loss', float(out['losses']['segment_contrastive_loss']),
+          'gathered losses', float(gath['gathered_loss_rank0']), float(gath['gathered_loss_rank1']), 'clamps', clamped_hi, float(out_lo['logit_scales'][0]))
+
+
+def shift_preds():
+    """Stage-1 zero-shot read-out `shift_and_get_preds` (train_clip_src/training/train.py:549-579) - the REAL function (its module imports
+    torchvision / torchaudio / matplotlib at module scope: import-only stand-ins, tests/golden/ref_shims_late) on seeded random features."""
+    ref_import.import_reference_avclip()
+    with ref_import._cwd(ref_import.REF):
+        from model.modules.feat_extractors.train_clip_src.training.train import shift_and_get_preds
+    out = {}
+    for tag, (B, S, D, W) in {'a': (3, 14, 768, 8), 'b': (2, 14, 768, 14), 'c': (4, 9, 64, 1), 'd': (1, 14, 768, 5)}.items():
+        g = torch.Generator().manual_seed(100 + B * S + W)
+        a = torch.nn.functional.normalize(torch.randn(B, S, D, generator=g), dim=-1)
+        v = torch.nn.functional.normalize(a + (10.0 if D > 64 else 0.8) * torch.randn(B, S, D, generator=g), dim=-1)   # weakly correlated: a non-trivial argmax
+        pa, pv = shift_and_get_preds(a, v, W)
+        out[f'{tag}_a'], out[f'{tag}_v'] = a.numpy(), v.numpy()
+        out[f'{tag}_W'] = np.int64(W)
+        out[f'{tag}_preds_a'], out[f'{tag}_preds_v'] = pa.numpy(), pv.numpy()
+        print('shift_preds', tag, (B, S, D, W), pa.tolist(), pv.tolist())
+    np.savez_compressed(HERE / 'shift_preds.npz', **out)
+
+
+def segments():
+    """GenerateMultipleSegments (dataset/transforms.py:400-500; is_start_random False, no jitter) - the REAL transform's segment ranges for a
+    grid of clip lengths / segment counts / strides.  Pins synchformer_amd.frontend.segment_ranges (device-side segmenting)."""
+    ref_import.import_reference_avclip()                                       # late shims: the module imports torchvision / torchaudio
+    with ref_import._cwd(ref_import.REF):
+        from dataset.transforms import GenerateMultipleSegments
+    cases = []
+    for v_len, a_len, v_fps, a_fps, seg_v, n_seg, step in [
+            (125, 80000, 25, 16000, 16, 14, 0.5),        # configs/sync.yaml: 5 s crop, 14 half-overlapping segments
+            (250, 160000, 25, 16000, 16, 14, 0.5), (250, 160000, 25, 16000, 16, 0, 0.5), (125, 80000, 25, 16000, 16, 0, 1.0),
+            (120, 76800, 25, 16000, 16, 13, 0.5),       # configs/ft_synchability.yaml: 13 segments
+            (131, 83210, 25, 16000, 16, 14, 0.5), (200, 127999, 25, 16000, 16, 0, 0.5), (125, 110250, 25, 22050, 16, 14, 0.5),
+            (150, 80000, 30, 16000, 16, 12, 0.5), (125, 80000, 25, 16000, 8, 20, 0.75), (124, 79360, 25, 16000, 16, 14, 0.5),
+            (100, 64000, 25, 16000, 16, 14, 0.5), (125, 60000, 25, 16000, 16, 14, 0.5)]:   # too short for 14 segments (video / audio): the transform asserts
+        t = GenerateMultipleSegments(segment_size_vframes=seg_v, n_segments=n_seg or None, is_start_random=False, step_size_seg=step)
+        item = dict(video=torch.zeros(v_len, 1, 1, 1), audio=torch.arange(a_len, dtype=torch.float32), path='synthetic',
+                    meta=dict(video=dict(fps=[v_fps]), audio=dict(framerate=[a_fps])))
+        try:
+            out = t(item)
+            a0 = out['audio'][:, 0].long().tolist()                           # audio sample index = its value
+            nseg, a_size = out['audio'].shape
+            v_size = out['video'].shape[1]
+            cases.append([v_len, a_len, v_fps, a_fps, seg_v, n_seg, int(round(step * 100)), 1, nseg, v_size, a_size] + a0 + [-1] * (32 - nseg))
+        except AssertionError:
+            cases.append([v_len, a_len, v_fps, a_fps, seg_v, n_seg, int(round(step * 100)), 0, 0, 0, 0] + [-1] * 32)
+        print('segments', cases[-1][:11], cases[-1][11:11 + max(cases[-1][8], 0)][:4], '...')
+    # the video starts are recovered the same way from a frame-index video
+    vcases = []
+    for c in cases:
+        v_len, a_len, v_fps, a_fps, seg_v, n_seg, step100, ok = c[:8]
+        if not ok:
+            vcases.append([-1] * 32)
+            continue
+        t = GenerateMultipleSegments(segment_size_vframes=seg_v, n_segments=n_seg or None, is_start_random=False, step_size_seg=step100 / 100)
+        item = dict(video=torch.arange(v_len, dtype=torch.float32).view(v_len, 1, 1, 1), audio=torch.zeros(a_len), path='synthetic',
+                    meta=dict(video=dict(fps=[v_fps]), audio=dict(framerate=[a_fps])))
+        v0 = t(item)['video'][:, 0, 0, 0, 0].long().tolist()
+        vcases.append(v0 + [-1] * (32 - len(v0)))
+    np.savez_compressed(HERE / 'segment_ranges.npz', cases=np.array(cases, dtype=np.int64), v_starts=np.array(vcases, dtype=np.int64),
+                        columns=np.array(['v_len', 'a_len', 'v_fps', 'a_fps', 'seg_v', 'n_seg(0=max)', 'step*100', 'ok', 'n_out', 'v_size', 'a_size',
+                                          'a_start[0..31]']))
 
 
 def _real_towers(gain):
@@ -255,7 +339,7 @@ def e2e_masked(B=1, S=2, gain=2.0):
 
 if __name__ == '__main__':
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['sync', 'sync_gain2', 'syncability', 'train', 'avclip', 'avclip_grads', 'masked']
+    which = sys.argv[1:] or ['sync', 'sync_gain2', 'syncability', 'train', 'avclip', 'shift_preds', 'segments', 'avclip_grads', 'masked']
     if 'sync' in which:
         e2e_sync(2)
     if 'sync_gain2' in which:
@@ -266,6 +350,10 @@ if __name__ == '__main__':
         train_grads(2)
     if 'avclip' in which:
         avclip(2, 3)
+    if 'shift_preds' in which:
+        shift_preds()
+    if 'segments' in which:
+        segments()
     if 'avclip_grads' in which:
         avclip_grads(1, 3)
     if 'masked' in which:

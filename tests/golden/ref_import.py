@@ -64,6 +64,24 @@ def import_reference():
     return _imported
 
 
+def import_reference_avclip():
+    """The REAL `AVCLIP` class (train_clip_src/open_clip/model.py:449-585) and `shift_and_get_preds` machinery of Stage 1.  Its package
+    imports torchvision and ftfy at module scope (image transforms / tokenizer clean-up, neither on the audio-visual path); both are absent
+    from this image, so import-only stand-ins (tests/golden/ref_shims_late/: every callable in them raises) go on sys.path AFTER
+    `transformers` has been imported - had transformers seen a `torchvision` it would try to use it."""
+    ref = import_reference()
+    if 'AVCLIP' in ref:
+        return ref
+    late = Path(__file__).resolve().parent / 'ref_shims_late'
+    for p in (str(late), str(REF / 'model' / 'modules' / 'feat_extractors' / 'train_clip_src')):     # `import open_clip` (top level) is used inside
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    with _cwd(REF):
+        from model.modules.feat_extractors.train_clip_src.open_clip.model import AVCLIP
+    ref['AVCLIP'] = AVCLIP
+    return ref
+
+
 def sync_yaml_model_params(n_segments_tokens: int = 198, num_off_cls: int = 21,
                            transformer_target: str = 'model.sync_model.GlobalTransformer') -> dict:
     """`configs/sync.yaml: model.params` with the four `${...}` interpolations resolved by hand and the

@@ -258,3 +258,25 @@ def test_postprocess_grid_and_topk_match_reference_semantics():
         assert top[b][0][0] >= top[b][1][0] >= top[b][4][0]
     with pytest.raises(ValueError):
         class_grid(-1, 1, 2)
+
+
+def test_segment_ranges_match_reference_transform():
+    """synchformer_amd.frontend.segment_ranges against the REAL GenerateMultipleSegments (dataset/transforms.py:400-500) run on index-valued
+    streams (tests/golden/segment_ranges.npz, made by make_golden.py segments): starts, sizes and counts are integers - exact."""
+    import numpy as np
+    from synchformer_amd.frontend import segment_ranges
+    g = np.load(Path(__file__).resolve().parent / 'golden' / 'segment_ranges.npz')
+    n_ok = 0
+    for c, vs in zip(g['cases'], g['v_starts']):
+        v_len, a_len, v_fps, a_fps, seg_v, n_seg, step100, ok, n_out, v_size, a_size = (int(x) for x in c[:11])
+        kw = dict(v_fps=v_fps, a_fps=a_fps, segment_size_vframes=seg_v, n_segments=n_seg or None, step_size_seg=step100 / 100)
+        if not ok:
+            with pytest.raises(ValueError):
+                segment_ranges(v_len, a_len, **kw)
+            continue
+        r = segment_ranges(v_len, a_len, **kw)
+        assert (r['n_segments'], r['v_size'], r['a_size']) == (n_out, v_size, a_size), (c[:11], r)
+        assert [r['a_start'] + i * r['a_stride'] for i in range(n_out)] == [int(x) for x in c[11:11 + n_out]], (c[:11], r)
+        assert [r['v_start'] + i * r['v_stride'] for i in range(n_out)] == [int(x) for x in vs[:n_out]], (c[:11], r)
+        n_ok += 1
+    assert n_ok >= 10

@@ -71,12 +71,27 @@ def test_avclip_forward_matches_reference_towers(gpu):
     vfeat, afeat = out['rgb_features'][0].cpu(), out['audio_features'][0].cpu()
     assert vfeat.shape == (B * S, 768) and out['rgb_features'][1] is None and out['logit_scales'][1] is None
     assert (vfeat.norm(dim=-1) - 1).abs().max() < 1e-5
-    cos_ref = torch.from_numpy(g['restated_sim_v2a']) * float(g['logit_scale'])
+    # the REAL AVCLIP class' outputs (forward / forward_for_logging of open_clip/model.py:475-567; cosines = sim * logit_scale)
+    cos_ref = torch.from_numpy(g['ref_sim_v2a']) * float(g['logit_scale'])
     dcos = (log['segment_sim_v2a'].cpu() * 0.07 - cos_ref).abs().max().item()
-    dloss = abs(float(out['losses']['segment_contrastive_loss']) - float(g['restated_loss']))
+    dloss = abs(float(out['losses']['segment_contrastive_loss']) - float(g['ref_loss']))
     print(f'avclip: vseg relrms {ev:.4f} aseg relrms {ea:.4f} | cos max {dcos:.5f} | loss delta {dloss:.5f}')
     assert ev < 1.5e-2 and ea < 1.5e-2
     assert dcos < 2e-3 and dloss < 1e-2
+    for k in ('v2a', 'a2v', 'v2v', 'a2a'):
+        d = (log[f'segment_sim_{k}'].cpu() - torch.from_numpy(g[f'ref_sim_{k}'])).abs().max().item() * 0.07
+        assert d < 2e-3, (k, d)
+    assert (vfeat - torch.from_numpy(g['ref_vfeat'])).abs().max() < 2e-3 and (afeat - torch.from_numpy(g['ref_afeat'])).abs().max() < 2e-3
+    assert abs(float(log['segment_contrastive_loss']) - float(g['ref_logging_loss'])) < 1e-2
+    # gathered features (gather_for_loss, world 2): the reference's eye(n, m) targets put the positive of LOCAL row i at column i on every rank
+    # (open_clip/model.py:489-512); HIP head fed the reference's own features so that only the convention is under test
+    eng = m._engine()
+    rv, ra = torch.from_numpy(g['ref_vfeat']).to(gpu), torch.from_numpy(g['ref_afeat']).to(gpu)
+    for r in range(2):
+        loc = slice(r * S, (r + 1) * S)
+        losses, sim_v2a, _ = eng.contrastive_loss(rv[loc].contiguous(), ra[loc].contiguous(), rv, ra, 0.07)
+        assert abs(float(losses.mean()) - float(g[f'gathered_loss_rank{r}'])) < 2e-4, r
+        assert (sim_v2a.cpu() - torch.from_numpy(g[f'gathered_sim_v2a_rank{r}'])).abs().max() < 2e-4
     assert torch.allclose(log['segment_sim_a2v'], log['segment_sim_v2a'].T, atol=1e-5)
     assert abs(float(log['segment_contrastive_loss']) - float(out['losses']['segment_contrastive_loss'])) < 1e-6
     # head kernels alone, fed the HIP features: exact fp32 restatement
@@ -87,8 +102,13 @@ def test_avclip_forward_matches_reference_towers(gpu):
     assert abs(float(loss) - float(out['losses']['segment_contrastive_loss'])) < 1e-5
     # clamp_logit_scales (open_clip/model.py:569-572)
     with torch.no_grad():
-        m.logit_scale.fill_(5.0)
-    assert float(m.clamp_logit_scales()[0].detach()) == 0.5
+        m.logit_scale.fill_(0.9)
+        assert abs(float(m(vis, aud)['logit_scales'][0]) - float(g['clamped_hi'])) < 1e-7
+        m.logit_scale.fill_(1e-5)
+        lo = m(vis, aud)
+    assert abs(float(lo['logit_scales'][0]) - float(g['clamped_lo'])) < 1e-9
+    # temperature 0.001: cosines are amplified 1000x, so the loss tolerance scales with the cosine error (2e-3 -> ~2 in logits); the bar is relative
+    assert abs(float(lo['losses']['segment_contrastive_loss']) - float(g['loss_at_clamped_lo'])) < 0.05 * float(g['loss_at_clamped_lo']) + 0.5
 
 
 @pytest.mark.parametrize('B,S,W', [(1, 14, 8), (3, 14, 8), (2, 9, 1), (2, 6, 5)])
@@ -103,6 +123,16 @@ def test_shift_and_get_preds(gpu, B, S, W):
     vf = v.unfold(-2, W, 1).contiguous().view(B, S - W + 1, -1)
     sim = af.double() @ vf.double().mT
     assert torch.equal(pa.cpu(), torch.argmax(sim, dim=-2)) and torch.equal(pv.cpu(), torch.argmax(sim, dim=-1))
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c', 'd'])
+def test_shift_and_get_preds_reference_golden(gpu, tag):
+    """Same read-out against the REAL `shift_and_get_preds` (train_clip_src/training/train.py:549-579) run on seeded features
+    (tests/golden/shift_preds.npz, made by make_golden.py shift_preds).  Integer outputs: exact."""
+    from synchformer_amd.stage1 import shift_and_get_preds
+    g = np.load(GOLD / 'shift_preds.npz')
+    pa, pv = shift_and_get_preds(torch.from_numpy(g[f'{tag}_a']).to(gpu), torch.from_numpy(g[f'{tag}_v']).to(gpu), int(g[f'{tag}_W']))
+    assert torch.equal(pa.cpu(), torch.from_numpy(g[f'{tag}_preds_a'])) and torch.equal(pv.cpu(), torch.from_numpy(g[f'{tag}_preds_v']))
 
 
 def test_eval_one_example(gpu):
