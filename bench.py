@@ -178,7 +178,7 @@ def main():
         # Stage-1 AVCLIP train step (configs/segment_avclip.yaml: base_batch_size 2 clips x 14 segments per GPU, both towers trainable)
         from synchformer_amd.stage1 import AVCLIPTrainer
         sd = {k: v for k, v in synth.make_state_dict(1337).items() if k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}
-        trainer = AVCLIPTrainer(sd, dev, lr=1e-4)
+        trainer = AVCLIPTrainer(sd, dev, lr=1e-4, drop_path_rate=0.2, seed=1337 + rank)     # train mode: DropPath 0.2 like the reference's towers
         step_fn = lambda v, a: trainer.train_step(v, a).reshape(1)
     else:
         eng = SynchformerEngine(synth.make_state_dict(1337), dev, seg_chunk=args.seg_chunk)

@@ -179,6 +179,11 @@ int sf_cross_entropy(const float* logits, int64_t ld, const int64_t* targets, in
  * the backward.  Dropout sites: sync_model.py:166, modules/transformer.py:70,73,90. */
 int sf_dropout(const void* x, int dtype, int64_t ldx, const float* residual, int64_t ldr, void* y, int64_t ldy, int64_t rows, int cols,
                float p, uint32_t seed, void* stream);
+/* Stochastic depth of the Stage-1 visual tower (DropPath at vit_helper.py:356,372,375, rates video_model_builder.py:86-87 = linspace(0, 0.2, 12)):
+ * y[r,:] = (residual ? residual[r,:] : 0) + seq_scale[r / seq_rows] * x[r,:], fp32, cols % 4 == 0; seq_scale[i] is 0 or 1/keep_prob per
+ * segment.  The forward applies it to a residual branch, the backward to the incoming gradient with the same scales. */
+int sf_scale_seq_add(const float* x, int64_t ldx, const float* seq_scale, int64_t seq_rows, const float* residual, int64_t ldr, float* y,
+                     int64_t ldy, int64_t rows, int cols, void* stream);
 /* norm_out[0] = ||g||_2 of a flat fp32 buffer (deterministic two-stage; workspace fp32 1024). */
 int sf_grad_norm(const float* g, int64_t n, float* norm_out, float* workspace, void* stream);
 /* clip_grad_norm_(max_norm, device-resident norm) + Adam(betas, eps, no weight decay) on flat fp32 buffers; also writes the

@@ -114,12 +114,17 @@ def divided_attention(x, sd, p, mode, heads=12, frames=8, tok_keep=None):
     return _lin(out, sd, p + '.proj')
 
 
-def divided_block(x, sd, p, tok_keep=None):
-    """DividedSpaceTimeBlock.forward (vit_helper.py:364-376); DropPath is identity in eval."""
+def divided_block(x, sd, p, tok_keep=None, drop_path=None):
+    """DividedSpaceTimeBlock.forward (vit_helper.py:364-376).  DropPath is identity in eval; in train mode (`drop_path` = (space, mlp) pair of
+    per-sample scale vectors (N,), each 0 or 1 / keep_prob, or None) the space-attention and MLP branches are scaled per sample
+    (vit_helper.py:372,375; timm DropPath: x * bernoulli(keep) / keep over dim 0) - the time-attention branch never is (:367-369)."""
+    dps, dpm = drop_path if drop_path is not None else (None, None)
     x = x + divided_attention(_ln(x, sd, p + '.norm3', EPS_VIS), sd, p + '.timeattn', 'time', tok_keep=tok_keep)
-    x = x + divided_attention(_ln(x, sd, p + '.norm1', EPS_VIS), sd, p + '.attn', 'space', tok_keep=tok_keep)
+    br = divided_attention(_ln(x, sd, p + '.norm1', EPS_VIS), sd, p + '.attn', 'space', tok_keep=tok_keep)
+    x = x + (br if dps is None else br * dps.view(-1, 1, 1))
     h = _gelu(_lin(_ln(x, sd, p + '.norm2', EPS_VIS), sd, p + '.mlp.fc1'))           # Mlp (vit_helper.py:379-398)
-    return x + _lin(h, sd, p + '.mlp.fc2')
+    br = _lin(h, sd, p + '.mlp.fc2')
+    return x + (br if dpm is None else br * dpm.view(-1, 1, 1))
 
 
 def agg_encoder_layer_cls(tokens, sd, p, heads=12, keep=None):
@@ -141,7 +146,7 @@ def agg_encoder_layer_cls(tokens, sd, p, heads=12, keep=None):
     return z[:, 0]
 
 
-def motionformer_segments(x, sd, p='vfeat_extractor', depth=None, cont_keep=None):
+def motionformer_segments(x, sd, p='vfeat_extractor', depth=None, cont_keep=None, drop_path=None):
     """MotionFormer.forward_segments (motionformer.py:225-252) with forward_features
     (video_model_builder.py:174-274).  x (N, 3, 16, 224, 224) -> (N, 8, 768)."""
     N = x.shape[0]
@@ -156,7 +161,7 @@ def motionformer_segments(x, sd, p='vfeat_extractor', depth=None, cont_keep=None
     x = torch.cat([sd[p + '.cls_token'].expand(N, 1, -1), tok], 1) + vis_pos_table(sd, p)
     i = 0
     while f'{p}.blocks.{i}.norm1.weight' in sd and (depth is None or i < depth):
-        x = divided_block(x, sd, f'{p}.blocks.{i}', tok_keep)
+        x = divided_block(x, sd, f'{p}.blocks.{i}', tok_keep, None if drop_path is None else drop_path[i])
         i += 1
     x = _ln(x[:, 1:], sd, p + '.norm', EPS_VIS)                       # drop CLS, final norm (mf:231-232)
     frames = 8
@@ -261,7 +266,7 @@ def global_transformer(v, a, sd, p='transformer', apply_head=True, masks=None):
     return _lin(x[:, 0], sd, f'{p}.{head}')
 
 
-def extract_vfeats(vis, sd, chunk=None, vis_mask=None):
+def extract_vfeats(vis, sd, chunk=None, vis_mask=None, drop_path=None):
     """Synchformer.extract_vfeats (sync_model.py:72-80) + MotionFormer.forward (motionformer.py:182-223).
     vis (B, S, Tv, C, H, W) -> (B, S, 8, 768).  `chunk` bounds CPU memory (segments per pass); results are
     identical to one pass (the reference's own for_loop switch, motionformer.py:200-207)."""
@@ -271,7 +276,9 @@ def extract_vfeats(vis, sd, chunk=None, vis_mask=None):
     m = None                                                           # vis_mask: same shape as vis, True = kept (sync_model.py:75-76)
     if vis_mask is not None:
         m = vis_mask.permute(0, 1, 3, 2, 4, 5).reshape(x.shape).bool()
-    out = torch.cat([motionformer_segments(x[i:i + chunk], sd, cont_keep=None if m is None else m[i:i + chunk])
+    # drop_path: per visual block a (space, mlp) pair of per-segment scale vectors (B*S,) or None - the Stage-1 TRAIN-mode forward
+    dp = lambda i: None if drop_path is None else [tuple(None if t is None else t[i:i + chunk] for t in pair) for pair in drop_path]
+    out = torch.cat([motionformer_segments(x[i:i + chunk], sd, cont_keep=None if m is None else m[i:i + chunk], drop_path=dp(i))
                      for i in range(0, x.shape[0], chunk)], 0)
     return out.reshape(B, S, *out.shape[1:])
 
@@ -296,12 +303,12 @@ def synchformer_forward(sd, vis, aud, targets=None, chunk=None, vis_mask=None, a
     return loss, logits
 
 
-def avclip_forward(sd, vis, aud, logit_scale=0.07, vfeat_all=None, afeat_all=None, chunk=None):
+def avclip_forward(sd, vis, aud, logit_scale=0.07, vfeat_all=None, afeat_all=None, chunk=None, drop_path=None):
     """Stage-1 AVCLIP.forward with alpha = 0 (train_clip_src/open_clip/model.py:475-533): towers with
     agg_time_module='AveragePooling' (mean over the t aggregated tokens, motionformer.py:139,246 / ast.py:88), DoNothingBridge
     projections, F.normalize, sim = feat @ feat_all^T / logit_scale, eye(n, m) soft targets (:512-518), symmetric CE (:520-523).
     `*_all` default to the local features (world_size == 1 / gather_for_loss False).  -> dict(vfeat, afeat, sim_v2a, sim_a2v, loss)."""
-    vfeat = F.normalize(extract_vfeats(vis, sd, chunk).mean(2).flatten(0, 1), dim=-1)      # (B*S, D)
+    vfeat = F.normalize(extract_vfeats(vis, sd, chunk, drop_path=drop_path).mean(2).flatten(0, 1), dim=-1)      # (B*S, D)
     afeat = F.normalize(extract_afeats(aud, sd).mean(2).flatten(0, 1), dim=-1)
     vfeat_all = vfeat if vfeat_all is None else vfeat_all
     afeat_all = afeat if afeat_all is None else afeat_all

@@ -44,6 +44,7 @@ SIGNATURES = {
     'sf_gelu_bwd': [_ptr, _ptr, _ptr, _i64, _ptr],
     'sf_gelu_bwd_bf16': [_ptr, _ptr, _ptr, _i64, _ptr],
     'sf_cross_entropy': [_ptr, _i64, _ptr, _i32, _i32, _ptr, _ptr, _i64, _f32, _ptr],
+    'sf_scale_seq_add': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i32, _ptr],
     'sf_dropout': [_ptr, _i32, _i64, _ptr, _i64, _ptr, _i64, _i64, _i32, _f32, C.c_uint32, _ptr],
     'sf_grad_norm': [_ptr, _i64, _ptr, _ptr, _ptr],
     'sf_adam_clip_step': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _f32, _f32, _f32, _f32, _f32, _i32, _ptr],

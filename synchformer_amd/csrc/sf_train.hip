@@ -533,6 +533,42 @@ extern "C" int sf_cross_entropy(const float* logits, int64_t ld, const int64_t* 
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Stochastic depth (DropPath, vit_helper.py:356,372,375; timm.models.layers.DropPath): a residual branch is kept or dropped per SAMPLE
+// (= per 0.64 s segment: the towers see (B*S, tokens, D)), kept branches scaled by 1 / keep_prob:
+//     y[r, :] = (residual ? residual[r, :] : 0) + seq_scale[r / seq_rows] * x[r, :]          (fp32, cols % 4 == 0)
+// seq_scale holds 0 or 1 / keep_prob per sequence (sf_dropout applied to a vector of ones: the same counter-based stream as the
+// element dropout, regenerated from (seed, site) in the backward, where the same kernel scales the incoming gradient).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scale_seq_add_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ seq_scale, int64_t seq_rows,
+                                                             const float* __restrict__ r, int64_t ldr, float* __restrict__ y, int64_t ldy, int64_t rows,
+                                                             int cols4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols4) return;
+  const int64_t row = i / cols4;
+  const int c = (int)(i - row * cols4) * 4;
+  const float sc = seq_scale[row / seq_rows];
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (sc != 0.f) {                                                  // a dropped branch is not even read
+    v = *reinterpret_cast<const float4*>(x + row * ldx + c);
+    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+  }
+  if (r) { const float4 t = *reinterpret_cast<const float4*>(r + row * ldr + c); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+  *reinterpret_cast<float4*>(y + row * ldy + c) = v;
+}
+
+extern "C" int sf_scale_seq_add(const float* x, int64_t ldx, const float* seq_scale, int64_t seq_rows, const float* residual, int64_t ldr, float* y,
+                                int64_t ldy, int64_t rows, int cols, void* stream) {
+  SF_CHECK_ARG(x && seq_scale && y && seq_rows >= 1 && cols >= 4 && (cols % 4) == 0, "sf_scale_seq_add: bad arguments");
+  SF_CHECK_ARG((ldx % 4) == 0 && (ldy % 4) == 0 && (!residual || (ldr % 4) == 0), "sf_scale_seq_add: row strides must be multiples of 4 elements");
+  if (rows <= 0) return 0;
+  const int64_t n = rows * (cols / 4);
+  hipLaunchKernelGGL(scale_seq_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, seq_scale, seq_rows, residual, ldr,
+                     y, ldy, rows, cols / 4);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Fused gradient clipping + Adam over a flat fp32 parameter buffer (make_backward_and_optim_step, train_utils.py:373-386:
 // clip_grad_norm_(params, max_norm) then torch.optim.Adam(betas, eps, weight_decay 0); :217-226).
 //   stage 1: sum of squares of the flat gradient (two-stage, deterministic) -> norm_out[0] = ||g||_2

@@ -176,6 +176,7 @@ class MotionFormer(torch.nn.Module):
         self.ckpt_path = ckpt_path
         self.extract_features, self.factorize_space_time, self.add_global_repr = True, True, False
         self.embed_dim, self.num_heads, self.temporal_resolution = 768, 12, 8
+        self.drop_path_rate = 0.2                       # VIT.DROP_PATH of divided_224_16x4.yaml:59 (train mode only; video_model_builder.py:33,86-87)
         schema = synth.state_dict_schema()
         _register_tree(self, schema, 'vfeat_extractor.', _seed)
         if ckpt_path is not None:                       # ssv2_divided_224_16x4.pyth or a Stage-1 *.pt (motionformer.py:52-80, 109-116, 156-173)
@@ -583,10 +584,13 @@ class AVCLIP(torch.nn.Module):
         tr = getattr(self, '_sf_trainer', None)
         if tr is None:
             tr = AVCLIPTrainer({k: p.detach() for k, p in named.items()}, self.logit_scale.device,
-                               clamp_scale=(self.clamp_scale_min, self.clamp_scale_max), gather_for_loss=self.gather_for_loss)
+                               clamp_scale=(self.clamp_scale_min, self.clamp_scale_max), gather_for_loss=self.gather_for_loss,
+                               seed=torch.initial_seed() & 0x7FFFFFFF)
             assert tr.keys == list(named), 'parameter order mismatch'
             object.__setattr__(self, '_sf_trainer', tr)
             object.__setattr__(self, '_sf_trainer_key', None)
+        # stochastic depth follows the module's mode like the reference's DropPath (train(): on, eval(): identity)
+        tr.drop_path_rate = float(self.v_encoder.drop_path_rate) if self.v_encoder.training else 0.0
         key = tuple((p.data_ptr(), p._version) for p in named.values())
         if key != self._sf_trainer_key:                                      # an external optimizer moved the nn.Parameters
             tr.load_params({k: p.detach() for k, p in named.items()})

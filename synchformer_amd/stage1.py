@@ -62,13 +62,17 @@ def cosine_lr(step: int, base_lr: float, warmup: int, total_steps: int) -> float
 
 class AVCLIPTrainer(FlatTrainer):
     def __init__(self, state_dict: Dict[str, torch.Tensor], device='cuda:0', lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
-                 max_clip_norm: float = 1.0, clamp_scale=(0.001, 0.5), init_scale: float = 0.07, gather_for_loss: bool = False):
+                 max_clip_norm: float = 1.0, clamp_scale=(0.001, 0.5), init_scale: float = 0.07, gather_for_loss: bool = False,
+                 drop_path_rate: float = 0.2, seed: int = 1337):
         sd = dict(normalise_keys(state_dict))
         if 'logit_scale' not in sd:
             sd['logit_scale'] = torch.tensor(init_scale)
         keys = [k for k in sd if k.startswith((V + '.', A + '.')) and not k.startswith(V + '.patch_embed.')] + ['logit_scale']
         self._init_flat(sd, keys, device, lr, betas, eps, max_clip_norm)
         self.clamp_scale, self.gather_for_loss = clamp_scale, gather_for_loss
+        # stochastic depth of the visual tower: DROP_PATH 0.2 (divided_224_16x4.yaml:59), block i drops its space-attention and MLP branches per
+        # segment with probability linspace(0, rate, depth)[i] (video_model_builder.py:86-87, vit_helper.py:356,372,375); 0 = evaluation mode
+        self.drop_path_rate, self.seed, self.fwd_count = float(drop_path_rate or 0.0), int(seed), 0
         self.fused_attn_bwd = True          # False: the gathered batched-GEMM attention backward (kept as a cross-check)
         self.two_streams = os.environ.get('SF_STAGE1_TWO_STREAMS', '1') != '0'   # audio tower next to the visual one (forward_backward)
         self._side = None
@@ -97,8 +101,32 @@ class AVCLIPTrainer(FlatTrainer):
     def _seqsum(self, x, n_seq, L, out):
         _chk(_lib.load().sf_seqsum(x.data_ptr(), x.stride(0), n_seq, L, D, out.data_ptr(), 0, _st()), 'sf_seqsum')
 
-    def _mlp_fwd(self, s, x_in, h_name, fc1, fc2, rows, eps_name, eps, tag):
-        """h = LN(x_in); pre = fc1(h); act = gelu(pre); returns x_in + fc2(act).  Saves h, pre, act."""
+    # ---- stochastic depth ---------------------------------------------------------------------------------------------------
+    def _dp_scales(self, block: int, site: int, n: int):
+        """Per-segment branch scales (0 or 1 / keep) of DropPath site `site` (0 = space attention, 1 = MLP) of visual block `block` for the current
+        forward pass, or None when that site is inactive.  sf_dropout over a vector of ones: counter-based, so the backward needs no saved mask."""
+        p_ = self.drop_path_rate * block / max(1, self.n_vblocks - 1)
+        if p_ <= 0.0:
+            return None
+        h = (self.seed * 0x9E3779B1 + self.fwd_count * 0x85EBCA6B + (2 * block + site) * 0xC2B2AE35 + 0x27D4EB2F) & 0xFFFFFFFF
+        h ^= h >> 15
+        ones = self._buf('dp_ones', (1, ((n + 3) // 4) * 4), torch.float32)
+        ones.fill_(1.0)
+        sc = self._buf(f'dp_scale_{block}_{site}', (1, ((n + 3) // 4) * 4), torch.float32)
+        from .train import dropout
+        dropout(ones, sc, 1, ones.shape[1], p_, (h * 0x2C1B3C6D) & 0xFFFFFFFF)
+        return sc
+
+    def _scale_seq(self, x, scales, seq_rows, rows, out, residual=None):
+        """out = (residual +) scales[row // seq_rows] * x  (fp32, 768 columns)."""
+        _chk(_lib.load().sf_scale_seq_add(x.data_ptr(), x.stride(0), scales.data_ptr(), seq_rows, residual.data_ptr() if residual is not None else None,
+                                          residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0), rows, D, _st()),
+             'sf_scale_seq_add')
+        return out
+
+    def _mlp_fwd(self, s, x_in, h_name, fc1, fc2, rows, eps_name, eps, tag, dp=None, seq_rows=0):
+        """h = LN(x_in); pre = fc1(h); act = gelu(pre); returns x_in + fc2(act) (x_in + dp[segment] * fc2(act) under stochastic depth).
+        Saves h, pre, act."""
         s['h2'] = self._buf(f'{tag}_h2', (rows, D), torch.bfloat16)
         ops.layernorm(x_in, *self._ln(eps_name), s['h2'], eps)
         s['pre'] = self._buf(f'{tag}_pre', (rows, FF), torch.bfloat16)
@@ -106,14 +134,20 @@ class AVCLIPTrainer(FlatTrainer):
         s['act'] = self._buf(f'{tag}_act', (rows, FF), torch.bfloat16)
         self._gelu_fwd(s['pre'], s['act'])
         out = self._buf(f'{tag}_xo', (rows, D), torch.float32)
-        ops.gemm(s['act'], *self._wb(fc2), out, residual=x_in)
+        if dp is None:
+            ops.gemm(s['act'], *self._wb(fc2), out, residual=x_in)
+        else:
+            br = self._buf('dp_branch', (rows, D), torch.float32)
+            ops.gemm(s['act'], *self._wb(fc2), br)
+            self._scale_seq(br, dp, seq_rows, rows, out, residual=x_in)
         return out
 
-    def _mlp_bwd(self, s, dx, x_in, fc1, fc2, rows, ln_name, eps):
+    def _mlp_bwd(self, s, dx, x_in, fc1, fc2, rows, ln_name, eps, dp=None, seq_rows=0):
         """dx (rows, 768) fp32 = gradient of the block output; adds the MLP branch's contribution through LN(x_in) into dx."""
+        dbr = dx if dp is None else self._scale_seq(dx, dp, seq_rows, rows, self._buf('dp_dbranch', (rows, D), torch.float32))   # gradient of the (scaled) branch
         dy_b = self._buf('dy_b', (rows, D), torch.bfloat16)
-        cast_bf16(dx, dy_b, rows, D)
-        dact = self._lin_bwd(fc2, dy_b, s['act'], rows, tag='act', dy_f32=dx, dx_dtype=torch.bfloat16)   # consumed by the bf16 GELU backward only
+        cast_bf16(dbr, dy_b, rows, D)
+        dact = self._lin_bwd(fc2, dy_b, s['act'], rows, tag='act', dy_f32=dbr, dx_dtype=torch.bfloat16)   # consumed by the bf16 GELU backward only
         dpre = self._buf('dpre', (rows, FF), torch.bfloat16)
         self._gelu_bwd(s['pre'], dact, dpre)
         dh = self._lin_bwd(fc1, dpre, s['h2'], rows, tag='h', dx_dtype=torch.bfloat16)                      # read once, by the LN backward
@@ -189,12 +223,13 @@ class AVCLIPTrainer(FlatTrainer):
                                               dqkv[:, 2 * D:].data_ptr(), dqkv.stride(0), n_seq, H, HD, 0.125, int(accumulate), _st()),
              'sf_attention_cls_bwd')
 
-    def _attn_branch_bwd(self, dx, rows, proj, att_saved, qkv_fn, h_saved, x_in, ln_name, eps, qkv_names):
+    def _attn_branch_bwd(self, dx, rows, proj, att_saved, qkv_fn, h_saved, x_in, ln_name, eps, qkv_names, dp=None, seq_rows=0):
         """Common tail of an attention residual branch: dx -> proj backward -> attention backward (qkv_fn) -> qkv linear(s)
-        backward -> LN backward accumulated into dx."""
+        backward -> LN backward accumulated into dx.  `dp`: per-segment stochastic-depth scales of this branch (None = branch always kept)."""
+        dbr = dx if dp is None else self._scale_seq(dx, dp, seq_rows, rows, self._buf('dp_dbranch', (rows, D), torch.float32))
         dy_b = self._buf('dy_b', (rows, D), torch.bfloat16)
-        cast_bf16(dx, dy_b, rows, D)
-        dO_b = self._lin_bwd(proj, dy_b, att_saved, rows, tag='h', dy_f32=dx, dx_dtype=torch.bfloat16)     # attention output gradient, bf16 for the attention backward
+        cast_bf16(dbr, dy_b, rows, D)
+        dO_b = self._lin_bwd(proj, dy_b, att_saved, rows, tag='h', dy_f32=dbr, dx_dtype=torch.bfloat16)     # attention output gradient, bf16 for the attention backward
         dqkv = qkv_fn(dO_b)
         if isinstance(qkv_names, str):                                        # one fused (2304, 768) projection
             dh = self._lin_bwd(qkv_names, dqkv, h_saved, rows, tag='h', dx_dtype=torch.bfloat16)
@@ -269,9 +304,16 @@ class AVCLIPTrainer(FlatTrainer):
                 s['att' + key] = self._buf(f'{t}_att{key}', (M, D), torch.bfloat16)
                 self._divided_fwd(s['qkv' + key], s['att' + key], n, kind)
                 xn = self._buf(f'{t}_x{key}', (M, D), torch.float32)
-                ops.gemm(s['att' + key], *self._wb(f'{p}.{att}.proj'), xn, residual=x)
+                dp = s['dp_s'] = self._dp_scales(i, 0, n) if kind == 'space' else None     # time attention has no DropPath (vit_helper.py:367-369)
+                if dp is None:
+                    ops.gemm(s['att' + key], *self._wb(f'{p}.{att}.proj'), xn, residual=x)
+                else:
+                    br = self._buf('dp_branch', (M, D), torch.float32)
+                    ops.gemm(s['att' + key], *self._wb(f'{p}.{att}.proj'), br)
+                    self._scale_seq(br, dp, VIS_L, M, xn, residual=x)
                 x = s['x' + key] = xn                                           # xt = after time attention, xs = after space attention
-            x = self._mlp_fwd(s, x, 'h2', p + '.mlp.fc1', p + '.mlp.fc2', M, p + '.norm2', EPS_VIS, t)
+            s['dp_m'] = self._dp_scales(i, 1, n)
+            x = self._mlp_fwd(s, x, 'h2', p + '.mlp.fc1', p + '.mlp.fc2', M, p + '.norm2', EPS_VIS, t, dp=s['dp_m'], seq_rows=VIS_L)
             sv['blocks'].append(s)
         sv['x_last'] = x
         Z = self._buf('v_Z', (n * 8 * AGG_V, D), torch.float32)
@@ -296,9 +338,9 @@ class AVCLIPTrainer(FlatTrainer):
             on_ready(self._key_range(V + '.norm.', V + '.spatial_attn_agg.'))
         for i in reversed(range(self.n_vblocks)):
             p, s = f'{V}.blocks.{i}', sv['blocks'][i]
-            self._mlp_bwd(s, dx, s['xs'], p + '.mlp.fc1', p + '.mlp.fc2', M, p + '.norm2', EPS_VIS)
+            self._mlp_bwd(s, dx, s['xs'], p + '.mlp.fc1', p + '.mlp.fc2', M, p + '.norm2', EPS_VIS, dp=s['dp_m'], seq_rows=VIS_L)
             self._attn_branch_bwd(dx, M, p + '.attn.proj', s['atts'], lambda dO, q=s['qkvs']: self._divided_bwd(q, dO, n, 'space'), s['hs'],
-                                  s['xt'], p + '.norm1', EPS_VIS, p + '.attn.qkv')
+                                  s['xt'], p + '.norm1', EPS_VIS, p + '.attn.qkv', dp=s['dp_s'], seq_rows=VIS_L)
             self._attn_branch_bwd(dx, M, p + '.timeattn.proj', s['attt'], lambda dO, q=s['qkvt']: self._divided_bwd(q, dO, n, 'time'), s['ht'],
                                   s['x'], p + '.norm3', EPS_VIS, p + '.timeattn.qkv')
             if on_ready and i % 3 == 0:                                        # blocks i .. i+2 are final: one ~92 MB bucket
@@ -480,6 +522,7 @@ class AVCLIPTrainer(FlatTrainer):
         n = B * S
         self.clamp_logit_scale()
         self.flat_g.zero_()
+        self.fwd_count += 1                                                    # a fresh set of stochastic-depth masks per forward pass
         aud3 = aud.reshape(n, aud.shape[-2], aud.shape[-1])
         if not self.two_streams:
             vout = self._fwd_visual(vis.reshape(n, *vis.shape[2:]))

@@ -86,11 +86,11 @@ def test_meanpool_l2norm_bwd(gpu, n, t):
     assert (dx.double() - xr.grad).abs().max().item() < 1e-5 * max(1.0, xr.grad.abs().max().item())
 
 
-def _setup(gpu, B, S, gain):
+def _setup(gpu, B, S, gain, drop_path_rate=0.0):
     from synchformer_amd import synth
     from synchformer_amd.stage1 import AVCLIPTrainer
     sd = {k: v for k, v in synth.make_state_dict(1337, gain=gain).items() if k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}
-    tr = AVCLIPTrainer(sd, gpu, lr=1e-4)
+    tr = AVCLIPTrainer(sd, gpu, lr=1e-4, drop_path_rate=drop_path_rate)
     return sd, tr, synth.make_video_u8(B, S, 1337), synth.make_spectrogram(B, S, 1337)
 
 
@@ -140,6 +140,43 @@ def test_avclip_grads_match_oracle(gpu):
     # alone is checked tightly on well-conditioned features in test_contrastive_head_matches_autograd.
     print('logit_scale grad hip', float(tr.g['logit_scale']), 'oracle', float(scale.grad))
     assert abs(float(tr.g['logit_scale']) - float(scale.grad)) < 3e-2
+
+
+def test_avclip_grads_with_drop_path_match_oracle(gpu):
+    """Stage-1 TRAIN-mode step: stochastic depth on the space-attention and MLP branches of the visual blocks (vit_helper.py:356,372,375; block i
+    drops with probability linspace(0, rate, 12)[i], video_model_builder.py:86-87).  The HIP masks come from its counter-based stream, not
+    torch's, so - like the dropout test of the Stage-2 step - they are read back and handed to the oracle, whose autograd then gives the
+    gradients of the same sub-network.  rate = 0.6 here (the configured 0.2 would rarely drop anything across 3 segments x 22 sites)."""
+    from oracle import synchformer_cpu as O
+    sd, tr, u8, aud = _setup(gpu, 1, 3, 2.0, drop_path_rate=0.6)
+    loss = tr.forward_backward(u8.to(gpu), aud.to(gpu))
+    dp, dropped = [], 0
+    for s in tr.sv_v['blocks']:
+        pair = tuple(None if t is None else t.reshape(-1)[:3].cpu().clone() for t in (s['dp_s'], s['dp_m']))
+        dropped += sum(int((t == 0).sum()) for t in pair if t is not None)
+        for bi, t in enumerate(pair):
+            if t is not None:
+                assert all(float(v) == 0.0 or abs(float(v) * (1 - 0.6 * len(dp) / 11) - 1) < 1e-5 for v in t), (len(dp), bi, t)
+        dp.append(pair)
+    assert dp[0] == (None, None) and dropped >= 5, dropped                      # block 0 never drops (rate 0); deeper blocks do
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not k.startswith('vfeat_extractor.patch_embed.')}
+    full = dict(sd)
+    full.update(leaves)
+    out = O.avclip_forward(full, O.rgb_frontend(u8), aud, logit_scale=torch.tensor(0.07), drop_path=dp)
+    out['loss'].backward()
+    print(f'drop-path: {dropped} dropped branches; loss hip {float(loss):.6f} oracle {float(out["loss"].detach()):.6f}')
+    assert abs(float(loss) - float(out['loss'])) < 5e-3
+    ref = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+    _compare(tr, ref)
+    # masks change from step to step, and eval mode (rate 0) reproduces the deterministic forward
+    first = [None if s['dp_m'] is None else s['dp_m'].reshape(-1)[:3].cpu().clone() for s in tr.sv_v['blocks']]
+    tr.forward_backward(u8.to(gpu), aud.to(gpu))
+    second = [None if s['dp_m'] is None else s['dp_m'].reshape(-1)[:3].cpu().clone() for s in tr.sv_v['blocks']]
+    assert any(a is not None and not torch.equal(a, b) for a, b in zip(first, second))
+    tr.drop_path_rate = 0.0
+    l0 = float(tr.forward_backward(u8.to(gpu), aud.to(gpu)))
+    _, tr0, _, _ = _setup(gpu, 1, 3, 2.0)
+    assert abs(l0 - float(tr0.forward_backward(u8.to(gpu), aud.to(gpu)))) < 1e-6
 
 
 def test_avclip_grads_match_reference_golden(gpu):
@@ -223,12 +260,15 @@ def test_avclip_dropin_training_loop(gpu):
            if k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}
     own['logit_scale'] = torch.tensor(0.07)
     m.load_state_dict(own, strict=True)
-    m = m.to(gpu).train()
+    m = m.to(gpu).eval()
     params = [p for p in m.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
     B, S = 2, 2
     vis = O.rgb_frontend(synth.make_video_u8(B, S, 1337)).permute(0, 1, 3, 2, 4, 5).contiguous().to(gpu)      # (B, S, C, Tv, H, W)
     aud = synth.make_spectrogram(B, S, 1337).squeeze(2).permute(0, 1, 3, 2).contiguous().to(gpu)               # (B, S, Ta, F)
+    with torch.no_grad():
+        ev0 = float(m(vis, aud)['losses']['segment_contrastive_loss'])
+    m.train()                                                                 # DropPath (rate 0.2) is active from here, like the reference's towers
     losses = []
     for it in range(4):
         opt.zero_grad()
@@ -237,6 +277,7 @@ def test_avclip_dropin_training_loop(gpu):
         (loss * 1024.0).backward()                                            # GradScaler-style scaled loss
         if it == 0:
             tr = m._sf_trainer
+            assert tr.drop_path_rate == 0.2
             g_mod = getattr(m.v_encoder.blocks, '3').attn.qkv.weight.grad / 1024.0
             assert torch.allclose(g_mod, tr.g['vfeat_extractor.blocks.3.attn.qkv.weight'], rtol=1e-5, atol=1e-9)
             assert m.v_encoder.patch_embed.proj.weight.grad is None
@@ -246,11 +287,13 @@ def test_avclip_dropin_training_loop(gpu):
         torch.nn.utils.clip_grad_norm_(params, 1.0, norm_type=2.0)
         opt.step()
         losses.append(float(loss.detach()))
-    print('drop-in stage-1 losses', [f'{x:.4f}' for x in losses])
-    assert losses[-1] < losses[0] - 1e-3
-    with torch.no_grad():                                                     # eval path sees the updated weights
+    print('drop-in stage-1 losses (train mode, stochastic depth)', [f'{x:.4f}' for x in losses], 'eval loss before', ev0)
+    m.eval()
+    with torch.no_grad():                                                     # eval path sees the updated weights, without stochastic depth
         ev = m(vis, aud)
-    assert float(ev['losses']['segment_contrastive_loss']) < losses[0]
+    assert float(ev['losses']['segment_contrastive_loss']) < ev0 - 1e-3
+    out = m(vis, aud)                                                         # grad-enabled forward in eval mode: the train kernels with DropPath off
+    assert m._sf_trainer.drop_path_rate == 0.0 and abs(float(out['losses']['segment_contrastive_loss']) - float(ev['losses']['segment_contrastive_loss'])) < 5e-3
 
 
 def _gather_head_worker(rank, world, port, q):
@@ -320,7 +363,7 @@ def _bucketed_worker(rank, world, port, q):
         from synchformer_amd import synth
         from synchformer_amd.stage1 import AVCLIPTrainer
         sd = {k: v for k, v in synth.make_state_dict(1337, gain=2.0).items() if k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}
-        tr = AVCLIPTrainer(sd, 'cuda:0')
+        tr = AVCLIPTrainer(sd, 'cuda:0', drop_path_rate=0.0)                  # the two passes below must see the same sub-network
         vis = synth.make_video_u8(1, 2, 100 + rank).cuda()
         aud = synth.make_spectrogram(1, 2, 100 + rank).cuda()
         tr.forward_backward(vis, aud)                                        # local gradients, no communication
