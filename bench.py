@@ -27,6 +27,10 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 import torch  # noqa: E402
 
 FLOP_PER_CLIP = 5.725e12          # algorithmic forward FLOPs per 14-segment clip
+# FLOPs the engine actually executes per clip: both aggregator layers are computed for output row 0 only (motionformer.py:332 reads nothing
+# else), which drops 14 x 8 x (out_proj 0.232 + MLP 1.859 + the 196 unused query rows of the attention 0.118) G = 0.247 T of the visual
+# aggregator and 14 x 6 x 0.17 G of the audio one
+FLOP_PER_CLIP_EXECUTED = 5.725e12 - 0.247e12 - 0.014e12
 PEAK_BF16 = 2.5e15                # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
@@ -45,6 +49,8 @@ def parse():
                     help="infer = BASELINE configs[1] (headline metric); train = configs[2]: Stage-2 step, frozen extractors, "
                          "backward + RCCL gradient all-reduce + fused clip/Adam (dropout 0.1 as in sync.yaml)")
     ap.add_argument('--graph', action='store_true', help='replay the forward as one captured HIP graph (infer workload only)')
+    ap.add_argument('--dropin', action='store_true', help="train workload through the drop-in nn.Module + torch.optim.Adam + GradScaler "
+                    "(the reference's loop body, train_utils.py:373-386) instead of SyncTrainer's fused step: the wrapper overhead as a number")
     return ap.parse_args()
 
 
@@ -120,16 +126,24 @@ def cpu_baseline(seconds_budget=25.0, max_threads=16):
     of this path slow down on a many-core host (measured), so `cores` reports the threads actually used."""
     from synchformer_amd import synth
     from oracle import synchformer_cpu as O
-    threads = max(1, min(os.cpu_count() or 1, max_threads))
-    torch.set_num_threads(threads)
     sd = synth.make_state_dict(1337)
     vis = O.rgb_frontend(synth.make_video_u8(1, 14))
     aud = synth.make_spectrogram(1, 14)
+    # thread count: measured on this host, one segment per candidate (the 768-wide matmuls of this path stop scaling long before a
+    # 256-thread host is full); the sweep is kept in the output so that `cores` is evidence, not an assertion
+    ncpu = os.cpu_count() or 1
+    sweep = {}
     with torch.no_grad():
-        O.extract_vfeats(vis[:, :1], sd)                      # warm-up (thread pool, allocator)
-        t0 = time.perf_counter()
-        O.extract_vfeats(vis[:, :1], sd)
-        t1 = time.perf_counter() - t0
+        for th in sorted({min(ncpu, c) for c in (max_threads, 32, 64, ncpu)}):
+            torch.set_num_threads(th)
+            O.extract_vfeats(vis[:, :1], sd)                  # warm-up (thread pool, allocator)
+            t0 = time.perf_counter()
+            O.extract_vfeats(vis[:, :1], sd)
+            sweep[th] = round(time.perf_counter() - t0, 3)
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+    with torch.no_grad():
+        t1 = sweep[threads]
         k = int(max(1, min(14, (seconds_budget - 2 * t1) // max(t1, 1e-3))))
         t0 = time.perf_counter()
         vf = O.extract_vfeats(vis[:, :k], sd, chunk=7)
@@ -141,8 +155,10 @@ def cpu_baseline(seconds_budget=25.0, max_threads=16):
         t_rest = time.perf_counter() - t0
     total = t_vis + t_rest
     return {'value': 1.0 / total, 'unit': 'clips/s', 'cores': threads, 'kind': 'port',
-            'sample': f'1 clip: visual branch on {k}/14 segments scaled x14/{k} ({t_vis:.1f} s/clip), audio branch + sync '
-                      f'transformer in full ({t_rest:.2f} s); fp32 torch CPU oracle; host has {os.cpu_count()} cpus'}
+            'sample': f'1 clip (clips are independent: the B = 4 rate is the same): visual branch on {k}/14 segments scaled x14/{k} '
+                      f'({t_vis:.1f} s/clip), audio branch + sync transformer in full ({t_rest:.2f} s); fp32 torch CPU oracle; host has '
+                      f'{os.cpu_count()} cpus',
+            'thread_sweep_s_per_segment': sweep}
 
 
 def main():
@@ -167,7 +183,33 @@ def main():
     from synchformer_amd import synth
     from synchformer_amd.engine import SynchformerEngine
     B = args.batch
-    if args.workload == 'train':
+    if args.workload == 'train' and args.dropin:
+        import synchformer_amd as sa
+        model = sa.instantiate_from_config(sa.sync_yaml_model_config())
+        model.load_state_dict(synth.make_state_dict(1337), strict=True)
+        model.seg_chunk = args.seg_chunk
+        model = model.to(dev)
+        for p_ in list(model.vfeat_extractor.parameters()) + list(model.afeat_extractor.parameters()):
+            p_.requires_grad = False
+        model.train(); model.vfeat_extractor.eval(); model.afeat_extractor.eval()
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if world > 1 else model
+        opt = torch.optim.Adam([p_ for p_ in model.parameters() if p_.requires_grad], lr=2e-6 * world, betas=(0.9, 0.999), eps=1e-7)
+        scaler = torch.amp.GradScaler('cuda')
+        targets = synth.make_targets(B, 21, seed=1337 + rank).to(dev)
+        trainer = None
+
+        def step_fn(v, a):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast('cuda'):
+                loss, _ = ddp(v, a, targets)
+            scaler.scale(loss).backward()
+            scaler.unscale_(opt)
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            scaler.step(opt)
+            scaler.update()
+            return loss.detach().reshape(1)
+        eng = model._engine(need_sync=False)
+    elif args.workload == 'train':
         from synchformer_amd.train import SyncTrainer
         trainer = SyncTrainer(synth.make_state_dict(1337), dev, lr=2e-6 * world, seg_chunk=args.seg_chunk, embd_pdrop=0.1, resid_pdrop=0.1,
                               attn_pdrop=0.1, seed=1337 + rank)
@@ -196,14 +238,26 @@ def main():
         step_fn = eng.capture(vis, aud)
     for _ in range(args.warmup):
         logits = step_fn(vis, aud)
+    comm_ms = []
+    timed_trainer = trainer if args.workload in ('train', 'stage1') and not args.dropin else None
+    if timed_trainer is not None and world > 1:
+        timed_trainer.time_comm = True
     # ---- the timed region: EXACTLY K steps of the product configuration, no instrumentation -------------------------------------
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         logits = step_fn(vis, aud)
+        if timed_trainer is not None and world > 1:
+            comm_ms.append(timed_trainer._comm_ev)                 # events are read after the timed region
     barrier()
     dt = time.perf_counter() - t0
     assert torch.isfinite(logits).all()
+    if timed_trainer is not None and world > 1:
+        timed_trainer.time_comm = False
+        mine = torch.tensor([timed_trainer.exposed_comm_ms()], device=dev, dtype=torch.float64)     # last step's stall on the gradient buckets
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        comm_ms = [round(float(t.item()), 3) for t in allr]
     # ---- roofline pass: the same K steps again with every sf_gemm_bf16 launch bracketed by HIP events on its launch stream.  The
     # product runs the audio tower on a second stream next to the visual one; an event pair on that stream would also time the queueing
     # behind the other tower's kernels, so for THIS pass the two towers are serialised on one stream (same kernels, same shapes, same
@@ -251,7 +305,15 @@ def main():
             # stage1: forward + dgrad + wgrad of every linear ~ 3x the forward FLOPs (attention backward ~2.5x; approximate)
             'path_flop_per_clip': FLOP_PER_CLIP * (3 if args.workload == 'stage1' else 1),
             'path_mfma_frac': round(value * FLOP_PER_CLIP * (3 if args.workload == 'stage1' else 1) / (world * PEAK_BF16), 4),
+            # the same with the FLOPs the engine executes (aggregators computed for their one consumed output row only)
+            'path_mfma_frac_executed': round(value * FLOP_PER_CLIP_EXECUTED * (3 if args.workload == 'stage1' else 1) / (world * PEAK_BF16), 4),
         }
+        if args.dropin:
+            out['config']['dropin'] = 'nn.Module + autocast + GradScaler + clip_grad_norm_ + torch.optim.Adam' + (' + DistributedDataParallel' if world > 1 else '')
+        if comm_ms:
+            out['comm'] = {'exposed_ms_last_step_by_rank': comm_ms,
+                           'what': 'time the compute stream waited for the gradient all-reduce (Stage-2: one flat 90 MB bucket after the backward; '
+                                   'Stage-1: 7 buckets launched under the backward, the wait is for what did not overlap)'}
         if n_gemm:
             ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
             out['roofline'] = {'bound': 'mfma', 'kernel': 'sf_gemm_bf16 + sf_gemm_res_ln768 (gemm_bf16_persistent_kernel, gemm_bf16_kernel, gemm_res_ln768_kernel)', 'achieved': round(ach, 1),

@@ -62,3 +62,35 @@ def all_gather_rows(local: torch.Tensor) -> torch.Tensor:
     out = torch.empty(dist.get_world_size() * local.shape[0], *local.shape[1:], dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
     return out
+
+
+def all_gather_pair(a: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Both modalities' (n, D) embeddings in ONE all-gather: the message is latency-bound (2 x 28 x 768 fp32 = 172 KB per rank at the
+    configured 2 clips x 14 segments), so two separate collectives cost two latencies for nothing.  Returns the two
+    (world * n, D) matrices in rank order, as `torch.cat(torch.distributed.nn.all_gather(x))` would (open_clip/model.py:489-491)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return a, b
+    world, n = dist.get_world_size(), a.shape[0]
+    assert a.shape == b.shape and a.dtype == b.dtype
+    local = torch.cat([a, b], 0).contiguous()                                             # (2 n, D)
+    out = torch.empty(world, 2 * n, *a.shape[1:], dtype=a.dtype, device=a.device)
+    dist.all_gather_into_tensor(out.view(world * 2 * n, *a.shape[1:]), local)
+    return out[:, :n].reshape(world * n, *a.shape[1:]), out[:, n:].reshape(world * n, *a.shape[1:])
+
+
+def reduce_scatter_pair(da_all: torch.Tensor, db_all: torch.Tensor, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Backward of `all_gather_pair`: every rank holds gradients w.r.t. ALL gathered rows, (world * n, D) per modality; rank r needs the sum
+    over ranks of rows [r n, (r + 1) n).  One reduce-scatter of a (world, 2 n, D) buffer on RCCL (each rank receives 2 n rows instead of
+    the world * 2 n an all-reduce would deliver); gloo has no reduce-scatter, so the CPU / shared-GPU tests take one all-reduce + slice -
+    the same sums."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return da_all, db_all
+    world, rank = dist.get_world_size(), dist.get_rank()
+    packed = torch.stack([da_all.view(world, n, -1), db_all.view(world, n, -1)], 1).contiguous()        # (world, 2, n, D)
+    if dist.get_backend() == 'nccl':
+        out = torch.empty_like(packed[0])
+        dist.reduce_scatter_tensor(out.view(-1), packed.view(-1), op=dist.ReduceOp.SUM)
+    else:
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        out = packed[rank]
+    return out[0], out[1]

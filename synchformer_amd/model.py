@@ -562,8 +562,8 @@ class AVCLIP(torch.nn.Module):
             return self._train_forward(vis, aud, logit_scales)
         vfeat, _, afeat, _ = self.encode_streams(vis, aud, for_loop, do_norm=True)
         if world_size > 1 and self.gather_for_loss:
-            from .dist import all_gather_rows
-            vfeat_all, afeat_all = all_gather_rows(vfeat), all_gather_rows(afeat)
+            from .dist import all_gather_pair
+            vfeat_all, afeat_all = all_gather_pair(vfeat, afeat)
         else:
             vfeat_all, afeat_all = vfeat, afeat
         loss_avc, _ = self.compute_loss(vfeat, afeat, vfeat_all.mT, afeat_all.mT, self.logit_scale, alpha=0)

@@ -73,6 +73,7 @@ class AVCLIPTrainer(FlatTrainer):
         # stochastic depth of the visual tower: DROP_PATH 0.2 (divided_224_16x4.yaml:59), block i drops its space-attention and MLP branches per
         # segment with probability linspace(0, rate, depth)[i] (video_model_builder.py:86-87, vit_helper.py:356,372,375); 0 = evaluation mode
         self.drop_path_rate, self.seed, self.fwd_count = float(drop_path_rate or 0.0), int(seed), 0
+        self.time_comm, self._comm_ev = False, None                            # bench.py: HIP events around the bucket waits
         self.fused_attn_bwd = True          # False: the gathered batched-GEMM attention backward (kept as a cross-check)
         self.two_streams = os.environ.get('SF_STAGE1_TWO_STREAMS', '1') != '0'   # audio tower next to the visual one (forward_backward)
         self._side = None
@@ -473,12 +474,12 @@ class AVCLIPTrainer(FlatTrainer):
 
     def _head(self, vfeat, afeat):
         """AVCLIP.compute_loss (open_clip/model.py:506-525) + its backward -> (dvfeat, dafeat) fp32 (n, 768); fills g[logit_scale]."""
-        from .dist import all_gather_rows
+        from .dist import all_gather_pair, reduce_scatter_pair
         n = vfeat.shape[0]
         s = float(self.p['logit_scale'])                                        # host scalar (one sync per step)
         world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
         gathered = self.gather_for_loss and world > 1
-        v_all, a_all = (all_gather_rows(vfeat), all_gather_rows(afeat)) if gathered else (vfeat, afeat)
+        v_all, a_all = all_gather_pair(vfeat, afeat) if gathered else (vfeat, afeat)      # one 172 KB message for both modalities
         m = v_all.shape[0]
         sims = [self._buf(f'sim{i}', (n, m), torch.float32) for i in range(2)]
         dsims = [self._buf(f'dsim{i}', (n, m), torch.float32) for i in range(2)]
@@ -500,11 +501,8 @@ class AVCLIPTrainer(FlatTrainer):
         self._matmul_nt(dsims[1], v_all, da, 1.0 / s)                           # d sim_a2v / d afeat
         self._matmul_nt(dsims[1].t(), afeat, dv_all, 1.0 / s)                   # d sim_a2v / d vfeat_all  (m, D)
         self._matmul_nt(dsims[0].t(), vfeat, da_all, 1.0 / s)                   # d sim_v2a / d afeat_all
-        if gathered:                                                            # backward of all_gather = reduce-scatter (sum over ranks)
-            torch.distributed.all_reduce(dv_all)
-            torch.distributed.all_reduce(da_all)
-            r = torch.distributed.get_rank()
-            dv_all, da_all = dv_all[r * n:(r + 1) * n], da_all[r * n:(r + 1) * n]
+        if gathered:                                                            # backward of all_gather = reduce-scatter (sum over ranks), one message
+            dv_all, da_all = reduce_scatter_pair(dv_all, da_all, n)
         ops_add = self._buf('head_sum', (2, n, D), torch.float32)
         torch.add(dv, dv_all, out=ops_add[0])                                   # two (n, 768) adds
         torch.add(da, da_all, out=ops_add[1])
@@ -591,12 +589,24 @@ class AVCLIPTrainer(FlatTrainer):
             if world > 1:
                 handles.append(dist.all_reduce(self.flat_g[span[0]:span[1]], async_op=True))
         loss = self.forward_backward(vis, aud, on_ready=reduce_range)
+        if world > 1 and self.time_comm:                                       # exposed communication = how long the compute stream stalls on the buckets
+            self._comm_ev = self._comm_ev or (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._comm_ev[0].record()
         for h in handles:
             h.wait()
         if world > 1:
+            if self.time_comm:
+                self._comm_ev[1].record()
             self.flat_g.div_(world)                                            # DDP semantics: mean over ranks
         self.optimizer_step(lr)
         return loss
+
+    def exposed_comm_ms(self) -> float:
+        """Milliseconds the compute stream waited for the gradient buckets in the last train_step (0 without a process group)."""
+        if self._comm_ev is None:
+            return 0.0
+        self._comm_ev[1].synchronize()
+        return self._comm_ev[0].elapsed_time(self._comm_ev[1])
 
     def model_state_dict(self) -> Dict[str, torch.Tensor]:
         """Checkpoint in the reference's AVCLIP key names (v_encoder. / a_encoder. / logit_scale)."""

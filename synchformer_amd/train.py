@@ -273,10 +273,25 @@ class FlatTrainer:
         bgemm(dST, Lp, H * L * Lp, L * Lp, qT, Lp, H * hd * Lp, hd * Lp, dk, ldg, L * ldg, hd, L, hd, Lp, B, H)    # dK = dS^T Q
         bgemm(PT, Lp, H * L * Lp, L * Lp, dOT, Lp, H * hd * Lp, hd * Lp, dv, ldg, L * ldg, hd, L, hd, Lp, B, H)    # dV = P^T dO
 
+    time_comm, _comm_ev = False, None
+
     def allreduce_grads(self):
         """DDP-equivalent gradient averaging: one flat 90 MB bucket over RCCL (C1 in SURVEY §2.2)."""
         from .dist import allreduce_mean_
-        allreduce_mean_(self.flat_g)
+        if self.time_comm and torch.distributed.is_available() and torch.distributed.is_initialized():
+            self._comm_ev = self._comm_ev or (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._comm_ev[0].record()
+            allreduce_mean_(self.flat_g)
+            self._comm_ev[1].record()
+        else:
+            allreduce_mean_(self.flat_g)
+
+    def exposed_comm_ms(self) -> float:
+        """Milliseconds of the last step's gradient all-reduce on the compute stream (0 without a process group)."""
+        if self._comm_ev is None:
+            return 0.0
+        self._comm_ev[1].synchronize()
+        return self._comm_ev[0].elapsed_time(self._comm_ev[1])
 
     def optimizer_step(self, lr: Optional[float] = None):
         """clip_grad_norm_(max_clip_norm) + Adam on the flat buffers (train_utils.py:373-386), then refresh operand copies."""

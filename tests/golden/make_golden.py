@@ -307,6 +307,46 @@ def avclip_grads(B=1, S=3, gain=2.0):
           'dscale', float(scale.grad))
 
 
+def avclip_grads_full(B=2, S=14, gain=2.0, chunk=2):
+    """Stage 1 at its CONFIGURED geometry (configs/segment_avclip.yaml:61 base_batch_size 2 x 14 segments = a 28 x 28 contrastive problem)
+    through the REAL AVCLIP class, eval mode (no DropPath), fp32.  The towers treat segments independently, so the backward is run `chunk`
+    segments at a time from the exact feature gradients of the real compute_loss (identical to one big backward, a fraction of the memory).
+    Stored: loss, the similarity matrix, d loss / d logit_scale, and the gradient NORM of every parameter tensor (+ a few small gradients)."""
+    m = _real_avclip(gain)
+    vis = rgb_frontend_ref(synth.make_video_u8(B, S, SEED)).float().permute(0, 1, 3, 2, 4, 5)       # (B, S, C, Tv, H, W)
+    aud = synth.make_spectrogram(B, S, SEED).squeeze(2).permute(0, 1, 3, 2)                          # (B, S, Ta, F)
+    n = B * S
+    v_flat, a_flat = vis.reshape(1, n, *vis.shape[2:]), aud.reshape(1, n, *aud.shape[2:])
+    with torch.no_grad():
+        vseg = torch.cat([m.v_encoder(v_flat[:, i:i + chunk], False)[0] for i in range(0, n, chunk)], 1)[0]      # (n, 768)
+        aseg = torch.cat([m.a_encoder(a_flat[:, i:i + chunk], False)[0] for i in range(0, n, chunk)], 1)[0]
+    vl, al = vseg.clone().requires_grad_(True), aseg.clone().requires_grad_(True)
+    vf, af = torch.nn.functional.normalize(vl, dim=-1), torch.nn.functional.normalize(al, dim=-1)
+    loss, (sim_v2a, _) = m.compute_loss(vf, af, vf.mT, af.mT, m.logit_scale, alpha=0)
+    loss.backward()
+    dscale = m.logit_scale.grad.clone()
+    for i in range(0, n, chunk):
+        vo = m.v_encoder(v_flat[:, i:i + chunk], False)[0][0]
+        vo.backward(vl.grad[i:i + chunk])
+        ao = m.a_encoder(a_flat[:, i:i + chunk], False)[0][0]
+        ao.backward(al.grad[i:i + chunk])
+        print('avclip_grads_full: segments', i, '..', i + chunk, flush=True)
+    named = [('vfeat_extractor.' + k, p_) for k, p_ in m.v_encoder.named_parameters()] + [('afeat_extractor.' + k, p_) for k, p_ in m.a_encoder.named_parameters()]
+    named = [(k, p_) for k, p_ in named if p_.grad is not None]
+    keep = ('vfeat_extractor.cls_token', 'vfeat_extractor.temp_embed', 'vfeat_extractor.blocks.0.norm3.weight', 'vfeat_extractor.blocks.11.attn.proj.bias',
+            'vfeat_extractor.norm.weight', 'vfeat_extractor.spatial_attn_agg.cls_token', 'afeat_extractor.ast.embeddings.cls_token',
+            'afeat_extractor.ast.encoder.layer.11.output.dense.bias', 'afeat_extractor.freq_attn_agg.linear1.bias')
+    out = dict(seed=np.int64(SEED), B=np.int64(B), S=np.int64(S), gain=np.float64(gain), loss=loss.detach().numpy(), logit_scale_grad=dscale.numpy(),
+               sim_v2a=sim_v2a.detach().numpy(), names=np.array([k for k, _ in named] + ['logit_scale']),
+               grad_norms=np.array([float(p_.grad.norm()) for _, p_ in named] + [float(dscale.abs())], dtype=np.float64))
+    for k, p_ in named:
+        if k in keep:
+            out['grad__' + k.replace('.', '__')] = p_.grad.numpy()
+    np.savez_compressed(HERE / f'avclip_grads_B{B}S{S}.npz', **out)
+    print('avclip_grads_full: loss', float(loss), 'dscale', float(dscale), 'total grad norm', float(np.sqrt((out['grad_norms'] ** 2).sum())),
+          'sim spread', float(sim_v2a.max() - sim_v2a.min()))
+
+
 def e2e_masked(B=1, S=2, gain=2.0):
     """Synchformer.forward with vis_mask / aud_mask (sync_model.py:38-89; token masks via the NaN trick) through the REAL reference."""
     n_pos = 2 + S * 14
@@ -356,5 +396,7 @@ if __name__ == '__main__':
         segments()
     if 'avclip_grads' in which:
         avclip_grads(1, 3)
+    if 'avclip_grads_full' in which:
+        avclip_grads_full(2, 14)
     if 'masked' in which:
         e2e_masked(1, 2)

@@ -57,7 +57,16 @@ def _gather_worker(rank, world, port, q):
         from synchformer_amd.dist import all_gather_rows
         local = torch.full((3, 768), float(rank)) + torch.arange(3.).unsqueeze(1)      # row i of rank r = r + i
         full = all_gather_rows(local)
-        q.put((rank, tuple(full.shape), full[:, 0].tolist()))
+        # both modalities in one message, and the matching backward (sum over ranks of the gradient rows this rank owns)
+        from synchformer_amd.dist import all_gather_pair, reduce_scatter_pair
+        va, aa = all_gather_pair(local, local + 100.0)
+        ok_pair = torch.equal(va, full) and torch.equal(aa, full + 100.0)
+        gv = torch.arange(6 * 768, dtype=torch.float32).view(6, 768) * (rank + 1)        # this rank's gradient w.r.t. ALL gathered rows
+        ga = -gv
+        dv, da = reduce_scatter_pair(gv, ga, 3)
+        want = torch.arange(6 * 768, dtype=torch.float32).view(6, 768)[rank * 3:(rank + 1) * 3] * 3.0       # (1 + 2) x the rows of this rank
+        ok_rs = torch.equal(dv, want) and torch.equal(da, -want)
+        q.put((rank, tuple(full.shape), full[:, 0].tolist(), ok_pair, ok_rs))
     finally:
         dist.destroy_process_group()
 
@@ -74,5 +83,6 @@ def test_two_rank_embedding_all_gather():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for _, shape, col in res:
+    for _, shape, col, ok_pair, ok_rs in res:
         assert shape == (6, 768) and col == [0., 1., 2., 1., 2., 3.]
+        assert ok_pair and ok_rs

@@ -215,6 +215,43 @@ def test_avclip_grads_match_reference_golden(gpu):
         assert rel < 6e-2, (k, rel)
 
 
+def test_avclip_grads_configured_geometry_golden(gpu):
+    """Stage 1 at its CONFIGURED geometry - 2 clips x 14 segments per GPU, a 28 x 28 contrastive problem (configs/segment_avclip.yaml:61) -
+    against the REAL AVCLIP class in eval mode (tests/golden/avclip_grads_B2S14.npz, make_golden.py avclip_grads_full): loss, the cosine
+    matrix, d loss / d logit_scale (well conditioned here: -0.54, unlike the 3 x 3 case) and the gradient norm of all 449 tensors."""
+    f = GOLD / 'avclip_grads_B2S14.npz'
+    if not f.exists():
+        pytest.skip(f'{f.name} missing')
+    g = np.load(f)
+    sd, tr, u8, aud = _setup(gpu, int(g['B']), int(g['S']), float(g['gain']))
+    loss = tr.forward_backward(u8.to(gpu), aud.to(gpu))
+    dscale, dscale_ref = float(tr.g['logit_scale']), float(g['logit_scale_grad'])
+    cos = tr.vfeat @ tr.afeat.T
+    dcos = (cos.cpu() - torch.from_numpy(g['sim_v2a']) * 0.07).abs().max().item()
+    print(f'2x14: loss hip {float(loss):.5f} ref {float(g["loss"]):.5f} | cos max err {dcos:.5f} | dscale hip {dscale:.5f} ref {dscale_ref:.5f}')
+    assert abs(float(loss) - float(g['loss'])) < 1e-2 and dcos < 2e-3
+    assert abs(dscale - dscale_ref) < 5e-2 * abs(dscale_ref)
+    names = [str(n) for n in g['names']]
+    norms = dict(zip(names, g['grad_norms']))
+    assert set(names) == set(tr.keys)
+    tot_ref = float(np.sqrt((g['grad_norms'][:-1].astype(np.float64) ** 2).sum()))
+    tot_got = float(tr.flat_g[:-1].norm())
+    print(f'grad norm hip {tot_got:.6f} reference {tot_ref:.6f}')
+    assert abs(tot_got / tot_ref - 1) < 1e-2
+    by_size = {}
+    for k in names[:-1]:
+        by_size[tr.g[k].numel()] = max(by_size.get(tr.g[k].numel(), 0.0), norms[k])
+    worst = max((abs(float(tr.g[k].norm()) - norms[k]) / max(norms[k], 0.05 * by_size[tr.g[k].numel()]), k) for k in names[:-1])
+    print('worst per-tensor gradient-norm error', worst)
+    assert worst[0] < 6e-2, worst
+    for key in g.files:
+        if key.startswith('grad__'):
+            k = key[len('grad__'):].replace('__', '.')
+            got, ref = tr.g[k].detach().cpu().float().reshape(-1), torch.from_numpy(g[key]).reshape(-1)
+            rel = ((got - ref).norm() / max(ref.norm().item(), 0.05 * by_size.get(tr.g[k].numel(), 0.0))).item()
+            assert rel < 6e-2, (k, rel)
+
+
 def test_contrastive_head_matches_autograd(gpu):
     """AVCLIP.compute_loss + backward on well-separated random unit features (fp32 kernels: tight tolerance)."""
     from synchformer_amd import synth

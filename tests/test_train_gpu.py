@@ -384,3 +384,162 @@ def test_dropout_train_step_matches_oracle_given_masks(gpu):
     l2 = tr.loss.item()
     tr.fwd_count = 0
     assert abs(tr.forward_backward(vf.to(gpu), af.to(gpu), tgt.to(gpu)).item() - loss) < 1e-6 and abs(l2 - loss) > 1e-6
+
+
+def _frozen_train_model(gpu, dropout=True):
+    import synchformer_amd as sa
+    from synchformer_amd import synth
+    cfg = sa.sync_yaml_model_config()
+    if not dropout:
+        for k in ('embd_pdrop', 'resid_pdrop', 'attn_pdrop'):
+            cfg['params']['transformer']['params'][k] = 0.0
+    model = sa.instantiate_from_config(cfg)
+    model.load_state_dict(synth.make_state_dict(1337), strict=True)
+    model = model.to(gpu)
+    for p in list(model.vfeat_extractor.parameters()) + list(model.afeat_extractor.parameters()):
+        p.requires_grad = False                                                          # get_model, train_utils.py:199-204
+    model.train()
+    model.vfeat_extractor.eval(); model.afeat_extractor.eval()                           # toggle_mode, train_utils.py:333-342
+    return model
+
+
+def test_dropin_autocast_gradscaler_loop(gpu):
+    """The reference's Stage-2 iteration with its REAL wrappers (train_sync.py:176-185, train_utils.py:373-386): forward under
+    torch.autocast('cuda'), GradScaler.scale(loss).backward(), unscale_, clip_grad_norm_, scaler.step, scaler.update - on the HIP-backed
+    module, with the config's dropout 0.1.  Also the regression test of the per-step engine rebuild: ONE engine object and ONE trainer serve
+    every step (only the 22.6M trainable copies are refreshed), and the dropout masks of consecutive steps differ (the trainer's forward
+    counter advances - a rebuilt trainer would replay the same masks every step)."""
+    from synchformer_amd import synth
+    model = _frozen_train_model(gpu)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=2e-4, betas=(0.9, 0.999), eps=1e-7)
+    scaler = torch.amp.GradScaler('cuda', enabled=True)
+    u8, aud = synth.make_video_u8(2, 14, 1337).to(gpu), synth.make_spectrogram(2, 14, 1337).to(gpu)
+    tgt = torch.from_numpy(np.load(GOLD / 'e2e_sync_B2.npz')['targets']).to(gpu)
+    losses, seeds, engines, trainers = [], [], set(), set()
+    for it in range(4):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', enabled=True):
+            loss, logits = model(u8, aud, tgt)
+        assert loss.dtype == torch.float32 and logits.dtype == torch.float32
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        assert torch.isfinite(gn)
+        scaler.step(opt)
+        scaler.update()
+        losses.append(loss.item())
+        tr = model._sf_trainer
+        seeds.append((tr.sv['embd_seed'], tr.sv['blocks'][0]['attn_seed'], tr.sv['blocks'][2]['mlp_seed']))
+        engines.add(id(model._sf_engine[1])); trainers.add(id(tr))
+    print('autocast + GradScaler losses', [f'{x:.4f}' for x in losses], 'scale', scaler.get_scale())
+    assert len(engines) == 1 and len(trainers) == 1, 'the engine / trainer were rebuilt between optimizer steps'
+    assert len(set(seeds)) == 4, f'dropout seeds repeat across steps: {seeds}'
+    assert scaler.get_scale() == 65536.0                                                 # no inf/nan step was skipped
+    assert min(losses[1:]) < losses[0]
+    # the masks themselves differ: regenerate the embedding-dropout mask of two steps
+    from synchformer_amd import train as T
+    ones = torch.ones(64, 768, device=gpu)
+    m0, m1 = torch.empty_like(ones), torch.empty_like(ones)
+    T.dropout(ones, m0, 64, 768, 0.1, seeds[0][0]); T.dropout(ones, m1, 64, 768, 0.1, seeds[1][0])
+    assert not torch.equal(m0, m1)
+    # inference after training sees the updated sync weights through the SAME engine (refreshed in place)
+    model.eval()
+    with torch.no_grad():
+        l_eval, _ = model(u8, aud, tgt)
+    assert id(model._sf_engine[1]) in engines and l_eval.item() < losses[0]
+
+
+def test_two_forwards_before_backward_raise(gpu):
+    """The autograd bridge keeps its activations in the trainer's shared workspaces: a backward through a forward that a later
+    grad-enabled forward has overwritten must fail loudly, not return the other forward's gradients."""
+    from synchformer_amd import synth
+    model = _frozen_train_model(gpu, dropout=False)
+    u8, aud = synth.make_video_u8(1, 14, 1337).to(gpu), synth.make_spectrogram(1, 14, 1337).to(gpu)
+    tgt = torch.zeros(1, dtype=torch.int64, device=gpu)
+    l1, _ = model(u8, aud, tgt)
+    l2, _ = model(u8, aud, tgt + 1)
+    with pytest.raises(RuntimeError, match='overwritten by a later grad-enabled forward'):
+        l1.backward()
+    l2.backward()                                                                        # the latest forward is fine
+    with torch.no_grad():
+        model(u8, aud, tgt)                                                              # a no_grad forward in between does not invalidate
+    l3, _ = model(u8, aud, tgt)
+    with torch.no_grad():
+        model(u8, aud, tgt)
+    l3.backward()
+
+
+def test_cross_entropy_out_of_range_target(gpu):
+    """sf_cross_entropy with a target outside [0, C): NaN loss, zero gradient row, no out-of-bounds read (F.cross_entropy raises)."""
+    from synchformer_amd import ops
+    z = torch.randn(4, 21, device=gpu)
+    loss, dz = torch.empty(1, device=gpu), torch.empty(4, 21, device=gpu)
+    ops.cross_entropy(z, torch.tensor([3, 20, 0, 7], device=gpu), loss, dz)
+    ref = torch.nn.functional.cross_entropy(z, torch.tensor([3, 20, 0, 7], device=gpu))
+    assert abs(loss.item() - ref.item()) < 1e-5
+    ops.cross_entropy(z, torch.tensor([3, -100, 0, 7], device=gpu), loss, dz)
+    assert torch.isnan(loss).all() and (dz[1] == 0).all() and torch.isfinite(dz).all()
+    ops.cross_entropy(z, torch.tensor([3, 21, 0, 7], device=gpu), loss, dz)
+    assert torch.isnan(loss).all() and (dz[1] == 0).all()
+
+
+def _ddp_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from synchformer_amd import synth
+        gpu = torch.device('cuda:0')
+        model = _frozen_train_model(gpu, dropout=False)
+
+        class DistributedDataParallel(torch.nn.parallel.DistributedDataParallel):      # scripts/train_utils.py:185-193
+            def __getattr__(self, name):
+                try:
+                    return super().__getattr__(name)
+                except AttributeError:
+                    return getattr(self.module, name)
+        ddp = DistributedDataParallel(model, device_ids=[0])                             # get_model, train_utils.py:208-210
+        assert ddp.compute_loss is not None                                              # attribute forwarding to the wrapped module
+        u8, aud = synth.make_video_u8(1, 14, 100 + rank).to(gpu), synth.make_spectrogram(1, 14, 100 + rank).to(gpu)
+        tgt = torch.tensor([3 + 5 * rank], device=gpu)
+        # local gradients of this rank's clip, then the DDP-averaged ones
+        model.zero_grad(set_to_none=True)
+        with ddp.no_sync():
+            loss, _ = ddp(u8, aud, tgt)
+            loss.backward()
+        local = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.requires_grad]).clone()
+        mean = local.clone()
+        dist.all_reduce(mean)
+        mean /= world
+        model.zero_grad(set_to_none=True)
+        loss, _ = ddp(u8, aud, tgt)
+        loss.backward()                                                                  # reducer hooks fire on the gradients the HIP backward returns
+        got = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.requires_grad])
+        q.put((rank, float((got - mean).abs().max()), float(mean.abs().max()), float((local - mean).abs().max())))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dropin_under_reference_ddp_wrapper(gpu):
+    """The reference wraps the model in its DistributedDataParallel subclass (train_utils.py:185-193, 208-210).  Two gloo ranks share the
+    GPU: the gradients DDP leaves on the nn.Parameters must be the mean over ranks of the per-rank HIP gradients."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, err, scale, spread in res:
+        assert err <= 1e-6 * max(1.0, scale), res                                        # DDP average == manual mean of the local gradients
+        assert spread > 1e-4 * scale, res                                                # ... and the two ranks really had different gradients
