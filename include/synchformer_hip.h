@@ -71,6 +71,20 @@ int sf_gemm_res_ln768(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t
                       float* X, int64_t ldx, const float* gamma, const float* beta, float eps, uint16_t* Y, int64_t ldy, int64_t M,
                       int64_t K, void* stream);
 
+/* ---- MX-FP8 path of the frozen feature extractors in the synchronizability fine-tune (BASELINE configs[4]; configs/ft_synchability.yaml:7,19:
+ * is_trainable False towers; the reference itself has no fp8 - fp16 autocast only, scripts/train_sync.py:178).  OCP Microscaling MXFP8: e4m3
+ * elements, one E8M0 scale byte per 32 consecutive k of a row. ---- */
+/* q (rows x K bytes, row stride ldq) and scales <- bf16 x (rows x K); K % 128 == 0.  Scales are STAGE-major for the GEMM's loads: plane k/128 (lds
+ * BYTES apart, lds >= rows * 4) holds 4 bytes per row = the E8M0 scales of that row's four 32-blocks in the 128-deep stage. */
+int sf_quantize_mxfp8(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scales, int64_t lds, int64_t rows, int64_t K, void* stream);
+/* sf_gemm_bf16's contract (bias, exact-erf GELU, fp32 residual, bf16|fp32 output, identity row maps) on MXFP8 operands: A (M x K) / W (N x K)
+ * e4m3 bytes with their stage-major scale planes sA / sW (K/128 planes, ldsa / ldsw bytes apart, 4 bytes per row); K % 128 == 0, N % 64 == 0.  v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate.
+ * Replaces the nn.Linear calls at vit_helper.py:103,155,392-396 (qkv / proj / fc1 / fc2 of the DividedSpaceTimeBlocks) when the engine is built
+ * with fp8 towers. */
+int sf_gemm_mxfp8(const uint8_t* A, int64_t lda, const uint8_t* sA, int64_t ldsa, const uint8_t* W, int64_t ldw, const uint8_t* sW, int64_t ldsw,
+                  const float* bias, void* C, int c_dtype, int64_t ldc, const float* R, int64_t ldr, int epilogue, int64_t M, int64_t N, int64_t K,
+                  void* stream);
+
 /* Tuning / test hook (process-global, not for production threads): force the GEMM tile configuration of subsequent sf_gemm_bf16
  * calls.  -1 = automatic choice by shape (default); 0 = 128x128x64, 4 waves, two workgroups per CU; 7 = persistent 256x256x64,
  * 8 waves, v_mfma_f32_32x32x16_bf16; 1-6, 8, 9 = the other tilings measured in profiles/r01_gemm_configs.md (tools/bench_gemm.py). */

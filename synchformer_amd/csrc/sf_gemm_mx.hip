@@ -1,0 +1,424 @@
+// MX-FP8 (OCP e4m3 elements, one E8M0 scale per 32 consecutive k) GEMM with the fused epilogues of sf_gemm_bf16, for gfx950 (MI355X):
+//     C[m, n] = epi( sum_k dq(A[m, k]) * dq(W[n, k]) + bias[n] ) (+ R[m, n]),   dq(x[r, k]) = e4m3(x[r, k]) * 2^(scale[r, k / 32] - 127)
+// The frozen feature extractors of the synchronizability fine-tune (BASELINE configs[4]; configs/ft_synchability.yaml:7,19 is_trainable False)
+// run their four big Linears per block (vit_helper.py:103,155,392-396) on it.  Why block-scaled and not per-tensor fp8: on gfx950 the plain
+// fp8 MFMA (v_mfma_f32_32x32x16_fp8_fp8) issues at the bf16 rate; only v_mfma_scale_f32_32x32x64_f8f6f4 - 64-deep, the dequantisation by the two
+// block scales fused into the instruction - runs at twice it (MI355X_MICROARCH.md, MFMA table).  And since the bf16 kernels of this repo are bound
+// by operand delivery per CU (profiles/r02_gemm_ln.md), halving the operand bytes per k is worth as much as the doubled matrix rate.
+//
+// Structure = gemm_bf16_persistent_kernel with the same BYTE geometry: a stage is 256 rows x 128 BYTES of A and of W (= 128 k instead of 64), LDS rows
+// of 128 B with the 16-byte chunk c of row r at slot c ^ ((r >> 1) & 7), two ring slots, LDS-DMA from inline asm, one counted wait + raw barrier
+// per stage, 8 waves as 2 x 4 with 128 x 64 wave tiles.  Per 64-deep MFMA a lane supplies 16 bytes of each of the two MX blocks of its row (the other
+// half-wave supplies the other 16) and ONE scale byte - that of block (lane >> 5) - taken from a dword (the 4 block scales of the row for the 128-deep
+// stage) that is loaded from the stage-major scale planes one stage ahead.  Which byte of a block lands in which operand dword cannot matter: A and W
+// use the same map and the dot product is a sum over the block; which BLOCK a byte is counted in does, and was established on the hardware.
+#include "sf_common.h"
+#include <stdlib.h>
+#include <type_traits>
+#include "../../include/synchformer_hip.h"
+
+#define MXBM 256
+#define MXBN 256
+#define MXBK 128                           // bytes = fp8 elements per row per stage
+#define MX_STAGE (2 * MXBM * MXBK)         // 64 KiB: A tile + W tile
+#define MX_EPI_LD 64
+#define MX_SLAB_BYTES (16 * MX_EPI_LD * 4) // 4 KiB per wave
+#define MX_LDS (2 * MX_STAGE + 8 * MX_SLAB_BYTES)
+#ifndef SF_MX_STORE_AUX
+#define SF_MX_STORE_AUX 2
+#endif
+
+typedef __attribute__((ext_vector_type(8))) int mx_i32x8;
+typedef __attribute__((ext_vector_type(4))) int mx_i32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int mx_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int mx_u32x2;
+
+struct MxArgs {
+  const uint8_t* A; int64_t lda; const uint8_t* sA; int64_t ldsa;
+  const uint8_t* W; int64_t ldw; const uint8_t* sW; int64_t ldsw;
+  const float* bias;
+  void* C; int64_t ldc;
+  const float* R; int64_t ldr;
+  int64_t M;
+  int N, K;
+  uint32_t tiles_n, tiles_total, nchunk;
+};
+
+__device__ __forceinline__ uint32_t mx_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+
+// Four LDS-DMA pieces (1 KiB each, consecutive in LDS from the wave-uniform address l0): SGPR base + zero-extended 32-bit lane offsets (the
+// operands stay below 4 GiB; 64-bit lane pointers do not fit next to 128 accumulators + the wider MX fragments: they spilled into the k-loop).
+__device__ __forceinline__ void mx_dma4(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, const void* sbase, uint32_t l0) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(l0)
+      : "memory", "scc");
+}
+
+__device__ __forceinline__ void mx_wait_vmcnt0_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt((0 & 0xF) | (0x7 << 4) | (0xF << 8) | (0 << 14));
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <bool OUT_BF16, bool GELU, bool HAS_RES>
+__device__ __forceinline__ void mx_epi_store(float4 (&v)[4], const float4& bias4, const float4 (&res)[4], __amdgpu_buffer_rsrc_t rc, uint32_t coff, uint32_t cstep) {
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    float4 x = v[ps];
+    x.x += bias4.x; x.y += bias4.y; x.z += bias4.z; x.w += bias4.w;
+    if (GELU) {
+      const sf_f32x2_t g0 = gelu_erf2(sf_f32x2_t{x.x, x.y}), g1 = gelu_erf2(sf_f32x2_t{x.z, x.w});
+      x.x = g0.x; x.y = g0.y; x.z = g1.x; x.w = g1.y;
+    }
+    if (HAS_RES) { x.x += res[ps].x; x.y += res[ps].y; x.z += res[ps].z; x.w += res[ps].w; }
+    if (OUT_BF16) {
+      mx_u32x2 o; o.x = pack_bf2(x.x, x.y); o.y = pack_bf2(x.z, x.w);
+      __builtin_amdgcn_raw_buffer_store_b64(o, rc, coff + ps * cstep, 0, SF_MX_STORE_AUX);
+    } else {
+      mx_u32x4 o;
+      o.x = __float_as_uint(x.x); o.y = __float_as_uint(x.y); o.z = __float_as_uint(x.z); o.w = __float_as_uint(x.w);
+      __builtin_amdgcn_raw_buffer_store_b128(o, rc, coff + ps * cstep, 0, SF_MX_STORE_AUX);
+    }
+  }
+}
+__device__ __forceinline__ void mx_load_res(float4 (&res)[4], __amdgpu_buffer_rsrc_t rr, uint32_t roff, uint32_t rstep) {
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const mx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rr, roff + ps * rstep, 0, 2);
+    res[ps] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+  }
+}
+
+template <bool OUT_BF16, bool GELU, bool HAS_RES>
+__global__ __launch_bounds__(512, 2) void gemm_mxfp8_persistent_kernel(MxArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  const uint32_t xcd = blockIdx.x & 7u, li = blockIdx.x >> 3, per_xcd_blocks = gridDim.x >> 3;
+  const uint32_t tiles_m = p.tiles_total / p.tiles_n;
+  const uint32_t mp8 = (tiles_m + 7u) >> 3;
+  const uint32_t mp0 = min(xcd * mp8, tiles_m), mp1 = min(mp0 + mp8, tiles_m), n_mp = mp1 - mp0;
+  const uint32_t gchunk = p.nchunk ? min(p.nchunk, p.tiles_n) : p.tiles_n;
+  const uint32_t n_chunks = (p.tiles_n + gchunk - 1) / gchunk, chunk_tiles = n_mp * gchunk;
+  const uint32_t t_end = n_mp * p.tiles_n;
+
+  const int piece_row = lane >> 3, slot = lane & 7;
+  const int sw = (l31 >> 1) & 7;
+  // operand fragment of the 64-deep step kk (0, 1) of a stage.  Measured on the hardware (tools/debug_mx.py): of a lane's 32 operand bytes the FIRST 16
+  // belong to the instruction's first scale block and the SECOND 16 to its second one, each block being completed by the other half-wave (lane ^ 32),
+  // and block b takes its scale from the lanes with (lane >> 5) == b.  So lane (row, hi) loads bytes [hi*16, +16) of MX block 2 kk and of MX block
+  // 2 kk + 1 of its row (chunks kk*4 + hi and kk*4 + 2 + hi) and supplies the scale byte of block 2 kk + hi.
+  int frag_off[2][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) frag_off[kk][h] = l31 * 128 + (((kk * 4 + h * 2 + hi) ^ sw) << 4);
+  const int a_base = wm * 128 * 128, b_base = MXBM * MXBK + wn * 64 * 128;
+
+  uint32_t a_src[4], b_src[4];                                    // byte offsets from p.A / p.W
+  uint32_t sa_off[4], sb_off[2];                                  // scale dwords of rows (wm*128 + i*32 + l31) of A / (wn*64 + j*32 + l31) of W: row * 4 within a stage plane
+  auto set_tile = [&](uint32_t t, int64_t& m0, int& n0) {
+    const uint32_t c = min(t / chunk_tiles, n_chunks - 1), r = t - c * chunk_tiles;
+    const uint32_t gw = (c == n_chunks - 1) ? p.tiles_n - c * gchunk : gchunk;
+    const uint32_t tm = mp0 + r / gw, tn = c * gchunk + r % gw;
+    m0 = (int64_t)tm * MXBM; n0 = (int)tn * MXBN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave * 4 + i) * 8 + piece_row;
+      const int gch = slot ^ ((row >> 1) & 7);
+      int64_t ar = m0 + row; if (ar > p.M - 1) ar = p.M - 1;
+      int br = n0 + row; if (br > p.N - 1) br = p.N - 1;
+      a_src[i] = (uint32_t)(ar * p.lda + gch * 16);
+      b_src[i] = (uint32_t)((int64_t)br * p.ldw + gch * 16);
+      int64_t sr = m0 + wm * 128 + i * 32 + l31; if (sr > p.M - 1) sr = p.M - 1;
+      sa_off[i] = (uint32_t)(sr * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int sr = n0 + wn * 64 + j * 32 + l31; if (sr > p.N - 1) sr = p.N - 1;
+      sb_off[j] = (uint32_t)(sr * 4);
+    }
+  };
+  const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(mx_lds_addr(smem) + (wave * 4) * 1024);
+  auto stage = [&](int s, int kt) {
+    const uint32_t l = lds_wave + s * MX_STAGE;
+    mx_dma4(a_src[0] + kt * MXBK, a_src[1] + kt * MXBK, a_src[2] + kt * MXBK, a_src[3] + kt * MXBK, p.A, l);
+    mx_dma4(b_src[0] + kt * MXBK, b_src[1] + kt * MXBK, b_src[2] + kt * MXBK, b_src[3] + kt * MXBK, p.W, l + MXBM * MXBK);
+  };
+  // scale matrices are STAGE-major: plane kt (ld bytes apart) holds one dword per row = the four E8M0 bytes of that row's 128-deep stage kt.  A
+  // row-major (rows, K/32) layout made every lane of these loads touch its own cache line: 3x the line requests of the operand stream itself.
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.sA), (short)0, (int)(uint32_t)((p.K / MXBK) * p.ldsa), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.sW), (short)0, (int)(uint32_t)((p.K / MXBK) * p.ldsw), 0x00020000);
+  auto load_scales = [&](uint32_t (&sa)[4], uint32_t (&sb)[2], int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sa[i] = __builtin_amdgcn_raw_buffer_load_b32(rsa, sa_off[i], kt * (int)p.ldsa, 0);   // 32 consecutive rows = one 128-byte line
+#pragma unroll
+    for (int j = 0; j < 2; ++j) sb[j] = __builtin_amdgcn_raw_buffer_load_b32(rsb, sb_off[j], kt * (int)p.ldsw, 0);
+  };
+
+  const int nk = p.K / MXBK;
+  uint32_t t = li;
+  if (t >= t_end) return;
+  int64_t m0; int n0;
+  set_tile(t, m0, n0);
+  uint32_t sa_n[4], sb_n[2];                                      // scales of the NEXT stage to be multiplied (loaded one stage ahead)
+  load_scales(sa_n, sb_n, 0);
+  stage(0, 0);
+  float* slab = reinterpret_cast<float*>(smem + 2 * MX_STAGE + wave * MX_SLAB_BYTES);
+  const int ecol = (lane & 15) * 4;
+  const uint32_t esz = OUT_BF16 ? 2u : 4u;
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, (short)0, (int)(uint32_t)(p.M * p.ldc * esz), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), (short)0, HAS_RES ? (int)(uint32_t)(p.M * p.ldr * 4) : 0, 0x00020000);
+  const uint32_t cstep = (uint32_t)(4 * p.ldc) * esz, rstep = (uint32_t)(4 * p.ldr) * 4u;
+
+  for (;;) {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // One 128-deep stage.  REFILL is a compile-time flag: the stage loop proper (kt < nk - 1) always refills the other slot and loads the next
+    // stage's scales, the last stage is peeled - with a run-time `if` around the LDS-DMA statements hipcc splits the body into basic blocks
+    // and sinks the MFMAs of the first 64-deep step below the fragment reads of the second (96 fragment registers live, ~60 spills in the loop).
+    auto kstep = [&](int kt, auto refill_tag) {
+      constexpr bool REFILL = decltype(refill_tag)::value;
+      mx_wait_vmcnt0_barrier();                                    // stage kt (and its scale dwords) landed; slot (kt+1)&1 is free
+      uint32_t sa_c[4], sb_c[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sa_c[i] = sa_n[i];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) sb_c[j] = sb_n[j];
+      if (REFILL) load_scales(sa_n, sb_n, kt + 1);                 // ahead of the refill in this wave's memory queue
+      const char* sa = smem + (kt & 1) * MX_STAGE + a_base;
+      const char* sb = smem + (kt & 1) * MX_STAGE + b_base;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        mx_i32x8 b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const mx_i32x4 lo = *reinterpret_cast<const mx_i32x4*>(sb + j * 32 * 128 + frag_off[kk][0]);
+          const mx_i32x4 hi4 = *reinterpret_cast<const mx_i32x4*>(sb + j * 32 * 128 + frag_off[kk][1]);
+          b[j] = mx_i32x8{lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        }
+        const int sh = (kk * 2 + hi) * 8;                          // this lane's MX block within the stage's four
+        int sbv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) sbv[j] = (int)((sb_c[j] >> sh) & 0xffu);
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {                           // A fragments two at a time
+          mx_i32x8 a[2];
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const int i = ih * 2 + ii;
+            const mx_i32x4 lo = *reinterpret_cast<const mx_i32x4*>(sa + i * 32 * 128 + frag_off[kk][0]);
+            const mx_i32x4 hi4 = *reinterpret_cast<const mx_i32x4*>(sa + i * 32 * 128 + frag_off[kk][1]);
+            a[ii] = mx_i32x8{lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+          }
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const int i = ih * 2 + ii;
+            const int sav = (int)((sa_c[i] >> sh) & 0xffu);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[ii], b[j], acc[i][j], 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, sav, 0, sbv[j]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (REFILL) {                                              // the refill's 8 LDS-DMA issues ride behind the two MFMA clusters
+          const uint32_t l = lds_wave + ((kt + 1) & 1) * MX_STAGE;
+          const int ko = (kt + 1) * MXBK;
+          if (kk == 0) mx_dma4(a_src[0] + ko, a_src[1] + ko, a_src[2] + ko, a_src[3] + ko, p.A, l);
+          else mx_dma4(b_src[0] + ko, b_src[1] + ko, b_src[2] + ko, b_src[3] + ko, p.W, l + MXBM * MXBK);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{});
+    kstep(nk - 1, std::false_type{});
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int64_t em0 = m0; const int en0 = n0;
+    const uint32_t tnext = t + per_xcd_blocks;
+    const bool more = tnext < t_end;
+    if (more) {
+      set_tile(tnext, m0, n0);
+      load_scales(sa_n, sb_n, 0);
+      stage(0, 0);
+    }
+
+    if (en0 + wn * 64 < p.N) {
+      const int gcol = en0 + wn * 64 + ecol;
+      const int64_t row0 = em0 + wm * 128 + (lane >> 4);
+      const uint32_t coff0 = (uint32_t)(row0 * p.ldc + gcol) * esz, roff0 = (uint32_t)(row0 * p.ldr + gcol) * 4u;
+      float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + gcol);
+      float4 res[2][4];
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) res[0][ps] = res[1][ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (HAS_RES) mx_load_res(res[0], rr, roff0, rstep);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int i = g >> 1, q2 = g & 1;
+        if (HAS_RES && g + 1 < 8) mx_load_res(res[(g + 1) & 1], rr, roff0 + (g + 1) * 4 * rstep, rstep);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              slab[(qq * 8 + hi * 4 + r) * MX_EPI_LD + j * 32 + l31] = acc[i][j][(q2 * 2 + qq) * 4 + r];
+        float4 v[4];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) v[ps] = *reinterpret_cast<const float4*>(slab + (ps * 4 + (lane >> 4)) * MX_EPI_LD + ecol);
+        mx_epi_store<OUT_BF16, GELU, HAS_RES>(v, bias4, res[g & 1], rc, coff0 + g * 4 * cstep, cstep);
+      }
+    }
+    if (!more) break;
+    t = tnext;
+  }
+}
+
+template <bool OUT_BF16, bool GELU, bool HAS_RES>
+static int mx_launch(MxArgs a, hipStream_t s) {
+  auto kern = gemm_mxfp8_persistent_kernel<OUT_BF16, GELU, HAS_RES>;
+  static bool attr_set = false;
+  static int n_cu = 0;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS);
+    if (e != hipSuccess) { sf_set_error("sf_gemm_mxfp8: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { sf_set_error("sf_gemm_mxfp8: device query failed"); return -1; }
+    n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const int64_t tiles_m = (a.M + MXBM - 1) / MXBM;
+  a.tiles_n = (uint32_t)((a.N + MXBN - 1) / MXBN);
+  const int64_t total = tiles_m * a.tiles_n;
+  if (total >= ((int64_t)1 << 31)) { sf_set_error("sf_gemm_mxfp8: too many tiles"); return -1; }
+  a.tiles_total = (uint32_t)total;
+  // column-chunked sweeps as in the bf16 kernel: keep the weight slice of a sweep (nchunk * 256 rows * K bytes) within ~2.4 MB of the XCD's L2
+  a.nchunk = a.K <= 2048 ? (uint32_t)(2400000 / (256 * a.K) > 0 ? 2400000 / (256 * a.K) : 1) : 0u;
+  int64_t blocks = (n_cu / 8) * 8;
+  const int64_t need = ((total + 7) / 8) * 8;
+  if (blocks > need) blocks = need;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), MX_LDS, s, a);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sf_gemm_mxfp8(const uint8_t* A, int64_t lda, const uint8_t* sA, int64_t ldsa, const uint8_t* W, int64_t ldw, const uint8_t* sW,
+                             int64_t ldsw, const float* bias, void* C, int c_dtype, int64_t ldc, const float* R, int64_t ldr, int epilogue, int64_t M,
+                             int64_t N, int64_t K, void* stream) {
+  SF_CHECK_ARG(A && sA && W && sW && C, "sf_gemm_mxfp8: null pointer");
+  SF_CHECK_ARG(c_dtype == SF_BF16 || c_dtype == SF_F32, "sf_gemm_mxfp8: c_dtype must be bf16 or f32");
+  SF_CHECK_ARG(epilogue == SF_EPI_NONE || epilogue == SF_EPI_GELU, "sf_gemm_mxfp8: bad epilogue %d", epilogue);
+  SF_CHECK_ARG(K > 0 && (K % MXBK) == 0, "sf_gemm_mxfp8: K=%lld must be a positive multiple of 128", (long long)K);
+  SF_CHECK_ARG((lda % 16) == 0 && (ldw % 16) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0,
+               "sf_gemm_mxfp8: A / W rows must be 16-byte aligned");
+  SF_CHECK_ARG((ldsa % 4) == 0 && (ldsw % 4) == 0 && ldsa >= M * 4 && ldsw >= N * 4 && ((uintptr_t)sA % 4) == 0 && ((uintptr_t)sW % 4) == 0,
+               "sf_gemm_mxfp8: scale planes must hold 4 bytes per row (plane stride >= rows * 4, 4-byte aligned)");
+  SF_CHECK_ARG((N % 64) == 0 && (ldc % 4) == 0 && (!R || (ldr % 4) == 0) && ((uintptr_t)C % 16) == 0 && (!R || ((uintptr_t)R % 16) == 0) &&
+                   (!bias || ((uintptr_t)bias % 16) == 0),
+               "sf_gemm_mxfp8: N %% 64 == 0 and 16-byte aligned outputs are required");
+  if (M <= 0 || N <= 0) return 0;
+  const int64_t m_pad = ((M + 255) / 256) * 256;
+  SF_CHECK_ARG(m_pad * ldc * (c_dtype == SF_BF16 ? 2 : 4) < ((int64_t)1 << 32) && (!R || m_pad * ldr * 4 < ((int64_t)1 << 32)),
+               "sf_gemm_mxfp8: C / R must stay below 4 GiB");
+  SF_CHECK_ARG(M * lda < ((int64_t)1 << 32) && N * ldw < ((int64_t)1 << 32) && (K / MXBK) * ldsa < ((int64_t)1 << 31) && (K / MXBK) * ldsw < ((int64_t)1 << 31),
+               "sf_gemm_mxfp8: operands and scale matrices must stay below 4 GiB (32-bit lane offsets)");
+  MxArgs a;
+  a.A = A; a.lda = lda; a.sA = sA; a.ldsa = ldsa; a.W = W; a.ldw = ldw; a.sW = sW; a.ldsw = ldsw; a.bias = bias; a.C = C; a.ldc = ldc;
+  a.R = R; a.ldr = ldr; a.M = M; a.N = (int)N; a.K = (int)K; a.tiles_n = a.tiles_total = a.nchunk = 0;
+  hipStream_t s = (hipStream_t)stream;
+  const bool gelu = epilogue == SF_EPI_GELU, res = R != nullptr, obf = c_dtype == SF_BF16;
+  if (obf) {
+    if (gelu) return res ? mx_launch<true, true, true>(a, s) : mx_launch<true, true, false>(a, s);
+    return res ? mx_launch<true, false, true>(a, s) : mx_launch<true, false, false>(a, s);
+  }
+  if (gelu) return res ? mx_launch<false, true, true>(a, s) : mx_launch<false, true, false>(a, s);
+  return res ? mx_launch<false, false, true>(a, s) : mx_launch<false, false, false>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// Quantiser: bf16 (rows x K, K % 128 == 0) -> OCP e4m3 elements + one E8M0 scale byte per 32 consecutive k (OCP Microscaling MXFP8):
+//   e = floor(log2(max |x| over the block)) - 8   (8 = exponent of the largest e4m3 normal, 448 = 1.75 * 2^8),  scale byte = e + 127,
+//   q = round-to-nearest-even( x * 2^-e ) saturated to +-448 (v_cvt_pk_fp8_f32, OCP on gfx950).  An all-zero block gets scale 2^-126.
+// Scales are written STAGE-major for the GEMM: scales[(k / 128) * lds + row * 4 + (k / 32) % 4].  One lane per block (64 B in, 32 B out); the
+// four lanes of a 128-deep stage combine their bytes and store one dword.
+// ------------------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void quantize_mxfp8_kernel(const bf16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q, int64_t ldq,
+                                                              uint8_t* __restrict__ sc, int64_t lds, int64_t rows, int kblocks) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < rows * kblocks;
+  if (!live) i = rows * kblocks - 1;                               // keep the quad complete for the shuffle below
+  const int64_t r = i / kblocks;
+  const int kb = (int)(i - r * kblocks);
+  const uint4* src = reinterpret_cast<const uint4*>(x + r * ldx + kb * 32);
+  float v[32];
+  float amax = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const uint4 t = src[c];
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[c * 8 + e * 2] = __uint_as_float(w[e] << 16);
+      v[c * 8 + e * 2 + 1] = __uint_as_float(w[e] & 0xffff0000u);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 32; ++e) amax = fmaxf(amax, fabsf(v[e]));
+  int be = (int)((__float_as_uint(amax) >> 23) & 0xff) - 8;      // biased exponent of amax, minus emax(e4m3); subnormal / zero amax -> clamp
+  if (be < 1) be = 1;
+  if (be > 254) be = 254;
+  const float inv = __uint_as_float((uint32_t)(254 - be) << 23);  // 2^-(be - 127)
+  uint32_t out[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    // the block maximum lands in [256, 512): saturate to the largest e4m3 normal first (the conversion itself would produce NaN above 448)
+    const float f0 = __builtin_amdgcn_fmed3f(v[e * 4] * inv, 448.f, -448.f), f1 = __builtin_amdgcn_fmed3f(v[e * 4 + 1] * inv, 448.f, -448.f);
+    const float f2 = __builtin_amdgcn_fmed3f(v[e * 4 + 2] * inv, 448.f, -448.f), f3 = __builtin_amdgcn_fmed3f(v[e * 4 + 3] * inv, 448.f, -448.f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(f0, f1, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(f2, f3, w, true);
+    out[e] = (uint32_t)w;
+  }
+  if (live) {
+    uint4* dst = reinterpret_cast<uint4*>(q + r * ldq + kb * 32);
+    dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+  }
+  // kblocks % 4 == 0 and the block index is the fastest thread dimension: lanes 4j .. 4j+3 hold the four blocks of one (row, stage)
+  uint32_t word = (uint32_t)be << ((kb & 3) * 8);
+  word |= __shfl_xor(word, 1, 64);
+  word |= __shfl_xor(word, 2, 64);
+  if (live && (kb & 3) == 0) *reinterpret_cast<uint32_t*>(sc + (int64_t)(kb >> 2) * lds + r * 4) = word;
+}
+
+extern "C" int sf_quantize_mxfp8(const bf16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scales, int64_t lds, int64_t rows, int64_t K,
+                                 void* stream) {
+  SF_CHECK_ARG(x && q && scales, "sf_quantize_mxfp8: null pointer");
+  SF_CHECK_ARG(K > 0 && (K % 128) == 0 && (ldx % 8) == 0 && (ldq % 16) == 0 && (lds % 4) == 0 && lds >= rows * 4 && ((uintptr_t)x % 16) == 0 &&
+                   ((uintptr_t)q % 16) == 0 && ((uintptr_t)scales % 4) == 0,
+               "sf_quantize_mxfp8: K %% 128 == 0, 16-byte aligned rows and scale planes of >= rows * 4 bytes are required");
+  if (rows <= 0) return 0;
+  const int64_t n = rows * (K / 32);
+  hipLaunchKernelGGL(quantize_mxfp8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, q, ldq, scales, lds, rows,
+                     (int)(K / 32));
+  SF_LAUNCH_CHECK();
+  return 0;
+}

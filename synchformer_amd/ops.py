@@ -65,6 +65,34 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     return out
 
 
+def quantize_mxfp8(x: torch.Tensor, q: torch.Tensor, scales: torch.Tensor, rows: Optional[int] = None):
+    """bf16 x (rows, K) -> q uint8 (rows, K) OCP e4m3 bytes + scales uint8 (K / 128, >= rows, 4): E8M0, one per 32 consecutive k, stage-major
+    (scales[k // 128, r, (k // 32) % 4])."""
+    assert x.dtype == torch.bfloat16 and q.dtype == torch.uint8 and scales.dtype == torch.uint8
+    rows = x.shape[0] if rows is None else rows
+    K = x.shape[1]
+    assert q.shape[1] == K and scales.dim() == 3 and scales.shape[0] == K // 128 and scales.shape[1] >= rows and scales.shape[2] == 4 and scales.is_contiguous()
+    rc = _lib.load().sf_quantize_mxfp8(_dev(x, 'x'), _ld(x), _dev(q, 'q'), _ld(q), _dev(scales, 'scales'), scales.stride(0), rows, K, _stream())
+    _lib.check(rc, 'sf_quantize_mxfp8')
+    return q, scales
+
+
+def gemm_mxfp8(a_q: torch.Tensor, a_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *,
+               M: Optional[int] = None, residual: Optional[torch.Tensor] = None, gelu: bool = False):
+    """out[m] = act(dq(a)[m] @ dq(w).T + bias) (+ residual[m]) on MXFP8 operands (see quantize_mxfp8)."""
+    assert a_q.dtype == torch.uint8 and w_q.dtype == torch.uint8 and a_s.dtype == torch.uint8 and w_s.dtype == torch.uint8
+    M = a_q.shape[0] if M is None else M
+    N, K = w_q.shape
+    assert a_q.shape[1] == K
+    assert a_s.dim() == 3 and w_s.dim() == 3 and a_s.shape[0] == K // 128 and w_s.shape[0] == K // 128 and a_s.is_contiguous() and w_s.is_contiguous()
+    rc = _lib.load().sf_gemm_mxfp8(_dev(a_q, 'a_q'), _ld(a_q), _dev(a_s, 'a_s'), a_s.stride(0), _dev(w_q, 'w_q'), _ld(w_q), _dev(w_s, 'w_s'), w_s.stride(0),
+                                   _dev(bias, 'bias') if bias is not None else None, _dev(out, 'out'), _DT[out.dtype], _ld(out),
+                                   _dev(residual, 'residual') if residual is not None else None, _ld(residual) if residual is not None else 0,
+                                   EPI_GELU if gelu else EPI_NONE, M, N, K, _stream())
+    _lib.check(rc, 'sf_gemm_mxfp8')
+    return out
+
+
 def gemm_res_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
                 y: torch.Tensor, eps: float, *, M: Optional[int] = None, residual: Optional[torch.Tensor] = None):
     """x[m] = a[m] @ w.T + bias + residual[m] (fp32, in place when residual is None or x), y[m] = LayerNorm(x[m]) * gamma + beta (bf16).

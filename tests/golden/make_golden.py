@@ -135,6 +135,45 @@ def train_grads(B=2):
     print('train loss', float(loss), 'total grad norm', float(np.sqrt((np.array(norms) ** 2).sum())))
 
 
+def train_grads_ft(B=2, S=13):
+    """Synchronizability fine-tune step (configs/ft_synchability.yaml: frozen extractors, GlobalTransformerWithSyncabilityHead over 13 segments =
+    184 tokens, 2-way sync_head on token 0, sync_model.py:176-190) through the REAL reference: features of both extractors, logits, CE loss and
+    the gradients of vproj / aproj / the transformer, eval mode (dropout off), fp32."""
+    model = ref_import.build_reference_synchformer(
+        n_segments_tokens=184, transformer_target='model.sync_model.GlobalTransformerWithSyncabilityHead')
+    sd = synth.make_state_dict(SEED, n_pos=184, n_out=2, head='sync_head')
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    vis = rgb_frontend_ref(synth.make_video_u8(B, S, SEED)).float()
+    aud = synth.make_spectrogram(B, S, SEED)
+    tgt = torch.tensor([1, 0][:B], dtype=torch.int64)
+    with torch.no_grad():
+        vf = model.extract_vfeats(vis, for_loop=False)
+        af = model.extract_afeats(aud, for_loop=False)
+    train = [(n, p_) for n, p_ in model.named_parameters() if n.startswith(('vproj.', 'aproj.', 'transformer.'))]
+    for p_ in model.parameters():
+        p_.requires_grad_(False)
+    for _, p_ in train:
+        p_.requires_grad_(True)
+    v, a = model.vproj(vf), model.aproj(af)
+    logits = model.transformer(v.view(B, -1, 768), a.view(B, -1, 768))
+    loss = model.compute_loss(logits, tgt)
+    loss.backward()
+    out = dict(seed=np.int64(SEED), B=np.int64(B), S=np.int64(S), loss=loss.detach().numpy(), logits=logits.detach().numpy(), targets=tgt.numpy(),
+               vfeat=vf.numpy(), afeat=af.numpy())
+    keep = ('transformer.sync_head.bias', 'transformer.sync_head.weight', 'transformer.ln_f.weight', 'transformer.OFF_tok', 'transformer.MOD_tok',
+            'vproj.bias', 'aproj.bias', 'transformer.blocks.0.attn.query.bias', 'transformer.blocks.2.mlp.2.bias', 'transformer.vis_in_lnorm.weight')
+    names, norms = [], []
+    for n, p_ in train:
+        names.append(n); norms.append(float(p_.grad.norm()))
+        if n in keep:
+            out['grad__' + n.replace('.', '__')] = p_.grad.numpy()
+    out['names'] = np.array(names); out['grad_norms'] = np.array(norms, dtype=np.float64)
+    out['grad__transformer__pos_emb__rows0_4'] = dict(train)['transformer.pos_emb_cfg.pos_emb'].grad[0, :4].numpy()
+    np.savez_compressed(HERE / f'train_ft_B{B}_grads.npz', **out)
+    print('ft train: logits', logits.detach(), 'loss', float(loss), 'total grad norm', float(np.sqrt((np.array(norms) ** 2).sum())), 'n tensors', len(names))
+
+
 def _real_avclip(gain, gather_for_loss=False):
     """The REAL AVCLIP (train_clip_src/open_clip/model.py:449-585) built from configs/segment_avclip.yaml's model section (interpolations
     resolved, ckpt_path null) with the synthetic weights loaded into its two towers."""
@@ -379,7 +418,7 @@ def e2e_masked(B=1, S=2, gain=2.0):
 
 if __name__ == '__main__':
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['sync', 'sync_gain2', 'syncability', 'train', 'avclip', 'shift_preds', 'segments', 'avclip_grads', 'masked']
+    which = sys.argv[1:] or ['sync', 'sync_gain2', 'syncability', 'train', 'train_ft', 'avclip', 'shift_preds', 'segments', 'avclip_grads', 'masked']
     if 'sync' in which:
         e2e_sync(2)
     if 'sync_gain2' in which:
@@ -388,6 +427,8 @@ if __name__ == '__main__':
         e2e_syncability(1)
     if 'train' in which:
         train_grads(2)
+    if 'train_ft' in which:
+        train_grads_ft(2)
     if 'avclip' in which:
         avclip(2, 3)
     if 'shift_preds' in which:

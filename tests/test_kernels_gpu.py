@@ -312,3 +312,75 @@ def test_gemm_res_ln_in_place_operand(gpu):
     x1, buf = r.clone(), a.clone()
     ops.gemm_res_ln(buf, w, b, x1, gam, bet, buf, 1e-6)
     assert torch.equal(x0, x1) and torch.equal(y0, buf)
+
+
+def _mx_dequant(q, s):
+    """OCP MXFP8 -> fp32: e4m3 bytes times 2^(scale - 127), one scale per 32 consecutive k."""
+    x = q.view(torch.float8_e4m3fn).float()
+    rows = q.shape[0]
+    sc = s[:, :rows].permute(1, 0, 2).reshape(rows, -1)                                 # stage-major (K/128, rows, 4) -> (rows, K/32)
+    return x * torch.exp2(sc.float() - 127.0).repeat_interleave(32, dim=1)
+
+
+def _mx_quant_ref(x):
+    """OCP Microscaling MXFP8 quantisation of a bf16 matrix, restated in torch: per 32-block scale 2^(floor(log2 amax) - 8), elements rounded to
+    nearest-even e4m3 after saturation to +-448."""
+    xf = x.float()
+    R, K = xf.shape
+    blk = xf.view(R, K // 32, 32)
+    amax = blk.abs().amax(-1)
+    e = torch.floor(torch.log2(torch.clamp(amax, min=2.0 ** -126))) - 8
+    byte = torch.clamp(e + 127, 1, 254)
+    q = torch.clamp(blk * torch.exp2(127 - byte).unsqueeze(-1), -448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.view(R, K).view(torch.uint8), byte.to(torch.uint8)
+
+
+@pytest.mark.parametrize('rows,K', [(5, 768), (300, 3072), (1000, 128)])
+def test_quantize_mxfp8(gpu, rows, K):
+    """sf_quantize_mxfp8 against the torch restatement of the OCP MX rule: scale bytes and element bytes are integers - exact."""
+    from synchformer_amd import ops
+    x = _bf(_rand(rows, K, seed=rows) * torch.exp(_rand(rows, 1, seed=K) * 2))      # rows of very different magnitude
+    x[0, :32] = 0.0                                                                    # an all-zero block
+    q = torch.empty(rows, K, device=gpu, dtype=torch.uint8)
+    s = torch.full((K // 128, rows + 2, 4), 255, device=gpu, dtype=torch.uint8)
+    ops.quantize_mxfp8(x.to(gpu), q, s)
+    q_ref, s_ref = _mx_quant_ref(x)
+    s_rows = s.cpu()[:, :rows].permute(1, 0, 2).reshape(rows, -1)
+    assert torch.equal(s_rows[1:], s_ref[1:]) and torch.equal(q.cpu(), q_ref) and (s.cpu()[:, rows:] == 255).all()
+    # elements within a factor 16 of their block maximum: one e4m3 rounding (2^-4 relative), or up to 2^-3 where the block maximum saturates at 448
+    err = (_mx_dequant(q.cpu(), s.cpu()) - x.float()).abs() / x.float().abs().clamp(min=1e-20)
+    assert err[x.float().abs() > x.float().abs().view(rows, -1, 32).amax(-1).repeat_interleave(32, 1) / 16].max() < 2.0 ** -3 + 1e-3
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 256, 128), (300, 768, 768), (9000, 2304, 768), (4100, 768, 3072), (70000, 3072, 768)])
+def test_gemm_mxfp8(gpu, M, N, K):
+    """sf_gemm_mxfp8 against an fp32 matmul of the DEQUANTISED operands (the kernel's exact contract: products of e4m3 values, scaled by the two
+    block scales, accumulated in fp32), with operands whose block scales differ widely along K and across rows so that a wrong scale byte, a
+    swapped k half or a transposed fragment cannot hide.  Then bias + exact-erf GELU (bf16 out) and bias + fp32 residual epilogues."""
+    from synchformer_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = _bf(torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-6, 6, (M, K // 32), generator=g).float()).repeat_interleave(32, 1))
+    w = _bf(torch.randn(N, K, generator=g) * 0.05 * torch.exp2(torch.randint(-4, 4, (N, K // 32), generator=g).float()).repeat_interleave(32, 1))
+    b = _rand(N, seed=3)
+    aq, asc = torch.empty(M, K, device=gpu, dtype=torch.uint8), torch.empty(K // 128, M, 4, device=gpu, dtype=torch.uint8)
+    wq, wsc = torch.empty(N, K, device=gpu, dtype=torch.uint8), torch.empty(K // 128, N, 4, device=gpu, dtype=torch.uint8)
+    ops.quantize_mxfp8(a.to(gpu), aq, asc)
+    ops.quantize_mxfp8(w.to(gpu), wq, wsc)
+    ref = (_mx_dequant(aq, asc).double() @ _mx_dequant(wq, wsc).double().t()).float().cpu() + b
+    out = torch.full((M + 3, N), 7.0, device=gpu)
+    ops.gemm_mxfp8(aq, asc, wq, wsc, b.to(gpu), out, M=M)
+    scale = ref.abs().max().item()
+    assert (out[:M].cpu() - ref).abs().max().item() < 1e-4 * scale, ((out[:M].cpu() - ref).abs().max().item(), scale)   # fp32 accumulation inside the MFMA: measured 3e-5
+    assert (out[M:] == 7.0).all(), 'rows beyond M were written'
+    # quantisation error against the un-quantised bf16 product: the property the FT path relies on (two e4m3 roundings per product, relative
+    # Frobenius error ~ 2^-4.5 = 4.3 % measured on Gaussian operands)
+    exact = a.float() @ w.float().t() + b
+    rel = ((out[:M].cpu() - exact).norm() / exact.norm()).item()
+    assert rel < 6e-2, rel
+    r = _rand(M, N, seed=5)
+    res = r.to(gpu).clone()
+    ops.gemm_mxfp8(aq, asc, wq, wsc, b.to(gpu), res, residual=res)
+    assert (res.cpu() - (ref + r)).abs().max().item() < 1e-4 * scale + 1e-5
+    hb = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+    ops.gemm_mxfp8(aq, asc, wq, wsc, b.to(gpu), hb, gelu=True)
+    torch.testing.assert_close(hb.float().cpu(), torch.nn.functional.gelu(ref), rtol=1e-2, atol=1e-2 * max(1.0, scale / 8))

@@ -259,6 +259,58 @@ def test_gradients_match_oracle_and_reference(gpu):
     assert not bad, bad
 
 
+def test_ft_syncability_train_step_matches_reference(gpu):
+    """The synchronizability fine-tune step (configs/ft_synchability.yaml: frozen extractors, GlobalTransformerWithSyncabilityHead over 13 segments
+    = 184 tokens, 2-way sync_head on token 0; sync_model.py:176-190) against the REAL reference (tests/golden/train_ft_B2_grads.npz,
+    make_golden.py train_ft): (a) the trainable part fed the reference's own features - logits, loss, all 63 gradient norms and the stored
+    gradients; (b) end to end from the uint8 frames / spectrograms through the HIP extractors, via the drop-in module and a train step."""
+    import synchformer_amd as sa
+    from synchformer_amd import synth
+    from synchformer_amd.train import SyncTrainer
+    g = np.load(GOLD / 'train_ft_B2_grads.npz')
+    B, S = int(g['B']), int(g['S'])
+    sd = synth.make_state_dict(1337, n_pos=184, n_out=2, head='sync_head')
+    tr = SyncTrainer(sd, gpu)
+    assert tr.head_name == 'sync_head' and tr.n_out == 2
+    vf, af, tgt = torch.from_numpy(g['vfeat']).to(gpu), torch.from_numpy(g['afeat']).to(gpu), torch.from_numpy(g['targets']).to(gpu)
+    loss = tr.forward_backward(vf, af, tgt).item()
+    assert abs(loss - float(g['loss'])) < 5e-3 and (tr.logits.cpu() - torch.from_numpy(g['logits'])).abs().max() < 1e-2
+    names = [str(n) for n in g['names']]
+    assert names == tr.keys
+    worst = max(max(0.0, abs(tr.g[n].norm().item() - ref) - 1e-4) / max(ref, 1e-9) for n, ref in zip(names, g['grad_norms']))
+    print('FT step: loss', loss, 'ref', float(g['loss']), '| worst relative grad-norm deviation', worst)
+    assert worst < 3e-2
+    for key in g.files:
+        if key.startswith('grad__') and 'rows0_4' not in key:
+            n = key[len('grad__'):].replace('__', '.')
+            got, ref = tr.g[n].cpu(), torch.from_numpy(g[key])
+            assert _rel(got, ref) < 3e-2 and torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item() > 0.999, n
+    assert _rel(tr.g['transformer.pos_emb_cfg.pos_emb'][0, :4].cpu(), torch.from_numpy(g['grad__transformer__pos_emb__rows0_4'])) < 3e-2
+    # (b) the drop-in module built from the FT yaml's model section: uint8 frames in, HIP extractors, autograd bridge
+    cfg = sa.sync_yaml_model_config(n_pos=184, transformer_target='model.sync_model.GlobalTransformerWithSyncabilityHead')
+    for k in ('embd_pdrop', 'resid_pdrop', 'attn_pdrop'):
+        cfg['params']['transformer']['params'][k] = 0.0
+    model = sa.instantiate_from_config(cfg)
+    assert not any(k.startswith('transformer.off_head') for k in model.state_dict()) and model.transformer.sync_head.out_features == 2
+    model.load_state_dict(sd, strict=True)
+    model = model.to(gpu)
+    for p in list(model.vfeat_extractor.parameters()) + list(model.afeat_extractor.parameters()):
+        p.requires_grad = False
+    model.train(); model.vfeat_extractor.eval(); model.afeat_extractor.eval()
+    u8, aud = synth.make_video_u8(B, S, 1337).to(gpu), synth.make_spectrogram(B, S, 1337).to(gpu)
+    l2, logits = model(u8, aud, tgt)
+    l2.backward()
+    assert abs(l2.item() - float(g['loss'])) < 1e-2 and (logits.detach().cpu() - torch.from_numpy(g['logits'])).abs().max() < 1.5e-2
+    norms = dict(zip(names, g['grad_norms']))
+    for n, p in model.named_parameters():
+        if p.requires_grad and norms[n] > 1e-3:
+            assert abs(p.grad.norm().item() - norms[n]) / norms[n] < 5e-2, n
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=2e-4, eps=1e-7)
+    opt.step()
+    l3, _ = model(u8, aud, tgt)
+    assert l3.item() < l2.item()
+
+
 def test_train_steps_reduce_loss_and_match_torch_adam(gpu):
     """Three full steps (frozen extractors on real inputs, 1 clip): loss goes down with an aggressive lr, parameters move exactly as
     torch Adam + clip would move them given the SAME gradients."""

@@ -1,0 +1,48 @@
+"""MXFP8 GEMM micro-benchmark on the model's shapes against the bf16 kernel (run on the GPU box): python tools/bench_gemm_mx.py [n_segments ...]"""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+from synchformer_amd import ops
+
+dev = torch.device('cuda:0')
+
+
+def timeit(fn, iters=6):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def main():
+    for n in [int(a) for a in sys.argv[1:]] or [208]:
+        M = n * 1569
+        print(f'--- n_seg {n}  M {M}')
+        for name, N, K, out_dt, gelu, res in [('qkv', 2304, 768, torch.bfloat16, False, False), ('proj+res', 768, 768, torch.float32, False, True),
+                                              ('fc1+gelu', 3072, 768, torch.bfloat16, True, False), ('fc2+res', 768, 3072, torch.float32, False, True)]:
+            a = torch.randn(M, K, device=dev).bfloat16()
+            w = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
+            b = torch.randn(N, device=dev)
+            out = torch.zeros(M, N, device=dev, dtype=out_dt)
+            aq, asc = torch.empty(M, K, device=dev, dtype=torch.uint8), torch.empty(K // 128, M, 4, device=dev, dtype=torch.uint8)
+            wq, wsc = torch.empty(N, K, device=dev, dtype=torch.uint8), torch.empty(K // 128, N, 4, device=dev, dtype=torch.uint8)
+            ops.quantize_mxfp8(w, wq, wsc)
+            t = {'bf16': [], 'quant': [], 'mx': []}
+            for _ in range(5):
+                t['bf16'].append(timeit(lambda: ops.gemm(a, w, b, out, gelu=gelu, residual=out if res else None)))
+                t['quant'].append(timeit(lambda: ops.quantize_mxfp8(a, aq, asc)))
+                t['mx'].append(timeit(lambda: ops.gemm_mxfp8(aq, asc, wq, wsc, b, out, gelu=gelu, residual=out if res else None)))
+            med = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
+            fl = 2.0 * M * N * K
+            print(f"{name:9s} N {N:4d} K {K:4d}: bf16 {med['bf16']:7.1f} us ({fl / med['bf16'] / 1e6:5.0f} TF) | mxfp8 {med['mx']:7.1f} us ({fl / med['mx'] / 1e6:5.0f} TF)"
+                  f" + quantise A {med['quant']:6.1f} us", flush=True)
+
+
+if __name__ == '__main__':
+    main()
