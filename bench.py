@@ -45,9 +45,10 @@ def parse():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL over xGMI; default) | gloo (plumbing tests)')
     ap.add_argument('--single-device', action='store_true', help='TEST ONLY: put every rank on cuda:0 (needs --dist-backend gloo)')
-    ap.add_argument('--workload', choices=['infer', 'train', 'stage1'], default='infer',
+    ap.add_argument('--workload', choices=['infer', 'train', 'stage1', 'ft'], default='infer',
                     help="infer = BASELINE configs[1] (headline metric); train = configs[2]: Stage-2 step, frozen extractors, "
-                         "backward + RCCL gradient all-reduce + fused clip/Adam (dropout 0.1 as in sync.yaml)")
+                         "backward + RCCL gradient all-reduce + fused clip/Adam (dropout 0.1 as in sync.yaml); ft = configs[4]: the "
+                         "synchronizability fine-tune step (13 segments, 2-way sync head) with the frozen extractors' Linears on MXFP8")
     ap.add_argument('--graph', action='store_true', help='replay the forward as one captured HIP graph (infer workload only)')
     ap.add_argument('--dropin', action='store_true', help="train workload through the drop-in nn.Module + torch.optim.Adam + GradScaler "
                     "(the reference's loop body, train_utils.py:373-386) instead of SyncTrainer's fused step: the wrapper overhead as a number")
@@ -91,14 +92,35 @@ class GemmTimer:
             nbytes = m * k * 2 + n * k * 2 + m * n * (4 + 4 + 2)                       # A + W + R read, X + Y written, each once
             self.records.append((e0, e1, 2.0 * m * n * k, nbytes))
             return r
+        def timed_mx(a_q, a_s, w_q, w_s, bias, out, *, M=None, residual=None, gelu=False, out_scales=None):
+            # the MXFP8 launches are recorded apart: their roofline is the MX-fp8 matrix peak, not the bf16 one
+            if not self.enabled:
+                return self.orig_mx(a_q, a_s, w_q, w_s, bias, out, M=M, residual=residual, gelu=gelu, out_scales=out_scales)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self.orig_mx(a_q, a_s, w_q, w_s, bias, out, M=M, residual=residual, gelu=gelu, out_scales=out_scales)
+            e1.record()
+            m = a_q.shape[0] if M is None else M
+            n, k = w_q.shape
+            nbytes = m * k + n * k + (m + n) * k // 32 + m * n * out.element_size() + (m * n * 4 if residual is not None else 0)
+            self.mx_records.append((e0, e1, 2.0 * m * n * k, nbytes))
+            return r
+        self.mx_records = []
         self.ops.gemm = timed
         self.orig_ln = self.ops.gemm_res_ln
         self.ops.gemm_res_ln = timed_ln
+        self.orig_mx = self.ops.gemm_mxfp8
+        self.ops.gemm_mxfp8 = timed_mx
         return self
 
     def __exit__(self, *a):
         self.ops.gemm = self.orig
         self.ops.gemm_res_ln = self.orig_ln
+        self.ops.gemm_mxfp8 = self.orig_mx
+
+    def mx_summary(self):
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.mx_records)
+        return len(self.mx_records), ms, sum(r[2] for r in self.mx_records), sum(r[3] for r in self.mx_records)
 
     def summary(self):
         ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
@@ -209,6 +231,15 @@ def main():
             scaler.update()
             return loss.detach().reshape(1)
         eng = model._engine(need_sync=False)
+    elif args.workload == 'ft':
+        # BASELINE configs[4]: configs/ft_synchability.yaml - frozen extractors, GlobalTransformerWithSyncabilityHead over 13 segments (184 tokens),
+        # 2-way head, batch 16 per GPU; the extractors' qkv / proj / fc1 / fc2 run on MXFP8 operands (v_mfma_scale_f32_32x32x64_f8f6f4)
+        from synchformer_amd.train import SyncTrainer
+        trainer = SyncTrainer(synth.make_state_dict(1337, n_pos=184, n_out=2, head='sync_head'), dev, lr=2e-6 * world, seg_chunk=args.seg_chunk,
+                              embd_pdrop=0.1, resid_pdrop=0.1, attn_pdrop=0.1, seed=1337 + rank, fp8_towers=True)
+        eng = trainer.engine
+        targets = synth.make_targets(B, 2, seed=1337 + rank).to(dev)
+        step_fn = lambda v, a: trainer.train_step(v, a, targets)
     elif args.workload == 'train':
         from synchformer_amd.train import SyncTrainer
         trainer = SyncTrainer(synth.make_state_dict(1337), dev, lr=2e-6 * world, seg_chunk=args.seg_chunk, embd_pdrop=0.1, resid_pdrop=0.1,
@@ -225,8 +256,9 @@ def main():
     else:
         eng = SynchformerEngine(synth.make_state_dict(1337), dev, seg_chunk=args.seg_chunk)
         step_fn = eng.forward
-    vis = synth.make_video_u8(B, 14, seed=1337 + rank).to(dev)            # (B,14,16,3,224,224) uint8, HBM-resident
-    aud = synth.make_spectrogram(B, 14, seed=1337 + rank).to(dev)         # (B,14,1,128,66) fp32
+    S = 13 if args.workload == 'ft' else 14                                # ft_synchability.yaml: 13 segments (184-token sync transformer)
+    vis = synth.make_video_u8(B, S, seed=1337 + rank).to(dev)             # (B,S,16,3,224,224) uint8, HBM-resident
+    aud = synth.make_spectrogram(B, S, seed=1337 + rank).to(dev)          # (B,S,1,128,66) fp32
 
     def barrier():
         if world > 1:
@@ -239,7 +271,7 @@ def main():
     for _ in range(args.warmup):
         logits = step_fn(vis, aud)
     comm_ms = []
-    timed_trainer = trainer if args.workload in ('train', 'stage1') and not args.dropin else None
+    timed_trainer = trainer if args.workload in ('train', 'stage1', 'ft') and not args.dropin else None
     if timed_trainer is not None and world > 1:
         timed_trainer.time_comm = True
     # ---- the timed region: EXACTLY K steps of the product configuration, no instrumentation -------------------------------------
@@ -263,9 +295,11 @@ def main():
     # behind the other tower's kernels, so for THIS pass the two towers are serialised on one stream (same kernels, same shapes, same
     # launch count; `value` above is not affected).  rocprofv3 --kernel-trace of this command sees both passes (profiles/).
     n_gemm, gemm_ms, gemm_flop, dt_roof = 0, 0.0, 0.0, 0.0
+    n_mx, mx_ms, mx_flop, mx_bytes = 0, 0.0, 0.0, 0
     if not args.no_kernel_timing and not args.graph:
         serial = {'infer': lambda on: setattr(eng, 'audio_side_stream', on),
                   'train': lambda on: setattr(eng, 'audio_side_stream', on),
+                  'ft': lambda on: setattr(eng, 'audio_side_stream', on),
                   'stage1': lambda on: setattr(trainer, 'two_streams', on)}[args.workload]
         serial(False)
         with GemmTimer() as gt:
@@ -278,6 +312,7 @@ def main():
             dt_roof = time.perf_counter() - t1
             if gt.enabled:
                 n_gemm, gemm_ms, gemm_flop = gt.summary()
+                n_mx, mx_ms, mx_flop, mx_bytes = gt.mx_summary()
         serial(True)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -288,25 +323,31 @@ def main():
     if rank == 0:
         out = {
             'metric': {'infer': 'clips/sec (14-seg offset pred)', 'train': 'clips/sec (Stage-2 train step, 14 segments)',
-                       'stage1': 'clips/sec (Stage-1 AVCLIP train step, 14 segments)'}[args.workload],
+                       'stage1': 'clips/sec (Stage-1 AVCLIP train step, 14 segments)',
+                       'ft': 'clips/sec (synchronizability fine-tune step, 13 segments, MXFP8 extractor GEMMs)'}[args.workload],
             'value': round(value, 3), 'unit': 'clips/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'mxfp8 (extractor Linears) + bf16' if args.workload == 'ft' else 'bf16',
+            'data': 'synthetic',
             'config': {'workload': ('BASELINE configs[1]: batched offset inference, configs/sync.yaml model (237.5M params, '
                                     'random-init), uint8 224x224 frames + 128x66 log-mel resident in HBM, full forward to 21-way logits')
                        if args.workload == 'infer' else
                        ('Stage-1 segment-level contrastive train step (configs/segment_avclip.yaml): forward with saved activations + backward of '
                         'both towers (214.8M params), symmetric InfoNCE over B*14 segments, flat gradient all-reduce, fused clip+AdamW')
                        if args.workload == 'stage1' else
+                       ('BASELINE configs[4]: synchronizability fine-tune step (configs/ft_synchability.yaml): frozen extractors with their qkv / proj / fc1 / '
+                        'fc2 Linears on MXFP8 (OCP e4m3 + E8M0 per 32 k), 184-token sync transformer with the 2-way sync head trained in bf16 (22.6M params), '
+                        'RCCL gradient all-reduce, fused clip+Adam')
+                       if args.workload == 'ft' else
                        ('BASELINE configs[2]: Stage-2 sync-module train step (configs/sync.yaml, embd/resid/attn dropout 0.1): frozen extractors forward, '
                         'backward of proj + sync transformer (22.6M params), flat 90 MB RCCL gradient all-reduce, fused clip+Adam'),
-                       'clips_per_gpu': B, 'segments': 14, 'seg_chunk': args.seg_chunk, 'hip_graph': bool(args.graph),
+                       'clips_per_gpu': B, 'segments': S, 'seg_chunk': args.seg_chunk, 'hip_graph': bool(args.graph),
                        'parallelism': f'replicas x{world}' if args.workload == 'infer' else f'dp{world}'},
             # stage1: forward + dgrad + wgrad of every linear ~ 3x the forward FLOPs (attention backward ~2.5x; approximate)
-            'path_flop_per_clip': FLOP_PER_CLIP * (3 if args.workload == 'stage1' else 1),
-            'path_mfma_frac': round(value * FLOP_PER_CLIP * (3 if args.workload == 'stage1' else 1) / (world * PEAK_BF16), 4),
+            'path_flop_per_clip': FLOP_PER_CLIP * (3 if args.workload == 'stage1' else 1) * S / 14,
+            'path_mfma_frac': round(value * FLOP_PER_CLIP * (3 if args.workload == 'stage1' else 1) * S / 14 / (world * PEAK_BF16), 4),
             # the same with the FLOPs the engine executes (aggregators computed for their one consumed output row only)
-            'path_mfma_frac_executed': round(value * FLOP_PER_CLIP_EXECUTED * (3 if args.workload == 'stage1' else 1) / (world * PEAK_BF16), 4),
+            'path_mfma_frac_executed': round(value * FLOP_PER_CLIP_EXECUTED * (3 if args.workload == 'stage1' else 1) * S / 14 / (world * PEAK_BF16), 4),
         }
         if args.dropin:
             out['config']['dropin'] = 'nn.Module + autocast + GradScaler + clip_grad_norm_ + torch.optim.Adam' + (' + DistributedDataParallel' if world > 1 else '')
@@ -325,6 +366,16 @@ def main():
                                'share_of_step_time': round(gemm_ms * 1e-3 / dt_roof, 3),
                                'measured': f'HIP events on the launch stream over a second pass of the same {args.steps} steps with the two towers '
                                            f'serialised on one stream ({1e3 * dt_roof / args.steps:.1f} ms/step); value is the un-instrumented two-stream pass'}
+        if n_mx:
+            ach = mx_flop / (mx_ms * 1e-3) / 1e12
+            # FT: the dominant kernel is the MXFP8 GEMM; its roofline is the dense MX-fp8 matrix peak (MI355X_MICROARCH.md: ~5 PFLOP/s)
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'sf_gemm_mxfp8 (gemm_mxfp8_persistent_kernel, v_mfma_scale_f32_32x32x64_f8f6f4)',
+                               'achieved': round(ach, 1), 'peak': 5000.0, 'unit': 'TFLOP/s', 'frac': round(ach / 5000.0, 4), 'traffic': None,
+                               'algorithmic_bytes_per_launch': round(mx_bytes / n_mx), 'launches': n_mx // args.steps,
+                               'avg_launch_ms': round(mx_ms / n_mx, 4), 'flop_per_launch': mx_flop / n_mx,
+                               'share_of_step_time': round(mx_ms * 1e-3 / dt_roof, 3),
+                               'bf16_gemm_launches': {'launches': n_gemm // args.steps, 'tflops': round(gemm_flop / max(gemm_ms, 1e-9) / 1e9, 1)},
+                               'measured': f'HIP events on the launch stream over a second pass of the same {args.steps} steps, towers serialised on one stream'}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -82,8 +82,13 @@ int sf_quantize_mxfp8(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, u
  * Replaces the nn.Linear calls at vit_helper.py:103,155,392-396 (qkv / proj / fc1 / fc2 of the DividedSpaceTimeBlocks) when the engine is built
  * with fp8 towers. */
 int sf_gemm_mxfp8(const uint8_t* A, int64_t lda, const uint8_t* sA, int64_t ldsa, const uint8_t* W, int64_t ldw, const uint8_t* sW, int64_t ldsw,
-                  const float* bias, void* C, int c_dtype, int64_t ldc, const float* R, int64_t ldr, int epilogue, int64_t M, int64_t N, int64_t K,
-                  void* stream);
+                  const float* bias, void* C, int c_dtype, int64_t ldc, uint8_t* sC, int64_t ldsc, const float* R, int64_t ldr, int epilogue, int64_t M,
+                  int64_t N, int64_t K, void* stream);
+/* c_dtype SF_U8: the output itself leaves as MXFP8 (C = e4m3 bytes, sC / ldsc = its stage-major scale planes) - the fc1 + GELU hidden activations feeding
+ * fc2 - quantised from the bf16-rounded value exactly as sf_quantize_mxfp8 would; N % 128 == 0, no residual. */
+/* LayerNorm(768) whose output leaves as MXFP8 (the A operand of the qkv / fc1 MX GEMMs): sf_layernorm768 followed by sf_quantize_mxfp8, in one pass. */
+int sf_layernorm768_mxfp8(const float* x, int64_t ldx, const float* gamma, const float* beta, uint8_t* q, int64_t ldq, uint8_t* scales, int64_t lds,
+                          int64_t rows, float eps, void* stream);
 
 /* Tuning / test hook (process-global, not for production threads): force the GEMM tile configuration of subsequent sf_gemm_bf16
  * calls.  -1 = automatic choice by shape (default); 0 = 128x128x64, 4 waves, two workgroups per CU; 7 = persistent 256x256x64,

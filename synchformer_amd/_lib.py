@@ -25,7 +25,8 @@ SIGNATURES = {
     'sf_gemm_tn_splitk': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _i32, _i64, _ptr],
     'sf_gemm_res_ln768': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _f32, _ptr, _i64, _i64, _i64, _ptr],
     'sf_quantize_mxfp8': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr],
-    'sf_gemm_mxfp8': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i64, _ptr, _i64, _i32, _i64, _i64, _i64, _ptr],
+    'sf_gemm_mxfp8': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i64, _ptr, _i64, _ptr, _i64, _i32, _i64, _i64, _i64, _ptr],
+    'sf_layernorm768_mxfp8': [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _f32, _ptr],
     'sf_gemm_force_config': [_i32],
     'sf_layernorm768': [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i64, _ptr, _i32, _i64, _f32, _ptr],
     'sf_broadcast_rows768': [_ptr, _i64, _i64, _ptr, _i64, _i64, _ptr],

@@ -38,6 +38,7 @@ struct MxArgs {
   const uint8_t* W; int64_t ldw; const uint8_t* sW; int64_t ldsw;
   const float* bias;
   void* C; int64_t ldc;
+  uint8_t* sC; int64_t ldsc;                                     // OUT_FP8: stage-major scale planes of the (quantised) output
   const float* R; int64_t ldr;
   int64_t M;
   int N, K;
@@ -69,8 +70,12 @@ __device__ __forceinline__ void mx_wait_vmcnt0_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <bool OUT_BF16, bool GELU, bool HAS_RES>
-__device__ __forceinline__ void mx_epi_store(float4 (&v)[4], const float4& bias4, const float4 (&res)[4], __amdgpu_buffer_rsrc_t rc, uint32_t coff, uint32_t cstep) {
+// OUT: 0 = fp32, 1 = bf16, 2 = MXFP8 (the output is the next MX GEMM's A operand: e4m3 bytes + one E8M0 byte per 32 columns, quantised from the bf16-
+// rounded value exactly as sf_quantize_mxfp8 would from a bf16 buffer; a 32-column block = 8 consecutive lanes of the 16-lane row group).
+template <int OUT, bool GELU, bool HAS_RES>
+__device__ __forceinline__ void mx_epi_store(float4 (&v)[4], const float4& bias4, const float4 (&res)[4], __amdgpu_buffer_rsrc_t rc, uint32_t coff, uint32_t cstep,
+                                             uint8_t* sc_ptr = nullptr, int64_t row = 0, int64_t M = 0, int lane = 0) {
+  constexpr bool OUT_BF16 = OUT == 1;
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
     float4 x = v[ps];
@@ -80,7 +85,19 @@ __device__ __forceinline__ void mx_epi_store(float4 (&v)[4], const float4& bias4
       x.x = g0.x; x.y = g0.y; x.z = g1.x; x.w = g1.y;
     }
     if (HAS_RES) { x.x += res[ps].x; x.y += res[ps].y; x.z += res[ps].z; x.w += res[ps].w; }
-    if (OUT_BF16) {
+    if (OUT == 2) {
+      const uint32_t p01 = pack_bf2(x.x, x.y), p23 = pack_bf2(x.z, x.w);
+      const float f0 = __uint_as_float(p01 << 16), f1 = __uint_as_float(p01 & 0xffff0000u), f2 = __uint_as_float(p23 << 16), f3 = __uint_as_float(p23 & 0xffff0000u);
+      float amax = fmaxf(fmaxf(fabsf(f0), fabsf(f1)), fmaxf(fabsf(f2), fabsf(f3)));
+      amax = fmaxf(amax, __shfl_xor(amax, 1, 64)); amax = fmaxf(amax, __shfl_xor(amax, 2, 64)); amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+      int be = (int)((__float_as_uint(amax) >> 23) & 0xff) - 8;
+      be = be < 1 ? 1 : (be > 254 ? 254 : be);
+      const float inv = __uint_as_float((uint32_t)(254 - be) << 23);
+      int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f0 * inv, 448.f, -448.f), __builtin_amdgcn_fmed3f(f1 * inv, 448.f, -448.f), 0, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f2 * inv, 448.f, -448.f), __builtin_amdgcn_fmed3f(f3 * inv, 448.f, -448.f), w, true);
+      __builtin_amdgcn_raw_buffer_store_b32((uint32_t)w, rc, coff + ps * cstep, 0, SF_MX_STORE_AUX);
+      if ((lane & 7) == 0 && row + ps * 4 < M) sc_ptr[(row + ps * 4) * 4] = (uint8_t)be;      // sc_ptr already points at this lane's (plane, byte-in-dword)
+    } else if (OUT_BF16) {
       mx_u32x2 o; o.x = pack_bf2(x.x, x.y); o.y = pack_bf2(x.z, x.w);
       __builtin_amdgcn_raw_buffer_store_b64(o, rc, coff + ps * cstep, 0, SF_MX_STORE_AUX);
     } else {
@@ -98,8 +115,9 @@ __device__ __forceinline__ void mx_load_res(float4 (&res)[4], __amdgpu_buffer_rs
   }
 }
 
-template <bool OUT_BF16, bool GELU, bool HAS_RES>
+template <int OUT, bool GELU, bool HAS_RES>
 __global__ __launch_bounds__(512, 2) void gemm_mxfp8_persistent_kernel(MxArgs p) {
+  constexpr bool OUT_BF16 = OUT == 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
@@ -177,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_persistent_kernel(MxArgs p)
   stage(0, 0);
   float* slab = reinterpret_cast<float*>(smem + 2 * MX_STAGE + wave * MX_SLAB_BYTES);
   const int ecol = (lane & 15) * 4;
-  const uint32_t esz = OUT_BF16 ? 2u : 4u;
+  const uint32_t esz = OUT == 2 ? 1u : (OUT_BF16 ? 2u : 4u);
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, (short)0, (int)(uint32_t)(p.M * p.ldc * esz), 0x00020000);
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), (short)0, HAS_RES ? (int)(uint32_t)(p.M * p.ldr * 4) : 0, 0x00020000);
   const uint32_t cstep = (uint32_t)(4 * p.ldc) * esz, rstep = (uint32_t)(4 * p.ldr) * 4u;
@@ -285,7 +303,13 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_persistent_kernel(MxArgs p)
         float4 v[4];
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) v[ps] = *reinterpret_cast<const float4*>(slab + (ps * 4 + (lane >> 4)) * MX_EPI_LD + ecol);
-        mx_epi_store<OUT_BF16, GELU, HAS_RES>(v, bias4, res[g & 1], rc, coff0 + g * 4 * cstep, cstep);
+        if (OUT == 2) {
+          const int colblock = gcol >> 5;                          // this lane's 32-column block of the output row
+          mx_epi_store<OUT, GELU, HAS_RES>(v, bias4, res[g & 1], rc, coff0 + g * 4 * cstep, cstep, p.sC + (int64_t)(colblock >> 2) * p.ldsc + (colblock & 3),
+                                           row0 + g * 16, p.M, lane);
+        } else {
+          mx_epi_store<OUT, GELU, HAS_RES>(v, bias4, res[g & 1], rc, coff0 + g * 4 * cstep, cstep);
+        }
       }
     }
     if (!more) break;
@@ -293,9 +317,9 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_persistent_kernel(MxArgs p)
   }
 }
 
-template <bool OUT_BF16, bool GELU, bool HAS_RES>
+template <int OUT, bool GELU, bool HAS_RES>
 static int mx_launch(MxArgs a, hipStream_t s) {
-  auto kern = gemm_mxfp8_persistent_kernel<OUT_BF16, GELU, HAS_RES>;
+  auto kern = gemm_mxfp8_persistent_kernel<OUT, GELU, HAS_RES>;
   static bool attr_set = false;
   static int n_cu = 0;
   if (!attr_set) {
@@ -322,10 +346,12 @@ static int mx_launch(MxArgs a, hipStream_t s) {
 }
 
 extern "C" int sf_gemm_mxfp8(const uint8_t* A, int64_t lda, const uint8_t* sA, int64_t ldsa, const uint8_t* W, int64_t ldw, const uint8_t* sW,
-                             int64_t ldsw, const float* bias, void* C, int c_dtype, int64_t ldc, const float* R, int64_t ldr, int epilogue, int64_t M,
-                             int64_t N, int64_t K, void* stream) {
+                             int64_t ldsw, const float* bias, void* C, int c_dtype, int64_t ldc, uint8_t* sC, int64_t ldsc, const float* R, int64_t ldr,
+                             int epilogue, int64_t M, int64_t N, int64_t K, void* stream) {
   SF_CHECK_ARG(A && sA && W && sW && C, "sf_gemm_mxfp8: null pointer");
-  SF_CHECK_ARG(c_dtype == SF_BF16 || c_dtype == SF_F32, "sf_gemm_mxfp8: c_dtype must be bf16 or f32");
+  SF_CHECK_ARG(c_dtype == SF_BF16 || c_dtype == SF_F32 || c_dtype == SF_U8, "sf_gemm_mxfp8: c_dtype must be bf16, f32 or u8 (MXFP8 output)");
+  SF_CHECK_ARG(c_dtype != SF_U8 || (sC && !R && (N % 128) == 0 && (ldsc % 4) == 0 && ldsc >= M * 4),
+               "sf_gemm_mxfp8: MXFP8 output needs scale planes (>= M * 4 bytes each), N %% 128 == 0 and no residual");
   SF_CHECK_ARG(epilogue == SF_EPI_NONE || epilogue == SF_EPI_GELU, "sf_gemm_mxfp8: bad epilogue %d", epilogue);
   SF_CHECK_ARG(K > 0 && (K % MXBK) == 0, "sf_gemm_mxfp8: K=%lld must be a positive multiple of 128", (long long)K);
   SF_CHECK_ARG((lda % 16) == 0 && (ldw % 16) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0,
@@ -337,21 +363,22 @@ extern "C" int sf_gemm_mxfp8(const uint8_t* A, int64_t lda, const uint8_t* sA, i
                "sf_gemm_mxfp8: N %% 64 == 0 and 16-byte aligned outputs are required");
   if (M <= 0 || N <= 0) return 0;
   const int64_t m_pad = ((M + 255) / 256) * 256;
-  SF_CHECK_ARG(m_pad * ldc * (c_dtype == SF_BF16 ? 2 : 4) < ((int64_t)1 << 32) && (!R || m_pad * ldr * 4 < ((int64_t)1 << 32)),
+  SF_CHECK_ARG(m_pad * ldc * (c_dtype == SF_U8 ? 1 : c_dtype == SF_BF16 ? 2 : 4) < ((int64_t)1 << 32) && (!R || m_pad * ldr * 4 < ((int64_t)1 << 32)),
                "sf_gemm_mxfp8: C / R must stay below 4 GiB");
   SF_CHECK_ARG(M * lda < ((int64_t)1 << 32) && N * ldw < ((int64_t)1 << 32) && (K / MXBK) * ldsa < ((int64_t)1 << 31) && (K / MXBK) * ldsw < ((int64_t)1 << 31),
                "sf_gemm_mxfp8: operands and scale matrices must stay below 4 GiB (32-bit lane offsets)");
   MxArgs a;
   a.A = A; a.lda = lda; a.sA = sA; a.ldsa = ldsa; a.W = W; a.ldw = ldw; a.sW = sW; a.ldsw = ldsw; a.bias = bias; a.C = C; a.ldc = ldc;
-  a.R = R; a.ldr = ldr; a.M = M; a.N = (int)N; a.K = (int)K; a.tiles_n = a.tiles_total = a.nchunk = 0;
+  a.sC = sC; a.ldsc = ldsc; a.R = R; a.ldr = ldr; a.M = M; a.N = (int)N; a.K = (int)K; a.tiles_n = a.tiles_total = a.nchunk = 0;
   hipStream_t s = (hipStream_t)stream;
   const bool gelu = epilogue == SF_EPI_GELU, res = R != nullptr, obf = c_dtype == SF_BF16;
+  if (c_dtype == SF_U8) return gelu ? mx_launch<2, true, false>(a, s) : mx_launch<2, false, false>(a, s);
   if (obf) {
-    if (gelu) return res ? mx_launch<true, true, true>(a, s) : mx_launch<true, true, false>(a, s);
-    return res ? mx_launch<true, false, true>(a, s) : mx_launch<true, false, false>(a, s);
+    if (gelu) return res ? mx_launch<1, true, true>(a, s) : mx_launch<1, true, false>(a, s);
+    return res ? mx_launch<1, false, true>(a, s) : mx_launch<1, false, false>(a, s);
   }
-  if (gelu) return res ? mx_launch<false, true, true>(a, s) : mx_launch<false, true, false>(a, s);
-  return res ? mx_launch<false, false, true>(a, s) : mx_launch<false, false, false>(a, s);
+  if (gelu) return res ? mx_launch<0, true, true>(a, s) : mx_launch<0, true, false>(a, s);
+  return res ? mx_launch<0, false, true>(a, s) : mx_launch<0, false, false>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------------

@@ -80,6 +80,71 @@ extern "C" int sf_layernorm768(const float* x, int64_t ldx, const int64_t* in_ma
 }
 
 // ------------------------------------------------------------------------------------------------------
+// LayerNorm(768) whose output leaves as MXFP8 (OCP e4m3 + one E8M0 scale per 32 columns, stage-major scale planes - see sf_quantize_mxfp8): the
+// A operand of the next MX GEMM, written directly instead of bf16 + a separate quantisation pass (fp8 towers of the synchronizability fine-tune).
+// One wave per row; lane l holds columns i*256 + 4 l .. + 3 (i < 3): a 32-column block is 8 consecutive lanes of one i.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm768_mxfp8_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, uint8_t* __restrict__ q, int64_t ldq,
+                                                                  uint8_t* __restrict__ sc, int64_t lds, int64_t rows, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* xr = x + r * ldx;
+  float4 v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum(s) * (1.0f / D_MODEL);
+  float qq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+    qq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  const float rstd = rsqrtf(wave_sum(qq) * (1.0f / D_MODEL) + eps);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * 256 + lane * 4;
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 b = *reinterpret_cast<const float4*>(beta + c);
+    float4 o;
+    o.x = v[i].x * rstd * g.x + b.x; o.y = v[i].y * rstd * g.y + b.y;
+    o.z = v[i].z * rstd * g.z + b.z; o.w = v[i].w * rstd * g.w + b.w;
+    // the bf16 rounding the un-fused path applies before quantising is kept: the quantiser's input is the SAME value either way
+    const uint32_t p01 = pack_bf2(o.x, o.y), p23 = pack_bf2(o.z, o.w);
+    o.x = __uint_as_float(p01 << 16); o.y = __uint_as_float(p01 & 0xffff0000u); o.z = __uint_as_float(p23 << 16); o.w = __uint_as_float(p23 & 0xffff0000u);
+    float amax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64)); amax = fmaxf(amax, __shfl_xor(amax, 2, 64)); amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    int be = (int)((__float_as_uint(amax) >> 23) & 0xff) - 8;
+    be = be < 1 ? 1 : (be > 254 ? 254 : be);
+    const float inv = __uint_as_float((uint32_t)(254 - be) << 23);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(o.x * inv, 448.f, -448.f), __builtin_amdgcn_fmed3f(o.y * inv, 448.f, -448.f), 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(o.z * inv, 448.f, -448.f), __builtin_amdgcn_fmed3f(o.w * inv, 448.f, -448.f), w, true);
+    *reinterpret_cast<uint32_t*>(q + r * ldq + c) = (uint32_t)w;
+    // scale bytes: block (i*8 + lane/8); the four blocks of a 128-column stage (lanes 0-31 or 32-63 of chunk i) form one dword of plane i*2 + lane/32
+    uint32_t word = (uint32_t)be << (((lane >> 3) & 3) * 8);
+    word |= __shfl_xor(word, 8, 64);
+    word |= __shfl_xor(word, 16, 64);
+    if ((lane & 31) == 0) *reinterpret_cast<uint32_t*>(sc + (int64_t)(i * 2 + (lane >> 5)) * lds + r * 4) = word;
+  }
+}
+
+extern "C" int sf_layernorm768_mxfp8(const float* x, int64_t ldx, const float* gamma, const float* beta, uint8_t* q, int64_t ldq, uint8_t* scales,
+                                     int64_t lds, int64_t rows, float eps, void* stream) {
+  SF_CHECK_ARG(x && gamma && beta && q && scales, "sf_layernorm768_mxfp8: null pointer");
+  SF_CHECK_ARG((ldx % 4) == 0 && (ldq % 16) == 0 && (lds % 4) == 0 && lds >= rows * 4 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)scales % 4) == 0,
+               "sf_layernorm768_mxfp8: aligned rows and scale planes of >= rows * 4 bytes are required");
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(layernorm768_mxfp8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, q, ldq, scales, lds,
+                     rows, eps);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // dst[(seq * dst_seq_rows + l) * ld + :] = table[l, :]  for l < L, seq < n_seq   (fp32, cols = 768)
 // Lays the positional table (+ CLS / DISTILL / OFF / MOD token rows, folded in at weight-prep time) under
 // every sequence; the patch-embed GEMM / LayerNorm then accumulate onto it.  Replaces the cat/expand/add

@@ -42,6 +42,18 @@ class _Lin:
         self.b = b.detach().to(dev, torch.float32).contiguous() if b is not None else None
 
 
+class _LinQ:
+    """MXFP8 weight: e4m3 bytes (N, K) + stage-major E8M0 scale planes (K / 128, N, 4) + fp32 bias, quantised ON the device by sf_quantize_mxfp8."""
+    __slots__ = ('q', 's', 'b')
+
+    def __init__(self, lin: '_Lin'):
+        N, K = lin.w.shape
+        self.q = torch.empty(N, K, device=lin.w.device, dtype=torch.uint8)
+        self.s = torch.empty(K // 128, N, 4, device=lin.w.device, dtype=torch.uint8)
+        ops.quantize_mxfp8(lin.w, self.q, self.s)
+        self.b = lin.b
+
+
 class _LN:
     __slots__ = ('g', 'b')
 
@@ -51,11 +63,14 @@ class _LN:
 
 
 class SynchformerEngine:
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device='cuda:0', seg_chunk: int = 224):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device='cuda:0', seg_chunk: int = 224, fp8_towers: bool = False):
         self.dev = torch.device(device)
         if self.dev.type != 'cuda':
             raise RuntimeError('SynchformerEngine needs a HIP device; there is no CPU path in the product')
         self.seg_chunk = seg_chunk
+        # fp8_towers: the six big Linears of every visual block run on MXFP8 operands (sf_gemm_mxfp8) - the frozen-extractor mode of the
+        # synchronizability fine-tune (BASELINE configs[4]).  Off (bf16) for every other workload: inference parity bars are stated for bf16.
+        self.fp8_towers = bool(fp8_towers)
         self._ws = {}
         self.audio_side_stream = os.environ.get('SF_AUDIO_SIDE_STREAM', '1') != '0'
         self.fuse_ln = os.environ.get('SF_FUSE_LN', '1') != '0'            # A/B switches of the full-row GEMM + residual + LayerNorm kernel
@@ -91,6 +106,9 @@ class SynchformerEngine:
                 t_qkv=lin(b + '.timeattn.qkv'), t_proj=lin(b + '.timeattn.proj'),
                 s_qkv=lin(b + '.attn.qkv'), s_proj=lin(b + '.attn.proj'),
                 fc1=lin(b + '.mlp.fc1'), fc2=lin(b + '.mlp.fc2')))
+            if self.fp8_towers:
+                blk = self.v_blocks[-1]
+                blk['mx'] = {k: _LinQ(blk[k]) for k in ('t_qkv', 't_proj', 's_qkv', 's_proj', 'fc1', 'fc2')}
             i += 1
         self.v_norm = _LN(sd, f'{v}.norm', dev)
         self.v_agg = self._agg(sd, f'{v}.spatial_attn_agg')
@@ -265,6 +283,9 @@ class SynchformerEngine:
                 groups = 8
             ops.attention_cls_combine(part, xn, n_part=groups, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
 
+        if self.fp8_towers:
+            self._visual_blocks_mxfp8(X, xn, qkv, rows, divided)
+            return self._visual_tail(X, n, out, tok_keep)
         # DividedSpaceTimeBlock.forward (vit_helper.py:364-376).  With `fuse_ln` every residual GEMM also emits the LayerNorm that opens the next
         # sub-layer (sf_gemm_res_ln768: the fp32 stream is read and written once per sub-layer, no separate LayerNorm launch); the last block's
         # fc2 stays un-fused because the norm after it is the row-mapped final norm below.
@@ -296,6 +317,33 @@ class SynchformerEngine:
                 if fuse_ln and bi + 1 < nb:
                     nx = self.v_blocks[bi + 1]['norm3']
                     ops.layernorm(X, nx.g, nx.b, xn, EPS_VIS)
+        self._visual_tail(X, n, out, tok_keep)
+
+    def _visual_blocks_mxfp8(self, X, xn, qkv, rows, divided):
+        """The 12 DividedSpaceTimeBlocks with every big Linear on MXFP8 operands.  Activations are quantised where they are produced when the
+        producer is ours to change (LayerNorm -> sf_layernorm768_mxfp8, fc1 + GELU -> the GEMM's own MXFP8 epilogue); the attention kernels
+        write bf16, which one sf_quantize_mxfp8 pass converts.  The residual stream, LayerNorm statistics and attention stay as in the bf16 path."""
+        xq = self._buf('XQ', rows * D, torch.uint8).view(rows, D)
+        xs = self._buf('XS', 6 * rows * 4, torch.uint8).view(6, rows, 4)
+        hq = self._buf('HQ', rows * FF, torch.uint8).view(rows, FF)
+        hs = self._buf('HS', 24 * rows * 4, torch.uint8).view(24, rows, 4)
+        for b in self.v_blocks:
+            mx = b['mx']
+            ops.layernorm_mxfp8(X, b['norm3'].g, b['norm3'].b, xq, xs, EPS_VIS)
+            ops.gemm_mxfp8(xq, xs, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, qkv)
+            divided('time')
+            ops.quantize_mxfp8(xn, xq, xs)
+            ops.gemm_mxfp8(xq, xs, mx['t_proj'].q, mx['t_proj'].s, mx['t_proj'].b, X, residual=X)
+            ops.layernorm_mxfp8(X, b['norm1'].g, b['norm1'].b, xq, xs, EPS_VIS)
+            ops.gemm_mxfp8(xq, xs, mx['s_qkv'].q, mx['s_qkv'].s, mx['s_qkv'].b, qkv)
+            divided('space')
+            ops.quantize_mxfp8(xn, xq, xs)
+            ops.gemm_mxfp8(xq, xs, mx['s_proj'].q, mx['s_proj'].s, mx['s_proj'].b, X, residual=X)
+            ops.layernorm_mxfp8(X, b['norm2'].g, b['norm2'].b, xq, xs, EPS_VIS)
+            ops.gemm_mxfp8(xq, xs, mx['fc1'].q, mx['fc1'].s, mx['fc1'].b, hq, gelu=True, out_scales=hs)
+            ops.gemm_mxfp8(hq, hs, mx['fc2'].q, mx['fc2'].s, mx['fc2'].b, X, residual=X)
+
+    def _visual_tail(self, X, n, out, tok_keep):
         # drop CLS -> final norm -> per-frame sequences with the aggregator CLS in front (mf:231-232, 356-375)
         Z = self._buf('Z', n * 8 * AGG_V * D, torch.float32).view(n * 8 * AGG_V, D)
         ops.broadcast_rows(Z, self.v_agg['cls'], n_seq=n * 8, dst_seq_rows=AGG_V)

@@ -77,9 +77,22 @@ def quantize_mxfp8(x: torch.Tensor, q: torch.Tensor, scales: torch.Tensor, rows:
     return q, scales
 
 
+def layernorm_mxfp8(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, q: torch.Tensor, scales: torch.Tensor, eps: float, rows: Optional[int] = None):
+    """(q, scales) = quantize_mxfp8(bf16(LayerNorm(x))) in one pass: x fp32 (rows, 768) -> q uint8 (rows, 768), scales uint8 (6, >= rows, 4)."""
+    assert x.dtype == torch.float32 and x.shape[1] == 768 and q.dtype == torch.uint8 and q.shape[1] == 768
+    rows = x.shape[0] if rows is None else rows
+    assert scales.dtype == torch.uint8 and scales.dim() == 3 and scales.shape[0] == 6 and scales.shape[1] >= rows and scales.is_contiguous()
+    rc = _lib.load().sf_layernorm768_mxfp8(_dev(x, 'x'), _ld(x), _dev(gamma, 'gamma'), _dev(beta, 'beta'), _dev(q, 'q'), _ld(q), _dev(scales, 'scales'),
+                                           scales.stride(0), rows, float(eps), _stream())
+    _lib.check(rc, 'sf_layernorm768_mxfp8')
+    return q, scales
+
+
 def gemm_mxfp8(a_q: torch.Tensor, a_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *,
-               M: Optional[int] = None, residual: Optional[torch.Tensor] = None, gelu: bool = False):
-    """out[m] = act(dq(a)[m] @ dq(w).T + bias) (+ residual[m]) on MXFP8 operands (see quantize_mxfp8)."""
+               M: Optional[int] = None, residual: Optional[torch.Tensor] = None, gelu: bool = False, out_scales: Optional[torch.Tensor] = None):
+    """out[m] = act(dq(a)[m] @ dq(w).T + bias) (+ residual[m]) on MXFP8 operands (see quantize_mxfp8).  With a uint8 `out` and `out_scales`
+    (N / 128, >= M, 4) the result itself leaves as MXFP8."""
+    assert (out.dtype == torch.uint8) == (out_scales is not None)
     assert a_q.dtype == torch.uint8 and w_q.dtype == torch.uint8 and a_s.dtype == torch.uint8 and w_s.dtype == torch.uint8
     M = a_q.shape[0] if M is None else M
     N, K = w_q.shape
@@ -87,6 +100,7 @@ def gemm_mxfp8(a_q: torch.Tensor, a_s: torch.Tensor, w_q: torch.Tensor, w_s: tor
     assert a_s.dim() == 3 and w_s.dim() == 3 and a_s.shape[0] == K // 128 and w_s.shape[0] == K // 128 and a_s.is_contiguous() and w_s.is_contiguous()
     rc = _lib.load().sf_gemm_mxfp8(_dev(a_q, 'a_q'), _ld(a_q), _dev(a_s, 'a_s'), a_s.stride(0), _dev(w_q, 'w_q'), _ld(w_q), _dev(w_s, 'w_s'), w_s.stride(0),
                                    _dev(bias, 'bias') if bias is not None else None, _dev(out, 'out'), _DT[out.dtype], _ld(out),
+                                   _dev(out_scales, 'out_scales') if out_scales is not None else None, out_scales.stride(0) if out_scales is not None else 0,
                                    _dev(residual, 'residual') if residual is not None else None, _ld(residual) if residual is not None else 0,
                                    EPI_GELU if gelu else EPI_NONE, M, N, K, _stream())
     _lib.check(rc, 'sf_gemm_mxfp8')

@@ -309,10 +309,11 @@ class FlatTrainer:
 class SyncTrainer(FlatTrainer):
     def __init__(self, state_dict: Dict[str, torch.Tensor], device='cuda:0', lr: float = 2e-6, betas=(0.9, 0.999), eps: float = 1e-7,
                  max_clip_norm: float = 1.0, embd_pdrop: float = 0.0, resid_pdrop: float = 0.0, attn_pdrop: float = 0.0, seed: int = 1337,
-                 seg_chunk: int = 224, engine: Optional[SynchformerEngine] = None):
+                 seg_chunk: int = 224, engine: Optional[SynchformerEngine] = None, fp8_towers: bool = False):
         self.embd_pdrop, self.resid_pdrop, self.attn_pdrop, self.seed = float(embd_pdrop or 0), float(resid_pdrop or 0), float(attn_pdrop or 0), seed
         self.fwd_count = 0
-        self.engine = engine if engine is not None else SynchformerEngine(state_dict, torch.device(device), seg_chunk=seg_chunk)   # frozen extractors
+        self.engine = engine if engine is not None else SynchformerEngine(state_dict, torch.device(device), seg_chunk=seg_chunk,
+                                                                          fp8_towers=fp8_towers)   # frozen extractors (MXFP8 GEMMs in the FT configuration)
         self._init_flat(state_dict, trainable_keys(state_dict), device, lr, betas, eps, max_clip_norm)
         self.n_blocks = len([k for k in self.keys if k.endswith('.ln1.weight')])
         self.heads = 8

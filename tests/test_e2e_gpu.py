@@ -67,6 +67,27 @@ def test_golden_syncability(gpu):
     assert dl < 1.5e-2, dl
 
 
+def test_mxfp8_towers_bound(gpu):
+    """BASELINE configs[4]: the synchronizability model (13 segments, 184 tokens, 2-way sync head) with the frozen extractors' Linears on MXFP8
+    operands (engine fp8_towers=True) against the bf16 engine on the same inputs and against the REAL reference's golden logits.  Stated bound of
+    the fp8 path at this (reference-like, gain 1) initialisation: segment features within 12 % relative RMS of the bf16 ones (measured 7.7 %: two
+    e4m3 roundings per product, 72 quantised GEMMs deep), logits within 3e-2 of the bf16 logits (measured 1e-2) and within 4e-2 of the fp32 reference."""
+    from synchformer_amd import synth
+    from synchformer_amd.engine import SynchformerEngine
+    g = np.load(GOLD / 'e2e_syncability_B1.npz')
+    sd = synth.make_state_dict(1337, n_pos=184, n_out=2, head='sync_head')
+    e16, e8 = SynchformerEngine(sd, gpu), SynchformerEngine(sd, gpu, fp8_towers=True)
+    u8, aud = synth.make_video_u8(1, 13, 1337).to(gpu), synth.make_spectrogram(1, 13, 1337).to(gpu)
+    v16, v8 = e16.extract_vfeats(u8), e8.extract_vfeats(u8)
+    l16, l8 = e16.forward(u8, aud).cpu(), e8.forward(u8, aud).cpu()
+    rel = _rel_rms(v8.cpu(), v16.cpu())
+    d16, dref = (l8 - l16).abs().max().item(), (l8 - torch.from_numpy(g['logits'])).abs().max().item()
+    print(f'mxfp8 towers: vfeat rel-RMS vs bf16 {rel:.4f} | logits max |d| vs bf16 {d16:.4f}, vs fp32 reference {dref:.4f}')
+    assert 1e-3 < rel < 0.12, rel                   # > 1e-3: the fp8 kernels really ran
+    assert d16 < 3e-2 and dref < 4e-2, (d16, dref)
+    assert (l8.argmax(-1) == torch.from_numpy(g['logits']).argmax(-1)).all()
+
+
 def test_oracle_small(gpu):
     """2 segments through both extractors + the sync transformer on random features, vs the CPU oracle."""
     from oracle import synchformer_cpu as O

@@ -384,3 +384,34 @@ def test_gemm_mxfp8(gpu, M, N, K):
     hb = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
     ops.gemm_mxfp8(aq, asc, wq, wsc, b.to(gpu), hb, gelu=True)
     torch.testing.assert_close(hb.float().cpu(), torch.nn.functional.gelu(ref), rtol=1e-2, atol=1e-2 * max(1.0, scale / 8))
+
+
+def test_layernorm_mxfp8_and_fp8_epilogue(gpu):
+    """sf_layernorm768_mxfp8 == sf_layernorm768 (bf16) followed by sf_quantize_mxfp8, byte for byte; and the MX GEMM's MXFP8-output epilogue
+    (fc1 + GELU -> the operand of fc2) == its bf16-output epilogue followed by sf_quantize_mxfp8."""
+    from synchformer_amd import ops
+    rows = 1000
+    x = (_rand(rows, 768, seed=1) * 2 + 0.3).to(gpu)
+    gam, bet = (1 + 0.1 * _rand(768, seed=2)).to(gpu), (0.1 * _rand(768, seed=3)).to(gpu)
+    yb = torch.empty(rows, 768, device=gpu, dtype=torch.bfloat16)
+    ops.layernorm(x, gam, bet, yb, 1e-6)
+    q0, s0 = torch.empty(rows, 768, device=gpu, dtype=torch.uint8), torch.zeros(6, rows, 4, device=gpu, dtype=torch.uint8)
+    ops.quantize_mxfp8(yb, q0, s0)
+    q1, s1 = torch.empty_like(q0), torch.zeros_like(s0)
+    ops.layernorm_mxfp8(x, gam, bet, q1, s1, 1e-6)
+    assert torch.equal(q0, q1) and torch.equal(s0, s1)
+    M, N, K = 2600, 3072, 768
+    w = _bf(_rand(N, K, seed=4, scale=0.05)).to(gpu)
+    wq, ws = torch.empty(N, K, device=gpu, dtype=torch.uint8), torch.empty(K // 128, N, 4, device=gpu, dtype=torch.uint8)
+    ops.quantize_mxfp8(w, wq, ws)
+    a = _bf(_rand(M, K, seed=5)).to(gpu)
+    aq, asc = torch.empty(M, K, device=gpu, dtype=torch.uint8), torch.empty(K // 128, M, 4, device=gpu, dtype=torch.uint8)
+    ops.quantize_mxfp8(a, aq, asc)
+    b = _rand(N, seed=6).to(gpu)
+    hb = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+    ops.gemm_mxfp8(aq, asc, wq, ws, b, hb, gelu=True)
+    h0, hs0 = torch.empty(M, N, device=gpu, dtype=torch.uint8), torch.zeros(N // 128, M, 4, device=gpu, dtype=torch.uint8)
+    ops.quantize_mxfp8(hb, h0, hs0)
+    h1, hs1 = torch.full((M + 2, N), 9, device=gpu, dtype=torch.uint8), torch.zeros(N // 128, M + 2, 4, device=gpu, dtype=torch.uint8)
+    ops.gemm_mxfp8(aq, asc, wq, ws, b, h1, gelu=True, out_scales=hs1, M=M)
+    assert torch.equal(h0, h1[:M]) and torch.equal(hs0, hs1[:, :M]) and (h1[M:] == 9).all() and (hs1[:, M:] == 0).all()
