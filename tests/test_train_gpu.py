@@ -305,7 +305,7 @@ def test_ft_syncability_train_step_matches_reference(gpu):
     for n, p in model.named_parameters():
         if p.requires_grad and norms[n] > 1e-3:
             assert abs(p.grad.norm().item() - norms[n]) / norms[n] < 5e-2, n
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=2e-4, eps=1e-7)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-5, eps=1e-7)   # Adam's first step moves every weight by lr
     opt.step()
     l3, _ = model(u8, aud, tgt)
     assert l3.item() < l2.item()
