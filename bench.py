@@ -131,13 +131,15 @@ class GemmTimer:
 
 def pmc_traffic():
     """HBM bytes per sf_gemm_bf16 launch from the committed PMC passes of this same command (tools/profile_bench.sh ->
-    profiles/r01_bench_roofline.json; counters cannot be read from inside the benchmark process).  None if absent."""
-    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_bench_roofline.json')
-    try:
-        with open(f) as fh:
-            return round(json.load(fh)['traffic_bytes_per_launch'])
-    except (OSError, KeyError, ValueError):
-        return None
+    profiles/r02_bench_roofline.json; counters cannot be read from inside the benchmark process).  None if absent."""
+    for tag in ('r02', 'r01'):
+        f = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', f'{tag}_bench_roofline.json')
+        try:
+            with open(f) as fh:
+                return round(json.load(fh)['traffic_bytes_per_launch'])
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def cpu_baseline(seconds_budget=25.0, max_threads=16):
