@@ -88,7 +88,7 @@ class GemmTimer:
             r = self.orig_ln(a, w, bias, x, gamma, beta, y, eps, M=M, residual=residual)
             e1.record()
             m = a.shape[0] if M is None else M
-            n, k = w.shape
+            n, k = 768, a.shape[1]                                                     # w is (768, K) or k-step-major (K/32, 768, 32)
             nbytes = m * k * 2 + n * k * 2 + m * n * (4 + 4 + 2)                       # A + W + R read, X + Y written, each once
             self.records.append((e0, e1, 2.0 * m * n * k, nbytes))
             return r

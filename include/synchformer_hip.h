@@ -63,7 +63,8 @@ int sf_gemm_tn_splitk(const uint16_t* dY, int64_t ldy, const uint16_t* X, int64_
 
 /* Full-row projection fused with the residual add and the NEXT LayerNorm (N = 768 fixed):
  *   X[m,:] = A[m,:] W^T + bias + R[m,:]  (fp32; X may alias R),   Y[m,:] = LayerNorm(X[m,:]) * gamma + beta  (bf16; Y may alias A).
- * A: M x K bf16, W: 768 x K bf16, K % 32 == 0; R / X / Y below 4 GiB.  One workgroup owns 128 complete rows, so the fp32 residual
+ * A: M x K bf16, W: 768 x K bf16 (row stride ldw), or - ldw == 32 - the same weight re-laid out k-step-major as [K/32][768][32] so that the 48 KiB
+ * slice of every 32-deep k-step is contiguous (full cache lines); K % 32 == 0; R / X / Y below 4 GiB.  One workgroup owns 128 complete rows, so the fp32 residual
  * stream is read once and written once per sub-layer and the separate sf_layernorm768 launch disappears.  Replaces, inside
  * DividedSpaceTimeBlock.forward (vit_helper.py:364-376), `x + temporal_fc/proj(...)` -> norm1, `x + proj(attn(...))` -> norm2 and
  * `x + mlp.fc2(...)` -> the next block's norm3. */

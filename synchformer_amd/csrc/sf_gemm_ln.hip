@@ -43,6 +43,9 @@
 #ifndef SF_RL_SPREAD
 #define SF_RL_SPREAD 1        // 1: one LDS-DMA piece behind every third MFMA of the k-step; 0: all seven behind the first MFMA cluster
 #endif
+#ifndef SF_RL_A_NT
+#define SF_RL_A_NT 0         // experiment: the A rows (read by exactly one workgroup) with the nt hint
+#endif
 #ifndef SF_RL_KROT
 #define SF_RL_KROT 1          // workgroup i of an XCD starts its k-loop at k-step (i * SF_RL_KROT) % nk instead of 0 (see below); 0 = off
 #endif
@@ -56,6 +59,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int rl_u32x2;
 struct ResLnArgs {
   const bf16_t* A; int64_t lda;
   const bf16_t* W; int64_t ldw;
+  uint32_t wk;                                                    // bytes between consecutive 32-deep k-steps of a W row (64 row-major, 768 * 64 k-step-major)
   const float* bias;
   const float* R; int64_t ldr;
   float* X; int64_t ldx;
@@ -92,6 +96,12 @@ __device__ __forceinline__ void rl_dma7(uint32_t voff_a, const void* sa, uint32_
 __device__ __forceinline__ void rl_dma1(uint32_t voff, const void* sbase, uint32_t lds) {
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+
+__device__ __forceinline__ void rl_dma1_nt(uint32_t voff, const void* sbase, uint32_t lds) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
 
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
   auto kmap = [&](int kt) { int k = kt + krot; return k >= nk ? k - nk : k; };
   auto stage = [&](int slot, int kt_) {
     const int kt = kmap(kt_);
-    rl_dma7(voff_a0 + kt * (RL_BK * 2), sa, voff_b0 + kt * (RL_BK * 2), sb0, sb1, sb2, sb3, sb4, sb5, lds_a_w + slot * RL_STAGE,
+    rl_dma7(voff_a0 + kt * (RL_BK * 2), sa, voff_b0 + kt * p.wk, sb0, sb1, sb2, sb3, sb4, sb5, lds_a_w + slot * RL_STAGE,
             lds_b_w + slot * RL_STAGE);
   };
   set_tile(m0);
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
         if (SF_RL_SPREAD) {
           // the vector-memory path takes ~16 cycles per 1-KiB piece and the issuing wave is held while it queues: seven back-to-back issues by
           // all eight waves right after the barrier leave the matrix pipe idle, one piece every third MFMA does not
-          const uint32_t ko = kmap(kt + 1) * (RL_BK * 2), la = lds_a_w + ((kt + 1) & 1) * RL_STAGE, lb = lds_b_w + ((kt + 1) & 1) * RL_STAGE;
+          const uint32_t ko = kmap(kt + 1) * (RL_BK * 2), kow = kmap(kt + 1) * p.wk, la = lds_a_w + ((kt + 1) & 1) * RL_STAGE, lb = lds_b_w + ((kt + 1) & 1) * RL_STAGE;
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -233,8 +243,8 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
                 const int piece = SF_RL_SPREAD == 2 ? (ks == 1 ? 6 : i * 3 + (j >> 1)) : ks * 4 + i * 2 + (j == 4);   // 0 .. 6: A, W0 .. W5
                 __builtin_amdgcn_sched_barrier(0);
                 if (refill && !((ABL & 32) && (piece & 1) == 0 && piece > 0)) {
-                  if (piece == 0) rl_dma1(voff_a0 + ko, sa, la);
-                  else rl_dma1(voff_b0 + ko, piece == 1 ? sb0 : piece == 2 ? sb1 : piece == 3 ? sb2 : piece == 4 ? sb3 : piece == 5 ? sb4 : sb5,
+                  if (piece == 0) { if (SF_RL_A_NT) rl_dma1_nt(voff_a0 + ko, sa, la); else rl_dma1(voff_a0 + ko, sa, la); }
+                  else rl_dma1(voff_b0 + kow, piece == 1 ? sb0 : piece == 2 ? sb1 : piece == 3 ? sb2 : piece == 4 ? sb3 : piece == 5 ? sb4 : sb5,
                                lb + (piece - 1) * 1024);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -420,7 +430,8 @@ extern "C" int sf_gemm_res_ln768(const bf16_t* A, int64_t lda, const bf16_t* W, 
                                  int64_t K, void* stream) {
   SF_CHECK_ARG(A && W && R && X && gamma && beta && Y, "sf_gemm_res_ln768: null pointer");
   SF_CHECK_ARG(K > 0 && (K % RL_BK) == 0 && K < (1 << 20), "sf_gemm_res_ln768: K=%lld must be a positive multiple of 32", (long long)K);
-  SF_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0 && lda >= K && ldw >= K, "sf_gemm_res_ln768: lda/ldw must be >= K and multiples of 8 elements");
+  const bool w_kmajor = ldw == RL_BK && K > RL_BK;                 // W given k-step-major: [K / 32][768][32] (every stage's 48 KiB slice contiguous)
+  SF_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0 && lda >= K && (ldw >= K || w_kmajor), "sf_gemm_res_ln768: lda/ldw must be >= K and multiples of 8 elements");
   SF_CHECK_ARG((ldr % 4) == 0 && (ldx % 4) == 0 && (ldy % 4) == 0 && ldr >= RL_N && ldx >= RL_N && ldy >= RL_N,
                "sf_gemm_res_ln768: ldr/ldx/ldy must be >= 768 and multiples of 4 elements");
   SF_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)R % 16) == 0 && ((uintptr_t)X % 16) == 0 &&
@@ -448,6 +459,7 @@ extern "C" int sf_gemm_res_ln768(const bf16_t* A, int64_t lda, const bf16_t* W, 
     attr_set = true;
   }
   ResLnArgs a;
+  a.wk = w_kmajor ? (uint32_t)(RL_N * RL_BK * 2) : (uint32_t)(RL_BK * 2);
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.R = R; a.ldr = ldr; a.X = X; a.ldx = ldx; a.gamma = gamma; a.beta = beta;
   a.Y = Y; a.ldy = ldy; a.M = M; a.K = (int)K; a.eps = eps;
   const int64_t tiles = m_pad / RL_BM;

@@ -34,12 +34,19 @@ EPS_VIS, EPS_AST, EPS_SYNC = 1e-6, 1e-12, 1e-5
 
 
 class _Lin:
-    """bf16 weight (N, K) + fp32 bias (N,) on device."""
-    __slots__ = ('w', 'b')
+    """bf16 weight (N, K) + fp32 bias (N,) on device; `wk` = the same weight k-step-major (K/32, 768, 32) for sf_gemm_res_ln768, made on demand."""
+    __slots__ = ('w', 'b', '_wk')
 
     def __init__(self, w, b, dev):
         self.w = w.detach().to(dev, torch.bfloat16).contiguous()
         self.b = b.detach().to(dev, torch.float32).contiguous() if b is not None else None
+        self._wk = None
+
+    @property
+    def wk(self):
+        if self._wk is None:
+            self._wk = ops.kmajor_weight(self.w)
+        return self._wk
 
 
 class _LinQ:
@@ -297,21 +304,21 @@ class SynchformerEngine:
             ops.gemm(xn, b['t_qkv'].w, b['t_qkv'].b, qkv)
             divided('time')
             if fuse_ln:
-                ops.gemm_res_ln(xn, b['t_proj'].w, b['t_proj'].b, X, b['norm1'].g, b['norm1'].b, xn, EPS_VIS)
+                ops.gemm_res_ln(xn, b['t_proj'].wk, b['t_proj'].b, X, b['norm1'].g, b['norm1'].b, xn, EPS_VIS)
             else:
                 ops.gemm(xn, b['t_proj'].w, b['t_proj'].b, X, residual=X)
                 ops.layernorm(X, b['norm1'].g, b['norm1'].b, xn, EPS_VIS)
             ops.gemm(xn, b['s_qkv'].w, b['s_qkv'].b, qkv)
             divided('space')
             if fuse_ln:
-                ops.gemm_res_ln(xn, b['s_proj'].w, b['s_proj'].b, X, b['norm2'].g, b['norm2'].b, xn, EPS_VIS)
+                ops.gemm_res_ln(xn, b['s_proj'].wk, b['s_proj'].b, X, b['norm2'].g, b['norm2'].b, xn, EPS_VIS)
             else:
                 ops.gemm(xn, b['s_proj'].w, b['s_proj'].b, X, residual=X)
                 ops.layernorm(X, b['norm2'].g, b['norm2'].b, xn, EPS_VIS)
             ops.gemm(xn, b['fc1'].w, b['fc1'].b, hid, gelu=True)
             if fuse_ln and self.fuse_ln_fc2 and bi + 1 < nb:
                 nx = self.v_blocks[bi + 1]['norm3']
-                ops.gemm_res_ln(hid, b['fc2'].w, b['fc2'].b, X, nx.g, nx.b, xn, EPS_VIS)
+                ops.gemm_res_ln(hid, b['fc2'].wk, b['fc2'].b, X, nx.g, nx.b, xn, EPS_VIS)
             else:
                 ops.gemm(hid, b['fc2'].w, b['fc2'].b, X, residual=X)
                 if fuse_ln and bi + 1 < nb:

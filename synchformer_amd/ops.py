@@ -112,15 +112,29 @@ def gemm_res_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], 
     """x[m] = a[m] @ w.T + bias + residual[m] (fp32, in place when residual is None or x), y[m] = LayerNorm(x[m]) * gamma + beta (bf16).
     a (>= M, K) bf16, w (768, K) bf16; y may be the buffer `a` lives in (each 128-row tile reads its A rows before it writes them)."""
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dtype == torch.float32 and y.dtype == torch.bfloat16
-    assert w.shape[0] == 768 and a.shape[1] == w.shape[1] and x.shape[1] == 768 and y.shape[1] == 768
+    K = a.shape[1]
+    if w.dim() == 3:                                        # k-step-major weight (K / 32, 768, 32), see kmajor_weight()
+        assert w.shape == (K // 32, 768, 32) and w.is_contiguous()
+        w_ptr, ldw = _dev(w, 'w'), 32
+    else:
+        assert w.shape == (768, K)
+        w_ptr, ldw = _dev(w, 'w'), _ld(w)
+    assert x.shape[1] == 768 and y.shape[1] == 768
     M = a.shape[0] if M is None else M
     r = x if residual is None else residual
     assert r.dtype == torch.float32
-    rc = _lib.load().sf_gemm_res_ln768(_dev(a, 'a'), _ld(a), _dev(w, 'w'), _ld(w), _dev(bias, 'bias') if bias is not None else None,
+    rc = _lib.load().sf_gemm_res_ln768(_dev(a, 'a'), _ld(a), w_ptr, ldw, _dev(bias, 'bias') if bias is not None else None,
                                        _dev(r, 'residual'), _ld(r), _dev(x, 'x'), _ld(x), _dev(gamma, 'gamma'), _dev(beta, 'beta'), float(eps),
-                                       _dev(y, 'y'), _ld(y), M, w.shape[1], _stream())
+                                       _dev(y, 'y'), _ld(y), M, K, _stream())
     _lib.check(rc, 'sf_gemm_res_ln768')
     return x, y
+
+
+def kmajor_weight(w: torch.Tensor) -> torch.Tensor:
+    """(768, K) bf16 Linear weight -> (K / 32, 768, 32): the layout sf_gemm_res_ln768 streams fastest (one contiguous 48 KiB slice per 32-deep k-step
+    instead of 768 half cache lines 2 K bytes apart).  Pure data movement, done once at weight-preparation time."""
+    N, K = w.shape
+    return w.view(N, K // 32, 32).permute(1, 0, 2).contiguous()
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, eps: float, *,

@@ -289,6 +289,12 @@ def test_gemm_res_ln(gpu, M, K):
     torch.testing.assert_close(x[:M].cpu(), x_ref, rtol=1e-4, atol=3e-4)
     torch.testing.assert_close(y[:M].float().cpu(), y_ref, rtol=1e-2, atol=1e-2)
     assert (x[M:] == 7.0).all() and (y[M:] == 3.0).all(), 'rows beyond M were written'
+    # the k-step-major weight layout (what the engine passes): same products in the same order -> bit-identical
+    xk = torch.full((M + 3, 768), 7.0, device=gpu)
+    xk[:M] = r.to(gpu)
+    yk = torch.full((M + 3, 768), 3.0, device=gpu, dtype=torch.bfloat16)
+    ops.gemm_res_ln(a.to(gpu), ops.kmajor_weight(w.to(gpu)), b.to(gpu), xk, gam.to(gpu), bet.to(gpu), yk, eps, M=M)
+    assert torch.equal(xk, x) and torch.equal(yk, y)
     # the un-fused pair on the same operands: same fp32 X up to summation order, same bf16 Y up to one rounding
     x2 = torch.empty(M, 768, device=gpu)
     x2.copy_(r)

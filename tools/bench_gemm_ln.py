@@ -32,17 +32,19 @@ def main():
             b, g, bt = torch.randn(768, device=dev), torch.randn(768, device=dev), torch.randn(768, device=dev)
             x = torch.randn(M, 768, device=dev)
             y = torch.empty(M, 768, device=dev, dtype=torch.bfloat16)
-            t = {'gemm': [], 'ln': [], 'fused': []}
+            wk = ops.kmajor_weight(w)
+            t = {'gemm': [], 'ln': [], 'fused': [], 'fused_k': []}
             for _ in range(7):      # interleaved rounds, median
                 t['gemm'].append(timeit(lambda: ops.gemm(a, w, b, x, residual=x)))
                 t['ln'].append(timeit(lambda: ops.layernorm(x, g, bt, y, 1e-6)))
                 t['fused'].append(timeit(lambda: ops.gemm_res_ln(a, w, b, x, g, bt, y, 1e-6)))
+                t['fused_k'].append(timeit(lambda: ops.gemm_res_ln(a, wk, b, x, g, bt, y, 1e-6)))
                 x.normal_()
             med = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
             fl = 2.0 * M * 768 * K
             byts = M * K * 2 + M * 768 * (4 + 4 + 2)
             print(f"{name:5s} K {K:4d}: gemm+res {med['gemm']:7.1f} us ({fl / med['gemm'] / 1e6:5.0f} TF) + layernorm {med['ln']:6.1f} us = "
-                  f"{med['gemm'] + med['ln']:7.1f} us | fused {med['fused']:7.1f} us ({fl / med['fused'] / 1e6:5.0f} TF, {byts / med['fused'] / 1e6:5.2f} TB/s algorithmic)",
+                  f"{med['gemm'] + med['ln']:7.1f} us | fused {med['fused']:7.1f} us ({fl / med['fused'] / 1e6:5.0f} TF, {byts / med['fused'] / 1e6:5.2f} TB/s algorithmic) | k-major W {med['fused_k']:7.1f} us",
                   flush=True)
 
 
