@@ -40,6 +40,7 @@ struct GemmArgs {
   int N, K;
   uint32_t tiles_n, tiles_total;
   uint32_t nchunk;   // persistent kernel: column tiles per sweep (0 = all)
+  int64_t wk;        // persistent kernel: elements between consecutive 64-deep k-tiles of a W row (64 row-major, N * 64 k-tile-major)
   // strided batch (blockIdx.y = b0 * batch_inner + b1): element offsets added to A / W / C per batch index
   int batch_inner;
   int64_t sA0, sA1, sW0, sW1, sC0, sC1;
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p
     const uint32_t l = lds_wave + s * P_STAGE;
     if (SF_A_NT) dma4_nt(a_src[0] + kt * PBK, a_src[1] + kt * PBK, a_src[2] + kt * PBK, a_src[3] + kt * PBK, l);
     else dma4(a_src[0] + kt * PBK, a_src[1] + kt * PBK, a_src[2] + kt * PBK, a_src[3] + kt * PBK, l);
-    dma4(b_src[0] + kt * PBK, b_src[1] + kt * PBK, b_src[2] + kt * PBK, b_src[3] + kt * PBK, l + PBM * PBK * 2);
+    dma4(b_src[0] + kt * p.wk, b_src[1] + kt * p.wk, b_src[2] + kt * p.wk, b_src[3] + kt * p.wk, l + PBM * PBK * 2);
   };
 
   uint32_t t = t_begin + li;
@@ -550,8 +551,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p
           __builtin_amdgcn_sched_barrier(0);
           const uint32_t l = lds_wave + ((kt + 1) & 1) * P_STAGE;
           const int ko = kmap(kt + 1) * PBK;
+          const int64_t kow = kmap(kt + 1) * p.wk;
           if (kk == 0) dma4(a_src[0] + ko, a_src[1] + ko, a_src[2] + ko, a_src[3] + ko, l);
-          else dma4(b_src[0] + ko, b_src[1] + ko, b_src[2] + ko, b_src[3] + ko, l + PBM * PBK * 2);
+          else dma4(b_src[0] + kow, b_src[1] + kow, b_src[2] + kow, b_src[3] + kow, l + PBM * PBK * 2);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -700,6 +702,9 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
   SF_CHECK_ARG(epilogue == SF_EPI_NONE || epilogue == SF_EPI_GELU, "sf_gemm_bf16: bad epilogue %d", epilogue);
   SF_CHECK_ARG(K > 0 && (K % 64) == 0, "sf_gemm_bf16: K=%lld must be a positive multiple of 64", (long long)K);
   SF_CHECK_ARG((lda % 8) == 0 && (ldw % 8) == 0, "sf_gemm_bf16: lda/ldw must be multiples of 8 elements (16 B)");
+  // ldw == 64 with K > 64: the weight is given k-tile-major, [K/64][N][64] (the 32 KiB slice of every 64-deep k-tile of a 256-row W tile is
+  // contiguous); only the persistent 256x256 kernel reads that layout
+  const bool w_kmajor = ldw == 64 && K > 64;
   SF_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "sf_gemm_bf16: A/W must be 16-byte aligned");
   SF_CHECK_ARG(M < ((int64_t)1 << 31) && N < ((int64_t)1 << 31), "sf_gemm_bf16: M, N must be < 2^31");
   if (M <= 0 || N <= 0) return 0;
@@ -713,7 +718,7 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldr;
   a.cmap = sf_rowmap(c_map); a.rmap = sf_rowmap(r_map);
   a.M = M; a.N = (int)N; a.K = (int)K;
-  a.tiles_n = 0; a.tiles_total = 0; a.nchunk = 0;
+  a.tiles_n = 0; a.tiles_total = 0; a.nchunk = 0; a.wk = w_kmajor ? N * 64 : 64;
   a.batch_inner = 0; a.sA0 = a.sA1 = a.sW0 = a.sW1 = a.sC0 = a.sC1 = 0;
   hipStream_t s = (hipStream_t)stream;
   const bool gelu = epilogue == SF_EPI_GELU, res = R != nullptr, obf = c_dtype == SF_BF16;
@@ -724,7 +729,8 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
     // everything small (AST, aggregators, sync transformer, heads) and every mapped/ragged GEMM takes the 128x128 kernel.
     const bool big = fast && M >= 8192 && N >= 512;
     cfg = 0;
-    if (big && !(res && K <= 1024)) {
+    if (w_kmajor) { SF_CHECK_ARG(big, "sf_gemm_bf16: a k-tile-major weight needs the persistent kernel (identity maps, N %% 64 == 0, M >= 8192, N >= 512)"); cfg = 7; }
+    if (!w_kmajor && big && !(res && K <= 1024)) {
       // Tile-round quantisation decides between the persistent 256x256 kernel (one workgroup per CU, ~8 % faster per tile pair when
       // the chip is full) and the 128x128 kernel (two per CU): e.g. fc2 of a single clip is 86 x 3 = 258 big tiles = TWO rounds of
       // 256 CUs at 50 % fill, but 1032 small tiles = 2.02 rounds of 512 slots.  Pick the better filled one (measured, M = 21,966 /
@@ -774,7 +780,7 @@ extern "C" int sf_gemm_bf16_batched(const bf16_t* A, int64_t lda, int64_t sA0, i
   GemmArgs a;
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.C = C; a.ldc = ldc; a.R = nullptr; a.ldr = 0;
   a.cmap = sf_rowmap(nullptr); a.rmap = sf_rowmap(nullptr);
-  a.M = M; a.N = (int)N; a.K = (int)K; a.tiles_n = 0; a.tiles_total = 0; a.nchunk = 0;
+  a.M = M; a.N = (int)N; a.K = (int)K; a.tiles_n = 0; a.tiles_total = 0; a.nchunk = 0; a.wk = 64;
   a.batch_inner = batch_inner; a.sA0 = sA0; a.sA1 = sA1; a.sW0 = sW0; a.sW1 = sW1; a.sC0 = sC0; a.sC1 = sC1;
   g_batch_count = (int64_t)batch_outer * batch_inner;
   // 64-deep stages when the contraction allows it (the split-K weight-gradient products of the train steps: K = chunks of 64 rows)

@@ -50,14 +50,20 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     """out[cmap(m)] = act(a[m] @ w.T + bias) (+ residual[rmap(m)]).  a (>=M, K) bf16, w (N, K) bf16."""
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
     M = a.shape[0] if M is None else M
-    N, K = w.shape
+    if w.dim() == 3:                                        # k-tile-major weight (K / 64, N, 64), see ktile_major_weight()
+        K, N = w.shape[0] * 64, w.shape[1]
+        assert w.shape[2] == 64 and w.is_contiguous()
+        w_ld = 64
+    else:
+        N, K = w.shape
+        w_ld = _ld(w)
     assert a.shape[1] == K
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() >= N
     if residual is not None:
         assert residual.dtype == torch.float32
     rc = _lib.load().sf_gemm_bf16(
-        _dev(a, 'a'), _ld(a), _dev(w, 'w'), _ld(w), _dev(bias, 'bias') if bias is not None else None,
+        _dev(a, 'a'), _ld(a), _dev(w, 'w'), w_ld, _dev(bias, 'bias') if bias is not None else None,
         _dev(out, 'out'), _DT[out.dtype], _ld(out), _map(c_map),
         _dev(residual, 'residual') if residual is not None else None, _ld(residual) if residual is not None else 0,
         _map(r_map), EPI_GELU if gelu else EPI_NONE, M, N, K, _stream())
@@ -128,6 +134,12 @@ def gemm_res_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], 
                                        _dev(y, 'y'), _ld(y), M, K, _stream())
     _lib.check(rc, 'sf_gemm_res_ln768')
     return x, y
+
+
+def ktile_major_weight(w: torch.Tensor) -> torch.Tensor:
+    """(N, K) bf16 Linear weight -> (K / 64, N, 64) for the persistent 256 x 256 x 64 kernel of sf_gemm_bf16 (contiguous 32 KiB W tile per k-tile)."""
+    N, K = w.shape
+    return w.view(N, K // 64, 64).permute(1, 0, 2).contiguous()
 
 
 def kmajor_weight(w: torch.Tensor) -> torch.Tensor:

@@ -421,3 +421,16 @@ def test_layernorm_mxfp8_and_fp8_epilogue(gpu):
     h1, hs1 = torch.full((M + 2, N), 9, device=gpu, dtype=torch.uint8), torch.zeros(N // 128, M + 2, 4, device=gpu, dtype=torch.uint8)
     ops.gemm_mxfp8(aq, asc, wq, ws, b, h1, gelu=True, out_scales=hs1, M=M)
     assert torch.equal(h0, h1[:M]) and torch.equal(hs0, hs1[:, :M]) and (h1[M:] == 9).all() and (hs1[:, M:] == 0).all()
+
+
+def test_gemm_ktile_major_weight(gpu):
+    """sf_gemm_bf16 with the weight given k-tile-major ((K/64, N, 64), ldw == 64): the same products in the same order as the row-major weight."""
+    from synchformer_amd import ops
+    M, N, K = 9000, 2304, 768
+    a, w, b = _bf(_rand(M, K, seed=1)).to(gpu), _bf(_rand(N, K, seed=2, scale=0.05)).to(gpu), _rand(N, seed=3).to(gpu)
+    o0, o1 = torch.empty(M, N, device=gpu, dtype=torch.bfloat16), torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(a, w, b, o0, gelu=True)
+    ops.gemm(a, ops.ktile_major_weight(w), b, o1, gelu=True)
+    assert torch.equal(o0, o1)
+    with pytest.raises(RuntimeError, match='k-tile-major'):
+        ops.gemm(a[:100], ops.ktile_major_weight(w), b, o1[:100])

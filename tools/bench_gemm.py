@@ -47,6 +47,11 @@ def main():
             for cfg in CFGS:
                 us = sorted(times[cfg])[len(times[cfg]) // 2]
                 line += f' c{cfg} {us:6.1f}us {2.0 * M * N * K / us / 1e6:5.0f}TF |'
+            if os.environ.get('KMAJOR', '1') != '0' and M >= 8192:
+                lib.sf_gemm_force_config(-1)
+                wk = ops.ktile_major_weight(w)
+                tk = sorted(timeit(lambda: ops.gemm(a, wk, b, out, gelu=gelu, residual=out if res else None), iters=6) for _ in range(7))[3]
+                line += f' c7 k-tile-major W {tk:6.1f}us {2.0 * M * N * K / tk / 1e6:5.0f}TF |'
             print(line, flush=True)
     lib.sf_gemm_force_config(-1)
 
