@@ -91,8 +91,8 @@ int sf_gemm_mxfp8(const uint8_t* A, int64_t lda, const uint8_t* sA, int64_t ldsa
 int sf_layernorm768_mxfp8(const float* x, int64_t ldx, const float* gamma, const float* beta, uint8_t* q, int64_t ldq, uint8_t* scales, int64_t lds,
                           int64_t rows, float eps, void* stream);
 
-/* Tuning / test hook (process-global, not for production threads): force the GEMM tile configuration of subsequent sf_gemm_bf16
- * calls.  -1 = automatic choice by shape (default); 0 = 128x128x64, 4 waves, two workgroups per CU; 7 = persistent 256x256x64,
+/* Tuning / test hook (state of the CALLING THREAD only; the launchers stay re-entrant): force the GEMM tile configuration of this thread's subsequent
+ * sf_gemm_bf16 calls.  -1 = automatic choice by shape (default); 0 = 128x128x64, 4 waves, two workgroups per CU; 7 = persistent 256x256x64,
  * 8 waves, v_mfma_f32_32x32x16_bf16; 1-6, 8, 9 = the other tilings measured in profiles/r01_gemm_configs.md (tools/bench_gemm.py). */
 void sf_gemm_force_config(int cfg);
 

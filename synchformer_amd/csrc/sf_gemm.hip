@@ -656,7 +656,7 @@ typedef GemmCfg<128, 128, 2, 2, 32, 4, 2, true> Cfg6;   // Cfg4 + fragment regis
 typedef GemmCfg<256, 128, 2, 2, 32, 3, 2> Cfg8;   // 4 waves x (128 x 64), 72 KiB, 2 workgroups/CU: epilogue overlaps the other WG's loop
 typedef GemmCfg<128, 256, 1, 4, 32, 3, 2> Cfg9;   // same, transposed block shape
 
-static int g_force_cfg = -1;   // tuning / test hook
+static thread_local int g_force_cfg = -1;   // tuning / test hook: per calling thread, so that a benchmark thread cannot change another thread's launches
 static thread_local int64_t g_batch_count = 1;   // set by sf_gemm_bf16_batched around its launch
 extern "C" void sf_gemm_force_config(int cfg) { g_force_cfg = cfg; }
 

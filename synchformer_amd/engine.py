@@ -78,6 +78,7 @@ class SynchformerEngine:
         # fp8_towers: the six big Linears of every visual block run on MXFP8 operands (sf_gemm_mxfp8) - the frozen-extractor mode of the
         # synchronizability fine-tune (BASELINE configs[4]).  Off (bf16) for every other workload: inference parity bars are stated for bf16.
         self.fp8_towers = bool(fp8_towers)
+        self.capture_blocks = None          # tests: a dict -> the fp32 residual stream after each visual block is cloned into it (key = block index)
         self._ws = {}
         self.audio_side_stream = os.environ.get('SF_AUDIO_SIDE_STREAM', '1') != '0'
         self.fuse_ln = os.environ.get('SF_FUSE_LN', '1') != '0'            # A/B switches of the full-row GEMM + residual + LayerNorm kernel
@@ -324,6 +325,8 @@ class SynchformerEngine:
                 if fuse_ln and bi + 1 < nb:
                     nx = self.v_blocks[bi + 1]['norm3']
                     ops.layernorm(X, nx.g, nx.b, xn, EPS_VIS)
+            if self.capture_blocks is not None:
+                self.capture_blocks[bi] = X.clone()
         self._visual_tail(X, n, out, tok_keep)
 
     def _visual_blocks_mxfp8(self, X, xn, qkv, rows, divided):

@@ -56,6 +56,29 @@ def test_golden_sync_logits_and_features(gpu, tag, gain, tol):
     assert (logits.argmax(-1) == torch.from_numpy(g['logits']).argmax(-1)).all()
 
 
+@pytest.mark.parametrize('fuse', [True, False])
+def test_golden_per_block_outputs(gpu, fuse):
+    """The residual stream right after visual blocks 0, 5 and 11 against the REAL reference's hooked block outputs (e2e_sync_B2.npz keeps
+    token rows 0, 1, 2, 197, 1000, 1568 of segments 0, 13 and 27): an error in one DividedSpaceTimeBlock is caught at that block, not 12
+    blocks later.  Both schedules (fused GEMM + LayerNorm kernel on 28 segments = 43,932 rows, and the un-fused pair).  Bars: relative RMS
+    1 %; max |delta| 2e-2 after block 0 growing to 7.5e-2 after block 11 (bf16 GEMM operands, fp32 stream of magnitude up to ~10; measured 3.6e-2)."""
+    g = np.load(GOLD / 'e2e_sync_B2.npz')
+    eng, _ = _engine(gpu)
+    eng.fuse_ln = fuse
+    eng.capture_blocks = {}
+    u8, _ = _inputs(2, 14)
+    eng.extract_vfeats(u8.to(gpu))
+    rows = [0, 1, 2, 197, 1000, 1568]
+    for bi in (0, 5, 11):
+        x = eng.capture_blocks[bi].view(28, 1569, 768)[[0, 13, 27]][:, rows].cpu()
+        ref = torch.from_numpy(g[f'vfeat_extractor__blocks__{bi}'])
+        assert ref.shape == x.shape, (ref.shape, x.shape)
+        rel, mx = _rel_rms(x, ref), (x - ref).abs().max().item()
+        print(f'block {bi} (fuse_ln {fuse}): rel-RMS {rel:.5f} max {mx:.5f}')
+        assert rel < 1e-2 and mx < 2e-2 * (1 + bi / 4), (bi, rel, mx)
+    eng.capture_blocks = None
+
+
 def test_golden_syncability(gpu):
     """S=13 segments, 184-token sync transformer, 2-way sync_head (configs/ft_synchability.yaml)."""
     g = np.load(GOLD / 'e2e_syncability_B1.npz')
