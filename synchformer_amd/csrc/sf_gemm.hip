@@ -645,6 +645,214 @@ static int dispatch_gemm_persistent(const GemmArgs& a, bool out_bf16, bool gelu,
   return res ? launch_gemm_persistent<false, false, true>(a, s) : launch_gemm_persistent<false, false, false>(a, s);
 }
 
+// =========================================================================================================
+// Config 10: the same persistent 256 x 256 x 64 tile on FOUR waves (one per SIMD), 128 x 128 accumulators each (256 registers: the
+// accumulator half of the unified file) - the wave shape the vendor library uses on these shapes.  Per k-tile a wave reads (128 + 128) x 64
+// operand elements from LDS where the 8-wave kernel's waves read (128 + 64) x 64 each: 128 KiB instead of 196 KiB of fragment traffic per CU
+// and k-tile - the 8-wave kernel's LDS pipe is as busy as its matrix pipe (profiles/r01_gemm_configs.md).  With one wave per SIMD nothing
+// covers a stall, so the loop is software-pipelined by hand and PINNED with sched_barrier(0) fences:
+//   * fragments are double-buffered per 16-deep step: while the 16 MFMAs of step kk run, the 8 fragment reads of step kk + 1 are issued, one
+//     behind every second MFMA;
+//   * the k-tile barrier sits in front of the LAST step of a k-tile: its fragments are already in registers, so the slot is free from there on
+//     (refilled with k-tile kt + 2 by 16 LDS-DMA pieces per wave, one behind each MFMA of that step) and the first fragments of k-tile kt + 1
+//     are read under those MFMAs.
+// =========================================================================================================
+#define W4_SLAB_BYTES (16 * P_EPI_LD * 4)
+#define W4_LDS (2 * P_STAGE + 4 * W4_SLAB_BYTES)
+
+template <bool OUT_BF16, bool GELU, bool HAS_RES>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;                      // 2 x 2 waves, wave tile 128 x 128
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  const uint32_t xcd = blockIdx.x & 7u, li = blockIdx.x >> 3, per_xcd_blocks = gridDim.x >> 3;
+  const uint32_t tiles_m = p.tiles_total / p.tiles_n;
+  const uint32_t mp8 = (tiles_m + 7u) >> 3;
+  const uint32_t mp0 = min(xcd * mp8, tiles_m), mp1 = min(mp0 + mp8, tiles_m), n_mp = mp1 - mp0;
+  const uint32_t gchunk = p.nchunk ? min(p.nchunk, p.tiles_n) : p.tiles_n;
+  const uint32_t n_chunks = (p.tiles_n + gchunk - 1) / gchunk, chunk_tiles = n_mp * gchunk;
+  const uint32_t t_end = n_mp * p.tiles_n;
+
+  const int piece_row = lane >> 3, slot = lane & 7;
+  const int sw = (l31 >> 1) & 7;
+  int frag_off[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) frag_off[kk] = l31 * 128 + (((kk * 2 + hi) ^ sw) << 4);
+  const int a_base = wm * 128 * 128, b_base = PBM * PBK * 2 + wn * 128 * 128;
+
+  const bf16_t* a_src[8];
+  const bf16_t* b_src[8];
+  auto set_tile = [&](uint32_t t, int64_t& m0, int& n0) {
+    const uint32_t c = min(t / chunk_tiles, n_chunks - 1), r = t - c * chunk_tiles;
+    const uint32_t gw = (c == n_chunks - 1) ? p.tiles_n - c * gchunk : gchunk;
+    const uint32_t tm = mp0 + r / gw, tn = c * gchunk + r % gw;
+    m0 = (int64_t)tm * PBM; n0 = (int)tn * PBN;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = (wave * 8 + i) * 8 + piece_row;            // tile row this lane fills (8 pieces of A and of B per wave)
+      const int gch = slot ^ ((row >> 1) & 7);
+      int64_t ar = m0 + row; if (ar > p.M - 1) ar = p.M - 1;
+      int br = n0 + row; if (br > p.N - 1) br = p.N - 1;
+      a_src[i] = p.A + ar * p.lda + gch * 8;
+      b_src[i] = p.W + (int64_t)br * p.ldw + gch * 8;
+    }
+  };
+  const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(lds_addr(smem) + (wave * 8) * 1024);
+  auto dma_quad = [&](int s, int kt, int q) {                     // q = 0, 1: A pieces 0-3 / 4-7;  q = 2, 3: B pieces 0-3 / 4-7
+    const uint32_t l = lds_wave + s * P_STAGE + (q >= 2 ? PBM * PBK * 2 : 0) + (q & 1) * 4096;
+    const int ko = kt * PBK;
+    const bf16_t* const* src = q >= 2 ? b_src : a_src;
+    const int o = (q & 1) * 4;
+    dma4(src[o] + ko, src[o + 1] + ko, src[o + 2] + ko, src[o + 3] + ko, l);
+  };
+  auto stage = [&](int s, int kt) { dma_quad(s, kt, 0); dma_quad(s, kt, 1); dma_quad(s, kt, 2); dma_quad(s, kt, 3); };
+
+  const int nk = p.K / PBK;
+  uint32_t t = li;
+  if (t >= t_end) return;
+  int64_t m0; int n0;
+  set_tile(t, m0, n0);
+  stage(0, 0);
+  if (nk > 1) stage(1, 1);
+  float* slab = reinterpret_cast<float*>(smem + 2 * P_STAGE + wave * W4_SLAB_BYTES);
+  const int ecol = (lane & 15) * 4;
+  const uint32_t esz = OUT_BF16 ? 2u : 4u;
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, (short)0, (int)(uint32_t)(p.M * p.ldc * esz), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), (short)0, HAS_RES ? (int)(uint32_t)(p.M * p.ldr * 4) : 0, 0x00020000);
+  const uint32_t cstep = (uint32_t)(4 * p.ldc) * esz, rstep = (uint32_t)(4 * p.ldr) * 4u;
+
+  for (;;) {
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    bf16x8 f0[8], f1[8];                                          // fragment sets: [0..3] = A row blocks, [4..7] = B column blocks
+    auto read_frag = [&](bf16x8& dst, const char* st, int idx, int kk) {
+      const int base = idx < 4 ? a_base + idx * 32 * 128 : b_base + (idx - 4) * 32 * 128;
+      dst = *reinterpret_cast<const bf16x8*>(st + base + frag_off[kk]);
+    };
+    // one 16-deep step: 16 MFMAs on `cur`; behind every second one a fragment of (nst, nkk) goes into `nxt`; DMA: 0 = none, else the quad
+    // of k-tile `dkt` for slot `dslot` behind MFMAs 1, 5, 9, 13
+    auto step = [&](bf16x8 (&cur)[8], bf16x8 (&nxt)[8], const char* nst, int nkk, bool do_reads, bool do_dma, int dslot, int dkt) {
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int m0_ = 2 * b, m1_ = 2 * b + 1;
+        if (!(SF_ABL & 4)) {
+          acc[m0_ >> 2][m0_ & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[m0_ >> 2], cur[4 + (m0_ & 3)], acc[m0_ >> 2][m0_ & 3], 0, 0, 0);
+          acc[m1_ >> 2][m1_ & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[m1_ >> 2], cur[4 + (m1_ & 3)], acc[m1_ >> 2][m1_ & 3], 0, 0, 0);
+        } else if (b == 0) {
+          acc[0][0][0] += (float)cur[0][0] + (float)cur[7][0];       // ablation: keep the fragments live, no matrix work
+        }
+        if (do_reads) read_frag(nxt[b], nst, b, nkk);
+        if (do_dma && (b & 1) == 0 && !(SF_ABL & 2)) dma_quad(dslot, dkt, b >> 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    wait_vmcnt_barrier<0>();                                      // k-tile 0 of this tile is visible
+#pragma unroll
+    for (int b = 0; b < 8; ++b) read_frag(f0[b], smem, b, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* st = smem + (kt & 1) * P_STAGE;
+      const char* stn = smem + ((kt + 1) & 1) * P_STAGE;
+      step(f0, f1, st, 1, true, false, 0, 0);
+      step(f1, f0, st, 2, true, false, 0, 0);
+      step(f0, f1, st, 3, true, false, 0, 0);
+      const bool more_k = kt + 1 < nk;
+      if (more_k) {
+        // every fragment of this k-tile is in registers once f1 has landed: publish k-tile kt + 1 and free this slot
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vmcnt_barrier<0>();
+      }
+      step(f1, f0, stn, 0, more_k, kt + 2 < nk, kt & 1, kt + 2);
+    }
+    // all waves are done with both slots -> next tile's first two k-tiles go in flight under the epilogue
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int64_t em0 = m0; const int en0 = n0;
+    const uint32_t tnext = t + per_xcd_blocks;
+    const bool more = tnext < t_end;
+    if (more) { set_tile(tnext, m0, n0); stage(0, 0); if (nk > 1) stage(1, 1); }
+
+    // ---- epilogue: 8 row groups x 2 column halves of (16 rows x 64 cols) through this wave's slab -------------------
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      if (en0 + wn * 128 + ch * 64 < p.N) {
+        const int gcol = en0 + wn * 128 + ch * 64 + ecol;
+        const int64_t row0 = em0 + wm * 128 + (lane >> 4);
+        const uint32_t coff0 = (uint32_t)(row0 * p.ldc + gcol) * esz, roff0 = (uint32_t)(row0 * p.ldr + gcol) * 4u;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + gcol);
+        float4 res[2][4];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) res[0][ps] = res[1][ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (HAS_RES) epi_group_load_res(res[0], rr, roff0, rstep);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          const int i = g >> 1, q2 = g & 1;
+          if (HAS_RES && g + 1 < 8) epi_group_load_res(res[(g + 1) & 1], rr, roff0 + (g + 1) * 4 * rstep, rstep);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                slab[(qq * 8 + hi * 4 + r) * P_EPI_LD + j * 32 + l31] = acc[i][ch * 2 + j][(q2 * 2 + qq) * 4 + r];
+          float4 v[4];
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) v[ps] = *reinterpret_cast<const float4*>(slab + (ps * 4 + (lane >> 4)) * P_EPI_LD + ecol);
+          epi_group_store<OUT_BF16, GELU, HAS_RES>(v, bias4, res[g & 1], rc, coff0 + g * 4 * cstep, cstep);
+        }
+      }
+    }
+    if (!more) break;
+    t = tnext;
+  }
+}
+
+template <bool OUT_BF16, bool GELU, bool HAS_RES>
+static int launch_gemm_w4(GemmArgs a, hipStream_t s) {
+  auto kern = gemm_bf16_w4_kernel<OUT_BF16, GELU, HAS_RES>;
+  static bool attr_set = false;
+  static int n_cu = 0;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
+    if (e != hipSuccess) { sf_set_error("sf_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { sf_set_error("sf_gemm_bf16: device query failed"); return -1; }
+    n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const int64_t tiles_m = (a.M + PBM - 1) / PBM;
+  a.tiles_n = (uint32_t)((a.N + PBN - 1) / PBN);
+  const int64_t total = tiles_m * a.tiles_n;
+  if (total >= ((int64_t)1 << 31)) { sf_set_error("sf_gemm_bf16: too many tiles"); return -1; }
+  a.tiles_total = (uint32_t)total;
+  a.nchunk = a.K <= 1024 ? (uint32_t)(2400000 / (512 * a.K) > 0 ? 2400000 / (512 * a.K) : 1) : 0u;
+  int64_t blocks = (n_cu / 8) * 8;
+  const int64_t need = ((total + 7) / 8) * 8;
+  if (blocks > need) blocks = need;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), W4_LDS, s, a);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+static int dispatch_gemm_w4(const GemmArgs& a, bool out_bf16, bool gelu, bool res, hipStream_t s) {
+  if (out_bf16) {
+    if (gelu) return res ? launch_gemm_w4<true, true, true>(a, s) : launch_gemm_w4<true, true, false>(a, s);
+    return res ? launch_gemm_w4<true, false, true>(a, s) : launch_gemm_w4<true, false, false>(a, s);
+  }
+  if (gelu) return res ? launch_gemm_w4<false, true, true>(a, s) : launch_gemm_w4<false, true, false>(a, s);
+  return res ? launch_gemm_w4<false, false, true>(a, s) : launch_gemm_w4<false, false, false>(a, s);
+}
+
 //                 BM   BN  WM WN BK NS wg/CU
 typedef GemmCfg<128, 128, 2, 2, 64, 2, 2> Cfg0;   // 4 waves,  64 KiB: small-M GEMMs (AST, aggregators, sync, heads)
 typedef GemmCfg<256, 256, 2, 4, 64, 2, 1> Cfg1;   // 8 waves, 128 KiB, 2-stage
@@ -755,6 +963,8 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
     case 9: return dispatch_gemm<Cfg9>(a, obf, gelu, res, fast, s);
     case 7: if (!fast) { sf_set_error("sf_gemm_bf16: config 7 needs N %% 64 == 0"); return -1; }
             return dispatch_gemm_persistent(a, obf, gelu, res, s);
+    case 10: if (!fast || w_kmajor) { sf_set_error("sf_gemm_bf16: config 10 needs N %% 64 == 0 and a row-major weight"); return -1; }
+            return dispatch_gemm_w4(a, obf, gelu, res, s);
     default: sf_set_error("sf_gemm_bf16: unknown tile config %d", cfg); return -1;
   }
 }
