@@ -72,6 +72,21 @@ __device__ __forceinline__ void dma4(const void* g0, const void* g1, const void*
       : "memory", "scc");
 }
 
+// The same four pieces addressed as SGPR base + zero-extended 32-bit lane offsets (operands below 4 GiB): half the address registers per piece.
+__device__ __forceinline__ void dma4s(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, const void* sbase, uint32_t l0) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(l0)
+      : "memory", "scc");
+}
+
 __device__ __forceinline__ void dma4_nt(const void* g0, const void* g1, const void* g2, const void* g3, uint32_t l0) {
   uint32_t keep;
   asm volatile(
@@ -682,8 +697,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmArgs p) {
   for (int kk = 0; kk < 4; ++kk) frag_off[kk] = l31 * 128 + (((kk * 2 + hi) ^ sw) << 4);
   const int a_base = wm * 128 * 128, b_base = PBM * PBK * 2 + wn * 128 * 128;
 
-  const bf16_t* a_src[8];
-  const bf16_t* b_src[8];
+  uint32_t a_src[8], b_src[8];                                  // byte offsets from p.A / p.W (both below 4 GiB: checked by the launcher)
   auto set_tile = [&](uint32_t t, int64_t& m0, int& n0) {
     const uint32_t c = min(t / chunk_tiles, n_chunks - 1), r = t - c * chunk_tiles;
     const uint32_t gw = (c == n_chunks - 1) ? p.tiles_n - c * gchunk : gchunk;
@@ -695,17 +709,17 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmArgs p) {
       const int gch = slot ^ ((row >> 1) & 7);
       int64_t ar = m0 + row; if (ar > p.M - 1) ar = p.M - 1;
       int br = n0 + row; if (br > p.N - 1) br = p.N - 1;
-      a_src[i] = p.A + ar * p.lda + gch * 8;
-      b_src[i] = p.W + (int64_t)br * p.ldw + gch * 8;
+      a_src[i] = (uint32_t)((ar * p.lda + gch * 8) * 2);
+      b_src[i] = (uint32_t)(((int64_t)br * p.ldw + gch * 8) * 2);
     }
   };
   const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(lds_addr(smem) + (wave * 8) * 1024);
   auto dma_quad = [&](int s, int kt, int q) {                     // q = 0, 1: A pieces 0-3 / 4-7;  q = 2, 3: B pieces 0-3 / 4-7
     const uint32_t l = lds_wave + s * P_STAGE + (q >= 2 ? PBM * PBK * 2 : 0) + (q & 1) * 4096;
-    const int ko = kt * PBK;
-    const bf16_t* const* src = q >= 2 ? b_src : a_src;
+    const uint32_t ko = (uint32_t)kt * (PBK * 2);
+    const uint32_t* src = q >= 2 ? b_src : a_src;
     const int o = (q & 1) * 4;
-    dma4(src[o] + ko, src[o + 1] + ko, src[o + 2] + ko, src[o + 3] + ko, l);
+    dma4s(src[o] + ko, src[o + 1] + ko, src[o + 2] + ko, src[o + 3] + ko, q >= 2 ? (const void*)p.W : (const void*)p.A, l);
   };
   auto stage = [&](int s, int kt) { dma_quad(s, kt, 0); dma_quad(s, kt, 1); dma_quad(s, kt, 2); dma_quad(s, kt, 3); };
 
@@ -963,7 +977,8 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
     case 9: return dispatch_gemm<Cfg9>(a, obf, gelu, res, fast, s);
     case 7: if (!fast) { sf_set_error("sf_gemm_bf16: config 7 needs N %% 64 == 0"); return -1; }
             return dispatch_gemm_persistent(a, obf, gelu, res, s);
-    case 10: if (!fast || w_kmajor) { sf_set_error("sf_gemm_bf16: config 10 needs N %% 64 == 0 and a row-major weight"); return -1; }
+    case 10: if (!fast || w_kmajor || M * lda * 2 >= ((int64_t)1 << 32) || N * ldw * 2 >= ((int64_t)1 << 32)) {
+              sf_set_error("sf_gemm_bf16: config 10 needs N %% 64 == 0, a row-major weight and operands below 4 GiB"); return -1; }
             return dispatch_gemm_w4(a, obf, gelu, res, s);
     default: sf_set_error("sf_gemm_bf16: unknown tile config %d", cfg); return -1;
   }
