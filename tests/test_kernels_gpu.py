@@ -423,6 +423,27 @@ def test_layernorm_mxfp8_and_fp8_epilogue(gpu):
     assert torch.equal(h0, h1[:M]) and torch.equal(hs0, hs1[:, :M]) and (h1[M:] == 9).all() and (hs1[:, M:] == 0).all()
 
 
+@pytest.mark.parametrize('cfg', [7, 10])
+def test_gemm_persistent_epilogues(gpu, cfg):
+    """The persistent 256x256 kernels (8 waves, 4 waves) over several tile rounds with a ragged last row
+    panel: GELU -> bf16 and in-place fp32 residual against fp32 torch on the same bf16 operands."""
+    from synchformer_amd import ops, _lib
+    M, N, K = 256 * 70 + 37, 768, 768
+    a, w, b = _bf(_rand(M, K, seed=40)).to(gpu), _bf(_rand(N, K, seed=41, scale=0.05)).to(gpu), _rand(N, seed=42).to(gpu)
+    lin = a.float() @ w.float().t() + b
+    _lib.load().sf_gemm_force_config(cfg)
+    try:
+        out = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+        ops.gemm(a, w, b, out, gelu=True)
+        x = _rand(M, N, seed=43).to(gpu)
+        x0 = x.clone()
+        ops.gemm(a, w, b, x, residual=x)
+    finally:
+        _lib.load().sf_gemm_force_config(-1)
+    torch.testing.assert_close(out.float(), torch.nn.functional.gelu(lin), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(x, lin + x0, rtol=1e-4, atol=3e-4)
+
+
 def test_gemm_ktile_major_weight(gpu):
     """sf_gemm_bf16 with the weight given k-tile-major ((K/64, N, 64), ldw == 64): the same products in the same order as the row-major weight."""
     from synchformer_amd import ops
