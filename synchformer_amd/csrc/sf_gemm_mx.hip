@@ -17,6 +17,12 @@
 #include <type_traits>
 #include "../../include/synchformer_hip.h"
 
+#ifndef SF_MX_ABL
+#define SF_MX_ABL 0   // measurement builds only (tools/ab_gemm_flags.sh): 2 = no operand refills inside a tile, 4 = no MFMAs
+#endif
+#ifndef SF_MX_DMA
+#define SF_MX_DMA 3   // where the refill's LDS-DMA issues sit (measured at 208 segments, qkv / fc2 us): 0 = A behind step 0, B behind step 1: 1041 / 1064;
+#endif                 // 1 = all 8 behind step 0: 1047 / 1056; 2 = A, B behind the two halves of step 0: 981 / 1022; 3 = pairs behind every MFMA pair of step 0: 979 / 993
 #define MXBM 256
 #define MXBN 256
 #define MXBK 128                           // bytes = fp8 elements per row per stage
@@ -63,6 +69,18 @@ __device__ __forceinline__ void mx_dma4(uint32_t v0, uint32_t v1, uint32_t v2, u
       : "memory", "scc");
 }
 
+__device__ __forceinline__ void mx_dma2(uint32_t v0, uint32_t v1, const void* sbase, uint32_t l0) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(v0), "v"(v1), "s"(sbase), "s"(l0)
+      : "memory", "scc");
+}
+
 __device__ __forceinline__ void mx_wait_vmcnt0_barrier() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_waitcnt((0 & 0xF) | (0x7 << 4) | (0xF << 8) | (0 << 14));
@@ -74,7 +92,7 @@ __device__ __forceinline__ void mx_wait_vmcnt0_barrier() {
 // rounded value exactly as sf_quantize_mxfp8 would from a bf16 buffer; a 32-column block = 8 consecutive lanes of the 16-lane row group).
 template <int OUT, bool GELU, bool HAS_RES>
 __device__ __forceinline__ void mx_epi_store(float4 (&v)[4], const float4& bias4, const float4 (&res)[4], __amdgpu_buffer_rsrc_t rc, uint32_t coff, uint32_t cstep,
-                                             uint8_t* sc_ptr = nullptr, int64_t row = 0, int64_t M = 0, int lane = 0) {
+                                             __amdgpu_buffer_rsrc_t rsc = __amdgpu_buffer_rsrc_t(), uint32_t sc_off = 0, int rows_left = 0) {
   constexpr bool OUT_BF16 = OUT == 1;
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
@@ -89,14 +107,19 @@ __device__ __forceinline__ void mx_epi_store(float4 (&v)[4], const float4& bias4
       const uint32_t p01 = pack_bf2(x.x, x.y), p23 = pack_bf2(x.z, x.w);
       const float f0 = __uint_as_float(p01 << 16), f1 = __uint_as_float(p01 & 0xffff0000u), f2 = __uint_as_float(p23 << 16), f3 = __uint_as_float(p23 & 0xffff0000u);
       float amax = fmaxf(fmaxf(fabsf(f0), fabsf(f1)), fmaxf(fabsf(f2), fabsf(f3)));
-      amax = fmaxf(amax, __shfl_xor(amax, 1, 64)); amax = fmaxf(amax, __shfl_xor(amax, 2, 64)); amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+      // max over the block's eight lanes on DPP (no LDS traffic): quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7 - i)
+      amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(amax), 0xB1, 0xF, 0xF, true)));
+      amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(amax), 0x4E, 0xF, 0xF, true)));
+      amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(amax), 0x141, 0xF, 0xF, true)));
       int be = (int)((__float_as_uint(amax) >> 23) & 0xff) - 8;
       be = be < 1 ? 1 : (be > 254 ? 254 : be);
       const float inv = __uint_as_float((uint32_t)(254 - be) << 23);
       int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f0 * inv, 448.f, -448.f), __builtin_amdgcn_fmed3f(f1 * inv, 448.f, -448.f), 0, false);
       w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f2 * inv, 448.f, -448.f), __builtin_amdgcn_fmed3f(f3 * inv, 448.f, -448.f), w, true);
       __builtin_amdgcn_raw_buffer_store_b32((uint32_t)w, rc, coff + ps * cstep, 0, SF_MX_STORE_AUX);
-      if ((lane & 7) == 0 && row + ps * 4 < M) sc_ptr[(row + ps * 4) * 4] = (uint8_t)be;      // sc_ptr already points at this lane's (plane, byte-in-dword)
+      // one scale byte per row and 32-column block, from the first lane of the block's eight; every other lane (and rows >= M, which would land in the
+      // next plane) gets an out-of-range offset that the buffer range check drops - no exec-mask branch in the store loop
+      __builtin_amdgcn_raw_buffer_store_b8((uint8_t)be, rsc, ps * 4 < rows_left ? sc_off + ps * 16 : 0xffffffffu, 0, 0);
     } else if (OUT_BF16) {
       mx_u32x2 o; o.x = pack_bf2(x.x, x.y); o.y = pack_bf2(x.z, x.w);
       __builtin_amdgcn_raw_buffer_store_b64(o, rc, coff + ps * cstep, 0, SF_MX_STORE_AUX);
@@ -199,6 +222,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_persistent_kernel(MxArgs p)
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, (short)0, (int)(uint32_t)(p.M * p.ldc * esz), 0x00020000);
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), (short)0, HAS_RES ? (int)(uint32_t)(p.M * p.ldr * 4) : 0, 0x00020000);
   const uint32_t cstep = (uint32_t)(4 * p.ldc) * esz, rstep = (uint32_t)(4 * p.ldr) * 4u;
+  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(p.sC, (short)0, OUT == 2 ? (int)(uint32_t)((p.N / MXBK) * p.ldsc) : 0, 0x00020000);
 
   for (;;) {
     f32x16 acc[4][2];
@@ -251,16 +275,44 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_persistent_kernel(MxArgs p)
             const int i = ih * 2 + ii;
             const int sav = (int)((sa_c[i] >> sh) & 0xffu);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[ii], b[j], acc[i][j], 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, sav, 0, sbv[j]);
+            for (int j = 0; j < 2; ++j) {
+              if (!(SF_MX_ABL & 4)) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[ii], b[j], acc[i][j], 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, sav, 0, sbv[j]);
+              else if (j == 0) acc[i][0][0] += (float)(a[ii][0] + b[0][0] + b[1][7] + sav + sbv[0] + sbv[1]);   // ablation: operands stay live, no matrix work
+            }
+            if (SF_MX_DMA == 3 && REFILL && kk == 0 && !(SF_MX_ABL & 2)) {
+              __builtin_amdgcn_sched_barrier(0);
+              const uint32_t l = lds_wave + ((kt + 1) & 1) * MX_STAGE;
+              const int ko = (kt + 1) * MXBK;
+              if (ih == 0) mx_dma2(a_src[2 * ii] + ko, a_src[2 * ii + 1] + ko, p.A, l + ii * 2048);
+              else mx_dma2(b_src[2 * ii] + ko, b_src[2 * ii + 1] + ko, p.W, l + MXBM * MXBK + ii * 2048);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          if (SF_MX_DMA == 2 && REFILL && kk == 0 && !(SF_MX_ABL & 2)) {
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t l = lds_wave + ((kt + 1) & 1) * MX_STAGE;
+            const int ko = (kt + 1) * MXBK;
+            if (ih == 0) mx_dma4(a_src[0] + ko, a_src[1] + ko, a_src[2] + ko, a_src[3] + ko, p.A, l);
+            else mx_dma4(b_src[0] + ko, b_src[1] + ko, b_src[2] + ko, b_src[3] + ko, p.W, l + MXBM * MXBK);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (REFILL) {                                              // the refill's 8 LDS-DMA issues ride behind the two MFMA clusters
+        if (SF_MX_DMA == 0 && REFILL && !(SF_MX_ABL & 2)) {
           const uint32_t l = lds_wave + ((kt + 1) & 1) * MX_STAGE;
           const int ko = (kt + 1) * MXBK;
           if (kk == 0) mx_dma4(a_src[0] + ko, a_src[1] + ko, a_src[2] + ko, a_src[3] + ko, p.A, l);
           else mx_dma4(b_src[0] + ko, b_src[1] + ko, b_src[2] + ko, b_src[3] + ko, p.W, l + MXBM * MXBK);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // the refill's 8 LDS-DMA issues ride behind the MFMAs of the FIRST 64-deep step: the whole stage is requested by the middle of the k-step
+        // (a 128-deep stage has only two steps - with the B pieces behind the second step's MFMAs, as in the bf16 kernel's four-step stage, they
+        // were issued right in front of the next wait and their full latency showed in every k-step: qkv 1041 us at 208 segments).
+        if (SF_MX_DMA == 1 && REFILL && kk == 0 && !(SF_MX_ABL & 2)) {
+          const uint32_t l = lds_wave + ((kt + 1) & 1) * MX_STAGE;
+          const int ko = (kt + 1) * MXBK;
+          mx_dma4(a_src[0] + ko, a_src[1] + ko, a_src[2] + ko, a_src[3] + ko, p.A, l);
+          mx_dma4(b_src[0] + ko, b_src[1] + ko, b_src[2] + ko, b_src[3] + ko, p.W, l + MXBM * MXBK);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -305,8 +357,10 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_persistent_kernel(MxArgs p)
         for (int ps = 0; ps < 4; ++ps) v[ps] = *reinterpret_cast<const float4*>(slab + (ps * 4 + (lane >> 4)) * MX_EPI_LD + ecol);
         if (OUT == 2) {
           const int colblock = gcol >> 5;                          // this lane's 32-column block of the output row
-          mx_epi_store<OUT, GELU, HAS_RES>(v, bias4, res[g & 1], rc, coff0 + g * 4 * cstep, cstep, p.sC + (int64_t)(colblock >> 2) * p.ldsc + (colblock & 3),
-                                           row0 + g * 16, p.M, lane);
+          const int64_t left = p.M - (row0 + g * 16);            // rows_left <= 0 for every lane that must not write a scale byte
+          const uint32_t sc_off = (uint32_t)((int64_t)(colblock >> 2) * p.ldsc + (colblock & 3) + (row0 + g * 16) * 4);
+          mx_epi_store<OUT, GELU, HAS_RES>(v, bias4, res[g & 1], rc, coff0 + g * 4 * cstep, cstep, rsc, sc_off,
+                                           (lane & 7) == 0 ? (int)(left > 64 ? 64 : left) : 0);
         } else {
           mx_epi_store<OUT, GELU, HAS_RES>(v, bias4, res[g & 1], rc, coff0 + g * 4 * cstep, cstep);
         }
@@ -365,6 +419,7 @@ extern "C" int sf_gemm_mxfp8(const uint8_t* A, int64_t lda, const uint8_t* sA, i
   const int64_t m_pad = ((M + 255) / 256) * 256;
   SF_CHECK_ARG(m_pad * ldc * (c_dtype == SF_U8 ? 1 : c_dtype == SF_BF16 ? 2 : 4) < ((int64_t)1 << 32) && (!R || m_pad * ldr * 4 < ((int64_t)1 << 32)),
                "sf_gemm_mxfp8: C / R must stay below 4 GiB");
+  SF_CHECK_ARG(c_dtype != SF_U8 || (N / MXBK) * ldsc < ((int64_t)1 << 31), "sf_gemm_mxfp8: the output scale planes must stay below 2 GiB");
   SF_CHECK_ARG(M * lda < ((int64_t)1 << 32) && N * ldw < ((int64_t)1 << 32) && (K / MXBK) * ldsa < ((int64_t)1 << 31) && (K / MXBK) * ldsw < ((int64_t)1 << 31),
                "sf_gemm_mxfp8: operands and scale matrices must stay below 4 GiB (32-bit lane offsets)");
   MxArgs a;

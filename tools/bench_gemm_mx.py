@@ -33,15 +33,18 @@ def main():
             aq, asc = torch.empty(M, K, device=dev, dtype=torch.uint8), torch.empty(K // 128, M, 4, device=dev, dtype=torch.uint8)
             wq, wsc = torch.empty(N, K, device=dev, dtype=torch.uint8), torch.empty(K // 128, N, 4, device=dev, dtype=torch.uint8)
             ops.quantize_mxfp8(w, wq, wsc)
-            t = {'bf16': [], 'quant': [], 'mx': []}
+            oq = torch.empty(M, N, device=dev, dtype=torch.uint8) if (not res and N % 128 == 0) else None       # MXFP8 output (the next GEMM's A operand)
+            osc = torch.empty(N // 128, M, 4, device=dev, dtype=torch.uint8) if oq is not None else None
+            t = {'bf16': [], 'quant': [], 'mx': [], 'mxq': []}
             for _ in range(5):
                 t['bf16'].append(timeit(lambda: ops.gemm(a, w, b, out, gelu=gelu, residual=out if res else None)))
                 t['quant'].append(timeit(lambda: ops.quantize_mxfp8(a, aq, asc)))
                 t['mx'].append(timeit(lambda: ops.gemm_mxfp8(aq, asc, wq, wsc, b, out, gelu=gelu, residual=out if res else None)))
+                t['mxq'].append(timeit(lambda: ops.gemm_mxfp8(aq, asc, wq, wsc, b, oq, gelu=gelu, out_scales=osc)) if oq is not None else 0.0)
             med = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
             fl = 2.0 * M * N * K
             print(f"{name:9s} N {N:4d} K {K:4d}: bf16 {med['bf16']:7.1f} us ({fl / med['bf16'] / 1e6:5.0f} TF) | mxfp8 {med['mx']:7.1f} us ({fl / med['mx'] / 1e6:5.0f} TF)"
-                  f" + quantise A {med['quant']:6.1f} us", flush=True)
+                  f" + quantise A {med['quant']:6.1f} us | MXFP8 out {med['mxq']:7.1f} us", flush=True)
 
 
 if __name__ == '__main__':
