@@ -105,7 +105,21 @@ class GemmTimer:
             nbytes = m * k + n * k + (m + n) * k // 32 + m * n * out.element_size() + (m * n * 4 if residual is not None else 0)
             self.mx_records.append((e0, e1, 2.0 * m * n * k, nbytes))
             return r
+        def timed_qt(x, w, bias, qkv_cls, out, partials, *, n_seq, n_groups, scale):
+            # the fused temporal qkv + time-attention launch is a GEMM launch too (sf_qkv_time_attention): 2304 x 768 over the patch rows
+            if not self.enabled:
+                return self.orig_qt(x, w, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self.orig_qt(x, w, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale)
+            e1.record()
+            m, n, k = n_seq * 8 * n_groups, 2304, 768
+            nbytes = m * k * 2 + n * k * 2 + m * 768 * 2                               # A + W read, the 768-wide attention output written
+            self.records.append((e0, e1, 2.0 * m * n * k, nbytes))
+            return r
         self.mx_records = []
+        self.orig_qt = self.ops.qkv_time_attention
+        self.ops.qkv_time_attention = timed_qt
         self.ops.gemm = timed
         self.orig_ln = self.ops.gemm_res_ln
         self.ops.gemm_res_ln = timed_ln
@@ -117,6 +131,7 @@ class GemmTimer:
         self.ops.gemm = self.orig
         self.ops.gemm_res_ln = self.orig_ln
         self.ops.gemm_mxfp8 = self.orig_mx
+        self.ops.qkv_time_attention = self.orig_qt
 
     def mx_summary(self):
         ms = sum(r[0].elapsed_time(r[1]) for r in self.mx_records)

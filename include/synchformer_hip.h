@@ -145,6 +145,17 @@ int sf_attention_cls_partial(const uint16_t* q, const uint16_t* k, const uint16_
 int sf_attention_cls_combine(const float* partials, int n_part, uint16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row,
                              int64_t n_seq, int heads, void* stream);
 
+/* The temporal half of DividedSpaceTimeBlock in ONE launch (vit_helper.py:366 `self.timeattn(self.norm3(x), ..., 'b (f n) d', '(b n) f d')`,
+ * DividedAttention.forward vit_helper.py:97-150): qkv projection (vit_helper.py:107) of every PATCH token + the 8-frame attention over
+ * [CLS key; the patch's 8 frames] in the GEMM's epilogue - the 2304-wide projection never reaches HBM.
+ * X (n_seq * (1 + 8 * n_groups), 768) bf16 = norm3(x), rows [CLS; frame-major patches] per sequence; W (2304, 768) bf16 = qkv.weight, bias 2304 fp32
+ * or NULL; qkv_cls (n_seq, 2304) bf16 = the same projection of the CLS rows (sf_gemm_bf16 on the strided CLS rows, lda = seq_rows * ldx);
+ * out (rows as X, 768) bf16: patch rows only; cls_partial [n_seq][12][n_groups / 4][66] fp32, records as in sf_attention_cls_partial (one per 4
+ * patches) - the CLS row of `out` (vit_helper.py:126) is then written by sf_attention_cls_combine(cls_partial, n_groups / 4, out, ...).
+ * 12 heads x 64; n_groups % 4 == 0; X and W below 4 GiB. */
+int sf_qkv_time_attention(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* qkv_cls, int64_t ldc,
+                          uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_groups, float scale, void* stream);
+
 /* One query row per sequence against n_keys consecutive rows (head_dim 64): the Motionformer CLS query
  * (vit_helper.py:126) and the only output row the aggregator layers ever read (motionformer.py:329-332). */
 int sf_attention_cls(const uint16_t* q, int64_t q_seq_rows, int q_row, const uint16_t* k, const uint16_t* v, int64_t ld,

@@ -1,0 +1,359 @@
+// Motionformer TIME attention fused into its qkv projection (gfx950): one launch computes, for every patch token, the temporal q | k | v of
+// DividedSpaceTimeBlock (vit_helper.py:366 -> DividedAttention.forward, vit_helper.py:97-150 with the '(b n) f d' regrouping of :343-344)
+// and the 8-frame attention over [CLS key; the patch's 8 frames] right in the GEMM's epilogue.  Un-fused (sf_gemm_bf16 -> sf_attention +
+// sf_attention_cls) the 2304-wide projection output goes to HBM (1.6 GB at 224 segments) and is read back twice; fused, only the 768-wide
+// attention output (0.54 GB) is written.
+//
+//   * GEMM tile = 256 token rows x 192 output features: the rows are 32 consecutive PATCHES x their 8 frames, GATHERED by the LDS-DMA source
+//     addresses (token (seg, f, p) lives at row seg * seq_rows + 1 + f * n_groups + p; the LDS image is lane-linear, the global side is per lane),
+//     the features are ONE head's q | k | v (W rows h*64.. of each of the three 768-row blocks).  So a workgroup ends its k-loop holding
+//     everything the time attention of 32 patches x one head needs, and nothing else.
+//   * 8 waves, wave w owns rows 32w .. 32w+31 (4 patches) x all 192 features: 6 accumulator blocks of v_mfma_f32_32x32x16_bf16 with the
+//     operands SWAPPED (C^T = W X^T), so a lane ends with ONE token's features (4 consecutive per register group) - packed to bf16 and stored to
+//     a wave-private LDS slab as rows [token][q 64 | k 64 | v 64] with 8-byte writes.
+//   * epilogue, per wave and patch: lane (frame qi, slice sub) reads q / k / v slices back with 16-byte LDS reads exactly as attn_tiny64_kernel
+//     reads them from HBM (same arithmetic: bf16 q, k, v - the accumulators are rounded to bf16 first, as the un-fused projection writes them -
+//     v_dot2 scores, base-2 softmax in fp32), the CLS key / value / query of the patch's sequence come from a small (n_seq, 2304) buffer the
+//     caller fills with the same projection of the CLS rows, and the CLS QUERY's share of these keys leaves as the (m, l, o[64]) partial of
+//     sf_attention's `cls_partial` mode, one record per wave ([seq][head][n_groups / 4][66] fp32, merged by sf_attention_cls_combine).
+//   * persistent, one workgroup per CU, heads fastest inside a row tile (the gathered A tile is re-read from L2 by the 12 head tiles), two
+//     56 KiB operand slots; the slabs (8 x 12.5 KiB) overlay slot 1, so only the next tile's FIRST k-tile is prefetched under the epilogue.
+#include "sf_common.h"
+#include <type_traits>
+#include "../../include/synchformer_hip.h"
+
+#define QT_BM 256
+#define QT_BN 192
+#define QT_BK 64
+#define QT_A_BYTES (QT_BM * 128)                 // 32 KiB
+#define QT_B_BYTES (QT_BN * 128)                 // 24 KiB
+#define QT_STAGE (QT_A_BYTES + QT_B_BYTES)       // 56 KiB
+#define QT_SLAB_LD 400                           // bytes per token row of a slab: 384 + 16 (the 16 lanes of a ds_write_b64 group hit 16 distinct bank pairs)
+#define QT_SLAB_BYTES (32 * QT_SLAB_LD)          // 12.5 KiB per wave
+#define QT_LDS (QT_STAGE + 8 * QT_SLAB_BYTES)    // 156 KiB: slot 0 | slot 1 = the first 56 KiB of the slab area
+#define QT_D 768
+#define QT_HEADS 12
+
+struct QtArgs {
+  const bf16_t* X; int64_t ldx;
+  const bf16_t* W; int64_t ldw;
+  const float* bias;
+  const bf16_t* qkv_cls; int64_t ldc;
+  bf16_t* out; int64_t ldo;
+  float* cls_part;
+  int64_t n_seq, seq_rows;
+  int n_groups;
+  float scale;
+  uint32_t tiles_m;
+};
+
+typedef __attribute__((ext_vector_type(2))) __bf16 qt_bf2;
+typedef __attribute__((ext_vector_type(2))) unsigned int qt_u32x2;
+
+__device__ __forceinline__ void qt_dma1(uint32_t voff, const void* sbase, uint32_t lds) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+__device__ __forceinline__ uint32_t qt_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+__device__ __forceinline__ void qt_wait_vmcnt0_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt((0 & 0xF) | (0x7 << 4) | (0xF << 8) | (0 << 14));
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ float qt_dot8(const uint4& a, const uint4& b) {
+  float d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(qt_bf2, a.x), __builtin_bit_cast(qt_bf2, b.x), 0.f, false);
+  d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(qt_bf2, a.y), __builtin_bit_cast(qt_bf2, b.y), d, false);
+  d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(qt_bf2, a.z), __builtin_bit_cast(qt_bf2, b.z), d, false);
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(qt_bf2, a.w), __builtin_bit_cast(qt_bf2, b.w), d, false);
+}
+__device__ __forceinline__ void qt_axpy8(sf_f32x2_t (&o)[4], float e, const uint4& v) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  const sf_f32x2_t e2 = {e, e};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const sf_f32x2_t vf = {__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
+    o[i] = e2 * vf + o[i];
+  }
+}
+// sum / max over the eight lanes sharing lane >> 3 (DPP: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror)
+__device__ __forceinline__ float qt_sum8(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+  return v;
+}
+
+__global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // persistent schedule: block b sits on XCD b % 8; every XCD owns a contiguous range of row tiles and walks (row tile, head) with the head fastest
+  const uint32_t xcd = blockIdx.x & 7u, li = blockIdx.x >> 3, per_xcd_blocks = gridDim.x >> 3;
+  const uint32_t mp8 = (p.tiles_m + 7u) >> 3;
+  const uint32_t mp0 = min(xcd * mp8, p.tiles_m), mp1 = min(mp0 + mp8, p.tiles_m);
+  const uint32_t t_end = (mp1 - mp0) * QT_HEADS;
+  uint32_t t = li;
+  if (t >= t_end) return;
+
+  const uint32_t n_patches = (uint32_t)(p.n_seq * p.n_groups);     // < 2^31 (host check): 32-bit divisions below
+  const int sw = (l31 >> 1) & 7;
+  int frag_off[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) frag_off[kk] = l31 * 128 + (((kk * 2 + hi) ^ sw) << 4);
+  const int a_base = wave * 32 * 128;
+
+  // LDS-DMA sources.  A: piece i of this wave = patch 4 * wave + i of the tile, lane (f = lane >> 3, chunk = lane & 7) -> LDS row 32 wave + 8 i + f.
+  // B: piece j = rows 24 wave + 8 j + (lane >> 3) of the head's 192 W rows (q | k | v blocks 768 rows apart; the head offset rides in the SGPR base).
+  uint32_t voff_a[4], voff_b[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int br = wave * 24 + j * 8 + (lane >> 3);
+    const int gch = (lane & 7) ^ ((br >> 1) & 7);
+    voff_b[j] = (uint32_t)(((int64_t)(br >> 6) * QT_D + (br & 63)) * p.ldw * 2 + gch * 16);
+  }
+  const char* wbase; uint32_t tm; int head;
+  auto set_tile = [&](uint32_t tt) {
+    tm = mp0 + tt / QT_HEADS; head = (int)(tt % QT_HEADS);
+    wbase = reinterpret_cast<const char*>(p.W) + (int64_t)head * 64 * p.ldw * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t g = tm * 32u + wave * 4 + i;                        // global patch index (seq, patch); the ragged last tile re-reads the last patch
+      if (g > n_patches - 1) g = n_patches - 1;
+      const uint32_t seq = g / (uint32_t)p.n_groups;
+      const int pp = (int)(g - seq * (uint32_t)p.n_groups);
+      const int f = lane >> 3;
+      const int64_t row = (int64_t)seq * p.seq_rows + 1 + (int64_t)f * p.n_groups + pp;
+      const int r = wave * 32 + i * 8 + f;
+      voff_a[i] = (uint32_t)(row * p.ldx * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
+    }
+  };
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(qt_lds_addr(smem));
+  const uint32_t lds_a_w = __builtin_amdgcn_readfirstlane(lds0 + wave * 4096), lds_b_w = __builtin_amdgcn_readfirstlane(lds0 + QT_A_BYTES + wave * 3072);
+  auto piece = [&](int pc, int slot, int kt) {                     // pc = 0 .. 3: A pieces, 4 .. 6: B pieces of k-tile kt
+    if (pc < 4) qt_dma1(voff_a[pc], reinterpret_cast<const char*>(p.X) + kt * 128, lds_a_w + slot * QT_STAGE + pc * 1024);
+    else qt_dma1(voff_b[pc - 4], wbase + kt * 128, lds_b_w + slot * QT_STAGE + (pc - 4) * 1024);
+  };
+  set_tile(t);
+#pragma unroll
+  for (int pc = 0; pc < 7; ++pc) piece(pc, 0, 0);
+
+  constexpr int nk = QT_D / QT_BK;                                  // 12 k-tiles
+  const float sc = p.scale * 1.44269504088896f;                    // softmax in base 2
+
+  for (;;) {
+    // accumulators start at the bias: block j = (q, k, v)[j >> 1], features (j & 1) * 32 + 8 g + 4 hi + i of head `head`
+    f32x16 acc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + (j >> 1) * QT_D + head * 64 + (j & 1) * 32 + g * 8 + hi * 4);
+        acc[j][g * 4 + 0] = b4.x; acc[j][g * 4 + 1] = b4.y; acc[j][g * 4 + 2] = b4.z; acc[j][g * 4 + 3] = b4.w;
+      }
+
+    // the CLS q / k / v slices of this wave's sequence (lane slice sub = lane & 7): loaded here, used in the epilogue
+    uint4 qc, kc, vc;
+    {
+      uint32_t g0 = tm * 32u + wave * 4;
+      if (g0 > n_patches - 1) g0 = n_patches - 1;
+      const bf16_t* cls = p.qkv_cls + (int64_t)(g0 / (uint32_t)p.n_groups) * p.ldc + head * 64 + (lane & 7) * 8;
+      qc = *reinterpret_cast<const uint4*>(cls);
+      kc = *reinterpret_cast<const uint4*>(cls + QT_D);
+      vc = *reinterpret_cast<const uint4*>(cls + 2 * QT_D);
+    }
+
+    auto kstep = [&](int kt, auto refill_tag) {
+      constexpr bool REFILL = decltype(refill_tag)::value;
+      qt_wait_vmcnt0_barrier();                                    // k-tile kt landed everywhere; the other slot is free (kt = 0: every wave is out of the slabs)
+      const char* st = smem + (kt & 1) * QT_STAGE;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(st + a_base + frag_off[kk]);
+        bf16x8 wf[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(st + QT_A_BYTES + j * 32 * 128 + frag_off[kk]);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf, acc[j], 0, 0, 0);
+          if (REFILL && (j == 2 || j == 5) && kk * 2 + (j == 5) < 7) {   // one LDS-DMA piece of k-tile kt + 1 behind every third MFMA
+            __builtin_amdgcn_sched_barrier(0);
+            piece(kk * 2 + (j == 5), (kt + 1) & 1, kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{});
+    kstep(nk - 1, std::false_type{});
+    // every wave is done with both slots: slot 0 takes the next tile's first k-tile, the slabs (over slot 1) take this tile's q | k | v
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const uint32_t etm = tm; const int ehead = head;
+    const uint32_t tnext = t + per_xcd_blocks;
+    const bool more = tnext < t_end;
+    if (more) {
+      set_tile(tnext);
+#pragma unroll
+      for (int pc = 0; pc < 7; ++pc) piece(pc, 0, 0);
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------------------------
+    // lane-derived values are re-derived from an opaque copy of the thread id: computed up front hipcc keeps them live across the k-loop
+    int etid = threadIdx.x;
+    asm volatile("" : "+v"(etid));
+    const int elane = etid & 63, ewave = etid >> 6, el31 = elane & 31, ehi = elane >> 5, qi = elane >> 3, sub = elane & 7;
+    char* slab = smem + QT_STAGE + ewave * QT_SLAB_BYTES;
+    // (1) accumulators -> bf16 -> slab row el31: [q 64 | k 64 | v 64], 4 consecutive features per 8-byte write
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        qt_u32x2 w;
+        w.x = pack_bf2(acc[j][g * 4 + 0], acc[j][g * 4 + 1]);
+        w.y = pack_bf2(acc[j][g * 4 + 2], acc[j][g * 4 + 3]);
+        *reinterpret_cast<qt_u32x2*>(slab + el31 * QT_SLAB_LD + (j * 32 + g * 8 + ehi * 4) * 2) = w;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // (2) per patch of this wave: lane (frame qi, slice sub) - attn_tiny64_kernel's arithmetic on LDS-resident q / k / v.  The wave's four patches
+    // belong to ONE sequence (n_groups % 4 == 0), whose CLS q / k / v slices were loaded at the top of the tile.
+    const uint32_t g0 = etm * 32u + ewave * 4;
+    const int64_t seq = (g0 < n_patches ? g0 : n_patches - 1) / (uint32_t)p.n_groups;
+    const int pp0 = (int)((g0 < n_patches ? g0 : n_patches - 1) - (uint32_t)seq * (uint32_t)p.n_groups);
+    // the CLS QUERY's share of this wave's 32 keys (plus the CLS key itself in the wave that holds patch 0): every lane keeps the running
+    // softmax state of ITS frame's tokens over the four patches; the eight frames are merged once, after the last patch
+    float rm = -INFINITY, rl = 0.f;
+    sf_f32x2_t ro[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ro[i] = sf_f32x2_t{0.f, 0.f};
+    {
+      const float c0 = qt_sum8(qt_dot8(qc, kc)) * sc;
+      if (pp0 == 0 && qi == 0) {                                   // frame-0 lanes of the first wave of a sequence carry the CLS key
+        rm = c0; rl = 1.f;
+        qt_axpy8(ro, 1.f, vc);
+      }
+    }
+#pragma unroll 1
+    for (int pi = 0; pi < 4; ++pi) {
+      if (g0 + pi >= n_patches) break;                             // wave-uniform (ragged last tile)
+      const int pp = pp0 + pi;
+      const char* prow = slab + (pi * 8) * QT_SLAB_LD + sub * 16;
+      const uint4 q = *reinterpret_cast<const uint4*>(prow + qi * QT_SLAB_LD);
+      float s[9];
+      float m;
+      {
+        const float d = qt_sum8(qt_dot8(q, kc));
+        s[0] = d * sc; m = s[0];
+      }
+      uint4 kown;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint4 kk = *reinterpret_cast<const uint4*>(prow + j * QT_SLAB_LD + 128);
+        s[j + 1] = qt_sum8(qt_dot8(q, kk)) * sc;
+        m = fmaxf(m, s[j + 1]);
+      }
+      float l = 0.f;
+      sf_f32x2_t o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = sf_f32x2_t{0.f, 0.f};
+      {
+        const float e = __builtin_amdgcn_exp2f(s[0] - m);
+        l += e; qt_axpy8(o, e, vc);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float e = __builtin_amdgcn_exp2f(s[j + 1] - m);
+        l += e;
+        qt_axpy8(o, e, *reinterpret_cast<const uint4*>(prow + j * QT_SLAB_LD + 256));
+      }
+      {
+        const float inv = 1.0f / l;
+        uint4 w;
+        w.x = pack_bf2(o[0].x * inv, o[0].y * inv); w.y = pack_bf2(o[1].x * inv, o[1].y * inv);
+        w.z = pack_bf2(o[2].x * inv, o[2].y * inv); w.w = pack_bf2(o[3].x * inv, o[3].y * inv);
+        const int64_t row = seq * p.seq_rows + 1 + (int64_t)qi * p.n_groups + pp;
+        *reinterpret_cast<uint4*>(p.out + row * p.ldo + ehead * 64 + sub * 8) = w;
+      }
+      {
+        kown = *reinterpret_cast<const uint4*>(prow + qi * QT_SLAB_LD + 128);
+        const float cs = qt_sum8(qt_dot8(qc, kown)) * sc;
+        const float nm = fmaxf(rm, cs);
+        const float a = __builtin_amdgcn_exp2f(rm - nm), e = __builtin_amdgcn_exp2f(cs - nm);   // rm = -inf at first: a = 0
+        rl = rl * a + e;
+        const sf_f32x2_t a2 = {a, a};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ro[i] = ro[i] * a2;
+        qt_axpy8(ro, e, *reinterpret_cast<const uint4*>(prow + qi * QT_SLAB_LD + 256));
+        rm = nm;
+      }
+    }
+    if (g0 < n_patches) {                                          // wave-uniform
+      float M = rm;
+      M = fmaxf(M, __shfl_xor(M, 8, 64)); M = fmaxf(M, __shfl_xor(M, 16, 64)); M = fmaxf(M, __shfl_xor(M, 32, 64));
+      const float f = __builtin_amdgcn_exp2f(rm - M);               // a frame lane without tokens (ragged tile) has rm = -inf: f = 0
+      float cl = rl * f;
+      sf_f32x2_t co[4];
+      const sf_f32x2_t f2 = {f, f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) co[i] = ro[i] * f2;
+#pragma unroll
+      for (int sh = 8; sh < 64; sh <<= 1) {
+        cl += __shfl_xor(cl, sh, 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { co[i].x += __shfl_xor(co[i].x, sh, 64); co[i].y += __shfl_xor(co[i].y, sh, 64); }
+      }
+      if (qi == 0) {
+        float* part = p.cls_part + ((seq * QT_HEADS + ehead) * (p.n_groups >> 2) + (pp0 >> 2)) * 66;
+        if (sub == 0) *reinterpret_cast<float2*>(part) = make_float2(M, cl);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float2*>(part + 2 + sub * 8 + 2 * i) = make_float2(co[i].x, co[i].y);
+      }
+    }
+    if (!more) break;
+    t = tnext;
+  }
+}
+
+// X (n_seq * seq_rows, 768) bf16: the LayerNorm'ed tokens, seq_rows = 1 + 8 * n_groups ([CLS; frame-major patches]); W (2304, 768) bf16 = [q; k; v]
+// rows, bias 2304 fp32 or NULL; qkv_cls (n_seq, 2304) bf16 = the same projection of every sequence's CLS row (sf_gemm_bf16 on the strided CLS
+// rows); out (rows as X, 768) bf16: the PATCH rows are written (row 0 of every sequence comes from sf_attention_cls_combine on cls_partial,
+// [n_seq][12][n_groups / 4][66] fp32: one record per wave = 4 patches).  Reference: vit_helper.py:97-150 (time attention of DividedSpaceTimeBlock), heads = 12, head dim 64.
+extern "C" int sf_qkv_time_attention(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* qkv_cls,
+                                     int64_t ldc, uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_groups, float scale,
+                                     void* stream) {
+  SF_CHECK_ARG(X && W && qkv_cls && out && cls_partial, "sf_qkv_time_attention: null pointer");
+  SF_CHECK_ARG((n_groups % 4) == 0, "sf_qkv_time_attention: n_groups must be a multiple of 4 (a wave's four patches share one sequence)");
+  SF_CHECK_ARG(n_groups >= 1 && (ldx % 8) == 0 && (ldw % 8) == 0 && (ldc % 8) == 0 && (ldo % 8) == 0, "sf_qkv_time_attention: row strides must be multiples of 8 elements");
+  SF_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)qkv_cls % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
+                   (!bias || ((uintptr_t)bias % 16) == 0) && ((uintptr_t)cls_partial % 8) == 0, "sf_qkv_time_attention: operands must be 16-byte aligned");
+  if (n_seq <= 0) return 0;
+  const int64_t seq_rows = 1 + 8 * (int64_t)n_groups;
+  SF_CHECK_ARG(n_seq * seq_rows * ldx * 2 < ((int64_t)1 << 32) && (int64_t)3 * QT_D * ldw * 2 < ((int64_t)1 << 32),
+               "sf_qkv_time_attention: X and W must stay below 4 GiB (32-bit lane offsets)");
+  static bool attr_set = false;
+  static int n_cu = 0;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)qkv_time_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, QT_LDS);
+    if (e != hipSuccess) { sf_set_error("sf_qkv_time_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { sf_set_error("sf_qkv_time_attention: device query failed"); return -1; }
+    n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  QtArgs a;
+  a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.qkv_cls = qkv_cls; a.ldc = ldc; a.out = out; a.ldo = ldo; a.cls_part = cls_partial;
+  a.n_seq = n_seq; a.seq_rows = seq_rows; a.n_groups = n_groups; a.scale = scale;
+  const int64_t tiles_m = (n_seq * n_groups + 31) / 32;
+  SF_CHECK_ARG(tiles_m * QT_HEADS < ((int64_t)1 << 31) && n_seq * n_groups < ((int64_t)1 << 31), "sf_qkv_time_attention: too many tiles");
+  a.tiles_m = (uint32_t)tiles_m;
+  int64_t blocks = (n_cu / 8) * 8;
+  const int64_t need = ((tiles_m * QT_HEADS + 7) / 8) * 8;
+  if (blocks > need) blocks = need;
+  hipLaunchKernelGGL(qkv_time_attn_kernel, dim3((unsigned)blocks), dim3(512), QT_LDS, (hipStream_t)stream, a);
+  SF_LAUNCH_CHECK();
+  return 0;
+}

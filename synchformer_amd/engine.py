@@ -83,6 +83,7 @@ class SynchformerEngine:
         self.audio_side_stream = os.environ.get('SF_AUDIO_SIDE_STREAM', '1') != '0'
         self.fuse_ln = os.environ.get('SF_FUSE_LN', '1') != '0'            # A/B switches of the full-row GEMM + residual + LayerNorm kernel
         self.fuse_ln_fc2 = os.environ.get('SF_FUSE_LN_FC2', '1') != '0'   # K = 3072: 1932 us fused vs 1708 + 277 us (profiles/r02_gemm_ln.md)
+        self.fuse_time = os.environ.get('SF_FUSE_TIME', '1') != '0'       # temporal qkv projection + time attention in one launch (sf_qkv_time_attention)
         self._a_side = None
         self.load_weights(state_dict)
 
@@ -298,16 +299,28 @@ class SynchformerEngine:
         # sub-layer (sf_gemm_res_ln768: the fp32 stream is read and written once per sub-layer, no separate LayerNorm launch); the last block's
         # fc2 stays un-fused because the norm after it is the row-mapped final norm below.
         fuse_ln = self.fuse_ln and rows >= 128 * 64
+        fuse_time = self.fuse_time and tok_keep is None and rows >= 128 * 64    # the fused kernel has no key masks
+        att = big[:rows * D].view(rows, D)                                        # the time block's attention output (its qkv never exists)
+        qkv_cls = self._buf('qkv_cls', n * 3 * D, torch.bfloat16).view(n, 3 * D)
         nb = len(self.v_blocks)
         for bi, b in enumerate(self.v_blocks):
             if bi == 0 or not fuse_ln:
                 ops.layernorm(X, b['norm3'].g, b['norm3'].b, xn, EPS_VIS)
-            ops.gemm(xn, b['t_qkv'].w, b['t_qkv'].b, qkv)
-            divided('time')
-            if fuse_ln:
-                ops.gemm_res_ln(xn, b['t_proj'].wk, b['t_proj'].b, X, b['norm1'].g, b['norm1'].b, xn, EPS_VIS)
+            if fuse_time:
+                # temporal qkv + time attention in one launch (sf_qkv_time_attention): the 2304-wide projection never reaches HBM.  The CLS rows'
+                # own projection (their k / v are every patch's first key, their q is the global CLS query) is a 224-row GEMM up front.
+                ops.gemm(xn.view(n, VIS_L, D)[:, 0], b['t_qkv'].w, b['t_qkv'].b, qkv_cls)
+                ops.qkv_time_attention(xn, b['t_qkv'].w, b['t_qkv'].b, qkv_cls, att, part, n_seq=n, n_groups=196, scale=0.125)
+                ops.attention_cls_combine(part, att, n_part=49, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
+                t_out = att
             else:
-                ops.gemm(xn, b['t_proj'].w, b['t_proj'].b, X, residual=X)
+                ops.gemm(xn, b['t_qkv'].w, b['t_qkv'].b, qkv)
+                divided('time')
+                t_out = xn
+            if fuse_ln:
+                ops.gemm_res_ln(t_out, b['t_proj'].wk, b['t_proj'].b, X, b['norm1'].g, b['norm1'].b, xn, EPS_VIS)
+            else:
+                ops.gemm(t_out, b['t_proj'].w, b['t_proj'].b, X, residual=X)
                 ops.layernorm(X, b['norm1'].g, b['norm1'].b, xn, EPS_VIS)
             ops.gemm(xn, b['s_qkv'].w, b['s_qkv'].b, qkv)
             divided('space')

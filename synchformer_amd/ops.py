@@ -238,6 +238,21 @@ def attention_cls_partial(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out
     return out
 
 
+def qkv_time_attention(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], qkv_cls: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, *,
+                       n_seq: int, n_groups: int, scale: float):
+    """Temporal qkv projection + time attention of every patch token in one launch (sf_qkv_time_attention): x (n_seq * (1 + 8 n_groups), 768) bf16,
+    w (2304, 768) bf16, qkv_cls (n_seq, 2304) bf16 = the projection of the CLS rows; out: patch rows of the attention output, partials: the CLS
+    query's softmax partials, one per 4 patches, for attention_cls_combine(n_part=n_groups // 4)."""
+    assert x.dtype == w.dtype == qkv_cls.dtype == out.dtype == torch.bfloat16 and partials.dtype == torch.float32
+    assert x.shape[1] == 768 and tuple(w.shape) == (2304, 768) and qkv_cls.shape[0] >= n_seq and qkv_cls.shape[1] == 2304 and out.shape[1] == 768
+    assert x.shape[0] >= n_seq * (1 + 8 * n_groups) and out.shape[0] >= n_seq * (1 + 8 * n_groups) and partials.numel() >= n_seq * 12 * (n_groups // 4) * 66 and n_groups % 4 == 0
+    rc = _lib.load().sf_qkv_time_attention(_dev(x, 'x'), _ld(x), _dev(w, 'w'), _ld(w), _dev(bias, 'bias') if bias is not None else None,
+                                           _dev(qkv_cls, 'qkv_cls'), _ld(qkv_cls), _dev(out, 'out'), _ld(out), _dev(partials, 'partials'), n_seq, n_groups,
+                                           float(scale), _stream())
+    _lib.check(rc, 'sf_qkv_time_attention')
+    return out
+
+
 def attention_cls_combine(partials: torch.Tensor, out: torch.Tensor, *, n_part: int, n_seq: int, out_seq_rows: int, out_row: int, heads: int):
     rc = _lib.load().sf_attention_cls_combine(_dev(partials, 'partials'), n_part, _dev(out, 'out'), _ld(out), out_seq_rows, out_row, n_seq, heads,
                                               _stream())

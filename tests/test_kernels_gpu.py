@@ -423,6 +423,50 @@ def test_layernorm_mxfp8_and_fp8_epilogue(gpu):
     assert torch.equal(h0, h1[:M]) and torch.equal(hs0, hs1[:, :M]) and (h1[M:] == 9).all() and (hs1[:, M:] == 0).all()
 
 
+@pytest.mark.parametrize('n_seq', [3, 70])
+def test_qkv_time_attention(gpu, n_seq):
+    """sf_qkv_time_attention (temporal qkv projection + time attention + CLS-query partials in one launch) against the un-fused sequence it
+    replaces: sf_gemm_bf16 -> sf_attention (time groups, CLS key first) + sf_attention_cls.  Both round the projection to bf16 before the
+    attention, but sum over k in different tile orders: a few q / k / v elements land one bf16 ulp apart, so the outputs agree to one ulp of
+    their magnitude (|o| < 2: 2^-7), not bit for bit.  n_seq = 3: a ragged last tile
+    (588 patches = 18.4 tiles); 70: several tile rounds, tiles straddling sequences."""
+    from synchformer_amd import ops
+    L, D = 1569, 768
+    rows = n_seq * L
+    x = _bf(_rand(rows, D, seed=50)).to(gpu)
+    w, b = _bf(_rand(3 * D, D, seed=51, scale=0.05)).to(gpu), (0.1 * _rand(3 * D, seed=52)).to(gpu)
+    # un-fused
+    qkv = torch.empty(rows, 3 * D, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(x, w, b, qkv)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    ref = torch.zeros(rows, D, device=gpu, dtype=torch.bfloat16)
+    ops.attention(q, k, v, ref, n_seq=n_seq, seq_rows=L, cls_row=0, heads=12, head_dim=64, scale=0.125, n_groups=196, row0=1, group_stride=1, tok_stride=196, n_tok=8)
+    ops.attention_cls(q, k, v, ref, n_seq=n_seq, q_seq_rows=L, q_row=0, kv_seq_rows=L, kv_row0=0, n_keys=L, out_seq_rows=L, out_row=0, heads=12, head_dim=64,
+                      scale=0.125)
+    # fused
+    qkv_cls = torch.empty(n_seq, 3 * D, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(x.view(n_seq, L, D)[:, 0], w, b, qkv_cls)
+    assert torch.equal(qkv_cls, qkv.view(n_seq, L, 3 * D)[:, 0])
+    out = torch.full((rows, D), 7.0, device=gpu, dtype=torch.bfloat16)
+    part = torch.empty(n_seq * 12 * 196 * 66, device=gpu)
+    ops.qkv_time_attention(x, w, b, qkv_cls, out, part, n_seq=n_seq, n_groups=196, scale=0.125)
+    assert (out.view(n_seq, L, D)[:, 0] == 7.0).all(), 'the fused kernel must not touch the CLS rows'
+    ops.attention_cls_combine(part, out, n_part=49, n_seq=n_seq, out_seq_rows=L, out_row=0, heads=12)
+    o, r = out.float().view(n_seq, L, D), ref.float().view(n_seq, L, D)
+    torch.testing.assert_close(o[:, 1:], r[:, 1:], rtol=2 ** -7, atol=2 ** -7)
+    assert (o[:, 1:] - r[:, 1:]).abs().gt(1e-3).float().mean() < 2e-3                    # ... and those are rare
+    torch.testing.assert_close(o[:, 0], r[:, 0], rtol=2 ** -6, atol=2 ** -7)
+    # and against fp32 torch on the bf16 projection (independent of the un-fused kernels)
+    qf = qkv.float().view(n_seq, L, 3, 12, 64)
+    qq, kk, vv = qf[:, :, 0], qf[:, :, 1], qf[:, :, 2]                                   # (n, L, 12, 64)
+    pk = torch.cat([kk[:, :1].unsqueeze(2).expand(-1, -1, 196, -1, -1), kk[:, 1:].reshape(n_seq, 8, 196, 12, 64)], 1)   # (n, 9, 196, 12, 64)
+    pv = torch.cat([vv[:, :1].unsqueeze(2).expand(-1, -1, 196, -1, -1), vv[:, 1:].reshape(n_seq, 8, 196, 12, 64)], 1)
+    pq = qq[:, 1:].reshape(n_seq, 8, 196, 12, 64)
+    att = torch.einsum('nfphd,ngphd->nphfg', pq, pk) * 0.125
+    po = torch.einsum('nphfg,ngphd->nfphd', att.softmax(-1), pv).reshape(n_seq, 8 * 196, D)
+    torch.testing.assert_close(o[:, 1:], po, rtol=2 ** -7, atol=2 ** -7)
+
+
 @pytest.mark.parametrize('cfg', [7, 10])
 def test_gemm_persistent_epilogues(gpu, cfg):
     """The persistent 256x256 kernels (8 waves, 4 waves) over several tile rounds with a ragged last row

@@ -43,12 +43,12 @@ if bench:
 lines += ['| kernel | calls | total ms | avg us | % |', '|---|---|---|---|---|']
 for r in stats[:16]:
     lines.append(f'| `{short(r["Name"])}` | {r["Calls"]} | {float(r["TotalDurationNs"]) / 1e6:.1f} | {float(r["AverageNs"]) / 1e3:.1f} | {float(r["Percentage"]):.1f} |')
-gem = [r for r in stats if 'gemm_bf16' in r['Name'] or 'gemm_res_ln768' in r['Name']]
+gem = [r for r in stats if 'gemm_bf16' in r['Name'] or 'gemm_res_ln768' in r['Name'] or 'qkv_time_attn' in r['Name']]
 if gem:
     calls_g = sum(int(r['Calls']) for r in gem)
     tot_g = sum(float(r['TotalDurationNs']) for r in gem) / 1e6
     tot_all = sum(float(r['TotalDurationNs']) for r in stats) / 1e6
-    lines += ['', f'All `sf_gemm_bf16` + `sf_gemm_res_ln768` kernels together (the kernel `bench.py` reports as `roofline`): {calls_g} launches over the 3 passes '
+    lines += ['', f'All `sf_gemm_bf16` + `sf_gemm_res_ln768` + `sf_qkv_time_attention` kernels together (the kernel `bench.py` reports as `roofline`): {calls_g} launches over the 3 passes '
               f'= {calls_g // 3} per step, {tot_g:.1f} ms, **{1e3 * tot_g / calls_g:.1f} us average**, {100 * tot_g / tot_all:.1f} % of GPU time '
               '(compare `roofline.launches`, `roofline.avg_launch_ms`, `roofline.share_of_step_time` of the bench line).']
 lines += ['', 'PMC per kernel (summed over all dispatches of the run, then per launch).  FETCH_SIZE/WRITE_SIZE are in KiB as rocprofv3',
@@ -66,12 +66,12 @@ for k, c in sorted(pmc.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE', 0))
     bank = 100 * c.get('SQ_LDS_BANK_CONFLICT', 0) / max(c.get('SQ_LDS_IDX_ACTIVE', 0), 1)
     lines.append(f'| `{k[:70]}` | {n} | {fetch:.0f} | {write:.0f} | {mfma:.1f} | {wait:.1f} | {hit:.1f} | {bank:.1f} |')
 # HBM traffic of the roofline kernel (all sf_gemm_bf16 launches), per launch: FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, KiB -> bytes
-gk = [(k, c) for k, c in pmc.items() if ('gemm_bf16' in k or 'gemm_res_ln768' in k) and calls[k]]
+gk = [(k, c) for k, c in pmc.items() if ('gemm_bf16' in k or 'gemm_res_ln768' in k or 'qkv_time_attn' in k) and calls[k]]
 if gk:
     n_l = sum(calls[k] for k, _ in gk)
     fetch_b = sum(c.get('FETCH_SIZE', 0) for _, c in gk) * 2 * 1024
     write_b = sum(c.get('WRITE_SIZE', 0) for _, c in gk) * 1024
-    roof = {'kernel': 'sf_gemm_bf16 + sf_gemm_res_ln768 (all launches)', 'launches_profiled': n_l, 'hbm_read_bytes_per_launch': fetch_b / n_l,
+    roof = {'kernel': 'sf_gemm_bf16 + sf_gemm_res_ln768 + sf_qkv_time_attention (all launches)', 'launches_profiled': n_l, 'hbm_read_bytes_per_launch': fetch_b / n_l,
             'hbm_write_bytes_per_launch': write_b / n_l, 'traffic_bytes_per_launch': (fetch_b + write_b) / n_l,
             'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_bench.sh (FETCH_SIZE x2 per MI355X_MICROARCH.md)'}
     Path(f'{dst}_roofline.json').write_text(json.dumps(roof, indent=1) + '\n')
