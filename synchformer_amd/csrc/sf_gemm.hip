@@ -114,6 +114,9 @@ __device__ __forceinline__ void dma4_nt(const void* g0, const void* g1, const vo
 #ifndef SF_DMA_SPREAD
 #define SF_DMA_SPREAD 1   // 1 (measured +1-2.6 %): issue the next stage's LDS-DMA behind the first two MFMA clusters instead of right after the barrier
 #endif
+#ifndef SF_EPI_WIDE
+#define SF_EPI_WIDE 1   // persistent kernel, bf16 output without residual: transposed accumulator blocks + 8-byte slab writes + 16-byte row stores
+#endif
 #ifndef SF_KROT
 #define SF_KROT 0      // (measured neutral on every shape: profiles/r02_gemm_ln.md) persistent kernel: workgroup i of an XCD walks its k-loop starting at k-tile (i * SF_KROT) % nk (0 = every workgroup starts at 0)
 #endif
@@ -465,6 +468,11 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES_PER_SIMD) void gemm_bf
 
 template <bool OUT_BF16, bool GELU, bool HAS_RES>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p) {
+  // bf16 output without residual (qkv, fc1 + GELU): the accumulator blocks are computed TRANSPOSED (operands swapped), so a lane holds four
+  // consecutive features of one token per register group; bias / GELU are applied in registers, the bf16 results go to the wave's slab as 8-byte
+  // writes (32 instead of 128 ds_write_b32 per tile) and leave as 16-byte row segments (16 dwordx4 stores instead of 32 dwordx2 - the store tail
+  // of a bf16 epilogue is store-ISSUE bound, MI355X_MICROARCH.md)
+  constexpr bool WIDE = OUT_BF16 && !HAS_RES && SF_EPI_WIDE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;                      // 2 x 4 waves, wave tile 128 x 64
@@ -561,7 +569,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = WIDE ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0)      // C^T block: lanes = tokens, registers = features
+                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         if (SF_DMA_SPREAD && refill && kk < 2) {                 // the refill's 8 LDS-DMA issues ride behind the first two MFMA clusters
           __builtin_amdgcn_sched_barrier(0);
           const uint32_t l = lds_wave + ((kt + 1) & 1) * P_STAGE;
@@ -583,6 +593,52 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p
     stage1_in_flight = false;
     if (more) { set_tile(tnext, m0, n0); stage(0, 0); if (nk > 1) { stage(1, 1); stage1_in_flight = true; } }
 
+    if (WIDE) {
+      // ---- wide bf16 epilogue: 4 passes of 32 tokens x 64 features through the wave's 4 KiB slab (rows of 128 B, 16-byte chunk c of row t at slot
+      // c ^ (t & 7), the two 8-byte halves of a chunk swapped in rows with bit 3 set: conflict-free for the 8-byte writes and the 16-byte reads) ----
+      int etid = threadIdx.x;
+      asm volatile("" : "+v"(etid));                              // lane-derived epilogue values must not be hoisted across the k-loop
+      const int el = etid & 63, el31 = el & 31, ehi = el >> 5;
+      if (en0 + wn * 64 < p.N) {                                  // wave-uniform
+        char* bslab = reinterpret_cast<char*>(slab);
+        const int colbase = en0 + wn * 64;
+        float4 bia[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            bia[j][g] = p.bias ? *reinterpret_cast<const float4*>(p.bias + colbase + j * 32 + g * 8 + ehi * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int wr_off = el31 * 128 + ((ehi ^ ((el31 >> 3) & 1)) << 3), sw7 = el31 & 7;
+        const int tr0 = el >> 3, ch = el & 7;
+        const int rd_off = tr0 * 128 + ((ch ^ (tr0 & 7)) << 4);
+        const uint32_t cbase = (uint32_t)((em0 + wm * 128 + tr0) * p.ldc + colbase + ch * 8) * 2u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              float4 x = make_float4(acc[i][j][g * 4 + 0] + bia[j][g].x, acc[i][j][g * 4 + 1] + bia[j][g].y, acc[i][j][g * 4 + 2] + bia[j][g].z,
+                                     acc[i][j][g * 4 + 3] + bia[j][g].w);
+              if (GELU) {
+                const sf_f32x2_t g0 = gelu_erf2(sf_f32x2_t{x.x, x.y}), g1 = gelu_erf2(sf_f32x2_t{x.z, x.w});
+                x.x = g0.x; x.y = g0.y; x.z = g1.x; x.w = g1.y;
+              }
+              u32x2 w; w.x = pack_bf2(x.x, x.y); w.y = pack_bf2(x.z, x.w);
+              *reinterpret_cast<u32x2*>(bslab + wr_off + (((j * 4 + g) ^ sw7) << 4)) = w;
+            }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(bslab + rd_off + rr * 8 * 128);
+            u32x4 o;
+            if (rr & 1) { o.x = v.z; o.y = v.w; o.z = v.x; o.w = v.y; } else { o = v; }
+            if (!(SF_ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(o, rc, cbase + (uint32_t)((i * 32 + rr * 8) * p.ldc) * 2u, 0, SF_EPI_STORE_AUX);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+      }
+    } else
     // ---- epilogue of tile (em0, en0): 8 branch-free groups of 16 rows x 64 cols through this wave's slab -------
     if (en0 + wn * 64 < p.N) {                                   // wave-uniform (N % 64 == 0 on this path)
       const int gcol = en0 + wn * 64 + ecol;
