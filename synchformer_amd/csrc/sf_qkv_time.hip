@@ -20,6 +20,7 @@
 //     56 KiB operand slots; the slabs (8 x 12.5 KiB) overlay slot 1, so only the next tile's FIRST k-tile is prefetched under the epilogue.
 #include "sf_common.h"
 #include <type_traits>
+#include <stdlib.h>
 #include "../../include/synchformer_hip.h"
 
 #define QT_BM 256
@@ -31,6 +32,9 @@
 #define QT_SLAB_LD 400                           // bytes per token row of a slab: 384 + 16 (the 16 lanes of a ds_write_b64 group hit 16 distinct bank pairs)
 #define QT_SLAB_BYTES (32 * QT_SLAB_LD)          // 12.5 KiB per wave
 #define QT_LDS (QT_STAGE + 8 * QT_SLAB_BYTES)    // 156 KiB: slot 0 | slot 1 = the first 56 KiB of the slab area
+#ifndef QT_ABL
+#define QT_ABL 0   // measurement builds: 1 = one of the four patch passes per wave, 2 = no operand refills, 4 = no MFMAs
+#endif
 #define QT_D 768
 #define QT_HEADS 12
 
@@ -45,6 +49,7 @@ struct QtArgs {
   int n_groups;
   float scale;
   uint32_t tiles_m;
+  uint32_t head_chunk;                                           // heads per sweep over an XCD's row tiles (divides 12)
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 qt_bf2;
@@ -114,9 +119,15 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
     const int gch = (lane & 7) ^ ((br >> 1) & 7);
     voff_b[j] = (uint32_t)(((int64_t)(br >> 6) * QT_D + (br & 63)) * p.ldw * 2 + gch * 16);
   }
+  // Inside an XCD's row-tile range the heads go in CHUNKS of `hc`: all row tiles x the chunk's heads (head fastest), then the next chunk.  With every
+  // head in flight at once (hc = 12) the XCD's L2 has to hold all of W (3.5 MB of its 4 MB) next to the streamed A tiles and thrashes: 2.4 GB
+  // fetched per launch at 224 segments for 0.54 GB of A (PMC, profiles/r02_bench_summary.md); a chunk of 6 heads keeps 1.8 MB of W resident
+  // and re-reads A once more.
+  const uint32_t hc = p.head_chunk, chunk_tiles = (mp1 - mp0) * hc;
   const char* wbase; uint32_t tm; int head;
   auto set_tile = [&](uint32_t tt) {
-    tm = mp0 + tt / QT_HEADS; head = (int)(tt % QT_HEADS);
+    const uint32_t c = tt / chunk_tiles, r = tt - c * chunk_tiles;
+    tm = mp0 + r / hc; head = (int)(c * hc + r % hc);
     wbase = reinterpret_cast<const char*>(p.W) + (int64_t)head * 64 * p.ldw * 2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -178,8 +189,9 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
         for (int j = 0; j < 6; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(st + QT_A_BYTES + j * 32 * 128 + frag_off[kk]);
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf, acc[j], 0, 0, 0);
-          if (REFILL && (j == 2 || j == 5) && kk * 2 + (j == 5) < 7) {   // one LDS-DMA piece of k-tile kt + 1 behind every third MFMA
+          if (!(QT_ABL & 4)) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf, acc[j], 0, 0, 0);
+          else if (j == 0) acc[0][0] += (float)xf[0] + (float)wf[0][0] + (float)wf[5][0];
+          if (REFILL && !(QT_ABL & 2) && (j == 2 || j == 5) && kk * 2 + (j == 5) < 7) {   // one LDS-DMA piece of k-tile kt + 1 behind every third MFMA
             __builtin_amdgcn_sched_barrier(0);
             piece(kk * 2 + (j == 5), (kt + 1) & 1, kt + 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
       }
     }
 #pragma unroll 1
-    for (int pi = 0; pi < 4; ++pi) {
+    for (int pi = 0; pi < (QT_ABL & 1 ? 1 : 4); ++pi) {
       if (g0 + pi >= n_patches) break;                             // wave-uniform (ragged last tile)
       const int pp = pp0 + pi;
       const char* prow = slab + (pi * 8) * QT_SLAB_LD + sub * 16;
@@ -350,6 +362,9 @@ extern "C" int sf_qkv_time_attention(const uint16_t* X, int64_t ldx, const uint1
   const int64_t tiles_m = (n_seq * n_groups + 31) / 32;
   SF_CHECK_ARG(tiles_m * QT_HEADS < ((int64_t)1 << 31) && n_seq * n_groups < ((int64_t)1 << 31), "sf_qkv_time_attention: too many tiles");
   a.tiles_m = (uint32_t)tiles_m;
+  static int env_hc = -1;
+  if (env_hc < 0) { const char* e = getenv("SF_QT_HEAD_CHUNK"); env_hc = e ? atoi(e) : 6; if (env_hc < 1 || QT_HEADS % env_hc) env_hc = 6; }
+  a.head_chunk = (uint32_t)env_hc;
   int64_t blocks = (n_cu / 8) * 8;
   const int64_t need = ((tiles_m * QT_HEADS + 7) / 8) * 8;
   if (blocks > need) blocks = need;
