@@ -90,6 +90,23 @@ __device__ __forceinline__ float qt_sum8(float v) {
   return v;
 }
 
+// sum over the lane pair (lane ^ 1); max / sum over the 16 lanes of a DPP row (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror)
+__device__ __forceinline__ float qt_sum2(float v) { return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float qt_max_row16(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0xB1, 0xF, 0xF, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x4E, 0xF, 0xF, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x141, 0xF, 0xF, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x140, 0xF, 0xF, false)));
+  return v;
+}
+__device__ __forceinline__ float qt_sum_row16(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
 __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -166,15 +183,20 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
         acc[j][g * 4 + 0] = b4.x; acc[j][g * 4 + 1] = b4.y; acc[j][g * 4 + 2] = b4.z; acc[j][g * 4 + 3] = b4.w;
       }
 
-    // the CLS q / k / v slices of this wave's sequence (lane slice sub = lane & 7): loaded here, used in the epilogue
-    uint4 qc, kc, vc;
+    // the CLS q / k / v of this wave's sequence, sliced for the two lane layouts of the epilogue: q and k by 32 head dims (lane & 1, score phase),
+    // v by 4 (lane & 15, P V phase).  Loaded here, used after the k-loop.
+    uint4 qcA[4], kcA[4];
+    qt_u32x2 vcB;
     {
       uint32_t g0 = tm * 32u + wave * 4;
       if (g0 > n_patches - 1) g0 = n_patches - 1;
-      const bf16_t* cls = p.qkv_cls + (int64_t)(g0 / (uint32_t)p.n_groups) * p.ldc + head * 64 + (lane & 7) * 8;
-      qc = *reinterpret_cast<const uint4*>(cls);
-      kc = *reinterpret_cast<const uint4*>(cls + QT_D);
-      vc = *reinterpret_cast<const uint4*>(cls + 2 * QT_D);
+      const bf16_t* cls = p.qkv_cls + (int64_t)(g0 / (uint32_t)p.n_groups) * p.ldc + head * 64;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        qcA[c] = *reinterpret_cast<const uint4*>(cls + (lane & 1) * 32 + c * 8);
+        kcA[c] = *reinterpret_cast<const uint4*>(cls + QT_D + (lane & 1) * 32 + c * 8);
+      }
+      vcB = *reinterpret_cast<const qt_u32x2*>(cls + 2 * QT_D + (lane & 15) * 4);
     }
 
     auto kstep = [&](int kt, auto refill_tag) {
@@ -218,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
     // lane-derived values are re-derived from an opaque copy of the thread id: computed up front hipcc keeps them live across the k-loop
     int etid = threadIdx.x;
     asm volatile("" : "+v"(etid));
-    const int elane = etid & 63, ewave = etid >> 6, el31 = elane & 31, ehi = elane >> 5, qi = elane >> 3, sub = elane & 7;
+    const int elane = etid & 63, ewave = etid >> 6, el31 = elane & 31, ehi = elane >> 5;
     char* slab = smem + QT_STAGE + ewave * QT_SLAB_BYTES;
     // (1) accumulators -> bf16 -> slab row el31: [q 64 | k 64 | v 64], 4 consecutive features per 8-byte write
 #pragma unroll
@@ -231,98 +253,121 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
         *reinterpret_cast<qt_u32x2*>(slab + el31 * QT_SLAB_LD + (j * 32 + g * 8 + ehi * 4) * 2) = w;
       }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // (2) per patch of this wave: lane (frame qi, slice sub) - attn_tiny64_kernel's arithmetic on LDS-resident q / k / v.  The wave's four patches
-    // belong to ONE sequence (n_groups % 4 == 0), whose CLS q / k / v slices were loaded at the top of the tile.
+    // The wave's four patches belong to ONE sequence (n_groups % 4 == 0); np of them exist (ragged last tile).
     const uint32_t g0 = etm * 32u + ewave * 4;
-    const int64_t seq = (g0 < n_patches ? g0 : n_patches - 1) / (uint32_t)p.n_groups;
-    const int pp0 = (int)((g0 < n_patches ? g0 : n_patches - 1) - (uint32_t)seq * (uint32_t)p.n_groups);
-    // the CLS QUERY's share of this wave's 32 keys (plus the CLS key itself in the wave that holds patch 0): every lane keeps the running
-    // softmax state of ITS frame's tokens over the four patches; the eight frames are merged once, after the last patch
-    float rm = -INFINITY, rl = 0.f;
-    sf_f32x2_t ro[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ro[i] = sf_f32x2_t{0.f, 0.f};
-    {
-      const float c0 = qt_sum8(qt_dot8(qc, kc)) * sc;
-      if (pp0 == 0 && qi == 0) {                                   // frame-0 lanes of the first wave of a sequence carry the CLS key
-        rm = c0; rl = 1.f;
-        qt_axpy8(ro, 1.f, vc);
-      }
-    }
-#pragma unroll 1
-    for (int pi = 0; pi < (QT_ABL & 1 ? 1 : 4); ++pi) {
-      if (g0 + pi >= n_patches) break;                             // wave-uniform (ragged last tile)
-      const int pp = pp0 + pi;
-      const char* prow = slab + (pi * 8) * QT_SLAB_LD + sub * 16;
-      const uint4 q = *reinterpret_cast<const uint4*>(prow + qi * QT_SLAB_LD);
-      float s[9];
-      float m;
+    const int np = g0 >= n_patches ? 0 : (n_patches - g0 < 4u ? (int)(n_patches - g0) : 4);
+    if (np > 0) {                                                  // wave-uniform
+      const int64_t seq = g0 / (uint32_t)p.n_groups;
+      const int pp0 = (int)(g0 - (uint32_t)seq * (uint32_t)p.n_groups);
+      const int pi = elane >> 4;                                    // patch of this lane in both phases
+      const bool live = pi < np;
+      // (2) SCORE phase: lane (patch pi, frame qi, half sub): 32 head dims of one query.  Scores against [CLS key; the patch's 8 frames], softmax,
+      // the normalised probabilities go to the (now dead) q area of the query's own slab row; the CLS QUERY's score against the lane's own token
+      // is reduced over the wave's 32 tokens (softmax state of sf_attention's cls_partial records, one record per wave).
       {
-        const float d = qt_sum8(qt_dot8(q, kc));
-        s[0] = d * sc; m = s[0];
-      }
-      uint4 kown;
+        const int qi = (elane >> 1) & 7, sub = elane & 1, tr = elane >> 1;
+        const char* rowp = slab + tr * QT_SLAB_LD + sub * 64;
+        uint4 q4[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const uint4 kk = *reinterpret_cast<const uint4*>(prow + j * QT_SLAB_LD + 128);
-        s[j + 1] = qt_sum8(qt_dot8(q, kk)) * sc;
-        m = fmaxf(m, s[j + 1]);
-      }
-      float l = 0.f;
-      sf_f32x2_t o[4];
+        for (int c = 0; c < 4; ++c) q4[c] = *reinterpret_cast<const uint4*>(rowp + c * 16);
+        float s[9];
+        {
+          float d = qt_dot8(q4[0], kcA[0]) + qt_dot8(q4[1], kcA[1]) + qt_dot8(q4[2], kcA[2]) + qt_dot8(q4[3], kcA[3]);
+          s[0] = qt_sum2(d) * sc;
+        }
+        float m = s[0];
+        float cs = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = sf_f32x2_t{0.f, 0.f};
-      {
-        const float e = __builtin_amdgcn_exp2f(s[0] - m);
-        l += e; qt_axpy8(o, e, vc);
-      }
+        for (int j = 0; j < 8; ++j) {
+          const char* kp = slab + (pi * 8 + j) * QT_SLAB_LD + 128 + sub * 64;
+          uint4 k4[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float e = __builtin_amdgcn_exp2f(s[j + 1] - m);
-        l += e;
-        qt_axpy8(o, e, *reinterpret_cast<const uint4*>(prow + j * QT_SLAB_LD + 256));
-      }
-      {
+          for (int c = 0; c < 4; ++c) k4[c] = *reinterpret_cast<const uint4*>(kp + c * 16);
+          const float d = qt_dot8(q4[0], k4[0]) + qt_dot8(q4[1], k4[1]) + qt_dot8(q4[2], k4[2]) + qt_dot8(q4[3], k4[3]);
+          s[j + 1] = qt_sum2(d) * sc;
+          m = fmaxf(m, s[j + 1]);
+        }
+        {                                                           // the CLS query against the lane's OWN token
+          const char* kp = slab + tr * QT_SLAB_LD + 128 + sub * 64;
+          uint4 k4[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) k4[c] = *reinterpret_cast<const uint4*>(kp + c * 16);
+          cs = qt_sum2(qt_dot8(qcA[0], k4[0]) + qt_dot8(qcA[1], k4[1]) + qt_dot8(qcA[2], k4[2]) + qt_dot8(qcA[3], k4[3])) * sc;
+        }
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { s[j] = __builtin_amdgcn_exp2f(s[j] - m); l += s[j]; }
         const float inv = 1.0f / l;
-        uint4 w;
-        w.x = pack_bf2(o[0].x * inv, o[0].y * inv); w.y = pack_bf2(o[1].x * inv, o[1].y * inv);
-        w.z = pack_bf2(o[2].x * inv, o[2].y * inv); w.w = pack_bf2(o[3].x * inv, o[3].y * inv);
-        const int64_t row = seq * p.seq_rows + 1 + (int64_t)qi * p.n_groups + pp;
-        *reinterpret_cast<uint4*>(p.out + row * p.ldo + ehead * 64 + sub * 8) = w;
-      }
-      {
-        kown = *reinterpret_cast<const uint4*>(prow + qi * QT_SLAB_LD + 128);
-        const float cs = qt_sum8(qt_dot8(qc, kown)) * sc;
-        const float nm = fmaxf(rm, cs);
-        const float a = __builtin_amdgcn_exp2f(rm - nm), e = __builtin_amdgcn_exp2f(cs - nm);   // rm = -inf at first: a = 0
-        rl = rl * a + e;
-        const sf_f32x2_t a2 = {a, a};
+        // CLS-query softmax over the wave's tokens: frame lanes come in pairs (sub) holding the same score
+        const float c0 = qt_sum2(qt_dot8(qcA[0], kcA[0]) + qt_dot8(qcA[1], kcA[1]) + qt_dot8(qcA[2], kcA[2]) + qt_dot8(qcA[3], kcA[3])) * sc;
+        if (!live) cs = -INFINITY;
+        float M = qt_max_row16(cs);
+        M = fmaxf(M, __shfl_xor(M, 16, 64)); M = fmaxf(M, __shfl_xor(M, 32, 64));
+        if (pp0 == 0) M = fmaxf(M, c0);                             // the CLS key itself is counted by the wave that holds patch 0
+        const float ec = __builtin_amdgcn_exp2f(cs - M);
+        float L = qt_sum_row16(sub == 0 ? ec : 0.f);
+        L += __shfl_xor(L, 16, 64); L += __shfl_xor(L, 32, 64);
+        const float e0 = pp0 == 0 ? __builtin_amdgcn_exp2f(c0 - M) : 0.f;
+        L += e0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // every q read above is done
+        if (sub == 0) {
+          float* prow = reinterpret_cast<float*>(slab + tr * QT_SLAB_LD);
+          *reinterpret_cast<float4*>(prow) = make_float4(s[0] * inv, s[1] * inv, s[2] * inv, s[3] * inv);
+          *reinterpret_cast<float4*>(prow + 4) = make_float4(s[4] * inv, s[5] * inv, s[6] * inv, s[7] * inv);
+          prow[8] = s[8] * inv;
+          reinterpret_cast<float*>(slab + (pi * 8) * QT_SLAB_LD + 64)[qi] = ec;      // the patch's eight CLS-query weights, contiguous in its first row
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // (3) P V phase: lane (patch pi, slice ds): 4 head dims of all 8 queries of the patch - every V element is unpacked once per patch
+        const int ds = elane & 15;
+        sf_f32x2_t v[9][2];
+        v[0][0] = sf_f32x2_t{__uint_as_float(vcB.x << 16), __uint_as_float(vcB.x & 0xffff0000u)};
+        v[0][1] = sf_f32x2_t{__uint_as_float(vcB.y << 16), __uint_as_float(vcB.y & 0xffff0000u)};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ro[i] = ro[i] * a2;
-        qt_axpy8(ro, e, *reinterpret_cast<const uint4*>(prow + qi * QT_SLAB_LD + 256));
-        rm = nm;
-      }
-    }
-    if (g0 < n_patches) {                                          // wave-uniform
-      float M = rm;
-      M = fmaxf(M, __shfl_xor(M, 8, 64)); M = fmaxf(M, __shfl_xor(M, 16, 64)); M = fmaxf(M, __shfl_xor(M, 32, 64));
-      const float f = __builtin_amdgcn_exp2f(rm - M);               // a frame lane without tokens (ragged tile) has rm = -inf: f = 0
-      float cl = rl * f;
-      sf_f32x2_t co[4];
-      const sf_f32x2_t f2 = {f, f};
+        for (int j = 0; j < 8; ++j) {
+          const qt_u32x2 vv = *reinterpret_cast<const qt_u32x2*>(slab + (pi * 8 + j) * QT_SLAB_LD + 256 + ds * 8);
+          v[j + 1][0] = sf_f32x2_t{__uint_as_float(vv.x << 16), __uint_as_float(vv.x & 0xffff0000u)};
+          v[j + 1][1] = sf_f32x2_t{__uint_as_float(vv.y << 16), __uint_as_float(vv.y & 0xffff0000u)};
+        }
+        const int64_t orow0 = seq * p.seq_rows + 1 + pp0 + pi;
+        bf16_t* optr = p.out + orow0 * p.ldo + ehead * 64 + ds * 4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) co[i] = ro[i] * f2;
+        for (int qq = 0; qq < 8; ++qq) {
+          const float* prow = reinterpret_cast<const float*>(slab + (pi * 8 + qq) * QT_SLAB_LD);
+          const float4 pa = *reinterpret_cast<const float4*>(prow), pb = *reinterpret_cast<const float4*>(prow + 4);
+          const float pc = prow[8];
+          const float pj[9] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w, pc};
+          sf_f32x2_t o0 = {0.f, 0.f}, o1 = {0.f, 0.f};
 #pragma unroll
-      for (int sh = 8; sh < 64; sh <<= 1) {
-        cl += __shfl_xor(cl, sh, 64);
+          for (int j = 0; j < 9; ++j) {
+            const sf_f32x2_t pj2 = {pj[j], pj[j]};
+            o0 = pj2 * v[j][0] + o0; o1 = pj2 * v[j][1] + o1;
+          }
+          qt_u32x2 w; w.x = pack_bf2(o0.x, o0.y); w.y = pack_bf2(o1.x, o1.y);
+          if (live) *reinterpret_cast<qt_u32x2*>(optr + (int64_t)qq * p.n_groups * p.ldo) = w;
+        }
+        // the CLS query's weighted values over this patch's 8 tokens, then over the wave's patches (lanes 16 and 32 apart), + the CLS key's own share
+        {
+          const float* ep = reinterpret_cast<const float*>(slab + (pi * 8) * QT_SLAB_LD + 64);
+          const float4 ea = *reinterpret_cast<const float4*>(ep), eb = *reinterpret_cast<const float4*>(ep + 4);
+          const float ej[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+          sf_f32x2_t c0v = {0.f, 0.f}, c1v = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { co[i].x += __shfl_xor(co[i].x, sh, 64); co[i].y += __shfl_xor(co[i].y, sh, 64); }
-      }
-      if (qi == 0) {
-        float* part = p.cls_part + ((seq * QT_HEADS + ehead) * (p.n_groups >> 2) + (pp0 >> 2)) * 66;
-        if (sub == 0) *reinterpret_cast<float2*>(part) = make_float2(M, cl);
+          for (int j = 0; j < 8; ++j) {
+            const sf_f32x2_t e2 = {ej[j], ej[j]};
+            c0v = e2 * v[j + 1][0] + c0v; c1v = e2 * v[j + 1][1] + c1v;
+          }
+          float co[4] = {c0v.x, c0v.y, c1v.x, c1v.y};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float2*>(part + 2 + sub * 8 + 2 * i) = make_float2(co[i].x, co[i].y);
+          for (int i = 0; i < 4; ++i) { co[i] += __shfl_xor(co[i], 16, 64); co[i] += __shfl_xor(co[i], 32, 64); }
+          co[0] += e0 * v[0][0].x; co[1] += e0 * v[0][0].y; co[2] += e0 * v[0][1].x; co[3] += e0 * v[0][1].y;
+          if (pi == 0) {
+            float* part = p.cls_part + ((seq * QT_HEADS + ehead) * (p.n_groups >> 2) + (pp0 >> 2)) * 66;
+            if (ds == 0) *reinterpret_cast<float2*>(part) = make_float2(M, L);
+            *reinterpret_cast<float2*>(part + 2 + ds * 4) = make_float2(co[0], co[1]);
+            *reinterpret_cast<float2*>(part + 4 + ds * 4) = make_float2(co[2], co[3]);
+          }
+        }
       }
     }
     if (!more) break;
