@@ -57,9 +57,11 @@ int sf_gemm_bf16_batched(const uint16_t* A, int64_t lda, int64_t sA0, int64_t sA
 /* Split-K weight-gradient product of the train steps (autograd of every nn.Linear on the path: dW = dY^T X, e.g. the qkv / proj / fc1 / fc2
  * layers of vit_helper.py:87-141 and modeling_ast.py:199-330): part[s] (N x K, fp32) = sum over token rows m in chunk s of dY[m,:]^T X[m,:],
  * chunk s = rows [s*kc, min((s+1)*kc, M)).  dY (M x N) and X (M x K) are the row-major bf16 activations as they are - no transposed copies.
- * N % 128 == 0, K % 128 == 0, kc % 64 == 0, split*kc >= M.  The caller sums the `split` partials (sf_seqsum). */
-int sf_gemm_tn_splitk(const uint16_t* dY, int64_t ldy, const uint16_t* X, int64_t ldx, float* part, int64_t M, int64_t N, int64_t K,
-                      int split, int64_t kc, void* stream);
+ * N % 128 == 0, K % 128 == 0, kc % 64 == 0, split*kc >= M.  The caller sums the `split` partials (sf_seqsum).
+ * bias_part (split x N, fp32) or NULL: the same chunks' column sums of dY - the bias gradient of the layer - from four extra MFMAs against an
+ * all-ones fragment in the workgroups that already hold those dY columns; summed by sf_seqsum(bias_part, N, split, 1, N, ...). */
+int sf_gemm_tn_splitk(const uint16_t* dY, int64_t ldy, const uint16_t* X, int64_t ldx, float* part, float* bias_part, int64_t M, int64_t N,
+                      int64_t K, int split, int64_t kc, void* stream);
 
 /* Full-row projection fused with the residual add and the NEXT LayerNorm (N = 768 fixed):
  *   X[m,:] = A[m,:] W^T + bias + R[m,:]  (fp32; X may alias R),   Y[m,:] = LayerNorm(X[m,:]) * gamma + beta  (bf16; Y may alias A).

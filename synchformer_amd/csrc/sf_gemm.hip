@@ -1096,6 +1096,8 @@ struct TnArgs {
   int64_t M;                           // valid token rows
   int kc;                              // token rows per split chunk (multiple of 64)
   uint32_t tiles_n;                    // column tiles (K / 128)
+  int64_t ldc_n;                       // N (row length of bias_part)
+  float* bias_part;                    // optional (split, N) fp32: per-chunk column sums of dY (the bias gradient's partials)
 };
 #define TN_BK 32                       // token rows per stage: one 32-deep MFMA k-step
 #define TN_NS 4                        // ring slots: three stages in flight while one is being multiplied
@@ -1170,6 +1172,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_splitk_kernel(TnArgs p) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = p.bias_part != nullptr && tn == 0 && wn == 0;
+  f32x4 accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
   for (int s_ = 0; s_ < TN_NS - 1; ++s_)
@@ -1195,6 +1201,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_splitk_kernel(TnArgs p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    if (do_bias) {                                                // wave-uniform: the column-tile-0 workgroups' wn == 0 waves
+      const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
+    }
+  }
+  // bias gradient partials: against an all-ones B fragment every column of the 16 x 16 block is the row sum of the dY^T fragment, i.e. the
+  // column sum of dY over this chunk's token rows - four extra MFMAs per k-step in 1 / (2 K/128) of the waves instead of a separate pass over dY
+  if (do_bias && fr == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<float4*>(p.bias_part + (int64_t)blockIdx.y * (p.ldc_n) + i0 + wm * 64 + i * 16 + fg * 4) = make_float4(accb[i][0], accb[i][1], accb[i][2], accb[i][3]);
   }
   __syncthreads();                                               // operand LDS becomes per-wave epilogue scratch
 
@@ -1220,8 +1238,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_splitk_kernel(TnArgs p) {
 }
 
 // part (split, N, K) fp32 <- per-chunk dY^T X; chunk s covers token rows [s*kc, min((s+1)*kc, M)).  The caller sums the chunks (sf_seqsum).
-extern "C" int sf_gemm_tn_splitk(const bf16_t* dY, int64_t ldy, const bf16_t* X, int64_t ldx, float* part, int64_t M, int64_t N, int64_t K,
-                                 int split, int64_t kc, void* stream) {
+// bias_part (split, N) fp32 or NULL <- per-chunk column sums of dY (the bias gradient; summed by sf_seqsum(bias_part, N, split, 1, N, ...)).
+extern "C" int sf_gemm_tn_splitk(const bf16_t* dY, int64_t ldy, const bf16_t* X, int64_t ldx, float* part, float* bias_part, int64_t M, int64_t N,
+                                 int64_t K, int split, int64_t kc, void* stream) {
   SF_CHECK_ARG(dY && X && part, "sf_gemm_tn_splitk: null pointer");
   SF_CHECK_ARG(M >= 1 && N >= 128 && K >= 128 && (N % 128) == 0 && (K % 128) == 0, "sf_gemm_tn_splitk: N=%lld and K=%lld must be multiples of 128",
                (long long)N, (long long)K);
@@ -1238,6 +1257,8 @@ extern "C" int sf_gemm_tn_splitk(const bf16_t* dY, int64_t ldy, const bf16_t* X,
   TnArgs a;
   a.A = dY; a.lda = ldy; a.B = X; a.ldb = ldx; a.C = part; a.ldc = K; a.sC = N * K; a.M = M; a.kc = (int)kc;
   a.tiles_n = (uint32_t)(K / 128);
+  a.bias_part = bias_part; a.ldc_n = N;
+  SF_CHECK_ARG(!bias_part || ((uintptr_t)bias_part % 16) == 0, "sf_gemm_tn_splitk: bias_part must be 16-byte aligned");
   const int64_t tiles = (N / 128) * (K / 128);
   SF_CHECK_ARG(tiles < ((int64_t)1 << 31), "sf_gemm_tn_splitk: too many tiles");
   hipLaunchKernelGGL(gemm_tn_splitk_kernel, dim3((unsigned)tiles, (unsigned)split), dim3(256), TN_LDS, (hipStream_t)stream, a);

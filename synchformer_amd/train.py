@@ -193,13 +193,14 @@ class FlatTrainer:
         kc = ((m_pad // split + 63) // 64) * 64
         if tn:
             # dW straight from the row-major gradient / saved input (ds_read_b64_tr_b16 operand reads): no transposed copies
-            if dy_f32 is None:
-                ws = self._buf('colsum_ws', (N * ((M + 63) // 64),), torch.float32)
-                colsum(dy_b, M, N, self.g[bkey], ws, accumulate=acc_bias)
+            # the bias gradient (column sums of dY) rides in the same launch: per-chunk partials from an all-ones MFMA in the workgroups of column tile 0
             part = self._buf('wgrad_part', (split * N, K), torch.float32)
-            _chk(_lib.load().sf_gemm_tn_splitk(dy_b.data_ptr(), dy_b.stride(0), x_b.data_ptr(), x_b.stride(0), part.data_ptr(), M, N, K, split, kc,
-                                               _st()), 'sf_gemm_tn_splitk')
+            bpart = self._buf('bgrad_part', (split, N), torch.float32) if dy_f32 is None else None
+            _chk(_lib.load().sf_gemm_tn_splitk(dy_b.data_ptr(), dy_b.stride(0), x_b.data_ptr(), x_b.stride(0), part.data_ptr(),
+                                               bpart.data_ptr() if bpart is not None else None, M, N, K, split, kc, _st()), 'sf_gemm_tn_splitk')
             _chk(_lib.load().sf_seqsum(part.data_ptr(), K, split, N, K, self.g[wkey].data_ptr(), 0, _st()), 'sf_seqsum')
+            if bpart is not None:
+                _chk(_lib.load().sf_seqsum(bpart.data_ptr(), N, split, 1, N, self.g[bkey].data_ptr(), int(acc_bias), _st()), 'sf_seqsum')
             return self._lin_dgrad(dy_b, M, N, K, wkey, need_dx, dx_out, tag, acc_dx, dx_dtype)
         m_pad = kc * split if split > 1 else m_pad
         dyT = self._buf('dyT', (N, m_pad), torch.bfloat16)

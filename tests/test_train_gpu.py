@@ -125,8 +125,16 @@ def test_tn_splitk_weight_gradient_gemm(gpu, M, N, K, split, kc):
     xw = torch.randn(M, K + 8, generator=g).bfloat16()
     dy, x = dyw.to(gpu)[:, 64:], xw.to(gpu)[:, :K]
     part = torch.full((split, N, K), float('nan'), device=gpu)
-    _lib.check(_lib.load().sf_gemm_tn_splitk(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), part.data_ptr(), M, N, K, split, kc,
+    bpart = torch.full((split, N), float('nan'), device=gpu)
+    _lib.check(_lib.load().sf_gemm_tn_splitk(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), part.data_ptr(), bpart.data_ptr(), M, N, K, split, kc,
                                              torch.cuda.current_stream().cuda_stream), 'sf_gemm_tn_splitk')
+    # the bias-gradient partials of the same launch: per-chunk column sums of dY (all-ones MFMA in the column-tile-0 workgroups)
+    ref_b = torch.stack([dyw[min(M, s_ * kc):min(M, (s_ + 1) * kc), 64:].double().sum(0) for s_ in range(split)])
+    torch.testing.assert_close(bpart.cpu().double(), ref_b, rtol=1e-4, atol=2e-3)
+    part2 = torch.full((split, N, K), float('nan'), device=gpu)                 # and without them (NULL): same weight-gradient partials
+    _lib.check(_lib.load().sf_gemm_tn_splitk(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), part2.data_ptr(), None, M, N, K, split, kc,
+                                             torch.cuda.current_stream().cuda_stream), 'sf_gemm_tn_splitk')
+    assert torch.equal(part, part2)
     got = part.cpu().double()
     for s_ in range(split):
         lo, hi = min(M, s_ * kc), min(M, (s_ + 1) * kc)
