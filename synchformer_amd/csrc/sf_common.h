@@ -74,22 +74,25 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // exact-erf GELU (nn.GELU default), 0.5 x (1 + erf(x / sqrt 2)) = 0.5 x + 0.5 |x| erf(|x| / sqrt 2), with erf from
 // Abramowitz-Stegun 7.1.28:  erf(z) = 1 - (1 + a1 z + ... + a6 z^6)^-16, |err| <= 3e-7 (measured in fp32 against float64 over
-// [-12, 12]: |gelu err| <= 8.8e-7, a fifth of a bf16 half-ulp at worst).  ONE transcendental (v_rcp) and no exp; the polynomial
+// [-12, 12]: |gelu err| <= 7.1e-7 in the folded form below, a fifth of a bf16 half-ulp at worst).  ONE transcendental (v_rcp) and no exp; the polynomial
 // and the four squarings are written on float2 so hipcc emits v_pk_fma_f32 / v_pk_mul_f32 (two elements per instruction): ~9
 // full-rate slots + 1 quarter-rate op per element, against ~17 + 2 for the 7.1.26 form (rcp AND exp) used before - the fc1
 // epilogue is VALU-bound, this is worth ~4 % on that GEMM.
 __device__ __forceinline__ sf_f32x2_t gelu_erf2(sf_f32x2_t x) {
+  // gelu(x) = max(x, 0) - 0.5 |x| (1 - erf(|x| / sqrt 2)) = max(x, 0) - 0.5 |x| / t^16,  t = 1 + b1 |x| + ... + b6 |x|^6 with b_k = a_k / sqrt(2)^k folded
+  // (15 scalar-equivalent operations per element instead of 17: no separate z = |x| / sqrt 2, no 1 - r).  Every finite x is handled (t^16 overflows to
+  // inf beyond |x| ~ 25: r = 0); x = +-inf itself gives 0 * inf = NaN where nn.GELU gives +inf / 0.
   const sf_f32x2_t ax = {__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
-  const sf_f32x2_t z = ax * 0.70710678118654752f;
-  sf_f32x2_t p = z * 0.0000430638f + 0.0002765672f;
-  p = p * z + 0.0001520143f;
-  p = p * z + 0.0092705272f;
-  p = p * z + 0.0422820123f;
-  p = p * z + 0.0705230784f;
-  p = p * z + 1.0f;
+  sf_f32x2_t p = ax * 5.3829750000e-06f + 4.8890635643e-05f;
+  p = p * ax + 3.8003575000e-05f;
+  p = p * ax + 3.2776263241e-03f;
+  p = p * ax + 2.1141006150e-02f;
+  p = p * ax + 4.9867346967e-02f;
+  p = p * ax + 1.0f;
   p = p * p; p = p * p; p = p * p; p = p * p;                  // ^16 (inf for |x| > ~25: rcp(inf) = 0, erf = 1)
   const sf_f32x2_t r = {__builtin_amdgcn_rcpf(p.x), __builtin_amdgcn_rcpf(p.y)};
-  return x * 0.5f + (ax * 0.5f) * (1.0f - r);
+  const sf_f32x2_t relu = {__builtin_fmaxf(x.x, 0.f), __builtin_fmaxf(x.y, 0.f)};
+  return (ax * -0.5f) * r + relu;
 }
 __device__ __forceinline__ float gelu_erf(float x) {
   const sf_f32x2_t v = {x, x};
