@@ -94,6 +94,22 @@ __device__ __forceinline__ sf_f32x2_t gelu_erf2(sf_f32x2_t x) {
   const sf_f32x2_t relu = {__builtin_fmaxf(x.x, 0.f), __builtin_fmaxf(x.y, 0.f)};
   return (ax * -0.5f) * r + relu;
 }
+// Two pairs in lockstep: dependent v_pk_* operations need a wait state between them (hipcc fills it with s_nop: 11 of the 29 issue slots of one
+// pair's chain); written interleaved, the second pair's operation sits in that slot.
+__device__ __forceinline__ void gelu_erf4(sf_f32x2_t& a, sf_f32x2_t& b) {
+  const sf_f32x2_t aa = {__builtin_fabsf(a.x), __builtin_fabsf(a.y)}, ab = {__builtin_fabsf(b.x), __builtin_fabsf(b.y)};
+  sf_f32x2_t pa = aa * 5.3829750000e-06f + 4.8890635643e-05f, pb = ab * 5.3829750000e-06f + 4.8890635643e-05f;
+  pa = pa * aa + 3.8003575000e-05f; pb = pb * ab + 3.8003575000e-05f;
+  pa = pa * aa + 3.2776263241e-03f; pb = pb * ab + 3.2776263241e-03f;
+  pa = pa * aa + 2.1141006150e-02f; pb = pb * ab + 2.1141006150e-02f;
+  pa = pa * aa + 4.9867346967e-02f; pb = pb * ab + 4.9867346967e-02f;
+  pa = pa * aa + 1.0f; pb = pb * ab + 1.0f;
+  pa = pa * pa; pb = pb * pb; pa = pa * pa; pb = pb * pb; pa = pa * pa; pb = pb * pb; pa = pa * pa; pb = pb * pb;
+  const sf_f32x2_t ra = {__builtin_amdgcn_rcpf(pa.x), __builtin_amdgcn_rcpf(pa.y)}, rb = {__builtin_amdgcn_rcpf(pb.x), __builtin_amdgcn_rcpf(pb.y)};
+  const sf_f32x2_t za = {__builtin_fmaxf(a.x, 0.f), __builtin_fmaxf(a.y, 0.f)}, zb = {__builtin_fmaxf(b.x, 0.f), __builtin_fmaxf(b.y, 0.f)};
+  a = (aa * -0.5f) * ra + za;
+  b = (ab * -0.5f) * rb + zb;
+}
 __device__ __forceinline__ float gelu_erf(float x) {
   const sf_f32x2_t v = {x, x};
   return gelu_erf2(v).x;

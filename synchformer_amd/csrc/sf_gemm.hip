@@ -139,7 +139,8 @@ __device__ __forceinline__ void epi_group_store(float4 (&v)[4], const float4& bi
     float4 x = v[ps];
     x.x += bias4.x; x.y += bias4.y; x.z += bias4.z; x.w += bias4.w;
     if (GELU) {
-      const sf_f32x2_t g0 = gelu_erf2(sf_f32x2_t{x.x, x.y}), g1 = gelu_erf2(sf_f32x2_t{x.z, x.w});
+      sf_f32x2_t g0 = {x.x, x.y}, g1 = {x.z, x.w};
+      gelu_erf4(g0, g1);
       x.x = g0.x; x.y = g0.y; x.z = g1.x; x.w = g1.y;
     }
     if (HAS_RES) { x.x += res[ps].x; x.y += res[ps].y; x.z += res[ps].z; x.w += res[ps].w; }
@@ -621,7 +622,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p
               float4 x = make_float4(acc[i][j][g * 4 + 0] + bia[j][g].x, acc[i][j][g * 4 + 1] + bia[j][g].y, acc[i][j][g * 4 + 2] + bia[j][g].z,
                                      acc[i][j][g * 4 + 3] + bia[j][g].w);
               if (GELU) {
-                const sf_f32x2_t g0 = gelu_erf2(sf_f32x2_t{x.x, x.y}), g1 = gelu_erf2(sf_f32x2_t{x.z, x.w});
+                sf_f32x2_t g0 = {x.x, x.y}, g1 = {x.z, x.w};
+                gelu_erf4(g0, g1);
                 x.x = g0.x; x.y = g0.y; x.z = g1.x; x.w = g1.y;
               }
               u32x2 w; w.x = pack_bf2(x.x, x.y); w.y = pack_bf2(x.z, x.w);

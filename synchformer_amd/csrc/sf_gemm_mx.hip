@@ -99,7 +99,8 @@ __device__ __forceinline__ void mx_epi_store(float4 (&v)[4], const float4& bias4
     float4 x = v[ps];
     x.x += bias4.x; x.y += bias4.y; x.z += bias4.z; x.w += bias4.w;
     if (GELU) {
-      const sf_f32x2_t g0 = gelu_erf2(sf_f32x2_t{x.x, x.y}), g1 = gelu_erf2(sf_f32x2_t{x.z, x.w});
+      sf_f32x2_t g0 = {x.x, x.y}, g1 = {x.z, x.w};
+      gelu_erf4(g0, g1);
       x.x = g0.x; x.y = g0.y; x.z = g1.x; x.w = g1.y;
     }
     if (HAS_RES) { x.x += res[ps].x; x.y += res[ps].y; x.z += res[ps].z; x.w += res[ps].w; }
