@@ -31,7 +31,8 @@
 #define QT_STAGE (QT_A_BYTES + QT_B_BYTES)       // 56 KiB
 #define QT_SLAB_LD 400                           // bytes per token row of a slab: 384 + 16 (the 16 lanes of a ds_write_b64 group hit 16 distinct bank pairs)
 #define QT_SLAB_BYTES (32 * QT_SLAB_LD)          // 12.5 KiB per wave
-#define QT_LDS (QT_STAGE + 8 * QT_SLAB_BYTES)    // 156 KiB: slot 0 | slot 1 = the first 56 KiB of the slab area
+#define QT_BIAS_OFF (QT_STAGE + 8 * QT_SLAB_BYTES) // 1 KiB behind the slabs: the head's q | k | v bias (192 floats), one LDS-DMA piece per tile
+#define QT_LDS (QT_BIAS_OFF + 1024)              // 157 KiB: slot 0 | slot 1 = the first 56 KiB of the slab area | bias
 #ifndef QT_ABL
 #define QT_ABL 0   // measurement builds: 1 = one of the four patch passes per wave, 2 = no operand refills, 4 = no MFMAs
 #endif
@@ -164,29 +165,30 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
     if (pc < 4) qt_dma1(voff_a[pc], reinterpret_cast<const char*>(p.X) + kt * 128, lds_a_w + slot * QT_STAGE + pc * 1024);
     else qt_dma1(voff_b[pc - 4], wbase + kt * 128, lds_b_w + slot * QT_STAGE + (pc - 4) * 1024);
   };
+  // the head's bias: lanes 0-47 of wave 0 fetch 16 bytes each of the q | k | v thirds (768 floats apart), the other lanes re-read lane 0's
+  const uint32_t voff_bias = lane < 48 ? (uint32_t)(((lane >> 4) * QT_D + (lane & 15) * 4) * 4) : 0u;
+  const uint32_t lds_bias = lds0 + QT_BIAS_OFF;
+  auto bias_piece = [&]() {                                        // wave-uniform branch; after set_tile (uses `head`)
+    if (wave == 0 && p.bias) qt_dma1(voff_bias, reinterpret_cast<const char*>(p.bias) + head * 256, lds_bias);
+  };
   set_tile(t);
 #pragma unroll
   for (int pc = 0; pc < 7; ++pc) piece(pc, 0, 0);
+  bias_piece();
 
   constexpr int nk = QT_D / QT_BK;                                  // 12 k-tiles
   const float sc = p.scale * 1.44269504088896f;                    // softmax in base 2
 
   for (;;) {
-    // accumulators start at the bias: block j = (q, k, v)[j >> 1], features (j & 1) * 32 + 8 g + 4 hi + i of head `head`
+    // accumulators start at the bias (block j = (q, k, v)[j >> 1], features (j & 1) * 32 + 8 g + 4 hi + i of head `head`), read from LDS behind the
+    // first k-step's barrier: the 192 floats arrive as an eighth LDS-DMA piece of wave 0 with the tile's first stage - 24 float4 global loads per
+    // lane and tile were 192 vector-memory instructions per workgroup and tile on a path that is the bottleneck of the k-loop
     f32x16 acc[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + (j >> 1) * QT_D + head * 64 + (j & 1) * 32 + g * 8 + hi * 4);
-        acc[j][g * 4 + 0] = b4.x; acc[j][g * 4 + 1] = b4.y; acc[j][g * 4 + 2] = b4.z; acc[j][g * 4 + 3] = b4.w;
-      }
 
     // the CLS q / k / v of this wave's sequence, sliced for the two lane layouts of the epilogue: q and k by 32 head dims (lane & 1, score phase),
-    // v by 4 (lane & 15, P V phase).  Loaded here, used after the k-loop.
+    // v by 8 (lane & 7, P V phase).  Loaded here, used after the k-loop.
     uint4 qcA[4], kcA[4];
-    qt_u32x2 vcB;
+    uint4 vcB;
     {
       uint32_t g0 = tm * 32u + wave * 4;
       if (g0 > n_patches - 1) g0 = n_patches - 1;
@@ -196,12 +198,23 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
         qcA[c] = *reinterpret_cast<const uint4*>(cls + (lane & 1) * 32 + c * 8);
         kcA[c] = *reinterpret_cast<const uint4*>(cls + QT_D + (lane & 1) * 32 + c * 8);
       }
-      vcB = *reinterpret_cast<const qt_u32x2*>(cls + 2 * QT_D + (lane & 15) * 4);
+      vcB = *reinterpret_cast<const uint4*>(cls + 2 * QT_D + (lane & 7) * 8);
     }
 
-    auto kstep = [&](int kt, auto refill_tag) {
+    auto kstep = [&](int kt, auto refill_tag, auto first_tag) {
       constexpr bool REFILL = decltype(refill_tag)::value;
+      constexpr bool FIRST = decltype(first_tag)::value;
       qt_wait_vmcnt0_barrier();                                    // k-tile kt landed everywhere; the other slot is free (kt = 0: every wave is out of the slabs)
+      if (FIRST) {
+        const float* bs = reinterpret_cast<const float*>(smem + QT_BIAS_OFF);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 b4 = p.bias ? *reinterpret_cast<const float4*>(bs + (j >> 1) * 64 + (j & 1) * 32 + g * 8 + hi * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc[j][g * 4 + 0] = b4.x; acc[j][g * 4 + 1] = b4.y; acc[j][g * 4 + 2] = b4.z; acc[j][g * 4 + 3] = b4.w;
+          }
+      }
       const char* st = smem + (kt & 1) * QT_STAGE;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
@@ -221,8 +234,9 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
         }
       }
     };
-    for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{});
-    kstep(nk - 1, std::false_type{});
+    kstep(0, std::true_type{}, std::true_type{});
+    for (int kt = 1; kt + 1 < nk; ++kt) kstep(kt, std::true_type{}, std::false_type{});
+    kstep(nk - 1, std::false_type{}, std::false_type{});
     // every wave is done with both slots: slot 0 takes the next tile's first k-tile, the slabs (over slot 1) take this tile's q | k | v
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -234,6 +248,7 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
       set_tile(tnext);
 #pragma unroll
       for (int pc = 0; pc < 7; ++pc) piece(pc, 0, 0);
+      bias_piece();
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------------------------
@@ -318,54 +333,68 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
           reinterpret_cast<float*>(slab + (pi * 8) * QT_SLAB_LD + 64)[qi] = ec;      // the patch's eight CLS-query weights, contiguous in its first row
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // (3) P V phase: lane (patch pi, slice ds): 4 head dims of all 8 queries of the patch - every V element is unpacked once per patch
-        const int ds = elane & 15;
-        sf_f32x2_t v[9][2];
-        v[0][0] = sf_f32x2_t{__uint_as_float(vcB.x << 16), __uint_as_float(vcB.x & 0xffff0000u)};
-        v[0][1] = sf_f32x2_t{__uint_as_float(vcB.y << 16), __uint_as_float(vcB.y & 0xffff0000u)};
+        // (3) P V phase: lane (patch pi, query half qh, slice ds): 8 head dims of 4 queries of the patch - every V element is unpacked twice per
+        // patch instead of once per query lane, and a query row leaves as eight 16-byte stores (store instructions, not bytes, are what the
+        // vector-memory path of a CU charges for)
+        const int qh = (elane >> 3) & 1, ds = elane & 7;
+        sf_f32x2_t v[9][4];
+        {
+          const uint32_t w[4] = {vcB.x, vcB.y, vcB.z, vcB.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[0][i] = sf_f32x2_t{__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const qt_u32x2 vv = *reinterpret_cast<const qt_u32x2*>(slab + (pi * 8 + j) * QT_SLAB_LD + 256 + ds * 8);
-          v[j + 1][0] = sf_f32x2_t{__uint_as_float(vv.x << 16), __uint_as_float(vv.x & 0xffff0000u)};
-          v[j + 1][1] = sf_f32x2_t{__uint_as_float(vv.y << 16), __uint_as_float(vv.y & 0xffff0000u)};
+          const uint4 vv = *reinterpret_cast<const uint4*>(slab + (pi * 8 + j) * QT_SLAB_LD + 256 + ds * 16);
+          const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[j + 1][i] = sf_f32x2_t{__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
         }
         const int64_t orow0 = seq * p.seq_rows + 1 + pp0 + pi;
-        bf16_t* optr = p.out + orow0 * p.ldo + ehead * 64 + ds * 4;
+        bf16_t* optr = p.out + orow0 * p.ldo + ehead * 64 + ds * 8;
 #pragma unroll
-        for (int qq = 0; qq < 8; ++qq) {
-          const float* prow = reinterpret_cast<const float*>(slab + (pi * 8 + qq) * QT_SLAB_LD);
+        for (int qq = 0; qq < 4; ++qq) {
+          const float* prow = reinterpret_cast<const float*>(slab + (pi * 8 + qh * 4 + qq) * QT_SLAB_LD);
           const float4 pa = *reinterpret_cast<const float4*>(prow), pb = *reinterpret_cast<const float4*>(prow + 4);
           const float pc = prow[8];
           const float pj[9] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w, pc};
-          sf_f32x2_t o0 = {0.f, 0.f}, o1 = {0.f, 0.f};
+          sf_f32x2_t o[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = sf_f32x2_t{0.f, 0.f};
 #pragma unroll
           for (int j = 0; j < 9; ++j) {
             const sf_f32x2_t pj2 = {pj[j], pj[j]};
-            o0 = pj2 * v[j][0] + o0; o1 = pj2 * v[j][1] + o1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = pj2 * v[j][i] + o[i];
           }
-          qt_u32x2 w; w.x = pack_bf2(o0.x, o0.y); w.y = pack_bf2(o1.x, o1.y);
-          if (live) *reinterpret_cast<qt_u32x2*>(optr + (int64_t)qq * p.n_groups * p.ldo) = w;
+          uint4 w;
+          w.x = pack_bf2(o[0].x, o[0].y); w.y = pack_bf2(o[1].x, o[1].y); w.z = pack_bf2(o[2].x, o[2].y); w.w = pack_bf2(o[3].x, o[3].y);
+          if (live) *reinterpret_cast<uint4*>(optr + (int64_t)(qh * 4 + qq) * p.n_groups * p.ldo) = w;
         }
         // the CLS query's weighted values over this patch's 8 tokens, then over the wave's patches (lanes 16 and 32 apart), + the CLS key's own share
         {
           const float* ep = reinterpret_cast<const float*>(slab + (pi * 8) * QT_SLAB_LD + 64);
           const float4 ea = *reinterpret_cast<const float4*>(ep), eb = *reinterpret_cast<const float4*>(ep + 4);
           const float ej[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
-          sf_f32x2_t c0v = {0.f, 0.f}, c1v = {0.f, 0.f};
+          sf_f32x2_t c[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) c[i] = sf_f32x2_t{0.f, 0.f};
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const sf_f32x2_t e2 = {ej[j], ej[j]};
-            c0v = e2 * v[j + 1][0] + c0v; c1v = e2 * v[j + 1][1] + c1v;
-          }
-          float co[4] = {c0v.x, c0v.y, c1v.x, c1v.y};
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { co[i] += __shfl_xor(co[i], 16, 64); co[i] += __shfl_xor(co[i], 32, 64); }
-          co[0] += e0 * v[0][0].x; co[1] += e0 * v[0][0].y; co[2] += e0 * v[0][1].x; co[3] += e0 * v[0][1].y;
-          if (pi == 0) {
+            for (int i = 0; i < 4; ++i) c[i] = e2 * v[j + 1][i] + c[i];
+          }
+          float co[8] = {c[0].x, c[0].y, c[1].x, c[1].y, c[2].x, c[2].y, c[3].x, c[3].y};
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { co[i] += __shfl_xor(co[i], 16, 64); co[i] += __shfl_xor(co[i], 32, 64); }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { co[2 * i] += e0 * v[0][i].x; co[2 * i + 1] += e0 * v[0][i].y; }
+          if (pi == 0 && qh == 0) {
             float* part = p.cls_part + ((seq * QT_HEADS + ehead) * (p.n_groups >> 2) + (pp0 >> 2)) * 66;
             if (ds == 0) *reinterpret_cast<float2*>(part) = make_float2(M, L);
-            *reinterpret_cast<float2*>(part + 2 + ds * 4) = make_float2(co[0], co[1]);
-            *reinterpret_cast<float2*>(part + 4 + ds * 4) = make_float2(co[2], co[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<float2*>(part + 2 + ds * 8 + 2 * i) = make_float2(co[2 * i], co[2 * i + 1]);
           }
         }
       }
