@@ -32,7 +32,8 @@
 #define QT_SLAB_LD 400                           // bytes per token row of a slab: 384 + 16 (the 16 lanes of a ds_write_b64 group hit 16 distinct bank pairs)
 #define QT_SLAB_BYTES (32 * QT_SLAB_LD)          // 12.5 KiB per wave
 #define QT_BIAS_OFF (QT_STAGE + 8 * QT_SLAB_BYTES) // 1 KiB behind the slabs: the head's q | k | v bias (192 floats), one LDS-DMA piece per tile
-#define QT_LDS (QT_BIAS_OFF + 1024)              // 157 KiB: slot 0 | slot 1 = the first 56 KiB of the slab area | bias
+#define QT_CLS_OFF (QT_BIAS_OFF + 1024)          // 8 x 384 B: the CLS q | k | v of every wave's sequence and head
+#define QT_LDS (QT_CLS_OFF + 8 * 384)            // 160 KiB: slot 0 | slot 1 = the first 56 KiB of the slab area | bias | CLS
 #ifndef QT_ABL
 #define QT_ABL 0   // measurement builds: 1 = one of the four patch passes per wave, 2 = no operand refills, 4 = no MFMAs
 #endif
@@ -185,20 +186,14 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
     // lane and tile were 192 vector-memory instructions per workgroup and tile on a path that is the bottleneck of the k-loop
     f32x16 acc[6];
 
-    // the CLS q / k / v of this wave's sequence, sliced for the two lane layouts of the epilogue: q and k by 32 head dims (lane & 1, score phase),
-    // v by 8 (lane & 7, P V phase).  Loaded here, used after the k-loop.
-    uint4 qcA[4], kcA[4];
-    uint4 vcB;
+    // the CLS q | k | v (3 x 128 B) of this wave's sequence and head: ONE load instruction per wave (lanes 0-23, 16 bytes each) instead of nine
+    // sliced ones, parked in 384 B of wave-private LDS behind the first k-step's wait and read back in the epilogue's two lane layouts
+    uint4 cls_raw = make_uint4(0u, 0u, 0u, 0u);
     {
       uint32_t g0 = tm * 32u + wave * 4;
       if (g0 > n_patches - 1) g0 = n_patches - 1;
       const bf16_t* cls = p.qkv_cls + (int64_t)(g0 / (uint32_t)p.n_groups) * p.ldc + head * 64;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        qcA[c] = *reinterpret_cast<const uint4*>(cls + (lane & 1) * 32 + c * 8);
-        kcA[c] = *reinterpret_cast<const uint4*>(cls + QT_D + (lane & 1) * 32 + c * 8);
-      }
-      vcB = *reinterpret_cast<const uint4*>(cls + 2 * QT_D + (lane & 7) * 8);
+      if (lane < 24) cls_raw = *reinterpret_cast<const uint4*>(cls + (lane >> 3) * QT_D + (lane & 7) * 8);
     }
 
     auto kstep = [&](int kt, auto refill_tag, auto first_tag) {
@@ -206,6 +201,7 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
       constexpr bool FIRST = decltype(first_tag)::value;
       qt_wait_vmcnt0_barrier();                                    // k-tile kt landed everywhere; the other slot is free (kt = 0: every wave is out of the slabs)
       if (FIRST) {
+        if (lane < 24) *reinterpret_cast<uint4*>(smem + QT_CLS_OFF + wave * 384 + lane * 16) = cls_raw;     // the explicit wait above covered the load
         const float* bs = reinterpret_cast<const float*>(smem + QT_BIAS_OFF);
 #pragma unroll
         for (int j = 0; j < 6; ++j)
@@ -276,6 +272,14 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
       const int pp0 = (int)(g0 - (uint32_t)seq * (uint32_t)p.n_groups);
       const int pi = elane >> 4;                                    // patch of this lane in both phases
       const bool live = pi < np;
+      const char* clsp = smem + QT_CLS_OFF + ewave * 384;
+      uint4 qcA[4], kcA[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        qcA[c] = *reinterpret_cast<const uint4*>(clsp + (elane & 1) * 64 + c * 16);
+        kcA[c] = *reinterpret_cast<const uint4*>(clsp + 128 + (elane & 1) * 64 + c * 16);
+      }
+      const uint4 vcB = *reinterpret_cast<const uint4*>(clsp + 256 + (elane & 7) * 16);
       // (2) SCORE phase: lane (patch pi, frame qi, half sub): 32 head dims of one query.  Scores against [CLS key; the patch's 8 frames], softmax,
       // the normalised probabilities go to the (now dead) q area of the query's own slab row; the CLS QUERY's score against the lane's own token
       // is reduced over the wave's 32 tokens (softmax state of sf_attention's cls_partial records, one record per wave).

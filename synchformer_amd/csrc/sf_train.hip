@@ -434,9 +434,11 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict_
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const uint2 u = reinterpret_cast<const uint2*>(pre)[i];
+  sf_f32x2_t a = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)}, b = {__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+  gelu_erf4(a, b);
   uint2 o;
-  o.x = pack_bf2(gelu_erf(__uint_as_float(u.x << 16)), gelu_erf(__uint_as_float(u.x & 0xffff0000u)));
-  o.y = pack_bf2(gelu_erf(__uint_as_float(u.y << 16)), gelu_erf(__uint_as_float(u.y & 0xffff0000u)));
+  o.x = pack_bf2(a.x, a.y);
+  o.y = pack_bf2(b.x, b.y);
   reinterpret_cast<uint2*>(act)[i] = o;
 }
 
