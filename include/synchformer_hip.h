@@ -81,7 +81,8 @@ int sf_gemm_res_ln768(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t
  * BYTES apart, lds >= rows * 4) holds 4 bytes per row = the E8M0 scales of that row's four 32-blocks in the 128-deep stage. */
 int sf_quantize_mxfp8(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scales, int64_t lds, int64_t rows, int64_t K, void* stream);
 /* sf_gemm_bf16's contract (bias, exact-erf GELU, fp32 residual, bf16|fp32 output, identity row maps) on MXFP8 operands: A (M x K) / W (N x K)
- * e4m3 bytes with their stage-major scale planes sA / sW (K/128 planes, ldsa / ldsw bytes apart, 4 bytes per row); K % 128 == 0, N % 64 == 0.  v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate.
+ * e4m3 bytes with their stage-major scale planes sA / sW (K/128 planes, ldsa / ldsw bytes apart, 4 bytes per row, the rows of a plane PADDED to whole
+ * 256-row tiles: ldsa >= ceil(M/256) * 1024, ldsw >= ceil(N/256) * 1024, 16-byte aligned - a tile's scales of one stage are fetched as one contiguous KiB); K % 128 == 0, N % 64 == 0.  v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate.
  * Replaces the nn.Linear calls at vit_helper.py:103,155,392-396 (qkv / proj / fc1 / fc2 of the DividedSpaceTimeBlocks) when the engine is built
  * with fp8 towers. */
 int sf_gemm_mxfp8(const uint8_t* A, int64_t lda, const uint8_t* sA, int64_t ldsa, const uint8_t* W, int64_t ldw, const uint8_t* sW, int64_t ldsw,

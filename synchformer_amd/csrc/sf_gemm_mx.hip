@@ -29,7 +29,8 @@
 #define MX_STAGE (2 * MXBM * MXBK)         // 64 KiB: A tile + W tile
 #define MX_EPI_LD 64
 #define MX_SLAB_BYTES (16 * MX_EPI_LD * 4) // 4 KiB per wave
-#define MX_LDS (2 * MX_STAGE + 8 * MX_SLAB_BYTES)
+#define MX_SCALE_OFF (2 * MX_STAGE)          // 2 slots x (1 KiB of A scale dwords + 1 KiB of W scale dwords) behind the operand slots
+#define MX_LDS (MX_SCALE_OFF + 4096)       // 132 KiB; the epilogue slabs overlay operand slot 1 (only stage 0 of the next tile is prefetched under the epilogue)
 #ifndef SF_MX_STORE_AUX
 #define SF_MX_STORE_AUX 2
 #endif
@@ -69,6 +70,11 @@ __device__ __forceinline__ void mx_dma4(uint32_t v0, uint32_t v1, uint32_t v2, u
       : "memory", "scc");
 }
 
+__device__ __forceinline__ void mx_dma1(uint32_t v0, const void* sbase, uint32_t l0) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(v0), "s"(sbase), "s"(l0) : "memory");
+}
 __device__ __forceinline__ void mx_dma2(uint32_t v0, uint32_t v1, const void* sbase, uint32_t l0) {
   uint32_t keep;
   asm volatile(
@@ -169,7 +175,6 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_persistent_kernel(MxArgs p)
   const int a_base = wm * 128 * 128, b_base = MXBM * MXBK + wn * 64 * 128;
 
   uint32_t a_src[4], b_src[4];                                    // byte offsets from p.A / p.W
-  uint32_t sa_off[4], sb_off[2];                                  // scale dwords of rows (wm*128 + i*32 + l31) of A / (wn*64 + j*32 + l31) of W: row * 4 within a stage plane
   auto set_tile = [&](uint32_t t, int64_t& m0, int& n0) {
     const uint32_t c = min(t / chunk_tiles, n_chunks - 1), r = t - c * chunk_tiles;
     const uint32_t gw = (c == n_chunks - 1) ? p.tiles_n - c * gchunk : gchunk;
@@ -183,13 +188,6 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_persistent_kernel(MxArgs p)
       int br = n0 + row; if (br > p.N - 1) br = p.N - 1;
       a_src[i] = (uint32_t)(ar * p.lda + gch * 16);
       b_src[i] = (uint32_t)((int64_t)br * p.ldw + gch * 16);
-      int64_t sr = m0 + wm * 128 + i * 32 + l31; if (sr > p.M - 1) sr = p.M - 1;
-      sa_off[i] = (uint32_t)(sr * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int sr = n0 + wn * 64 + j * 32 + l31; if (sr > p.N - 1) sr = p.N - 1;
-      sb_off[j] = (uint32_t)(sr * 4);
     }
   };
   const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(mx_lds_addr(smem) + (wave * 4) * 1024);
@@ -198,26 +196,25 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_persistent_kernel(MxArgs p)
     mx_dma4(a_src[0] + kt * MXBK, a_src[1] + kt * MXBK, a_src[2] + kt * MXBK, a_src[3] + kt * MXBK, p.A, l);
     mx_dma4(b_src[0] + kt * MXBK, b_src[1] + kt * MXBK, b_src[2] + kt * MXBK, b_src[3] + kt * MXBK, p.W, l + MXBM * MXBK);
   };
-  // scale matrices are STAGE-major: plane kt (ld bytes apart) holds one dword per row = the four E8M0 bytes of that row's 128-deep stage kt.  A
-  // row-major (rows, K/32) layout made every lane of these loads touch its own cache line: 3x the line requests of the operand stream itself.
-  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.sA), (short)0, (int)(uint32_t)((p.K / MXBK) * p.ldsa), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.sW), (short)0, (int)(uint32_t)((p.K / MXBK) * p.ldsw), 0x00020000);
-  auto load_scales = [&](uint32_t (&sa)[4], uint32_t (&sb)[2], int kt) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sa[i] = __builtin_amdgcn_raw_buffer_load_b32(rsa, sa_off[i], kt * (int)p.ldsa, 0);   // 32 consecutive rows = one 128-byte line
-#pragma unroll
-    for (int j = 0; j < 2; ++j) sb[j] = __builtin_amdgcn_raw_buffer_load_b32(rsb, sb_off[j], kt * (int)p.ldsw, 0);
+  // scale matrices are STAGE-major: plane kt (ld bytes apart) holds one dword per row = the four E8M0 bytes of that row's 128-deep stage kt, so the
+  // scales of a stage's 256 A rows (and of its 256 W rows) are ONE contiguous KiB = one LDS-DMA piece each (waves 0 and 1), next to the stage's 64
+  // operand pieces.  As six dword loads per lane they were 48 more vector-memory instructions per stage - on the path that bounds the k-loop.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t lds_sc = __builtin_amdgcn_readfirstlane(mx_lds_addr(smem) + MX_SCALE_OFF);
+  auto scale_piece = [&](int s, int kt, int64_t mm, int nn) {      // planes are padded to whole 256-row tiles (host check): no clamping
+    if (wave_u == 0) mx_dma1((uint32_t)lane * 16u, p.sA + (int64_t)kt * p.ldsa + mm * 4, lds_sc + s * 2048);
+    else if (wave_u == 1) mx_dma1((uint32_t)lane * 16u, p.sW + (int64_t)kt * p.ldsw + (int64_t)nn * 4, lds_sc + s * 2048 + 1024);
   };
+  const int sa_rd = MX_SCALE_OFF + (wm * 128 + l31) * 4, sb_rd = MX_SCALE_OFF + 1024 + (wn * 64 + l31) * 4;
 
   const int nk = p.K / MXBK;
   uint32_t t = li;
   if (t >= t_end) return;
   int64_t m0; int n0;
   set_tile(t, m0, n0);
-  uint32_t sa_n[4], sb_n[2];                                      // scales of the NEXT stage to be multiplied (loaded one stage ahead)
-  load_scales(sa_n, sb_n, 0);
+  scale_piece(0, 0, m0, n0);
   stage(0, 0);
-  float* slab = reinterpret_cast<float*>(smem + 2 * MX_STAGE + wave * MX_SLAB_BYTES);
+  float* slab = reinterpret_cast<float*>(smem + MX_STAGE + wave * MX_SLAB_BYTES);
   const int ecol = (lane & 15) * 4;
   const uint32_t esz = OUT == 2 ? 1u : (OUT_BF16 ? 2u : 4u);
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, (short)0, (int)(uint32_t)(p.M * p.ldc * esz), 0x00020000);
@@ -242,10 +239,10 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_persistent_kernel(MxArgs p)
       mx_wait_vmcnt0_barrier();                                    // stage kt (and its scale dwords) landed; slot (kt+1)&1 is free
       uint32_t sa_c[4], sb_c[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sa_c[i] = sa_n[i];
+      for (int i = 0; i < 4; ++i) sa_c[i] = *reinterpret_cast<const uint32_t*>(smem + sa_rd + (kt & 1) * 2048 + i * 128);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) sb_c[j] = sb_n[j];
-      if (REFILL) load_scales(sa_n, sb_n, kt + 1);                 // ahead of the refill in this wave's memory queue
+      for (int j = 0; j < 2; ++j) sb_c[j] = *reinterpret_cast<const uint32_t*>(smem + sb_rd + (kt & 1) * 2048 + j * 128);
+      if (REFILL && !(SF_MX_ABL & 2)) scale_piece((kt + 1) & 1, kt + 1, m0, n0);
       const char* sa = smem + (kt & 1) * MX_STAGE + a_base;
       const char* sb = smem + (kt & 1) * MX_STAGE + b_base;
 #pragma unroll
@@ -328,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_persistent_kernel(MxArgs p)
     const bool more = tnext < t_end;
     if (more) {
       set_tile(tnext, m0, n0);
-      load_scales(sa_n, sb_n, 0);
+      scale_piece(0, 0, m0, n0);
       stage(0, 0);
     }
 
@@ -411,8 +408,10 @@ extern "C" int sf_gemm_mxfp8(const uint8_t* A, int64_t lda, const uint8_t* sA, i
   SF_CHECK_ARG(K > 0 && (K % MXBK) == 0, "sf_gemm_mxfp8: K=%lld must be a positive multiple of 128", (long long)K);
   SF_CHECK_ARG((lda % 16) == 0 && (ldw % 16) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0,
                "sf_gemm_mxfp8: A / W rows must be 16-byte aligned");
-  SF_CHECK_ARG((ldsa % 4) == 0 && (ldsw % 4) == 0 && ldsa >= M * 4 && ldsw >= N * 4 && ((uintptr_t)sA % 4) == 0 && ((uintptr_t)sW % 4) == 0,
-               "sf_gemm_mxfp8: scale planes must hold 4 bytes per row (plane stride >= rows * 4, 4-byte aligned)");
+  SF_CHECK_ARG((ldsa % 16) == 0 && (ldsw % 16) == 0 && ldsa >= ((M + 255) / 256) * 1024 && ldsw >= ((N + 255) / 256) * 1024 && ((uintptr_t)sA % 16) == 0 &&
+                   ((uintptr_t)sW % 16) == 0,
+               "sf_gemm_mxfp8: scale planes must hold 4 bytes per row with the rows PADDED to whole 256-row tiles (plane stride >= ceil(rows / 256) * 1024 "
+               "bytes, 16-byte aligned): a tile's scales are fetched as one KiB");
   SF_CHECK_ARG((N % 64) == 0 && (ldc % 4) == 0 && (!R || (ldr % 4) == 0) && ((uintptr_t)C % 16) == 0 && (!R || ((uintptr_t)R % 16) == 0) &&
                    (!bias || ((uintptr_t)bias % 16) == 0),
                "sf_gemm_mxfp8: N %% 64 == 0 and 16-byte aligned outputs are required");

@@ -56,7 +56,7 @@ class _LinQ:
     def __init__(self, lin: '_Lin'):
         N, K = lin.w.shape
         self.q = torch.empty(N, K, device=lin.w.device, dtype=torch.uint8)
-        self.s = torch.empty(K // 128, N, 4, device=lin.w.device, dtype=torch.uint8)
+        self.s = ops.mx_scale_planes(N, K, lin.w.device)
         ops.quantize_mxfp8(lin.w, self.q, self.s)
         self.b = lin.b
 
@@ -347,9 +347,10 @@ class SynchformerEngine:
         producer is ours to change (LayerNorm -> sf_layernorm768_mxfp8, fc1 + GELU -> the GEMM's own MXFP8 epilogue); the attention kernels
         write bf16, which one sf_quantize_mxfp8 pass converts.  The residual stream, LayerNorm statistics and attention stay as in the bf16 path."""
         xq = self._buf('XQ', rows * D, torch.uint8).view(rows, D)
-        xs = self._buf('XS', 6 * rows * 4, torch.uint8).view(6, rows, 4)
+        rows_p = ((rows + 255) // 256) * 256                               # scale planes are padded to whole 256-row tiles (ops.mx_scale_planes)
+        xs = self._buf('XS', 6 * rows_p * 4, torch.uint8).view(6, rows_p, 4)
         hq = self._buf('HQ', rows * FF, torch.uint8).view(rows, FF)
-        hs = self._buf('HS', 24 * rows * 4, torch.uint8).view(24, rows, 4)
+        hs = self._buf('HS', 24 * rows_p * 4, torch.uint8).view(24, rows_p, 4)
         for b in self.v_blocks:
             mx = b['mx']
             ops.layernorm_mxfp8(X, b['norm3'].g, b['norm3'].b, xq, xs, EPS_VIS)

@@ -71,6 +71,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     return out
 
 
+def mx_scale_planes(rows: int, K: int, device) -> torch.Tensor:
+    """Stage-major E8M0 scale planes for an MXFP8 operand of `rows` x K: uint8 (K / 128, rows padded to whole 256-row tiles, 4).  The padding is what
+    lets sf_gemm_mxfp8 fetch a tile's scales of one stage as one contiguous KiB (one LDS-DMA piece)."""
+    return torch.zeros(K // 128, ((rows + 255) // 256) * 256, 4, device=device, dtype=torch.uint8)
+
+
 def quantize_mxfp8(x: torch.Tensor, q: torch.Tensor, scales: torch.Tensor, rows: Optional[int] = None):
     """bf16 x (rows, K) -> q uint8 (rows, K) OCP e4m3 bytes + scales uint8 (K / 128, >= rows, 4): E8M0, one per 32 consecutive k, stage-major
     (scales[k // 128, r, (k // 32) % 4])."""

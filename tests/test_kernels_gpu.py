@@ -368,8 +368,8 @@ def test_gemm_mxfp8(gpu, M, N, K):
     a = _bf(torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-6, 6, (M, K // 32), generator=g).float()).repeat_interleave(32, 1))
     w = _bf(torch.randn(N, K, generator=g) * 0.05 * torch.exp2(torch.randint(-4, 4, (N, K // 32), generator=g).float()).repeat_interleave(32, 1))
     b = _rand(N, seed=3)
-    aq, asc = torch.empty(M, K, device=gpu, dtype=torch.uint8), torch.empty(K // 128, M, 4, device=gpu, dtype=torch.uint8)
-    wq, wsc = torch.empty(N, K, device=gpu, dtype=torch.uint8), torch.empty(K // 128, N, 4, device=gpu, dtype=torch.uint8)
+    aq, asc = torch.empty(M, K, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(M, K, gpu)
+    wq, wsc = torch.empty(N, K, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(N, K, gpu)
     ops.quantize_mxfp8(a.to(gpu), aq, asc)
     ops.quantize_mxfp8(w.to(gpu), wq, wsc)
     ref = (_mx_dequant(aq, asc).double() @ _mx_dequant(wq, wsc).double().t()).float().cpu() + b
@@ -408,10 +408,10 @@ def test_layernorm_mxfp8_and_fp8_epilogue(gpu):
     assert torch.equal(q0, q1) and torch.equal(s0, s1)
     M, N, K = 2600, 3072, 768
     w = _bf(_rand(N, K, seed=4, scale=0.05)).to(gpu)
-    wq, ws = torch.empty(N, K, device=gpu, dtype=torch.uint8), torch.empty(K // 128, N, 4, device=gpu, dtype=torch.uint8)
+    wq, ws = torch.empty(N, K, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(N, K, gpu)
     ops.quantize_mxfp8(w, wq, ws)
     a = _bf(_rand(M, K, seed=5)).to(gpu)
-    aq, asc = torch.empty(M, K, device=gpu, dtype=torch.uint8), torch.empty(K // 128, M, 4, device=gpu, dtype=torch.uint8)
+    aq, asc = torch.empty(M, K, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(M, K, gpu)
     ops.quantize_mxfp8(a, aq, asc)
     b = _rand(N, seed=6).to(gpu)
     hb = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)

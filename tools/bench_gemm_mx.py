@@ -30,11 +30,11 @@ def main():
             w = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
             b = torch.randn(N, device=dev)
             out = torch.zeros(M, N, device=dev, dtype=out_dt)
-            aq, asc = torch.empty(M, K, device=dev, dtype=torch.uint8), torch.empty(K // 128, M, 4, device=dev, dtype=torch.uint8)
-            wq, wsc = torch.empty(N, K, device=dev, dtype=torch.uint8), torch.empty(K // 128, N, 4, device=dev, dtype=torch.uint8)
+            aq, asc = torch.empty(M, K, device=dev, dtype=torch.uint8), ops.mx_scale_planes(M, K, dev)
+            wq, wsc = torch.empty(N, K, device=dev, dtype=torch.uint8), ops.mx_scale_planes(N, K, dev)
             ops.quantize_mxfp8(w, wq, wsc)
             oq = torch.empty(M, N, device=dev, dtype=torch.uint8) if (not res and N % 128 == 0) else None       # MXFP8 output (the next GEMM's A operand)
-            osc = torch.empty(N // 128, M, 4, device=dev, dtype=torch.uint8) if oq is not None else None
+            osc = ops.mx_scale_planes(M, N, dev) if oq is not None else None
             t = {'bf16': [], 'quant': [], 'mx': [], 'mxq': []}
             for _ in range(5):
                 t['bf16'].append(timeit(lambda: ops.gemm(a, w, b, out, gelu=gelu, residual=out if res else None)))
