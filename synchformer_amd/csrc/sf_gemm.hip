@@ -553,6 +553,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // WIDE: the wave's 64 bias values as ONE load (lanes 0-15) here, at the top of the tile, handed round through the slab in the epilogue.  Loaded in
+    // the epilogue (8 float4 per lane) they sat BEHIND the next tile's 16 LDS-DMA pieces in the in-order vector-memory queue: the epilogue's first
+    // use waited for both prefetched stages to land.
+    float4 bias_raw = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (WIDE && p.bias && lane < 16 && n0 + wn * 64 < p.N) bias_raw = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + lane * 4);
 
     for (int kt = 0; kt < nk; ++kt) {
       wait_vmcnt_barrier<0>();                                   // tile kt landed everywhere; slot (kt+1)&1 is free
@@ -603,12 +608,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p
       if (en0 + wn * 64 < p.N) {                                  // wave-uniform
         char* bslab = reinterpret_cast<char*>(slab);
         const int colbase = en0 + wn * 64;
+        if (el < 16) *reinterpret_cast<float4*>(bslab + el * 16) = bias_raw;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         float4 bia[2][4];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            bia[j][g] = p.bias ? *reinterpret_cast<const float4*>(p.bias + colbase + j * 32 + g * 8 + ehi * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int g = 0; g < 4; ++g) bia[j][g] = *reinterpret_cast<const float4*>(bslab + (j * 32 + g * 8 + ehi * 4) * 4);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int wr_off = el31 * 128 + ((ehi ^ ((el31 >> 3) & 1)) << 3), sw7 = el31 & 7;
         const int tr0 = el >> 3, ch = el & 7;
         const int rd_off = tr0 * 128 + ((ch ^ (tr0 & 7)) << 4);
