@@ -374,7 +374,7 @@ def main():
                                    'Stage-1: 7 buckets launched under the backward, the wait is for what did not overlap)'}
         if n_gemm:
             ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'sf_gemm_bf16 + sf_gemm_res_ln768 (gemm_bf16_persistent_kernel, gemm_bf16_kernel, gemm_res_ln768_kernel)', 'achieved': round(ach, 1),
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'sf_gemm_bf16 + sf_gemm_res_ln768 + sf_qkv_time_attention (gemm_bf16_persistent_kernel, gemm_bf16_kernel, gemm_res_ln768_kernel, qkv_time_attn_kernel; GEMM FLOPs only - the fused LayerNorm / attention work of the last two is not counted)', 'achieved': round(ach, 1),
                                'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': round(ach / (PEAK_BF16 / 1e12), 4),
                                'traffic': pmc_traffic(), 'algorithmic_bytes_per_launch': round(gt.bytes / n_gemm),
                                'launches': n_gemm // args.steps,
