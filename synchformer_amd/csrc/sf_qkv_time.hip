@@ -11,13 +11,18 @@
 //   * 8 waves, wave w owns rows 32w .. 32w+31 (4 patches) x all 192 features: 6 accumulator blocks of v_mfma_f32_32x32x16_bf16 with the
 //     operands SWAPPED (C^T = W X^T), so a lane ends with ONE token's features (4 consecutive per register group) - packed to bf16 and stored to
 //     a wave-private LDS slab as rows [token][q 64 | k 64 | v 64] with 8-byte writes.
-//   * epilogue, per wave and patch: lane (frame qi, slice sub) reads q / k / v slices back with 16-byte LDS reads exactly as attn_tiny64_kernel
-//     reads them from HBM (same arithmetic: bf16 q, k, v - the accumulators are rounded to bf16 first, as the un-fused projection writes them -
-//     v_dot2 scores, base-2 softmax in fp32), the CLS key / value / query of the patch's sequence come from a small (n_seq, 2304) buffer the
-//     caller fills with the same projection of the CLS rows, and the CLS QUERY's share of these keys leaves as the (m, l, o[64]) partial of
-//     sf_attention's `cls_partial` mode, one record per wave ([seq][head][n_groups / 4][66] fp32, merged by sf_attention_cls_combine).
-//   * persistent, one workgroup per CU, heads fastest inside a row tile (the gathered A tile is re-read from L2 by the 12 head tiles), two
-//     56 KiB operand slots; the slabs (8 x 12.5 KiB) overlay slot 1, so only the next tile's FIRST k-tile is prefetched under the epilogue.
+//   * epilogue, per wave (its 4 patches = 32 tokens, all of one sequence): the arithmetic of attn_tiny64_kernel (bf16 q, k, v - the accumulators are
+//     rounded to bf16 first, as the un-fused projection writes them - v_dot2 scores, base-2 softmax in fp32, fp32 P V) in two lane layouts:
+//       SCORE phase, lane (patch, frame, half head): 32 head dims of one query against [CLS key; the patch's 8 frames]; the normalised probabilities
+//       go to the query's own (by then dead) q row of the slab; the CLS QUERY's score of the lane's token is reduced over the wave (DPP row
+//       operations + two cross-row shuffles) into the softmax state of one `cls_partial` record per wave ([seq][head][n_groups / 4][66] fp32 as in
+//       sf_attention's cls_partial mode, merged by sf_attention_cls_combine);
+//       P V phase, lane (patch, query half, 8-dim slice): 8 head dims of 4 queries, so every V element is unpacked twice per patch instead of once
+//       per query lane and a query row leaves as 16-byte stores; the CLS query's weighted values ride on the same unpacked V.
+//     The CLS key / value / query of the sequence come from a small (n_seq, 2304) buffer the caller fills with the same projection of the CLS rows
+//     (one 16-byte load per lane 0-23 at the top of the tile, parked in 384 B of wave-private LDS); the head's bias arrives as one LDS-DMA piece per tile.
+//   * persistent, one workgroup per CU; inside an XCD's range of row tiles the heads go in chunks of 6 (head fastest), two 56 KiB operand slots;
+//     the slabs (8 x 12.5 KiB) overlay slot 1, so only the next tile's FIRST k-tile is prefetched under the epilogue.  160 KiB of LDS exactly.
 #include "sf_common.h"
 #include <type_traits>
 #include <stdlib.h>
