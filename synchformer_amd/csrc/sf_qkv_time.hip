@@ -39,6 +39,9 @@
 #define QT_BIAS_OFF (QT_STAGE + 8 * QT_SLAB_BYTES) // 1 KiB behind the slabs: the head's q | k | v bias (192 floats), one LDS-DMA piece per tile
 #define QT_CLS_OFF (QT_BIAS_OFF + 1024)          // 8 x 384 B: the CLS q | k | v of every wave's sequence and head
 #define QT_LDS (QT_CLS_OFF + 8 * 384)            // 160 KiB: slot 0 | slot 1 = the first 56 KiB of the slab area | bias | CLS
+#ifndef QT_OUT_NT
+#define QT_OUT_NT 1   // attention output with the nt hint: read once, by the next launch (+0.4 % on the step, interleaved A/B)
+#endif
 #ifndef QT_ABL
 #define QT_ABL 0   // measurement builds: 1 = one of the four patch passes per wave, 2 = no operand refills, 4 = no MFMAs
 #endif
@@ -378,7 +381,12 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
           }
           uint4 w;
           w.x = pack_bf2(o[0].x, o[0].y); w.y = pack_bf2(o[1].x, o[1].y); w.z = pack_bf2(o[2].x, o[2].y); w.w = pack_bf2(o[3].x, o[3].y);
-          if (live) *reinterpret_cast<uint4*>(optr + (int64_t)(qh * 4 + qq) * p.n_groups * p.ldo) = w;
+          if (live) {
+            typedef __attribute__((ext_vector_type(4))) unsigned int qt_u32x4;
+            qt_u32x4* dst = reinterpret_cast<qt_u32x4*>(optr + (int64_t)(qh * 4 + qq) * p.n_groups * p.ldo);
+            const qt_u32x4 wv = {w.x, w.y, w.z, w.w};
+            if (QT_OUT_NT) __builtin_nontemporal_store(wv, dst); else *dst = wv;
+          }
         }
         // the CLS query's weighted values over this patch's 8 tokens, then over the wave's patches (lanes 16 and 32 apart), + the CLS key's own share
         {
