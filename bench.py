@@ -173,7 +173,7 @@ def cpu_baseline(seconds_budget=25.0, max_threads=16):
     ncpu = os.cpu_count() or 1
     sweep = {}
     with torch.no_grad():
-        for th in sorted({min(ncpu, c) for c in (max_threads, 32, 64, ncpu)}):
+        for th in sorted({min(ncpu, c) for c in (max_threads, 32, 64)}):   # all 256 threads of the box: 78 s per segment (oversubscribed; measured once in round 2, profiles/r02_batch_sweep.md) - not re-timed on every run
             torch.set_num_threads(th)
             O.extract_vfeats(vis[:, :1], sd)                  # warm-up (thread pool, allocator)
             t0 = time.perf_counter()
