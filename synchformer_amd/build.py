@@ -1,35 +1,66 @@
-"""Build libsynchformer_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libsynchformer_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+One object per .hip source (compiled in parallel, rebuilt only when the source or a header changed), then one link."""
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / 'csrc'
 OUT = PKG / 'lib' / 'libsynchformer_hip.so'
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wall', '-Wno-unused-function']
+OBJ = PKG / 'lib' / 'obj'
+CFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+# extra -D flags for throw-away ablation builds (tools/ab_*.sh); the product build has none
+EXTRA = os.environ.get('SF_EXTRA_FLAGS', '').split()
 
 
 def sources():
     return sorted(CSRC.glob('*.hip'))
 
 
+def _headers():
+    return sorted(CSRC.glob('*.h')) + [PKG.parent / 'include' / 'synchformer_hip.h']
+
+
+def _stale(target: Path, deps) -> bool:
+    return (not target.exists()) or any(d.stat().st_mtime > target.stat().st_mtime for d in deps)
+
+
 def needs_build() -> bool:
-    if not OUT.exists():
-        return True
-    deps = sources() + sorted(CSRC.glob('*.h')) + [PKG.parent / 'include' / 'synchformer_hip.h']
-    return any(d.stat().st_mtime > OUT.stat().st_mtime for d in deps)
+    return _stale(OUT, sources() + _headers())
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
-    if not force and not needs_build():
+    if not force and not needs_build() and not EXTRA:
         return OUT
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not Path(hipcc).exists():
         raise RuntimeError('hipcc not found; cannot build libsynchformer_hip.so')
-    OUT.parent.mkdir(parents=True, exist_ok=True)
+    OBJ.mkdir(parents=True, exist_ok=True)
+    hdrs = _headers()
+    stamp = OBJ / '.flags'
+    flags_txt = ' '.join(CFLAGS + EXTRA)
+    if not stamp.exists() or stamp.read_text() != flags_txt:
+        force = True
+    jobs = []
+    for src in sources():
+        obj = OBJ / (src.stem + '.o')
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append((src, obj))
+
+    def compile_one(job):
+        src, obj = job
+        cmd = [hipcc, *CFLAGS, *EXTRA, '-c', str(src), '-o', str(obj)]
+        if verbose:
+            print('[build]', ' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(compile_one, jobs))
+    stamp.write_text(flags_txt)
     tmp = OUT.with_suffix('.so.tmp')
-    cmd = [hipcc, *FLAGS, *map(str, sources()), '-o', str(tmp)]
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *[str(OBJ / (s.stem + '.o')) for s in sources()], '-o', str(tmp)]
     if verbose:
         print('[build]', ' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
@@ -38,4 +69,5 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
 
 if __name__ == '__main__':
-    build(force=True)
+    import sys
+    build(force='--force' in sys.argv)

@@ -21,7 +21,7 @@ def _rand(*shape, seed=0, scale=1.0):
 def test_gemm_identity_asymmetric(gpu, gemm_cfg):
     """A = I against an asymmetric W catches swapped fragment rows/cols (guide rule 16)."""
     from synchformer_amd import ops
-    K = 320
+    K = 320 if gemm_cfg != 11 else 384      # config 11 walks pairs of 64-deep k-tiles
     a = torch.eye(K)
     w = torch.arange(320 * K, dtype=torch.float32).reshape(320, K) % 251 - 125.0   # exactly representable in bf16
     out = torch.empty(K, 320, device=gpu)
@@ -29,7 +29,7 @@ def test_gemm_identity_asymmetric(gpu, gemm_cfg):
     torch.testing.assert_close(out.cpu(), w.t().contiguous(), rtol=0, atol=0)
 
 
-@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10], ids=['auto'] + [f'cfg{i}' for i in range(11)])
+@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11], ids=['auto'] + [f'cfg{i}' for i in range(12)])
 def gemm_cfg(request, gpu):
     from synchformer_amd import _lib
     _lib.load().sf_gemm_force_config(request.param)
@@ -41,7 +41,7 @@ def gemm_cfg(request, gpu):
                                    (3, 2, 768), (1568 * 2, 768, 1536), (144, 768, 256)])
 def test_gemm_bias(gpu, gemm_cfg, M, N, K):
     from synchformer_amd import ops
-    if gemm_cfg in (7, 10) and N % 64:
+    if gemm_cfg in (7, 10, 11) and N % 64:
         pytest.skip('persistent configs serve N % 64 == 0 only')
     a, w, b = _bf(_rand(M, K, seed=1)), _bf(_rand(N, K, seed=2, scale=0.05)), _rand(N, seed=3)
     ref = a.float() @ w.float().t() + b
@@ -56,7 +56,7 @@ def test_gemm_bias(gpu, gemm_cfg, M, N, K):
 
 def test_gemm_gelu_residual_maps(gpu, gemm_cfg):
     from synchformer_amd import ops
-    if gemm_cfg in (7, 10):
+    if gemm_cfg in (7, 10, 11):
         pytest.skip('persistent configs serve identity row maps only')
     M, N, K = 400, 768, 768
     a, w, b = _bf(_rand(M, K, seed=4)), _bf(_rand(N, K, seed=5, scale=0.05)), _rand(N, seed=6)
@@ -467,7 +467,7 @@ def test_qkv_time_attention(gpu, n_seq):
     torch.testing.assert_close(o[:, 1:], po, rtol=2 ** -7, atol=2 ** -7)
 
 
-@pytest.mark.parametrize('cfg', [7, 10])
+@pytest.mark.parametrize('cfg', [7, 10, 11])
 def test_gemm_persistent_epilogues(gpu, cfg):
     """The persistent 256x256 kernels (8 waves, 4 waves) over several tile rounds with a ragged last row
     panel: GELU -> bf16 and in-place fp32 residual against fp32 torch on the same bf16 operands."""
@@ -486,6 +486,36 @@ def test_gemm_persistent_epilogues(gpu, cfg):
         _lib.load().sf_gemm_force_config(-1)
     torch.testing.assert_close(out.float(), torch.nn.functional.gelu(lin), rtol=1e-2, atol=1e-2)
     torch.testing.assert_close(x, lin + x0, rtol=1e-4, atol=3e-4)
+
+
+@pytest.mark.parametrize('M,N,K,gelu,res', [(256 * 70 + 37, 2304, 768, False, False), (256 * 131 + 1, 3072, 768, True, False), (256 * 67 + 255, 768, 3072, False, True),
+                                            (256 * 9, 768, 1536, False, False), (300, 768, 256, True, False)])
+def test_gemm_pp_bitwise_equals_config7(gpu, M, N, K, gelu, res):
+    """The quadrant-phased persistent kernel (config 11) sums every accumulator over k in the same order with the same MFMA as config 7: the
+    outputs must be bit-identical, on every repetition (the repetitions screen for LDS-DMA / ds_read ordering races, which would show up as
+    rare wrong tiles)."""
+    from synchformer_amd import ops, _lib
+    a, w, b = _bf(_rand(M, K, seed=50)).to(gpu), _bf(_rand(N, K, seed=51, scale=0.05)).to(gpu), _rand(N, seed=52).to(gpu)
+    x0 = _rand(M, N, seed=53).to(gpu)
+    lib = _lib.load()
+
+    def run(cfg, k_major):
+        lib.sf_gemm_force_config(cfg)
+        try:
+            if res:
+                out = x0.clone()
+                ops.gemm(a, ops.ktile_major_weight(w) if k_major else w, b, out, residual=out)
+            else:
+                out = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+                ops.gemm(a, ops.ktile_major_weight(w) if k_major else w, b, out, gelu=gelu)
+        finally:
+            lib.sf_gemm_force_config(-1)
+        return out
+    ref = run(7, False)
+    for rep in range(6):
+        assert torch.equal(run(11, False), ref), f'repetition {rep}'
+    if M >= 8192:
+        assert torch.equal(run(11, True), ref), 'k-tile-major weight'
 
 
 def test_gemm_ktile_major_weight(gpu):

@@ -8,7 +8,7 @@ from synchformer_amd import ops, _lib
 
 dev = torch.device('cuda:0')
 import os
-CFGS = tuple(int(c) for c in os.environ.get('CFGS', '0,1,7').split(','))
+CFGS = tuple(int(c) for c in os.environ.get('CFGS', '7,11').split(','))
 lib = _lib.load()
 
 
