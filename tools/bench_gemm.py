@@ -29,10 +29,13 @@ def main():
     for n in segs:
         M = n * 1569
         print(f'--- n_seg {n}  M {M}')
+        only = os.environ.get('SHAPES')
         for name, N, K, out_dt, gelu, res in [('qkv', 2304, 768, torch.bfloat16, False, False),
                                               ('proj+res', 768, 768, torch.float32, False, True),
                                               ('fc1+gelu', 3072, 768, torch.bfloat16, True, False),
                                               ('fc2+res', 768, 3072, torch.float32, False, True)]:
+            if only and name not in only.split(','):
+                continue
             a = torch.randn(M, K, device=dev).bfloat16()
             w = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
             b = torch.randn(N, device=dev)
@@ -40,7 +43,7 @@ def main():
             line = f'{name:9s} N {N:4d} K {K:4d}: '
             # interleaved rounds (guide rule 24): every config is timed in every round, report the median
             times = {cfg: [] for cfg in CFGS}
-            for _ in range(7):
+            for _ in range(int(os.environ.get('ROUNDS', '7'))):
                 for cfg in CFGS:
                     lib.sf_gemm_force_config(cfg)
                     times[cfg].append(timeit(lambda: ops.gemm(a, w, b, out, gelu=gelu, residual=out if res else None), iters=6))
