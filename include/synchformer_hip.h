@@ -96,7 +96,9 @@ int sf_layernorm768_mxfp8(const float* x, int64_t ldx, const float* gamma, const
 
 /* Tuning / test hook (state of the CALLING THREAD only; the launchers stay re-entrant): force the GEMM tile configuration of this thread's subsequent
  * sf_gemm_bf16 calls.  -1 = automatic choice by shape (default); 0 = 128x128x64, 4 waves, two workgroups per CU; 7 = persistent 256x256x64,
- * 8 waves, v_mfma_f32_32x32x16_bf16; 1-6, 8, 9 = the other tilings measured in profiles/r01_gemm_configs.md (tools/bench_gemm.py). */
+ * 8 waves, v_mfma_f32_32x32x16_bf16 (round 2's schedule: one 64-KiB stage of prefetch); 11 = the same tile with the quadrant-phased schedule of round 3
+ * (half-tile LDS-DMA stream 1.5 stages ahead, counted waits, staggered wave groups: sf_gemm_pp.hip; K %% 128 == 0) - the automatic choice for the big
+ * token GEMMs; 10 = 4 waves of 128x128; 1-6, 8, 9 = the other tilings measured in profiles/r01_gemm_configs.md (tools/bench_gemm.py). */
 void sf_gemm_force_config(int cfg);
 
 /* y[omap(r), :] (=|+=) LayerNorm(x[imap(r), :]) * gamma + beta over 768 columns; x fp32, y bf16|fp32.

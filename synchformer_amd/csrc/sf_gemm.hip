@@ -866,6 +866,7 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
     const bool big = fast && M >= 8192 && N >= 512;
     cfg = 0;
     if (w_kmajor) { SF_CHECK_ARG(big, "sf_gemm_bf16: a k-tile-major weight needs the persistent kernel (identity maps, N %% 64 == 0, M >= 8192, N >= 512)"); cfg = 7; }
+    const bool pp = sf_gemm_pp_supported(a);                       // round 3: the quadrant-phased kernel replaces config 7 wherever K is a whole number of k-tile pairs
     if (!w_kmajor && big && !(res && K <= 1024)) {
       // Tile-round quantisation decides between the persistent 256x256 kernel (one workgroup per CU, ~8 % faster per tile pair when
       // the chip is full) and the 128x128 kernel (two per CU): e.g. fc2 of a single clip is 86 x 3 = 258 big tiles = TWO rounds of
@@ -878,6 +879,7 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
       const double e7 = t7 / (r7 * n_cu), e0 = t0 / (r0 * 2 * n_cu);
       cfg = (e7 * 1.08 >= e0) ? 7 : 0;
     }
+    if (cfg == 7 && pp) cfg = 11;
   }
   if (w_kmajor && cfg != 7 && cfg != 11) { sf_set_error("sf_gemm_bf16: only the persistent kernels (configs 7, 11) read a k-tile-major weight (forced config %d)", cfg); return -1; }
   switch (cfg) {
