@@ -29,7 +29,7 @@ extern "C" {
 enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2, SF_U8 = 3 };   /* element types */
 enum { SF_EPI_NONE = 0, SF_EPI_GELU = 1 };                  /* GEMM epilogue activation */
 
-#define SF_ABI_VERSION 1
+#define SF_ABI_VERSION 2
 int sf_abi_version(void);
 const char* sf_last_error(void);
 /* "gfx950" + build flags; lets the host assert it loaded the library it built */
@@ -100,6 +100,9 @@ int sf_layernorm768_mxfp8(const float* x, int64_t ldx, const float* gamma, const
  * (half-tile LDS-DMA stream 1.5 stages ahead, counted waits, staggered wave groups: sf_gemm_pp.hip; K %% 128 == 0) - the automatic choice for the big
  * token GEMMs; 10 = 4 waves of 128x128; 1-6, 8, 9 = the other tilings measured in profiles/r01_gemm_configs.md (tools/bench_gemm.py). */
 void sf_gemm_force_config(int cfg);
+/* The same kind of hook for sf_gemm_res_ln768's main-loop schedule: -1 default (quadrant-phased, round 3), 0 = round 2's loop (one stage of prefetch),
+ * 1 = quadrant-phased.  Both sum every accumulator in the same order: bit-identical outputs (the tests compare them). */
+void sf_gemm_res_ln_force_schedule(int sched);
 
 /* y[omap(r), :] (=|+=) LayerNorm(x[imap(r), :]) * gamma + beta over 768 columns; x fp32, y bf16|fp32.
  * Replaces nn.LayerNorm at vit_helper.py:366-375, motionformer.py:232, modeling_ast.py:301,315,535,

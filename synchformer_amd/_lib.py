@@ -10,7 +10,7 @@ from pathlib import Path
 
 LIB_DIR = Path(__file__).resolve().parent / 'lib'
 LIB_NAME = 'libsynchformer_hip.so'
-ABI_VERSION = 1
+ABI_VERSION = 2     # 2: round 3 (sf_gemm_res_ln_force_schedule; round 2 changed sf_gemm_tn_splitk's signature without a bump)
 
 _i64, _i32, _f32, _ptr = C.c_int64, C.c_int, C.c_float, C.c_void_p
 
@@ -28,6 +28,7 @@ SIGNATURES = {
     'sf_gemm_mxfp8': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i64, _ptr, _i64, _ptr, _i64, _i32, _i64, _i64, _i64, _ptr],
     'sf_layernorm768_mxfp8': [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _f32, _ptr],
     'sf_gemm_force_config': [_i32],
+    'sf_gemm_res_ln_force_schedule': [_i32],
     'sf_layernorm768': [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i64, _ptr, _i32, _i64, _f32, _ptr],
     'sf_broadcast_rows768': [_ptr, _i64, _i64, _ptr, _i64, _i64, _ptr],
     'sf_gather_rows768': [_ptr, _i64, _ptr, _ptr, _i32, _i64, _i64, _ptr],
@@ -75,7 +76,7 @@ SIGNATURES = {
     'sf_qkv_time_attention': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i32, _f32, _ptr],
     'sf_attention_cls': [_ptr, _i64, _i32, _ptr, _ptr, _i64, _i64, _i32, _i32, _ptr, _i64, _i64, _i32, _i64, _i32, _i32, _f32, _ptr],
 }
-_RESTYPES = {'sf_last_error': C.c_char_p, 'sf_build_info': C.c_char_p, 'sf_gemm_force_config': None}
+_RESTYPES = {'sf_last_error': C.c_char_p, 'sf_build_info': C.c_char_p, 'sf_gemm_force_config': None, 'sf_gemm_res_ln_force_schedule': None}
 
 _lib = None
 

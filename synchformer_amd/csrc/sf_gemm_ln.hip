@@ -21,6 +21,7 @@
 // epilogue runs, so the epilogue's HBM traffic and the next main loop's first operand loads overlap.
 #include "sf_common.h"
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/synchformer_hip.h"
 
 #define RL_BM 128
@@ -36,6 +37,30 @@
 #define RL_PARAM_OFF (RL_STAT_OFF + 2 * RL_STAT_BYTES) // bias | gamma | beta (768 floats each), staged once per workgroup
 #define RL_LDS (RL_PARAM_OFF + 3 * RL_N * 4)           // 157 KiB
 #define RL_RING_WAVE 12288                             // residual landing ring inside the (idle) operand slots: 3 steps x 4 KiB per wave
+
+// ---- round 3: the quadrant-phased schedule of sf_gemm_pp.hip on this tile (template parameter PP) --------------------------------------------
+// A k-step (32 deep) is THREE phases, one per third of the wave's 192 columns (2 x 2 blocks x 2 k-halves = 8 MFMAs each); the stage is cut into
+// A (8 KiB) | W0 | W1 | W2 (16 KiB each: for every column wave its 64 columns c*64 .. c*64+63); A's fragments stay in registers for the three phases.
+// Every part is refilled (for k-step kt+2) two phases after its last fragment read, one W third (2 LDS-DMA pieces per wave, + the A piece with W0)
+// per phase, so that one whole stage (7 pieces per wave = 56 KiB per CU) is in flight behind every counted wait (vmcnt 7), and the wm = 1 waves run
+// one barrier behind the wm = 0 waves: on every SIMD one wave multiplies while the other reads fragments and issues loads.  The stage stride is
+// 64 KiB (bit 16 of the four fragment-address registers is flipped once per k-step; the 8 KiB between the stages hold the row statistics and the bias).
+// The load stream is per tile (the residual of the epilogue lands in the idle operand slots, as before); same products in the same order as the
+// round-2 loop, so the two schedules are bit-identical (tests/test_kernels_gpu.py::test_gemm_res_ln_schedules_bitwise).
+#define RP_STRIDE 65536
+#define RP_W_OFF 8192
+#define RP_THIRD 16384
+#define RP_STAT_OFF 57344                              // 4 KiB of row statistics + 3 KiB of bias in the gap between the stages
+#define RP_BIAS_OFF (RP_STAT_OFF + 2 * RL_STAT_BYTES)
+#define RP_SLAB_OFF (RP_STRIDE + RL_STAGE)             // 122880
+#define RP_GB_OFF (RP_SLAB_OFF + 8 * RL_SLAB_BYTES)    // gamma | beta
+#define RP_LDS (RP_GB_OFF + 2 * RL_N * 4)              // 161792 B
+#ifndef SF_RL_PP
+#define SF_RL_PP 1            // 1: quadrant-phased schedule (round 3); 0: round 2's loop (SF_RL_SCHED=0 in the environment selects it at run time, for tests)
+#endif
+#ifndef SF_RL_STORECNT
+#define SF_RL_STORECNT 1      // first k-step of a tile: the 48 Y stores of the previous epilogue may stay in flight behind the loads (vmcnt 7 + 48)
+#endif
 
 #ifndef SF_RL_STORE_AUX
 #define SF_RL_STORE_AUX 2     // nt: written once, consumed by a later launch
@@ -99,6 +124,27 @@ __device__ __forceinline__ void rl_dma1(uint32_t voff, const void* sbase, uint32
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
 
+// two consecutive pieces (a W third of this wave)
+__device__ __forceinline__ void rl_dma2(uint32_t v0, uint32_t v1, const void* sbase, uint32_t lds) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %4\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep) : "v"(v0), "v"(v1), "s"(sbase), "s"(lds) : "memory", "scc");
+}
+template <int N>
+__device__ __forceinline__ void rl_wait_vmcnt() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
+}
+__device__ __forceinline__ void rl_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ void rl_dma1_nt(uint32_t voff, const void* sbase, uint32_t lds) {
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
@@ -144,7 +190,7 @@ __device__ __forceinline__ float rl_row16_sum(float v) {
 
 // ABL: ablation mask of the measurement builds (tools/bench_gemm_ln.py, SF_RL_ABL): 1 = no residual loads, 2 = no X stores, 4 = no Y stores,
 // 8 = no operand refills after the first two stages, 16 = no MFMAs, 32 = only half of the W pieces are refilled.  The product instantiation is ABL = 0.
-template <int ABL>
+template <int ABL, bool PP>
 __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -190,19 +236,48 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
     rl_dma7(voff_a0 + kt * (RL_BK * 2), sa, voff_b0 + kt * p.wk, sb0, sb1, sb2, sb3, sb4, sb5, lds_a_w + slot * RL_STAGE,
             lds_b_w + slot * RL_STAGE);
   };
+  // ---- PP: lane offsets of this wave's two pieces of a W third (buffer row r = wave * 32 + j * 16 + prow <-> W row (r >> 6) * 192 + c * 64 + (r & 63)),
+  // the third's 64-row shift and the k-step go into the scalar base ----
+  uint32_t voff_w[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) voff_w[j] = (uint32_t)(((wave >> 1) * 192 + (wave & 1) * 32 + j * 16 + prow) * (int)p.ldw * 2 + pchunk * 16);
+  const char* w0 = reinterpret_cast<const char*>(p.W);
+  const int64_t third_b = (int64_t)64 * p.ldw * 2;
+  auto pp_issue_w = [&](int c, int slot, int kt_) {
+    if (ABL & 8) return;
+    rl_dma2(voff_w[0], voff_w[1], w0 + c * third_b + (int64_t)kmap(kt_) * p.wk, lds0 + slot * RP_STRIDE + RP_W_OFF + c * RP_THIRD + wave * 2048);
+  };
+  auto pp_issue_a = [&](int slot, int kt_) {
+    if (ABL & 8) return;
+    rl_dma1(voff_a0 + kmap(kt_) * (RL_BK * 2), sa, lds0 + slot * RP_STRIDE + wave * 1024);
+  };
+  auto pp_prologue = [&]() {                                       // A | W0, W1, W2 of k-step 0 and A | W0 of k-step 1: 10 pieces per wave
+    rl_dma1(voff_a0 + kmap(0) * (RL_BK * 2), sa, lds0 + wave * 1024);
+    rl_dma2(voff_w[0], voff_w[1], w0 + (int64_t)kmap(0) * p.wk, lds0 + RP_W_OFF + wave * 2048);
+    rl_dma2(voff_w[0], voff_w[1], w0 + third_b + (int64_t)kmap(0) * p.wk, lds0 + RP_W_OFF + RP_THIRD + wave * 2048);
+    rl_dma2(voff_w[0], voff_w[1], w0 + 2 * third_b + (int64_t)kmap(0) * p.wk, lds0 + RP_W_OFF + 2 * RP_THIRD + wave * 2048);
+    rl_dma1(voff_a0 + kmap(1) * (RL_BK * 2), sa, lds0 + RP_STRIDE + wave * 1024);
+    rl_dma2(voff_w[0], voff_w[1], w0 + (int64_t)kmap(1) * p.wk, lds0 + RP_STRIDE + RP_W_OFF + wave * 2048);
+  };
   set_tile(m0);
-  stage(0, 0);
   bool stage1_in_flight = false;
-  if (nk > 1) { stage(1, 1); stage1_in_flight = true; }
+  if (PP) pp_prologue();
+  else {
+    stage(0, 0);
+    if (nk > 1) { stage(1, 1); stage1_in_flight = true; }
+  }
 
-  float* stat = reinterpret_cast<float*>(smem + RL_STAT_OFF);
-  float* prm = reinterpret_cast<float*>(smem + RL_PARAM_OFF);     // the epilogue reads bias / gamma / beta from LDS: a global load there would make
-  for (int i = tid; i < RL_N; i += 512) {                          // hipcc wait vmcnt(0), i.e. for every residual piece still in flight
-    prm[i] = p.bias ? p.bias[i] : 0.f;
-    prm[RL_N + i] = p.gamma[i];
-    prm[2 * RL_N + i] = p.beta[i];
+  float* stat = reinterpret_cast<float*>(smem + (PP ? RP_STAT_OFF : RL_STAT_OFF));
+  float* pbias = reinterpret_cast<float*>(smem + (PP ? RP_BIAS_OFF : RL_PARAM_OFF));     // the epilogue reads bias / gamma / beta from LDS: a global load there
+  float* pgamma = reinterpret_cast<float*>(smem + (PP ? RP_GB_OFF : RL_PARAM_OFF + RL_N * 4));   // would make hipcc wait vmcnt(0), i.e. for every residual piece
+  float* pbeta = pgamma + RL_N;                                                              // still in flight
+  for (int i = tid; i < RL_N; i += 512) {
+    pbias[i] = p.bias ? p.bias[i] : 0.f;
+    pgamma[i] = p.gamma[i];
+    pbeta[i] = p.beta[i];
   }
   __syncthreads();
+  bool y_stores_behind = false;                                    // PP: the previous epilogue's 48 Y stores were issued after this tile's first loads
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), (short)0, (int)(uint32_t)(p.M * p.ldr * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(p.X, (short)0, (int)(uint32_t)(p.M * p.ldx * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.Y, (short)0, (int)(uint32_t)(p.M * p.ldy * 2), 0x00020000);
@@ -216,6 +291,108 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    if constexpr (PP) {
+      int fa[2], fw[2];                                            // fragment addresses in the CURRENT stage (bit 16 flipped once per k-step)
+      {
+        int ptid = threadIdx.x;
+        asm volatile("" : "+v"(ptid));
+        const int pl31 = ptid & 31, phi = (ptid & 63) >> 5;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int sw = ((ks * 2 + phi) ^ ((pl31 >> 2) & 3)) << 4;
+          fa[ks] = (wm * 64 + pl31) * 64 + sw;                     // + i * 2048
+          fw[ks] = RP_W_OFF + (wn * 64 + pl31) * 64 + sw;          // + c * RP_THIRD + jj * 2048
+        }
+      }
+      bf16x8 a[2][2], w[2][2];
+      auto mma = [&](auto Cc) {
+        constexpr int C = decltype(Cc)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              if (!(ABL & 16)) acc[i][2 * C + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], w[jj][ks], acc[i][2 * C + jj], 0, 0, 0);
+              else if (ks == 0 && i == 0 && jj == 0) asm volatile("" :: "v"(a[0][0]), "v"(a[1][1]), "v"(w[0][0]), "v"(w[1][1]));
+            }
+        __builtin_amdgcn_s_setprio(0);
+      };
+      auto read_w = [&](auto Cc) {
+        constexpr int C = decltype(Cc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) w[jj][ks] = *reinterpret_cast<const bf16x8*>(smem + C * RP_THIRD + jj * 2048 + fw[ks]);
+      };
+      // one k-step in stage S; `more1` = k-step kt+1 exists, `more2` = k-step kt+2 exists, `first` = first k-step of the tile
+      auto kstep = [&](auto Sc, int kt, bool more1, bool more2, bool first) {
+        constexpr int S = decltype(Sc)::value;
+        const bool behind = SF_RL_STORECNT && first && y_stores_behind;
+        // ---- phase 0: A x W third 0 ----
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a[i][ks] = *reinterpret_cast<const bf16x8*>(smem + i * 2048 + fa[ks]);
+        read_w(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (more1) pp_issue_w(1, S ^ 1, kt + 1);
+        if (ABL & 8) rl_wait_vmcnt<0>();                           // W third 1 of this k-step has landed; the youngest stage stays in flight
+        else if (!more1) rl_wait_vmcnt<2>();
+        else if (behind) rl_wait_vmcnt<7 + 48>();
+        else rl_wait_vmcnt<7>();
+        rl_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        rl_barrier();
+        // ---- phase 1: third 1 ----
+        read_w(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (more1) pp_issue_w(2, S ^ 1, kt + 1);
+        if (!more1 || (ABL & 8)) rl_wait_vmcnt<0>();               // W third 2 has landed
+        else if (behind) rl_wait_vmcnt<7 + 48>();
+        else rl_wait_vmcnt<7>();
+        rl_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        rl_barrier();
+        // ---- phase 2: third 2; the fragment addresses move on to the other stage ----
+        read_w(std::integral_constant<int, 2>{});
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(fa[ks]));
+          asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(fw[ks]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more2) { pp_issue_a(S, kt + 2); pp_issue_w(0, S, kt + 2); }
+        if (more1) {                                               // A | W third 0 of the next k-step have landed
+          if (ABL & 8) rl_wait_vmcnt<0>();
+          else if (!more2) rl_wait_vmcnt<4>();
+          else if (behind) rl_wait_vmcnt<7 + 48>();
+          else rl_wait_vmcnt<7>();
+        }
+        rl_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(std::integral_constant<int, 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        rl_barrier();
+      };
+      // A | W third 0 of k-step 0 have landed (this wave's pieces), then everybody's
+      if (ABL & 8) rl_wait_vmcnt<0>();
+      else if (SF_RL_STORECNT && y_stores_behind) rl_wait_vmcnt<7 + 48>();
+      else rl_wait_vmcnt<7>();
+      rl_barrier();
+      if (wm == 1) rl_barrier();                                   // the wm = 1 waves run one barrier behind
+      for (int kt = 0; kt < nk; kt += 2) {
+        const bool more = kt + 2 < nk;
+        kstep(std::integral_constant<int, 0>{}, kt, true, more, kt == 0);
+        kstep(std::integral_constant<int, 1>{}, kt + 1, more, more, false);
+      }
+      if (wm == 0) rl_barrier();                                   // re-align; also: every wave is done with both stages
+    } else {
     for (int kt = 0; kt < nk; ++kt) {
       rl_wait_vmcnt_barrier<0>();                                  // stage kt landed everywhere; slot (kt+1)&1 is free
       const bool refill = kt + 1 < nk && !(kt == 0 && stage1_in_flight) && !(ABL & 8);
@@ -267,6 +444,7 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    }
     const int64_t em0 = m0;
     const uint32_t tnext = t + gridDim.x;
     const bool more = tnext < p.tiles;
@@ -284,9 +462,10 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
     asm volatile("" : "+v"(etid));
     const int elane = etid & 63, l31 = elane & 31, hi = elane >> 5, lr = elane >> 4, ecol = (elane & 15) * 4;
     const int gcol0 = wn * 192 + ecol;                             // + c * 64
-    float* slab = reinterpret_cast<float*>(smem + RL_SLAB_OFF + wave * RL_SLAB_BYTES);
-    const char* ring = smem + wave * RL_RING_WAVE + elane * 16;
-    const uint32_t ring_lds = lds0 + wave * RL_RING_WAVE;
+    float* slab = reinterpret_cast<float*>(smem + (PP ? RP_SLAB_OFF : RL_SLAB_OFF) + wave * RL_SLAB_BYTES);
+    const int ring_off = PP ? (wave >> 2) * RP_STRIDE + (wave & 3) * RL_RING_WAVE : wave * RL_RING_WAVE;   // PP: not across the statistics between the stages
+    const char* ring = smem + ring_off + elane * 16;
+    const uint32_t ring_lds = lds0 + ring_off;
     int64_t rrow0 = em0 + wm * 64;                                  // tail tile: rows beyond M re-read row M - 1 (their outputs are dropped)
     if (rrow0 > p.M - 1) rrow0 = p.M - 1;
     const int64_t rleft = p.M - 1 - rrow0;
@@ -309,7 +488,7 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
 #pragma unroll
     for (int s = 0; s < 12; ++s) {
       const int c = s >> 2, g = s & 3, i = g >> 1, q2 = g & 1;
-      const float4 bias4 = *reinterpret_cast<const float4*>(prm + gcol0 + c * 64);
+      const float4 bias4 = *reinterpret_cast<const float4*>(pbias + gcol0 + c * 64);
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -371,8 +550,11 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
     if (more) {
       m0 = (int64_t)tnext * RL_BM;
       set_tile(m0);
-      stage(0, 0);
-      if (nk > 1) { stage(1, 1); stage1_in_flight = true; }
+      if (PP) { pp_prologue(); y_stores_behind = true; }
+      else {
+        stage(0, 0);
+        if (nk > 1) { stage(1, 1); stage1_in_flight = true; }
+      }
     }
     // ---- pass 3: centred second moments (the mean of a row is re-derived from its 4 partials where it is needed: no 32 live registers) ----
     float* stat2 = stat + RL_BM * 4;
@@ -400,8 +582,8 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
     float4 gm[3], bt[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      gm[c] = *reinterpret_cast<const float4*>(prm + RL_N + gcol0 + c * 64);
-      bt[c] = *reinterpret_cast<const float4*>(prm + 2 * RL_N + gcol0 + c * 64);
+      gm[c] = *reinterpret_cast<const float4*>(pgamma + gcol0 + c * 64);
+      bt[c] = *reinterpret_cast<const float4*>(pbeta + gcol0 + c * 64);
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -425,6 +607,9 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
   }
 }
 
+static thread_local int g_rl_force_sched = -1;   // test hook (per calling thread): -1 default, 0 round 2's loop, 1 quadrant-phased
+extern "C" void sf_gemm_res_ln_force_schedule(int sched) { g_rl_force_sched = sched; }
+
 extern "C" int sf_gemm_res_ln768(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* R, int64_t ldr,
                                  float* X, int64_t ldx, const float* gamma, const float* beta, float eps, bf16_t* Y, int64_t ldy, int64_t M,
                                  int64_t K, void* stream) {
@@ -447,10 +632,11 @@ extern "C" int sf_gemm_res_ln768(const bf16_t* A, int64_t lda, const bf16_t* W, 
   static bool attr_set = false;
   static int n_cu = 0;
   if (!attr_set) {
-    const void* kerns[] = {(const void*)gemm_res_ln768_kernel<0>, (const void*)gemm_res_ln768_kernel<1>, (const void*)gemm_res_ln768_kernel<15>,
-                           (const void*)gemm_res_ln768_kernel<17>, (const void*)gemm_res_ln768_kernel<33>, (const void*)gemm_res_ln768_kernel<49>};
+    const void* kerns[] = {(const void*)gemm_res_ln768_kernel<0, false>, (const void*)gemm_res_ln768_kernel<1, false>, (const void*)gemm_res_ln768_kernel<15, false>,
+                           (const void*)gemm_res_ln768_kernel<17, false>, (const void*)gemm_res_ln768_kernel<0, true>, (const void*)gemm_res_ln768_kernel<7, true>,
+                           (const void*)gemm_res_ln768_kernel<15, true>, (const void*)gemm_res_ln768_kernel<23, true>};
     for (const void* k : kerns) {
-      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS);
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS > RL_LDS ? RP_LDS : RL_LDS);
       if (e != hipSuccess) { sf_set_error("sf_gemm_res_ln768: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     }
     int dev = 0; hipDeviceProp_t prop;
@@ -466,18 +652,30 @@ extern "C" int sf_gemm_res_ln768(const bf16_t* A, int64_t lda, const bf16_t* W, 
   SF_CHECK_ARG(tiles < ((int64_t)1 << 31), "sf_gemm_res_ln768: too many tiles");
   a.tiles = (uint32_t)tiles;
   int64_t blocks = tiles < n_cu ? tiles : n_cu;                    // one persistent workgroup per CU
-  static int abl = -1, max_blocks = -1;
+  static int abl = -1, max_blocks = -1, sched = -1;
   if (max_blocks < 0) { const char* e = getenv("SF_RL_BLOCKS"); max_blocks = e ? atoi(e) : 0; }   // measurement hook: fewer resident workgroups
   if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
   if (abl < 0) { const char* e = getenv("SF_RL_ABL"); abl = e ? atoi(e) : 0; }
-  switch (abl) {
-    case 0: hipLaunchKernelGGL(gemm_res_ln768_kernel<0>, dim3((unsigned)blocks), dim3(512), RL_LDS, (hipStream_t)stream, a); break;
-    case 1: hipLaunchKernelGGL(gemm_res_ln768_kernel<1>, dim3((unsigned)blocks), dim3(512), RL_LDS, (hipStream_t)stream, a); break;
-    case 15: hipLaunchKernelGGL(gemm_res_ln768_kernel<15>, dim3((unsigned)blocks), dim3(512), RL_LDS, (hipStream_t)stream, a); break;
-    case 17: hipLaunchKernelGGL(gemm_res_ln768_kernel<17>, dim3((unsigned)blocks), dim3(512), RL_LDS, (hipStream_t)stream, a); break;
-    case 33: hipLaunchKernelGGL(gemm_res_ln768_kernel<33>, dim3((unsigned)blocks), dim3(512), RL_LDS, (hipStream_t)stream, a); break;
-    case 49: hipLaunchKernelGGL(gemm_res_ln768_kernel<49>, dim3((unsigned)blocks), dim3(512), RL_LDS, (hipStream_t)stream, a); break;
-    default: sf_set_error("sf_gemm_res_ln768: unknown SF_RL_ABL %d", abl); return -1;
+  if (sched < 0) { const char* e = getenv("SF_RL_SCHED"); sched = e ? atoi(e) : SF_RL_PP; }       // 0: round 2's loop, 1: quadrant-phased (needs K % 64 == 0)
+  const bool pp = (sched != 0 || g_rl_force_sched == 1) && g_rl_force_sched != 0 && (K % 64) == 0 && K >= 128;
+  const dim3 grid((unsigned)blocks), blk(512);
+  hipStream_t st = (hipStream_t)stream;
+  if (pp) {
+    switch (abl) {     // ablations: 1 no residual, 2 no X stores, 4 no Y stores, 8 no refills after the first two stages, 16 no MFMA
+      case 0: hipLaunchKernelGGL((gemm_res_ln768_kernel<0, true>), grid, blk, RP_LDS, st, a); break;
+      case 7: hipLaunchKernelGGL((gemm_res_ln768_kernel<7, true>), grid, blk, RP_LDS, st, a); break;
+      case 15: hipLaunchKernelGGL((gemm_res_ln768_kernel<15, true>), grid, blk, RP_LDS, st, a); break;
+      case 23: hipLaunchKernelGGL((gemm_res_ln768_kernel<23, true>), grid, blk, RP_LDS, st, a); break;
+      default: sf_set_error("sf_gemm_res_ln768: unknown SF_RL_ABL %d for the quadrant-phased schedule", abl); return -1;
+    }
+  } else {
+    switch (abl) {
+      case 0: hipLaunchKernelGGL((gemm_res_ln768_kernel<0, false>), grid, blk, RL_LDS, st, a); break;
+      case 1: hipLaunchKernelGGL((gemm_res_ln768_kernel<1, false>), grid, blk, RL_LDS, st, a); break;
+      case 15: hipLaunchKernelGGL((gemm_res_ln768_kernel<15, false>), grid, blk, RL_LDS, st, a); break;
+      case 17: hipLaunchKernelGGL((gemm_res_ln768_kernel<17, false>), grid, blk, RL_LDS, st, a); break;
+      default: sf_set_error("sf_gemm_res_ln768: unknown SF_RL_ABL %d", abl); return -1;
+    }
   }
   SF_LAUNCH_CHECK();
   return 0;

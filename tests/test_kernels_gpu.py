@@ -306,6 +306,32 @@ def test_gemm_res_ln(gpu, M, K):
     assert ((y[:M].float() - y2.float()).abs() <= 2.0 ** -7 * y2.float().abs() + 1e-4).all()
 
 
+@pytest.mark.parametrize('M,K', [(128 * 300 + 37, 768), (128 * 290 + 1, 3072), (200, 768)])
+def test_gemm_res_ln_schedules_bitwise(gpu, M, K):
+    """The quadrant-phased main loop of sf_gemm_res_ln768 (round 3) sums every accumulator in the same k order as round 2's loop: X and Y must be
+    bit-identical, on every repetition (the repetitions screen for LDS-DMA / ds_read ordering races), for both weight layouts."""
+    from synchformer_amd import ops, _lib
+    lib = _lib.load()
+    a, w = _bf(_rand(M, K, seed=61)).to(gpu), _bf(_rand(768, K, seed=62, scale=0.05)).to(gpu)
+    b, r = _rand(768, seed=63).to(gpu), (_rand(M, 768, seed=64, scale=2.0) + 0.5).to(gpu)
+    gam, bet = (1.0 + 0.1 * _rand(768, seed=65)).to(gpu), (0.1 * _rand(768, seed=66)).to(gpu)
+
+    def run(sched, wt):
+        lib.sf_gemm_res_ln_force_schedule(sched)
+        try:
+            x, y = r.clone(), torch.empty(M, 768, device=gpu, dtype=torch.bfloat16)
+            ops.gemm_res_ln(a, wt, b, x, gam, bet, y, 1e-6)
+        finally:
+            lib.sf_gemm_res_ln_force_schedule(-1)
+        return x, y
+    x0, y0 = run(0, w)
+    wk = ops.kmajor_weight(w)
+    for rep in range(5):
+        for wt in (w, wk):
+            x1, y1 = run(1, wt)
+            assert torch.equal(x1, x0) and torch.equal(y1, y0), f'repetition {rep}'
+
+
 def test_gemm_res_ln_in_place_operand(gpu):
     """Y aliasing A (the engine's XN buffer holds the attention output going in and the normalised rows coming out) and X aliasing R."""
     from synchformer_amd import ops

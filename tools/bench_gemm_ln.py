@@ -4,7 +4,8 @@ import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
-from synchformer_amd import ops
+from synchformer_amd import ops, _lib
+import os
 
 dev = torch.device('cuda:0')
 
@@ -33,18 +34,22 @@ def main():
             x = torch.randn(M, 768, device=dev)
             y = torch.empty(M, 768, device=dev, dtype=torch.bfloat16)
             wk = ops.kmajor_weight(w)
-            t = {'gemm': [], 'ln': [], 'fused': [], 'fused_k': []}
+            t = {'gemm': [], 'ln': [], 'fused': [], 'fused_k': [], 'r2_k': []}
+            lib = _lib.load()
             for _ in range(7):      # interleaved rounds, median
                 t['gemm'].append(timeit(lambda: ops.gemm(a, w, b, x, residual=x)))
                 t['ln'].append(timeit(lambda: ops.layernorm(x, g, bt, y, 1e-6)))
                 t['fused'].append(timeit(lambda: ops.gemm_res_ln(a, w, b, x, g, bt, y, 1e-6)))
                 t['fused_k'].append(timeit(lambda: ops.gemm_res_ln(a, wk, b, x, g, bt, y, 1e-6)))
+                lib.sf_gemm_res_ln_force_schedule(0)
+                t['r2_k'].append(timeit(lambda: ops.gemm_res_ln(a, wk, b, x, g, bt, y, 1e-6)))
+                lib.sf_gemm_res_ln_force_schedule(-1)
                 x.normal_()
             med = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
             fl = 2.0 * M * 768 * K
             byts = M * K * 2 + M * 768 * (4 + 4 + 2)
             print(f"{name:5s} K {K:4d}: gemm+res {med['gemm']:7.1f} us ({fl / med['gemm'] / 1e6:5.0f} TF) + layernorm {med['ln']:6.1f} us = "
-                  f"{med['gemm'] + med['ln']:7.1f} us | fused {med['fused']:7.1f} us ({fl / med['fused'] / 1e6:5.0f} TF, {byts / med['fused'] / 1e6:5.2f} TB/s algorithmic) | k-major W {med['fused_k']:7.1f} us",
+                  f"{med['gemm'] + med['ln']:7.1f} us | fused {med['fused']:7.1f} us ({fl / med['fused'] / 1e6:5.0f} TF, {byts / med['fused'] / 1e6:5.2f} TB/s algorithmic) | k-major W {med['fused_k']:7.1f} us ({fl / med['fused_k'] / 1e6:5.0f} TF) | round-2 loop, k-major W {med['r2_k']:7.1f} us",
                   flush=True)
 
 
