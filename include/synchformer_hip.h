@@ -103,6 +103,7 @@ void sf_gemm_force_config(int cfg);
 /* The same kind of hook for sf_gemm_res_ln768's main-loop schedule: -1 default (quadrant-phased, round 3), 0 = round 2's loop (one stage of prefetch),
  * 1 = quadrant-phased.  Both sum every accumulator in the same order: bit-identical outputs (the tests compare them). */
 void sf_gemm_res_ln_force_schedule(int sched);
+void sf_qkv_time_force_schedule(int sched);        /* the same for sf_qkv_time_attention */
 
 /* y[omap(r), :] (=|+=) LayerNorm(x[imap(r), :]) * gamma + beta over 768 columns; x fp32, y bf16|fp32.
  * Replaces nn.LayerNorm at vit_helper.py:366-375, motionformer.py:232, modeling_ast.py:301,315,535,

@@ -47,6 +47,18 @@
 #endif
 #define QT_D 768
 #define QT_HEADS 12
+// Round 3, template parameter PP: the quadrant-phased schedule of sf_gemm_pp.hip / sf_gemm_res_ln768 on this tile.  A k-tile (64 deep, 24 MFMAs per
+// wave) is THREE phases - the q, k and v thirds of the head's 192 W rows, 2 blocks x 4 k-steps = 8 MFMAs each; the wave's own A fragments stay in
+// registers for the three phases.  Parts of a stage: A (4 pieces per wave: the wave's own 32 rows) | W0 | W1 | W2 (1 piece per wave each); every part is
+// refilled for k-tile kt+2 two phases after its last fragment read, 3 / 3 / 1 pieces per phase:
+//     phase 0 of k-tile kt: W1, A2, A3 of kt+1 | phase 1: W2 of kt+1 | phase 2: W0, A0, A1 of kt+2
+// behind counted waits (vmcnt 9 / 7 / 4: the youngest 4-9 pieces per wave stay in flight), and waves 4-7 run one barrier behind waves 0-3, so that on
+// every SIMD one wave multiplies while the other reads fragments and issues loads.  Per tile: k-tile 0 arrives under the previous epilogue (stage 0),
+// as before; the CLS q | k | v of the tile now arrive by an LDS-DMA piece issued in the previous epilogue (no compiler-visible load is left in the
+// kernel, so hipcc inserts no vmcnt(0) of its own).  Same products in the same order as the round-2 loop: bit-identical outputs.
+#ifndef QT_PP
+#define QT_PP 1
+#endif
 
 struct QtArgs {
   const bf16_t* X; int64_t ldx;
@@ -69,6 +81,16 @@ __device__ __forceinline__ void qt_dma1(uint32_t voff, const void* sbase, uint32
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void qt_wait_vmcnt() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
+}
+__device__ __forceinline__ void qt_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ uint32_t qt_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 __device__ __forceinline__ void qt_wait_vmcnt0_barrier() {
@@ -117,9 +139,11 @@ __device__ __forceinline__ float qt_sum_row16(float v) {
   return v;
 }
 
+template <bool PP>
 __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
 
   // persistent schedule: block b sits on XCD b % 8; every XCD owns a contiguous range of row tiles and walks (row tile, head) with the head fastest
@@ -142,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
   uint32_t voff_a[4], voff_b[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const int br = wave * 24 + j * 8 + (lane >> 3);
+    const int br = PP ? j * 64 + wave * 8 + (lane >> 3) : wave * 24 + j * 8 + (lane >> 3);   // PP: piece j = this wave's 8 rows of W third j
     const int gch = (lane & 7) ^ ((br >> 1) & 7);
     voff_b[j] = (uint32_t)(((int64_t)(br >> 6) * QT_D + (br & 63)) * p.ldw * 2 + gch * 16);
   }
@@ -172,7 +196,16 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
   const uint32_t lds_a_w = __builtin_amdgcn_readfirstlane(lds0 + wave * 4096), lds_b_w = __builtin_amdgcn_readfirstlane(lds0 + QT_A_BYTES + wave * 3072);
   auto piece = [&](int pc, int slot, int kt) {                     // pc = 0 .. 3: A pieces, 4 .. 6: B pieces of k-tile kt
     if (pc < 4) qt_dma1(voff_a[pc], reinterpret_cast<const char*>(p.X) + kt * 128, lds_a_w + slot * QT_STAGE + pc * 1024);
+    else if (PP) qt_dma1(voff_b[pc - 4], wbase + kt * 128, lds0 + QT_A_BYTES + slot * QT_STAGE + (pc - 4) * 8192 + wave * 1024);
     else qt_dma1(voff_b[pc - 4], wbase + kt * 128, lds_b_w + slot * QT_STAGE + (pc - 4) * 1024);
+  };
+  // PP: the CLS q | k | v (3 x 128 B) of this wave's sequence and head as one masked LDS-DMA piece (lanes 0-23, 16 bytes each) into the wave's 384 B
+  const uint32_t lds_cls = __builtin_amdgcn_readfirstlane(lds0 + QT_CLS_OFF + wave * 384);
+  auto cls_piece = [&]() {
+    uint32_t g0 = tm * 32u + wave * 4;
+    if (g0 > n_patches - 1) g0 = n_patches - 1;
+    const char* cls = reinterpret_cast<const char*>(p.qkv_cls + (int64_t)(g0 / (uint32_t)p.n_groups) * p.ldc + head * 64);
+    if (lane < 24) qt_dma1((uint32_t)(((lane >> 3) * QT_D + (lane & 7) * 8) * 2), cls, lds_cls);
   };
   // the head's bias: lanes 0-47 of wave 0 fetch 16 bytes each of the q | k | v thirds (768 floats apart), the other lanes re-read lane 0's
   const uint32_t voff_bias = lane < 48 ? (uint32_t)(((lane >> 4) * QT_D + (lane & 15) * 4) * 4) : 0u;
@@ -184,6 +217,7 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
 #pragma unroll
   for (int pc = 0; pc < 7; ++pc) piece(pc, 0, 0);
   bias_piece();
+  if (PP) { cls_piece(); qt_wait_vmcnt<0>(); }
 
   constexpr int nk = QT_D / QT_BK;                                  // 12 k-tiles
   const float sc = p.scale * 1.44269504088896f;                    // softmax in base 2
@@ -197,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
     // the CLS q | k | v (3 x 128 B) of this wave's sequence and head: ONE load instruction per wave (lanes 0-23, 16 bytes each) instead of nine
     // sliced ones, parked in 384 B of wave-private LDS behind the first k-step's wait and read back in the epilogue's two lane layouts
     uint4 cls_raw = make_uint4(0u, 0u, 0u, 0u);
-    {
+    if (!PP) {
       uint32_t g0 = tm * 32u + wave * 4;
       if (g0 > n_patches - 1) g0 = n_patches - 1;
       const bf16_t* cls = p.qkv_cls + (int64_t)(g0 / (uint32_t)p.n_groups) * p.ldc + head * 64;
@@ -238,6 +272,95 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
         }
       }
     };
+    if constexpr (PP) {
+      const int wg = wave >> 2;                                     // waves 4-7 run one barrier behind waves 0-3
+      int fo[4];                                                   // fragment offsets, re-derived here (not kept live across the epilogue)
+      {
+        int ptid = threadIdx.x;
+        asm volatile("" : "+v"(ptid));
+        const int pl31 = ptid & 31, phi = (ptid & 63) >> 5;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fo[kk] = pl31 * 128 + (((kk * 2 + phi) ^ ((pl31 >> 1) & 7)) << 4);
+      }
+      // every wave is out of its slab (they overlay stage 1) and has waited for its pieces of k-tile 0 (vmcnt 0 in front of the epilogue's stores)
+      qt_barrier();
+      if (!(QT_ABL & 2)) { piece(4, 1, 1); piece(0, 1, 1); piece(1, 1, 1); }          // W0, A0, A1 of k-tile 1
+      {
+        const float* bs = reinterpret_cast<const float*>(smem + QT_BIAS_OFF);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 b4 = p.bias ? *reinterpret_cast<const float4*>(bs + (j >> 1) * 64 + (j & 1) * 32 + g * 8 + hi * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc[j][g * 4 + 0] = b4.x; acc[j][g * 4 + 1] = b4.y; acc[j][g * 4 + 2] = b4.z; acc[j][g * 4 + 3] = b4.w;
+          }
+      }
+      bf16x8 xf[4], wf[2][4];
+      auto read_w = [&](const char* st, auto Cc) {
+        constexpr int C = decltype(Cc)::value;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) wf[jj][kk] = *reinterpret_cast<const bf16x8*>(st + QT_A_BYTES + (2 * C + jj) * 4096 + fo[kk]);
+      };
+      auto mma = [&](auto Cc) {
+        constexpr int C = decltype(Cc)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            if (!(QT_ABL & 4)) acc[2 * C + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[jj][kk], xf[kk], acc[2 * C + jj], 0, 0, 0);
+            else if (kk == 0 && jj == 0) asm volatile("" :: "v"(xf[0]), "v"(xf[3]), "v"(wf[0][0]), "v"(wf[1][3]));
+          }
+        __builtin_amdgcn_s_setprio(0);
+      };
+      // one k-tile in stage S; more1 / more2: k-tiles kt+1 / kt+2 exist; first: k-tile 0 (its W thirds 1 and 2 have landed already)
+      auto ktile = [&](auto Sc, int kt, bool more1, bool more2, bool first) {
+        constexpr int S = decltype(Sc)::value;
+        const char* st = smem + S * QT_STAGE;
+        const bool ld1 = more1 && !(QT_ABL & 2), ld2 = more2 && !(QT_ABL & 2);
+        // ---- phase 0: q third ----
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) xf[kk] = *reinterpret_cast<const bf16x8*>(st + a_base + fo[kk]);
+        read_w(st, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (ld1) { piece(5, S ^ 1, kt + 1); piece(2, S ^ 1, kt + 1); piece(3, S ^ 1, kt + 1); }   // W1, A2, A3 of k-tile kt+1
+        if (!first) { if (QT_ABL & 2) qt_wait_vmcnt<0>(); else if (more1) qt_wait_vmcnt<9>(); else qt_wait_vmcnt<3>(); }   // W third 1 of this k-tile has landed
+        qt_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        qt_barrier();
+        // ---- phase 1: k third ----
+        read_w(st, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (ld1) piece(6, S ^ 1, kt + 1);                                                          // W2 of k-tile kt+1
+        if (!first) { if (!more1 || (QT_ABL & 2)) qt_wait_vmcnt<0>(); else qt_wait_vmcnt<7>(); }   // W third 2 has landed
+        qt_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        qt_barrier();
+        // ---- phase 2: v third ----
+        read_w(st, std::integral_constant<int, 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (ld2) { piece(4, S, kt + 2); piece(0, S, kt + 2); piece(1, S, kt + 2); }                // W0, A0, A1 of k-tile kt+2
+        if (more1) { if (QT_ABL & 2) qt_wait_vmcnt<0>(); else if (more2) qt_wait_vmcnt<4>(); else qt_wait_vmcnt<1>(); }   // A | W third 0 of k-tile kt+1 have landed
+        qt_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(std::integral_constant<int, 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        qt_barrier();
+      };
+      if (wg == 1) qt_barrier();
+      for (int kt = 0; kt < nk; kt += 2) {
+        const bool more = kt + 2 < nk;
+        ktile(std::integral_constant<int, 0>{}, kt, true, more, kt == 0);
+        ktile(std::integral_constant<int, 1>{}, kt + 1, more, more, false);
+      }
+      if (wg == 0) qt_barrier();                                   // re-align; every wave is done with both stages
+    } else {
     kstep(0, std::true_type{}, std::true_type{});
     for (int kt = 1; kt + 1 < nk; ++kt) kstep(kt, std::true_type{}, std::false_type{});
     kstep(nk - 1, std::false_type{}, std::false_type{});
@@ -245,6 +368,7 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    }
     const uint32_t etm = tm; const int ehead = head;
     const uint32_t tnext = t + per_xcd_blocks;
     const bool more = tnext < t_end;
@@ -275,19 +399,24 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
     // The wave's four patches belong to ONE sequence (n_groups % 4 == 0); np of them exist (ragged last tile).
     const uint32_t g0 = etm * 32u + ewave * 4;
     const int np = g0 >= n_patches ? 0 : (n_patches - g0 < 4u ? (int)(n_patches - g0) : 4);
+    const char* clsp = smem + QT_CLS_OFF + ewave * 384;
+    uint4 qcA[4], kcA[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      qcA[c] = *reinterpret_cast<const uint4*>(clsp + (elane & 1) * 64 + c * 16);
+      kcA[c] = *reinterpret_cast<const uint4*>(clsp + 128 + (elane & 1) * 64 + c * 16);
+    }
+    const uint4 vcB = *reinterpret_cast<const uint4*>(clsp + 256 + (elane & 7) * 16);
+    if (PP && more) {                                              // this tile's CLS slices are in registers: the next tile's may land
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      cls_piece();
+    }
+    if (np == 0 && PP) qt_wait_vmcnt<0>();                         // (waves with patches wait in front of their stores, below)
     if (np > 0) {                                                  // wave-uniform
       const int64_t seq = g0 / (uint32_t)p.n_groups;
       const int pp0 = (int)(g0 - (uint32_t)seq * (uint32_t)p.n_groups);
       const int pi = elane >> 4;                                    // patch of this lane in both phases
       const bool live = pi < np;
-      const char* clsp = smem + QT_CLS_OFF + ewave * 384;
-      uint4 qcA[4], kcA[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        qcA[c] = *reinterpret_cast<const uint4*>(clsp + (elane & 1) * 64 + c * 16);
-        kcA[c] = *reinterpret_cast<const uint4*>(clsp + 128 + (elane & 1) * 64 + c * 16);
-      }
-      const uint4 vcB = *reinterpret_cast<const uint4*>(clsp + 256 + (elane & 7) * 16);
       // (2) SCORE phase: lane (patch pi, frame qi, half sub): 32 head dims of one query.  Scores against [CLS key; the patch's 8 frames], softmax,
       // the normalised probabilities go to the (now dead) q area of the query's own slab row; the CLS QUERY's score against the lane's own token
       // is reduced over the wave's 32 tokens (softmax state of sf_attention's cls_partial records, one record per wave).
@@ -348,6 +477,9 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
         // (3) P V phase: lane (patch pi, query half qh, slice ds): 8 head dims of 4 queries of the patch - every V element is unpacked twice per
         // patch instead of once per query lane, and a query row leaves as eight 16-byte stores (store instructions, not bytes, are what the
         // vector-memory path of a CU charges for)
+        // PP: the next tile's k-tile 0, bias and CLS pieces (issued at the top of this epilogue) have landed by now; waiting for them HERE, in front of
+        // this epilogue's stores, keeps the stores out of every counted wait of the next k-loop
+        if (PP) qt_wait_vmcnt<0>();
         const int qh = (elane >> 3) & 1, ds = elane & 7;
         sf_f32x2_t v[9][4];
         {
@@ -425,6 +557,9 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
 // rows, bias 2304 fp32 or NULL; qkv_cls (n_seq, 2304) bf16 = the same projection of every sequence's CLS row (sf_gemm_bf16 on the strided CLS
 // rows); out (rows as X, 768) bf16: the PATCH rows are written (row 0 of every sequence comes from sf_attention_cls_combine on cls_partial,
 // [n_seq][12][n_groups / 4][66] fp32: one record per wave = 4 patches).  Reference: vit_helper.py:97-150 (time attention of DividedSpaceTimeBlock), heads = 12, head dim 64.
+static thread_local int g_qt_force_sched = -1;   // test hook (per calling thread): -1 default, 0 round 2's loop, 1 quadrant-phased
+extern "C" void sf_qkv_time_force_schedule(int sched) { g_qt_force_sched = sched; }
+
 extern "C" int sf_qkv_time_attention(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* qkv_cls,
                                      int64_t ldc, uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_groups, float scale,
                                      void* stream) {
@@ -440,7 +575,8 @@ extern "C" int sf_qkv_time_attention(const uint16_t* X, int64_t ldx, const uint1
   static bool attr_set = false;
   static int n_cu = 0;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)qkv_time_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, QT_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)qkv_time_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, QT_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)qkv_time_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, QT_LDS);
     if (e != hipSuccess) { sf_set_error("sf_qkv_time_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { sf_set_error("sf_qkv_time_attention: device query failed"); return -1; }
@@ -459,7 +595,11 @@ extern "C" int sf_qkv_time_attention(const uint16_t* X, int64_t ldx, const uint1
   int64_t blocks = (n_cu / 8) * 8;
   const int64_t need = ((tiles_m * QT_HEADS + 7) / 8) * 8;
   if (blocks > need) blocks = need;
-  hipLaunchKernelGGL(qkv_time_attn_kernel, dim3((unsigned)blocks), dim3(512), QT_LDS, (hipStream_t)stream, a);
+  static int env_sched = -1;
+  if (env_sched < 0) { const char* e = getenv("SF_QT_SCHED"); env_sched = e ? atoi(e) : QT_PP; }
+  const bool pp = g_qt_force_sched >= 0 ? g_qt_force_sched != 0 : env_sched != 0;
+  if (pp) hipLaunchKernelGGL(qkv_time_attn_kernel<true>, dim3((unsigned)blocks), dim3(512), QT_LDS, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(qkv_time_attn_kernel<false>, dim3((unsigned)blocks), dim3(512), QT_LDS, (hipStream_t)stream, a);
   SF_LAUNCH_CHECK();
   return 0;
 }

@@ -493,6 +493,35 @@ def test_qkv_time_attention(gpu, n_seq):
     torch.testing.assert_close(o[:, 1:], po, rtol=2 ** -7, atol=2 ** -7)
 
 
+@pytest.mark.parametrize('n_seq', [2, 29])
+def test_qkv_time_attention_schedules_bitwise(gpu, n_seq):
+    """The quadrant-phased main loop of sf_qkv_time_attention (round 3; CLS slices by LDS-DMA) against round 2's loop: same products in the same order,
+    same epilogue - attention output and CLS partials bit-identical on every repetition (29 sequences = 178 row tiles x 12 heads: several tiles per
+    workgroup, ragged last tile)."""
+    from synchformer_amd import ops, _lib
+    lib = _lib.load()
+    D, L = 768, 1 + 8 * 196
+    rows = n_seq * L
+    x = _bf(_rand(rows, D, seed=70)).to(gpu)
+    w, b = _bf(_rand(3 * D, D, seed=71, scale=0.05)).to(gpu), _rand(3 * D, seed=72).to(gpu)
+    qkv_cls = torch.empty(n_seq, 3 * D, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(x.view(n_seq, L, D)[:, 0], w, b, qkv_cls)
+
+    def run(sched):
+        lib.sf_qkv_time_force_schedule(sched)
+        try:
+            out = torch.full((rows, D), 7.0, device=gpu, dtype=torch.bfloat16)
+            part = torch.zeros(n_seq * 12 * 49 * 66, device=gpu)
+            ops.qkv_time_attention(x, w, b, qkv_cls, out, part, n_seq=n_seq, n_groups=196, scale=0.125)
+        finally:
+            lib.sf_qkv_time_force_schedule(-1)
+        return out, part
+    o0, p0 = run(0)
+    for rep in range(5):
+        o1, p1 = run(1)
+        assert torch.equal(o1, o0) and torch.equal(p1, p0), f'repetition {rep}'
+
+
 @pytest.mark.parametrize('cfg', [7, 10, 11])
 def test_gemm_persistent_epilogues(gpu, cfg):
     """The persistent 256x256 kernels (8 waves, 4 waves) over several tile rounds with a ragged last row

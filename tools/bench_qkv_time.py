@@ -3,7 +3,7 @@ import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
-from synchformer_amd import ops
+from synchformer_amd import ops, _lib
 
 dev = torch.device('cuda:0')
 L, D = 1569, 768
@@ -42,16 +42,20 @@ def main():
         ops.qkv_time_attention(x, w, b, qkv_cls, out, part, n_seq=n, n_groups=196, scale=0.125)
         ops.attention_cls_combine(part, out, n_part=49, n_seq=n, out_seq_rows=L, out_row=0, heads=12)
 
-    t = {'gemm': [], 'unfused': [], 'fused': [], 'fused_kernel': []}
+    t = {'gemm': [], 'unfused': [], 'fused': [], 'fused_kernel': [], 'r2_kernel': []}
+    lib = _lib.load()
     for _ in range(5):
         t['gemm'].append(timeit(lambda: ops.gemm(x, w, b, qkv)))
         t['unfused'].append(timeit(unfused))
         t['fused'].append(timeit(fused))
         t['fused_kernel'].append(timeit(lambda: ops.qkv_time_attention(x, w, b, qkv_cls, out, part, n_seq=n, n_groups=196, scale=0.125)))
+        lib.sf_qkv_time_force_schedule(0)
+        t['r2_kernel'].append(timeit(lambda: ops.qkv_time_attention(x, w, b, qkv_cls, out, part, n_seq=n, n_groups=196, scale=0.125)))
+        lib.sf_qkv_time_force_schedule(-1)
     med = {k_: sorted(v_)[len(v_) // 2] for k_, v_ in t.items()}
     fl = 2.0 * rows * 3 * D * D
     print(f"n_seg {n}: qkv GEMM alone {med['gemm']:7.1f} us ({fl / med['gemm'] / 1e6:4.0f} TF) | un-fused qkv + time attention + CLS {med['unfused']:7.1f} us | "
-          f"fused (CLS-row GEMM + kernel + combine) {med['fused']:7.1f} us, kernel alone {med['fused_kernel']:7.1f} us ({fl / med['fused_kernel'] / 1e6:4.0f} TF)")
+          f"fused (CLS-row GEMM + kernel + combine) {med['fused']:7.1f} us, kernel alone {med['fused_kernel']:7.1f} us ({fl / med['fused_kernel'] / 1e6:4.0f} TF) | round-2 loop kernel {med['r2_kernel']:7.1f} us")
 
 
 if __name__ == '__main__':
