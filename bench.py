@@ -4,19 +4,28 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+(a plain `python bench.py --gpus N` with N > 1 re-executes itself through torch.distributed.run, one rank per GPU.)
 
 Workload = BASELINE.json configs[1]: batched offset inference, configs/sync.yaml model, random-init weights,
 synthetic 224x224 @ 25 fps uint8 frames + 128x66 log-mel spectrograms already resident in HBM.  One "step" = one
 full Synchformer.forward() (RGB front-end -> Motionformer -> AST -> sync transformer -> logits) over B clips per GPU.
 Multi-GPU: inference shards by clip with no data-path collective ("replicas only"): every rank runs
 its own B clips; value = all clips / max-over-ranks time (weak scaling).
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the bf16 GEMM, timed live with HIP events on the
-launch stream in a second pass of the same K steps - see main()) and `cpu_baseline` (the CPU oracle timed on this box's host cores, N=1 only).
+Prints ONE JSON line on rank 0 with
+  * `roofline`: every GEMM-family kernel of the step timed live with HIP events on the launch stream in a second pass of the same K steps
+    (`roofline.kernels`, one entry per kernel symbol as rocprofv3 names it; `roofline.kernel` = the dominant one by time),
+  * `cpu_baseline`: the CPU oracle timed on this box's host cores (N = 1 only),
+  * `workloads`: BASELINE configs[2] / [3] / [4] (Stage-2 train step, Stage-1 AVCLIP train step at 2 clips per GPU, synchronizability fine-tune on
+    MXFP8 extractor GEMMs), a few steps each AFTER the headline region - on N > 1 these run their RCCL collectives (gradient all-reduce, bucketed
+    overlap); a watchdog prints the headline line without them if they do not finish.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -24,14 +33,15 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
-import torch  # noqa: E402
-
 FLOP_PER_CLIP = 5.725e12          # algorithmic forward FLOPs per 14-segment clip
 # FLOPs the engine actually executes per clip: both aggregator layers are computed for output row 0 only (motionformer.py:332 reads nothing
 # else), which drops 14 x 8 x (out_proj 0.232 + MLP 1.859 + the 196 unused query rows of the attention 0.118) G = 0.247 T of the visual
 # aggregator and 14 x 6 x 0.17 G of the audio one
 FLOP_PER_CLIP_EXECUTED = 5.725e12 - 0.247e12 - 0.014e12
 PEAK_BF16 = 2.5e15                # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_MXFP8 = 5.0e15               # dense MX-fp8 MFMA peak
+HBM_ACHIEVABLE = 6.3e12           # achievable HBM3E stream rate (MI355X_MICROARCH.md: 6.29 TB/s measured of 8 TB/s)
+TRAFFIC_FILE = 'profiles/r03_bench_roofline.json'
 
 
 def parse():
@@ -39,15 +49,17 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=16, help='clips per GPU per step (configs/sync.yaml batch = 16)')
+    ap.add_argument('--batch', type=int, default=None, help='clips per GPU per step (default 16 = configs/sync.yaml; stage1: 2 = segment_avclip.yaml)')
     ap.add_argument('--seg-chunk', type=int, default=224)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-workloads', action='store_true', help='headline workload only (no configs[2]/[3]/[4] section)')
+    ap.add_argument('--workload-steps', type=int, default=5)
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL over xGMI; default) | gloo (plumbing tests)')
     ap.add_argument('--single-device', action='store_true', help='TEST ONLY: put every rank on cuda:0 (needs --dist-backend gloo)')
     ap.add_argument('--workload', choices=['infer', 'train', 'stage1', 'ft'], default='infer',
                     help="infer = BASELINE configs[1] (headline metric); train = configs[2]: Stage-2 step, frozen extractors, "
-                         "backward + RCCL gradient all-reduce + fused clip/Adam (dropout 0.1 as in sync.yaml); ft = configs[4]: the "
+                         "backward + RCCL gradient all-reduce + fused clip/Adam (dropout 0.1 as in sync.yaml); stage1 = configs[3]; ft = configs[4]: the "
                          "synchronizability fine-tune step (13 segments, 2-way sync head) with the frozen extractors' Linears on MXFP8")
     ap.add_argument('--graph', action='store_true', help='replay the forward as one captured HIP graph (infer workload only)')
     ap.add_argument('--dropin', action='store_true', help="train workload through the drop-in nn.Module + torch.optim.Adam + GradScaler "
@@ -55,106 +67,140 @@ def parse():
     return ap.parse_args()
 
 
+def respawn_distributed(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks through torch.distributed.run (one per GPU, rendezvous on 127.0.0.1)."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    raise SystemExit(subprocess.run(cmd).returncode)
+
+
+import torch  # noqa: E402
+
+
+# ---- live kernel timing ---------------------------------------------------------------------------------------------------------------------
 class GemmTimer:
-    """Brackets every sf_gemm_bf16 launch with HIP events on the launch stream (= torch's current stream)."""
+    """Brackets every GEMM-family launch (sf_gemm_bf16, sf_gemm_res_ln768, sf_qkv_time_attention, sf_gemm_mxfp8) with HIP events on the launch
+    stream (= torch's current stream) and files it under the kernel symbol rocprofv3 reports for it."""
 
     def __init__(self):
         from synchformer_amd import ops
         self.ops = ops
-        self.orig = ops.gemm
-        self.records = []
+        self.records = []          # (e0, e1, flop, algorithmic bytes, kernel symbol, shape label, family)
         self.enabled = False
 
+    @staticmethod
+    def _gemm_symbol(m, n, k, out_bf16, gelu, res, mapped):
+        big = (not mapped) and m >= 8192 and n >= 512 and n % 64 == 0 and not (res and k <= 1024)
+        b = lambda v: 'true' if v else 'false'
+        if big and k % 128 == 0 and k >= 256:
+            return f'gemm_bf16_pp_kernel<{b(out_bf16)}, {b(gelu)}, {b(res)}>'
+        if big:
+            return f'gemm_bf16_persistent_kernel<{b(out_bf16)}, {b(gelu)}, {b(res)}>'
+        return 'gemm_bf16_kernel<GemmCfg<128, 128, 2, 2, 64, 2, 2, false>, ...> (small / mapped GEMMs: AST, aggregators, sync transformer, heads)'
+
+    def _rec(self, fn, flop, nbytes, sym, shape, family='bf16'):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.records.append((e0, e1, flop, nbytes, sym, shape, family))
+        return r
+
     def __enter__(self):
+        ops = self.ops
+        self.orig = {k: getattr(ops, k) for k in ('gemm', 'gemm_res_ln', 'gemm_mxfp8', 'qkv_time_attention')}
+        o = self.orig
+
         def timed(a, w, bias, out, *, M=None, **kw):
             if not self.enabled:
-                return self.orig(a, w, bias, out, M=M, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = self.orig(a, w, bias, out, M=M, **kw)
-            e1.record()
+                return o['gemm'](a, w, bias, out, M=M, **kw)
             m = a.shape[0] if M is None else M
-            n, k = w.shape
+            n, k = (w.shape[1], w.shape[0] * 64) if w.dim() == 3 else w.shape
             res = kw.get('residual')
             nbytes = m * k * 2 + n * k * 2 + m * n * out.element_size() + (m * n * 4 if res is not None else 0)   # A + W + C (+ R), each once
-            self.records.append((e0, e1, 2.0 * m * n * k, nbytes))
-            return r
+            sym = self._gemm_symbol(m, n, k, out.dtype == torch.bfloat16, bool(kw.get('gelu')), res is not None,
+                                    kw.get('c_map') is not None or kw.get('r_map') is not None)
+            return self._rec(lambda: o['gemm'](a, w, bias, out, M=M, **kw), 2.0 * m * n * k, nbytes, sym, f'N={n} K={k}')
+
         def timed_ln(a, w, bias, x, gamma, beta, y, eps, *, M=None, residual=None):
-            # the full-row GEMM + residual + LayerNorm launches are GEMM launches of the same family (sf_gemm_res_ln768)
             if not self.enabled:
-                return self.orig_ln(a, w, bias, x, gamma, beta, y, eps, M=M, residual=residual)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = self.orig_ln(a, w, bias, x, gamma, beta, y, eps, M=M, residual=residual)
-            e1.record()
+                return o['gemm_res_ln'](a, w, bias, x, gamma, beta, y, eps, M=M, residual=residual)
             m = a.shape[0] if M is None else M
             n, k = 768, a.shape[1]                                                     # w is (768, K) or k-step-major (K/32, 768, 32)
             nbytes = m * k * 2 + n * k * 2 + m * n * (4 + 4 + 2)                       # A + W + R read, X + Y written, each once
-            self.records.append((e0, e1, 2.0 * m * n * k, nbytes))
-            return r
+            return self._rec(lambda: o['gemm_res_ln'](a, w, bias, x, gamma, beta, y, eps, M=M, residual=residual), 2.0 * m * n * k, nbytes,
+                             'gemm_res_ln768_kernel<0, true>', f'K={k}')
+
         def timed_mx(a_q, a_s, w_q, w_s, bias, out, *, M=None, residual=None, gelu=False, out_scales=None):
-            # the MXFP8 launches are recorded apart: their roofline is the MX-fp8 matrix peak, not the bf16 one
             if not self.enabled:
-                return self.orig_mx(a_q, a_s, w_q, w_s, bias, out, M=M, residual=residual, gelu=gelu, out_scales=out_scales)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = self.orig_mx(a_q, a_s, w_q, w_s, bias, out, M=M, residual=residual, gelu=gelu, out_scales=out_scales)
-            e1.record()
+                return o['gemm_mxfp8'](a_q, a_s, w_q, w_s, bias, out, M=M, residual=residual, gelu=gelu, out_scales=out_scales)
             m = a_q.shape[0] if M is None else M
             n, k = w_q.shape
             nbytes = m * k + n * k + (m + n) * k // 32 + m * n * out.element_size() + (m * n * 4 if residual is not None else 0)
-            self.mx_records.append((e0, e1, 2.0 * m * n * k, nbytes))
-            return r
+            return self._rec(lambda: o['gemm_mxfp8'](a_q, a_s, w_q, w_s, bias, out, M=M, residual=residual, gelu=gelu, out_scales=out_scales),
+                             2.0 * m * n * k, nbytes, 'gemm_mxfp8_persistent_kernel', f'N={n} K={k}', 'mxfp8')
+
         def timed_qt(x, w, bias, qkv_cls, out, partials, *, n_seq, n_groups, scale):
-            # the fused temporal qkv + time-attention launch is a GEMM launch too (sf_qkv_time_attention): 2304 x 768 over the patch rows
             if not self.enabled:
-                return self.orig_qt(x, w, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = self.orig_qt(x, w, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale)
-            e1.record()
+                return o['qkv_time_attention'](x, w, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale)
             m, n, k = n_seq * 8 * n_groups, 2304, 768
             nbytes = m * k * 2 + n * k * 2 + m * 768 * 2                               # A + W read, the 768-wide attention output written
-            self.records.append((e0, e1, 2.0 * m * n * k, nbytes))
-            return r
-        self.mx_records = []
-        self.orig_qt = self.ops.qkv_time_attention
-        self.ops.qkv_time_attention = timed_qt
-        self.ops.gemm = timed
-        self.orig_ln = self.ops.gemm_res_ln
-        self.ops.gemm_res_ln = timed_ln
-        self.orig_mx = self.ops.gemm_mxfp8
-        self.ops.gemm_mxfp8 = timed_mx
+            return self._rec(lambda: o['qkv_time_attention'](x, w, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale),
+                             2.0 * m * n * k, nbytes, 'qkv_time_attn_kernel<true>', 'N=2304 K=768')
+
+        ops.gemm, ops.gemm_res_ln, ops.gemm_mxfp8, ops.qkv_time_attention = timed, timed_ln, timed_mx, timed_qt
         return self
 
     def __exit__(self, *a):
-        self.ops.gemm = self.orig
-        self.ops.gemm_res_ln = self.orig_ln
-        self.ops.gemm_mxfp8 = self.orig_mx
-        self.ops.qkv_time_attention = self.orig_qt
+        for k, v in self.orig.items():
+            setattr(self.ops, k, v)
 
-    def mx_summary(self):
-        ms = sum(r[0].elapsed_time(r[1]) for r in self.mx_records)
-        return len(self.mx_records), ms, sum(r[2] for r in self.mx_records), sum(r[3] for r in self.mx_records)
+    def kernels(self, steps):
+        """Per kernel symbol (and per shape inside it): launches per step, average duration, TFLOP/s, fraction of the roofline that bounds it."""
+        by = {}
+        for e0, e1, fl, nb, sym, shape, fam in self.records:
+            ms = e0.elapsed_time(e1)
+            d = by.setdefault(sym, {'family': fam, 'n': 0, 'ms': 0.0, 'flop': 0.0, 'bytes': 0.0, 'shapes': {}})
+            d['n'] += 1; d['ms'] += ms; d['flop'] += fl; d['bytes'] += nb
+            s = d['shapes'].setdefault(shape, {'n': 0, 'ms': 0.0, 'flop': 0.0, 'bytes': 0.0})
+            s['n'] += 1; s['ms'] += ms; s['flop'] += fl; s['bytes'] += nb
 
-    def summary(self):
-        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
-        fl = sum(r[2] for r in self.records)
-        self.bytes = sum(r[3] for r in self.records)
-        return len(self.records), ms, fl
+        def entry(name, d, fam):
+            peak = PEAK_MXFP8 if fam == 'mxfp8' else PEAK_BF16
+            tf, tbs = d['flop'] / (d['ms'] * 1e-3), d['bytes'] / (d['ms'] * 1e-3)
+            hbm = tbs / HBM_ACHIEVABLE > tf / peak                    # the roofline it sits closer to
+            e = {'name': name, 'launches': d['n'] // steps, 'avg_us': round(1e3 * d['ms'] / d['n'], 1), 'tflops': round(tf / 1e12, 1),
+                 'frac': round(tf / peak, 4), 'bound': 'hbm' if hbm else 'mfma'}
+            if hbm:
+                e['algorithmic_TBps'] = round(tbs / 1e12, 2)
+                e['frac_of_6.3TBps'] = round(tbs / HBM_ACHIEVABLE, 3)
+            return e
+        out = []
+        for sym, d in sorted(by.items(), key=lambda kv: -kv[1]['ms']):
+            e = entry(sym, d, d['family'])
+            e['share_of_gemm_time'] = None
+            if len(d['shapes']) > 1 and not sym.startswith('gemm_bf16_kernel'):
+                e['shapes'] = [entry(sh, sd, d['family']) for sh, sd in sorted(d['shapes'].items(), key=lambda kv: -kv[1]['ms'])]
+            out.append(e)
+        tot = sum(d['ms'] for d in by.values())
+        for e, (_, d) in zip(out, sorted(by.items(), key=lambda kv: -kv[1]['ms'])):
+            e['share_of_gemm_time'] = round(d['ms'] / tot, 3)
+        return out, by
 
 
 def pmc_traffic():
-    """HBM bytes per sf_gemm_bf16 launch from the committed PMC passes of this same command (tools/profile_bench.sh ->
-    profiles/r02_bench_roofline.json; counters cannot be read from inside the benchmark process).  None if absent."""
-    for tag in ('r02', 'r01'):
-        f = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', f'{tag}_bench_roofline.json')
+    """HBM bytes per GEMM-family launch from the committed PMC passes of this same command (tools/profile_bench.sh -> profiles/*_bench_roofline.json;
+    counters cannot be read from inside the benchmark process).  (value, source) or (None, None)."""
+    for f in (TRAFFIC_FILE, 'profiles/r02_bench_roofline.json', 'profiles/r01_bench_roofline.json'):
         try:
-            with open(f) as fh:
-                return round(json.load(fh)['traffic_bytes_per_launch'])
+            with open(ROOT / f) as fh:
+                return round(json.load(fh)['traffic_bytes_per_launch']), f'{f} (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)'
         except (OSError, KeyError, ValueError):
             continue
-    return None
+    return None, None
 
 
 def cpu_baseline(seconds_budget=25.0, max_threads=16):
@@ -162,18 +208,17 @@ def cpu_baseline(seconds_budget=25.0, max_threads=16):
     cores of this box, fp32.  BOUNDED sample: the visual branch (97.6 % of the path's CPU time) is timed
     on `k` of the 14 segments of one clip and scaled by 14/k (segments are independent and identical in cost); the audio
     branch and the sync transformer are timed in full for the clip.  Threads are capped: beyond ~16 the 768-wide matmuls
-    of this path slow down on a many-core host (measured), so `cores` reports the threads actually used."""
+    of this path slow down on a many-core host (measured), so `cores` reports the threads actually used.  A second, shorter sample
+    times the visual branch at B = 4 clips (SURVEY §8d asks for B in {1, 4})."""
     from synchformer_amd import synth
     from oracle import synchformer_cpu as O
     sd = synth.make_state_dict(1337)
     vis = O.rgb_frontend(synth.make_video_u8(1, 14))
     aud = synth.make_spectrogram(1, 14)
-    # thread count: measured on this host, one segment per candidate (the 768-wide matmuls of this path stop scaling long before a
-    # 256-thread host is full); the sweep is kept in the output so that `cores` is evidence, not an assertion
     ncpu = os.cpu_count() or 1
     sweep = {}
     with torch.no_grad():
-        for th in sorted({min(ncpu, c) for c in (max_threads, 32, 64)}):   # all 256 threads of the box: 78 s per segment (oversubscribed; measured once in round 2, profiles/r02_batch_sweep.md) - not re-timed on every run
+        for th in sorted({min(ncpu, c) for c in (max_threads, 32, 64)}):   # all 256 threads of the box: 78 s per segment (measured once in round 2, profiles/r02_batch_sweep.md)
             torch.set_num_threads(th)
             O.extract_vfeats(vis[:, :1], sd)                  # warm-up (thread pool, allocator)
             t0 = time.perf_counter()
@@ -192,37 +237,47 @@ def cpu_baseline(seconds_budget=25.0, max_threads=16):
         v = O._lin(vf, sd, 'vproj')
         O.global_transformer(torch.cat([v] * (14 // k + 1), 1)[:, :14].reshape(1, -1, 768), O._lin(af, sd, 'aproj').reshape(1, -1, 768), sd)
         t_rest = time.perf_counter() - t0
+        # B = 4: the visual branch of 4 clips on k4 segments each
+        k4 = int(max(1, min(3, 8.0 // max(4 * t1, 1e-3))))
+        vis4 = O.rgb_frontend(synth.make_video_u8(4, k4, seed=7))
+        t0 = time.perf_counter()
+        O.extract_vfeats(vis4, sd, chunk=4 * k4)
+        t_vis4 = (time.perf_counter() - t0) * 14.0 / k4
     total = t_vis + t_rest
-    return {'value': 1.0 / total, 'unit': 'clips/s', 'cores': threads, 'kind': 'port',
-            'sample': f'1 clip (clips are independent: the B = 4 rate is the same): visual branch on {k}/14 segments scaled x14/{k} '
-                      f'({t_vis:.1f} s/clip), audio branch + sync transformer in full ({t_rest:.2f} s); fp32 torch CPU oracle; host has '
-                      f'{os.cpu_count()} cpus',
+    total4 = t_vis4 + 4 * t_rest
+    return {'value': round(1.0 / total, 5), 'unit': 'clips/s', 'cores': threads, 'kind': 'port',
+            'sample': f'B = 1: visual branch on {k}/14 segments scaled x14/{k} ({t_vis:.1f} s/clip), audio branch + sync transformer in full '
+                      f'({t_rest:.2f} s); fp32 torch CPU oracle; host has {os.cpu_count()} cpus',
+            'b4': {'value': round(4.0 / total4, 5), 'unit': 'clips/s',
+                   'sample': f'B = 4: visual branch of 4 clips on {k4}/14 segments each, scaled x14/{k4} ({t_vis4:.1f} s per 4 clips) + 4 x the B = 1 audio / sync time'},
             'thread_sweep_s_per_segment': sweep}
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N > 1')
-    if args.single_device:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    if world > 1:
-        import torch.distributed as dist
-        if args.dist_backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
-        else:
-            dist.init_process_group(args.dist_backend)
+# ---- workloads ------------------------------------------------------------------------------------------------------------------------------
+WORKLOAD_DOC = {
+    'infer': ('clips/sec (14-seg offset pred)',
+              'BASELINE configs[1]: batched offset inference, configs/sync.yaml model (237.5M params, random-init), uint8 224x224 frames + 128x66 log-mel '
+              'resident in HBM, full forward to 21-way logits'),
+    'train': ('clips/sec (Stage-2 train step, 14 segments)',
+              'BASELINE configs[2]: Stage-2 sync-module train step (configs/sync.yaml, embd/resid/attn dropout 0.1): frozen extractors forward, '
+              'backward of proj + sync transformer (22.6M params), flat 90 MB RCCL gradient all-reduce, fused clip+Adam'),
+    'stage1': ('clips/sec (Stage-1 AVCLIP train step, 14 segments)',
+               'BASELINE configs[3]: Stage-1 segment-level contrastive train step (configs/segment_avclip.yaml): forward with saved activations + backward of '
+               'both towers (214.8M params), symmetric InfoNCE over B*14 segments, 7 gradient buckets all-reduced under the backward, fused clip+AdamW'),
+    'ft': ('clips/sec (synchronizability fine-tune step, 13 segments, MXFP8 extractor GEMMs)',
+           'BASELINE configs[4]: synchronizability fine-tune step (configs/ft_synchability.yaml): frozen extractors with their qkv / proj / fc1 / '
+           'fc2 Linears on MXFP8 (OCP e4m3 + E8M0 per 32 k), 184-token sync transformer with the 2-way sync head trained in bf16 (22.6M params), '
+           'RCCL gradient all-reduce, fused clip+Adam'),
+}
 
+
+def build_workload(name, args, dev, rank, world, local):
+    """-> dict(step_fn, vis, aud, B, S, serial(on), trainer)"""
     from synchformer_amd import synth
     from synchformer_amd.engine import SynchformerEngine
-    B = args.batch
-    if args.workload == 'train' and args.dropin:
+    B = args.batch if (args.batch is not None and name == args.workload) else (2 if name == 'stage1' else 16)
+    trainer, eng = None, None
+    if name == 'train' and args.dropin:
         import synchformer_amd as sa
         model = sa.instantiate_from_config(sa.sync_yaml_model_config())
         model.load_state_dict(synth.make_state_dict(1337), strict=True)
@@ -235,7 +290,6 @@ def main():
         opt = torch.optim.Adam([p_ for p_ in model.parameters() if p_.requires_grad], lr=2e-6 * world, betas=(0.9, 0.999), eps=1e-7)
         scaler = torch.amp.GradScaler('cuda')
         targets = synth.make_targets(B, 21, seed=1337 + rank).to(dev)
-        trainer = None
 
         def step_fn(v, a):
             opt.zero_grad(set_to_none=True)
@@ -248,23 +302,23 @@ def main():
             scaler.update()
             return loss.detach().reshape(1)
         eng = model._engine(need_sync=False)
-    elif args.workload == 'ft':
-        # BASELINE configs[4]: configs/ft_synchability.yaml - frozen extractors, GlobalTransformerWithSyncabilityHead over 13 segments (184 tokens),
-        # 2-way head, batch 16 per GPU; the extractors' qkv / proj / fc1 / fc2 run on MXFP8 operands (v_mfma_scale_f32_32x32x64_f8f6f4)
+    elif name == 'ft':
+        # configs/ft_synchability.yaml - frozen extractors, GlobalTransformerWithSyncabilityHead over 13 segments (184 tokens), 2-way head, batch 16 per
+        # GPU; the extractors' qkv / proj / fc1 / fc2 run on MXFP8 operands (v_mfma_scale_f32_32x32x64_f8f6f4)
         from synchformer_amd.train import SyncTrainer
         trainer = SyncTrainer(synth.make_state_dict(1337, n_pos=184, n_out=2, head='sync_head'), dev, lr=2e-6 * world, seg_chunk=args.seg_chunk,
                               embd_pdrop=0.1, resid_pdrop=0.1, attn_pdrop=0.1, seed=1337 + rank, fp8_towers=True)
         eng = trainer.engine
         targets = synth.make_targets(B, 2, seed=1337 + rank).to(dev)
         step_fn = lambda v, a: trainer.train_step(v, a, targets)
-    elif args.workload == 'train':
+    elif name == 'train':
         from synchformer_amd.train import SyncTrainer
         trainer = SyncTrainer(synth.make_state_dict(1337), dev, lr=2e-6 * world, seg_chunk=args.seg_chunk, embd_pdrop=0.1, resid_pdrop=0.1,
                               attn_pdrop=0.1, seed=1337 + rank)
         eng = trainer.engine
         targets = synth.make_targets(B, 21, seed=1337 + rank).to(dev)
         step_fn = lambda v, a: trainer.train_step(v, a, targets)
-    elif args.workload == 'stage1':
+    elif name == 'stage1':
         # Stage-1 AVCLIP train step (configs/segment_avclip.yaml: base_batch_size 2 clips x 14 segments per GPU, both towers trainable)
         from synchformer_amd.stage1 import AVCLIPTrainer
         sd = {k: v for k, v in synth.make_state_dict(1337).items() if k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}
@@ -273,98 +327,143 @@ def main():
     else:
         eng = SynchformerEngine(synth.make_state_dict(1337), dev, seg_chunk=args.seg_chunk)
         step_fn = eng.forward
-    S = 13 if args.workload == 'ft' else 14                                # ft_synchability.yaml: 13 segments (184-token sync transformer)
+    S = 13 if name == 'ft' else 14                                         # ft_synchability.yaml: 13 segments (184-token sync transformer)
     vis = synth.make_video_u8(B, S, seed=1337 + rank).to(dev)             # (B,S,16,3,224,224) uint8, HBM-resident
     aud = synth.make_spectrogram(B, S, seed=1337 + rank).to(dev)          # (B,S,1,128,66) fp32
+    serial = (lambda on: setattr(trainer, 'two_streams', on)) if name == 'stage1' else (lambda on: setattr(eng, 'audio_side_stream', on))
+    return {'step_fn': step_fn, 'vis': vis, 'aud': aud, 'B': B, 'S': S, 'serial': serial, 'trainer': None if args.dropin else trainer, 'eng': eng}
+
+
+def roofline_of(kernels, by, name):
+    """The `roofline` object for workload `name` from the per-kernel entries: the single dominant kernel (by time) + the family aggregate."""
+    dom = kernels[0]
+    fam = 'mxfp8' if name == 'ft' and any(d['family'] == 'mxfp8' for d in by.values()) else 'bf16'
+    sel = [d for d in by.values() if d['family'] == fam]
+    ms, fl, nb, n = sum(d['ms'] for d in sel), sum(d['flop'] for d in sel), sum(d['bytes'] for d in sel), sum(d['n'] for d in sel)
+    peak = PEAK_MXFP8 if fam == 'mxfp8' else PEAK_BF16
+    return dom, {'tflops': round(fl / (ms * 1e-3) / 1e12, 1), 'frac': round(fl / (ms * 1e-3) / peak, 4), 'launch_count': n, 'ms': ms,
+                 'flop': fl, 'bytes': nb, 'peak': peak / 1e12}
+
+
+def run_steps(w, steps, barrier, world, dist):
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = w['step_fn'](w['vis'], w['aud'])
+    barrier()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    return dt
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world == 1 and args.gpus > 1 and 'RANK' not in os.environ:
+        respawn_distributed(args)
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    rank = int(os.environ.get('RANK', 0))
+    local = 0 if args.single_device else int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
+
+    def gather_ranks(x):
+        if world == 1:
+            return [x]
+        mine = torch.tensor([x], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        return [float(t.item()) for t in allr]
+
+    name = args.workload
+    w = build_workload(name, args, dev, rank, world, local)
+    B, S = w['B'], w['S']
+    step_fn = w['step_fn']
     if args.graph:
-        assert args.workload == 'infer', '--graph serves the inference workload'
-        step_fn = eng.capture(vis, aud)
+        assert name == 'infer', '--graph serves the inference workload'
+        w['step_fn'] = step_fn = w['eng'].capture(w['vis'], w['aud'])
     for _ in range(args.warmup):
-        logits = step_fn(vis, aud)
-    comm_ms = []
-    timed_trainer = trainer if args.workload in ('train', 'stage1', 'ft') and not args.dropin else None
+        logits = step_fn(w['vis'], w['aud'])
+    timed_trainer = w['trainer'] if name in ('train', 'stage1', 'ft') else None
     if timed_trainer is not None and world > 1:
         timed_trainer.time_comm = True
     # ---- the timed region: EXACTLY K steps of the product configuration, no instrumentation -------------------------------------
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        logits = step_fn(vis, aud)
-        if timed_trainer is not None and world > 1:
-            comm_ms.append(timed_trainer._comm_ev)                 # events are read after the timed region
+        logits = step_fn(w['vis'], w['aud'])
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
     assert torch.isfinite(logits).all()
+    comm_ms = []
     if timed_trainer is not None and world > 1:
         timed_trainer.time_comm = False
-        mine = torch.tensor([timed_trainer.exposed_comm_ms()], device=dev, dtype=torch.float64)     # last step's stall on the gradient buckets
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        comm_ms = [round(float(t.item()), 3) for t in allr]
-    # ---- roofline pass: the same K steps again with every sf_gemm_bf16 launch bracketed by HIP events on its launch stream.  The
+        comm_ms = [round(x, 3) for x in gather_ranks(timed_trainer.exposed_comm_ms())]     # last step's stall on the gradient buckets
+    per_rank = [round(B * args.steps / x, 3) for x in gather_ranks(dt_local)]
+    dt = max_over_ranks(dt_local)
+
+    # ---- roofline pass: the same K steps again with every GEMM-family launch bracketed by HIP events on its launch stream.  The
     # product runs the audio tower on a second stream next to the visual one; an event pair on that stream would also time the queueing
     # behind the other tower's kernels, so for THIS pass the two towers are serialised on one stream (same kernels, same shapes, same
     # launch count; `value` above is not affected).  rocprofv3 --kernel-trace of this command sees both passes (profiles/).
-    n_gemm, gemm_ms, gemm_flop, dt_roof = 0, 0.0, 0.0, 0.0
-    n_mx, mx_ms, mx_flop, mx_bytes = 0, 0.0, 0.0, 0
-    if not args.no_kernel_timing and not args.graph:
-        serial = {'infer': lambda on: setattr(eng, 'audio_side_stream', on),
-                  'train': lambda on: setattr(eng, 'audio_side_stream', on),
-                  'ft': lambda on: setattr(eng, 'audio_side_stream', on),
-                  'stage1': lambda on: setattr(trainer, 'two_streams', on)}[args.workload]
-        serial(False)
+    def kernel_pass(wl, steps):
+        wl['serial'](False)
         with GemmTimer() as gt:
             gt.enabled = rank == 0
             barrier()
             t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step_fn(vis, aud)
+            for _ in range(steps):
+                wl['step_fn'](wl['vis'], wl['aud'])
             barrier()
-            dt_roof = time.perf_counter() - t1
-            if gt.enabled:
-                n_gemm, gemm_ms, gemm_flop = gt.summary()
-                n_mx, mx_ms, mx_flop, mx_bytes = gt.mx_summary()
-        serial(True)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+            dt_r = time.perf_counter() - t1
+            res = gt.kernels(steps) if gt.enabled and gt.records else (None, None)
+        wl['serial'](True)
+        return res[0], res[1], dt_r
+
+    kernels = by = None
+    dt_roof = 0.0
+    if not args.no_kernel_timing and not args.graph:
+        kernels, by, dt_roof = kernel_pass(w, args.steps)
+
     clips = B * world * args.steps
     value = clips / dt
+    out = None
     if rank == 0:
+        train_x = 3 if name == 'stage1' else 1
         out = {
-            'metric': {'infer': 'clips/sec (14-seg offset pred)', 'train': 'clips/sec (Stage-2 train step, 14 segments)',
-                       'stage1': 'clips/sec (Stage-1 AVCLIP train step, 14 segments)',
-                       'ft': 'clips/sec (synchronizability fine-tune step, 13 segments, MXFP8 extractor GEMMs)'}[args.workload],
-            'value': round(value, 3), 'unit': 'clips/s', 'n_gpus': world,
+            'metric': WORKLOAD_DOC[name][0],
+            'value': round(value, 3), 'unit': 'clips/s', 'n_gpus': world, 'rccl_ranks': world if (world > 1 and args.dist_backend == 'nccl') else 0,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'mxfp8 (extractor Linears) + bf16' if args.workload == 'ft' else 'bf16',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'mxfp8 (extractor Linears) + bf16' if name == 'ft' else 'bf16',
             'data': 'synthetic',
-            'config': {'workload': ('BASELINE configs[1]: batched offset inference, configs/sync.yaml model (237.5M params, '
-                                    'random-init), uint8 224x224 frames + 128x66 log-mel resident in HBM, full forward to 21-way logits')
-                       if args.workload == 'infer' else
-                       ('Stage-1 segment-level contrastive train step (configs/segment_avclip.yaml): forward with saved activations + backward of '
-                        'both towers (214.8M params), symmetric InfoNCE over B*14 segments, flat gradient all-reduce, fused clip+AdamW')
-                       if args.workload == 'stage1' else
-                       ('BASELINE configs[4]: synchronizability fine-tune step (configs/ft_synchability.yaml): frozen extractors with their qkv / proj / fc1 / '
-                        'fc2 Linears on MXFP8 (OCP e4m3 + E8M0 per 32 k), 184-token sync transformer with the 2-way sync head trained in bf16 (22.6M params), '
-                        'RCCL gradient all-reduce, fused clip+Adam')
-                       if args.workload == 'ft' else
-                       ('BASELINE configs[2]: Stage-2 sync-module train step (configs/sync.yaml, embd/resid/attn dropout 0.1): frozen extractors forward, '
-                        'backward of proj + sync transformer (22.6M params), flat 90 MB RCCL gradient all-reduce, fused clip+Adam'),
-                       'clips_per_gpu': B, 'segments': S, 'seg_chunk': args.seg_chunk, 'hip_graph': bool(args.graph),
-                       'parallelism': f'replicas x{world}' if args.workload == 'infer' else f'dp{world}'},
+            'config': {'workload': WORKLOAD_DOC[name][1], 'clips_per_gpu': B, 'segments': S, 'seg_chunk': args.seg_chunk, 'hip_graph': bool(args.graph),
+                       'parallelism': f'replicas x{world}' if name == 'infer' else f'dp{world}'},
+            'clips_per_s_by_rank': per_rank,
             # stage1: forward + dgrad + wgrad of every linear ~ 3x the forward FLOPs (attention backward ~2.5x; approximate)
-            'path_flop_per_clip': FLOP_PER_CLIP * (3 if args.workload == 'stage1' else 1) * S / 14,
-            'path_mfma_frac': round(value * FLOP_PER_CLIP * (3 if args.workload == 'stage1' else 1) * S / 14 / (world * PEAK_BF16), 4),
+            'path_flop_per_clip': FLOP_PER_CLIP * train_x * S / 14,
+            'path_mfma_frac': round(value * FLOP_PER_CLIP * train_x * S / 14 / (world * PEAK_BF16), 4),
             # the same with the FLOPs the engine executes (aggregators computed for their one consumed output row only)
-            'path_mfma_frac_executed': round(value * FLOP_PER_CLIP_EXECUTED * (3 if args.workload == 'stage1' else 1) * S / 14 / (world * PEAK_BF16), 4),
+            'path_mfma_frac_executed': round(value * FLOP_PER_CLIP_EXECUTED * train_x * S / 14 / (world * PEAK_BF16), 4),
         }
         if args.dropin:
             out['config']['dropin'] = 'nn.Module + autocast + GradScaler + clip_grad_norm_ + torch.optim.Adam' + (' + DistributedDataParallel' if world > 1 else '')
@@ -372,30 +471,77 @@ def main():
             out['comm'] = {'exposed_ms_last_step_by_rank': comm_ms,
                            'what': 'time the compute stream waited for the gradient all-reduce (Stage-2: one flat 90 MB bucket after the backward; '
                                    'Stage-1: 7 buckets launched under the backward, the wait is for what did not overlap)'}
-        if n_gemm:
-            ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'sf_gemm_bf16 + sf_gemm_res_ln768 + sf_qkv_time_attention (gemm_bf16_persistent_kernel, gemm_bf16_kernel, gemm_res_ln768_kernel, qkv_time_attn_kernel; GEMM FLOPs only - the fused LayerNorm / attention work of the last two is not counted)', 'achieved': round(ach, 1),
-                               'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': round(ach / (PEAK_BF16 / 1e12), 4),
-                               'traffic': pmc_traffic(), 'algorithmic_bytes_per_launch': round(gt.bytes / n_gemm),
-                               'launches': n_gemm // args.steps,
-                               'avg_launch_ms': round(gemm_ms / n_gemm, 4),
-                               'flop_per_launch': gemm_flop / n_gemm,
-                               'share_of_step_time': round(gemm_ms * 1e-3 / dt_roof, 3),
-                               'measured': f'HIP events on the launch stream over a second pass of the same {args.steps} steps with the two towers '
-                                           f'serialised on one stream ({1e3 * dt_roof / args.steps:.1f} ms/step); value is the un-instrumented two-stream pass'}
-        if n_mx:
-            ach = mx_flop / (mx_ms * 1e-3) / 1e12
-            # FT: the dominant kernel is the MXFP8 GEMM; its roofline is the dense MX-fp8 matrix peak (MI355X_MICROARCH.md: ~5 PFLOP/s)
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'sf_gemm_mxfp8 (gemm_mxfp8_persistent_kernel, v_mfma_scale_f32_32x32x64_f8f6f4)',
-                               'achieved': round(ach, 1), 'peak': 5000.0, 'unit': 'TFLOP/s', 'frac': round(ach / 5000.0, 4), 'traffic': None,
-                               'algorithmic_bytes_per_launch': round(mx_bytes / n_mx), 'launches': n_mx // args.steps,
-                               'avg_launch_ms': round(mx_ms / n_mx, 4), 'flop_per_launch': mx_flop / n_mx,
-                               'share_of_step_time': round(mx_ms * 1e-3 / dt_roof, 3),
-                               'bf16_gemm_launches': {'launches': n_gemm // args.steps, 'tflops': round(gemm_flop / max(gemm_ms, 1e-9) / 1e9, 1)},
-                               'measured': f'HIP events on the launch stream over a second pass of the same {args.steps} steps, towers serialised on one stream'}
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        if kernels:
+            dom, agg = roofline_of(kernels, by, name)
+            traffic, tsrc = pmc_traffic() if name == 'infer' else (None, None)
+            out['roofline'] = {
+                'bound': dom['bound'], 'kernel': dom['name'], 'achieved': dom['tflops'] if dom['bound'] == 'mfma' else dom['algorithmic_TBps'],
+                'peak': (agg['peak'] if dom['bound'] == 'mfma' else 8.0), 'unit': 'TFLOP/s' if dom['bound'] == 'mfma' else 'TB/s',
+                'frac': dom['frac'] if dom['bound'] == 'mfma' else round(dom['algorithmic_TBps'] / 8.0, 4),
+                'avg_launch_us': dom['avg_us'], 'launches': dom['launches'],
+                'traffic': traffic, 'traffic_source': tsrc,
+                'kernels': kernels,
+                'gemm_family': {'what': 'all GEMM-family launches of a step together (sf_gemm_bf16 + sf_gemm_res_ln768 + sf_qkv_time_attention'
+                                        + (' ; MXFP8 launches only' if name == 'ft' else '') + '), GEMM FLOPs only - the fused LayerNorm / attention / GELU work is not counted',
+                                'tflops': agg['tflops'], 'frac': agg['frac'], 'launches': agg['launch_count'] // args.steps,
+                                'avg_launch_ms': round(agg['ms'] / agg['launch_count'], 4), 'flop_per_launch': agg['flop'] / agg['launch_count'],
+                                'algorithmic_bytes_per_launch': round(agg['bytes'] / agg['launch_count']),
+                                'share_of_step_time': round(agg['ms'] * 1e-3 / dt_roof, 3)},
+                'measured': f'HIP events on the launch stream over a second pass of the same {args.steps} steps with the two towers '
+                            f'serialised on one stream ({1e3 * dt_roof / args.steps:.1f} ms/step); value is the un-instrumented two-stream pass'}
+
+    # ---- the other BASELINE workloads (configs[2], [3], [4]): a few steps each, after the headline region, into the same line ----------------
+    def emit():
+        if rank == 0 and out is not None:
+            print(json.dumps(out), flush=True)
+
+    if name == 'infer' and not args.no_workloads and not args.graph:
+        done = threading.Event()
+
+        def watchdog():                                            # a hung collective in an extra workload must not cost the headline number
+            if not done.wait(240.0):
+                if rank == 0:
+                    out['workloads_error'] = 'watchdog: the extra workloads did not finish within 240 s'
+                    emit()
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        del w, step_fn, logits
+        torch.cuda.empty_cache()
+        wl_out = {}
+        for wn in ('train', 'stage1', 'ft'):
+            try:
+                ww = build_workload(wn, args, dev, rank, world, local)
+                for _ in range(2):
+                    ww['step_fn'](ww['vis'], ww['aud'])
+                if ww['trainer'] is not None and world > 1:
+                    ww['trainer'].time_comm = True
+                dtw = max_over_ranks(run_steps(ww, args.workload_steps, barrier, world, dist))
+                comm = None
+                if ww['trainer'] is not None and world > 1:
+                    ww['trainer'].time_comm = False
+                    comm = [round(x, 3) for x in gather_ranks(ww['trainer'].exposed_comm_ms())]
+                kk, bb, _ = kernel_pass(ww, 2) if not args.no_kernel_timing else (None, None, 0.0)
+                if rank == 0:
+                    e = {'metric': WORKLOAD_DOC[wn][0], 'config': WORKLOAD_DOC[wn][1], 'clips_per_gpu': ww['B'], 'segments': ww['S'], 'steps': args.workload_steps,
+                         'ms_per_step': round(1e3 * dtw / args.workload_steps, 3), 'clips_per_s': round(ww['B'] * world * args.workload_steps / dtw, 3)}
+                    if comm is not None:
+                        e['comm_exposed_ms_last_step_by_rank'] = comm
+                    if kk:
+                        dom, agg = roofline_of(kk, bb, wn)
+                        e['roofline'] = {'kernel': dom['name'], 'bound': dom['bound'], 'frac': dom['frac'], 'tflops': dom['tflops'], 'avg_us': dom['avg_us'],
+                                         'gemm_family_tflops': agg['tflops'], 'gemm_family_frac': agg['frac'],
+                                         'kernels': [{k_: v_ for k_, v_ in x.items() if k_ != 'shapes'} for x in kk[:6]]}
+                    wl_out[wn] = e
+                del ww
+                torch.cuda.empty_cache()
+            except Exception as ex:                                # noqa: BLE001 - reported in the line, the headline number stands
+                wl_out[wn] = {'error': f'{type(ex).__name__}: {ex}'[:300]}
+        if rank == 0:
+            out['workloads'] = wl_out
+        done.set()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline()
+    emit()
     if world > 1:
         dist.destroy_process_group()
 

@@ -333,39 +333,48 @@ def test_avclip_dropin_training_loop(gpu):
     assert m._sf_trainer.drop_path_rate == 0.0 and abs(float(out['losses']['segment_contrastive_loss']) - float(ev['losses']['segment_contrastive_loss'])) < 5e-3
 
 
-def _gather_head_worker(rank, world, port, q):
+def _gather_head_worker(rank, world, port, q, backend='gloo'):
     import os
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    dev = torch.device('cuda', rank if backend == 'nccl' else 0)            # gloo: two processes share the one GPU; nccl (= RCCL): one GPU per rank
+    torch.cuda.set_device(dev)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from synchformer_amd import synth
         from synchformer_amd.stage1 import AVCLIPTrainer
         sd = {k: v for k, v in synth.make_state_dict(1337).items() if k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}
-        tr = AVCLIPTrainer(sd, 'cuda:0', gather_for_loss=True)
+        tr = AVCLIPTrainer(sd, dev, gather_for_loss=True)
         n = 4
         g = torch.Generator().manual_seed(7)
         v_all = torch.nn.functional.normalize(torch.randn(world * n, 768, generator=g), dim=-1)
         a_all = torch.nn.functional.normalize(v_all + 0.7 * torch.randn(world * n, 768, generator=g), dim=-1)
-        dv, da = tr._head(v_all[rank * n:(rank + 1) * n].cuda(), a_all[rank * n:(rank + 1) * n].cuda())
+        dv, da = tr._head(v_all[rank * n:(rank + 1) * n].to(dev), a_all[rank * n:(rank + 1) * n].to(dev))
         q.put((rank, dv.cpu(), da.cpu(), float(tr.losses.mean()), float(tr.g['logit_scale'])))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def test_gathered_contrastive_head_two_ranks(gpu):
-    """gather_for_loss=True with world_size 2 (two processes sharing the one GPU, gloo): forward all-gather of the embeddings
-    and the sum-over-ranks backward of torch.distributed.nn.all_gather (open_clip/model.py:489-494) against single-process autograd."""
+@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
+def test_gathered_contrastive_head_two_ranks(gpu, backend):
+    """gather_for_loss=True with world_size 2: forward all-gather of the embeddings (dist.all_gather_pair) and the sum-over-ranks backward of
+    torch.distributed.nn.all_gather (open_clip/model.py:489-494; dist.reduce_scatter_pair) against single-process autograd.  gloo: two processes
+    sharing the one GPU (all-reduce + slice); nccl = RCCL, one GPU per rank, the reduce_scatter_tensor branch (skipped on a single-GPU box)."""
     import socket
     import torch.multiprocessing as mp
+    if backend == 'nccl' and torch.cuda.device_count() < 2:
+        pytest.skip('the RCCL path needs two GPUs')
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     world, n = 2, 4
-    procs = [ctx.Process(target=_gather_head_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gather_head_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
@@ -391,18 +400,23 @@ def test_gathered_contrastive_head_two_ranks(gpu):
         assert abs(dscale - float(scales[r].grad)) < 1e-4 * abs(float(scales[r].grad))
 
 
-def _bucketed_worker(rank, world, port, q):
+def _bucketed_worker(rank, world, port, q, backend='gloo'):
     import os
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    dev = torch.device('cuda', rank if backend == 'nccl' else 0)
+    torch.cuda.set_device(dev)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from synchformer_amd import synth
         from synchformer_amd.stage1 import AVCLIPTrainer
         sd = {k: v for k, v in synth.make_state_dict(1337, gain=2.0).items() if k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}
-        tr = AVCLIPTrainer(sd, 'cuda:0', drop_path_rate=0.0)                  # the two passes below must see the same sub-network
-        vis = synth.make_video_u8(1, 2, 100 + rank).cuda()
-        aud = synth.make_spectrogram(1, 2, 100 + rank).cuda()
+        tr = AVCLIPTrainer(sd, dev, drop_path_rate=0.0)                      # the two passes below must see the same sub-network
+        vis = synth.make_video_u8(1, 2, 100 + rank).to(dev)
+        aud = synth.make_spectrogram(1, 2, 100 + rank).to(dev)
         tr.forward_backward(vis, aud)                                        # local gradients, no communication
         g_mean = tr.flat_g.clone()
         dist.all_reduce(g_mean)
@@ -417,16 +431,20 @@ def _bucketed_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_bucketed_gradient_allreduce_two_ranks(gpu):
-    """train_step's 7 gradient buckets (launched while the backward runs) must equal one mean all-reduce of the whole flat buffer."""
+@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
+def test_bucketed_gradient_allreduce_two_ranks(gpu, backend):
+    """train_step's 7 gradient buckets (launched while the backward runs) must equal one mean all-reduce of the whole flat buffer.  nccl: the
+    all_reduce(async_op=True) calls run on RCCL's own stream behind an event on the compute stream (two GPUs; skipped on a single-GPU box)."""
     import socket
     import torch.multiprocessing as mp
+    if backend == 'nccl' and torch.cuda.device_count() < 2:
+        pytest.skip('the RCCL path needs two GPUs')
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_bucketed_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_bucketed_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=900) for _ in procs)
