@@ -416,9 +416,63 @@ def e2e_masked(B=1, S=2, gain=2.0):
     print('masked logits', logits, 'unmasked', logits_nomask, 'max diff', float((logits - logits_nomask).abs().max()))
 
 
+def checkpoints():
+    """what the REAL reference constructors hold after reading the synthetic checkpoint files of ckpt_fixtures.py -
+    `MotionFormer(ckpt_path='...epoch_best.pt')` (motionformer.py:52-80, 156-173), `AST(ckpt_path='...epoch_best.pt')` (ast.py:58-60, 113-131) and
+    `AST(ckpt_path='MIT/ast-finetuned-audioset-10-10-0.4593')` with its 1214 -> 74 position cut (ast.py:49-53, 240-245).  For the last one the two
+    `from_pretrained` calls - the hub download - are pointed at the local synthetic weights; everything behind them is the reference's own code.
+    Stored per tensor: sum, sum |x|, first element (float64) + the whole truncated position table."""
+    import tempfile
+    import ckpt_fixtures as cf
+    ref = ref_import.import_reference()
+    tower = dict(extract_features=True, agg_time_module='torch.nn.Identity', add_global_repr=False)
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        s1 = cf.write_stage1_ckpt(td / 'epoch_best.pt')
+        with ref_import._cwd(ref_import.REF):
+            vt = ref['MotionFormer'](ckpt_path=str(s1), factorize_space_time=True, agg_space_module='TransformerEncoderLayer', **tower)
+            at = ref['AST'](ckpt_path=str(s1), max_spec_t=66, factorize_freq_time=True, agg_freq_module='TransformerEncoderLayer', **tower)
+        for tag, m in (('s1_v', vt), ('s1_a', at)):
+            names, vals = cf.digest(m.state_dict())
+            out[f'{tag}_names'], out[f'{tag}_vals'] = np.array(names), vals
+        out['s1_v_patch_embed_requires_grad'] = np.array([p.requires_grad for p in vt.patch_embed.parameters()])
+        # HF AST: the hub fetch replaced by the local synthetic weights, the constructor untouched
+        import model.modules.feat_extractors.audio.ast as ast_mod
+        hf_sd = cf.hf_ast_state()
+
+        def local_model(cls, name, revision=None, **kw):
+            assert name == 'MIT/ast-finetuned-audioset-10-10-0.4593'
+            cfg = ast_mod.ASTConfig()
+            cfg.num_labels = 527
+            m = cls(cfg)
+            st = m.load_state_dict(hf_sd, strict=True)
+            return m
+
+        def local_cfg(cls, name, revision=None, **kw):
+            cfg = cls()
+            cfg.num_labels = 527
+            return cfg
+        old_m, old_c = ast_mod.ASTForAudioClassification.from_pretrained, ast_mod.ASTConfig.from_pretrained
+        ast_mod.ASTForAudioClassification.from_pretrained = classmethod(local_model)
+        ast_mod.ASTConfig.from_pretrained = classmethod(local_cfg)
+        try:
+            with ref_import._cwd(ref_import.REF):
+                ah = ref['AST'](ckpt_path='MIT/ast-finetuned-audioset-10-10-0.4593', max_spec_t=66, factorize_freq_time=True,
+                                agg_freq_module='TransformerEncoderLayer', **tower)
+        finally:
+            ast_mod.ASTForAudioClassification.from_pretrained, ast_mod.ASTConfig.from_pretrained = old_m, old_c
+        ast_only = {k: v for k, v in ah.state_dict().items() if k.startswith('ast.')}           # (the aggregator is random-initialised there)
+        names, vals = cf.digest(ast_only)
+        out['hf_names'], out['hf_vals'] = np.array(names), vals
+        out['hf_position_embeddings'] = ah.state_dict()['ast.embeddings.position_embeddings'].numpy()
+    np.savez_compressed(HERE / 'checkpoints.npz', **out)
+    print('checkpoints:', {k: getattr(v, 'shape', None) for k, v in out.items()})
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['sync', 'sync_gain2', 'syncability', 'train', 'train_ft', 'avclip', 'shift_preds', 'segments', 'avclip_grads', 'masked']
+    which = sys.argv[1:] or ['sync', 'sync_gain2', 'syncability', 'train', 'train_ft', 'avclip', 'shift_preds', 'segments', 'avclip_grads', 'masked', 'checkpoints']
     if 'sync' in which:
         e2e_sync(2)
     if 'sync_gain2' in which:
@@ -441,3 +495,5 @@ if __name__ == '__main__':
         avclip_grads_full(2, 14)
     if 'masked' in which:
         e2e_masked(1, 2)
+    if 'checkpoints' in which:
+        checkpoints()

@@ -215,6 +215,36 @@ def test_checkpoint_adapters(tmp_path):
         sa.AST(ckpt_path=ck.HF_AST_NAME, max_spec_t=66, factorize_freq_time=True, agg_freq_module='TransformerEncoderLayer', **tower)
 
 
+def test_checkpoint_adapters_match_reference_loaders(tmp_path):
+    """f4 pinned to the reference's own loaders: tests/golden/checkpoints.npz holds, per tensor, what the REAL `MotionFormer(ckpt_path=...)` /
+    `AST(ckpt_path=...)` constructors (motionformer.py:52-80, 156-173; ast.py:49-60, 113-131, 240-245) ended up with after reading the synthetic
+    Stage-1 `epoch_best.pt` and the HF-style AST weights of tests/golden/ckpt_fixtures.py (tests/golden/make_golden.py::checkpoints).  The same files,
+    rebuilt here from their seeds and loaded through synchformer_amd.checkpoint, must give the same tensors under the same names."""
+    import sys
+    import numpy as np
+    import torch
+    import synchformer_amd as sa
+    gold_dir = Path(__file__).resolve().parent / 'golden'
+    sys.path.insert(0, str(gold_dir))
+    import ckpt_fixtures as cf
+    g = np.load(gold_dir / 'checkpoints.npz')
+    tower = dict(extract_features=True, agg_time_module='torch.nn.Identity', add_global_repr=False)
+    s1 = cf.write_stage1_ckpt(tmp_path / 'epoch_best.pt')
+    v = sa.MotionFormer(ckpt_path=str(s1), factorize_space_time=True, agg_space_module='TransformerEncoderLayer', **tower)
+    a = sa.AST(ckpt_path=str(s1), max_spec_t=66, factorize_freq_time=True, agg_freq_module='TransformerEncoderLayer', **tower)
+    for tag, m in (('s1_v', v), ('s1_a', a)):
+        names, vals = cf.digest(m.state_dict())
+        assert names == list(g[f'{tag}_names']), f'{tag}: state-dict names differ from the reference module'
+        assert np.array_equal(vals, g[f'{tag}_vals']), f'{tag}: {[n for n, x, y in zip(names, vals, g[f"{tag}_vals"]) if not np.array_equal(x, y)][:5]}'
+    assert [p.requires_grad for p in v.patch_embed.parameters()] == list(g['s1_v_patch_embed_requires_grad'])   # motionformer.py:176
+    hf = cf.write_hf_ast_dir(tmp_path / 'hf_ast')
+    ah = sa.AST(ckpt_path=str(hf), max_spec_t=66, factorize_freq_time=True, agg_freq_module='TransformerEncoderLayer', **tower)
+    ast_only = {k: x for k, x in ah.state_dict().items() if k.startswith('ast.')}
+    names, vals = cf.digest(ast_only)
+    assert names == list(g['hf_names']) and np.array_equal(vals, g['hf_vals'])
+    assert torch.equal(ah.state_dict()['ast.embeddings.position_embeddings'], torch.from_numpy(g['hf_position_embeddings']))   # rows [:12 * 6 + 2] of 1214
+
+
 def test_lr_schedules_match_torch_and_open_clip():
     """Stage-2 `constant_with_warmup` against torch's own SequentialLR (train_utils.py:236-246); Stage-1 cosine against the formulas of
     train_clip_src/training/scheduler.py:9-10, 43-53."""

@@ -208,6 +208,33 @@ def test_dropin_module_matches_golden(gpu):
     assert (l2 - logits - 1.0).abs().max().item() < 1e-4
 
 
+def test_checkpoint_adapter_path_reproduces_golden(gpu, tmp_path):
+    """f4 end to end on the GPU: the towers come out of a Stage-1 `epoch_best.pt` through `MotionFormer(ckpt_path=)` / `AST(ckpt_path=)` (the
+    adapters of synchformer_amd.checkpoint, pinned to the reference's loaders by test_checkpoint_adapters_match_reference_loaders), the sync module
+    out of a released-format `ckpt['model']` saved from a DDP wrapper - and the forward reproduces the real reference's golden logits."""
+    import sys
+    import synchformer_amd as sa
+    from synchformer_amd import checkpoint as ck, synth
+    sys.path.insert(0, str(GOLD))
+    import ckpt_fixtures as cf
+    g = np.load(GOLD / 'e2e_sync_B2.npz')
+    s1 = cf.write_stage1_ckpt(tmp_path / 'epoch_best.pt', seed=1337, gain=1.0)
+    cfg = sa.sync_yaml_model_config()
+    cfg['params']['vfeat_extractor']['params']['ckpt_path'] = str(s1)
+    cfg['params']['afeat_extractor']['params']['ckpt_path'] = str(s1)
+    model = sa.instantiate_from_config(cfg)
+    sd = synth.make_state_dict(1337)
+    torch.save({'model': {'module.' + k: v for k, v in sd.items() if not k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}, 'epoch': 3}, tmp_path / 'sync.pt')
+    status = model.load_state_dict(ck.synchformer_state(ck.load_file(tmp_path / 'sync.pt')), strict=False)
+    assert not status.unexpected_keys and all(k.startswith(('vfeat_extractor.', 'afeat_extractor.')) for k in status.missing_keys)
+    model = model.to(gpu).eval()
+    u8, aud = _inputs(2, 14)
+    with torch.no_grad():
+        loss, logits = model(u8.to(gpu), aud.to(gpu), torch.from_numpy(g['targets']).to(gpu))
+    assert (logits.cpu() - torch.from_numpy(g['logits'])).abs().max().item() < 1.5e-2
+    assert abs(loss.item() - float(g['loss'])) < 1e-2
+
+
 def test_graph_replay_matches_eager(gpu):
     """engine.capture(): the whole forward as one HIP graph; replay on new inputs must reproduce the eager launches bit for bit."""
     from synchformer_amd import synth
