@@ -284,6 +284,15 @@ int sf_attention_masked(const uint16_t* q, const uint16_t* k, const uint16_t* v,
 int sf_attention_cls_masked(const uint16_t* q, int64_t q_seq_rows, int q_row, const uint16_t* k, const uint16_t* v, int64_t ld,
                             int64_t kv_seq_rows, int kv_row0, int n_keys, uint16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row,
                             int64_t n_seq, int heads, int head_dim, float scale, const uint8_t* key_keep, void* stream);
+/* The masked forward on the fused schedules (round 3): sf_attention_cls_partial and sf_qkv_time_attention with the same key flags (one byte per K/V /
+ * token row, 0 = masked: -inf before the softmax, for the patch queries and for the CLS query's partial records; a record whose keys are all masked is
+ * (m = -inf, l = 0, o = 0) and drops out in sf_attention_cls_combine).  Reference: vit_helper.py:34-42, 107-141, sync_model.py:72-89. */
+int sf_attention_cls_partial_masked(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld, uint16_t* out, int64_t ldo, int64_t n_seq,
+                                    int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok, int cls_row, int heads,
+                                    int head_dim, float scale, float* cls_partial, const uint8_t* key_keep, void* stream);
+int sf_qkv_time_attention_masked(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* qkv_cls, int64_t ldc,
+                                 uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_groups, float scale, const uint8_t* key_keep,
+                                 void* stream);
 
 /* Stage-1 zero-shot sync check (shift_and_get_preds, train_clip_src/training/train.py:549-579): G = audio-to-video segment similarity
  * (n_clips*S x n_clips*S, fp32, clip-major); per clip, window sims are W-long diagonal sums of its S x S block;

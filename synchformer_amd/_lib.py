@@ -75,6 +75,8 @@ SIGNATURES = {
     'sf_attention_cls_partial': [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _ptr, _ptr],
     'sf_attention_cls_combine': [_ptr, _i32, _ptr, _i64, _i64, _i32, _i64, _i32, _ptr],
     'sf_qkv_time_attention': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i32, _f32, _ptr],
+    'sf_qkv_time_attention_masked': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i32, _f32, _ptr, _ptr],
+    'sf_attention_cls_partial_masked': [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _ptr, _ptr, _ptr],
     'sf_attention_cls': [_ptr, _i64, _i32, _ptr, _ptr, _i64, _i64, _i32, _i32, _ptr, _i64, _i64, _i32, _i64, _i32, _i32, _f32, _ptr],
 }
 _RESTYPES = {'sf_last_error': C.c_char_p, 'sf_build_info': C.c_char_p, 'sf_gemm_force_config': None, 'sf_gemm_res_ln_force_schedule': None, 'sf_qkv_time_force_schedule': None}

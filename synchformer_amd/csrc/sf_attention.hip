@@ -817,12 +817,13 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
       for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
     m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
     const float msc = m * sc2;
+    const float msafe = m == -INFINITY ? 0.f : msc;                  // every key of this query masked (the CLS query's slot of a fully masked group): zeros, not NaN
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = (SF_ATT_ABL & 4) ? s[kt][r] : __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc2, -msc));   // -inf -> 0
+        const float e = (SF_ATT_ABL & 4) ? s[kt][r] : __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc2, -msafe));   // -inf -> 0
         s[kt][r] = e; l += e;
       }
     }
@@ -961,6 +962,16 @@ extern "C" int sf_attention_cls_partial(const bf16_t* q, const bf16_t* k, const 
   SF_CHECK_ARG(n_tok <= 8 || (n_tok % 16) != 0, "sf_attention_cls_partial: n_tok %% 16 == 0 leaves no free query slot");
   return attention_impl(q, k, v, ld, out, ldo, n_seq, seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim, scale,
                         cls_partial, stream);
+}
+
+// ... and with token masks (the masked forward on the fused-CLS schedule): key_keep as in sf_attention_masked
+extern "C" int sf_attention_cls_partial_masked(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ldo, int64_t n_seq,
+                                               int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok, int cls_row,
+                                               int heads, int head_dim, float scale, float* cls_partial, const uint8_t* key_keep, void* stream) {
+  SF_CHECK_ARG(cls_partial && key_keep && cls_row >= 0 && head_dim == 64 && n_tok > 8, "sf_attention_cls_partial_masked: needs a partial buffer, key flags, cls_row >= 0, head_dim 64 and the MFMA path (n_tok > 8)");
+  SF_CHECK_ARG((n_tok % 16) != 0, "sf_attention_cls_partial_masked: n_tok %% 16 == 0 leaves no free query slot");
+  return attention_impl(q, k, v, ld, out, ldo, n_seq, seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim, scale,
+                        cls_partial, stream, key_keep);
 }
 
 static int attention_impl(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ldo,

@@ -72,6 +72,7 @@ struct QtArgs {
   float scale;
   uint32_t tiles_m;
   uint32_t head_chunk;                                           // heads per sweep over an XCD's row tiles (divides 12)
+  const uint8_t* key_keep;                                       // optional token keep flags, one byte per row of X (0 = masked key: -inf before the softmax)
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 qt_bf2;
@@ -422,6 +423,15 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
       // is reduced over the wave's 32 tokens (softmax state of sf_attention's cls_partial records, one record per wave).
       {
         const int qi = (elane >> 1) & 7, sub = elane & 1, tr = elane >> 1;
+        // token masks (Synchformer.forward(vis_mask=): vit_helper.py:34-42, 107-141): bit 0 = the CLS key, bit j + 1 = frame j of the lane's patch
+        uint32_t kb = 0x1ffu;
+        if (p.key_keep) {                                           // wave-uniform
+          const uint8_t* kk = p.key_keep + seq * p.seq_rows;
+          const int pidx = pp0 + (pi < np ? pi : np - 1);
+          kb = kk[0] ? 1u : 0u;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (kk[1 + j * p.n_groups + pidx]) kb |= 2u << j;
+        }
         const char* rowp = slab + tr * QT_SLAB_LD + sub * 64;
         uint4 q4[4];
 #pragma unroll
@@ -429,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
         float s[9];
         {
           float d = qt_dot8(q4[0], kcA[0]) + qt_dot8(q4[1], kcA[1]) + qt_dot8(q4[2], kcA[2]) + qt_dot8(q4[3], kcA[3]);
-          s[0] = qt_sum2(d) * sc;
+          s[0] = (kb & 1u) ? qt_sum2(d) * sc : -INFINITY;
         }
         float m = s[0];
         float cs = 0.f;
@@ -440,7 +450,7 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) k4[c] = *reinterpret_cast<const uint4*>(kp + c * 16);
           const float d = qt_dot8(q4[0], k4[0]) + qt_dot8(q4[1], k4[1]) + qt_dot8(q4[2], k4[2]) + qt_dot8(q4[3], k4[3]);
-          s[j + 1] = qt_sum2(d) * sc;
+          s[j + 1] = ((kb >> (j + 1)) & 1u) ? qt_sum2(d) * sc : -INFINITY;
           m = fmaxf(m, s[j + 1]);
         }
         {                                                           // the CLS query against the lane's OWN token
@@ -450,20 +460,23 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
           for (int c = 0; c < 4; ++c) k4[c] = *reinterpret_cast<const uint4*>(kp + c * 16);
           cs = qt_sum2(qt_dot8(qcA[0], k4[0]) + qt_dot8(qcA[1], k4[1]) + qt_dot8(qcA[2], k4[2]) + qt_dot8(qcA[3], k4[3])) * sc;
         }
+        if (m == -INFINITY) m = 0.f;                                // every key of the query masked (the CLS key included): all-zero weights, not NaN
         float l = 0.f;
 #pragma unroll
         for (int j = 0; j < 9; ++j) { s[j] = __builtin_amdgcn_exp2f(s[j] - m); l += s[j]; }
-        const float inv = 1.0f / l;
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
         // CLS-query softmax over the wave's tokens: frame lanes come in pairs (sub) holding the same score
-        const float c0 = qt_sum2(qt_dot8(qcA[0], kcA[0]) + qt_dot8(qcA[1], kcA[1]) + qt_dot8(qcA[2], kcA[2]) + qt_dot8(qcA[3], kcA[3])) * sc;
-        if (!live) cs = -INFINITY;
+        float c0 = qt_sum2(qt_dot8(qcA[0], kcA[0]) + qt_dot8(qcA[1], kcA[1]) + qt_dot8(qcA[2], kcA[2]) + qt_dot8(qcA[3], kcA[3])) * sc;
+        if (!(kb & 1u)) c0 = -INFINITY;
+        if (!live || !((kb >> (qi + 1)) & 1u)) cs = -INFINITY;
         float M = qt_max_row16(cs);
         M = fmaxf(M, __shfl_xor(M, 16, 64)); M = fmaxf(M, __shfl_xor(M, 32, 64));
         if (pp0 == 0) M = fmaxf(M, c0);                             // the CLS key itself is counted by the wave that holds patch 0
-        const float ec = __builtin_amdgcn_exp2f(cs - M);
+        const float Ms = M == -INFINITY ? 0.f : M;                  // every token of the wave masked: an empty record (M = -inf, L = 0), not NaN
+        const float ec = __builtin_amdgcn_exp2f(cs - Ms);
         float L = qt_sum_row16(sub == 0 ? ec : 0.f);
         L += __shfl_xor(L, 16, 64); L += __shfl_xor(L, 32, 64);
-        const float e0 = pp0 == 0 ? __builtin_amdgcn_exp2f(c0 - M) : 0.f;
+        const float e0 = pp0 == 0 ? __builtin_amdgcn_exp2f(c0 - Ms) : 0.f;
         L += e0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // every q read above is done
         if (sub == 0) {
@@ -560,9 +573,28 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
 static thread_local int g_qt_force_sched = -1;   // test hook (per calling thread): -1 default, 0 round 2's loop, 1 quadrant-phased
 extern "C" void sf_qkv_time_force_schedule(int sched) { g_qt_force_sched = sched; }
 
+static int qkv_time_impl(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* qkv_cls,
+                         int64_t ldc, uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_groups, float scale,
+                         const uint8_t* key_keep, void* stream);
+
 extern "C" int sf_qkv_time_attention(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* qkv_cls,
                                      int64_t ldc, uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_groups, float scale,
                                      void* stream) {
+  return qkv_time_impl(X, ldx, W, ldw, bias, qkv_cls, ldc, out, ldo, cls_partial, n_seq, n_groups, scale, nullptr, stream);
+}
+
+// The same with token masks: key_keep[row] == 0 (one byte per row of X, CLS rows included) masks K/V row `row` in the patch queries' time attention and
+// in the CLS query's partials, as sf_attention_masked / sf_attention_cls_masked do on the un-fused path (vit_helper.py:34-42, 107-141).
+extern "C" int sf_qkv_time_attention_masked(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* qkv_cls,
+                                            int64_t ldc, uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_groups, float scale,
+                                            const uint8_t* key_keep, void* stream) {
+  SF_CHECK_ARG(key_keep, "sf_qkv_time_attention_masked: null key_keep");
+  return qkv_time_impl(X, ldx, W, ldw, bias, qkv_cls, ldc, out, ldo, cls_partial, n_seq, n_groups, scale, key_keep, stream);
+}
+
+static int qkv_time_impl(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* qkv_cls,
+                         int64_t ldc, uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_groups, float scale,
+                         const uint8_t* key_keep, void* stream) {
   SF_CHECK_ARG(X && W && qkv_cls && out && cls_partial, "sf_qkv_time_attention: null pointer");
   SF_CHECK_ARG((n_groups % 4) == 0, "sf_qkv_time_attention: n_groups must be a multiple of 4 (a wave's four patches share one sequence)");
   SF_CHECK_ARG(n_groups >= 1 && (ldx % 8) == 0 && (ldw % 8) == 0 && (ldc % 8) == 0 && (ldo % 8) == 0, "sf_qkv_time_attention: row strides must be multiples of 8 elements");
@@ -585,7 +617,7 @@ extern "C" int sf_qkv_time_attention(const uint16_t* X, int64_t ldx, const uint1
   }
   QtArgs a;
   a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.qkv_cls = qkv_cls; a.ldc = ldc; a.out = out; a.ldo = ldo; a.cls_part = cls_partial;
-  a.n_seq = n_seq; a.seq_rows = seq_rows; a.n_groups = n_groups; a.scale = scale;
+  a.n_seq = n_seq; a.seq_rows = seq_rows; a.n_groups = n_groups; a.scale = scale; a.key_keep = key_keep;
   const int64_t tiles_m = (n_seq * n_groups + 31) / 32;
   SF_CHECK_ARG(tiles_m * QT_HEADS < ((int64_t)1 << 31) && n_seq * n_groups < ((int64_t)1 << 31), "sf_qkv_time_attention: too many tiles");
   a.tiles_m = (uint32_t)tiles_m;

@@ -270,7 +270,8 @@ class SynchformerEngine:
         tok_keep = None
         if keep is not None:                                            # content mask (n, 16, 3, 224, 224) bool -> token keep flags
             tok_keep = ops.token_mask_video(keep, self.v_w0_sign, torch.empty(rows, device=self.dev, dtype=torch.uint8))
-            fuse_mode = 'none'                                          # the fused CLS partials are not built for masks
+            if fuse_mode == 'both':                                     # the tiny-group kernel's partial mode has no masked entry point: time goes un-fused
+                fuse_mode = 'space'                                     # (large batches fuse it into its projection anyway, below)
 
         def divided(kind):
             if fuse_mode == 'none' or (fuse_mode == 'space' and kind == 'time'):
@@ -288,7 +289,7 @@ class SynchformerEngine:
                 groups = 196
             else:                # '(b f) n d' groups (vit_helper.py:341-342)
                 ops.attention_cls_partial(q, k, v, xn, part, n_seq=n, seq_rows=VIS_L, n_groups=8, row0=1, group_stride=196,
-                                          tok_stride=1, n_tok=196, cls_row=0, heads=12, head_dim=64, scale=0.125)
+                                          tok_stride=1, n_tok=196, cls_row=0, heads=12, head_dim=64, scale=0.125, key_keep=tok_keep)
                 groups = 8
             ops.attention_cls_combine(part, xn, n_part=groups, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
 
@@ -299,7 +300,7 @@ class SynchformerEngine:
         # sub-layer (sf_gemm_res_ln768: the fp32 stream is read and written once per sub-layer, no separate LayerNorm launch); the last block's
         # fc2 stays un-fused because the norm after it is the row-mapped final norm below.
         fuse_ln = self.fuse_ln and rows >= 128 * 64
-        fuse_time = self.fuse_time and tok_keep is None and rows >= 128 * 64    # the fused kernel has no key masks
+        fuse_time = self.fuse_time and rows >= 128 * 64
         att = big[:rows * D].view(rows, D)                                        # the time block's attention output (its qkv never exists)
         qkv_cls = self._buf('qkv_cls', n * 3 * D, torch.bfloat16).view(n, 3 * D)
         nb = len(self.v_blocks)
@@ -310,7 +311,7 @@ class SynchformerEngine:
                 # temporal qkv + time attention in one launch (sf_qkv_time_attention): the 2304-wide projection never reaches HBM.  The CLS rows'
                 # own projection (their k / v are every patch's first key, their q is the global CLS query) is a 224-row GEMM up front.
                 ops.gemm(xn.view(n, VIS_L, D)[:, 0], b['t_qkv'].w, b['t_qkv'].b, qkv_cls)
-                ops.qkv_time_attention(xn, b['t_qkv'].w, b['t_qkv'].b, qkv_cls, att, part, n_seq=n, n_groups=196, scale=0.125)
+                ops.qkv_time_attention(xn, b['t_qkv'].w, b['t_qkv'].b, qkv_cls, att, part, n_seq=n, n_groups=196, scale=0.125, key_keep=tok_keep)
                 ops.attention_cls_combine(part, att, n_part=49, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
                 t_out = att
             else:

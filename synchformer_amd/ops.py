@@ -233,10 +233,18 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
 
 def attention_cls_partial(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, *, n_seq: int,
                           seq_rows: int, n_groups: int, row0: int, group_stride: int, tok_stride: int, n_tok: int, cls_row: int, heads: int,
-                          head_dim: int, scale: float):
-    """`attention` + per-group partials of the CLS query into `partials` (fp32, >= n_seq*heads*n_groups*66 elements)."""
+                          head_dim: int, scale: float, key_keep: Optional[torch.Tensor] = None):
+    """`attention` + per-group partials of the CLS query into `partials` (fp32, >= n_seq*heads*n_groups*66 elements).  key_keep: optional uint8 flags per
+    K/V row (0 = masked key), as in `attention`."""
     assert q.dtype == k.dtype == v.dtype == out.dtype == torch.bfloat16 and partials.dtype == torch.float32
     assert _ld(q) == _ld(k) == _ld(v) and partials.numel() >= n_seq * heads * n_groups * 66
+    if key_keep is not None:
+        assert key_keep.dtype == torch.uint8 and key_keep.numel() >= n_seq * seq_rows
+        rc = _lib.load().sf_attention_cls_partial_masked(_dev(q, 'q'), _dev(k, 'k'), _dev(v, 'v'), _ld(q), _dev(out, 'out'), _ld(out), n_seq, seq_rows,
+                                                         n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim, float(scale),
+                                                         _dev(partials, 'partials'), _dev(key_keep, 'key_keep'), _stream())
+        _lib.check(rc, 'sf_attention_cls_partial_masked')
+        return out
     rc = _lib.load().sf_attention_cls_partial(_dev(q, 'q'), _dev(k, 'k'), _dev(v, 'v'), _ld(q), _dev(out, 'out'), _ld(out), n_seq, seq_rows,
                                               n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim, float(scale),
                                               _dev(partials, 'partials'), _stream())
@@ -245,13 +253,20 @@ def attention_cls_partial(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out
 
 
 def qkv_time_attention(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], qkv_cls: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, *,
-                       n_seq: int, n_groups: int, scale: float):
+                       n_seq: int, n_groups: int, scale: float, key_keep: Optional[torch.Tensor] = None):
     """Temporal qkv projection + time attention of every patch token in one launch (sf_qkv_time_attention): x (n_seq * (1 + 8 n_groups), 768) bf16,
     w (2304, 768) bf16, qkv_cls (n_seq, 2304) bf16 = the projection of the CLS rows; out: patch rows of the attention output, partials: the CLS
     query's softmax partials, one per 4 patches, for attention_cls_combine(n_part=n_groups // 4)."""
     assert x.dtype == w.dtype == qkv_cls.dtype == out.dtype == torch.bfloat16 and partials.dtype == torch.float32
     assert x.shape[1] == 768 and tuple(w.shape) == (2304, 768) and qkv_cls.shape[0] >= n_seq and qkv_cls.shape[1] == 2304 and out.shape[1] == 768
     assert x.shape[0] >= n_seq * (1 + 8 * n_groups) and out.shape[0] >= n_seq * (1 + 8 * n_groups) and partials.numel() >= n_seq * 12 * (n_groups // 4) * 66 and n_groups % 4 == 0
+    if key_keep is not None:                                   # token masks: one uint8 per row of x, 0 = masked key
+        assert key_keep.dtype == torch.uint8 and key_keep.numel() >= n_seq * (1 + 8 * n_groups)
+        rc = _lib.load().sf_qkv_time_attention_masked(_dev(x, 'x'), _ld(x), _dev(w, 'w'), _ld(w), _dev(bias, 'bias') if bias is not None else None,
+                                                      _dev(qkv_cls, 'qkv_cls'), _ld(qkv_cls), _dev(out, 'out'), _ld(out), _dev(partials, 'partials'), n_seq,
+                                                      n_groups, float(scale), _dev(key_keep, 'key_keep'), _stream())
+        _lib.check(rc, 'sf_qkv_time_attention_masked')
+        return out
     rc = _lib.load().sf_qkv_time_attention(_dev(x, 'x'), _ld(x), _dev(w, 'w'), _ld(w), _dev(bias, 'bias') if bias is not None else None,
                                            _dev(qkv_cls, 'qkv_cls'), _ld(qkv_cls), _dev(out, 'out'), _ld(out), _dev(partials, 'partials'), n_seq, n_groups,
                                            float(scale), _stream())

@@ -280,20 +280,48 @@ def test_token_masks_match_reference_golden(gpu):
     dn = (logits - torch.from_numpy(g['logits_nomask'])).abs().max().item()
     print(f'masked: vfeat relrms {ev:.4f} afeat relrms {ea:.4f} logits max {dl:.5f} (distance to the unmasked logits {dn:.3f})')
     assert ev < 1.5e-2 and ea < 1.5e-2 and dl < 4e-2 and dn > 0.1
-    # an all-ones mask must be a no-op, bit for bit (against the same un-fused CLS schedule the masked path uses)
-    import os
+    # an all-ones mask must be a no-op, bit for bit: since round 3 the masked forward runs the same fused schedule (space attention with CLS partials,
+    # at >= 6 segments also the fused temporal qkv + time attention) with key flags
     ones_v, ones_a = torch.ones_like(vm), torch.ones_like(am)
     got = eng.forward(u8.to(gpu), aud.to(gpu), ones_v.to(gpu), ones_a.to(gpu))
+    ref = eng.forward(u8.to(gpu), aud.to(gpu))
+    assert torch.equal(got, ref)
+
+
+def test_masked_forward_on_the_fused_schedule(gpu):
+    """Masks at a batch large enough for every fused launch (6 segments = 9414 token rows: sf_qkv_time_attention_masked, sf_attention_cls_partial_masked,
+    sf_gemm_res_ln768): against the un-fused masked schedule of round 2 (which the real reference's golden pins at 2 segments), and an all-ones mask
+    bit-equal to no mask.  One whole frame and one whole 4-patch x 8-frame wave are masked on top of the random boxes, so that a CLS partial record with
+    every key masked (m = -inf, l = 0) goes through the combine."""
+    import os
+    from synchformer_amd import synth
+    from synchformer_amd.engine import SynchformerEngine
+    B, S = 1, 6
+    sd = synth.make_state_dict(1337, gain=2.0, n_pos=2 + S * 14)
+    eng = SynchformerEngine(sd, gpu)
+    u8, aud = synth.make_video_u8(B, S, 77), synth.make_spectrogram(B, S, 77)
+    vm, am = synth.make_masks(B, S, 77)
+    vm[0, 1, 4:6] = False                                                     # segment 1: frames 4-5 = one whole token frame
+    vm[0, 2, :, :, 0:16, 0:64] = False                                        # segment 2: patches 0-3 in all 8 token frames = one whole wave of the fused kernel
+    fused = eng.forward(u8.to(gpu), aud.to(gpu), vm.to(gpu), am.to(gpu))
+    assert torch.isfinite(fused).all()
     old = os.environ.get('SF_CLS_FUSION')
     os.environ['SF_CLS_FUSION'] = 'none'
+    eng.fuse_time = False
     try:
-        ref = eng.forward(u8.to(gpu), aud.to(gpu))
+        unfused = eng.forward(u8.to(gpu), aud.to(gpu), vm.to(gpu), am.to(gpu))
     finally:
+        eng.fuse_time = True
         if old is None:
             del os.environ['SF_CLS_FUSION']
         else:
             os.environ['SF_CLS_FUSION'] = old
-    assert torch.equal(got, ref)
+    nomask = eng.forward(u8.to(gpu), aud.to(gpu))
+    d, dn = (fused - unfused).abs().max().item(), (fused - nomask).abs().max().item()
+    print(f'masked fused vs un-fused: {d:.5f}; distance to the unmasked logits {dn:.3f}')
+    assert d < 1e-2 and dn > 0.05
+    ones = eng.forward(u8.to(gpu), aud.to(gpu), torch.ones_like(vm).to(gpu), torch.ones_like(am).to(gpu))
+    assert torch.equal(ones, nomask)
 
 
 def test_dropin_module_forward_with_masks(gpu):
