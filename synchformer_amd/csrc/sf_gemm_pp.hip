@@ -21,6 +21,10 @@
 //     counted wait that retires it, with the wait in front of the phase's FIRST barrier (so that the lagging group's wait also precedes
 //     the leading group's read); a buffer is refilled two phases after its last read.
 // Fragment registers: a[2][4] (one A half, 2 row blocks x 4 k-steps), b0[4], b1[4]: 64 VGPRs beside the 128 accumulators.
+// Schedules measured against this one and dropped (profiles/r03_gemm_pp.md): the phase's LDS-DMA issue behind the first MFMAs of the matrix segment
+// (-5 %) or in front of the fragment reads (neutral); the NEXT phase's fragment reads interleaved with the MFMAs into the registers they free
+// (-3 %: any instruction between the MFMAs costs the matrix pipe more than the read segment gains); reads balanced 8 / 4 / 8 / 4 (with the first:
+// -5 %); two 16-MFMA phases per k-tile, i.e. half the barriers (+1 %, within noise).  The matrix segment has to stay pure MFMA.
 #include "sf_gemm_common.h"
 #include <type_traits>
 
@@ -74,6 +78,13 @@ __device__ __forceinline__ void pp_barrier() {
 #define PP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 template <int V> using ic = std::integral_constant<int, V>;
+
+#if SF_PP_ABL & 32
+// tracing build (SF_PP_ABL & 32): per wave, s_memtime cycles spent in [read segment | wait at the first barrier | matrix segment | wait at the second
+// barrier | epilogue], summed over the launch: g_pp_trace[block][wave][5]
+__device__ unsigned long long g_pp_trace[256 * 8 * 5];
+#define PP_T(var) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); var = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#endif
 
 template <bool OUT_BF16, bool GELU, bool HAS_RES>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   issue(ic<0>{}, ic<0>{}, ic<1>{}); issue(ic<1>{}, ic<0>{}, ic<1>{}); issue(ic<2>{}, ic<0>{}, ic<1>{}); issue(ic<3>{}, ic<0>{}, ic<1>{});
   issue(ic<0>{}, ic<1>{}, ic<1>{}); issue(ic<1>{}, ic<1>{}, ic<1>{});
   asm volatile("" ::: "memory");
-  pp_wait_vmcnt<8>();                                            // A0 | B0 of k-tile 0 have landed (this wave's pieces)
+  pp_wait_vmcnt<8>();                                            // A0 | B0 of k-tile 0 have landed (this wave's pieces)   // A0 | B0 (schedule 3: and B1) of k-tile 0 have landed (this wave's pieces)
   pp_barrier();
   int extra = 0;                                                 // epilogue stores that may still be in flight behind the loads (first k-tile of a tile)
 
@@ -224,6 +235,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
       if (SF_PP_PRIO) __builtin_amdgcn_s_setprio(0);
     };
     // one k-tile held in stage S; `first` = first k-tile after an epilogue
+#if SF_PP_ABL & 32
+    unsigned long long tr_t0, tr_t1, tr_t2, tr_t3, tr_acc[5] = {0, 0, 0, 0, 0};
+    PP_T(tr_t0);
+    auto bar_a = [&]() { PP_T(tr_t1); pp_barrier(); PP_T(tr_t2); tr_acc[0] += tr_t1 - tr_t0; tr_acc[1] += tr_t2 - tr_t1; };
+    auto bar_b = [&]() { PP_T(tr_t3); pp_barrier(); PP_T(tr_t0); tr_acc[2] += tr_t3 - tr_t2; tr_acc[3] += tr_t0 - tr_t3; };
+#else
+    auto bar_a = [&]() { pp_barrier(); };
+    auto bar_b = [&]() { pp_barrier(); };
+#endif
     auto ktile = [&](auto Sc, auto SURE, bool first) {
       constexpr int S = decltype(Sc)::value;
       const char* st = smem + S * Q_STAGE;
@@ -236,22 +256,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) if (rd) a[i][kk] = *reinterpret_cast<const bf16x8*>(st + i * 4096 + a_off[kk]);
       __builtin_amdgcn_sched_barrier(0);
-      wait_loads(issue(ic<2>{}, ic<S ^ 1>{}, SURE), first);            // B1(kt+1); B1(kt) landed
-      pp_barrier();
+      wait_loads(issue(ic<2>{}, ic<S ^ 1>{}, SURE), first);            // B1(kt+1) issued; B1(kt) landed
+      bar_a();
       __builtin_amdgcn_sched_barrier(0);
       mma(ic<0>{}, ic<0>{}, b0);
       __builtin_amdgcn_sched_barrier(0);
-      pp_barrier();
+      bar_b();
       // ---- phase 1: (A0, B1) ----
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) if (rd) b1[kk] = *reinterpret_cast<const bf16x8*>(st + Q_HALF + b_off[kk]);
       __builtin_amdgcn_sched_barrier(0);
-      wait_loads(issue(ic<3>{}, ic<S ^ 1>{}, SURE), first);            // A1(kt+1); A1(kt) landed
-      pp_barrier();
+      wait_loads(issue(ic<3>{}, ic<S ^ 1>{}, SURE), first);            // A1(kt+1) issued; A1(kt) landed
+      bar_a();
       __builtin_amdgcn_sched_barrier(0);
       mma(ic<0>{}, ic<1>{}, b1);
       __builtin_amdgcn_sched_barrier(0);
-      pp_barrier();
+      bar_b();
       // ---- phase 2: (A1, B1) ----
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
@@ -259,18 +279,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
         for (int i = 0; i < 2; ++i) if (rd) a[i][kk] = *reinterpret_cast<const bf16x8*>(st + Q_HALF + i * 4096 + a_off[kk]);
       __builtin_amdgcn_sched_barrier(0);
       issue(ic<0>{}, ic<S>{}, SURE);                             // A0(kt+2); phase 3 reads nothing: no wait
-      pp_barrier();
+      bar_a();
       __builtin_amdgcn_sched_barrier(0);
       mma(ic<1>{}, ic<1>{}, b1);
       __builtin_amdgcn_sched_barrier(0);
-      pp_barrier();
+      bar_b();
       // ---- phase 3: (A1, B0) ----
       wait_loads(issue(ic<1>{}, ic<S>{}, SURE), first);                // B0(kt+2); A0 | B0 of k-tile kt+1 landed
-      pp_barrier();
+      bar_a();
       __builtin_amdgcn_sched_barrier(0);
       mma(ic<1>{}, ic<0>{}, b0);
       __builtin_amdgcn_sched_barrier(0);
-      pp_barrier();
+      bar_b();
     };
 
     if (wm == 1 && !(SF_PP_ABL & 8)) pp_barrier();                                   // the wm = 1 waves run one barrier behind
@@ -282,6 +302,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 
     const int64_t em0 = m0; const int en0 = n0;
     extra = 0;
+#if SF_PP_ABL & 32
+    unsigned long long tr_e0; PP_T(tr_e0);
+#endif
     if (SF_PP_ABL & 1) {
       float sum = 0.f;
 #pragma unroll
@@ -372,6 +395,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
         epi_group_store<OUT_BF16, GELU, HAS_RES>(v, bias4, res[g & 1], rc, coff0 + g * 4 * cstep, cstep);
       }
     }
+#if SF_PP_ABL & 32
+    {
+      unsigned long long tr_e1; PP_T(tr_e1);
+      tr_acc[4] += tr_e1 - tr_e0;
+      if (lane == 0 && blockIdx.x < 256) for (int i = 0; i < 5; ++i) g_pp_trace[(blockIdx.x * 8 + wave) * 5 + i] += tr_acc[i];
+    }
+#endif
     t += per_xcd_blocks;
     if (t >= t_end) break;
     tile_origin(t, m0, n0);
@@ -404,8 +434,27 @@ static int launch_gemm_pp(GemmArgs a, hipStream_t s) {
   int64_t blocks = (n_cu[dev] / 8) * 8;                          // one workgroup per CU, a multiple of the 8 XCDs
   const int64_t need = ((total + 7) / 8) * 8;
   if (blocks > need) blocks = need;
+#if SF_PP_ABL & 32
+  static unsigned long long zero[256 * 8 * 5] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pp_trace), zero, sizeof(zero));
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), Q_LDS, s, a);
   SF_LAUNCH_CHECK();
+#if SF_PP_ABL & 32
+  {
+    static unsigned long long host[256 * 8 * 5];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pp_trace), sizeof(host));
+    static int calls = 0;
+    if ((calls++ % 16) == 0) {
+      double g[2][5] = {{0}};
+      for (int b = 0; b < 256; ++b) for (int w = 0; w < 8; ++w) for (int i = 0; i < 5; ++i) g[w >> 2][i] += (double)host[(b * 8 + w) * 5 + i] / (256.0 * 4.0);
+      const char* nm[5] = {"read segment", "wait barrier A", "matrix segment", "wait barrier B", "epilogue"};
+      fprintf(stderr, "[pp trace] M %lld N %d K %d obf %d gelu %d res %d: cycles per wave\n", (long long)a.M, a.N, a.K, (int)OUT_BF16, (int)GELU, (int)HAS_RES);
+      for (int i = 0; i < 5; ++i) fprintf(stderr, "    %-16s waves 0-3: %12.0f   waves 4-7: %12.0f\n", nm[i], g[0][i], g[1][i]);
+    }
+  }
+#endif
   return 0;
 }
 
