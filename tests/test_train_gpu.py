@@ -603,3 +603,30 @@ def test_dropin_under_reference_ddp_wrapper(gpu):
     for rank, err, scale, spread in res:
         assert err <= 1e-6 * max(1.0, scale), res                                        # DDP average == manual mean of the local gradients
         assert spread > 1e-4 * scale, res                                                # ... and the two ranks really had different gradients
+
+
+def test_ft_fp8_train_step_matches_reference(gpu):
+    """What `bench.py --workload ft` times, as a whole: `SyncTrainer(sd, fp8_towers=True).train_step` from the uint8 frames / spectrograms (the frozen
+    extractors' Linears on MXFP8 operands, the 184-token sync transformer + 2-way head trained in bf16) against the REAL reference's fine-tune step
+    (tests/golden/train_ft_B2_grads.npz: fp32 extractors).  Stated bound of the fp8 path (two e4m3 roundings per product, 72 quantised GEMMs deep; the bf16
+    step is within 5e-3 / 1e-2 / 3 %): loss within 1e-2, logits within 2.5e-2, every gradient norm within 8 % and the stored gradients' cosine > 0.99
+    (measured: 7.5e-4, 6.5e-3, 2.0 %, 0.9952)."""
+    from synchformer_amd import synth
+    from synchformer_amd.train import SyncTrainer
+    g = np.load(GOLD / 'train_ft_B2_grads.npz')
+    B, S = int(g['B']), int(g['S'])
+    sd = synth.make_state_dict(1337, n_pos=184, n_out=2, head='sync_head')
+    tr = SyncTrainer(sd, gpu, fp8_towers=True)
+    u8, aud = synth.make_video_u8(B, S, 1337).to(gpu), synth.make_spectrogram(B, S, 1337).to(gpu)
+    tgt = torch.from_numpy(g['targets']).to(gpu)
+    p_before = {n: tr.p[n].clone() for n in tr.keys[:4]}
+    loss = tr.train_step(u8, aud, tgt, lr=0.0).item()                       # lr 0: the gradients stay inspectable, the parameters unchanged
+    dl = (tr.logits.cpu() - torch.from_numpy(g['logits'])).abs().max().item()
+    names = [str(n) for n in g['names']]
+    assert names == tr.keys
+    worst = max(max(0.0, abs(tr.g[n].norm().item() - ref) - 1e-4) / max(ref, 1e-9) for n, ref in zip(names, g['grad_norms']))
+    cos = min(torch.nn.functional.cosine_similarity(tr.g[k[len('grad__'):].replace('__', '.')].flatten().cpu(), torch.from_numpy(g[k]).flatten(), dim=0).item()
+              for k in g.files if k.startswith('grad__') and 'rows0_4' not in k)
+    print(f'FT fp8 train step: loss {loss:.5f} ref {float(g["loss"]):.5f} | logits max |d| {dl:.4f} | worst grad-norm deviation {worst:.4f} | min cosine {cos:.5f}')
+    assert abs(loss - float(g['loss'])) < 1e-2 and dl < 2.5e-2 and worst < 0.08 and cos > 0.99
+    assert all(torch.equal(tr.p[n], p_before[n]) for n in p_before)
