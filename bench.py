@@ -125,13 +125,13 @@ class GemmTimer:
                                     kw.get('c_map') is not None or kw.get('r_map') is not None)
             return self._rec(lambda: o['gemm'](a, w, bias, out, M=M, **kw), 2.0 * m * n * k, nbytes, sym, f'N={n} K={k}')
 
-        def timed_ln(a, w, bias, x, gamma, beta, y, eps, *, M=None, residual=None):
+        def timed_ln(a, w, bias, x, gamma, beta, y, eps, *, M=None, residual=None, **kw):
             if not self.enabled:
-                return o['gemm_res_ln'](a, w, bias, x, gamma, beta, y, eps, M=M, residual=residual)
+                return o['gemm_res_ln'](a, w, bias, x, gamma, beta, y, eps, M=M, residual=residual, **kw)
             m = a.shape[0] if M is None else M
             n, k = 768, a.shape[1]                                                     # w is (768, K) or k-step-major (K/32, 768, 32)
             nbytes = m * k * 2 + n * k * 2 + m * n * (4 + 4 + 2)                       # A + W + R read, X + Y written, each once
-            return self._rec(lambda: o['gemm_res_ln'](a, w, bias, x, gamma, beta, y, eps, M=M, residual=residual), 2.0 * m * n * k, nbytes,
+            return self._rec(lambda: o['gemm_res_ln'](a, w, bias, x, gamma, beta, y, eps, M=M, residual=residual, **kw), 2.0 * m * n * k, nbytes,
                              'gemm_res_ln768_kernel<0, true>', f'K={k}')
 
         def timed_mx(a_q, a_s, w_q, w_s, bias, out, *, M=None, residual=None, gelu=False, out_scales=None):
@@ -143,12 +143,12 @@ class GemmTimer:
             return self._rec(lambda: o['gemm_mxfp8'](a_q, a_s, w_q, w_s, bias, out, M=M, residual=residual, gelu=gelu, out_scales=out_scales),
                              2.0 * m * n * k, nbytes, 'gemm_mxfp8_persistent_kernel', f'N={n} K={k}', 'mxfp8')
 
-        def timed_qt(x, w, bias, qkv_cls, out, partials, *, n_seq, n_groups, scale):
+        def timed_qt(x, w, bias, qkv_cls, out, partials, *, n_seq, n_groups, scale, **kw):
             if not self.enabled:
-                return o['qkv_time_attention'](x, w, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale)
+                return o['qkv_time_attention'](x, w, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale, **kw)
             m, n, k = n_seq * 8 * n_groups, 2304, 768
             nbytes = m * k * 2 + n * k * 2 + m * 768 * 2                               # A + W read, the 768-wide attention output written
-            return self._rec(lambda: o['qkv_time_attention'](x, w, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale),
+            return self._rec(lambda: o['qkv_time_attention'](x, w, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale, **kw),
                              2.0 * m * n * k, nbytes, 'qkv_time_attn_kernel<true>', 'N=2304 K=768')
 
         ops.gemm, ops.gemm_res_ln, ops.gemm_mxfp8, ops.qkv_time_attention = timed, timed_ln, timed_mx, timed_qt
@@ -442,8 +442,14 @@ def main():
 
     kernels = by = None
     dt_roof = 0.0
+    roofline_error = None
     if not args.no_kernel_timing and not args.graph:
-        kernels, by, dt_roof = kernel_pass(w, args.steps)
+        try:
+            kernels, by, dt_roof = kernel_pass(w, args.steps)
+        except Exception as ex:                                    # noqa: BLE001 - instrumentation must not cost the headline number
+            if world > 1:
+                raise                                              # (ranks would diverge at the next barrier)
+            roofline_error = f'{type(ex).__name__}: {ex}'[:300]
 
     clips = B * world * args.steps
     value = clips / dt
@@ -471,6 +477,8 @@ def main():
             out['comm'] = {'exposed_ms_last_step_by_rank': comm_ms,
                            'what': 'time the compute stream waited for the gradient all-reduce (Stage-2: one flat 90 MB bucket after the backward; '
                                    'Stage-1: 7 buckets launched under the backward, the wait is for what did not overlap)'}
+        if roofline_error:
+            out['roofline_error'] = roofline_error
         if kernels:
             dom, agg = roofline_of(kernels, by, name)
             traffic, tsrc = pmc_traffic() if name == 'infer' else (None, None)

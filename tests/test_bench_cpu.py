@@ -1,0 +1,17 @@
+"""bench.py's live kernel timer wraps ops.* entry points: its wrappers must accept every keyword argument the engine passes (a mismatch kills the
+driver's benchmark run, not a test) - checked here by signature, on CPU."""
+import inspect
+
+
+def test_gemm_timer_wrappers_accept_the_ops_keywords():
+    import bench
+    from synchformer_amd import ops
+    gt = bench.GemmTimer()
+    with gt:
+        for name in ('gemm', 'gemm_res_ln', 'gemm_mxfp8', 'qkv_time_attention'):
+            wrapped, orig = getattr(ops, name), gt.orig[name]
+            po, pw = inspect.signature(orig).parameters, inspect.signature(wrapped).parameters
+            has_kw = any(p.kind == inspect.Parameter.VAR_KEYWORD for p in pw.values())
+            missing = [k for k, p in po.items() if p.kind == inspect.Parameter.KEYWORD_ONLY and k not in pw]
+            assert has_kw or not missing, f'bench.GemmTimer wrapper of ops.{name} does not accept {missing}'
+    assert ops.gemm is gt.orig['gemm']

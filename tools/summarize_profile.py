@@ -36,7 +36,7 @@ for line in open(src / 'stats.log'):
     if line.startswith('{"metric"'):
         bench = json.loads(line)
 lines = [f'# rocprofv3 summary - {dst.name}', '',
-         'Command: `SF_AUDIO_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing`  (the configuration of bench.py\'s roofline pass: both towers on one stream, so kernel durations are not stretched by co-running kernels; the product runs the audio tower on a second stream)',
+         'Command: `SF_AUDIO_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-workloads`  (the configuration of bench.py\'s roofline pass: both towers on one stream, so kernel durations are not stretched by co-running kernels; the product runs the audio tower on a second stream)',
          '(PMC counters from separate `--pmc` passes of the same command; 3 forward passes x 16 clips in every pass).', '']
 if bench:
     lines += [f'bench line under the profiler: {bench["value"]} clips/s, {bench["ms_per_step"]} ms/step', '']
