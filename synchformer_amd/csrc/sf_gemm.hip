@@ -877,7 +877,7 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
       const double t7 = (double)((M + 255) / 256) * (double)((N + 255) / 256), t0 = (double)((M + 127) / 128) * (double)((N + 127) / 128);
       const double r7 = (double)(int64_t)((t7 + n_cu - 1) / n_cu), r0 = (double)(int64_t)((t0 + 2 * n_cu - 1) / (2 * n_cu));
       const double e7 = t7 / (r7 * n_cu), e0 = t0 / (r0 * 2 * n_cu);
-      cfg = (e7 * 1.08 >= e0) ? 7 : 0;
+      cfg = (e7 * (pp ? 1.20 : 1.08) >= e0) ? 7 : 0;             // (config 11 is another ~12 % ahead of config 7 per filled round: tools/bench_gemm.py 14 28 56)
     }
     if (cfg == 7 && pp) cfg = 11;
   }
