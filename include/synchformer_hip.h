@@ -104,6 +104,7 @@ void sf_gemm_force_config(int cfg);
  * 1 = quadrant-phased.  Both sum every accumulator in the same order: bit-identical outputs (the tests compare them). */
 void sf_gemm_res_ln_force_schedule(int sched);
 void sf_qkv_time_force_schedule(int sched);        /* the same for sf_qkv_time_attention */
+void sf_gemm_mx_force_schedule(int sched);         /* ... and for sf_gemm_mxfp8 (quadrant-phased needs K % 256 == 0) */
 
 /* y[omap(r), :] (=|+=) LayerNorm(x[imap(r), :]) * gamma + beta over 768 columns; x fp32, y bf16|fp32.
  * Replaces nn.LayerNorm at vit_helper.py:366-375, motionformer.py:232, modeling_ast.py:301,315,535,

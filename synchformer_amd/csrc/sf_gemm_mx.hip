@@ -96,12 +96,12 @@ __device__ __forceinline__ void mx_wait_vmcnt0_barrier() {
 
 // OUT: 0 = fp32, 1 = bf16, 2 = MXFP8 (the output is the next MX GEMM's A operand: e4m3 bytes + one E8M0 byte per 32 columns, quantised from the bf16-
 // rounded value exactly as sf_quantize_mxfp8 would from a bf16 buffer; a 32-column block = 8 consecutive lanes of the 16-lane row group).
-template <int OUT, bool GELU, bool HAS_RES>
-__device__ __forceinline__ void mx_epi_store(float4 (&v)[4], const float4& bias4, const float4 (&res)[4], __amdgpu_buffer_rsrc_t rc, uint32_t coff, uint32_t cstep,
+template <int OUT, bool GELU, bool HAS_RES, int NPS = 4>
+__device__ __forceinline__ void mx_epi_store(float4 (&v)[NPS], const float4& bias4, const float4 (&res)[NPS], __amdgpu_buffer_rsrc_t rc, uint32_t coff, uint32_t cstep,
                                              __amdgpu_buffer_rsrc_t rsc = __amdgpu_buffer_rsrc_t(), uint32_t sc_off = 0, int rows_left = 0) {
   constexpr bool OUT_BF16 = OUT == 1;
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
+  for (int ps = 0; ps < NPS; ++ps) {
     float4 x = v[ps];
     x.x += bias4.x; x.y += bias4.y; x.z += bias4.z; x.w += bias4.w;
     if (GELU) {
@@ -137,9 +137,10 @@ __device__ __forceinline__ void mx_epi_store(float4 (&v)[4], const float4& bias4
     }
   }
 }
-__device__ __forceinline__ void mx_load_res(float4 (&res)[4], __amdgpu_buffer_rsrc_t rr, uint32_t roff, uint32_t rstep) {
+template <int NPS>
+__device__ __forceinline__ void mx_load_res(float4 (&res)[NPS], __amdgpu_buffer_rsrc_t rr, uint32_t roff, uint32_t rstep) {
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
+  for (int ps = 0; ps < NPS; ++ps) {
     const mx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rr, roff + ps * rstep, 0, 2);
     res[ps] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
   }
@@ -338,11 +339,11 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_persistent_kernel(MxArgs p)
       float4 res[2][4];
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) res[0][ps] = res[1][ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (HAS_RES) mx_load_res(res[0], rr, roff0, rstep);
+      if (HAS_RES) mx_load_res<4>(res[0], rr, roff0, rstep);
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         const int i = g >> 1, q2 = g & 1;
-        if (HAS_RES && g + 1 < 8) mx_load_res(res[(g + 1) & 1], rr, roff0 + (g + 1) * 4 * rstep, rstep);
+        if (HAS_RES && g + 1 < 8) mx_load_res<4>(res[(g + 1) & 1], rr, roff0 + (g + 1) * 4 * rstep, rstep);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -369,13 +370,359 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_persistent_kernel(MxArgs p)
   }
 }
 
+
+// =============================================================================================================================================
+// Round 3: the quadrant-phased schedule of sf_gemm_pp.hip on MXFP8 operands (same BYTE geometry: a 128-deep fp8 k-tile = 4 half-tiles of 16 KiB,
+// a quadrant = 64 x 32 outputs = 4 MFMAs of 32x32x64 = the 256 matrix cycles of 8 bf16 MFMAs).  Differences to the bf16 kernel:
+//   * the scale dwords of a k-tile (one per row: the four E8M0 bytes of its 128-deep stage) are a NINTH piece per wave and k-tile - 64 rows x 4 bytes
+//     by global_load_lds_dword, waves 0-3 the A rows, waves 4-7 the W rows - issued with half-tile A0, all six dwords a lane needs read in phase 0
+//     (so the scale buffer is free for its refill two phases later, like A0): every counted wait is vmcnt(9);
+//   * a lane's scale byte of MFMA step kk is byte 2 kk + (lane >> 5) of its dword: the dwords are shifted by (lane >> 5) * 8 once per k-tile and the
+//     bytes picked with constant v_bfe in the read segment (the matrix segment stays pure MFMA);
+//   * LDS: 128 KiB ring + 4 KiB scale buffers + 8 x 2 KiB epilogue slabs (the epilogue walks 16 groups of 8 rows instead of 8 of 16) = 148 KiB: the
+//     slabs no longer overlay an operand slot, so the load stream runs across tiles as in the bf16 kernel.
+// Same products in the same order as the round-2 kernel below: bit-identical outputs (tests/test_kernels_gpu.py::test_gemm_mxfp8_schedules_bitwise).
+// =============================================================================================================================================
+#define MQ_HALF (128 * 128)
+#define MQ_STAGE (4 * MQ_HALF)
+#define MQ_SCALE_OFF (2 * MQ_STAGE)
+#define MQ_SLAB_OFF (MQ_SCALE_OFF + 4096)
+#define MQ_SLAB_BYTES 2048
+#define MQ_LDS (MQ_SLAB_OFF + 8 * MQ_SLAB_BYTES)   // 151,552 B
+#ifndef SF_MX_STORECNT
+#define SF_MX_STORECNT 1
+#endif
+
+__device__ __forceinline__ void mq_dma2(uint32_t v0, uint32_t v1, const void* sbase, uint32_t l0) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %4\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep) : "v"(v0), "v"(v1), "s"(sbase), "s"(l0) : "memory", "scc");
+}
+// 64 lanes x 4 bytes (a 256-byte piece): lane offset in %1, SGPR base
+__device__ __forceinline__ void mq_dma_dword(uint32_t v0, const void* sbase, uint32_t l0) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(v0), "s"(sbase), "s"(l0) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void mq_wait_vmcnt() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
+}
+__device__ __forceinline__ void mq_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+template <int V> using mq_ic = std::integral_constant<int, V>;
+
+template <int OUT, bool GELU, bool HAS_RES>
+__global__ __launch_bounds__(512, 2) void gemm_mxfp8_pp_kernel(MxArgs p) {
+  constexpr bool OUT_BF16 = OUT == 1;
+  constexpr int EPI_VM = OUT == 2 ? 54 : 32;                     // vector-memory operations of one epilogue (OUT 2: 64, capped by the 6-bit counter: 9 + 54 = 63)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  const uint32_t xcd = blockIdx.x & 7u, li = blockIdx.x >> 3, per_xcd_blocks = gridDim.x >> 3;
+  const uint32_t tiles_m = p.tiles_total / p.tiles_n;
+  const uint32_t mp8 = (tiles_m + 7u) >> 3;
+  const uint32_t mp0 = min(xcd * mp8, tiles_m), mp1 = min(mp0 + mp8, tiles_m), n_mp = mp1 - mp0;
+  const uint32_t gchunk = p.nchunk ? min(p.nchunk, p.tiles_n) : p.tiles_n;
+  const uint32_t n_chunks = (p.tiles_n + gchunk - 1) / gchunk, chunk_tiles = n_mp * gchunk;
+  const uint32_t t_end = n_mp * p.tiles_n;
+  auto tile_origin = [&](uint32_t t, int64_t& m0, int& n0) {
+    const uint32_t c = min(t / chunk_tiles, n_chunks - 1), r = t - c * chunk_tiles;
+    const uint32_t gw = (c == n_chunks - 1) ? p.tiles_n - c * gchunk : gchunk;
+    const uint32_t tm = mp0 + r / gw, tn = c * gchunk + r % gw;
+    m0 = (int64_t)tm * 256; n0 = (int)tn * 256;
+  };
+
+  // fragment offsets inside the current stage (flipped by bit 16 once per k-tile): [kk][h] = chunk kk * 4 + h * 2 + hi of the lane's row
+  const int sw = (l31 >> 1) & 7;
+  int a_off[2][2], b_off[2][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      a_off[kk][h] = (wm * 64 + l31) * 128 + (((kk * 4 + h * 2 + hi) ^ sw) << 4);                  // + ha * MQ_HALF + i * 4096
+      b_off[kk][h] = 2 * MQ_HALF + (wn * 32 + l31) * 128 + (((kk * 4 + h * 2 + hi) ^ sw) << 4);     // + hb * MQ_HALF
+    }
+
+  // ---- load iterator ----
+  const int nk = p.K / 128;
+  uint32_t ld_t = li;
+  bool ld_ok = ld_t < t_end;
+  if (!ld_ok) return;
+  int ld_kt = 0;
+  const char* ldA = nullptr; const char* ldW = nullptr; const char* ldS = nullptr;   // ldS: this wave's 64 scale dwords of the tile (A rows or W rows)
+  uint32_t oA[2][2], oW[2][2];
+  const int64_t ld_sstep = wave < 4 ? p.ldsa : p.ldsw;
+  auto ld_set = [&](uint32_t t) {
+    int64_t m0; int n0;
+    tile_origin(t, m0, n0);
+    ldA = reinterpret_cast<const char*>(p.A) + m0 * p.lda;
+    ldW = reinterpret_cast<const char*>(p.W) + (int64_t)n0 * p.ldw;
+    ldS = wave < 4 ? reinterpret_cast<const char*>(p.sA) + (m0 + wave * 64) * 4 : reinterpret_cast<const char*>(p.sW) + ((int64_t)n0 + (wave - 4) * 64) * 4;
+    const int64_t mleft = p.M - 1 - m0;
+    const int mrem = mleft < 255 ? (int)mleft : 255, nrem = min(p.N - 1 - n0, 255);
+    int ltid = threadIdx.x;
+    asm volatile("" : "+v"(ltid));
+    const int lr = (ltid & 63) >> 3, lc = ltid & 7;
+    const uint32_t lda1 = (uint32_t)p.lda, ldw1 = (uint32_t)p.ldw;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = wave * 16 + j * 8 + lr;
+      const uint32_t gch = (uint32_t)((lc ^ ((r >> 1) & 7)) << 4);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int tr = min((r >> 6) * 128 + h * 64 + (r & 63), mrem);
+        const int tc = min((r >> 5) * 64 + h * 32 + (r & 31), nrem);
+        oA[h][j] = __umul24((uint32_t)tr, lda1) + gch;
+        oW[h][j] = __umul24((uint32_t)tc, ldw1) + gch;
+      }
+    }
+  };
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(mx_lds_addr(smem));
+  const uint32_t lds_wave = lds0 + wave * 2048;
+  const uint32_t lds_sc_w = lds0 + MQ_SCALE_OFF + wave * 256;      // + stage * 2048: [A rows 0-255 | W rows 0-255] dwords
+  const uint32_t lane4 = (uint32_t)lane * 4u;
+  // PART: 0 = A0 (+ the k-tile's scale piece), 1 = B0, 2 = B1, 3 = A1
+  auto issue = [&](auto PARTc, auto STc) -> bool {
+    constexpr int PART = decltype(PARTc)::value, ST = decltype(STc)::value;
+    constexpr bool isA = PART == 0 || PART == 3;
+    constexpr int h = PART >= 2 ? 1 : 0;
+    const bool did = ld_ok;
+    if (did) {
+      const uint32_t l = lds_wave + ST * MQ_STAGE + (isA ? h : 2 + h) * MQ_HALF;
+      if (isA) mq_dma2(oA[h][0], oA[h][1], ldA + (int64_t)ld_kt * 128, l);
+      else mq_dma2(oW[h][0], oW[h][1], ldW + (int64_t)ld_kt * 128, l);
+      if (PART == 0) mq_dma_dword(lane4, ldS + (int64_t)ld_kt * ld_sstep, lds_sc_w + ST * 2048);
+      if (PART == 3) {
+        if (++ld_kt == nk) {
+          ld_kt = 0;
+          ld_t += per_xcd_blocks;
+          ld_ok = ld_t < t_end;
+          if (ld_ok) ld_set(ld_t);
+        }
+      }
+    }
+    return did;
+  };
+
+  uint32_t t = li;
+  int64_t m0; int n0;
+  tile_origin(t, m0, n0);
+  char* bslab = smem + MQ_SLAB_OFF + wave * MQ_SLAB_BYTES;
+  const uint32_t slab_lds = __builtin_amdgcn_readfirstlane(mx_lds_addr(bslab));
+  const uint32_t esz = OUT == 2 ? 1u : (OUT_BF16 ? 2u : 4u);
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, (short)0, (int)(uint32_t)(p.M * p.ldc * esz), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), (short)0, HAS_RES ? (int)(uint32_t)(p.M * p.ldr * 4) : 0, 0x00020000);
+  const uint32_t cstep = (uint32_t)(4 * p.ldc) * esz, rstep = (uint32_t)(4 * p.ldr) * 4u;
+  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(p.sC, (short)0, OUT == 2 ? (int)(uint32_t)((p.N / MXBK) * p.ldsc) : 0, 0x00020000);
+  const bool has_bias = p.bias != nullptr;
+  // the wave's 64 bias values: one 256-byte LDS-DMA piece into the (idle) slab at the top of the tile - no compiler-visible load, no compiler vmcnt(0)
+  auto issue_bias = [&](int n0_) {
+    if (has_bias) mq_dma_dword(lane4, reinterpret_cast<const char*>(p.bias + min(n0_ + wn * 64, p.N - 64)), slab_lds);
+  };
+
+  ld_set(ld_t);
+  issue_bias(n0);
+  issue(mq_ic<0>{}, mq_ic<0>{}); issue(mq_ic<1>{}, mq_ic<0>{}); issue(mq_ic<2>{}, mq_ic<0>{}); issue(mq_ic<3>{}, mq_ic<0>{});
+  issue(mq_ic<0>{}, mq_ic<1>{}); issue(mq_ic<1>{}, mq_ic<1>{});
+  mq_wait_vmcnt<9>();                                             // A0 (+ scales) | B0 of k-tile 0 have landed: B1, A1, A0 + scales, B0 (2 + 2 + 3 + 2) are younger
+  mq_barrier();
+  int extra = 0;
+
+  for (;;) {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // (opaque to the optimiser: folding the zeros into the first MFMAs' C operands makes hipcc peel the first k-tile pair - a second copy of the loop
+    // body, and 165-323 spilled registers)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[i][j]));
+    mx_i32x8 a[2][2], b0[2], b1[2];                               // [i][kk], [kk]
+    uint32_t sa[2][2], sb[2];                                     // scale dwords [ha][i], [hb], shifted so that byte 2 kk is this lane's block of step kk
+
+    auto wait_loads = [&](bool issued, bool first) {
+      if (!issued) mq_wait_vmcnt<0>();
+      else if (SF_MX_STORECNT && first && extra) mq_wait_vmcnt<9 + EPI_VM>();
+      else mq_wait_vmcnt<9>();
+    };
+    auto frag = [&](const char* base, const int (&off)[2][2], int kk) -> mx_i32x8 {
+      const mx_i32x4 lo = *reinterpret_cast<const mx_i32x4*>(base + off[kk][0]);
+      const mx_i32x4 hi4 = *reinterpret_cast<const mx_i32x4*>(base + off[kk][1]);
+      return mx_i32x8{lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    };
+    auto mma = [&](auto HAc, auto HBc, const mx_i32x8 (&bf)[2], const int (&sav)[2][2], const int (&sbv)[2]) {
+      constexpr int HA = decltype(HAc)::value, HB = decltype(HBc)::value;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[HA * 2 + i][HB] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i][kk], bf[kk], acc[HA * 2 + i][HB], 0, 0, 0, sav[i][kk], 0, sbv[kk]);
+      // the MFMAs are pure to the optimiser: with the run-time branches of the read segments around, LLVM sinks them towards their next use (the next
+      // k-tile's MFMAs on the same accumulator) - out of the matrix segment, with every fragment live across phases; an opaque use pins them here
+      asm volatile("" : "+v"(acc[HA * 2][HB]), "+v"(acc[HA * 2 + 1][HB]));
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto pick = [&](uint32_t dw, int kk) -> int { return (int)((dw >> (kk * 16)) & 0xffu); };
+    auto ktile = [&](auto Sc, bool first) {
+      constexpr int S = decltype(Sc)::value;
+      const char* st = smem;                                        // a_off / b_off carry the stage
+      int sav[2][2], sbv[2];
+      // ---- phase 0: (A0, B0); all scale dwords of the k-tile ----
+      {
+        const char* scp = smem + MQ_SCALE_OFF + S * 2048;
+#pragma unroll
+        for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) sa[ha][i] = *reinterpret_cast<const uint32_t*>(scp + (wm * 128 + ha * 64 + i * 32 + l31) * 4) >> (hi * 8);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) sb[hb] = *reinterpret_cast<const uint32_t*>(scp + 1024 + (wn * 64 + hb * 32 + l31) * 4) >> (hi * 8);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) b0[kk] = frag(st, b_off, kk);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i][kk] = frag(st + i * 4096, a_off, kk);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) { sbv[kk] = pick(sb[0], kk); sav[0][kk] = pick(sa[0][0], kk); sav[1][kk] = pick(sa[0][1], kk); }
+      __builtin_amdgcn_sched_barrier(0);
+      wait_loads(issue(mq_ic<2>{}, mq_ic<S ^ 1>{}), first);        // B1(kt+1) issued; B1(kt) landed
+      mq_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(mq_ic<0>{}, mq_ic<0>{}, b0, sav, sbv);
+      __builtin_amdgcn_sched_barrier(0);
+      mq_barrier();
+      // ---- phase 1: (A0, B1) ----
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) b1[kk] = frag(st + MQ_HALF, b_off, kk);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) sbv[kk] = pick(sb[1], kk);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_loads(issue(mq_ic<3>{}, mq_ic<S ^ 1>{}), first);        // A1(kt+1) issued; A1(kt) landed
+      mq_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(mq_ic<0>{}, mq_ic<1>{}, b1, sav, sbv);
+      __builtin_amdgcn_sched_barrier(0);
+      mq_barrier();
+      // ---- phase 2: (A1, B1); the fragment addresses move on to the other stage ----
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i][kk] = frag(st + MQ_HALF + i * 4096, a_off, kk);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) { sav[0][kk] = pick(sa[1][0], kk); sav[1][kk] = pick(sa[1][1], kk); }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(a_off[kk][h]));
+          asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(b_off[kk][h]));
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      issue(mq_ic<0>{}, mq_ic<S>{});                               // A0 + scales of k-tile kt+2; phase 3 reads nothing: no wait
+      mq_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(mq_ic<1>{}, mq_ic<1>{}, b1, sav, sbv);
+      __builtin_amdgcn_sched_barrier(0);
+      mq_barrier();
+      // ---- phase 3: (A1, B0) ----
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) sbv[kk] = pick(sb[0], kk);
+      wait_loads(issue(mq_ic<1>{}, mq_ic<S>{}), first);            // B0(kt+2) issued; A0 + scales | B0 of k-tile kt+1 landed
+      mq_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(mq_ic<1>{}, mq_ic<0>{}, b0, sav, sbv);
+      __builtin_amdgcn_sched_barrier(0);
+      mq_barrier();
+    };
+
+    if (wm == 1) mq_barrier();                                    // the wm = 1 waves run one barrier behind
+    int kt_first = 0;
+    asm volatile("" : "+s"(kt_first));                             // opaque zero: `kt == 0` lets hipcc peel the first iteration - a second copy of the body, with spills
+    for (int kt = 0; kt < nk; kt += 2) {
+      ktile(mq_ic<0>{}, kt == kt_first);
+      ktile(mq_ic<1>{}, false);
+    }
+    if (wm == 0) mq_barrier();
+
+    const int64_t em0 = m0; const int en0 = n0;
+    extra = 0;
+    if (en0 + wn * 64 < p.N) {
+      extra = 1;
+      int etid = threadIdx.x;
+      asm volatile("" : "+v"(etid));
+      const int el = etid & 63, el31 = el & 31, ehi = el >> 5, ecol = (el & 15) * 4;
+      float* slab = reinterpret_cast<float*>(bslab);
+      const int gcol = en0 + wn * 64 + ecol;
+      const int64_t row0 = em0 + wm * 128 + (el >> 4);
+      const uint32_t coff0 = (uint32_t)(row0 * p.ldc + gcol) * esz, roff0 = (uint32_t)(row0 * p.ldr + gcol) * 4u;
+      float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_bias) bias4 = *reinterpret_cast<const float4*>(slab + ecol);      // landed long ago: every counted wait of the k-loop covered it
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float4 res[2][2];
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) res[0][ps] = res[1][ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (HAS_RES) mx_load_res<2>(res[0], rr, roff0, rstep);
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {                               // rows g * 8 .. + 7 of the wave's 128
+        const int i = g >> 2, q4 = g & 3;
+        if (HAS_RES && g + 1 < 16) mx_load_res<2>(res[(g + 1) & 1], rr, roff0 + (g + 1) * 2 * rstep, rstep);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) slab[(ehi * 4 + r) * MX_EPI_LD + j * 32 + el31] = acc[i][j][q4 * 4 + r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float4 v[2];
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) v[ps] = *reinterpret_cast<const float4*>(slab + (ps * 4 + (el >> 4)) * MX_EPI_LD + ecol);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (OUT == 2) {
+          const int colblock = gcol >> 5;
+          const int64_t left = p.M - (row0 + g * 8);
+          const uint32_t sc_off = (uint32_t)((int64_t)(colblock >> 2) * p.ldsc + (colblock & 3) + (row0 + g * 8) * 4);
+          mx_epi_store<OUT, GELU, HAS_RES, 2>(v, bias4, res[g & 1], rc, coff0 + g * 2 * cstep, cstep, rsc, sc_off, (el & 7) == 0 ? (int)(left > 64 ? 64 : left) : 0);
+        } else {
+          mx_epi_store<OUT, GELU, HAS_RES, 2>(v, bias4, res[g & 1], rc, coff0 + g * 2 * cstep, cstep);
+        }
+      }
+    }
+    t += per_xcd_blocks;
+    if (t >= t_end) break;
+    tile_origin(t, m0, n0);
+    issue_bias(n0);
+  }
+}
+
+static thread_local int g_mx_force_sched = -1;   // test hook (per calling thread): -1 default, 0 round 2's loop, 1 quadrant-phased
+extern "C" void sf_gemm_mx_force_schedule(int sched) { g_mx_force_sched = sched; }
+
 template <int OUT, bool GELU, bool HAS_RES>
 static int mx_launch(MxArgs a, hipStream_t s) {
   auto kern = gemm_mxfp8_persistent_kernel<OUT, GELU, HAS_RES>;
+  auto kern_pp = gemm_mxfp8_pp_kernel<OUT, GELU, HAS_RES>;
   static bool attr_set = false;
   static int n_cu = 0;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kern_pp, hipFuncAttributeMaxDynamicSharedMemorySize, MQ_LDS);
     if (e != hipSuccess) { sf_set_error("sf_gemm_mxfp8: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { sf_set_error("sf_gemm_mxfp8: device query failed"); return -1; }
@@ -392,7 +739,12 @@ static int mx_launch(MxArgs a, hipStream_t s) {
   int64_t blocks = (n_cu / 8) * 8;
   const int64_t need = ((total + 7) / 8) * 8;
   if (blocks > need) blocks = need;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), MX_LDS, s, a);
+  static int env_sched = -1;
+  if (env_sched < 0) { const char* e = getenv("SF_MX_SCHED"); env_sched = e ? atoi(e) : 1; }
+  // quadrant-phased: whole pairs of 128-deep k-tiles (static stage indices), 24-bit row offsets
+  const bool pp = (g_mx_force_sched >= 0 ? g_mx_force_sched != 0 : env_sched != 0) && (a.K % 256) == 0 && a.lda < (1 << 23) && a.ldw < (1 << 23);
+  if (pp) hipLaunchKernelGGL(kern_pp, dim3((unsigned)blocks), dim3(512), MQ_LDS, s, a);
+  else hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), MX_LDS, s, a);
   SF_LAUNCH_CHECK();
   return 0;
 }

@@ -418,6 +418,46 @@ def test_gemm_mxfp8(gpu, M, N, K):
     torch.testing.assert_close(hb.float().cpu(), torch.nn.functional.gelu(ref), rtol=1e-2, atol=1e-2 * max(1.0, scale / 8))
 
 
+@pytest.mark.parametrize('M,N,K', [(256 * 70 + 37, 2304, 768), (256 * 67 + 255, 768, 3072), (300, 768, 256)])
+def test_gemm_mxfp8_schedules_bitwise(gpu, M, N, K):
+    """The quadrant-phased MXFP8 kernel (round 3) against round 2's loop: same products in the same order, so fp32 / bf16 + GELU / MXFP8 outputs (bytes and
+    scale planes) and the fp32-residual epilogue must be bit-identical on every repetition (the race screen for the LDS-DMA stream incl. the scale pieces)."""
+    from synchformer_amd import ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    a = _bf(torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-6, 6, (M, K // 32), generator=g).float()).repeat_interleave(32, 1)).to(gpu)
+    w = _bf(torch.randn(N, K, generator=g) * 0.05 * torch.exp2(torch.randint(-4, 4, (N, K // 32), generator=g).float()).repeat_interleave(32, 1)).to(gpu)
+    b, r = _rand(N, seed=3).to(gpu), _rand(M, N, seed=5).to(gpu)
+    aq, asc = torch.empty(M, K, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(M, K, gpu)
+    wq, wsc = torch.empty(N, K, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(N, K, gpu)
+    ops.quantize_mxfp8(a, aq, asc)
+    ops.quantize_mxfp8(w, wq, wsc)
+
+    def run(sched):
+        lib.sf_gemm_mx_force_schedule(sched)
+        try:
+            o32 = torch.empty(M, N, device=gpu)
+            ops.gemm_mxfp8(aq, asc, wq, wsc, b, o32)
+            ores = r.clone()
+            ops.gemm_mxfp8(aq, asc, wq, wsc, b, ores, residual=ores)
+            ob = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+            ops.gemm_mxfp8(aq, asc, wq, wsc, b, ob, gelu=True)
+            outs = [o32, ores, ob]
+            if N % 128 == 0:
+                oq, osc = torch.zeros(M, N, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(M, N, gpu)
+                osc.zero_()
+                ops.gemm_mxfp8(aq, asc, wq, wsc, b, oq, gelu=True, out_scales=osc)
+                outs += [oq, osc]
+        finally:
+            lib.sf_gemm_mx_force_schedule(-1)
+        return outs
+    ref = run(0)
+    for rep in range(4):
+        got = run(1)
+        for i, (x, y) in enumerate(zip(got, ref)):
+            assert torch.equal(x, y), f'repetition {rep}, output {i}'
+
+
 def test_layernorm_mxfp8_and_fp8_epilogue(gpu):
     """sf_layernorm768_mxfp8 == sf_layernorm768 (bf16) followed by sf_quantize_mxfp8, byte for byte; and the MX GEMM's MXFP8-output epilogue
     (fc1 + GELU -> the operand of fc2) == its bf16-output epilogue followed by sf_quantize_mxfp8."""

@@ -3,7 +3,8 @@ import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
-from synchformer_amd import ops
+from synchformer_amd import ops, _lib
+lib = _lib.load()
 
 dev = torch.device('cuda:0')
 
@@ -35,16 +36,19 @@ def main():
             ops.quantize_mxfp8(w, wq, wsc)
             oq = torch.empty(M, N, device=dev, dtype=torch.uint8) if (not res and N % 128 == 0) else None       # MXFP8 output (the next GEMM's A operand)
             osc = ops.mx_scale_planes(M, N, dev) if oq is not None else None
-            t = {'bf16': [], 'quant': [], 'mx': [], 'mxq': []}
+            t = {'bf16': [], 'quant': [], 'mx': [], 'mxq': [], 'mx_r2': []}
             for _ in range(5):
                 t['bf16'].append(timeit(lambda: ops.gemm(a, w, b, out, gelu=gelu, residual=out if res else None)))
                 t['quant'].append(timeit(lambda: ops.quantize_mxfp8(a, aq, asc)))
                 t['mx'].append(timeit(lambda: ops.gemm_mxfp8(aq, asc, wq, wsc, b, out, gelu=gelu, residual=out if res else None)))
+                lib.sf_gemm_mx_force_schedule(0)
+                t['mx_r2'].append(timeit(lambda: ops.gemm_mxfp8(aq, asc, wq, wsc, b, out, gelu=gelu, residual=out if res else None)))
+                lib.sf_gemm_mx_force_schedule(-1)
                 t['mxq'].append(timeit(lambda: ops.gemm_mxfp8(aq, asc, wq, wsc, b, oq, gelu=gelu, out_scales=osc)) if oq is not None else 0.0)
             med = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
             fl = 2.0 * M * N * K
             print(f"{name:9s} N {N:4d} K {K:4d}: bf16 {med['bf16']:7.1f} us ({fl / med['bf16'] / 1e6:5.0f} TF) | mxfp8 {med['mx']:7.1f} us ({fl / med['mx'] / 1e6:5.0f} TF)"
-                  f" + quantise A {med['quant']:6.1f} us | MXFP8 out {med['mxq']:7.1f} us", flush=True)
+                  f" + quantise A {med['quant']:6.1f} us | MXFP8 out {med['mxq']:7.1f} us | round-2 loop {med['mx_r2']:7.1f} us ({fl / med['mx_r2'] / 1e6:5.0f} TF)", flush=True)
 
 
 if __name__ == '__main__':
