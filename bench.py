@@ -141,7 +141,7 @@ class GemmTimer:
             n, k = w_q.shape
             nbytes = m * k + n * k + (m + n) * k // 32 + m * n * out.element_size() + (m * n * 4 if residual is not None else 0)
             return self._rec(lambda: o['gemm_mxfp8'](a_q, a_s, w_q, w_s, bias, out, M=M, residual=residual, gelu=gelu, out_scales=out_scales),
-                             2.0 * m * n * k, nbytes, 'gemm_mxfp8_persistent_kernel', f'N={n} K={k}', 'mxfp8')
+                             2.0 * m * n * k, nbytes, 'gemm_mxfp8_pp_kernel' if k % 256 == 0 else 'gemm_mxfp8_persistent_kernel', f'N={n} K={k}', 'mxfp8')
 
         def timed_qt(x, w, bias, qkv_cls, out, partials, *, n_seq, n_groups, scale, **kw):
             if not self.enabled:

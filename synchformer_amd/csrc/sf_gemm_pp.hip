@@ -36,6 +36,12 @@
 #ifndef SF_PP_PRIO
 #define SF_PP_PRIO 1                   // s_setprio 1 around the MFMA segments
 #endif
+#ifndef SF_PP_SLIM
+#define SF_PP_SLIM 1                   // 1: branch-free read segments - running k-tile base pointers, and a dry load iterator (last k-tiles of a workgroup's last
+#endif                                 //    tile) issues DUMMY pieces into the idle epilogue slab, so that every counted wait keeps its count (no `issued` branch)
+#ifndef SF_PP_NOPEEL
+#define SF_PP_NOPEEL 0                 // 1: the first k-tile pair of a tile is not recognisable to the optimiser (no peeled second copy of the loop body)
+#endif
 #ifndef SF_PP_ABL
 #define SF_PP_ABL 0                    // throw-away ablation builds (tools/ab_pp.sh): 1 no epilogue, 2 no LDS-DMA in the loop, 4 no MFMA, 8 no stagger, 16 no fragment reads in the loop
 #endif
@@ -155,12 +161,35 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     }
   };
   const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 2048);
+  const uint32_t slab_dummy = __builtin_amdgcn_readfirstlane(lds_addr(smem) + 2 * Q_STAGE + wave * Q_SLAB_BYTES + 1024);   // 2 KiB behind the slab's bias row
+  const char* curA = nullptr; const char* curW = nullptr;
+  const int64_t wk2 = p.wk * 2;
   // PART: 0 = A0, 1 = B0, 2 = B1, 3 = A1 (the order in which a k-tile's halves are read); returns whether a load was issued
   // SURE: the caller has established that the iterator cannot run dry at this point (no branch)
   auto issue = [&](auto PARTc, auto STc, auto SUREc) -> bool {
     constexpr int PART = decltype(PARTc)::value, ST = decltype(STc)::value;
     constexpr bool isA = PART == 0 || PART == 3;
     constexpr int h = PART >= 2 ? 1 : 0;
+    if (SF_PP_SLIM) {
+      // branch-free: the k-tile bases run along (curA / curW); when the iterator is dry they stay on the last valid k-tile and the pieces go to this
+      // wave's (idle) epilogue slab instead of the ring - same instruction count, same vmcnt bookkeeping, nobody reads them
+      const uint32_t real = lds_wave + ST * Q_STAGE + (isA ? h : 2 + h) * Q_HALF;
+      const uint32_t l = ld_ok ? real : slab_dummy;
+      if ((SF_PP_ABL & 2) && !decltype(SUREc)::value) {}
+      else if (isA) pp_dma2(oA[h][0], oA[h][1], curA, l);
+      else pp_dma2(oW[h][0], oW[h][1], curW, l);
+      if (PART == 3 && ld_ok) {
+        if (++ld_kt == nk) {
+          ld_kt = 0;
+          ld_t += per_xcd_blocks;
+          ld_ok = ld_t < t_end;
+          if (ld_ok) { ld_set(ld_t); curA = ldA; curW = ldW; }
+        } else {
+          curA += 128; curW += wk2;
+        }
+      }
+      return true;
+    }
     const bool did = decltype(SUREc)::value ? true : ld_ok;
     if (did) {
       const uint32_t l = lds_wave + ST * Q_STAGE + (isA ? h : 2 + h) * Q_HALF;
@@ -198,6 +227,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 
   // ---- prologue: k-tile 0 and A0 | B0 of k-tile 1 in flight -------------------------------------------------------------------
   ld_set(ld_t);
+  curA = ldA; curW = ldW;
   issue_bias(n0);
   issue(ic<0>{}, ic<0>{}, ic<1>{}); issue(ic<1>{}, ic<0>{}, ic<1>{}); issue(ic<2>{}, ic<0>{}, ic<1>{}); issue(ic<3>{}, ic<0>{}, ic<1>{});
   issue(ic<0>{}, ic<1>{}, ic<1>{}); issue(ic<1>{}, ic<1>{}, ic<1>{});
@@ -218,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 
     auto wait_loads = [&](bool issued, bool first) {
       asm volatile("" ::: "memory");
-      if (!issued) pp_wait_vmcnt<0>();
+      if (!SF_PP_SLIM && !issued) pp_wait_vmcnt<0>();
       else if (SF_PP_STORECNT && first && extra) pp_wait_vmcnt<8 + EPI_STORES>();
       else pp_wait_vmcnt<8>();
     };
@@ -232,6 +262,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
         for (int i = 0; i < 2; ++i)
           acc[HA * 2 + i][HB] = WIDE ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[kk], a[i][kk], acc[HA * 2 + i][HB], 0, 0, 0)   // C^T block: lanes = tokens
                                      : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], bf[kk], acc[HA * 2 + i][HB], 0, 0, 0);
+      // an opaque use pins the (pure) MFMAs inside their matrix segment: LLVM otherwise may sink them towards their next use across the run-time
+      // branches of the read segments (it did in the MXFP8 fork of this loop: 400 spilled registers)
+      asm volatile("" : "+v"(acc[HA * 2][HB]), "+v"(acc[HA * 2 + 1][HB]));
       if (SF_PP_PRIO) __builtin_amdgcn_s_setprio(0);
     };
     // one k-tile held in stage S; `first` = first k-tile after an epilogue
@@ -294,12 +327,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     };
 
     if (wm == 1 && !(SF_PP_ABL & 8)) pp_barrier();                                   // the wm = 1 waves run one barrier behind
+    int kt_first = 0;
+    if (SF_PP_NOPEEL) asm volatile("" : "+s"(kt_first));           // opaque zero: with a literal `kt == 0` hipcc peels the first iteration (a second copy of the body)
     for (int kt = 0; kt < nk; kt += 2) {       // (two copies of the k-tile body - a branch-free one for the steady state - cost 250+ spilled registers)
-      ktile(ic<0>{}, ic<0>{}, kt == 0);
+      ktile(ic<0>{}, ic<0>{}, kt == kt_first);
       ktile(ic<1>{}, ic<0>{}, false);
     }
     if (wm == 0 && !(SF_PP_ABL & 8)) pp_barrier();                                   // re-align: both groups run the epilogue concurrently
 
+    if (SF_PP_SLIM && !ld_ok) pp_wait_vmcnt<0>();                  // dummy pieces of a dry iterator land in the slab: all of them before the epilogue uses it
     const int64_t em0 = m0; const int en0 = n0;
     extra = 0;
 #if SF_PP_ABL & 32
