@@ -243,21 +243,34 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
   for (int j = 0; j < 2; ++j) voff_w[j] = (uint32_t)(((wave >> 1) * 192 + (wave & 1) * 32 + j * 16 + prow) * (int)p.ldw * 2 + pchunk * 16);
   const char* w0 = reinterpret_cast<const char*>(p.W);
   const int64_t third_b = (int64_t)64 * p.ldw * 2;
-  auto pp_issue_w = [&](int c, int slot, int kt_) {
+  // running offsets of the load stream (scalar; no per-issue multiplies in the read segments): wo1 = rotated k-step kt+1 (W thirds 1 and 2 are issued
+  // in phases 0 / 1), wo2 / ao2 = rotated k-step kt+2 (A and W third 0, phase 2)
+  const char* wb1 = w0 + third_b; const char* wb2 = w0 + 2 * third_b;
+  uint32_t wo1 = 0, wo2 = 0, ao2 = 0;
+  int kq2 = 0;
+  auto pp_issue_w = [&](int c, int slot) {
     if (ABL & 8) return;
-    rl_dma2(voff_w[0], voff_w[1], w0 + c * third_b + (int64_t)kmap(kt_) * p.wk, lds0 + slot * RP_STRIDE + RP_W_OFF + c * RP_THIRD + wave * 2048);
+    rl_dma2(voff_w[0], voff_w[1], c == 0 ? w0 + wo2 : (c == 1 ? wb1 + wo1 : wb2 + wo1), lds0 + slot * RP_STRIDE + RP_W_OFF + c * RP_THIRD + wave * 2048);
   };
-  auto pp_issue_a = [&](int slot, int kt_) {
+  auto pp_issue_a = [&](int slot) {
     if (ABL & 8) return;
-    rl_dma1(voff_a0 + kmap(kt_) * (RL_BK * 2), sa, lds0 + slot * RP_STRIDE + wave * 1024);
+    rl_dma1(voff_a0, reinterpret_cast<const char*>(sa) + ao2, lds0 + slot * RP_STRIDE + wave * 1024);
+  };
+  auto pp_advance = [&]() {                                        // end of a k-step: kt+2 becomes kt+1, the next rotated k-step becomes kt+2
+    wo1 = wo2;
+    if (++kq2 == nk) { kq2 = 0; wo2 = 0; ao2 = 0; } else { wo2 += p.wk; ao2 += RL_BK * 2; }
   };
   auto pp_prologue = [&]() {                                       // A | W0, W1, W2 of k-step 0 and A | W0 of k-step 1: 10 pieces per wave
-    rl_dma1(voff_a0 + kmap(0) * (RL_BK * 2), sa, lds0 + wave * 1024);
-    rl_dma2(voff_w[0], voff_w[1], w0 + (int64_t)kmap(0) * p.wk, lds0 + RP_W_OFF + wave * 2048);
-    rl_dma2(voff_w[0], voff_w[1], w0 + third_b + (int64_t)kmap(0) * p.wk, lds0 + RP_W_OFF + RP_THIRD + wave * 2048);
-    rl_dma2(voff_w[0], voff_w[1], w0 + 2 * third_b + (int64_t)kmap(0) * p.wk, lds0 + RP_W_OFF + 2 * RP_THIRD + wave * 2048);
-    rl_dma1(voff_a0 + kmap(1) * (RL_BK * 2), sa, lds0 + RP_STRIDE + wave * 1024);
-    rl_dma2(voff_w[0], voff_w[1], w0 + (int64_t)kmap(1) * p.wk, lds0 + RP_STRIDE + RP_W_OFF + wave * 2048);
+    const int k0 = kmap(0), k1 = kmap(1);
+    rl_dma1(voff_a0 + k0 * (RL_BK * 2), sa, lds0 + wave * 1024);
+    rl_dma2(voff_w[0], voff_w[1], w0 + (int64_t)k0 * p.wk, lds0 + RP_W_OFF + wave * 2048);
+    rl_dma2(voff_w[0], voff_w[1], w0 + third_b + (int64_t)k0 * p.wk, lds0 + RP_W_OFF + RP_THIRD + wave * 2048);
+    rl_dma2(voff_w[0], voff_w[1], w0 + 2 * third_b + (int64_t)k0 * p.wk, lds0 + RP_W_OFF + 2 * RP_THIRD + wave * 2048);
+    rl_dma1(voff_a0 + k1 * (RL_BK * 2), sa, lds0 + RP_STRIDE + wave * 1024);
+    rl_dma2(voff_w[0], voff_w[1], w0 + (int64_t)k1 * p.wk, lds0 + RP_STRIDE + RP_W_OFF + wave * 2048);
+    wo1 = (uint32_t)k1 * p.wk;
+    kq2 = nk > 2 ? kmap(2) : 0;
+    wo2 = (uint32_t)kq2 * p.wk; ao2 = (uint32_t)kq2 * (RL_BK * 2);
   };
   set_tile(m0);
   bool stage1_in_flight = false;
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
           for (int i = 0; i < 2; ++i) a[i][ks] = *reinterpret_cast<const bf16x8*>(smem + i * 2048 + fa[ks]);
         read_w(std::integral_constant<int, 0>{});
         __builtin_amdgcn_sched_barrier(0);
-        if (more1) pp_issue_w(1, S ^ 1, kt + 1);
+        if (more1) pp_issue_w(1, S ^ 1);
         if (ABL & 8) rl_wait_vmcnt<0>();                           // W third 1 of this k-step has landed; the youngest stage stays in flight
         else if (!more1) rl_wait_vmcnt<2>();
         else if (behind) rl_wait_vmcnt<7 + 48>();
@@ -350,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
         // ---- phase 1: third 1 ----
         read_w(std::integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
-        if (more1) pp_issue_w(2, S ^ 1, kt + 1);
+        if (more1) pp_issue_w(2, S ^ 1);
         if (!more1 || (ABL & 8)) rl_wait_vmcnt<0>();               // W third 2 has landed
         else if (behind) rl_wait_vmcnt<7 + 48>();
         else rl_wait_vmcnt<7>();
@@ -367,7 +380,8 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
           asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(fw[ks]));
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (more2) { pp_issue_a(S, kt + 2); pp_issue_w(0, S, kt + 2); }
+        if (more2) { pp_issue_a(S); pp_issue_w(0, S); }
+        pp_advance();
         if (more1) {                                               // A | W third 0 of the next k-step have landed
           if (ABL & 8) rl_wait_vmcnt<0>();
           else if (!more2) rl_wait_vmcnt<4>();
