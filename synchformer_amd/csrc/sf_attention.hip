@@ -535,12 +535,7 @@ extern "C" int sf_attention_group_bwd(const bf16_t* q, const bf16_t* k, const bf
   a.q = q; a.k = k; a.v = v; a.ld = ld; a.dO = dO; a.lddo = lddo; a.dq = dq; a.dk = dk; a.dv = dv; a.ldg = ldg; a.cls_part = cls_part;
   a.seq_rows = seq_rows; a.n_groups = n_groups; a.row0 = row0; a.group_stride = group_stride; a.tok_stride = tok_stride; a.n_tok = n_tok;
   a.cls_row = cls_row; a.heads = heads; a.scale = scale;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_group_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS);
-    if (e != hipSuccess) { sf_set_error("sf_attention_group_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
-  }
+  if (int rc = sf_prepare_kernel((const void*)attn_group_bwd_kernel, GB_LDS, "sf_attention_group_bwd")) return rc;
   const int64_t units = n_seq * n_groups * heads;
   SF_CHECK_ARG(units < ((int64_t)1 << 31), "sf_attention_group_bwd: too many groups");
   hipLaunchKernelGGL(attn_group_bwd_kernel, dim3((unsigned)units), dim3(GB_WAVES * 64), GB_LDS, (hipStream_t)stream, a);
@@ -885,12 +880,7 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
 template <int D, int NKT>
 static int launch_attn_mfma(const AttnArgs& a, int64_t n_seq, hipStream_t s) {
   auto kern = attn_mfma_kernel<D, NKT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AttLds<D>::TOTAL);
-    if (e != hipSuccess) { sf_set_error("sf_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
-  }
+  if (int rc = sf_prepare_kernel((const void*)kern, AttLds<D>::TOTAL, "sf_attention")) return rc;
   const int64_t blocks = n_seq * a.n_groups * a.heads;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), AttLds<D>::TOTAL, s, a);
   SF_LAUNCH_CHECK();

@@ -25,6 +25,13 @@ void sf_set_error(const char* fmt, ...);
     if (e__ != hipSuccess) { sf_set_error("%s: %s", __func__, hipGetErrorString(e__)); return (int)e__; } \
   } while (0)
 
+// ---- per-device launch set-up (sf_misc.hip): safe for a process that drives several GPUs and for concurrent host threads ---------------
+// sf_prepare_kernel: hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, current device) - the attribute is per device, a process-wide
+// `static bool` would leave the second GPU of a process without it; 0 or the HIP error (sf_last_error set).  sf_cu_count: multiprocessors of the
+// current device, cached per device (0 on error, sf_last_error set).
+int sf_prepare_kernel(const void* kernel, int lds_bytes, const char* who);
+int sf_cu_count(const char* who);
+
 // ---- row maps -----------------------------------------------------------------------------------------
 // A logical row r (< 2^31) of an operand lives at physical row
 //     (r / n12) * sA + ((r % n12) / n2) * s1 + (r % n2) * s2 + off

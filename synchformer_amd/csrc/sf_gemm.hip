@@ -534,16 +534,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent_kernel(GemmArgs p
 template <bool OUT_BF16, bool GELU, bool HAS_RES>
 static int launch_gemm_persistent(GemmArgs a, hipStream_t s) {
   auto kern = gemm_bf16_persistent_kernel<OUT_BF16, GELU, HAS_RES>;
-  static bool attr_set = false;
-  static int n_cu = 0;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-    if (e != hipSuccess) { sf_set_error("sf_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { sf_set_error("sf_gemm_bf16: device query failed"); return -1; }
-    n_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  if (int rc = sf_prepare_kernel((const void*)kern, P_LDS, "sf_gemm_bf16")) return rc;
+  const int n_cu = sf_cu_count("sf_gemm_bf16");
+  if (n_cu <= 0) return -1;
   const int64_t tiles_m = (a.M + PBM - 1) / PBM;
   a.tiles_n = (uint32_t)((a.N + PBN - 1) / PBN);
   const int64_t total = tiles_m * a.tiles_n;
@@ -748,16 +741,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmArgs p) {
 template <bool OUT_BF16, bool GELU, bool HAS_RES>
 static int launch_gemm_w4(GemmArgs a, hipStream_t s) {
   auto kern = gemm_bf16_w4_kernel<OUT_BF16, GELU, HAS_RES>;
-  static bool attr_set = false;
-  static int n_cu = 0;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
-    if (e != hipSuccess) { sf_set_error("sf_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { sf_set_error("sf_gemm_bf16: device query failed"); return -1; }
-    n_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  if (int rc = sf_prepare_kernel((const void*)kern, W4_LDS, "sf_gemm_bf16")) return rc;
+  const int n_cu = sf_cu_count("sf_gemm_bf16");
+  if (n_cu <= 0) return -1;
   const int64_t tiles_m = (a.M + PBM - 1) / PBM;
   a.tiles_n = (uint32_t)((a.N + PBN - 1) / PBN);
   const int64_t total = tiles_m * a.tiles_n;
@@ -799,12 +785,7 @@ extern "C" void sf_gemm_force_config(int cfg) { g_force_cfg = cfg; }
 template <class Cfg, bool OUT_BF16, bool GELU, bool HAS_RES, bool FAST>
 static int launch_gemm(GemmArgs a, hipStream_t s) {
   auto kern = gemm_bf16_kernel<Cfg, OUT_BF16, GELU, HAS_RES, FAST>;
-  static bool attr_set = false;   // benign race: the attribute call is idempotent
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
-    if (e != hipSuccess) { sf_set_error("sf_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
-  }
+  if (int rc = sf_prepare_kernel((const void*)kern, Cfg::LDS, "sf_gemm_bf16")) return rc;
   const int64_t tiles_m = (a.M + Cfg::BM - 1) / Cfg::BM;
   a.tiles_n = (uint32_t)((a.N + Cfg::BN - 1) / Cfg::BN);
   const int64_t total = tiles_m * a.tiles_n;
@@ -872,8 +853,8 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
       // the chip is full) and the 128x128 kernel (two per CU): e.g. fc2 of a single clip is 86 x 3 = 258 big tiles = TWO rounds of
       // 256 CUs at 50 % fill, but 1032 small tiles = 2.02 rounds of 512 slots.  Pick the better filled one (measured, M = 21,966 /
       // 43,932: fc2 600 -> 803 / 766 -> 917 TFLOP/s; the 16-clip batch keeps the persistent kernel everywhere).
-      static int n_cu = 0;
-      if (!n_cu) { int dev = 0; hipDeviceProp_t prop; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256; }
+      int n_cu = sf_cu_count("sf_gemm_bf16");
+      if (n_cu <= 0) n_cu = 256;
       const double t7 = (double)((M + 255) / 256) * (double)((N + 255) / 256), t0 = (double)((M + 127) / 128) * (double)((N + 127) / 128);
       const double r7 = (double)(int64_t)((t7 + n_cu - 1) / n_cu), r0 = (double)(int64_t)((t0 + 2 * n_cu - 1) / (2 * n_cu));
       const double e7 = t7 / (r7 * n_cu), e0 = t0 / (r0 * 2 * n_cu);
@@ -1111,12 +1092,7 @@ extern "C" int sf_gemm_tn_splitk(const bf16_t* dY, int64_t ldy, const bf16_t* X,
                "sf_gemm_tn_splitk: split * kc must cover M, kc %% 64 == 0");
   SF_CHECK_ARG((ldy % 8) == 0 && (ldx % 8) == 0 && ((uintptr_t)dY % 16) == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)part % 16) == 0,
                "sf_gemm_tn_splitk: operands must be 16-byte aligned with row strides %% 8 == 0");
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_splitk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS);
-    if (e != hipSuccess) { sf_set_error("sf_gemm_tn_splitk: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
-  }
+  if (int rc = sf_prepare_kernel((const void*)gemm_tn_splitk_kernel, TN_LDS, "sf_gemm_tn_splitk")) return rc;
   TnArgs a;
   a.A = dY; a.lda = ldy; a.B = X; a.ldb = ldx; a.C = part; a.ldc = K; a.sC = N * K; a.M = M; a.kc = (int)kc;
   a.tiles_n = (uint32_t)(K / 128);

@@ -643,21 +643,8 @@ extern "C" int sf_gemm_res_ln768(const bf16_t* A, int64_t lda, const bf16_t* W, 
   SF_CHECK_ARG(m_pad * ldr * 4 < ((int64_t)1 << 32) && m_pad * ldx * 4 < ((int64_t)1 << 32) && m_pad * ldy * 2 < ((int64_t)1 << 32),
                "sf_gemm_res_ln768: R / X / Y must stay below 4 GiB");
   SF_CHECK_ARG(128 * lda * 2 + K * 2 < ((int64_t)1 << 31) && 16 * ldw * 2 + K * 2 < ((int64_t)1 << 31), "sf_gemm_res_ln768: row strides too large");
-  static bool attr_set = false;
-  static int n_cu = 0;
-  if (!attr_set) {
-    const void* kerns[] = {(const void*)gemm_res_ln768_kernel<0, false>, (const void*)gemm_res_ln768_kernel<1, false>, (const void*)gemm_res_ln768_kernel<15, false>,
-                           (const void*)gemm_res_ln768_kernel<17, false>, (const void*)gemm_res_ln768_kernel<0, true>, (const void*)gemm_res_ln768_kernel<7, true>,
-                           (const void*)gemm_res_ln768_kernel<15, true>, (const void*)gemm_res_ln768_kernel<23, true>};
-    for (const void* k : kerns) {
-      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS > RL_LDS ? RP_LDS : RL_LDS);
-      if (e != hipSuccess) { sf_set_error("sf_gemm_res_ln768: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    }
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { sf_set_error("sf_gemm_res_ln768: device query failed"); return -1; }
-    n_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  const int n_cu = sf_cu_count("sf_gemm_res_ln768");
+  if (n_cu <= 0) return -1;
   ResLnArgs a;
   a.wk = w_kmajor ? (uint32_t)(RL_N * RL_BK * 2) : (uint32_t)(RL_BK * 2);
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.R = R; a.ldr = ldr; a.X = X; a.ldx = ldx; a.gamma = gamma; a.beta = beta;
@@ -674,20 +661,22 @@ extern "C" int sf_gemm_res_ln768(const bf16_t* A, int64_t lda, const bf16_t* W, 
   const bool pp = (sched != 0 || g_rl_force_sched == 1) && g_rl_force_sched != 0 && (K % 64) == 0 && K >= 128;
   const dim3 grid((unsigned)blocks), blk(512);
   hipStream_t st = (hipStream_t)stream;
+#define RL_LAUNCH(ABL_, PP_, LDS_) do { if (int rc_ = sf_prepare_kernel((const void*)gemm_res_ln768_kernel<ABL_, PP_>, LDS_, "sf_gemm_res_ln768")) return rc_; \
+    hipLaunchKernelGGL((gemm_res_ln768_kernel<ABL_, PP_>), grid, blk, LDS_, st, a); } while (0)
   if (pp) {
     switch (abl) {     // ablations: 1 no residual, 2 no X stores, 4 no Y stores, 8 no refills after the first two stages, 16 no MFMA
-      case 0: hipLaunchKernelGGL((gemm_res_ln768_kernel<0, true>), grid, blk, RP_LDS, st, a); break;
-      case 7: hipLaunchKernelGGL((gemm_res_ln768_kernel<7, true>), grid, blk, RP_LDS, st, a); break;
-      case 15: hipLaunchKernelGGL((gemm_res_ln768_kernel<15, true>), grid, blk, RP_LDS, st, a); break;
-      case 23: hipLaunchKernelGGL((gemm_res_ln768_kernel<23, true>), grid, blk, RP_LDS, st, a); break;
+      case 0: RL_LAUNCH(0, true, RP_LDS); break;
+      case 7: RL_LAUNCH(7, true, RP_LDS); break;
+      case 15: RL_LAUNCH(15, true, RP_LDS); break;
+      case 23: RL_LAUNCH(23, true, RP_LDS); break;
       default: sf_set_error("sf_gemm_res_ln768: unknown SF_RL_ABL %d for the quadrant-phased schedule", abl); return -1;
     }
   } else {
     switch (abl) {
-      case 0: hipLaunchKernelGGL((gemm_res_ln768_kernel<0, false>), grid, blk, RL_LDS, st, a); break;
-      case 1: hipLaunchKernelGGL((gemm_res_ln768_kernel<1, false>), grid, blk, RL_LDS, st, a); break;
-      case 15: hipLaunchKernelGGL((gemm_res_ln768_kernel<15, false>), grid, blk, RL_LDS, st, a); break;
-      case 17: hipLaunchKernelGGL((gemm_res_ln768_kernel<17, false>), grid, blk, RL_LDS, st, a); break;
+      case 0: RL_LAUNCH(0, false, RL_LDS); break;
+      case 1: RL_LAUNCH(1, false, RL_LDS); break;
+      case 15: RL_LAUNCH(15, false, RL_LDS); break;
+      case 17: RL_LAUNCH(17, false, RL_LDS); break;
       default: sf_set_error("sf_gemm_res_ln768: unknown SF_RL_ABL %d", abl); return -1;
     }
   }

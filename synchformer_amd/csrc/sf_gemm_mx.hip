@@ -718,17 +718,10 @@ template <int OUT, bool GELU, bool HAS_RES>
 static int mx_launch(MxArgs a, hipStream_t s) {
   auto kern = gemm_mxfp8_persistent_kernel<OUT, GELU, HAS_RES>;
   auto kern_pp = gemm_mxfp8_pp_kernel<OUT, GELU, HAS_RES>;
-  static bool attr_set = false;
-  static int n_cu = 0;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kern_pp, hipFuncAttributeMaxDynamicSharedMemorySize, MQ_LDS);
-    if (e != hipSuccess) { sf_set_error("sf_gemm_mxfp8: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { sf_set_error("sf_gemm_mxfp8: device query failed"); return -1; }
-    n_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  if (int rc = sf_prepare_kernel((const void*)kern, MX_LDS, "sf_gemm_mxfp8")) return rc;
+  if (int rc = sf_prepare_kernel((const void*)kern_pp, MQ_LDS, "sf_gemm_mxfp8")) return rc;
+  const int n_cu = sf_cu_count("sf_gemm_mxfp8");
+  if (n_cu <= 0) return -1;
   const int64_t tiles_m = (a.M + MXBM - 1) / MXBM;
   a.tiles_n = (uint32_t)((a.N + MXBN - 1) / MXBN);
   const int64_t total = tiles_m * a.tiles_n;

@@ -448,16 +448,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 template <bool OUT_BF16, bool GELU, bool HAS_RES>
 static int launch_gemm_pp(GemmArgs a, hipStream_t s) {
   auto kern = gemm_bf16_pp_kernel<OUT_BF16, GELU, HAS_RES>;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { sf_set_error("sf_gemm_bf16: device query failed"); return -1; }
-  static int n_cu[64] = {0};                                     // per device: the LDS attribute is per device, too
-  if (!n_cu[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
-    if (e != hipSuccess) { sf_set_error("sf_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { sf_set_error("sf_gemm_bf16: device query failed"); return -1; }
-    n_cu[dev] = prop.multiProcessorCount;
-  }
+  if (int rc = sf_prepare_kernel((const void*)kern, Q_LDS, "sf_gemm_bf16")) return rc;
+  const int n_cus = sf_cu_count("sf_gemm_bf16");
+  if (n_cus <= 0) return -1;
   const int64_t tiles_m = (a.M + 255) / 256;
   a.tiles_n = (uint32_t)((a.N + 255) / 256);
   const int64_t total = tiles_m * a.tiles_n;
@@ -467,7 +460,7 @@ static int launch_gemm_pp(GemmArgs a, hipStream_t s) {
   if (env_chunk == -2) { const char* e = getenv("SF_GEMM_NCHUNK"); env_chunk = e ? atoi(e) : -1; }
   if (env_chunk >= 0) a.nchunk = (uint32_t)env_chunk;
   else a.nchunk = a.K <= 1024 ? (uint32_t)(2400000 / (512 * a.K) > 0 ? 2400000 / (512 * a.K) : 1) : 0u;
-  int64_t blocks = (n_cu[dev] / 8) * 8;                          // one workgroup per CU, a multiple of the 8 XCDs
+  int64_t blocks = (n_cus / 8) * 8;                          // one workgroup per CU, a multiple of the 8 XCDs
   const int64_t need = ((total + 7) / 8) * 8;
   if (blocks > need) blocks = need;
 #if SF_PP_ABL & 32

@@ -604,17 +604,10 @@ static int qkv_time_impl(const uint16_t* X, int64_t ldx, const uint16_t* W, int6
   const int64_t seq_rows = 1 + 8 * (int64_t)n_groups;
   SF_CHECK_ARG(n_seq * seq_rows * ldx * 2 < ((int64_t)1 << 32) && (int64_t)3 * QT_D * ldw * 2 < ((int64_t)1 << 32),
                "sf_qkv_time_attention: X and W must stay below 4 GiB (32-bit lane offsets)");
-  static bool attr_set = false;
-  static int n_cu = 0;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)qkv_time_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, QT_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)qkv_time_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, QT_LDS);
-    if (e != hipSuccess) { sf_set_error("sf_qkv_time_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { sf_set_error("sf_qkv_time_attention: device query failed"); return -1; }
-    n_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  if (int rc = sf_prepare_kernel((const void*)qkv_time_attn_kernel<true>, QT_LDS, "sf_qkv_time_attention")) return rc;
+  if (int rc = sf_prepare_kernel((const void*)qkv_time_attn_kernel<false>, QT_LDS, "sf_qkv_time_attention")) return rc;
+  const int n_cu = sf_cu_count("sf_qkv_time_attention");
+  if (n_cu <= 0) return -1;
   QtArgs a;
   a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.qkv_cls = qkv_cls; a.ldc = ldc; a.out = out; a.ldo = ldo; a.cls_part = cls_partial;
   a.n_seq = n_seq; a.seq_rows = seq_rows; a.n_groups = n_groups; a.scale = scale; a.key_keep = key_keep;

@@ -149,6 +149,9 @@ class SynchformerEngine:
         """vproj / aproj / sync transformer (22.6M parameters: the part Stage-2 trains).  Cheap enough to refresh after every
         optimizer step of an external optimizer without touching the tower operands or the workspaces."""
         dev = self.dev
+        # new operand tensors replace the old ones (their allocator blocks are released): a HIP graph captured before this call still points at the OLD
+        # blocks, so captured replays are invalidated through this counter (capture() checks it) instead of silently reading freed memory
+        self._sync_generation = getattr(self, '_sync_generation', 0) + 1
         f32 = lambda k: sd[k].detach().to(dev, torch.float32)
         lin = lambda k: _Lin(sd[k + '.weight'], sd[k + '.bias'], dev)
         self.vproj, self.aproj = lin('vproj'), lin('aproj')
@@ -604,8 +607,12 @@ class SynchformerEngine:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             static_out = self.forward(static_vis, static_aud)
+        generation = getattr(self, '_sync_generation', 0)
 
         def run(v: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
+            if getattr(self, '_sync_generation', 0) != generation:
+                raise RuntimeError('the sync-module weights were refreshed (load_sync_weights) after this graph was captured: its launches point at the '
+                                   'released operand buffers - capture again')
             if v.shape != static_vis.shape or a.shape != static_aud.shape or v.dtype != static_vis.dtype:
                 raise ValueError('captured graph serves one input shape/dtype; capture again for another')
             static_vis.copy_(v, non_blocking=True)

@@ -384,10 +384,15 @@ class Synchformer(torch.nn.Module):
 
     # -- engine cache ---------------------------------------------------------------------------------------
     def _split_keys(self):
-        frozen, sync = [], []
-        for n, p in self.named_parameters():
-            (sync if n.startswith(('vproj.', 'aproj.', 'transformer.')) else frozen).append((p.data_ptr(), p._version))
-        return tuple(frozen), tuple(sync)
+        # (storage, version) of every parameter, extractor side and sync side.  The parameter LISTS are cached (the module tree does not change; walking
+        # named_parameters() of ~700 tensors three to four times per forward cost a few ms of host time per training step); the versions are read fresh.
+        lists = self.__dict__.get('_sf_param_lists')
+        if lists is None:
+            frozen, sync = [], []
+            for n, p in self.named_parameters():
+                (sync if n.startswith(('vproj.', 'aproj.', 'transformer.')) else frozen).append(p)
+            lists = self.__dict__['_sf_param_lists'] = (frozen, sync)
+        return (tuple((p.data_ptr(), p._version) for p in lists[0]), tuple((p.data_ptr(), p._version) for p in lists[1]))
 
     def _engine(self, need_sync: bool = True) -> SynchformerEngine:
         """The engine is keyed on the EXTRACTOR parameters only (214.8M weights, the multi-GB workspaces): an optimizer step on
