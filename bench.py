@@ -82,7 +82,7 @@ import torch  # noqa: E402
 
 # ---- live kernel timing ---------------------------------------------------------------------------------------------------------------------
 class GemmTimer:
-    """Brackets every GEMM-family launch (sf_gemm_bf16, sf_gemm_res_ln768, sf_qkv_time_attention, sf_gemm_mxfp8) with HIP events on the launch
+    """Brackets every GEMM-family launch (sf_gemm_bf16, sf_gemm_res_ln768, sf_qkv_time_attention, sf_gemm_mxfp8, sf_gemm_mx_res_ln768) with HIP events on the launch
     stream (= torch's current stream) and files it under the kernel symbol rocprofv3 reports for it."""
 
     def __init__(self):
@@ -111,7 +111,7 @@ class GemmTimer:
 
     def __enter__(self):
         ops = self.ops
-        self.orig = {k: getattr(ops, k) for k in ('gemm', 'gemm_res_ln', 'gemm_mxfp8', 'qkv_time_attention')}
+        self.orig = {k: getattr(ops, k) for k in ('gemm', 'gemm_res_ln', 'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention')}
         o = self.orig
 
         def timed(a, w, bias, out, *, M=None, **kw):
@@ -143,6 +143,15 @@ class GemmTimer:
             return self._rec(lambda: o['gemm_mxfp8'](a_q, a_s, w_q, w_s, bias, out, M=M, residual=residual, gelu=gelu, out_scales=out_scales),
                              2.0 * m * n * k, nbytes, 'gemm_mxfp8_pp_kernel' if k % 256 == 0 else 'gemm_mxfp8_persistent_kernel', f'N={n} K={k}', 'mxfp8')
 
+        def timed_mxln(a_q, a_s, w_q, w_s, bias, x, gamma, beta, y_q, y_s, eps, *, M=None, residual=None, **kw):
+            if not self.enabled:
+                return o['gemm_mx_res_ln'](a_q, a_s, w_q, w_s, bias, x, gamma, beta, y_q, y_s, eps, M=M, residual=residual, **kw)
+            m = a_q.shape[0] if M is None else M
+            n, k = 768, a_q.shape[1]
+            nbytes = m * k + n * k + (m + n) * k // 32 + m * n * (4 + 4 + 1) + m * n // 32     # A + W + scales + R read, X + Y + Y's scales written
+            return self._rec(lambda: o['gemm_mx_res_ln'](a_q, a_s, w_q, w_s, bias, x, gamma, beta, y_q, y_s, eps, M=M, residual=residual, **kw),
+                             2.0 * m * n * k, nbytes, 'gemm_mx_res_ln768_kernel', f'K={k}', 'mxfp8')
+
         def timed_qt(x, w, bias, qkv_cls, out, partials, *, n_seq, n_groups, scale, **kw):
             if not self.enabled:
                 return o['qkv_time_attention'](x, w, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale, **kw)
@@ -151,7 +160,7 @@ class GemmTimer:
             return self._rec(lambda: o['qkv_time_attention'](x, w, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale, **kw),
                              2.0 * m * n * k, nbytes, 'qkv_time_attn_kernel<true>', 'N=2304 K=768')
 
-        ops.gemm, ops.gemm_res_ln, ops.gemm_mxfp8, ops.qkv_time_attention = timed, timed_ln, timed_mx, timed_qt
+        ops.gemm, ops.gemm_res_ln, ops.gemm_mxfp8, ops.gemm_mx_res_ln, ops.qkv_time_attention = timed, timed_ln, timed_mx, timed_mxln, timed_qt
         return self
 
     def __exit__(self, *a):

@@ -93,6 +93,14 @@ int sf_gemm_mxfp8(const uint8_t* A, int64_t lda, const uint8_t* sA, int64_t ldsa
 /* LayerNorm(768) whose output leaves as MXFP8 (the A operand of the qkv / fc1 MX GEMMs): sf_layernorm768 followed by sf_quantize_mxfp8, in one pass. */
 int sf_layernorm768_mxfp8(const float* x, int64_t ldx, const float* gamma, const float* beta, uint8_t* q, int64_t ldq, uint8_t* scales, int64_t lds,
                           int64_t rows, float eps, void* stream);
+/* sf_gemm_res_ln768 on MXFP8 operands with an MXFP8 output: X = dq(A) dq(W)^T + bias + R (fp32, 768 columns, X may alias R), (Y, sY) = the MXFP8
+ * quantisation of bf16(LayerNorm(X) * gamma + beta) - sf_gemm_mxfp8 with the residual epilogue followed by sf_layernorm768_mxfp8, in one launch
+ * (`x = x + proj(...)` / `x = x + fc2(...)` and the LayerNorm that opens the next sub-layer, vit_helper.py:364-376, in the fp8 towers).  A (M x K) / W (768 x K)
+ * e4m3 bytes, K % 128 == 0; scale planes as for sf_gemm_mxfp8 with ldsa >= ceil(M/128) * 512, ldsw >= 3072, ldsy >= 4 M (6 planes).  Y / sY may alias
+ * A / sA when K == 768. */
+int sf_gemm_mx_res_ln768(const uint8_t* A, int64_t lda, const uint8_t* sA, int64_t ldsa, const uint8_t* W, int64_t ldw, const uint8_t* sW, int64_t ldsw,
+                         const float* bias, const float* R, int64_t ldr, float* X, int64_t ldx, const float* gamma, const float* beta, float eps,
+                         uint8_t* Y, int64_t ldy, uint8_t* sY, int64_t ldsy, int64_t M, int64_t K, void* stream);
 
 /* Tuning / test hook (state of the CALLING THREAD only; the launchers stay re-entrant): force the GEMM tile configuration of this thread's subsequent
  * sf_gemm_bf16 calls.  -1 = automatic choice by shape (default); 0 = 128x128x64, 4 waves, two workgroups per CU; 7 = persistent 256x256x64,

@@ -78,6 +78,7 @@ class SynchformerEngine:
         # fp8_towers: the six big Linears of every visual block run on MXFP8 operands (sf_gemm_mxfp8) - the frozen-extractor mode of the
         # synchronizability fine-tune (BASELINE configs[4]).  Off (bf16) for every other workload: inference parity bars are stated for bf16.
         self.fp8_towers = bool(fp8_towers)
+        self.fuse_mx_ln = True                       # fp8 towers: sf_gemm_mx_res_ln768 instead of sf_gemm_mxfp8 + sf_layernorm768_mxfp8 (tests switch it off to compare)
         self.capture_blocks = None          # tests: a dict -> the fp32 residual stream after each visual block is cloned into it (key = block index)
         self._ws = {}
         self.audio_side_stream = os.environ.get('SF_AUDIO_SIDE_STREAM', '1') != '0'
@@ -355,21 +356,34 @@ class SynchformerEngine:
         xs = self._buf('XS', 6 * rows_p * 4, torch.uint8).view(6, rows_p, 4)
         hq = self._buf('HQ', rows * FF, torch.uint8).view(rows, FF)
         hs = self._buf('HS', 24 * rows_p * 4, torch.uint8).view(24, rows_p, 4)
-        for b in self.v_blocks:
+        fuse = self.fuse_mx_ln                                            # proj / fc2 + residual + the next LayerNorm + its quantisation in one launch (sf_gemm_mx_res_ln768)
+        nb = len(self.v_blocks)
+        for bi, b in enumerate(self.v_blocks):
             mx = b['mx']
-            ops.layernorm_mxfp8(X, b['norm3'].g, b['norm3'].b, xq, xs, EPS_VIS)
+            if bi == 0 or not fuse:
+                ops.layernorm_mxfp8(X, b['norm3'].g, b['norm3'].b, xq, xs, EPS_VIS)
             ops.gemm_mxfp8(xq, xs, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, qkv)
             divided('time')
             ops.quantize_mxfp8(xn, xq, xs)
-            ops.gemm_mxfp8(xq, xs, mx['t_proj'].q, mx['t_proj'].s, mx['t_proj'].b, X, residual=X)
-            ops.layernorm_mxfp8(X, b['norm1'].g, b['norm1'].b, xq, xs, EPS_VIS)
+            if fuse:
+                ops.gemm_mx_res_ln(xq, xs, mx['t_proj'].q, mx['t_proj'].s, mx['t_proj'].b, X, b['norm1'].g, b['norm1'].b, xq, xs, EPS_VIS)
+            else:
+                ops.gemm_mxfp8(xq, xs, mx['t_proj'].q, mx['t_proj'].s, mx['t_proj'].b, X, residual=X)
+                ops.layernorm_mxfp8(X, b['norm1'].g, b['norm1'].b, xq, xs, EPS_VIS)
             ops.gemm_mxfp8(xq, xs, mx['s_qkv'].q, mx['s_qkv'].s, mx['s_qkv'].b, qkv)
             divided('space')
             ops.quantize_mxfp8(xn, xq, xs)
-            ops.gemm_mxfp8(xq, xs, mx['s_proj'].q, mx['s_proj'].s, mx['s_proj'].b, X, residual=X)
-            ops.layernorm_mxfp8(X, b['norm2'].g, b['norm2'].b, xq, xs, EPS_VIS)
+            if fuse:
+                ops.gemm_mx_res_ln(xq, xs, mx['s_proj'].q, mx['s_proj'].s, mx['s_proj'].b, X, b['norm2'].g, b['norm2'].b, xq, xs, EPS_VIS)
+            else:
+                ops.gemm_mxfp8(xq, xs, mx['s_proj'].q, mx['s_proj'].s, mx['s_proj'].b, X, residual=X)
+                ops.layernorm_mxfp8(X, b['norm2'].g, b['norm2'].b, xq, xs, EPS_VIS)
             ops.gemm_mxfp8(xq, xs, mx['fc1'].q, mx['fc1'].s, mx['fc1'].b, hq, gelu=True, out_scales=hs)
-            ops.gemm_mxfp8(hq, hs, mx['fc2'].q, mx['fc2'].s, mx['fc2'].b, X, residual=X)
+            if fuse and bi + 1 < nb:
+                nx = self.v_blocks[bi + 1]['norm3']
+                ops.gemm_mx_res_ln(hq, hs, mx['fc2'].q, mx['fc2'].s, mx['fc2'].b, X, nx.g, nx.b, xq, xs, EPS_VIS)
+            else:
+                ops.gemm_mxfp8(hq, hs, mx['fc2'].q, mx['fc2'].s, mx['fc2'].b, X, residual=X)
 
     def _visual_tail(self, X, n, out, tok_keep):
         # drop CLS -> final norm -> per-frame sequences with the aggregator CLS in front (mf:231-232, 356-375)

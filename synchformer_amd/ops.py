@@ -119,6 +119,27 @@ def gemm_mxfp8(a_q: torch.Tensor, a_s: torch.Tensor, w_q: torch.Tensor, w_s: tor
     return out
 
 
+def gemm_mx_res_ln(a_q: torch.Tensor, a_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], x: torch.Tensor, gamma: torch.Tensor,
+                   beta: torch.Tensor, y_q: torch.Tensor, y_s: torch.Tensor, eps: float, *, M: Optional[int] = None, residual: Optional[torch.Tensor] = None):
+    """gemm_res_ln on MXFP8 operands with an MXFP8 output: x[m] = dq(a)[m] @ dq(w).T + bias + residual[m] (fp32, in place when residual is None or x),
+    (y_q, y_s) = quantize_mxfp8(bf16(LayerNorm(x[m]) * gamma + beta)).  (y_q, y_s) may be (a_q, a_s) when K == 768."""
+    assert a_q.dtype == torch.uint8 and w_q.dtype == torch.uint8 and a_s.dtype == torch.uint8 and w_s.dtype == torch.uint8 and y_q.dtype == torch.uint8 and y_s.dtype == torch.uint8
+    assert x.dtype == torch.float32 and x.shape[1] == 768 and y_q.shape[1] == 768
+    M = a_q.shape[0] if M is None else M
+    K = a_q.shape[1]
+    assert w_q.shape == (768, K)
+    assert a_s.dim() == 3 and w_s.dim() == 3 and y_s.dim() == 3 and a_s.shape[0] == K // 128 and w_s.shape[0] == K // 128 and y_s.shape[0] == 6
+    assert a_s.is_contiguous() and w_s.is_contiguous() and y_s.is_contiguous()
+    r = x if residual is None else residual
+    assert r.dtype == torch.float32
+    rc = _lib.load().sf_gemm_mx_res_ln768(_dev(a_q, 'a_q'), _ld(a_q), _dev(a_s, 'a_s'), a_s.stride(0), _dev(w_q, 'w_q'), _ld(w_q), _dev(w_s, 'w_s'), w_s.stride(0),
+                                          _dev(bias, 'bias') if bias is not None else None, _dev(r, 'residual'), _ld(r), _dev(x, 'x'), _ld(x),
+                                          _dev(gamma, 'gamma'), _dev(beta, 'beta'), float(eps), _dev(y_q, 'y_q'), _ld(y_q), _dev(y_s, 'y_s'), y_s.stride(0),
+                                          M, K, _stream())
+    _lib.check(rc, 'sf_gemm_mx_res_ln768')
+    return x, y_q, y_s
+
+
 def gemm_res_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
                 y: torch.Tensor, eps: float, *, M: Optional[int] = None, residual: Optional[torch.Tensor] = None):
     """x[m] = a[m] @ w.T + bias + residual[m] (fp32, in place when residual is None or x), y[m] = LayerNorm(x[m]) * gamma + beta (bf16).

@@ -489,6 +489,59 @@ def test_layernorm_mxfp8_and_fp8_epilogue(gpu):
     assert torch.equal(h0, h1[:M]) and torch.equal(hs0, hs1[:, :M]) and (h1[M:] == 9).all() and (hs1[:, M:] == 0).all()
 
 
+@pytest.mark.parametrize('M,K', [(100, 128), (128 * 5 + 17, 768), (128 * 300 + 77, 768), (128 * 270 + 1, 3072)])
+def test_gemm_mx_res_ln(gpu, M, K):
+    """sf_gemm_mx_res_ln768 against the pair it replaces - sf_gemm_mxfp8 with the residual epilogue, then sf_layernorm768_mxfp8 - and against an fp64
+    reference on the DEQUANTISED operands.  The fused kernel rotates its k-loop per workgroup, so X agrees to fp32 summation-order noise, and the MXFP8
+    bytes of Y agree except where that noise crosses a bf16 / e4m3 rounding boundary (a bounded fraction; the dequantised values then differ by one step).
+    Repetitions must be bit-identical (race screen); rows beyond M stay untouched; (Y, sY) may be the (A, sA) buffers when K == 768."""
+    from synchformer_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    a = _bf(torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-3, 3, (M, K // 32), generator=g).float()).repeat_interleave(32, 1))
+    w = _bf(torch.randn(768, K, generator=g) * 0.03 * torch.exp2(torch.randint(-2, 2, (768, K // 32), generator=g).float()).repeat_interleave(32, 1))
+    b, r = _rand(768, seed=3).to(gpu), (_rand(M, 768, seed=5) * 2 + 0.2).to(gpu)
+    gam, bet = (1 + 0.1 * _rand(768, seed=6)).to(gpu), (0.1 * _rand(768, seed=7)).to(gpu)
+    aq, asc = torch.empty(M, K, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(M, K, gpu)
+    wq, wsc = torch.empty(768, K, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(768, K, gpu)
+    ops.quantize_mxfp8(a.to(gpu), aq, asc)
+    ops.quantize_mxfp8(w.to(gpu), wq, wsc)
+    # the pair
+    x0 = r.clone()
+    ops.gemm_mxfp8(aq, asc, wq, wsc, b, x0, residual=x0)
+    q0, s0 = torch.empty(M, 768, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(M, 768, gpu)
+    ops.layernorm_mxfp8(x0, gam, bet, q0, s0, 1e-6)
+    # fused
+    def fused():
+        x = torch.full((M + 3, 768), 7.0, device=gpu)
+        x[:M] = r
+        q, sc = torch.full((M + 3, 768), 9, device=gpu, dtype=torch.uint8), torch.full((6, ((M + 255) // 256) * 256 + 256, 4), 3, device=gpu, dtype=torch.uint8)
+        ops.gemm_mx_res_ln(aq, asc, wq, wsc, b, x, gam, bet, q, sc, 1e-6, M=M)
+        return x, q, sc
+    x1, q1, s1 = fused()
+    assert (x1[M:] == 7.0).all() and (q1[M:] == 9).all() and (s1[:, M:] == 3).all(), 'rows beyond M were written'
+    for rep in range(3):
+        x2, q2, s2 = fused()
+        assert torch.equal(x1, x2) and torch.equal(q1, q2) and torch.equal(s1, s2), f'repetition {rep}'
+    ref = (_mx_dequant(aq, asc).double() @ _mx_dequant(wq, wsc).double().t()).float() + b + r
+    scale = ref.abs().max().item()
+    assert (x1[:M] - ref).abs().max().item() < 1e-4 * scale, ((x1[:M] - ref).abs().max().item(), scale)
+    assert (x1[:M] - x0).abs().max().item() < 2e-5 * scale
+    d0, d1 = _mx_dequant(q0, s0), _mx_dequant(q1[:M], s1)
+    diff_bytes = (q0 != q1[:M]).float().mean().item()
+    diff_scales = (s0[:, :M] != s1[:, :M]).float().mean().item()
+    assert diff_bytes < 2e-3 and diff_scales < 2e-3, (diff_bytes, diff_scales)
+    blockmax = d0.abs().view(M, 24, 32).amax(-1).repeat_interleave(32, 1)
+    assert ((d1 - d0).abs() <= blockmax * 2.0 ** -2 + 1e-6).all()      # one e4m3 step of the block (two where the block's scale byte itself moved)
+    ln = torch.nn.functional.layer_norm(ref.double(), (768,), gam.double(), bet.double(), 1e-6).float()
+    rel = ((d1 - ln).norm() / ln.norm()).item()
+    assert rel < 4e-2, rel
+    if K == 768:                                                     # in place: the output overwrites the A operand and its scale planes
+        x3 = r.clone()
+        aq3, as3 = aq.clone(), asc.clone()
+        ops.gemm_mx_res_ln(aq3, as3, wq, wsc, b, x3, gam, bet, aq3, as3, 1e-6)
+        assert torch.equal(x3, x1[:M]) and torch.equal(aq3, q1[:M]) and torch.equal(as3[:, :M], s1[:, :M])
+
+
 @pytest.mark.parametrize('n_seq', [3, 70])
 def test_qkv_time_attention(gpu, n_seq):
     """sf_qkv_time_attention (temporal qkv projection + time attention + CLS-query partials in one launch) against the un-fused sequence it

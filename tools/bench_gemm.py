@@ -33,8 +33,13 @@ def main():
         for name, N, K, out_dt, gelu, res in [('qkv', 2304, 768, torch.bfloat16, False, False),
                                               ('proj+res', 768, 768, torch.float32, False, True),
                                               ('fc1+gelu', 3072, 768, torch.bfloat16, True, False),
-                                              ('fc2+res', 768, 3072, torch.float32, False, True)]:
-            if only and name not in only.split(','):
+                                              ('fc2+res', 768, 3072, torch.float32, False, True),
+                                              # the data-gradient products of the Stage-1 backward (named in SHAPES only)
+                                              ('dproj', 768, 768, torch.bfloat16, False, False),
+                                              ('dqkv', 768, 2304, torch.float32, False, False),
+                                              ('dfc1', 768, 3072, torch.float32, False, False),
+                                              ('dfc2', 3072, 768, torch.bfloat16, False, False)]:
+            if (only and name not in only.split(',')) or (not only and name.startswith('d')):
                 continue
             a = torch.randn(M, K, device=dev).bfloat16()
             w = (torch.randn(N, K, device=dev) * 0.02).bfloat16()

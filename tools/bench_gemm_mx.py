@@ -47,8 +47,18 @@ def main():
                 t['mxq'].append(timeit(lambda: ops.gemm_mxfp8(aq, asc, wq, wsc, b, oq, gelu=gelu, out_scales=osc)) if oq is not None else 0.0)
             med = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
             fl = 2.0 * M * N * K
+            extra = ''
+            if res:                                                   # the fused proj / fc2 + residual + LayerNorm + quantisation against the pair it replaces
+                gam, bet = torch.ones(768, device=dev), torch.zeros(768, device=dev)
+                yq, ysc = torch.empty(M, 768, device=dev, dtype=torch.uint8), ops.mx_scale_planes(M, 768, dev)
+                tf, tl = [], []
+                for _ in range(5):
+                    tf.append(timeit(lambda: ops.gemm_mx_res_ln(aq, asc, wq, wsc, b, out, gam, bet, yq, ysc, 1e-6)))
+                    tl.append(timeit(lambda: ops.layernorm_mxfp8(out, gam, bet, yq, ysc, 1e-6)))
+                tf, tl = sorted(tf)[2], sorted(tl)[2]
+                extra = f' | + LayerNorm -> MXFP8: separate {tl:6.1f} us, fused sf_gemm_mx_res_ln768 {tf:7.1f} us ({fl / tf / 1e6:5.0f} TF) vs pair {med["mx"] + tl:7.1f} us'
             print(f"{name:9s} N {N:4d} K {K:4d}: bf16 {med['bf16']:7.1f} us ({fl / med['bf16'] / 1e6:5.0f} TF) | mxfp8 {med['mx']:7.1f} us ({fl / med['mx'] / 1e6:5.0f} TF)"
-                  f" + quantise A {med['quant']:6.1f} us | MXFP8 out {med['mxq']:7.1f} us | round-2 loop {med['mx_r2']:7.1f} us ({fl / med['mx_r2'] / 1e6:5.0f} TF)", flush=True)
+                  f" + quantise A {med['quant']:6.1f} us | MXFP8 out {med['mxq']:7.1f} us | round-2 loop {med['mx_r2']:7.1f} us ({fl / med['mx_r2'] / 1e6:5.0f} TF)" + extra, flush=True)
 
 
 if __name__ == '__main__':
