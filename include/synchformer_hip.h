@@ -195,6 +195,10 @@ int sf_mel_frontend(const float* wave, int64_t n_seg, int n_samples, int hop, co
 /* out[b][c][r] = in[b][r][c] (bf16), columns r in [R, R_pad) zero-filled; two-level batch strides in elements. */
 int sf_transpose_bf16(const uint16_t* in, int64_t ld_in, int64_t sI0, int64_t sI1, uint16_t* out, int64_t ld_out, int64_t sO0,
                       int64_t sO1, int R, int C, int R_pad, int batch_outer, int batch_inner, void* stream);
+/* n_tensors transposes of sf_transpose_bf16's wide kind (C % 8 == 0, R_pad % 8 == 0, 16-byte aligned rows) in one launch: table[t] = { in, out, ld_in, ld_out,
+ * R, C, R_pad, ceil(R_pad / 64) } as int64 and tile_prefix[t] = 64 x 64 tiles before tensor t (n_tensors + 1 ints), both in DEVICE memory.  The bf16 W^T
+ * operand copies of all trainable weights after an optimizer step. */
+int sf_transpose_bf16_multi(const int64_t* table, const int* tile_prefix, int n_tensors, int total_tiles, void* stream);
 /* y = bf16(scale * x) for a (rows, cols) fp32 matrix, cols % 4 == 0. */
 int sf_cast_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int64_t rows, int cols, float scale, void* stream);
 /* P[r,:L] = softmax(scale * S[r,:L]) (bf16), P[r,L:L_pad] = 0; L <= 256 (attention probabilities, modules/transformer.py:67-69). */
@@ -228,6 +232,11 @@ int sf_cross_entropy(const float* logits, int64_t ld, const int64_t* targets, in
  * the backward.  Dropout sites: sync_model.py:166, modules/transformer.py:70,73,90. */
 int sf_dropout(const void* x, int dtype, int64_t ldx, const float* residual, int64_t ldr, void* y, int64_t ldy, int64_t rows, int cols,
                float p, uint32_t seed, void* stream);
+/* Head of a residual branch's backward in the Stage-1 towers (the `x = x + drop_path(branch(x))` sites of vit_helper.py:364-376 / modeling_ast.py ASTLayer):
+ * y = bf16(s[r / seq_rows] * dx[r, :]) (the dY operand of the branch's output Linear) and dbias (=|+=) the fp32 column sums of the scaled gradient, in one
+ * pass over dx (seq_scale may be NULL).  Replaces sf_scale_seq_add -> sf_cast_bf16 -> sf_colsum.  cols % 32 == 0; workspace >= cols * ceil(rows / 64) floats. */
+int sf_branch_grad(const float* dx, int64_t ldx, const float* seq_scale, int64_t seq_rows, uint16_t* y, int64_t ldy, int64_t rows, int cols, float* dbias,
+                   int accumulate, float* workspace, void* stream);
 /* Stochastic depth of the Stage-1 visual tower (DropPath at vit_helper.py:356,372,375, rates video_model_builder.py:86-87 = linspace(0, 0.2, 12)):
  * y[r,:] = (residual ? residual[r,:] : 0) + seq_scale[r / seq_rows] * x[r,:], fp32, cols % 4 == 0; seq_scale[i] is 0 or 1/keep_prob per
  * segment.  The forward applies it to a residual branch, the backward to the incoming gradient with the same scales. */

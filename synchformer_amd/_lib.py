@@ -41,6 +41,7 @@ SIGNATURES = {
     'sf_mel_frontend': [_ptr, _i64, _i32, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _i32, _f32, _f32, _ptr],
     'sf_transpose_bf16': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _ptr],
     'sf_cast_bf16': [_ptr, _i64, _ptr, _i64, _i64, _i32, _f32, _ptr],
+    'sf_transpose_bf16_multi': [_ptr, _ptr, _i32, _i32, _ptr],
     'sf_softmax_rows': [_ptr, _i64, _ptr, _i64, _i64, _i32, _i32, _f32, _ptr],
     'sf_softmax_bwd_rows': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i32, _i32, _f32, _ptr],
     'sf_layernorm768_bwd': [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i32, _ptr, _ptr, _i32, _ptr, _i64, _f32, _ptr],
@@ -52,6 +53,7 @@ SIGNATURES = {
     'sf_gelu_bwd_bf16': [_ptr, _ptr, _ptr, _i64, _ptr],
     'sf_cross_entropy': [_ptr, _i64, _ptr, _i32, _i32, _ptr, _ptr, _i64, _f32, _ptr],
     'sf_scale_seq_add': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i32, _ptr],
+    'sf_branch_grad': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i32, _ptr, _i32, _ptr, _ptr],
     'sf_dropout': [_ptr, _i32, _i64, _ptr, _i64, _ptr, _i64, _i64, _i32, _f32, C.c_uint32, _ptr],
     'sf_grad_norm': [_ptr, _i64, _ptr, _ptr, _ptr],
     'sf_adam_clip_step': [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _f32, _f32, _f32, _f32, _f32, _i32, _ptr],

@@ -84,6 +84,50 @@ extern "C" int sf_transpose_bf16(const bf16_t* in, int64_t ld_in, int64_t sI0, i
   return 0;
 }
 
+// Many transposes in ONE launch (the bf16 W^T copies of every trainable weight after an optimizer step: 194 launches of ~5 us in the Stage-1 step).
+// table[t] = { in, out, ld_in, ld_out, R, C, R_pad, tiles_x } as int64 (device memory, built once: the operand copies never move); tile_prefix[t] = number of
+// 64 x 64 tiles of tensors 0 .. t-1 (n + 1 entries).  Every tensor must satisfy the conditions of the wide kernel above.
+__global__ __launch_bounds__(256) void transpose_bf16_multi_kernel(const int64_t* __restrict__ table, const int* __restrict__ tile_prefix, int n_tensors) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];
+  int lo = 0, hi = n_tensors;                                        // the tensor whose tile range holds blockIdx.x
+  const int b = blockIdx.x;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tile_prefix[mid] <= b) lo = mid; else hi = mid; }
+  const int64_t* d = table + (int64_t)lo * 8;
+  const bf16_t* in = reinterpret_cast<const bf16_t*>(d[0]);
+  bf16_t* out = reinterpret_cast<bf16_t*>(d[1]);
+  const int64_t ld_in = d[2], ld_out = d[3];
+  const int R = (int)d[4], C = (int)d[5], R_pad = (int)d[6], tiles_x = (int)d[7];
+  const int tl = b - tile_prefix[lo];
+  const int r0 = (tl % tiles_x) * 64, c0 = (tl / tiles_x) * 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = threadIdx.x + i * 256, row = idx >> 3, ch = idx & 7;
+    const int r = r0 + row, c = c0 + ch * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (r < R && c < C) v = *reinterpret_cast<const uint4*>(in + (int64_t)r * ld_in + c);
+    *reinterpret_cast<uint4*>(&tile[row][ch * 8]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = threadIdx.x + i * 256, oc = idx & 63, rch = idx >> 6;
+    const int c = c0 + oc, r = r0 + rch * 8;
+    if (c < C && r < R_pad) {
+      uint32_t w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (uint32_t)tile[rch * 8 + 2 * e][oc] | ((uint32_t)tile[rch * 8 + 2 * e + 1][oc] << 16);
+      *reinterpret_cast<uint4*>(out + (int64_t)c * ld_out + r) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
+extern "C" int sf_transpose_bf16_multi(const int64_t* table, const int* tile_prefix, int n_tensors, int total_tiles, void* stream) {
+  SF_CHECK_ARG(table && tile_prefix && n_tensors >= 1 && total_tiles >= 1, "sf_transpose_bf16_multi: bad arguments");
+  hipLaunchKernelGGL(transpose_bf16_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, table, tile_prefix, n_tensors);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // fp32 -> bf16 cast of a (rows, cols) matrix (cols % 4 == 0), optional scale.
 // ------------------------------------------------------------------------------------------------------
@@ -566,6 +610,71 @@ extern "C" int sf_scale_seq_add(const float* x, int64_t ldx, const float* seq_sc
   const int64_t n = rows * (cols / 4);
   hipLaunchKernelGGL(scale_seq_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, seq_scale, seq_rows, residual, ldr,
                      y, ldy, rows, cols / 4);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Head of a residual branch's backward (Stage-1 towers): from the fp32 gradient of the block output dx
+//     y[r, :]   = bf16( s[r / seq_rows] * dx[r, :] )              the dY operand of the proj / fc2 weight- and data-gradient GEMMs
+//     dbias[c]  (=|+=) sum_r s[r / seq_rows] * dx[r, c]           in fp32, BEFORE the rounding (biases are cancellation-prone)
+// in ONE pass over dx (s = per-segment stochastic-depth scale, or absent).  Replaces sf_scale_seq_add -> sf_cast_bf16 -> sf_colsum's first stage:
+// three reads of the fp32 gradient and an fp32 copy of the scaled branch gradient.  A block covers rows_per_blk rows x 32 columns (8 lanes = one
+// 128-byte line of a row, 32 row lanes); its column sums go to `part` and are reduced by colsum_partials_kernel (second launch).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void branch_grad_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ seq_scale, int64_t seq_rows,
+                                                           bf16_t* __restrict__ y, int64_t ldy, int64_t rows, int cols, int rows_per_blk,
+                                                           float* __restrict__ part) {
+  __shared__ float red[4][8 * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rl = tid >> 3, ch = tid & 7;
+  const int c0 = blockIdx.x * 32 + ch * 4;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_blk, r1 = min(r0 + rows_per_blk, rows);
+  // a block's rows touch at most two sequences (host: rows_per_blk <= seq_rows)
+  float s0 = 1.f, s1 = 1.f;
+  int64_t edge = rows;
+  if (seq_scale) {
+    const int64_t q = r0 / seq_rows;
+    edge = (q + 1) * seq_rows;
+    s0 = seq_scale[q];
+    s1 = edge < r1 ? seq_scale[q + 1] : 0.f;
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = r0 + rl; r < r1; r += 32) {
+    const float sc = r < edge ? s0 : s1;
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sc != 0.f) {                                                // a dropped branch is not even read
+      u = *reinterpret_cast<const float4*>(x + r * ldx + c0);
+      u.x *= sc; u.y *= sc; u.z *= sc; u.w *= sc;
+    }
+    acc[0] += u.x; acc[1] += u.y; acc[2] += u.z; acc[3] += u.w;
+    uint2 o; o.x = pack_bf2(u.x, u.y); o.y = pack_bf2(u.z, u.w);
+    *reinterpret_cast<uint2*>(y + r * ldy + c0) = o;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {                                     // over the 8 row lanes of the wave that share this chunk
+    float t = acc[e];
+    t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+    if (lane < 8) red[wave][ch * 4 + e] = t;
+  }
+  __syncthreads();
+  if (tid < 32) part[(int64_t)blockIdx.y * cols + blockIdx.x * 32 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+extern "C" int sf_branch_grad(const float* dx, int64_t ldx, const float* seq_scale, int64_t seq_rows, uint16_t* y, int64_t ldy, int64_t rows, int cols,
+                              float* dbias, int accumulate, float* workspace, void* stream) {
+  SF_CHECK_ARG(dx && y && dbias && workspace && cols >= 32 && (cols % 32) == 0, "sf_branch_grad: bad arguments (cols must be a multiple of 32)");
+  SF_CHECK_ARG((ldx % 4) == 0 && (ldy % 4) == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)y % 8) == 0, "sf_branch_grad: rows must be 16-byte (dx) / 8-byte (y) aligned");
+  if (rows <= 0) return 0;
+  int rpb = rows >= 16384 ? 256 : 64;                               // workspace contract as sf_colsum: cols * ceil(rows / 64) floats
+  SF_CHECK_ARG(!seq_scale || seq_rows >= 64, "sf_branch_grad: sequences shorter than a 64-row block are not supported");
+  if (seq_scale && rpb > seq_rows) rpb = 64;
+  const int64_t nblk = (rows + rpb - 1) / rpb;
+  SF_CHECK_ARG(nblk < 65536, "sf_branch_grad: too many rows");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(branch_grad_kernel, dim3(cols / 32, (unsigned)nblk), dim3(256), 0, s, dx, ldx, seq_scale, seq_rows, y, ldy, rows, cols, rpb, workspace);
+  SF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((cols + 63) / 64), dim3(1024), 0, s, workspace, nblk, (int64_t)cols, dbias, cols, accumulate);
   SF_LAUNCH_CHECK();
   return 0;
 }

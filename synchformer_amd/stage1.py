@@ -125,6 +125,15 @@ class AVCLIPTrainer(FlatTrainer):
              'sf_scale_seq_add')
         return out
 
+    def _branch_dy(self, dx, dp, seq_rows, rows, bias_key):
+        """Head of a residual branch's backward: dY = bf16(dp[segment] * dx) for the branch's output Linear, and that Linear's bias gradient (fp32 column
+        sums of the scaled gradient) into g[bias_key], in one pass over dx (sf_branch_grad)."""
+        dy_b = self._buf('dy_b', (rows, D), torch.bfloat16)
+        ws = self._buf('colsum_ws', (D * ((rows + 63) // 64),), torch.float32)
+        _chk(_lib.load().sf_branch_grad(dx.data_ptr(), dx.stride(0), dp.data_ptr() if dp is not None else None, max(1, seq_rows), dy_b.data_ptr(), dy_b.stride(0),
+                                        rows, D, self.g[bias_key].data_ptr(), 0, ws.data_ptr(), _st()), 'sf_branch_grad')
+        return dy_b
+
     def _mlp_fwd(self, s, x_in, h_name, fc1, fc2, rows, eps_name, eps, tag, dp=None, seq_rows=0):
         """h = LN(x_in); pre = fc1(h); act = gelu(pre); returns x_in + fc2(act) (x_in + dp[segment] * fc2(act) under stochastic depth).
         Saves h, pre, act."""
@@ -145,10 +154,8 @@ class AVCLIPTrainer(FlatTrainer):
 
     def _mlp_bwd(self, s, dx, x_in, fc1, fc2, rows, ln_name, eps, dp=None, seq_rows=0):
         """dx (rows, 768) fp32 = gradient of the block output; adds the MLP branch's contribution through LN(x_in) into dx."""
-        dbr = dx if dp is None else self._scale_seq(dx, dp, seq_rows, rows, self._buf('dp_dbranch', (rows, D), torch.float32))   # gradient of the (scaled) branch
-        dy_b = self._buf('dy_b', (rows, D), torch.bfloat16)
-        cast_bf16(dbr, dy_b, rows, D)
-        dact = self._lin_bwd(fc2, dy_b, s['act'], rows, tag='act', dy_f32=dbr, dx_dtype=torch.bfloat16)   # consumed by the bf16 GELU backward only
+        dy_b = self._branch_dy(dx, dp, seq_rows, rows, fc2 + '.bias')                                     # gradient of the (scaled) branch + fc2's bias gradient
+        dact = self._lin_bwd(fc2, dy_b, s['act'], rows, tag='act', bias_done=True, dx_dtype=torch.bfloat16)   # consumed by the bf16 GELU backward only
         dpre = self._buf('dpre', (rows, FF), torch.bfloat16)
         self._gelu_bwd(s['pre'], dact, dpre)
         dh = self._lin_bwd(fc1, dpre, s['h2'], rows, tag='h', dx_dtype=torch.bfloat16)                      # read once, by the LN backward
@@ -227,10 +234,8 @@ class AVCLIPTrainer(FlatTrainer):
     def _attn_branch_bwd(self, dx, rows, proj, att_saved, qkv_fn, h_saved, x_in, ln_name, eps, qkv_names, dp=None, seq_rows=0):
         """Common tail of an attention residual branch: dx -> proj backward -> attention backward (qkv_fn) -> qkv linear(s)
         backward -> LN backward accumulated into dx.  `dp`: per-segment stochastic-depth scales of this branch (None = branch always kept)."""
-        dbr = dx if dp is None else self._scale_seq(dx, dp, seq_rows, rows, self._buf('dp_dbranch', (rows, D), torch.float32))
-        dy_b = self._buf('dy_b', (rows, D), torch.bfloat16)
-        cast_bf16(dbr, dy_b, rows, D)
-        dO_b = self._lin_bwd(proj, dy_b, att_saved, rows, tag='h', dy_f32=dbr, dx_dtype=torch.bfloat16)     # attention output gradient, bf16 for the attention backward
+        dy_b = self._branch_dy(dx, dp, seq_rows, rows, proj + '.bias')
+        dO_b = self._lin_bwd(proj, dy_b, att_saved, rows, tag='h', bias_done=True, dx_dtype=torch.bfloat16)  # attention output gradient, bf16 for the attention backward
         dqkv = qkv_fn(dO_b)
         if isinstance(qkv_names, str):                                        # one fused (2304, 768) projection
             dh = self._lin_bwd(qkv_names, dqkv, h_saved, rows, tag='h', dx_dtype=torch.bfloat16)

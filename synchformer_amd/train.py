@@ -130,6 +130,8 @@ class FlatTrainer:
         self.loss = torch.zeros(1, device=self.dev, dtype=torch.float32)
         self._ws: Dict[str, torch.Tensor] = {}
         self._wT: Dict[str, torch.Tensor] = {}
+        self._wT_table = None                     # device table of sf_transpose_bf16_multi, built on the first refresh
+        self._wT_single: List[str] = []
         self._refresh_transposed()
 
     # ---- small helpers -----------------------------------------------------------------------------------
@@ -146,18 +148,31 @@ class FlatTrainer:
         return v
 
     def _refresh_transposed(self):
-        """bf16 W^T copies (dgrad operands) of every 2-D trainable weight; called after each optimizer step."""
-        for k in self.keys:
-            w = self.b[k]
-            if w.dim() != 2 or not k.endswith('weight'):
-                continue
-            N, K = w.shape
-            n_pad = ((N + 63) // 64) * 64
-            t = self._wT.get(k)
-            if t is None:
-                t = torch.zeros(K, n_pad, device=self.dev, dtype=torch.bfloat16)
-                self._wT[k] = t
-            transpose(w, K, 0, 0, t, n_pad, 0, 0, N, K, n_pad)
+        """bf16 W^T copies (dgrad operands) of every 2-D trainable weight; called after each optimizer step.  One launch for all of them
+        (sf_transpose_bf16_multi over a device-resident table: the operand copies never move); odd shapes take sf_transpose_bf16 one by one."""
+        if self._wT_table is None:
+            rows, prefix, self._wT_single = [], [0], []
+            for k in self.keys:
+                w = self.b[k]
+                if w.dim() != 2 or not k.endswith('weight'):
+                    continue
+                N, K = w.shape
+                n_pad = ((N + 63) // 64) * 64
+                t = self._wT[k] = torch.zeros(K, n_pad, device=self.dev, dtype=torch.bfloat16)
+                if K % 8 == 0 and w.data_ptr() % 16 == 0 and w.stride(0) % 8 == 0:
+                    tx, ty = (n_pad + 63) // 64, (K + 63) // 64
+                    rows.append([w.data_ptr(), t.data_ptr(), w.stride(0), n_pad, N, K, n_pad, tx])
+                    prefix.append(prefix[-1] + tx * ty)
+                else:
+                    self._wT_single.append(k)
+            self._wT_table = (torch.tensor(rows, dtype=torch.int64, device=self.dev), torch.tensor(prefix, dtype=torch.int32, device=self.dev), len(rows), prefix[-1]) \
+                if rows else ()
+        if self._wT_table:
+            tab, pre, n, total = self._wT_table
+            _chk(_lib.load().sf_transpose_bf16_multi(tab.data_ptr(), pre.data_ptr(), n, total, _st()), 'sf_transpose_bf16_multi')
+        for k in self._wT_single:
+            w, t = self.b[k], self._wT[k]
+            transpose(w, w.shape[1], 0, 0, t, t.shape[1], 0, 0, w.shape[0], w.shape[1], t.shape[1])
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         return {k: v.detach().clone() for k, v in self.p.items()}
@@ -174,15 +189,16 @@ class FlatTrainer:
         return self.b[name + '.weight'], self.p[name + '.bias']
 
     def _lin_bwd(self, name, dy_b, x_b, M, *, need_dx=True, dx_out=None, tag='', wkey=None, bkey=None, acc_bias=False, acc_dx=False, dy_f32=None,
-                 dx_dtype=torch.float32):
+                 dx_dtype=torch.float32, bias_done=False):
         """dy_b (M, N) bf16 (row stride may exceed N), x_b (M, K) bf16 saved input.  Fills g[W], g[b]; returns dx fp32 (M, K).
         `wkey` / `bkey` name tensors that do not follow the `<name>.weight` / `<name>.bias` convention (in_proj_weight, conv kernels).
-        dx_dtype=torch.bfloat16 lets the dgrad GEMM write dx in bf16 when the only consumer is a bf16 kernel (no fp32 round trip + cast)."""
+        dx_dtype=torch.bfloat16 lets the dgrad GEMM write dx in bf16 when the only consumer is a bf16 kernel (no fp32 round trip + cast).
+        bias_done: g[b] has been filled by the producer of dy_b (sf_branch_grad sums the fp32 gradient while it casts it)."""
         wkey, bkey = wkey or name + '.weight', bkey or name + '.bias'
         N = self.p[wkey].shape[0]
         K = self.p[wkey].numel() // N
         m_pad = ((M + 63) // 64) * 64
-        if dy_f32 is not None:                                                       # fp32 gradient at hand: sum that (cancellation-prone biases)
+        if dy_f32 is not None and not bias_done:                                     # fp32 gradient at hand: sum that (cancellation-prone biases)
             ws = self._buf('colsum_ws', (N * ((M + 63) // 64),), torch.float32)
             colsum(dy_f32, M, N, self.g[bkey], ws, accumulate=acc_bias)
         # dW = dy^T x: an (N, K) output is only (N/128)*(K/128) tiles (36 for a 768x768 weight) however long the M contraction is,
@@ -195,7 +211,7 @@ class FlatTrainer:
             # dW straight from the row-major gradient / saved input (ds_read_b64_tr_b16 operand reads): no transposed copies
             # the bias gradient (column sums of dY) rides in the same launch: per-chunk partials from an all-ones MFMA in the workgroups of column tile 0
             part = self._buf('wgrad_part', (split * N, K), torch.float32)
-            bpart = self._buf('bgrad_part', (split, N), torch.float32) if dy_f32 is None else None
+            bpart = self._buf('bgrad_part', (split, N), torch.float32) if dy_f32 is None and not bias_done else None
             _chk(_lib.load().sf_gemm_tn_splitk(dy_b.data_ptr(), dy_b.stride(0), x_b.data_ptr(), x_b.stride(0), part.data_ptr(),
                                                bpart.data_ptr() if bpart is not None else None, M, N, K, split, kc, _st()), 'sf_gemm_tn_splitk')
             _chk(_lib.load().sf_seqsum(part.data_ptr(), K, split, N, K, self.g[wkey].data_ptr(), 0, _st()), 'sf_seqsum')
@@ -207,7 +223,7 @@ class FlatTrainer:
         xT = self._buf('xT', (K, m_pad), torch.bfloat16)
         transpose(dy_b, dy_b.stride(0), 0, 0, dyT, m_pad, 0, 0, M, N, m_pad)
         transpose(x_b, x_b.stride(0), 0, 0, xT, m_pad, 0, 0, M, K, m_pad)
-        if dy_f32 is None:                                                           # bias gradient = row sums of dy^T (zero-padded columns add 0)
+        if dy_f32 is None and not bias_done:                                         # bias gradient = row sums of dy^T (zero-padded columns add 0)
             _chk(_lib.load().sf_rowsum_bf16(dyT.data_ptr(), m_pad, N, m_pad, self.g[bkey].data_ptr(), int(acc_bias), _st()), 'sf_rowsum_bf16')
         if split > 1:
             part = self._buf('wgrad_part', (split * N, K), torch.float32)
