@@ -379,31 +379,160 @@ def register_torch_ops():
     if _registered:
         return
     from torch.library import custom_op
+    # the direct launchers, bound now: ops.via_dispatcher() re-points the module-level names at these custom ops
+    d_ = {n: globals()[n] for n in ('gemm', 'layernorm', 'attention', 'attention_cls', 'im2col_video', 'gemm_res_ln', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'quantize_mxfp8', 'layernorm_mxfp8', 'gemm_mxfp8', 'gemm_mx_res_ln')}
 
     @custom_op('synchformer::gemm_bf16', mutates_args=('out',), device_types='cuda')
     def _gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, residual: Optional[torch.Tensor],
               gelu: bool) -> None:
-        gemm(a, w, bias, out, residual=residual, gelu=gelu)
+        d_['gemm'](a, w, bias, out, residual=residual, gelu=gelu)
 
     @custom_op('synchformer::layernorm768', mutates_args=('out',), device_types='cuda')
     def _ln(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, eps: float) -> None:
-        layernorm(x, gamma, beta, out, eps)
+        d_['layernorm'](x, gamma, beta, out, eps)
 
     @custom_op('synchformer::attention', mutates_args=('out',), device_types='cuda')
     def _attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, n_seq: int, seq_rows: int, n_groups: int, row0: int,
               group_stride: int, tok_stride: int, n_tok: int, cls_row: int, heads: int, head_dim: int, scale: float) -> None:
-        attention(q, k, v, out, n_seq=n_seq, seq_rows=seq_rows, n_groups=n_groups, row0=row0, group_stride=group_stride,
+        d_['attention'](q, k, v, out, n_seq=n_seq, seq_rows=seq_rows, n_groups=n_groups, row0=row0, group_stride=group_stride,
                   tok_stride=tok_stride, n_tok=n_tok, cls_row=cls_row, heads=heads, head_dim=head_dim, scale=scale)
 
     @custom_op('synchformer::attention_cls', mutates_args=('out',), device_types='cuda')
     def _attn_cls(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, n_seq: int, q_seq_rows: int, q_row: int,
                   kv_seq_rows: int, kv_row0: int, n_keys: int, out_seq_rows: int, out_row: int, heads: int, head_dim: int,
                   scale: float) -> None:
-        attention_cls(q, k, v, out, n_seq=n_seq, q_seq_rows=q_seq_rows, q_row=q_row, kv_seq_rows=kv_seq_rows, kv_row0=kv_row0,
+        d_['attention_cls'](q, k, v, out, n_seq=n_seq, q_seq_rows=q_seq_rows, q_row=q_row, kv_seq_rows=kv_seq_rows, kv_row0=kv_row0,
                       n_keys=n_keys, out_seq_rows=out_seq_rows, out_row=out_row, heads=heads, head_dim=head_dim, scale=scale)
 
     @custom_op('synchformer::im2col_video', mutates_args=('out',), device_types='cuda')
     def _im2col(vid: torch.Tensor, out: torch.Tensor) -> None:
-        im2col_video(vid, out)
+        d_['im2col_video'](vid, out)
+
+    # the fused launches the engine's default schedule is made of (rounds 2 / 3)
+    @custom_op('synchformer::gemm_res_ln768', mutates_args=('x', 'y'), device_types='cuda')
+    def _gemm_res_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch.Tensor,
+                     eps: float) -> None:
+        d_['gemm_res_ln'](a, w, bias, x, gamma, beta, y, eps)
+
+    @custom_op('synchformer::qkv_time_attention', mutates_args=('out', 'partials'), device_types='cuda')
+    def _qkv_time(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], qkv_cls: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, n_seq: int,
+                  n_groups: int, scale: float, key_keep: Optional[torch.Tensor]) -> None:
+        d_['qkv_time_attention'](x, w, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale, key_keep=key_keep)
+
+    @custom_op('synchformer::attention_cls_partial', mutates_args=('out', 'partials'), device_types='cuda')
+    def _attn_part(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, n_seq: int, seq_rows: int, n_groups: int,
+                   row0: int, group_stride: int, tok_stride: int, n_tok: int, cls_row: int, heads: int, head_dim: int, scale: float,
+                   key_keep: Optional[torch.Tensor]) -> None:
+        d_['attention_cls_partial'](q, k, v, out, partials, n_seq=n_seq, seq_rows=seq_rows, n_groups=n_groups, row0=row0, group_stride=group_stride,
+                              tok_stride=tok_stride, n_tok=n_tok, cls_row=cls_row, heads=heads, head_dim=head_dim, scale=scale, key_keep=key_keep)
+
+    @custom_op('synchformer::attention_cls_combine', mutates_args=('out',), device_types='cuda')
+    def _attn_comb(partials: torch.Tensor, out: torch.Tensor, n_part: int, n_seq: int, out_seq_rows: int, out_row: int, heads: int) -> None:
+        d_['attention_cls_combine'](partials, out, n_part=n_part, n_seq=n_seq, out_seq_rows=out_seq_rows, out_row=out_row, heads=heads)
+
+    @custom_op('synchformer::quantize_mxfp8', mutates_args=('q', 'scales'), device_types='cuda')
+    def _quant(x: torch.Tensor, q: torch.Tensor, scales: torch.Tensor) -> None:
+        d_['quantize_mxfp8'](x, q, scales)
+
+    @custom_op('synchformer::layernorm768_mxfp8', mutates_args=('q', 'scales'), device_types='cuda')
+    def _ln_mx(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, q: torch.Tensor, scales: torch.Tensor, eps: float) -> None:
+        d_['layernorm_mxfp8'](x, gamma, beta, q, scales, eps)
+
+    @custom_op('synchformer::gemm_mxfp8', mutates_args=('out', 'out_scales'), device_types='cuda')
+    def _gemm_mx(a_q: torch.Tensor, a_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor,
+                 out_scales: Optional[torch.Tensor], residual: Optional[torch.Tensor], gelu: bool) -> None:
+        d_['gemm_mxfp8'](a_q, a_s, w_q, w_s, bias, out, residual=residual, gelu=gelu, out_scales=out_scales)
+
+    @custom_op('synchformer::gemm_mx_res_ln768', mutates_args=('x', 'y_q', 'y_s'), device_types='cuda')
+    def _gemm_mx_res_ln(a_q: torch.Tensor, a_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], x: torch.Tensor,
+                        gamma: torch.Tensor, beta: torch.Tensor, y_q: torch.Tensor, y_s: torch.Tensor, eps: float) -> None:
+        d_['gemm_mx_res_ln'](a_q, a_s, w_q, w_s, bias, x, gamma, beta, y_q, y_s, eps)
 
     _registered = True
+
+
+class via_dispatcher:
+    """Context manager: while active, the launches the engine's default schedule is made of go through the PyTorch dispatcher
+    (`torch.ops.synchformer.*`, registered above) instead of straight into the C ABI - what a torch-side integration (profiler, dispatch modes,
+    `torch.library` consumers) sees.  Calls with arguments the registered schemas do not carry (row maps, explicit M) fall through to the direct path.
+        with ops.via_dispatcher(): logits = engine.forward(vis, aud)
+    The results are the same launches on the same buffers (tests/test_e2e_gpu.py compares them bit for bit)."""
+    NAMES = ('gemm', 'layernorm', 'gemm_res_ln', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'quantize_mxfp8', 'layernorm_mxfp8',
+             'gemm_mxfp8', 'gemm_mx_res_ln')
+
+    def __init__(self):
+        self.calls = 0
+
+    def __enter__(self):
+        register_torch_ops()
+        g = globals()
+        o = self.orig = {n: g[n] for n in self.NAMES}
+        t = torch.ops.synchformer
+
+        def count(fn):
+            def run(*a):
+                self.calls += 1
+                return fn(*a)
+            return run
+
+        def gemm_(a, w, bias, out, *, M=None, residual=None, gelu=False, c_map=None, r_map=None):
+            if M is not None or c_map is not None or r_map is not None:
+                return o['gemm'](a, w, bias, out, M=M, residual=residual, gelu=gelu, c_map=c_map, r_map=r_map)
+            count(t.gemm_bf16)(a, w, bias, out, residual, gelu)
+            return out
+
+        def layernorm_(x, gamma, beta, out, eps, **kw):
+            if kw:
+                return o['layernorm'](x, gamma, beta, out, eps, **kw)
+            count(t.layernorm768)(x, gamma, beta, out, eps)
+            return out
+
+        def gemm_res_ln_(a, w, bias, x, gamma, beta, y, eps, *, M=None, residual=None):
+            if M is not None or residual is not None:
+                return o['gemm_res_ln'](a, w, bias, x, gamma, beta, y, eps, M=M, residual=residual)
+            count(t.gemm_res_ln768)(a, w, bias, x, gamma, beta, y, eps)
+            return x, y
+
+        def qkv_time_(x, w, bias, qkv_cls, out, partials, *, n_seq, n_groups, scale, key_keep=None):
+            count(t.qkv_time_attention)(x, w, bias, qkv_cls, out, partials, n_seq, n_groups, scale, key_keep)
+            return out
+
+        def attn_part_(q, k, v, out, partials, *, n_seq, seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim, scale, key_keep=None):
+            count(t.attention_cls_partial)(q, k, v, out, partials, n_seq, seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim, scale,
+                                           key_keep)
+            return out
+
+        def attn_comb_(partials, out, *, n_part, n_seq, out_seq_rows, out_row, heads):
+            count(t.attention_cls_combine)(partials, out, n_part, n_seq, out_seq_rows, out_row, heads)
+            return out
+
+        def quant_(x, q, scales, rows=None):
+            if rows is not None:
+                return o['quantize_mxfp8'](x, q, scales, rows)
+            count(t.quantize_mxfp8)(x, q, scales)
+            return q, scales
+
+        def ln_mx_(x, gamma, beta, q, scales, eps, rows=None):
+            if rows is not None:
+                return o['layernorm_mxfp8'](x, gamma, beta, q, scales, eps, rows)
+            count(t.layernorm768_mxfp8)(x, gamma, beta, q, scales, eps)
+            return q, scales
+
+        def gemm_mx_(a_q, a_s, w_q, w_s, bias, out, *, M=None, residual=None, gelu=False, out_scales=None):
+            if M is not None:
+                return o['gemm_mxfp8'](a_q, a_s, w_q, w_s, bias, out, M=M, residual=residual, gelu=gelu, out_scales=out_scales)
+            count(t.gemm_mxfp8)(a_q, a_s, w_q, w_s, bias, out, out_scales, residual, gelu)
+            return out
+
+        def gemm_mx_ln_(a_q, a_s, w_q, w_s, bias, x, gamma, beta, y_q, y_s, eps, *, M=None, residual=None):
+            if M is not None or residual is not None:
+                return o['gemm_mx_res_ln'](a_q, a_s, w_q, w_s, bias, x, gamma, beta, y_q, y_s, eps, M=M, residual=residual)
+            count(t.gemm_mx_res_ln768)(a_q, a_s, w_q, w_s, bias, x, gamma, beta, y_q, y_s, eps)
+            return x, y_q, y_s
+
+        g.update(gemm=gemm_, layernorm=layernorm_, gemm_res_ln=gemm_res_ln_, qkv_time_attention=qkv_time_, attention_cls_partial=attn_part_,
+                 attention_cls_combine=attn_comb_, quantize_mxfp8=quant_, layernorm_mxfp8=ln_mx_, gemm_mxfp8=gemm_mx_, gemm_mx_res_ln=gemm_mx_ln_)
+        return self
+
+    def __exit__(self, *exc):
+        globals().update(self.orig)
