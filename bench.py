@@ -93,11 +93,12 @@ class GemmTimer:
 
     @staticmethod
     def _gemm_symbol(m, n, k, out_bf16, gelu, res, mapped):
-        big = (not mapped) and m >= 8192 and n >= 512 and n % 64 == 0 and not (res and k <= 1024)
+        from synchformer_amd import _lib
+        cfg = 0 if mapped else _lib.load().sf_gemm_bf16_auto_config(m, n, k, int(res))     # the library's own choice (tile-round fill decides at small batches)
         b = lambda v: 'true' if v else 'false'
-        if big and k % 128 == 0 and k >= 256:
+        if cfg == 11:
             return f'gemm_bf16_pp_kernel<{b(out_bf16)}, {b(gelu)}, {b(res)}>'
-        if big:
+        if cfg == 7:
             return f'gemm_bf16_persistent_kernel<{b(out_bf16)}, {b(gelu)}, {b(res)}>'
         return 'gemm_bf16_kernel<GemmCfg<128, 128, 2, 2, 64, 2, 2, false>, ...> (small / mapped GEMMs: AST, aggregators, sync transformer, heads)'
 

@@ -108,6 +108,9 @@ int sf_gemm_mx_res_ln768(const uint8_t* A, int64_t lda, const uint8_t* sA, int64
  * (half-tile LDS-DMA stream 1.5 stages ahead, counted waits, staggered wave groups: sf_gemm_pp.hip; K %% 128 == 0) - the automatic choice for the big
  * token GEMMs; 10 = 4 waves of 128x128; 1-6, 8, 9 = the other tilings measured in profiles/r01_gemm_configs.md (tools/bench_gemm.py). */
 void sf_gemm_force_config(int cfg);
+/* The configuration the automatic choice takes for a row-major, identity-mapped GEMM of this shape (0, 7 or 11): bench.py files its live launch timings
+ * under the kernel symbol rocprofv3 reports for that configuration. */
+int sf_gemm_bf16_auto_config(int64_t M, int64_t N, int64_t K, int has_residual);
 /* The same kind of hook for sf_gemm_res_ln768's main-loop schedule: -1 default (quadrant-phased, round 3), 0 = round 2's loop (one stage of prefetch),
  * 1 = quadrant-phased.  Both sum every accumulator in the same order: bit-identical outputs (the tests compare them). */
 void sf_gemm_res_ln_force_schedule(int sched);
@@ -237,6 +240,10 @@ int sf_dropout(const void* x, int dtype, int64_t ldx, const float* residual, int
  * pass over dx (seq_scale may be NULL).  Replaces sf_scale_seq_add -> sf_cast_bf16 -> sf_colsum.  cols % 32 == 0; workspace >= cols * ceil(rows / 64) floats. */
 int sf_branch_grad(const float* dx, int64_t ldx, const float* seq_scale, int64_t seq_rows, uint16_t* y, int64_t ldy, int64_t rows, int cols, float* dbias,
                    int accumulate, float* workspace, void* stream);
+/* x = residual + seq_scale[r / seq_rows] * branch (fp32; seq_scale may be NULL = 1) and y = bf16(LayerNorm(x) * gamma + beta) in one pass: the stochastic-depth
+ * residual add and the next sub-layer's norm of the Stage-1 forward (vit_helper.py:364-376); sf_scale_seq_add followed by sf_layernorm768. */
+int sf_add_scale_ln768(const float* branch, int64_t ldb, const float* seq_scale, int64_t seq_rows, const float* residual, int64_t ldr, float* x, int64_t ldx,
+                       const float* gamma, const float* beta, uint16_t* y, int64_t ldy, int64_t rows, float eps, void* stream);
 /* Stochastic depth of the Stage-1 visual tower (DropPath at vit_helper.py:356,372,375, rates video_model_builder.py:86-87 = linspace(0, 0.2, 12)):
  * y[r,:] = (residual ? residual[r,:] : 0) + seq_scale[r / seq_rows] * x[r,:], fp32, cols % 4 == 0; seq_scale[i] is 0 or 1/keep_prob per
  * segment.  The forward applies it to a residual branch, the backward to the incoming gradient with the same scales. */

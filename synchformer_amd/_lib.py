@@ -29,6 +29,7 @@ SIGNATURES = {
     'sf_layernorm768_mxfp8': [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _f32, _ptr],
     'sf_gemm_mx_res_ln768': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _f32, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr],
     'sf_gemm_force_config': [_i32],
+    'sf_gemm_bf16_auto_config': [_i64, _i64, _i64, _i32],
     'sf_gemm_res_ln_force_schedule': [_i32],
     'sf_qkv_time_force_schedule': [_i32],
     'sf_gemm_mx_force_schedule': [_i32],
@@ -53,6 +54,7 @@ SIGNATURES = {
     'sf_gelu_bwd_bf16': [_ptr, _ptr, _ptr, _i64, _ptr],
     'sf_cross_entropy': [_ptr, _i64, _ptr, _i32, _i32, _ptr, _ptr, _i64, _f32, _ptr],
     'sf_scale_seq_add': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i32, _ptr],
+    'sf_add_scale_ln768': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _f32, _ptr],
     'sf_branch_grad': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i32, _ptr, _i32, _ptr, _ptr],
     'sf_dropout': [_ptr, _i32, _i64, _ptr, _i64, _ptr, _i64, _i64, _i32, _f32, C.c_uint32, _ptr],
     'sf_grad_norm': [_ptr, _i64, _ptr, _ptr, _ptr],

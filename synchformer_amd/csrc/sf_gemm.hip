@@ -811,6 +811,34 @@ static int dispatch_gemm(const GemmArgs& a, bool out_bf16, bool gelu, bool res, 
   return res ? launch_gemm<Cfg, false, false, true, true>(a, s) : launch_gemm<Cfg, false, false, false, true>(a, s);
 }
 
+// The automatic tile-configuration choice of sf_gemm_bf16 (-1 = no configuration serves these arguments: a k-tile-major weight outside the persistent kernels' range).
+static int gemm_auto_config(int64_t M, int64_t N, int64_t K, bool fast, bool res, bool w_kmajor, bool pp_ok) {
+  // Measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_configs.md): the persistent 256x256 kernel wins on the
+  // big token GEMMs; the short-K fp32-residual projection (N = K = 768) is HBM-bound and prefers 2 workgroups/CU;
+  // everything small (AST, aggregators, sync transformer, heads) and every mapped/ragged GEMM takes the 128x128 kernel.
+  const bool big = fast && M >= 8192 && N >= 512;
+  int cfg = 0;
+  if (w_kmajor) { if (!big) return -1; cfg = 7; }
+  const bool pp = pp_ok;                       // round 3: the quadrant-phased kernel replaces config 7 wherever K is a whole number of k-tile pairs
+  if (!w_kmajor && big && !(res && K <= 1024)) {
+    // Tile-round quantisation decides between the persistent 256x256 kernel (one workgroup per CU, ~8 % faster per tile pair when
+    // the chip is full) and the 128x128 kernel (two per CU): e.g. fc2 of a single clip is 86 x 3 = 258 big tiles = TWO rounds of
+    // 256 CUs at 50 % fill, but 1032 small tiles = 2.02 rounds of 512 slots.  Pick the better filled one (measured, M = 21,966 /
+    // 43,932: fc2 600 -> 803 / 766 -> 917 TFLOP/s; the 16-clip batch keeps the persistent kernel everywhere).
+    int n_cu = sf_cu_count("sf_gemm_bf16");
+    if (n_cu <= 0) n_cu = 256;
+    const double t7 = (double)((M + 255) / 256) * (double)((N + 255) / 256), t0 = (double)((M + 127) / 128) * (double)((N + 127) / 128);
+    const double r7 = (double)(int64_t)((t7 + n_cu - 1) / n_cu), r0 = (double)(int64_t)((t0 + 2 * n_cu - 1) / (2 * n_cu));
+    const double e7 = t7 / (r7 * n_cu), e0 = t0 / (r0 * 2 * n_cu);
+    // (config 11 is another ~12 % ahead of config 7 per filled round: tools/bench_gemm.py 14 28 56.  Two Stage-1 clips, N = 768, are the tie - 516 big tiles
+    // against 2064 small ones, fill 0.672 vs 0.806 = 1 : 1.2: measured there config 11 wins without a residual - dproj 58 vs 63 us, dqkv 160 vs 165, dfc1 206
+    // vs 217 - and loses with the fp32 residual epilogue, fc2 237 vs 228)
+    cfg = (e7 * (pp ? (res ? 1.18 : 1.24) : 1.08) >= e0) ? 7 : 0;
+  }
+  if (cfg == 7 && pp) cfg = 11;
+  return cfg;
+}
+
 extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, void* C,
                             int c_dtype, int64_t ldc, const int64_t* c_map, const float* R, int64_t ldr,
                             const int64_t* r_map, int epilogue, int64_t M, int64_t N, int64_t K, void* stream) {
@@ -841,26 +869,8 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
   const bool gelu = epilogue == SF_EPI_GELU, res = R != nullptr, obf = c_dtype == SF_BF16;
   int cfg = g_force_cfg;
   if (cfg < 0) {
-    // Measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_configs.md): the persistent 256x256 kernel wins on the
-    // big token GEMMs; the short-K fp32-residual projection (N = K = 768) is HBM-bound and prefers 2 workgroups/CU;
-    // everything small (AST, aggregators, sync transformer, heads) and every mapped/ragged GEMM takes the 128x128 kernel.
-    const bool big = fast && M >= 8192 && N >= 512;
-    cfg = 0;
-    if (w_kmajor) { SF_CHECK_ARG(big, "sf_gemm_bf16: a k-tile-major weight needs the persistent kernel (identity maps, N %% 64 == 0, M >= 8192, N >= 512)"); cfg = 7; }
-    const bool pp = sf_gemm_pp_supported(a);                       // round 3: the quadrant-phased kernel replaces config 7 wherever K is a whole number of k-tile pairs
-    if (!w_kmajor && big && !(res && K <= 1024)) {
-      // Tile-round quantisation decides between the persistent 256x256 kernel (one workgroup per CU, ~8 % faster per tile pair when
-      // the chip is full) and the 128x128 kernel (two per CU): e.g. fc2 of a single clip is 86 x 3 = 258 big tiles = TWO rounds of
-      // 256 CUs at 50 % fill, but 1032 small tiles = 2.02 rounds of 512 slots.  Pick the better filled one (measured, M = 21,966 /
-      // 43,932: fc2 600 -> 803 / 766 -> 917 TFLOP/s; the 16-clip batch keeps the persistent kernel everywhere).
-      int n_cu = sf_cu_count("sf_gemm_bf16");
-      if (n_cu <= 0) n_cu = 256;
-      const double t7 = (double)((M + 255) / 256) * (double)((N + 255) / 256), t0 = (double)((M + 127) / 128) * (double)((N + 127) / 128);
-      const double r7 = (double)(int64_t)((t7 + n_cu - 1) / n_cu), r0 = (double)(int64_t)((t0 + 2 * n_cu - 1) / (2 * n_cu));
-      const double e7 = t7 / (r7 * n_cu), e0 = t0 / (r0 * 2 * n_cu);
-      cfg = (e7 * (pp ? 1.20 : 1.08) >= e0) ? 7 : 0;             // (config 11 is another ~12 % ahead of config 7 per filled round: tools/bench_gemm.py 14 28 56)
-    }
-    if (cfg == 7 && pp) cfg = 11;
+    cfg = gemm_auto_config(M, N, K, fast, res, w_kmajor, sf_gemm_pp_supported(a));
+    SF_CHECK_ARG(cfg >= 0, "sf_gemm_bf16: a k-tile-major weight needs the persistent kernel (identity maps, N %% 64 == 0, M >= 8192, N >= 512)");
   }
   if (w_kmajor && cfg != 7 && cfg != 11) { sf_set_error("sf_gemm_bf16: only the persistent kernels (configs 7, 11) read a k-tile-major weight (forced config %d)", cfg); return -1; }
   switch (cfg) {
@@ -882,6 +892,14 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
             return dispatch_gemm_w4(a, obf, gelu, res, s);
     default: sf_set_error("sf_gemm_bf16: unknown tile config %d", cfg); return -1;
   }
+}
+
+// Which tile configuration the automatic choice takes for a row-major, identity-mapped, 16-byte aligned GEMM of this shape (bench.py files its launch timings under
+// the kernel symbol rocprofv3 will report): 0 = 128 x 128, 7 / 11 = persistent 256 x 256 (round-2 / quadrant-phased schedule).
+extern "C" int sf_gemm_bf16_auto_config(int64_t M, int64_t N, int64_t K, int has_residual) {
+  GemmArgs a;
+  a.lda = K; a.ldw = K; a.K = (int)K;
+  return gemm_auto_config(M, N, K, (N % 64) == 0, has_residual != 0, false, sf_gemm_pp_supported(a));
 }
 
 // Strided-batched small GEMM: for b0 < batch_outer, b1 < batch_inner

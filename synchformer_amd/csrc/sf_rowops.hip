@@ -80,6 +80,67 @@ extern "C" int sf_layernorm768(const float* x, int64_t ldx, const int64_t* in_ma
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Residual add with a per-sequence branch scale (stochastic depth), fused with the LayerNorm that reads the sum next (Stage-1 towers, forward):
+//     x[r, :] = residual[r, :] + seq_scale[r / seq_rows] * branch[r, :]        (fp32)
+//     y[r, :] = bf16( LayerNorm(x[r, :]) * gamma + beta )
+// `x = x + drop_path(branch)` followed by the next sub-layer's norm (vit_helper.py:364-376).  Was sf_scale_seq_add -> sf_layernorm768: the second launch
+// re-read the sum it had just been written.  One wave per row, as layernorm768_kernel; a dropped branch (scale 0) is not read.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add_scale_ln768_kernel(const float* __restrict__ br, int64_t ldb, const float* __restrict__ seq_scale, int64_t seq_rows,
+                                                               const float* __restrict__ res, int64_t ldr, float* __restrict__ x, int64_t ldx,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                               int64_t ldy, int64_t rows, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float sc = seq_scale ? seq_scale[r / seq_rows] : 1.f;
+  float4 v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const float4*>(res + r * ldr + i * 256 + lane * 4);
+  if (sc != 0.f) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float4 b = *reinterpret_cast<const float4*>(br + r * ldb + i * 256 + lane * 4);
+      v[i].x += sc * b.x; v[i].y += sc * b.y; v[i].z += sc * b.z; v[i].w += sc * b.w;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) *reinterpret_cast<float4*>(x + r * ldx + i * 256 + lane * 4) = v[i];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum(s) * (1.0f / D_MODEL);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+    q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / D_MODEL) + eps);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * 256 + lane * 4;
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 b = *reinterpret_cast<const float4*>(beta + c);
+    uint2 p;
+    p.x = pack_bf2(v[i].x * rstd * g.x + b.x, v[i].y * rstd * g.y + b.y);
+    p.y = pack_bf2(v[i].z * rstd * g.z + b.z, v[i].w * rstd * g.w + b.w);
+    *reinterpret_cast<uint2*>(y + r * ldy + c) = p;
+  }
+}
+
+extern "C" int sf_add_scale_ln768(const float* branch, int64_t ldb, const float* seq_scale, int64_t seq_rows, const float* residual, int64_t ldr, float* x,
+                                  int64_t ldx, const float* gamma, const float* beta, uint16_t* y, int64_t ldy, int64_t rows, float eps, void* stream) {
+  SF_CHECK_ARG(branch && residual && x && gamma && beta && y && (!seq_scale || seq_rows >= 1), "sf_add_scale_ln768: bad arguments");
+  SF_CHECK_ARG((ldb % 4) == 0 && (ldr % 4) == 0 && (ldx % 4) == 0 && (ldy % 4) == 0, "sf_add_scale_ln768: row strides must be multiples of 4 elements");
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(add_scale_ln768_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, branch, ldb, seq_scale, seq_rows, residual, ldr,
+                     x, ldx, gamma, beta, y, ldy, rows, eps);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // LayerNorm(768) whose output leaves as MXFP8 (OCP e4m3 + one E8M0 scale per 32 columns, stage-major scale planes - see sf_quantize_mxfp8): the
 // A operand of the next MX GEMM, written directly instead of bf16 + a separate quantisation pass (fp8 towers of the synchronizability fine-tune).
 // One wave per row; lane l holds columns i*256 + 4 l .. + 3 (i < 3): a 32-column block is 8 consecutive lanes of one i.

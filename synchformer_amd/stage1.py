@@ -77,6 +77,7 @@ class AVCLIPTrainer(FlatTrainer):
         self.fused_attn_bwd = True          # False: the gathered batched-GEMM attention backward (kept as a cross-check)
         self.two_streams = os.environ.get('SF_STAGE1_TWO_STREAMS', '1') != '0'   # audio tower next to the visual one (forward_backward)
         self._side = None
+        self._pre_ln = set()                # workspace buffers whose LayerNorm output _add_branch has already produced (consumed by _ln_into)
         self.n_vblocks = len([k for k in keys if k.startswith(V + '.blocks.') and k.endswith('.norm1.weight')])
         self.n_alayers = len([k for k in keys if k.endswith('.layernorm_before.weight')])
 
@@ -134,11 +135,33 @@ class AVCLIPTrainer(FlatTrainer):
                                         rows, D, self.g[bias_key].data_ptr(), 0, ws.data_ptr(), _st()), 'sf_branch_grad')
         return dy_b
 
-    def _mlp_fwd(self, s, x_in, h_name, fc1, fc2, rows, eps_name, eps, tag, dp=None, seq_rows=0):
+    def _add_branch(self, br, dp, seq_rows, rows, x_res, out, next_ln=None):
+        """out = x_res + dp[segment] * br; with next_ln = (norm name, buffer name, eps) the LayerNorm that reads `out` next is computed in the same pass
+        (sf_add_scale_ln768) into that buffer, and the call site of that norm finds it done (_ln_into)."""
+        if next_ln is None:
+            return self._scale_seq(br, dp, seq_rows, rows, out, residual=x_res)
+        name, bufname, eps = next_ln
+        y = self._buf(bufname, (rows, D), torch.bfloat16)
+        g, b = self._ln(name)
+        _chk(_lib.load().sf_add_scale_ln768(br.data_ptr(), br.stride(0), dp.data_ptr(), seq_rows, x_res.data_ptr(), x_res.stride(0), out.data_ptr(), out.stride(0),
+                                            g.data_ptr(), b.data_ptr(), y.data_ptr(), y.stride(0), rows, eps, _st()), 'sf_add_scale_ln768')
+        self._pre_ln.add(self._ws_prefix + bufname)
+        return out
+
+    def _ln_into(self, x, name, bufname, rows, eps):
+        """LayerNorm `name` of x into the workspace buffer `bufname` (bf16) - unless _add_branch already produced it together with x."""
+        y = self._buf(bufname, (rows, D), torch.bfloat16)
+        key = self._ws_prefix + bufname
+        if key in self._pre_ln:
+            self._pre_ln.discard(key)
+        else:
+            ops.layernorm(x, *self._ln(name), y, eps)
+        return y
+
+    def _mlp_fwd(self, s, x_in, h_name, fc1, fc2, rows, eps_name, eps, tag, dp=None, seq_rows=0, next_ln=None):
         """h = LN(x_in); pre = fc1(h); act = gelu(pre); returns x_in + fc2(act) (x_in + dp[segment] * fc2(act) under stochastic depth).
-        Saves h, pre, act."""
-        s['h2'] = self._buf(f'{tag}_h2', (rows, D), torch.bfloat16)
-        ops.layernorm(x_in, *self._ln(eps_name), s['h2'], eps)
+        Saves h, pre, act.  next_ln: the norm that reads the result next (see _add_branch)."""
+        s['h2'] = self._ln_into(x_in, eps_name, f'{tag}_h2', rows, eps)
         s['pre'] = self._buf(f'{tag}_pre', (rows, FF), torch.bfloat16)
         ops.gemm(s['h2'], *self._wb(fc1), s['pre'])
         s['act'] = self._buf(f'{tag}_act', (rows, FF), torch.bfloat16)
@@ -149,7 +172,7 @@ class AVCLIPTrainer(FlatTrainer):
         else:
             br = self._buf('dp_branch', (rows, D), torch.float32)
             ops.gemm(s['act'], *self._wb(fc2), br)
-            self._scale_seq(br, dp, seq_rows, rows, out, residual=x_in)
+            self._add_branch(br, dp, seq_rows, rows, x_in, out, next_ln)
         return out
 
     def _mlp_bwd(self, s, dx, x_in, fc1, fc2, rows, ln_name, eps, dp=None, seq_rows=0):
@@ -303,8 +326,7 @@ class AVCLIPTrainer(FlatTrainer):
             p, t = f'{V}.blocks.{i}', f'v{i}'
             s = dict(x=x)
             for kind, ln, att, key in (('time', 'norm3', 'timeattn', 't'), ('space', 'norm1', 'attn', 's')):
-                s['h' + key] = self._buf(f'{t}_h{key}', (M, D), torch.bfloat16)
-                ops.layernorm(x, *self._ln(f'{p}.{ln}'), s['h' + key], EPS_VIS)
+                s['h' + key] = self._ln_into(x, f'{p}.{ln}', f'{t}_h{key}', M, EPS_VIS)
                 s['qkv' + key] = self._buf(f'{t}_qkv{key}', (M, 3 * D), torch.bfloat16)
                 ops.gemm(s['h' + key], *self._wb(f'{p}.{att}.qkv'), s['qkv' + key])
                 s['att' + key] = self._buf(f'{t}_att{key}', (M, D), torch.bfloat16)
@@ -316,10 +338,11 @@ class AVCLIPTrainer(FlatTrainer):
                 else:
                     br = self._buf('dp_branch', (M, D), torch.float32)
                     ops.gemm(s['att' + key], *self._wb(f'{p}.{att}.proj'), br)
-                    self._scale_seq(br, dp, VIS_L, M, xn, residual=x)
+                    self._add_branch(br, dp, VIS_L, M, x, xn, next_ln=(p + '.norm2', f'{t}_h2', EPS_VIS))
                 x = s['x' + key] = xn                                           # xt = after time attention, xs = after space attention
             s['dp_m'] = self._dp_scales(i, 1, n)
-            x = self._mlp_fwd(s, x, 'h2', p + '.mlp.fc1', p + '.mlp.fc2', M, p + '.norm2', EPS_VIS, t, dp=s['dp_m'], seq_rows=VIS_L)
+            nxt = (f'{V}.blocks.{i + 1}.norm3', f'v{i + 1}_ht', EPS_VIS) if i + 1 < self.n_vblocks else None     # the norm that opens the next block
+            x = self._mlp_fwd(s, x, 'h2', p + '.mlp.fc1', p + '.mlp.fc2', M, p + '.norm2', EPS_VIS, t, dp=s['dp_m'], seq_rows=VIS_L, next_ln=nxt)
             sv['blocks'].append(s)
         sv['x_last'] = x
         Z = self._buf('v_Z', (n * 8 * AGG_V, D), torch.float32)
