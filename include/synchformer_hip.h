@@ -62,6 +62,11 @@ int sf_gemm_bf16_batched(const uint16_t* A, int64_t lda, int64_t sA0, int64_t sA
  * all-ones fragment in the workgroups that already hold those dY columns; summed by sf_seqsum(bias_part, N, split, 1, N, ...). */
 int sf_gemm_tn_splitk(const uint16_t* dY, int64_t ldy, const uint16_t* X, int64_t ldx, float* part, float* bias_part, int64_t M, int64_t N,
                       int64_t K, int split, int64_t kc, void* stream);
+/* The same product on the quadrant-phased 256 x 256 x 64 schedule (sf_gemm_tn_pp.hip) for the big weight gradients: N % 256 == 0, K % 256 == 0, kc % 128 == 0,
+ * no empty chunk ((split - 1) * kc < M); rows beyond M contribute zero (buffer range check of the LDS-DMA).  bias_part: (split, N) fp32 or NULL - per-chunk
+ * column sums of dY (the bias gradient), summed by sf_seqsum(bias_part, N, split, 1, N, ...). */
+int sf_gemm_tn_pp(const uint16_t* dY, int64_t ldy, const uint16_t* X, int64_t ldx, float* part, float* bias_part, int64_t M, int64_t N, int64_t K, int split,
+                  int64_t kc, void* stream);
 
 /* Full-row projection fused with the residual add and the NEXT LayerNorm (N = 768 fixed):
  *   X[m,:] = A[m,:] W^T + bias + R[m,:]  (fp32; X may alias R),   Y[m,:] = LayerNorm(X[m,:]) * gamma + beta  (bf16; Y may alias A).

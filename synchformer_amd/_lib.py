@@ -23,6 +23,7 @@ SIGNATURES = {
     'sf_gemm_bf16': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i64, _ptr, _ptr, _i64, _ptr, _i32, _i64, _i64, _i64, _ptr],
     'sf_gemm_bf16_batched': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _ptr, _ptr, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _ptr],
     'sf_gemm_tn_splitk': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i32, _i64, _ptr],
+    'sf_gemm_tn_pp': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i32, _i64, _ptr],
     'sf_gemm_res_ln768': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _f32, _ptr, _i64, _i64, _i64, _ptr],
     'sf_quantize_mxfp8': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr],
     'sf_gemm_mxfp8': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i64, _ptr, _i64, _ptr, _i64, _i32, _i64, _i64, _i64, _ptr],

@@ -126,6 +126,8 @@ class FlatTrainer:
         self.step_count = 0
         self._ws_prefix = ''
         self.tn_wgrad = os.environ.get('SF_TN_WGRAD', '1') != '0'      # weight gradients straight from row-major operands (sf_gemm_tn_splitk)
+        self.tn_pp = os.environ.get('SF_TN_PP', '1') != '0'            # ... the big ones on the quadrant-phased 256 x 256 kernel (sf_gemm_tn_pp)
+        self.n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count if torch.cuda.is_available() else 256
         self.norm = torch.zeros(1, device=self.dev, dtype=torch.float32)
         self.loss = torch.zeros(1, device=self.dev, dtype=torch.float32)
         self._ws: Dict[str, torch.Tensor] = {}
@@ -207,6 +209,20 @@ class FlatTrainer:
         tn = self.tn_wgrad and N % 128 == 0 and K % 128 == 0 and M >= 512 and dy_b.stride(0) % 8 == 0 and x_b.stride(0) % 8 == 0
         split = _wgrad_split(tiles) if M >= 8192 else (max(1, min(_wgrad_split(tiles), m_pad // 128)) if tn else 1)   # short M: >= 128 rows per chunk
         kc = ((m_pad // split + 63) // 64) * 64
+        if tn and self.tn_pp and N % 256 == 0 and K % 256 == 0 and M >= 8192:
+            # the big weight gradients: quadrant-phased 256 x 256 kernel (sf_gemm_tn_pp), as many chunks as fill the chip once with 256 x 256 tiles
+            t256 = (N // 256) * (K // 256)
+            sp = max(1, self.n_cu // t256)
+            kc2 = ((M + sp - 1) // sp + 127) // 128 * 128
+            sp = (M + kc2 - 1) // kc2
+            part = self._buf('wgrad_part', (sp * N, K), torch.float32)
+            bpart = self._buf('bgrad_part', (sp, N), torch.float32) if dy_f32 is None and not bias_done else None
+            _chk(_lib.load().sf_gemm_tn_pp(dy_b.data_ptr(), dy_b.stride(0), x_b.data_ptr(), x_b.stride(0), part.data_ptr(),
+                                           bpart.data_ptr() if bpart is not None else None, M, N, K, sp, kc2, _st()), 'sf_gemm_tn_pp')
+            _chk(_lib.load().sf_seqsum(part.data_ptr(), K, sp, N, K, self.g[wkey].data_ptr(), 0, _st()), 'sf_seqsum')
+            if bpart is not None:
+                _chk(_lib.load().sf_seqsum(bpart.data_ptr(), N, sp, 1, N, self.g[bkey].data_ptr(), int(acc_bias), _st()), 'sf_seqsum')
+            return self._lin_dgrad(dy_b, M, N, K, wkey, need_dx, dx_out, tag, acc_dx, dx_dtype)
         if tn:
             # dW straight from the row-major gradient / saved input (ds_read_b64_tr_b16 operand reads): no transposed copies
             # the bias gradient (column sums of dY) rides in the same launch: per-chunk partials from an all-ones MFMA in the workgroups of column tile 0

@@ -115,6 +115,40 @@ def test_attention_cls_backward_matches_autograd(gpu):
     assert _rel(acc.float().cpu()[:, Dm:], want) < 1e-2
 
 
+@pytest.mark.parametrize('M,N,K,split,kc', [(1000, 256, 256, 4, 256), (43932, 768, 768, 27, 1664), (43932, 2304, 768, 9, 4992), (20000, 768, 3072, 10, 2048),
+                                            (130, 256, 512, 1, 256)])
+def test_tn_pp_weight_gradient_gemm(gpu, M, N, K, split, kc):
+    """sf_gemm_tn_pp (the weight-gradient product on the quadrant-phased 256 x 256 schedule): part[s] = dY[chunk s]^T X[chunk s] from the ROW-MAJOR operands;
+    ragged last chunk (token rows beyond M arrive as zeros from the buffer range check of the LDS-DMA), operands that are column slices of wider buffers.
+    Against fp64 torch on the same bf16 values, and bit-identical on repetition (race screen of the counted-wait schedule)."""
+    from synchformer_amd import _lib
+    g = torch.Generator().manual_seed(M + N)
+    dyw = torch.randn(M, N + 64, generator=g).bfloat16()
+    xw = torch.randn(M, K + 8, generator=g).bfloat16()
+    dy, x = dyw.to(gpu)[:, 64:], xw.to(gpu)[:, :K]
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(with_bias=True):
+        part = torch.full((split, N, K), float('nan'), device=gpu)
+        bpart = torch.full((split, N), float('nan'), device=gpu)
+        _lib.check(_lib.load().sf_gemm_tn_pp(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), part.data_ptr(), bpart.data_ptr() if with_bias else None,
+                                             M, N, K, split, kc, st), 'sf_gemm_tn_pp')
+        return part, bpart
+    part, bpart = run()
+    for rep in range(3):
+        p2, b2 = run()
+        assert torch.equal(p2, part) and torch.equal(b2, bpart), f'repetition {rep}'
+    assert torch.equal(run(False)[0], part)
+    # the bias-gradient partials of the same launch: per-chunk column sums of dY
+    ref_b = torch.stack([dyw[min(M, s_ * kc):min(M, (s_ + 1) * kc), 64:].double().sum(0) for s_ in range(split)])
+    torch.testing.assert_close(bpart.cpu().double(), ref_b, rtol=1e-4, atol=2e-3 * max(1.0, (kc / 1000) ** 0.5))
+    dyd, xd = dyw.to(gpu)[:, 64:].double(), xw.to(gpu)[:, :K].double()
+    for s_ in range(split):
+        lo, hi = min(M, s_ * kc), min(M, (s_ + 1) * kc)
+        ref = dyd[lo:hi].T @ xd[lo:hi]
+        torch.testing.assert_close(part[s_].double(), ref, rtol=1e-4, atol=2e-3 * max(1.0, ((hi - lo) / 1000) ** 0.5))
+
+
 @pytest.mark.parametrize('M,N,K,split,kc', [(1000, 128, 256, 4, 256), (4321, 768, 384, 7, 640), (200, 256, 128, 1, 256), (130, 128, 128, 3, 64)])
 def test_tn_splitk_weight_gradient_gemm(gpu, M, N, K, split, kc):
     """part[s] = dY[chunk s]^T X[chunk s] from the ROW-MAJOR operands (ds_read_b64_tr_b16 operand reads); ragged last chunk, chunks past M
