@@ -11,6 +11,7 @@
 //   * AST / sync-transformer / aggregator full self-attention: 1 group, n_tok = L, no extra key
 // The CLS query itself (attends to ALL rows of its sequence, vit_helper.py:126) is `sf_attention_cls`.
 #include "sf_common.h"
+#include <stdlib.h>
 #include "../../include/synchformer_hip.h"
 
 struct AttnArgs {
@@ -326,8 +327,8 @@ extern "C" int sf_attention_tiny_bwd(const bf16_t* q, const bf16_t* k, const bf1
 #define GB_LD 72                 // bf16 per LDS row: 64 + 8 pad (144 B: 8-byte aligned fragments, 36-dword stride)
 #define GB_ROWS 208
 #define GB_MAT (GB_ROWS * GB_LD * 2)                       // 29,952 B per staged matrix
-#define GB_WAVES 8                // two waves per SIMD: the fragment reads are dependent LDS round trips, a second wave hides them
-#define GB_LDS (4 * GB_MAT + GB_ROWS * 3 * 4 + GB_WAVES * 16 * GB_LD * 2)
+#define GB_WAVES 16               // one wave per query tile (pass 1) / key tile (pass 2) of the 13; four waves per SIMD hide the dependent LDS round trips of the fragment reads
+#define GB_LDS(WAVES) (4 * GB_MAT + GB_ROWS * 3 * 4 + (WAVES) * 16 * GB_LD * 2)
 
 __device__ __forceinline__ bf16x4 gb_row_frag(const bf16_t* X, int row, int k0) { return *reinterpret_cast<const bf16x4*>(X + row * GB_LD + k0); }
 // Column fragment X[row0 + 0..3][col0 + lr] of a row-major LDS matrix (lane = 16*lg + lr; row0 is the same for the 16 lanes of a group)
@@ -345,7 +346,8 @@ __device__ __forceinline__ bf16x4 gb_pack(const f32x4& v) {
   return r.f;
 }
 
-__global__ __launch_bounds__(GB_WAVES * 64) void attn_group_bwd_kernel(AttnBwdArgs p) {
+template <int GBW>
+__global__ __launch_bounds__(GBW * 64) void attn_group_bwd_kernel(AttnBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* Kr = reinterpret_cast<bf16_t*>(smem);
   bf16_t* Vr = Kr + GB_ROWS * GB_LD;
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(GB_WAVES * 64) void attn_group_bwd_kernel(AttnBwdAr
   auto tok_row = [&](int i) -> int64_t { return first + (int64_t)i * p.tok_stride; };
 
   // ---- stage K, V (key rows) and Q, dO (query rows): 208 rows x 8 chunks of 16 B each, zero beyond the valid rows -------------
-  for (int idx = tid; idx < GB_ROWS * 8; idx += GB_WAVES * 64) {
+  for (int idx = tid; idx < GB_ROWS * 8; idx += GBW * 64) {
     const int row = idx >> 3, ch = idx & 7;
     uint4 kk = make_uint4(0, 0, 0, 0), vv = kk, qq = kk, dd = kk;
     if (row < nk) {
@@ -394,58 +396,72 @@ __global__ __launch_bounds__(GB_WAVES * 64) void attn_group_bwd_kernel(AttnBwdAr
   bf16_t* myout = outl + wave * 16 * GB_LD;
 
   // ---- pass 1: per query tile - statistics and dQ.  Tiles are S^T: lane's query = qt*16 + lr, its keys = kt*16 + lg*4 + r ---------
-  for (int qt = wave; qt < nqt; qt += GB_WAVES) {
-    f32x4 sT[13], dpT[13];
+  for (int qt = wave; qt < nqt; qt += GBW) {
+    // Online softmax over the key tiles (running maximum, accumulators rescaled when it moves): no score or dP tile outlives its key tile, and
+    // dQ = scale / l * (sum_k e dP K - delta sum_k e K) is accumulated as those two sums (e = un-normalised probability) - 4 more MFMAs per key tile than
+    // forming dS first, but ~90 registers instead of 167, which is what lets 16 waves (every query / key tile its own wave) share the CU.
     bf16x4 qf[4], df[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { qf[ks] = gb_row_frag(Qr, qt * 16 + lr, ks * 16 + lg * 4); df[ks] = gb_row_frag(Dr, qt * 16 + lr, ks * 16 + lg * 4); }
-    float m = -INFINITY;
+    float m = -INFINITY, l = 0.f, delta = 0.f;                    // m is kept equal in the four lanes (lg) of a query column; l, delta are per-lane partials
+    f32x4 dq1[4], dq2[4];
 #pragma unroll
-    for (int kt = 0; kt < 13; ++kt) {
-      sT[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dpT[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (kt < nkt) {
+    for (int dt = 0; dt < 4; ++dt) { dq1[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dq2[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int kt = 0; kt < nkt; ++kt) {
+      f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          sT[kt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb_row_frag(Kr, kt * 16 + lr, ks * 16 + lg * 4), qf[ks], sT[kt], 0, 0, 0);
-          dpT[kt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb_row_frag(Vr, kt * 16 + lr, ks * 16 + lg * 4), df[ks], dpT[kt], 0, 0, 0);
-        }
+      for (int ks = 0; ks < 4; ++ks) {
+        sc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb_row_frag(Kr, kt * 16 + lr, ks * 16 + lg * 4), qf[ks], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb_row_frag(Vr, kt * 16 + lr, ks * 16 + lg * 4), df[ks], dp, 0, 0, 0);
       }
+      float tmax = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (kt * 16 + lg * 4 + r >= nk) sT[kt][r] = -INFINITY;
-        m = fmaxf(m, sT[kt][r]);
+        if (kt * 16 + lg * 4 + r >= nk) sc[r] = -INFINITY;
+        tmax = fmaxf(tmax, sc[r]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64)); tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m, tmax);                          // finite: key 0 of tile 0 always exists
+      if (__any(m_new != m)) {                                     // the running maximum of some query moved: rescale what has been summed under the old one
+        const float alpha = __builtin_amdgcn_exp2f((m - m_new) * sc2);   // first tile: exp2(-inf) = 0
+        l *= alpha; delta *= alpha;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                              // the accumulators hold query ROWS lg*4 + r: their factor sits in the lanes of that query column
+          const float ar = __shfl(alpha, lg * 4 + r, 64);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) { dq1[dt][r] *= ar; dq2[dt][r] *= ar; }
+        }
+        m = m_new;
+      }
+      const float msc_ = m * sc2;
+      f32x4 e, edp;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        e[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], sc2, -msc_));     // -inf -> 0
+        edp[r] = e[r] * dp[r];
+        l += e[r]; delta += edp[r];
+      }
+      const bf16x4 ef = gb_pack(e), edpf = gb_pack(edp);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x4 kc = gb_col_frag(Kr, kt * 16 + lg * 4, dt * 16, lr);
+        dq1[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(edpf, kc, dq1[dt], 0, 0, 0);
+        dq2[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ef, kc, dq2[dt], 0, 0, 0);
       }
     }
-    m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
     const float msc = m * sc2;
-    float l = 0.f, delta = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 13; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __builtin_amdgcn_exp2f(fmaf(sT[kt][r], sc2, -msc));      // -inf -> 0
-        sT[kt][r] = e; l += e; delta += e * dpT[kt][r];
-      }
     l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
     delta += __shfl_xor(delta, 16, 64); delta += __shfl_xor(delta, 32, 64);
     const float linv = 1.0f / l;
     delta *= linv;
     if (lg == 0) { float* st = stats + (qt * 16 + lr) * 3; st[0] = msc; st[1] = linv; st[2] = delta; }
-    // dS tiles (rows = query, k = key) and dQ = dS K
+    // l and delta belong to the lane's query COLUMN (qt*16 + lr); the dQ accumulators hold query ROWS lg*4 + r: fetch the row's values from its column lane
     f32x4 dq[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 4; ++r) {
+      const float lrow = __shfl(linv, lg * 4 + r, 64), drow = __shfl(delta, lg * 4 + r, 64);
 #pragma unroll
-    for (int kt = 0; kt < 13; ++kt) {
-      if (kt < nkt) {
-        f32x4 ds;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ds[r] = sT[kt][r] * linv * (dpT[kt][r] - delta) * p.scale;
-        const bf16x4 dsf = gb_pack(ds);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsf, gb_col_frag(Kr, kt * 16 + lg * 4, dt * 16, lr), dq[dt], 0, 0, 0);
-      }
+      for (int dt = 0; dt < 4; ++dt) dq[dt][r] = (dq1[dt][r] - drow * dq2[dt][r]) * (lrow * p.scale);
     }
     // dq[dt][r] = dQ[query qt*16 + lg*4 + r][d = dt*16 + lr] -> staging -> 16-byte row stores
 #pragma unroll
@@ -467,7 +483,7 @@ __global__ __launch_bounds__(GB_WAVES * 64) void attn_group_bwd_kernel(AttnBwdAr
   __syncthreads();                                             // statistics of every query are in LDS
 
   // ---- pass 2: per key tile - dK, dV.  Tiles are S: lane's key = kt*16 + lr, its queries = qt*16 + lg*4 + r ----------------------
-  for (int kt = wave; kt < nkt; kt += GB_WAVES) {
+  for (int kt = wave; kt < nkt; kt += GBW) {
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -535,10 +551,17 @@ extern "C" int sf_attention_group_bwd(const bf16_t* q, const bf16_t* k, const bf
   a.q = q; a.k = k; a.v = v; a.ld = ld; a.dO = dO; a.lddo = lddo; a.dq = dq; a.dk = dk; a.dv = dv; a.ldg = ldg; a.cls_part = cls_part;
   a.seq_rows = seq_rows; a.n_groups = n_groups; a.row0 = row0; a.group_stride = group_stride; a.tok_stride = tok_stride; a.n_tok = n_tok;
   a.cls_row = cls_row; a.heads = heads; a.scale = scale;
-  if (int rc = sf_prepare_kernel((const void*)attn_group_bwd_kernel, GB_LDS, "sf_attention_group_bwd")) return rc;
   const int64_t units = n_seq * n_groups * heads;
   SF_CHECK_ARG(units < ((int64_t)1 << 31), "sf_attention_group_bwd: too many groups");
-  hipLaunchKernelGGL(attn_group_bwd_kernel, dim3((unsigned)units), dim3(GB_WAVES * 64), GB_LDS, (hipStream_t)stream, a);
+  static int waves = -1;
+  if (waves < 0) { const char* e = getenv("SF_GB_WAVES"); waves = e ? atoi(e) : GB_WAVES; }      // measurement hook: 8 = round 2's workgroup (two tiles per wave)
+  if (waves == 8) {
+    if (int rc = sf_prepare_kernel((const void*)attn_group_bwd_kernel<8>, GB_LDS(8), "sf_attention_group_bwd")) return rc;
+    hipLaunchKernelGGL(attn_group_bwd_kernel<8>, dim3((unsigned)units), dim3(8 * 64), GB_LDS(8), (hipStream_t)stream, a);
+  } else {
+    if (int rc = sf_prepare_kernel((const void*)attn_group_bwd_kernel<GB_WAVES>, GB_LDS(GB_WAVES), "sf_attention_group_bwd")) return rc;
+    hipLaunchKernelGGL(attn_group_bwd_kernel<GB_WAVES>, dim3((unsigned)units), dim3(GB_WAVES * 64), GB_LDS(GB_WAVES), (hipStream_t)stream, a);
+  }
   SF_LAUNCH_CHECK();
   return 0;
 }
