@@ -67,6 +67,9 @@ int sf_gemm_tn_splitk(const uint16_t* dY, int64_t ldy, const uint16_t* X, int64_
  * column sums of dY (the bias gradient), summed by sf_seqsum(bias_part, N, split, 1, N, ...). */
 int sf_gemm_tn_pp(const uint16_t* dY, int64_t ldy, const uint16_t* X, int64_t ldx, float* part, float* bias_part, int64_t M, int64_t N, int64_t K, int split,
                   int64_t kc, void* stream);
+/* dW = sum over the `split` chunk planes of `part` (n_w = N * K floats each) and, in the same launch, db (=|+=) the sum of the `split` rows of bias_part (n_b = N
+ * floats each; bias_part may be NULL): the reduction behind sf_gemm_tn_splitk / sf_gemm_tn_pp.  n_w % 4 == 0, n_b % 4 == 0, 16-byte aligned. */
+int sf_wgrad_sum(const float* part, int64_t n_w, int split, float* dw, const float* bias_part, int64_t n_b, float* db, int accumulate_bias, void* stream);
 
 /* Full-row projection fused with the residual add and the NEXT LayerNorm (N = 768 fixed):
  *   X[m,:] = A[m,:] W^T + bias + R[m,:]  (fp32; X may alias R),   Y[m,:] = LayerNorm(X[m,:]) * gamma + beta  (bf16; Y may alias A).

@@ -50,6 +50,7 @@ SIGNATURES = {
     'sf_layernorm768_bwd_bf16': [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i32, _ptr, _ptr, _i32, _ptr, _i64, _f32, _ptr],
     'sf_colsum': [_ptr, _i32, _i64, _i64, _i32, _ptr, _i32, _ptr, _ptr],
     'sf_seqsum': [_ptr, _i64, _i32, _i32, _i32, _ptr, _i32, _ptr],
+    'sf_wgrad_sum': [_ptr, _i64, _i32, _ptr, _ptr, _i64, _ptr, _i32, _ptr],
     'sf_gelu_fwd': [_ptr, _ptr, _i64, _ptr],
     'sf_gelu_bwd': [_ptr, _ptr, _ptr, _i64, _ptr],
     'sf_gelu_bwd_bf16': [_ptr, _ptr, _ptr, _i64, _ptr],

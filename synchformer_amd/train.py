@@ -219,9 +219,7 @@ class FlatTrainer:
             bpart = self._buf('bgrad_part', (sp, N), torch.float32) if dy_f32 is None and not bias_done else None
             _chk(_lib.load().sf_gemm_tn_pp(dy_b.data_ptr(), dy_b.stride(0), x_b.data_ptr(), x_b.stride(0), part.data_ptr(),
                                            bpart.data_ptr() if bpart is not None else None, M, N, K, sp, kc2, _st()), 'sf_gemm_tn_pp')
-            _chk(_lib.load().sf_seqsum(part.data_ptr(), K, sp, N, K, self.g[wkey].data_ptr(), 0, _st()), 'sf_seqsum')
-            if bpart is not None:
-                _chk(_lib.load().sf_seqsum(bpart.data_ptr(), N, sp, 1, N, self.g[bkey].data_ptr(), int(acc_bias), _st()), 'sf_seqsum')
+            self._wgrad_sum(part, bpart, sp, N, K, wkey, bkey, acc_bias)
             return self._lin_dgrad(dy_b, M, N, K, wkey, need_dx, dx_out, tag, acc_dx, dx_dtype)
         if tn:
             # dW straight from the row-major gradient / saved input (ds_read_b64_tr_b16 operand reads): no transposed copies
@@ -230,9 +228,7 @@ class FlatTrainer:
             bpart = self._buf('bgrad_part', (split, N), torch.float32) if dy_f32 is None and not bias_done else None
             _chk(_lib.load().sf_gemm_tn_splitk(dy_b.data_ptr(), dy_b.stride(0), x_b.data_ptr(), x_b.stride(0), part.data_ptr(),
                                                bpart.data_ptr() if bpart is not None else None, M, N, K, split, kc, _st()), 'sf_gemm_tn_splitk')
-            _chk(_lib.load().sf_seqsum(part.data_ptr(), K, split, N, K, self.g[wkey].data_ptr(), 0, _st()), 'sf_seqsum')
-            if bpart is not None:
-                _chk(_lib.load().sf_seqsum(bpart.data_ptr(), N, split, 1, N, self.g[bkey].data_ptr(), int(acc_bias), _st()), 'sf_seqsum')
+            self._wgrad_sum(part, bpart, split, N, K, wkey, bkey, acc_bias)
             return self._lin_dgrad(dy_b, M, N, K, wkey, need_dx, dx_out, tag, acc_dx, dx_dtype)
         m_pad = kc * split if split > 1 else m_pad
         dyT = self._buf('dyT', (N, m_pad), torch.bfloat16)
@@ -248,6 +244,17 @@ class FlatTrainer:
         else:
             ops.gemm(dyT, xT, None, self.g[wkey].view(N, K), M=N)
         return self._lin_dgrad(dy_b, M, N, K, wkey, need_dx, dx_out, tag, acc_dx, dx_dtype)
+
+    def _wgrad_sum(self, part, bpart, split, N, K, wkey, bkey, acc_bias):
+        """g[W] = sum of the split-K chunk planes, g[b] (=|+=) sum of the bias partials - one launch (sf_wgrad_sum)."""
+        gw = self.g[wkey]
+        if N % 4 == 0 and gw.data_ptr() % 16 == 0 and (bpart is None or self.g[bkey].data_ptr() % 16 == 0):
+            _chk(_lib.load().sf_wgrad_sum(part.data_ptr(), N * K, split, gw.data_ptr(), bpart.data_ptr() if bpart is not None else None, N,
+                                          self.g[bkey].data_ptr() if bpart is not None else None, int(acc_bias), _st()), 'sf_wgrad_sum')
+            return
+        _chk(_lib.load().sf_seqsum(part.data_ptr(), K, split, N, K, gw.data_ptr(), 0, _st()), 'sf_seqsum')       # (a gradient slot that is not 16-byte aligned)
+        if bpart is not None:
+            _chk(_lib.load().sf_seqsum(bpart.data_ptr(), N, split, 1, N, self.g[bkey].data_ptr(), int(acc_bias), _st()), 'sf_seqsum')
 
     def _lin_dgrad(self, dy_b, M, N, K, wkey, need_dx, dx_out, tag, acc_dx, dx_dtype=torch.float32):
         if not need_dx:
