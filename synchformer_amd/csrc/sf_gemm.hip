@@ -894,6 +894,27 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
   }
 }
 
+// fc1 of a TRAINED MLP in one launch: pre = A W^T + bias (bf16) AND act = gelu(pre) (bf16), both kept for the backward (was sf_gemm_bf16 -> sf_gelu_fwd).
+// Config 11 only: K % 128 == 0, K >= 256, N % 64 == 0, 16-byte aligned rows, outputs below 4 GiB; returns 1 (nothing launched) when the shape is outside
+// that range, so the caller can take the two-launch path.
+extern "C" int sf_gemm_bf16_gelu_dual(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, bf16_t* pre, bf16_t* act, int64_t ldc,
+                                      int64_t M, int64_t N, int64_t K, void* stream) {
+  SF_CHECK_ARG(A && W && pre && act, "sf_gemm_bf16_gelu_dual: null pointer");
+  if (M <= 0 || N <= 0) return 0;
+  const int64_t m_pad = ((M + 255) / 256) * 256;
+  const bool ok = K > 0 && (K % 128) == 0 && K >= 256 && (N % 64) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && (ldc % 4) == 0 && ((uintptr_t)A % 16) == 0 &&
+                  ((uintptr_t)W % 16) == 0 && ((uintptr_t)pre % 16) == 0 && ((uintptr_t)act % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0) &&
+                  m_pad * ldc * 2 < ((int64_t)1 << 32) && M >= 256 && N >= 256 && M < ((int64_t)1 << 31) && N < ((int64_t)1 << 31);
+  GemmArgs a;
+  a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.C = act; a.C2 = pre; a.ldc = ldc; a.R = nullptr; a.ldr = 0;
+  a.cmap = sf_rowmap(nullptr); a.rmap = sf_rowmap(nullptr);
+  a.M = M; a.N = (int)N; a.K = (int)K;
+  a.tiles_n = 0; a.tiles_total = 0; a.nchunk = 0; a.wk = 64;
+  a.batch_inner = 0; a.sA0 = a.sA1 = a.sW0 = a.sW1 = a.sC0 = a.sC1 = 0;
+  if (!ok || !sf_gemm_pp_supported(a)) return 1;
+  return sf_gemm_pp_dispatch(a, true, true, false, (hipStream_t)stream);
+}
+
 // Which tile configuration the automatic choice takes for a row-major, identity-mapped, 16-byte aligned GEMM of this shape (bench.py files its launch timings under
 // the kernel symbol rocprofv3 will report): 0 = 128 x 128, 7 / 11 = persistent 256 x 256 (round-2 / quadrant-phased schedule).
 extern "C" int sf_gemm_bf16_auto_config(int64_t M, int64_t N, int64_t K, int has_residual) {

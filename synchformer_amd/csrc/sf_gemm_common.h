@@ -15,6 +15,7 @@ struct GemmArgs {
   const bf16_t* W; int64_t ldw;
   const float* bias;
   void* C; int64_t ldc;
+  void* C2 = nullptr;  // config 11, GELU epilogue: also write the pre-activation here (same dtype and row stride as C)
   const float* R; int64_t ldr;
   RowMap cmap, rmap;
   int64_t M;

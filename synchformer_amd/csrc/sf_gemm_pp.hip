@@ -92,10 +92,13 @@ __device__ unsigned long long g_pp_trace[256 * 8 * 5];
 #define PP_T(var) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); var = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
 #endif
 
-template <bool OUT_BF16, bool GELU, bool HAS_RES>
+// DUAL (with GELU, bf16 output, no residual): the pre-activation goes to p.C2 as well - the forward of a TRAINED MLP keeps both (fc1 of the Stage-1 towers:
+// the backward needs gelu'(pre), fc2 reads gelu(pre)); was sf_gemm_bf16 -> sf_gelu_fwd, a second pass over the (rows, 3072) activations.
+template <bool OUT_BF16, bool GELU, bool HAS_RES, bool DUAL = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   constexpr bool WIDE = OUT_BF16 && !HAS_RES;                    // transposed accumulator blocks + 16-byte row stores (as config 7)
-  constexpr int EPI_STORES = WIDE ? 16 : 32;                     // buffer stores per wave and epilogue
+  static_assert(!DUAL || (WIDE && GELU), "DUAL is the bf16 GELU epilogue with a second output");
+  constexpr int EPI_STORES = WIDE ? (DUAL ? 32 : 16) : 32;       // buffer stores per wave and epilogue
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   const uint32_t esz = OUT_BF16 ? 2u : 4u;
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, (short)0, (int)(uint32_t)(p.M * p.ldc * esz), 0x00020000);
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), (short)0, HAS_RES ? (int)(uint32_t)(p.M * p.ldr * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc(DUAL ? p.C2 : p.C, (short)0, DUAL ? (int)(uint32_t)(p.M * p.ldc * esz) : 0, 0x00020000);
   const uint32_t cstep = (uint32_t)(4 * p.ldc) * esz, rstep = (uint32_t)(4 * p.ldr) * 4u;
   const bool has_bias = p.bias != nullptr;
   // WIDE: the wave's 64 bias values travel by one LDS-DMA piece into the (idle) epilogue slab at the top of the tile - no
@@ -375,6 +379,26 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
         const uint32_t cbase = (uint32_t)((em0 + wm * 128 + tr0) * p.ldc + colbase + ch * 8) * 2u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+          if (DUAL) {                                            // the pre-activation first: same slab round trip, stores to C2
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                u32x2 w;
+                w.x = pack_bf2(acc[i][j][g * 4 + 0] + bia[j][g].x, acc[i][j][g * 4 + 1] + bia[j][g].y);
+                w.y = pack_bf2(acc[i][j][g * 4 + 2] + bia[j][g].z, acc[i][j][g * 4 + 3] + bia[j][g].w);
+                *reinterpret_cast<u32x2*>(bslab + wr_off + (((j * 4 + g) ^ sw7) << 4)) = w;
+              }
+            PP_WAVE_SYNC();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const u32x4 v = *reinterpret_cast<const u32x4*>(bslab + rd_off + q * 8 * 128);
+              u32x4 o;
+              if (q & 1) { o.x = v.z; o.y = v.w; o.z = v.x; o.w = v.y; } else { o = v; }
+              __builtin_amdgcn_raw_buffer_store_b128(o, rc2, cbase + (uint32_t)((i * 32 + q * 8) * p.ldc) * 2u, 0, SF_EPI_STORE_AUX);
+            }
+            PP_WAVE_SYNC();
+          }
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -445,9 +469,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   }
 }
 
-template <bool OUT_BF16, bool GELU, bool HAS_RES>
+template <bool OUT_BF16, bool GELU, bool HAS_RES, bool DUAL = false>
 static int launch_gemm_pp(GemmArgs a, hipStream_t s) {
-  auto kern = gemm_bf16_pp_kernel<OUT_BF16, GELU, HAS_RES>;
+  auto kern = gemm_bf16_pp_kernel<OUT_BF16, GELU, HAS_RES, DUAL>;
   if (int rc = sf_prepare_kernel((const void*)kern, Q_LDS, "sf_gemm_bf16")) return rc;
   const int n_cus = sf_cu_count("sf_gemm_bf16");
   if (n_cus <= 0) return -1;
@@ -493,6 +517,10 @@ bool sf_gemm_pp_supported(const GemmArgs& a) {
 }
 
 int sf_gemm_pp_dispatch(const GemmArgs& a, bool out_bf16, bool gelu, bool res, hipStream_t s) {
+  if (a.C2) {
+    if (!(out_bf16 && gelu && !res)) { sf_set_error("sf_gemm_bf16: a second (pre-activation) output needs the bf16 GELU epilogue without residual"); return -1; }
+    return launch_gemm_pp<true, true, false, true>(a, s);
+  }
   if (out_bf16) {
     if (gelu) return res ? launch_gemm_pp<true, true, true>(a, s) : launch_gemm_pp<true, true, false>(a, s);
     return res ? launch_gemm_pp<true, false, true>(a, s) : launch_gemm_pp<true, false, false>(a, s);

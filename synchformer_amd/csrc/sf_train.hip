@@ -290,8 +290,9 @@ __global__ __launch_bounds__(256) void layernorm768_bwd_kernel(const float* __re
 }
 
 // out[c] (=|+=) sum_p part[p * stride + c], c < cols  (second stage of the two-stage column reductions)
+// out2 != NULL: columns >= cols_split go to out2[c - cols_split] (the dgamma | dbeta pair of the LayerNorm backward in one launch)
 __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __restrict__ part, int64_t n_part, int64_t stride, float* __restrict__ out,
-                                                                int cols, int accumulate) {
+                                                                int cols, int accumulate, float* __restrict__ out2 = nullptr, int cols_split = 0) {
   // 64 columns x 16 interleaved row lanes per workgroup, four independent partial sums per thread: enough loads in flight that the
   // second stage of the column reductions is not a chain of dependent L2 round trips (it was 9 % of the Stage-1 train step)
   __shared__ float red[16][64];
@@ -314,7 +315,8 @@ __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __re
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += red[i][cl];
-    out[c] = accumulate ? out[c] + s : s;
+    float* o = (out2 && c >= cols_split) ? out2 + (c - cols_split) : out + c;
+    *o = accumulate ? *o + s : s;
   }
 }
 
@@ -331,8 +333,7 @@ static int layernorm768_bwd_impl(const float* x, int64_t ldx, const int64_t* x_m
   else hipLaunchKernelGGL(layernorm768_bwd_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, x, ldx, sf_rowmap(x_map), gamma, dy, lddy,
                           sf_rowmap(dy_map), dx, lddx, sf_rowmap(dx_map), accumulate_dx, workspace, rows, eps, rpw);
   SF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3(12), dim3(1024), 0, s, workspace, nblk, (int64_t)2 * 768, dgamma, 768, accumulate_dparams);
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3(12), dim3(1024), 0, s, workspace + 768, nblk, (int64_t)2 * 768, dbeta, 768, accumulate_dparams);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(24), dim3(1024), 0, s, workspace, nblk, (int64_t)2 * 768, dgamma, 2 * 768, accumulate_dparams, dbeta, 768);
   SF_LAUNCH_CHECK();
   return 0;
 }

@@ -163,9 +163,16 @@ class AVCLIPTrainer(FlatTrainer):
         Saves h, pre, act.  next_ln: the norm that reads the result next (see _add_branch)."""
         s['h2'] = self._ln_into(x_in, eps_name, f'{tag}_h2', rows, eps)
         s['pre'] = self._buf(f'{tag}_pre', (rows, FF), torch.bfloat16)
-        ops.gemm(s['h2'], *self._wb(fc1), s['pre'])
         s['act'] = self._buf(f'{tag}_act', (rows, FF), torch.bfloat16)
-        self._gelu_fwd(s['pre'], s['act'])
+        w1, b1 = self._wb(fc1)
+        # fc1 + GELU with both the pre-activation and the activation kept, in one launch where the quadrant-phased kernel applies (the big visual MLPs)
+        rc = 1 if rows < 8192 else _lib.load().sf_gemm_bf16_gelu_dual(s['h2'].data_ptr(), s['h2'].stride(0), w1.data_ptr(), w1.stride(0), b1.data_ptr(),
+                                                                       s['pre'].data_ptr(), s['act'].data_ptr(), FF, rows, FF, D, _st())
+        if rc == 1:
+            ops.gemm(s['h2'], w1, b1, s['pre'])
+            self._gelu_fwd(s['pre'], s['act'])
+        else:
+            _chk(rc, 'sf_gemm_bf16_gelu_dual')
         out = self._buf(f'{tag}_xo', (rows, D), torch.float32)
         if dp is None:
             ops.gemm(s['act'], *self._wb(fc2), out, residual=x_in)

@@ -717,6 +717,31 @@ def test_gemm_pp_bitwise_equals_config7(gpu, M, N, K, gelu, res):
         assert torch.equal(run(11, True), ref), 'k-tile-major weight'
 
 
+def test_gemm_gelu_dual(gpu):
+    """sf_gemm_bf16_gelu_dual (fc1 of a trained MLP: pre-activation AND gelu(pre) from one launch of config 11): the pre-activation is bit-identical to
+    sf_gemm_bf16's bf16 output on config 11, the activation to its GELU epilogue; shapes outside config 11's range return 1 without launching."""
+    from synchformer_amd import ops, _lib
+    lib = _lib.load()
+    M, N, K = 256 * 37 + 19, 3072, 768
+    a, w, b = _bf(_rand(M, K, seed=70)).to(gpu), _bf(_rand(N, K, seed=71, scale=0.05)).to(gpu), _rand(N, seed=72).to(gpu)
+    st = torch.cuda.current_stream().cuda_stream
+    pre, act = torch.full((M + 2, N), 3.0, device=gpu, dtype=torch.bfloat16), torch.full((M + 2, N), 5.0, device=gpu, dtype=torch.bfloat16)
+    rc = lib.sf_gemm_bf16_gelu_dual(a.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), pre.data_ptr(), act.data_ptr(), N, M, N, K, st)
+    assert rc == 0
+    lib.sf_gemm_force_config(11)
+    try:
+        p0, a0 = torch.empty(M, N, device=gpu, dtype=torch.bfloat16), torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+        ops.gemm(a, w, b, p0)
+        ops.gemm(a, w, b, a0, gelu=True)
+    finally:
+        lib.sf_gemm_force_config(-1)
+    assert torch.equal(pre[:M], p0) and torch.equal(act[:M], a0)
+    assert (pre[M:] == 3.0).all() and (act[M:] == 5.0).all(), 'rows beyond M were written'
+    ref = a.float() @ w.float().t() + b
+    torch.testing.assert_close(act[:M].float(), torch.nn.functional.gelu(ref), rtol=1e-2, atol=2e-2)
+    assert lib.sf_gemm_bf16_gelu_dual(a.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), pre.data_ptr(), act.data_ptr(), N, M, N, 192, st) == 1     # K % 128 != 0
+
+
 def test_gemm_ktile_major_weight(gpu):
     """sf_gemm_bf16 with the weight given k-tile-major ((K/64, N, 64), ldw == 64): the same products in the same order as the row-major weight."""
     from synchformer_amd import ops
