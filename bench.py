@@ -162,11 +162,46 @@ class GemmTimer:
                              2.0 * m * n * k, nbytes, 'qkv_time_attn_kernel<true>', 'N=2304 K=768')
 
         ops.gemm, ops.gemm_res_ln, ops.gemm_mxfp8, ops.gemm_mx_res_ln, ops.qkv_time_attention = timed, timed_ln, timed_mx, timed_mxln, timed_qt
+        # the train steps call three GEMM entry points straight on the C ABI (weight gradients, fc1 + GELU with two outputs): wrap those on the library object
+        from synchformer_amd import _lib
+        lib = self.lib = _lib.load()
+        self.lib_orig = {n: getattr(lib, n) for n in ('sf_gemm_tn_pp', 'sf_gemm_tn_splitk', 'sf_gemm_bf16_gelu_dual')}
+        lo = self.lib_orig
+
+        def tn_pp(dy, ldy, x, ldx, part, bpart, M, N, K, split, kc, st):
+            if not self.enabled:
+                return lo['sf_gemm_tn_pp'](dy, ldy, x, ldx, part, bpart, M, N, K, split, kc, st)
+            return self._rec(lambda: lo['sf_gemm_tn_pp'](dy, ldy, x, ldx, part, bpart, M, N, K, split, kc, st), 2.0 * M * N * K, M * (N + K) * 2 + split * N * K * 4,
+                             'gemm_tn_pp_kernel', f'N={N} K={K}')
+
+        def tn_splitk(dy, ldy, x, ldx, part, bpart, M, N, K, split, kc, st):
+            if not self.enabled:
+                return lo['sf_gemm_tn_splitk'](dy, ldy, x, ldx, part, bpart, M, N, K, split, kc, st)
+            return self._rec(lambda: lo['sf_gemm_tn_splitk'](dy, ldy, x, ldx, part, bpart, M, N, K, split, kc, st), 2.0 * M * N * K,
+                             M * (N + K) * 2 + split * N * K * 4, 'gemm_tn_splitk_kernel', f'N={N} K={K}')
+
+        def gelu_dual(a, lda, w, ldw, bias, pre, act, ldc, M, N, K, st):
+            if not self.enabled:
+                return lo['sf_gemm_bf16_gelu_dual'](a, lda, w, ldw, bias, pre, act, ldc, M, N, K, st)
+            box = {}
+
+            def run():
+                box['rc'] = lo['sf_gemm_bf16_gelu_dual'](a, lda, w, ldw, bias, pre, act, ldc, M, N, K, st)
+                return box['rc']
+            n0 = len(self.records)
+            rc = self._rec(run, 2.0 * M * N * K, M * K * 2 + N * K * 2 + 2 * M * N * 2, 'gemm_bf16_pp_kernel<true, true, false, true>', f'N={N} K={K}')
+            if rc == 1:                                                # outside config 11's range: nothing was launched (the caller takes the two-launch path)
+                del self.records[n0:]
+            return rc
+
+        lib.sf_gemm_tn_pp, lib.sf_gemm_tn_splitk, lib.sf_gemm_bf16_gelu_dual = tn_pp, tn_splitk, gelu_dual
         return self
 
     def __exit__(self, *a):
         for k, v in self.orig.items():
             setattr(self.ops, k, v)
+        for k, v in self.lib_orig.items():
+            setattr(self.lib, k, v)
 
     def kernels(self, steps):
         """Per kernel symbol (and per shape inside it): launches per step, average duration, TFLOP/s, fraction of the roofline that bounds it."""

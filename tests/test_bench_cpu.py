@@ -15,3 +15,9 @@ def test_gemm_timer_wrappers_accept_the_ops_keywords():
             missing = [k for k, p in po.items() if p.kind == inspect.Parameter.KEYWORD_ONLY and k not in pw]
             assert has_kw or not missing, f'bench.GemmTimer wrapper of ops.{name} does not accept {missing}'
     assert ops.gemm is gt.orig['gemm']
+    # ... and the three GEMM entry points the train steps call straight on the C ABI are wrapped on the library object and put back
+    from synchformer_amd import _lib
+    lib = _lib.load()
+    for name in ('sf_gemm_tn_pp', 'sf_gemm_tn_splitk', 'sf_gemm_bf16_gelu_dual'):
+        assert getattr(lib, name) is gt.lib_orig[name]
+        assert len(inspect.signature(gt.lib_orig[name].__call__).parameters) >= 0
