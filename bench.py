@@ -112,7 +112,7 @@ class GemmTimer:
 
     def __enter__(self):
         ops = self.ops
-        self.orig = {k: getattr(ops, k) for k in ('gemm', 'gemm_res_ln', 'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention')}
+        self.orig = {k: getattr(ops, k) for k in ('gemm', 'gemm_res_ln', 'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention', 'qkv_time_attention_mx')}
         o = self.orig
 
         def timed(a, w, bias, out, *, M=None, **kw):
@@ -159,9 +159,18 @@ class GemmTimer:
             m, n, k = n_seq * 8 * n_groups, 2304, 768
             nbytes = m * k * 2 + n * k * 2 + m * 768 * 2                               # A + W read, the 768-wide attention output written
             return self._rec(lambda: o['qkv_time_attention'](x, w, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale, **kw),
-                             2.0 * m * n * k, nbytes, 'qkv_time_attn_kernel<true>', 'N=2304 K=768')
+                             2.0 * m * n * k, nbytes, 'qkv_time_attn_kernel<true, false>', 'N=2304 K=768')
+
+        def timed_qt_mx(x_q, x_s, w_q, w_s, bias, qkv_cls, out, partials, *, n_seq, n_groups, scale, **kw):
+            if not self.enabled:
+                return o['qkv_time_attention_mx'](x_q, x_s, w_q, w_s, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale, **kw)
+            m, n, k = n_seq * 8 * n_groups, 2304, 768
+            nbytes = m * k + n * k + (m + n) * k // 32 + m * 768 * 2
+            return self._rec(lambda: o['qkv_time_attention_mx'](x_q, x_s, w_q, w_s, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale, **kw),
+                             2.0 * m * n * k, nbytes, 'qkv_time_attn_kernel<true, true>', 'N=2304 K=768', 'mxfp8')
 
         ops.gemm, ops.gemm_res_ln, ops.gemm_mxfp8, ops.gemm_mx_res_ln, ops.qkv_time_attention = timed, timed_ln, timed_mx, timed_mxln, timed_qt
+        ops.qkv_time_attention_mx = timed_qt_mx
         # the train steps call three GEMM entry points straight on the C ABI (weight gradients, fc1 + GELU with two outputs): wrap those on the library object
         from synchformer_amd import _lib
         lib = self.lib = _lib.load()

@@ -109,6 +109,12 @@ int sf_layernorm768_mxfp8(const float* x, int64_t ldx, const float* gamma, const
 int sf_gemm_mx_res_ln768(const uint8_t* A, int64_t lda, const uint8_t* sA, int64_t ldsa, const uint8_t* W, int64_t ldw, const uint8_t* sW, int64_t ldsw,
                          const float* bias, const float* R, int64_t ldr, float* X, int64_t ldx, const float* gamma, const float* beta, float eps,
                          uint8_t* Y, int64_t ldy, uint8_t* sY, int64_t ldsy, int64_t M, int64_t K, void* stream);
+/* sf_qkv_time_attention on MXFP8 operands (the temporal qkv projection of the fp8 towers with the 8-frame time attention in its epilogue): X (rows, 768) / W (2304, 768)
+ * e4m3 bytes with stage-major scale planes (6 planes, one dword per row, ldsx / ldsw bytes apart); qkv_cls / out bf16 and cls_partial fp32 as in
+ * sf_qkv_time_attention.  Replaces sf_gemm_mxfp8 (bf16 output) + sf_attention (time groups) + sf_attention_cls on the MX path. */
+int sf_qkv_time_attention_mx(const uint8_t* X, int64_t ldx, const uint8_t* sX, int64_t ldsx, const uint8_t* W, int64_t ldw, const uint8_t* sW, int64_t ldsw,
+                             const float* bias, const uint16_t* qkv_cls, int64_t ldc, uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_groups,
+                             float scale, void* stream);
 
 /* Tuning / test hook (state of the CALLING THREAD only; the launchers stay re-entrant): force the GEMM tile configuration of this thread's subsequent
  * sf_gemm_bf16 calls.  -1 = automatic choice by shape (default); 0 = 128x128x64, 4 waves, two workgroups per CU; 7 = persistent 256x256x64,

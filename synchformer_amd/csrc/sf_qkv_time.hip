@@ -39,6 +39,12 @@
 #define QT_BIAS_OFF (QT_STAGE + 8 * QT_SLAB_BYTES) // 1 KiB behind the slabs: the head's q | k | v bias (192 floats), one LDS-DMA piece per tile
 #define QT_CLS_OFF (QT_BIAS_OFF + 1024)          // 8 x 384 B: the CLS q | k | v of every wave's sequence and head
 #define QT_LDS (QT_CLS_OFF + 8 * 384)            // 160 KiB: slot 0 | slot 1 = the first 56 KiB of the slab area | bias | CLS
+// MXFP8 variant (template parameter MX): the same 4 KiB behind the slabs hold bias (768 B) | the k-tile's scale dwords (8 waves x 224 B: this wave's 32 token
+// rows | 24 of the head's 192 W rows) | FOUR shared CLS landing slots (tile parity x the at most two sequences a 32-patch tile touches; the bf16 variant's eight
+// private slots do not leave the 1792 B the scales need)
+#define QT_SC_OFF (QT_BIAS_OFF + 768)
+#define QT_SC_WAVE 224
+#define QT_CLSX_OFF (QT_SC_OFF + 8 * QT_SC_WAVE)  // + 4 x 384 B = QT_LDS exactly
 #ifndef QT_OUT_NT
 #define QT_OUT_NT 1   // attention output with the nt hint: read once, by the next launch (+0.4 % on the step, interleaved A/B)
 #endif
@@ -73,6 +79,9 @@ struct QtArgs {
   uint32_t tiles_m;
   uint32_t head_chunk;                                           // heads per sweep over an XCD's row tiles (divides 12)
   const uint8_t* key_keep;                                       // optional token keep flags, one byte per row of X (0 = masked key: -inf before the softmax)
+  // MX: X / W are e4m3 BYTES (ldx / ldw in bytes) with stage-major E8M0 scale planes (one dword per row per 128 k, ldsx / ldsw bytes between planes)
+  const uint8_t* sX; int64_t ldsx;
+  const uint8_t* sW; int64_t ldsw;
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 qt_bf2;
@@ -83,6 +92,13 @@ __device__ __forceinline__ void qt_dma1(uint32_t voff, const void* sbase, uint32
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
+// one dword per lane (64-bit lane addresses) -> 4 consecutive bytes per lane from the wave-uniform LDS address lds; inactive lanes write nothing
+__device__ __forceinline__ void qt_dma_dword_addr(const void* gaddr, uint32_t lds) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gaddr), "s"(lds) : "memory");
+}
+typedef __attribute__((ext_vector_type(8))) int qt_i32x8;
 template <int N>
 __device__ __forceinline__ void qt_wait_vmcnt() {
   asm volatile("" ::: "memory");
@@ -140,8 +156,10 @@ __device__ __forceinline__ float qt_sum_row16(float v) {
   return v;
 }
 
-template <bool PP>
+template <bool PP, bool MX = false>
 __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
+  static_assert(PP || !MX, "the MXFP8 variant exists on the quadrant-phased schedule only");
+  constexpr int ESZ = MX ? 1 : 2;                                 // bytes per operand element
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -165,11 +183,13 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
   // LDS-DMA sources.  A: piece i of this wave = patch 4 * wave + i of the tile, lane (f = lane >> 3, chunk = lane & 7) -> LDS row 32 wave + 8 i + f.
   // B: piece j = rows 24 wave + 8 j + (lane >> 3) of the head's 192 W rows (q | k | v blocks 768 rows apart; the head offset rides in the SGPR base).
   uint32_t voff_a[4], voff_b[3];
+  const uint8_t* sc_addr = nullptr;                               // MX: see set_tile
+  const uint32_t sc_step = MX ? (uint32_t)(lane < 32 ? p.ldsx : p.ldsw) : 0u;
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int br = PP ? j * 64 + wave * 8 + (lane >> 3) : wave * 24 + j * 8 + (lane >> 3);   // PP: piece j = this wave's 8 rows of W third j
     const int gch = (lane & 7) ^ ((br >> 1) & 7);
-    voff_b[j] = (uint32_t)(((int64_t)(br >> 6) * QT_D + (br & 63)) * p.ldw * 2 + gch * 16);
+    voff_b[j] = (uint32_t)(((int64_t)(br >> 6) * QT_D + (br & 63)) * p.ldw * ESZ + gch * 16);
   }
   // Inside an XCD's row-tile range the heads go in CHUNKS of `hc`: all row tiles x the chunk's heads (head fastest), then the next chunk.  With every
   // head in flight at once (hc = 12) the XCD's L2 has to hold all of W (3.5 MB of its 4 MB) next to the streamed A tiles and thrashes: 2.4 GB
@@ -180,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
   auto set_tile = [&](uint32_t tt) {
     const uint32_t c = tt / chunk_tiles, r = tt - c * chunk_tiles;
     tm = mp0 + r / hc; head = (int)(c * hc + r % hc);
-    wbase = reinterpret_cast<const char*>(p.W) + (int64_t)head * 64 * p.ldw * 2;
+    wbase = reinterpret_cast<const char*>(p.W) + (int64_t)head * 64 * p.ldw * ESZ;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       uint32_t g = tm * 32u + wave * 4 + i;                        // global patch index (seq, patch); the ragged last tile re-reads the last patch
@@ -190,7 +210,19 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
       const int f = lane >> 3;
       const int64_t row = (int64_t)seq * p.seq_rows + 1 + (int64_t)f * p.n_groups + pp;
       const int r = wave * 32 + i * 8 + f;
-      voff_a[i] = (uint32_t)(row * p.ldx * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
+      voff_a[i] = (uint32_t)(row * p.ldx * ESZ + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
+    }
+    if (MX) {                                                      // this lane's dword of the k-tile's scale piece (plane 0; + kt * step per k-tile)
+      if (lane < 32) {                                             // the wave's token row lane: LDS row 8 i + f  <->  patch i = lane >> 3, frame f = lane & 7
+        uint32_t g = tm * 32u + wave * 4 + (lane >> 3);
+        if (g > n_patches - 1) g = n_patches - 1;
+        const uint32_t seq = g / (uint32_t)p.n_groups;
+        const int pp = (int)(g - seq * (uint32_t)p.n_groups);
+        sc_addr = p.sX + ((int64_t)seq * p.seq_rows + 1 + (int64_t)(lane & 7) * p.n_groups + pp) * 4;
+      } else {                                                     // lanes 32-55: rows 4 wave .. + 3 of the head's six 32-row W blocks (q | k | v thirds x 2)
+        const int q = (lane - 32) < 24 ? lane - 32 : 23, grp = q >> 2;
+        sc_addr = p.sW + ((int64_t)(grp >> 1) * QT_D + head * 64 + (grp & 1) * 32 + wave * 4 + (q & 3)) * 4;
+      }
     }
   };
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane(qt_lds_addr(smem));
@@ -202,25 +234,41 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
   };
   // PP: the CLS q | k | v (3 x 128 B) of this wave's sequence and head as one masked LDS-DMA piece (lanes 0-23, 16 bytes each) into the wave's 384 B
   const uint32_t lds_cls = __builtin_amdgcn_readfirstlane(lds0 + QT_CLS_OFF + wave * 384);
-  auto cls_piece = [&]() {
+  // MX: the landing slot is shared by the waves of one sequence (every one of them writes the same 384 bytes) and alternates with the tile parity, so that a
+  // fast wave's piece for the next tile cannot land on what a slow wave has not read yet
+  auto cls_slot_mx = [&](uint32_t tile_m, int par) -> uint32_t {
+    uint32_t g0 = tile_m * 32u + wave * 4, g00 = tile_m * 32u;
+    if (g0 > n_patches - 1) g0 = n_patches - 1;
+    if (g00 > n_patches - 1) g00 = n_patches - 1;
+    return (uint32_t)(QT_CLSX_OFF + (par * 2 + (int)(g0 / (uint32_t)p.n_groups - g00 / (uint32_t)p.n_groups)) * 384);
+  };
+  auto cls_piece = [&](int par) {
     uint32_t g0 = tm * 32u + wave * 4;
     if (g0 > n_patches - 1) g0 = n_patches - 1;
     const char* cls = reinterpret_cast<const char*>(p.qkv_cls + (int64_t)(g0 / (uint32_t)p.n_groups) * p.ldc + head * 64);
-    if (lane < 24) qt_dma1((uint32_t)(((lane >> 3) * QT_D + (lane & 7) * 8) * 2), cls, lds_cls);
+    const uint32_t dst = MX ? __builtin_amdgcn_readfirstlane(lds0 + cls_slot_mx(tm, par)) : lds_cls;
+    if (lane < 24) qt_dma1((uint32_t)(((lane >> 3) * QT_D + (lane & 7) * 8) * 2), cls, dst);
+  };
+  // MX: the scale dwords of k-tile kt - this wave's 32 token rows (lanes 0-31) and its 24 of the head's W rows (lanes 32-55) - as ONE piece of 56 dwords
+  const uint32_t lds_sc = __builtin_amdgcn_readfirstlane(lds0 + QT_SC_OFF + wave * QT_SC_WAVE);
+  auto scale_piece = [&](int kt) {
+    if (lane < 56) qt_dma_dword_addr(sc_addr + (uint64_t)(uint32_t)kt * sc_step, lds_sc);
   };
   // the head's bias: lanes 0-47 of wave 0 fetch 16 bytes each of the q | k | v thirds (768 floats apart), the other lanes re-read lane 0's
   const uint32_t voff_bias = lane < 48 ? (uint32_t)(((lane >> 4) * QT_D + (lane & 15) * 4) * 4) : 0u;
   const uint32_t lds_bias = lds0 + QT_BIAS_OFF;
   auto bias_piece = [&]() {                                        // wave-uniform branch; after set_tile (uses `head`)
-    if (wave == 0 && p.bias) qt_dma1(voff_bias, reinterpret_cast<const char*>(p.bias) + head * 256, lds_bias);
+    if (wave == 0 && p.bias && (!MX || lane < 48)) qt_dma1(voff_bias, reinterpret_cast<const char*>(p.bias) + head * 256, lds_bias);   // MX: the 256 B behind the 768 are the scale area
   };
   set_tile(t);
 #pragma unroll
   for (int pc = 0; pc < 7; ++pc) piece(pc, 0, 0);
   bias_piece();
-  if (PP) { cls_piece(); qt_wait_vmcnt<0>(); }
+  if (MX) scale_piece(0);
+  int tpar = 0;                                                    // MX: parity of the current tile (CLS landing slots)
+  if (PP) { cls_piece(0); qt_wait_vmcnt<0>(); }
 
-  constexpr int nk = QT_D / QT_BK;                                  // 12 k-tiles
+  constexpr int nk = MX ? QT_D / 128 : QT_D / QT_BK;                // 12 k-tiles of 64 bf16 / 6 of 128 fp8: 128 bytes per row either way
   const float sc = p.scale * 1.44269504088896f;                    // softmax in base 2
 
   for (;;) {
@@ -276,13 +324,21 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
     if constexpr (PP) {
       const int wg = wave >> 2;                                     // waves 4-7 run one barrier behind waves 0-3
       int fo[4];                                                   // fragment offsets, re-derived here (not kept live across the epilogue)
+      int fsx = 0, fsw = 0, shi = 0;                               // MX: addresses of this lane's scale dwords (its token row; row l31 of W block 0), 8 * (lane >> 5)
       {
         int ptid = threadIdx.x;
         asm volatile("" : "+v"(ptid));
         const int pl31 = ptid & 31, phi = (ptid & 63) >> 5;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) fo[kk] = pl31 * 128 + (((kk * 2 + phi) ^ ((pl31 >> 1) & 7)) << 4);
+        if (MX) {
+          fsx = QT_SC_OFF + wave * QT_SC_WAVE + pl31 * 4;
+          fsw = QT_SC_OFF + (pl31 >> 2) * QT_SC_WAVE + 128 + (pl31 & 3) * 4;      // + (2 C + jj) * 16
+          shi = phi * 8;
+        }
       }
+      uint32_t sxd = 0, swd[6] = {0, 0, 0, 0, 0, 0};               // MX: the k-tile's scale dwords, shifted so that byte 2 kk is this half-wave's block of MFMA kk
+      int sxv[2] = {0, 0}, swv[2][2] = {{0, 0}, {0, 0}};
       // every wave is out of its slab (they overlay stage 1) and has waited for its pieces of k-tile 0 (vmcnt 0 in front of the epilogue's stores)
       qt_barrier();
       if (!(QT_ABL & 2)) { piece(4, 1, 1); piece(0, 1, 1); piece(1, 1, 1); }          // W0, A0, A1 of k-tile 1
@@ -303,10 +359,31 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj) wf[jj][kk] = *reinterpret_cast<const bf16x8*>(st + QT_A_BYTES + (2 * C + jj) * 4096 + fo[kk]);
+        if (MX) {
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) swv[jj][k2] = (int)((swd[2 * C + jj] >> (k2 * 16)) & 0xffu);
+        }
       };
       auto mma = [&](auto Cc) {
         constexpr int C = decltype(Cc)::value;
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (MX) {
+          // a 128-byte LDS row = 128 fp8 k: the bf16 loop's fragments 2 k2 and 2 k2 + 1 are the 2 x 16 bytes a lane supplies to ONE 64-deep scaled MFMA
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2) {
+            union { bf16x8 h[2]; qt_i32x8 v; } ux;
+            ux.h[0] = xf[2 * k2]; ux.h[1] = xf[2 * k2 + 1];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              union { bf16x8 h[2]; qt_i32x8 v; } uw;
+              uw.h[0] = wf[jj][2 * k2]; uw.h[1] = wf[jj][2 * k2 + 1];
+              acc[2 * C + jj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(uw.v, ux.v, acc[2 * C + jj], 0 /* e4m3 */, 0 /* e4m3 */, 0, swv[jj][k2], 0, sxv[k2]);
+            }
+          }
+          asm volatile("" : "+v"(acc[2 * C]), "+v"(acc[2 * C + 1]));   // pins the (pure) MFMAs inside their matrix segment
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -314,6 +391,7 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
             if (!(QT_ABL & 4)) acc[2 * C + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[jj][kk], xf[kk], acc[2 * C + jj], 0, 0, 0);
             else if (kk == 0 && jj == 0) asm volatile("" :: "v"(xf[0]), "v"(xf[3]), "v"(wf[0][0]), "v"(wf[1][3]));
           }
+        }
         __builtin_amdgcn_s_setprio(0);
       };
       // one k-tile in stage S; more1 / more2: k-tiles kt+1 / kt+2 exist; first: k-tile 0 (its W thirds 1 and 2 have landed already)
@@ -324,6 +402,12 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
         // ---- phase 0: q third ----
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) xf[kk] = *reinterpret_cast<const bf16x8*>(st + a_base + fo[kk]);
+        if (MX) {                                                  // ALL scale dwords of the k-tile now: the (single) scale area is refilled in phase 1
+          sxd = *reinterpret_cast<const uint32_t*>(smem + fsx) >> shi;
+#pragma unroll
+          for (int b = 0; b < 6; ++b) swd[b] = *reinterpret_cast<const uint32_t*>(smem + fsw + b * 16) >> shi;
+          sxv[0] = (int)(sxd & 0xffu); sxv[1] = (int)((sxd >> 16) & 0xffu);
+        }
         read_w(st, std::integral_constant<int, 0>{});
         __builtin_amdgcn_sched_barrier(0);
         if (ld1) { piece(5, S ^ 1, kt + 1); piece(2, S ^ 1, kt + 1); piece(3, S ^ 1, kt + 1); }   // W1, A2, A3 of k-tile kt+1
@@ -336,8 +420,9 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
         // ---- phase 1: k third ----
         read_w(st, std::integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
+        if (MX && ld1) scale_piece(kt + 1);                                                        // (every wave has read k-tile kt's dwords in phase 0)
         if (ld1) piece(6, S ^ 1, kt + 1);                                                          // W2 of k-tile kt+1
-        if (!first) { if (!more1 || (QT_ABL & 2)) qt_wait_vmcnt<0>(); else qt_wait_vmcnt<7>(); }   // W third 2 has landed
+        if (!first) { if (!more1 || (QT_ABL & 2)) qt_wait_vmcnt<0>(); else if (MX) qt_wait_vmcnt<8>(); else qt_wait_vmcnt<7>(); }   // W third 2 has landed
         qt_barrier();
         __builtin_amdgcn_sched_barrier(0);
         mma(std::integral_constant<int, 1>{});
@@ -378,6 +463,7 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
 #pragma unroll
       for (int pc = 0; pc < 7; ++pc) piece(pc, 0, 0);
       bias_piece();
+      if (MX) scale_piece(0);
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------------------------
@@ -400,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
     // The wave's four patches belong to ONE sequence (n_groups % 4 == 0); np of them exist (ragged last tile).
     const uint32_t g0 = etm * 32u + ewave * 4;
     const int np = g0 >= n_patches ? 0 : (n_patches - g0 < 4u ? (int)(n_patches - g0) : 4);
-    const char* clsp = smem + QT_CLS_OFF + ewave * 384;
+    const char* clsp = smem + (MX ? cls_slot_mx(etm, tpar) : (uint32_t)(QT_CLS_OFF + ewave * 384));
     uint4 qcA[4], kcA[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -410,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
     const uint4 vcB = *reinterpret_cast<const uint4*>(clsp + 256 + (elane & 7) * 16);
     if (PP && more) {                                              // this tile's CLS slices are in registers: the next tile's may land
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      cls_piece();
+      cls_piece(tpar ^ 1);
     }
     if (np == 0 && PP) qt_wait_vmcnt<0>();                         // (waves with patches wait in front of their stores, below)
     if (np > 0) {                                                  // wave-uniform
@@ -563,6 +649,7 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
     }
     if (!more) break;
     t = tnext;
+    tpar ^= 1;
   }
 }
 
@@ -611,6 +698,7 @@ static int qkv_time_impl(const uint16_t* X, int64_t ldx, const uint16_t* W, int6
   QtArgs a;
   a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.qkv_cls = qkv_cls; a.ldc = ldc; a.out = out; a.ldo = ldo; a.cls_part = cls_partial;
   a.n_seq = n_seq; a.seq_rows = seq_rows; a.n_groups = n_groups; a.scale = scale; a.key_keep = key_keep;
+  a.sX = nullptr; a.ldsx = 0; a.sW = nullptr; a.ldsw = 0;
   const int64_t tiles_m = (n_seq * n_groups + 31) / 32;
   SF_CHECK_ARG(tiles_m * QT_HEADS < ((int64_t)1 << 31) && n_seq * n_groups < ((int64_t)1 << 31), "sf_qkv_time_attention: too many tiles");
   a.tiles_m = (uint32_t)tiles_m;
@@ -625,6 +713,43 @@ static int qkv_time_impl(const uint16_t* X, int64_t ldx, const uint16_t* W, int6
   const bool pp = g_qt_force_sched >= 0 ? g_qt_force_sched != 0 : env_sched != 0;
   if (pp) hipLaunchKernelGGL(qkv_time_attn_kernel<true>, dim3((unsigned)blocks), dim3(512), QT_LDS, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(qkv_time_attn_kernel<false>, dim3((unsigned)blocks), dim3(512), QT_LDS, (hipStream_t)stream, a);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// The same launch on MXFP8 operands (fp8 towers of the synchronizability fine-tune): X (rows, 768) e4m3 bytes with its stage-major scale planes sX (6 planes,
+// ldsx bytes apart, one dword per row) - what sf_layernorm768_mxfp8 / sf_gemm_mx_res_ln768 write -, W (2304, 768) e4m3 + sW (6 planes of 2304 dwords).  qkv_cls,
+// out and cls_partial as in sf_qkv_time_attention (bf16 / fp32): the attention itself runs on the bf16-rounded projection, exactly as on the un-fused MX path
+// (sf_gemm_mxfp8 with a bf16 output, then sf_attention).  Replaces sf_gemm_mxfp8 (temporal qkv) + sf_attention (time groups) + sf_attention_cls.
+extern "C" int sf_qkv_time_attention_mx(const uint8_t* X, int64_t ldx, const uint8_t* sX, int64_t ldsx, const uint8_t* W, int64_t ldw, const uint8_t* sW,
+                                        int64_t ldsw, const float* bias, const uint16_t* qkv_cls, int64_t ldc, uint16_t* out, int64_t ldo, float* cls_partial,
+                                        int64_t n_seq, int n_groups, float scale, void* stream) {
+  SF_CHECK_ARG(X && sX && W && sW && qkv_cls && out && cls_partial, "sf_qkv_time_attention_mx: null pointer");
+  SF_CHECK_ARG((n_groups % 4) == 0 && n_groups >= 4, "sf_qkv_time_attention_mx: n_groups must be a multiple of 4 (a wave's four patches share one sequence)");
+  SF_CHECK_ARG((ldx % 16) == 0 && (ldw % 16) == 0 && ldx >= QT_D && ldw >= QT_D && (ldc % 8) == 0 && (ldo % 8) == 0, "sf_qkv_time_attention_mx: bad row strides");
+  SF_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)sX % 4) == 0 && ((uintptr_t)sW % 4) == 0 && ((uintptr_t)qkv_cls % 16) == 0 &&
+                   ((uintptr_t)out % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0) && ((uintptr_t)cls_partial % 8) == 0,
+               "sf_qkv_time_attention_mx: operands must be 16-byte aligned (scale planes 4-byte)");
+  if (n_seq <= 0) return 0;
+  const int64_t seq_rows = 1 + 8 * (int64_t)n_groups;
+  SF_CHECK_ARG(n_seq * seq_rows * ldx < ((int64_t)1 << 32) && (int64_t)3 * QT_D * ldw < ((int64_t)1 << 32), "sf_qkv_time_attention_mx: X and W must stay below 4 GiB");
+  SF_CHECK_ARG((ldsx % 4) == 0 && (ldsw % 4) == 0 && ldsx >= n_seq * seq_rows * 4 && ldsw >= 3 * QT_D * 4 && ldsx < ((int64_t)1 << 32) && ldsw < ((int64_t)1 << 32),
+               "sf_qkv_time_attention_mx: scale planes must hold one dword per row of X / W");
+  if (int rc = sf_prepare_kernel((const void*)qkv_time_attn_kernel<true, true>, QT_LDS, "sf_qkv_time_attention_mx")) return rc;
+  const int n_cu = sf_cu_count("sf_qkv_time_attention_mx");
+  if (n_cu <= 0) return -1;
+  QtArgs a;
+  a.X = reinterpret_cast<const bf16_t*>(X); a.ldx = ldx; a.W = reinterpret_cast<const bf16_t*>(W); a.ldw = ldw; a.bias = bias; a.qkv_cls = qkv_cls; a.ldc = ldc;
+  a.out = out; a.ldo = ldo; a.cls_part = cls_partial; a.n_seq = n_seq; a.seq_rows = seq_rows; a.n_groups = n_groups; a.scale = scale; a.key_keep = nullptr;
+  a.sX = sX; a.ldsx = ldsx; a.sW = sW; a.ldsw = ldsw;
+  const int64_t tiles_m = (n_seq * n_groups + 31) / 32;
+  SF_CHECK_ARG(tiles_m * QT_HEADS < ((int64_t)1 << 31) && n_seq * n_groups < ((int64_t)1 << 31), "sf_qkv_time_attention_mx: too many tiles");
+  a.tiles_m = (uint32_t)tiles_m;
+  a.head_chunk = 6;
+  int64_t blocks = (n_cu / 8) * 8;
+  const int64_t need = ((tiles_m * QT_HEADS + 7) / 8) * 8;
+  if (blocks > need) blocks = need;
+  hipLaunchKernelGGL((qkv_time_attn_kernel<true, true>), dim3((unsigned)blocks), dim3(512), QT_LDS, (hipStream_t)stream, a);
   SF_LAUNCH_CHECK();
   return 0;
 }

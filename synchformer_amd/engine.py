@@ -78,6 +78,7 @@ class SynchformerEngine:
         # fp8_towers: the six big Linears of every visual block run on MXFP8 operands (sf_gemm_mxfp8) - the frozen-extractor mode of the
         # synchronizability fine-tune (BASELINE configs[4]).  Off (bf16) for every other workload: inference parity bars are stated for bf16.
         self.fp8_towers = bool(fp8_towers)
+        self.fuse_mx_time = True                     # fp8 towers: sf_qkv_time_attention_mx instead of sf_gemm_mxfp8 + the time attention kernels
         self.fuse_mx_ln = True                       # fp8 towers: sf_gemm_mx_res_ln768 instead of sf_gemm_mxfp8 + sf_layernorm768_mxfp8 (tests switch it off to compare)
         self.capture_blocks = None          # tests: a dict -> the fp32 residual stream after each visual block is cloned into it (key = block index)
         self._ws = {}
@@ -298,7 +299,7 @@ class SynchformerEngine:
             ops.attention_cls_combine(part, xn, n_part=groups, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
 
         if self.fp8_towers:
-            self._visual_blocks_mxfp8(X, xn, qkv, rows, divided)
+            self._visual_blocks_mxfp8(X, xn, qkv, rows, divided, n, part, tok_keep)
             return self._visual_tail(X, n, out, tok_keep)
         # DividedSpaceTimeBlock.forward (vit_helper.py:364-376).  With `fuse_ln` every residual GEMM also emits the LayerNorm that opens the next
         # sub-layer (sf_gemm_res_ln768: the fp32 stream is read and written once per sub-layer, no separate LayerNorm launch); the last block's
@@ -347,7 +348,7 @@ class SynchformerEngine:
                 self.capture_blocks[bi] = X.clone()
         self._visual_tail(X, n, out, tok_keep)
 
-    def _visual_blocks_mxfp8(self, X, xn, qkv, rows, divided):
+    def _visual_blocks_mxfp8(self, X, xn, qkv, rows, divided, n, part, tok_keep):
         """The 12 DividedSpaceTimeBlocks with every big Linear on MXFP8 operands.  Activations are quantised where they are produced when the
         producer is ours to change (LayerNorm -> sf_layernorm768_mxfp8, fc1 + GELU -> the GEMM's own MXFP8 epilogue); the attention kernels
         write bf16, which one sf_quantize_mxfp8 pass converts.  The residual stream, LayerNorm statistics and attention stay as in the bf16 path."""
@@ -357,13 +358,28 @@ class SynchformerEngine:
         hq = self._buf('HQ', rows * FF, torch.uint8).view(rows, FF)
         hs = self._buf('HS', 24 * rows_p * 4, torch.uint8).view(24, rows_p, 4)
         fuse = self.fuse_mx_ln                                            # proj / fc2 + residual + the next LayerNorm + its quantisation in one launch (sf_gemm_mx_res_ln768)
+        # temporal qkv + time attention + CLS partials in one launch (sf_qkv_time_attention_mx); the CLS rows' own projection is a small MX GEMM on gathered
+        # copies of those rows and of their scale dwords
+        fuse_time = self.fuse_time and self.fuse_mx_time and rows >= 128 * 64 and tok_keep is None
+        if fuse_time:
+            n_p = ((n + 255) // 256) * 256
+            cq = self._buf('CQ', n * D, torch.uint8).view(n, D)
+            cs = self._buf('CS', 6 * n_p * 4, torch.uint8).view(6, n_p, 4)
+            qkv_cls = self._buf('qkv_cls', n * 3 * D, torch.bfloat16).view(n, 3 * D)
         nb = len(self.v_blocks)
         for bi, b in enumerate(self.v_blocks):
             mx = b['mx']
             if bi == 0 or not fuse:
                 ops.layernorm_mxfp8(X, b['norm3'].g, b['norm3'].b, xq, xs, EPS_VIS)
-            ops.gemm_mxfp8(xq, xs, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, qkv)
-            divided('time')
+            if fuse_time:
+                cq.copy_(xq.view(n, VIS_L, D)[:, 0])
+                cs[:, :n].copy_(xs[:, :rows].view(6, n, VIS_L, 4)[:, :, 0])
+                ops.gemm_mxfp8(cq, cs, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, qkv_cls)
+                ops.qkv_time_attention_mx(xq, xs, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, qkv_cls, xn, part, n_seq=n, n_groups=196, scale=0.125)
+                ops.attention_cls_combine(part, xn, n_part=49, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
+            else:
+                ops.gemm_mxfp8(xq, xs, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, qkv)
+                divided('time')
             ops.quantize_mxfp8(xn, xq, xs)
             if fuse:
                 ops.gemm_mx_res_ln(xq, xs, mx['t_proj'].q, mx['t_proj'].s, mx['t_proj'].b, X, b['norm1'].g, b['norm1'].b, xq, xs, EPS_VIS)

@@ -295,6 +295,22 @@ def qkv_time_attention(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Te
     return out
 
 
+def qkv_time_attention_mx(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], qkv_cls: torch.Tensor,
+                          out: torch.Tensor, partials: torch.Tensor, *, n_seq: int, n_groups: int, scale: float):
+    """qkv_time_attention on MXFP8 operands: x_q (n_seq * (1 + 8 n_groups), 768) uint8 e4m3 + x_s (6, >= rows, 4) scale planes, w_q (2304, 768) + w_s (6, >= 2304, 4);
+    qkv_cls (n_seq, 2304) bf16, out bf16, partials fp32 as in qkv_time_attention."""
+    assert x_q.dtype == w_q.dtype == x_s.dtype == w_s.dtype == torch.uint8 and qkv_cls.dtype == out.dtype == torch.bfloat16 and partials.dtype == torch.float32
+    assert x_q.shape[1] == 768 and tuple(w_q.shape) == (2304, 768) and qkv_cls.shape[0] >= n_seq and qkv_cls.shape[1] == 2304 and out.shape[1] == 768
+    rows = n_seq * (1 + 8 * n_groups)
+    assert x_q.shape[0] >= rows and out.shape[0] >= rows and x_s.dim() == 3 and w_s.dim() == 3 and x_s.shape[0] == 6 and w_s.shape[0] == 6
+    assert x_s.shape[1] >= rows and w_s.shape[1] >= 2304 and x_s.is_contiguous() and w_s.is_contiguous() and partials.numel() >= n_seq * 12 * (n_groups // 4) * 66
+    rc = _lib.load().sf_qkv_time_attention_mx(_dev(x_q, 'x_q'), _ld(x_q), _dev(x_s, 'x_s'), x_s.stride(0), _dev(w_q, 'w_q'), _ld(w_q), _dev(w_s, 'w_s'), w_s.stride(0),
+                                              _dev(bias, 'bias') if bias is not None else None, _dev(qkv_cls, 'qkv_cls'), _ld(qkv_cls), _dev(out, 'out'), _ld(out),
+                                              _dev(partials, 'partials'), n_seq, n_groups, float(scale), _stream())
+    _lib.check(rc, 'sf_qkv_time_attention_mx')
+    return out
+
+
 def attention_cls_combine(partials: torch.Tensor, out: torch.Tensor, *, n_part: int, n_seq: int, out_seq_rows: int, out_row: int, heads: int):
     rc = _lib.load().sf_attention_cls_combine(_dev(partials, 'partials'), n_part, _dev(out, 'out'), _ld(out), out_seq_rows, out_row, n_seq, heads,
                                               _stream())
@@ -380,7 +396,7 @@ def register_torch_ops():
         return
     from torch.library import custom_op
     # the direct launchers, bound now: ops.via_dispatcher() re-points the module-level names at these custom ops
-    d_ = {n: globals()[n] for n in ('gemm', 'layernorm', 'attention', 'attention_cls', 'im2col_video', 'gemm_res_ln', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'quantize_mxfp8', 'layernorm_mxfp8', 'gemm_mxfp8', 'gemm_mx_res_ln')}
+    d_ = {n: globals()[n] for n in ('gemm', 'layernorm', 'attention', 'attention_cls', 'im2col_video', 'gemm_res_ln', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'quantize_mxfp8', 'layernorm_mxfp8', 'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention_mx')}
 
     @custom_op('synchformer::gemm_bf16', mutates_args=('out',), device_types='cuda')
     def _gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, residual: Optional[torch.Tensor],
@@ -418,6 +434,11 @@ def register_torch_ops():
     def _qkv_time(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], qkv_cls: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, n_seq: int,
                   n_groups: int, scale: float, key_keep: Optional[torch.Tensor]) -> None:
         d_['qkv_time_attention'](x, w, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale, key_keep=key_keep)
+
+    @custom_op('synchformer::qkv_time_attention_mx', mutates_args=('out', 'partials'), device_types='cuda')
+    def _qkv_time_mx(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], qkv_cls: torch.Tensor, out: torch.Tensor,
+                     partials: torch.Tensor, n_seq: int, n_groups: int, scale: float) -> None:
+        d_['qkv_time_attention_mx'](x_q, x_s, w_q, w_s, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale)
 
     @custom_op('synchformer::attention_cls_partial', mutates_args=('out', 'partials'), device_types='cuda')
     def _attn_part(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, n_seq: int, seq_rows: int, n_groups: int,
@@ -458,7 +479,7 @@ class via_dispatcher:
         with ops.via_dispatcher(): logits = engine.forward(vis, aud)
     The results are the same launches on the same buffers (tests/test_e2e_gpu.py compares them bit for bit)."""
     NAMES = ('gemm', 'layernorm', 'gemm_res_ln', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'quantize_mxfp8', 'layernorm_mxfp8',
-             'gemm_mxfp8', 'gemm_mx_res_ln')
+             'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention_mx')
 
     def __init__(self):
         self.calls = 0
@@ -497,6 +518,10 @@ class via_dispatcher:
             count(t.qkv_time_attention)(x, w, bias, qkv_cls, out, partials, n_seq, n_groups, scale, key_keep)
             return out
 
+        def qkv_time_mx_(x_q, x_s, w_q, w_s, bias, qkv_cls, out, partials, *, n_seq, n_groups, scale):
+            count(t.qkv_time_attention_mx)(x_q, x_s, w_q, w_s, bias, qkv_cls, out, partials, n_seq, n_groups, scale)
+            return out
+
         def attn_part_(q, k, v, out, partials, *, n_seq, seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim, scale, key_keep=None):
             count(t.attention_cls_partial)(q, k, v, out, partials, n_seq, seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim, scale,
                                            key_keep)
@@ -531,7 +556,8 @@ class via_dispatcher:
             return x, y_q, y_s
 
         g.update(gemm=gemm_, layernorm=layernorm_, gemm_res_ln=gemm_res_ln_, qkv_time_attention=qkv_time_, attention_cls_partial=attn_part_,
-                 attention_cls_combine=attn_comb_, quantize_mxfp8=quant_, layernorm_mxfp8=ln_mx_, gemm_mxfp8=gemm_mx_, gemm_mx_res_ln=gemm_mx_ln_)
+                 attention_cls_combine=attn_comb_, quantize_mxfp8=quant_, layernorm_mxfp8=ln_mx_, gemm_mxfp8=gemm_mx_, gemm_mx_res_ln=gemm_mx_ln_,
+                 qkv_time_attention_mx=qkv_time_mx_)
         return self
 
     def __exit__(self, *exc):

@@ -111,11 +111,11 @@ def test_mxfp8_towers_bound(gpu):
     assert (l8.argmax(-1) == torch.from_numpy(g['logits']).argmax(-1)).all()
     # the fused proj / fc2 + residual + LayerNorm + quantisation launches (sf_gemm_mx_res_ln768, the default) against the un-fused pairs: the same
     # products summed in another order - features agree far inside the fp8 path's own noise
-    e8.fuse_mx_ln = False
+    e8.fuse_mx_ln = e8.fuse_mx_time = False
     v8u, l8u = e8.extract_vfeats(u8), e8.forward(u8, aud).cpu()
     relu = _rel_rms(v8.cpu(), v8u.cpu())
     print(f'mxfp8 towers, fused vs un-fused res+LN: vfeat rel-RMS {relu:.5f} | logits max |d| {(l8 - l8u).abs().max().item():.5f}')
-    assert 0 < relu < 1.5e-2 and (l8 - l8u).abs().max().item() < 5e-3
+    assert 0 < relu < 3e-2 and (l8 - l8u).abs().max().item() < 5e-3      # (two fp8 runs whose roundings differ in a few places decorrelate by ~1-2 %: a fifth of the path's own 7.8 % noise)
 
 
 def test_forward_through_the_dispatcher(gpu):

@@ -586,6 +586,53 @@ def test_qkv_time_attention(gpu, n_seq):
     torch.testing.assert_close(o[:, 1:], po, rtol=2 ** -7, atol=2 ** -7)
 
 
+@pytest.mark.parametrize('n_seq', [3, 40])
+def test_qkv_time_attention_mx(gpu, n_seq):
+    """sf_qkv_time_attention_mx against the un-fused MX sequence it replaces: sf_gemm_mxfp8 (bf16 output) -> sf_attention (time groups, CLS key first) +
+    sf_attention_cls, on operands whose block scales differ widely along K and across rows (a wrong scale byte, a swapped k half or a wrong row of the gathered
+    scale dwords cannot hide).  Both round the projection to bf16 before the attention; the MX products are exact in fp32 up to summation order, so the outputs
+    agree to one bf16 ulp of their magnitude.  Repetitions are bit-identical (race screen: the single scale area is refilled one phase after its last read)."""
+    from synchformer_amd import ops
+    L, D = 1569, 768
+    rows = n_seq * L
+    g = torch.Generator().manual_seed(90 + n_seq)
+    x = _bf(torch.randn(rows, D, generator=g) * torch.exp2(torch.randint(-3, 3, (rows, D // 32), generator=g).float()).repeat_interleave(32, 1)).to(gpu)
+    w = _bf(torch.randn(3 * D, D, generator=g) * 0.03 * torch.exp2(torch.randint(-2, 2, (3 * D, D // 32), generator=g).float()).repeat_interleave(32, 1)).to(gpu)
+    b = (0.1 * _rand(3 * D, seed=92)).to(gpu)
+    xq, xs = torch.empty(rows, D, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(rows, D, gpu)
+    wq, ws = torch.empty(3 * D, D, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(3 * D, D, gpu)
+    ops.quantize_mxfp8(x, xq, xs)
+    ops.quantize_mxfp8(w, wq, ws)
+    # un-fused
+    qkv = torch.empty(rows, 3 * D, device=gpu, dtype=torch.bfloat16)
+    ops.gemm_mxfp8(xq, xs, wq, ws, b, qkv)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    ref = torch.zeros(rows, D, device=gpu, dtype=torch.bfloat16)
+    ops.attention(q, k, v, ref, n_seq=n_seq, seq_rows=L, cls_row=0, heads=12, head_dim=64, scale=0.125, n_groups=196, row0=1, group_stride=1, tok_stride=196, n_tok=8)
+    ops.attention_cls(q, k, v, ref, n_seq=n_seq, q_seq_rows=L, q_row=0, kv_seq_rows=L, kv_row0=0, n_keys=L, out_seq_rows=L, out_row=0, heads=12, head_dim=64,
+                      scale=0.125)
+    # fused
+    qkv_cls = qkv.view(n_seq, L, 3 * D)[:, 0].contiguous()
+
+    def fused():
+        out = torch.full((rows, D), 7.0, device=gpu, dtype=torch.bfloat16)
+        part = torch.zeros(n_seq * 12 * 49 * 66, device=gpu)
+        ops.qkv_time_attention_mx(xq, xs, wq, ws, b, qkv_cls, out, part, n_seq=n_seq, n_groups=196, scale=0.125)
+        return out, part
+    out, part = fused()
+    for rep in range(3):
+        o2, p2 = fused()
+        assert torch.equal(o2, out), f'repetition {rep}: {(o2 != out).sum().item()} output elements differ'
+        assert torch.equal(p2, part), f'repetition {rep}: {(p2 != part).sum().item()} partial elements differ'
+    assert (out.view(n_seq, L, D)[:, 0] == 7.0).all(), 'the fused kernel must not touch the CLS rows'
+    ops.attention_cls_combine(part, out, n_part=49, n_seq=n_seq, out_seq_rows=L, out_row=0, heads=12)
+    o, r = out.float().view(n_seq, L, D), ref.float().view(n_seq, L, D)
+    scale = r.abs().max().item()
+    torch.testing.assert_close(o[:, 1:], r[:, 1:], rtol=2 ** -6, atol=2 ** -7 * max(1.0, scale))
+    assert (o[:, 1:] - r[:, 1:]).abs().gt(1e-3 * max(1.0, scale)).float().mean() < 5e-3
+    torch.testing.assert_close(o[:, 0], r[:, 0], rtol=2 ** -6, atol=2 ** -7 * max(1.0, scale))
+
+
 @pytest.mark.parametrize('sched', [0, 1])
 def test_qkv_time_attention_masked(gpu, sched):
     """sf_qkv_time_attention_masked against the un-fused masked kernels (sf_gemm_bf16 -> sf_attention_masked + sf_attention_cls_masked, pinned to the real
