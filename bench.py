@@ -97,7 +97,7 @@ class GemmTimer:
         cfg = 0 if mapped else _lib.load().sf_gemm_bf16_auto_config(m, n, k, int(res))     # the library's own choice (tile-round fill decides at small batches)
         b = lambda v: 'true' if v else 'false'
         if cfg == 11:
-            return f'gemm_bf16_pp_kernel<{b(out_bf16)}, {b(gelu)}, {b(res)}>'
+            return f'gemm_bf16_pp_kernel<{b(out_bf16)}, {b(gelu)}, {b(res)}, false>'
         if cfg == 7:
             return f'gemm_bf16_persistent_kernel<{b(out_bf16)}, {b(gelu)}, {b(res)}>'
         return 'gemm_bf16_kernel<GemmCfg<128, 128, 2, 2, 64, 2, 2, false>, ...> (small / mapped GEMMs: AST, aggregators, sync transformer, heads)'
