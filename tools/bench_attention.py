@@ -41,3 +41,14 @@ oa = torch.zeros(448 * 74, 768, device=dev, dtype=torch.bfloat16)
 t = timeit(lambda: ops.attention(qa[:, :768], qa[:, 768:1536], qa[:, 1536:], oa, n_seq=448, seq_rows=74, n_groups=1, row0=0,
                                  group_stride=0, tok_stride=1, n_tok=74, cls_row=-1, heads=12, head_dim=64, scale=0.125))
 print(f'AST 74 tokens x 448 seq: {t:7.1f} us')
+# layout probe: the same space attention with every head's q | k | v rows contiguous ([seq x head][token][192], 384 B per token) instead of 128-byte
+# slices of 4608-byte rows - emulated as 12 x n single-head sequences with ld = 192; and with q, k, v in three separate head-major planes (ld = 64)
+hm = (torch.randn(n * 12 * L, 192, device=dev)).bfloat16()
+ohm = torch.zeros(n * 12 * L, 64, device=dev, dtype=torch.bfloat16)
+t = timeit(lambda: ops.attention(hm[:, :64], hm[:, 64:128], hm[:, 128:], ohm, n_seq=n * 12, seq_rows=L, n_groups=8, row0=1, group_stride=196, tok_stride=1,
+                                 n_tok=196, cls_row=0, heads=1, head_dim=64, scale=0.125))
+print(f'space, head-major q|k|v rows (ld 192): {t:7.1f} us  {mb / t:6.2f} TB/s-equivalent')
+pl = (torch.randn(3, n * 12 * L, 64, device=dev)).bfloat16()
+t = timeit(lambda: ops.attention(pl[0], pl[1], pl[2], ohm, n_seq=n * 12, seq_rows=L, n_groups=8, row0=1, group_stride=196, tok_stride=1,
+                                 n_tok=196, cls_row=0, heads=1, head_dim=64, scale=0.125))
+print(f'space, three head-major planes (ld 64): {t:7.1f} us  {mb / t:6.2f} TB/s-equivalent')
