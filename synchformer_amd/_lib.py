@@ -10,7 +10,7 @@ from pathlib import Path
 
 LIB_DIR = Path(__file__).resolve().parent / 'lib'
 LIB_NAME = 'libsynchformer_hip.so'
-ABI_VERSION = 2     # 2: round 3 (sf_gemm_res_ln_force_schedule; round 2 changed sf_gemm_tn_splitk's signature without a bump)
+ABI_VERSION = 3     # 3: round 3, second half (sf_gemm_mx_res_ln768, sf_qkv_time_attention_mx, sf_gemm_tn_pp, sf_branch_grad, ... added); 2: sf_gemm_res_ln_force_schedule
 
 _i64, _i32, _f32, _ptr = C.c_int64, C.c_int, C.c_float, C.c_void_p
 
