@@ -43,7 +43,7 @@
 #define SF_PP_NOPEEL 0                 // 1: the first k-tile pair of a tile is not recognisable to the optimiser (no peeled second copy of the loop body)
 #endif
 #ifndef SF_PP_ABL
-#define SF_PP_ABL 0                    // throw-away ablation builds (tools/ab_pp.sh): 1 no epilogue, 2 no LDS-DMA in the loop, 4 no MFMA, 8 no stagger, 16 no fragment reads in the loop
+#define SF_PP_ABL 0                    // throw-away ablation builds (tools/ab_pp.sh): 1 no epilogue, 2 no LDS-DMA in the loop, 4 no MFMA, 8 no stagger, 16 no fragment reads in the loop, 64 no B1 reads, 128 no A1 reads (wrong results: what does a lighter LDS read load buy?)
 #endif
 #ifndef SF_PP_STORECNT
 #define SF_PP_STORECNT 1               // first k-tile after an epilogue: allow the epilogue's stores to stay in flight (vmcnt 8 + stores)
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
       bar_b();
       // ---- phase 1: (A0, B1) ----
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) if (rd) b1[kk] = *reinterpret_cast<const bf16x8*>(st + Q_HALF + b_off[kk]);
+      for (int kk = 0; kk < 4; ++kk) { if (SF_PP_ABL & 64) b1[kk] = b0[kk]; else if (rd) b1[kk] = *reinterpret_cast<const bf16x8*>(st + Q_HALF + b_off[kk]); }   // (ABL 64: no B1 fragment reads - a sixth of the LDS read bytes)
       __builtin_amdgcn_sched_barrier(0);
       wait_loads(issue(ic<3>{}, ic<S ^ 1>{}, SURE), first);            // A1(kt+1) issued; A1(kt) landed
       bar_a();
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) if (rd) a[i][kk] = *reinterpret_cast<const bf16x8*>(st + Q_HALF + i * 4096 + a_off[kk]);
+        for (int i = 0; i < 2; ++i) if (rd && !(SF_PP_ABL & 128)) a[i][kk] = *reinterpret_cast<const bf16x8*>(st + Q_HALF + i * 4096 + a_off[kk]);   // (ABL 128: no A1 reads - a third)
       __builtin_amdgcn_sched_barrier(0);
       issue(ic<0>{}, ic<S>{}, SURE);                             // A0(kt+2); phase 3 reads nothing: no wait
       bar_a();
