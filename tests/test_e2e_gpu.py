@@ -138,6 +138,24 @@ def test_forward_through_the_dispatcher(gpu):
         assert torch.equal(direct, disp)
 
 
+@pytest.mark.parametrize('fp8', [False, True])
+def test_forward_soak_bitwise_repeatable(gpu, fp8):
+    """Race screen of the whole default schedule: every kernel of the hot path waits for its LDS-DMA operands with hand-counted `vmcnt` waits that hipcc
+    does not see, and reuses LDS regions one or two phases after their last read.  A mistake there shows up as rare wrong tiles, not as a crash: run the
+    fused (large-batch) forward 25 times on the same inputs - bf16 towers and MXFP8 towers - and require the same bits every time."""
+    from synchformer_amd import synth
+    from synchformer_amd.engine import SynchformerEngine
+    sd = synth.make_state_dict(1337, n_pos=184, n_out=2, head='sync_head') if fp8 else synth.make_state_dict(1337)
+    S = 13 if fp8 else 14
+    eng = SynchformerEngine(sd, gpu, fp8_towers=fp8)
+    u8, aud = synth.make_video_u8(6, S, 11).to(gpu), synth.make_spectrogram(6, S, 11).to(gpu)
+    first_v, first_l = eng.extract_vfeats(u8).clone(), eng.forward(u8, aud).clone()
+    assert torch.isfinite(first_l).all()
+    for rep in range(25):
+        assert torch.equal(eng.forward(u8, aud), first_l), f'logits differ in repetition {rep}'
+    assert torch.equal(eng.extract_vfeats(u8), first_v)
+
+
 def test_oracle_small(gpu):
     """2 segments through both extractors + the sync transformer on random features, vs the CPU oracle."""
     from oracle import synchformer_cpu as O

@@ -285,6 +285,26 @@ def test_avclip_train_steps_reduce_loss(gpu):
     assert 'logit_scale' in ck and any(k.startswith('v_encoder.blocks.0.') for k in ck) and len(ck) == 451 - 2
 
 
+def test_avclip_train_steps_are_deterministic(gpu):
+    """Two trainers from the same weights, seed and inputs take bit-identical steps (no atomics in the gradient path: split-K chunk planes are summed in a fixed
+    order, the counted-wait schedules of sf_gemm_tn_pp / sf_gemm_bf16 have no run-to-run freedom): loss and a sample of the updated weights after 3 steps, at
+    the configured 2 x 14-segment geometry (the big-GEMM paths: config 11, sf_gemm_tn_pp, sf_gemm_bf16_gelu_dual, 16-wave attention backward)."""
+    from synchformer_amd import synth
+    from synchformer_amd.stage1 import AVCLIPTrainer
+    sd = {k: v for k, v in synth.make_state_dict(1337).items() if k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}
+    vis, aud = synth.make_video_u8(2, 14, seed=5).to(gpu), synth.make_spectrogram(2, 14, seed=5).to(gpu)
+    runs = []
+    for _ in range(2):
+        tr = AVCLIPTrainer(sd, gpu, lr=1e-4, drop_path_rate=0.2, seed=99)
+        losses = [float(tr.train_step(vis, aud)) for _ in range(3)]
+        probe = torch.cat([tr.flat_p[:4096], tr.flat_p[tr.flat_p.numel() // 2: tr.flat_p.numel() // 2 + 4096], tr.flat_p[-4096:]]).clone()
+        runs.append((losses, probe))
+        del tr
+        torch.cuda.empty_cache()
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1])
+
+
 def test_avclip_dropin_training_loop(gpu):
     """The reference's Stage-1 loop body (train_clip_src/training/train.py:103-154) on the drop-in module: scaled loss.backward(),
     unscale, clip_grad_norm_, torch.optim.AdamW - gradients arrive on the nn.Parameters through the autograd bridge."""
