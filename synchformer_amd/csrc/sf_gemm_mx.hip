@@ -494,26 +494,29 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_pp_kernel(MxArgs p) {
   const uint32_t lds_sc_w = lds0 + MQ_SCALE_OFF + wave * 256;      // + stage * 2048: [A rows 0-255 | W rows 0-255] dwords
   const uint32_t lane4 = (uint32_t)lane * 4u;
   // PART: 0 = A0 (+ the k-tile's scale piece), 1 = B0, 2 = B1, 3 = A1
+  // Branch-free (as sf_gemm_pp.hip's SLIM): the k-tile bases run along (curA / curW / curS); a DRY iterator (last k-tiles of the workgroup's last tile) keeps
+  // issuing - the same pieces of the last valid k-tile into the ring buffers that are free for a refill by construction - so that every counted wait keeps
+  // its count and no read segment carries an `issued` branch; vmcnt(0) in front of that tile's epilogue retires them before the workgroup can end
+  const char* curA = nullptr; const char* curW = nullptr; const char* curS = nullptr;
   auto issue = [&](auto PARTc, auto STc) -> bool {
     constexpr int PART = decltype(PARTc)::value, ST = decltype(STc)::value;
     constexpr bool isA = PART == 0 || PART == 3;
     constexpr int h = PART >= 2 ? 1 : 0;
-    const bool did = ld_ok;
-    if (did) {
-      const uint32_t l = lds_wave + ST * MQ_STAGE + (isA ? h : 2 + h) * MQ_HALF;
-      if (isA) mq_dma2(oA[h][0], oA[h][1], ldA + (int64_t)ld_kt * 128, l);
-      else mq_dma2(oW[h][0], oW[h][1], ldW + (int64_t)ld_kt * 128, l);
-      if (PART == 0) mq_dma_dword(lane4, ldS + (int64_t)ld_kt * ld_sstep, lds_sc_w + ST * 2048);
-      if (PART == 3) {
-        if (++ld_kt == nk) {
-          ld_kt = 0;
-          ld_t += per_xcd_blocks;
-          ld_ok = ld_t < t_end;
-          if (ld_ok) ld_set(ld_t);
-        }
+    const uint32_t l = lds_wave + ST * MQ_STAGE + (isA ? h : 2 + h) * MQ_HALF;
+    if (isA) mq_dma2(oA[h][0], oA[h][1], curA, l);
+    else mq_dma2(oW[h][0], oW[h][1], curW, l);
+    if (PART == 0) mq_dma_dword(lane4, curS, lds_sc_w + ST * 2048);
+    if (PART == 3 && ld_ok) {
+      if (++ld_kt == nk) {
+        ld_kt = 0;
+        ld_t += per_xcd_blocks;
+        ld_ok = ld_t < t_end;
+        if (ld_ok) { ld_set(ld_t); curA = ldA; curW = ldW; curS = ldS; }
+      } else {
+        curA += 128; curW += 128; curS += ld_sstep;
       }
     }
-    return did;
+    return true;
   };
 
   uint32_t t = li;
@@ -533,6 +536,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_pp_kernel(MxArgs p) {
   };
 
   ld_set(ld_t);
+  curA = ldA; curW = ldW; curS = ldS;
   issue_bias(n0);
   issue(mq_ic<0>{}, mq_ic<0>{}); issue(mq_ic<1>{}, mq_ic<0>{}); issue(mq_ic<2>{}, mq_ic<0>{}); issue(mq_ic<3>{}, mq_ic<0>{});
   issue(mq_ic<0>{}, mq_ic<1>{}); issue(mq_ic<1>{}, mq_ic<1>{});
@@ -663,6 +667,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_pp_kernel(MxArgs p) {
     }
     if (wm == 0) mq_barrier();
 
+    if (!ld_ok) mq_wait_vmcnt<0>();                                // a dry iterator's pieces must have landed before this workgroup's LDS can be handed on
     const int64_t em0 = m0; const int en0 = n0;
     extra = 0;
     if (en0 + wn * 64 < p.N) {
