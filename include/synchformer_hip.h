@@ -310,6 +310,9 @@ int sf_meanpool_l2norm768_bwd(const float* x, int64_t ldx, int t, const float* d
  * [sample0 + s*seg_stride, +n_samples) of wave (n_clips, clip_samples).  Reflect padding of the STFT stays inside a segment. */
 int sf_im2col_video_clips(const void* vid, int dtype, int64_t n_clips, int64_t clip_frames, int frame0, int seg_stride, int n_seg,
                           uint16_t* out, void* stream);
+/* ... into the TOKEN layout: out bf16 (n_clips * n_seg * 1569, 1536), segment n's 1568 patch rows at n * 1569 + 1 .., its row 0 (the CLS slot) zeroed - the
+ * patch-embedding GEMM (Conv3d of PatchEmbed3D, motionformer.py) then runs with identity row maps straight onto the (n * 1569, 768) token matrix. */
+int sf_im2col_video_tokens(const void* vid, int dtype, int64_t n_clips, int64_t clip_frames, int frame0, int seg_stride, int n_seg, uint16_t* out, void* stream);
 int sf_mel_frontend_clips(const float* wave, int64_t n_clips, int64_t clip_samples, int64_t sample0, int64_t seg_stride, int n_seg,
                           int n_samples, int hop, const float* tw_cos, const float* tw_sin, const float* fb, const int* fb_lo,
                           const int* fb_hi, int n_mels, float* power_ws, float* out, int pad_to, float mean, float std, void* stream);

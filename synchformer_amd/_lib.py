@@ -71,6 +71,7 @@ SIGNATURES = {
                              _i32, _f32, _i32, _ptr],
     'sf_meanpool_l2norm768_bwd': [_ptr, _i64, _i32, _ptr, _i64, _ptr, _i64, _i32, _i64, _ptr],
     'sf_im2col_video_clips': [_ptr, _i32, _i64, _i64, _i32, _i32, _i32, _ptr, _ptr],
+    'sf_im2col_video_tokens': [_ptr, _i32, _i64, _i64, _i32, _i32, _i32, _ptr, _ptr],
     'sf_mel_frontend_clips': [_ptr, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _i32, _f32, _f32, _ptr],
     'sf_token_mask_video': [_ptr, _i64, _ptr, _ptr, _ptr],
     'sf_token_mask_spec': [_ptr, _i64, _i32, _i32, _ptr, _ptr, _ptr],

@@ -320,11 +320,20 @@ __device__ __forceinline__ void load16(const void* p, float* f) {
 }
 
 template <int DT>
+// tok_rows: rows per segment of `out` - 1568 (patch rows only) or 1569 = TOKEN layout: segment n's patches at rows n*1569 + 1 .., row n*1569 (the CLS
+// slot) zeroed by 96 extra runs per segment, so that the patch-embedding GEMM runs with identity row maps on the persistent kernel (the CLS rows multiply zeros)
 __global__ __launch_bounds__(256) void im2col_video_kernel(const void* __restrict__ vid, bf16_t* __restrict__ out,
-                                                            int64_t total_runs, int n_seg_clip, int64_t clip_frames, int frame0, int seg_stride) {
+                                                            int64_t total_runs, int n_seg_clip, int64_t clip_frames, int frame0, int seg_stride, int tok_rows) {
   // run index = (((n*8 + f)*2 + dt)*3 + c)*224*14 + (h*16+dh)*14 + w   (walks memory order of `vid` per frame)
   const int64_t run = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (run >= total_runs) return;
+  if (run >= total_runs) {
+    const int64_t z = run - total_runs, n_total = total_runs / (16 * 3 * 224 * 14);
+    if (tok_rows == 1569 && z < n_total * 96) {
+      uint4* dst = reinterpret_cast<uint4*>(out + (z / 96) * 1569 * 1536 + (z % 96) * 16);
+      dst[0] = make_uint4(0u, 0u, 0u, 0u); dst[1] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    return;
+  }
   const int w = (int)(run % 14);
   int64_t t = run / 14;
   const int y = (int)(t % 224); t /= 224;
@@ -340,7 +349,7 @@ __global__ __launch_bounds__(256) void im2col_video_kernel(const void* __restric
   float v[16];
   load16<DT>(reinterpret_cast<const char*>(vid) + src * esz, v);
   const int h = y >> 4, dh = y & 15;
-  const int64_t row = n * 1568 + f * 196 + h * 14 + w;
+  const int64_t row = n * tok_rows + (tok_rows - 1568) + f * 196 + h * 14 + w;
   const int col = ((c * 2 + dt) * 16 + dh) * 16;
   uint4 o0, o1;
   o0.x = pack_bf2(v[0], v[1]); o0.y = pack_bf2(v[2], v[3]); o0.z = pack_bf2(v[4], v[5]); o0.w = pack_bf2(v[6], v[7]);
@@ -350,15 +359,15 @@ __global__ __launch_bounds__(256) void im2col_video_kernel(const void* __restric
 }
 
 static int launch_im2col_video(const void* vid, int dtype, bf16_t* out, int64_t n_seg, int n_seg_clip, int64_t clip_frames, int frame0, int seg_stride,
-                               hipStream_t s) {
+                               hipStream_t s, int tok_rows = 1568) {
   const int64_t total = n_seg * 16 * 3 * 224 * 14;
   if (total <= 0) return 0;
-  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  dim3 grid((unsigned)((total + (tok_rows == 1569 ? n_seg * 96 : 0) + 255) / 256)), block(256);
   switch (dtype) {
-    case SF_F32: hipLaunchKernelGGL((im2col_video_kernel<SF_F32>), grid, block, 0, s, vid, out, total, n_seg_clip, clip_frames, frame0, seg_stride); break;
-    case SF_BF16: hipLaunchKernelGGL((im2col_video_kernel<SF_BF16>), grid, block, 0, s, vid, out, total, n_seg_clip, clip_frames, frame0, seg_stride); break;
-    case SF_F16: hipLaunchKernelGGL((im2col_video_kernel<SF_F16>), grid, block, 0, s, vid, out, total, n_seg_clip, clip_frames, frame0, seg_stride); break;
-    default: hipLaunchKernelGGL((im2col_video_kernel<SF_U8>), grid, block, 0, s, vid, out, total, n_seg_clip, clip_frames, frame0, seg_stride); break;
+    case SF_F32: hipLaunchKernelGGL((im2col_video_kernel<SF_F32>), grid, block, 0, s, vid, out, total, n_seg_clip, clip_frames, frame0, seg_stride, tok_rows); break;
+    case SF_BF16: hipLaunchKernelGGL((im2col_video_kernel<SF_BF16>), grid, block, 0, s, vid, out, total, n_seg_clip, clip_frames, frame0, seg_stride, tok_rows); break;
+    case SF_F16: hipLaunchKernelGGL((im2col_video_kernel<SF_F16>), grid, block, 0, s, vid, out, total, n_seg_clip, clip_frames, frame0, seg_stride, tok_rows); break;
+    default: hipLaunchKernelGGL((im2col_video_kernel<SF_U8>), grid, block, 0, s, vid, out, total, n_seg_clip, clip_frames, frame0, seg_stride, tok_rows); break;
   }
   return 0;
 }
@@ -378,6 +387,19 @@ extern "C" int sf_im2col_video_clips(const void* vid, int dtype, int64_t n_clips
   SF_CHECK_ARG(n_seg >= 1 && frame0 >= 0 && seg_stride >= 0 && frame0 + (int64_t)(n_seg - 1) * seg_stride + 16 <= clip_frames,
                "sf_im2col_video_clips: segments [%d + s*%d, +16) do not fit %lld frames", frame0, seg_stride, (long long)clip_frames);
   launch_im2col_video(vid, dtype, out, n_clips * n_seg, n_seg, clip_frames, frame0, seg_stride, (hipStream_t)stream);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// The same gather into the TOKEN layout: out bf16 (n_clips * n_seg * 1569, 1536), row 0 of every segment zero (see im2col_video_kernel).  n_seg = 1,
+// clip_frames = 16, frame0 = seg_stride = 0 is the plain per-segment input of sf_im2col_video.
+extern "C" int sf_im2col_video_tokens(const void* vid, int dtype, int64_t n_clips, int64_t clip_frames, int frame0, int seg_stride, int n_seg, bf16_t* out,
+                                      void* stream) {
+  SF_CHECK_ARG(vid && out, "sf_im2col_video_tokens: null pointer");
+  SF_CHECK_ARG(dtype >= 0 && dtype <= 3, "sf_im2col_video_tokens: bad dtype %d", dtype);
+  SF_CHECK_ARG(n_seg >= 1 && frame0 >= 0 && seg_stride >= 0 && frame0 + (int64_t)(n_seg - 1) * seg_stride + 16 <= clip_frames,
+               "sf_im2col_video_tokens: segments [%d + s*%d, +16) do not fit %lld frames", frame0, seg_stride, (long long)clip_frames);
+  launch_im2col_video(vid, dtype, out, n_clips * n_seg, n_seg, clip_frames, frame0, seg_stride, (hipStream_t)stream, 1569);
   SF_LAUNCH_CHECK();
   return 0;
 }

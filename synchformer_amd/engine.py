@@ -78,6 +78,7 @@ class SynchformerEngine:
         # fp8_towers: the six big Linears of every visual block run on MXFP8 operands (sf_gemm_mxfp8) - the frozen-extractor mode of the
         # synchronizability fine-tune (BASELINE configs[4]).  Off (bf16) for every other workload: inference parity bars are stated for bf16.
         self.fp8_towers = bool(fp8_towers)
+        self.pe_tokens = os.environ.get('SF_PE_TOKENS', '1') != '0'      # patch embedding on the token layout (identity row maps, persistent GEMM)
         self.fuse_mx_time = True                     # fp8 towers: sf_qkv_time_attention_mx instead of sf_gemm_mxfp8 + the time attention kernels
         self.fuse_mx_ln = True                       # fp8 towers: sf_gemm_mx_res_ln768 instead of sf_gemm_mxfp8 + sf_layernorm768_mxfp8 (tests switch it off to compare)
         self.capture_blocks = None          # tests: a dict -> the fp32 residual stream after each visual block is cloned into it (key = block index)
@@ -108,6 +109,8 @@ class SynchformerEngine:
         pos, temp = f32(f'{v}.pos_embed')[0], f32(f'{v}.temp_embed')[0]
         body = (pos[1:].unsqueeze(0) + temp.unsqueeze(1)).reshape(-1, D)       # row f*196+n (vmb:248-254)
         self.v_table = torch.cat([pos[:1] + f32(f'{v}.cls_token')[0], body], 0).contiguous()   # (1569, 768)
+        self.v_table_pe = self.v_table.clone()                                                   # ... for the token-layout patch embedding (extract_vfeats): its
+        self.v_table_pe[0] -= self.v_pe.b                                                        # GEMM adds the bias to the CLS rows as well
         self.v_blocks = []
         i = 0
         while f'{v}.blocks.{i}.norm1.weight' in sd:
@@ -257,14 +260,26 @@ class SynchformerEngine:
         X = self._buf('X', rows * D, torch.float32).view(rows, D)
         xn = self._buf('XN', n * 8 * AGG_V * D, torch.bfloat16)[:rows * D].view(rows, D)
         big = self._buf('BIG', n * 8 * AGG_V * FF, torch.bfloat16)
-        patches = big[:n * VIS_P * 1536].view(n * VIS_P, 1536)
-        if clip_seg is None:
-            ops.im2col_video(vid, patches)
+        if rows >= 128 * 64 and self.pe_tokens:
+            # patches in the TOKEN layout (a zero row in every segment's CLS slot): the patch-embedding GEMM runs with identity row maps on the persistent kernel
+            # (with the row maps it took the 128 x 128 kernel: 1.5 ms per 224-segment launch at 0.55 PFLOP/s).  The CLS rows come out as table + 0 W + bias; the
+            # table copy used here has the bias taken off its CLS entry
+            patches = big[:rows * 1536].view(rows, 1536)
+            if clip_seg is None:
+                ops.im2col_video_tokens(vid, patches)
+            else:
+                ops.im2col_video_tokens(vid, patches, *clip_seg)
+            ops.broadcast_rows(X, self.v_table_pe, n_seq=n, dst_seq_rows=VIS_L)
+            ops.gemm(patches, self.v_pe.w, self.v_pe.b, X, residual=X)
         else:
-            ops.im2col_video_clips(vid, patches, *clip_seg)
-        ops.broadcast_rows(X, self.v_table, n_seq=n, dst_seq_rows=VIS_L)
-        tokmap = ops.rowmap(VIS_P, VIS_P, VIS_L, 0, 1, 1)
-        ops.gemm(patches, self.v_pe.w, self.v_pe.b, X, residual=X, c_map=tokmap, r_map=tokmap)
+            patches = big[:n * VIS_P * 1536].view(n * VIS_P, 1536)
+            if clip_seg is None:
+                ops.im2col_video(vid, patches)
+            else:
+                ops.im2col_video_clips(vid, patches, *clip_seg)
+            ops.broadcast_rows(X, self.v_table, n_seq=n, dst_seq_rows=VIS_L)
+            tokmap = ops.rowmap(VIS_P, VIS_P, VIS_L, 0, 1, 1)
+            ops.gemm(patches, self.v_pe.w, self.v_pe.b, X, residual=X, c_map=tokmap, r_map=tokmap)
         qkv = big[:rows * 3 * D].view(rows, 3 * D)
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         hid = big[:rows * FF].view(rows, FF)

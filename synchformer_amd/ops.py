@@ -222,6 +222,15 @@ def im2col_video_clips(vid: torch.Tensor, out: torch.Tensor, frame0: int, seg_st
     return out
 
 
+def im2col_video_tokens(vid: torch.Tensor, out: torch.Tensor, frame0: int = 0, seg_stride: int = 0, n_seg: int = 1):
+    """im2col_video / im2col_video_clips into the TOKEN layout: out bf16 (segments * 1569, 1536), every segment's row 0 zero, its patches at rows 1 .. 1568."""
+    assert vid.is_contiguous() and vid.dim() == 5 and tuple(vid.shape[2:]) == (3, 224, 224)
+    assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.shape[1] == 1536 and out.shape[0] >= vid.shape[0] * n_seg * 1569
+    rc = _lib.load().sf_im2col_video_tokens(_dev(vid, 'vid'), _DT[vid.dtype], vid.shape[0], vid.shape[1], frame0, seg_stride, n_seg, _dev(out, 'out'), _stream())
+    _lib.check(rc, 'sf_im2col_video_tokens')
+    return out
+
+
 def im2col_spec(spec: torch.Tensor, out: torch.Tensor):
     """spec fp32 (n_seg, F, Ta) contiguous -> out bf16 (n_seg*nf*nt, 256)."""
     assert spec.is_contiguous() and spec.dtype == torch.float32 and spec.dim() == 3

@@ -586,6 +586,27 @@ def test_qkv_time_attention(gpu, n_seq):
     torch.testing.assert_close(o[:, 1:], po, rtol=2 ** -7, atol=2 ** -7)
 
 
+def test_im2col_video_tokens(gpu):
+    """sf_im2col_video_tokens = sf_im2col_video / _clips with every segment's 1568 patch rows at rows 1 .. 1568 of a 1569-row block whose row 0 is zeroed
+    (whatever the buffer held before): bit-identical patch rows, for the per-segment input and for segments read in place from un-segmented clips."""
+    from synchformer_amd import ops
+    g = torch.Generator().manual_seed(7)
+    vid = torch.randint(0, 256, (3, 16, 3, 224, 224), generator=g, dtype=torch.uint8).to(gpu)
+    ref = torch.empty(3 * 1568, 1536, device=gpu, dtype=torch.bfloat16)
+    ops.im2col_video(vid, ref)
+    tok = torch.full((3 * 1569 + 2, 1536), 5.0, device=gpu, dtype=torch.bfloat16)
+    ops.im2col_video_tokens(vid, tok)
+    t3 = tok[:3 * 1569].view(3, 1569, 1536)
+    assert torch.equal(t3[:, 1:].reshape(-1, 1536), ref) and (t3[:, 0] == 0).all() and (tok[3 * 1569:] == 5.0).all()
+    clips = torch.randint(0, 256, (2, 40, 3, 224, 224), generator=g, dtype=torch.uint8).to(gpu)
+    ref2 = torch.empty(2 * 4 * 1568, 1536, device=gpu, dtype=torch.bfloat16)
+    ops.im2col_video_clips(clips, ref2, 2, 7, 4)
+    tok2 = torch.full((2 * 4 * 1569, 1536), 5.0, device=gpu, dtype=torch.bfloat16)
+    ops.im2col_video_tokens(clips, tok2, 2, 7, 4)
+    t8 = tok2.view(8, 1569, 1536)
+    assert torch.equal(t8[:, 1:].reshape(-1, 1536), ref2) and (t8[:, 0] == 0).all()
+
+
 @pytest.mark.parametrize('n_seq', [3, 40])
 def test_qkv_time_attention_mx(gpu, n_seq):
     """sf_qkv_time_attention_mx against the un-fused MX sequence it replaces: sf_gemm_mxfp8 (bf16 output) -> sf_attention (time groups, CLS key first) +
