@@ -42,7 +42,10 @@ def main():
                 t['fused'].append(timeit(lambda: ops.gemm_res_ln(a, w, b, x, g, bt, y, 1e-6)))
                 t['fused_k'].append(timeit(lambda: ops.gemm_res_ln(a, wk, b, x, g, bt, y, 1e-6)))
                 lib.sf_gemm_res_ln_force_schedule(0)
-                t['r2_k'].append(timeit(lambda: ops.gemm_res_ln(a, wk, b, x, g, bt, y, 1e-6)))
+                try:                                                   # (ablation builds exist for one schedule or the other)
+                    t['r2_k'].append(timeit(lambda: ops.gemm_res_ln(a, wk, b, x, g, bt, y, 1e-6)))
+                except RuntimeError:
+                    t['r2_k'].append(float('nan'))
                 lib.sf_gemm_res_ln_force_schedule(-1)
                 x.normal_()
             med = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
