@@ -211,11 +211,17 @@ class AVCLIPTrainer(FlatTrainer):
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         kw = dict(n_groups=196, row0=1, group_stride=1, tok_stride=196, n_tok=8) if kind == 'time' else \
             dict(n_groups=8, row0=1, group_stride=196, tok_stride=1, n_tok=196)
-        # the CLS query's attention over all 1569 keys (vit_helper.py:126) rides in the group kernels as per-group softmax partials, merged by a tiny combine
-        # launch - as in the inference engine - instead of a second pass over K / V (sf_attention_cls)
-        part = self._buf('cls_part', (n * H * 196 * 66,), torch.float32)
-        ops.attention_cls_partial(q, k, v, att, part, n_seq=n, seq_rows=VIS_L, cls_row=0, heads=H, head_dim=HD, scale=0.125, **kw)
-        ops.attention_cls_combine(part, att, n_part=kw['n_groups'], n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=H)
+        if kind == 'space':
+            # the CLS query's attention over all 1569 keys (vit_helper.py:126) rides in the space kernel as 8 per-frame softmax partials, merged by a tiny combine
+            # launch - as in the inference engine - instead of a second pass over K / V (sf_attention_cls).  Not for the time groups: 196 partial records per
+            # (segment, head) make the combine launch slower than the pass it replaces (59 us against 44 us, profiled)
+            part = self._buf('cls_part', (n * H * 8 * 66,), torch.float32)
+            ops.attention_cls_partial(q, k, v, att, part, n_seq=n, seq_rows=VIS_L, cls_row=0, heads=H, head_dim=HD, scale=0.125, **kw)
+            ops.attention_cls_combine(part, att, n_part=8, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=H)
+            return
+        ops.attention(q, k, v, att, n_seq=n, seq_rows=VIS_L, cls_row=0, heads=H, head_dim=HD, scale=0.125, **kw)
+        ops.attention_cls(q, k, v, att, n_seq=n, q_seq_rows=VIS_L, q_row=0, kv_seq_rows=VIS_L, kv_row0=0, n_keys=VIS_L,
+                          out_seq_rows=VIS_L, out_row=0, heads=H, head_dim=HD, scale=0.125)
 
     def _attn_bwd_chunked(self, Gq, GdO, Gd, nseq, Lg):
         step = max(1, 60000 // H)                                 # batched-GEMM grids take < 65536 (sequence, head) pairs
