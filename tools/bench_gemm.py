@@ -8,6 +8,7 @@ from synchformer_amd import ops, _lib
 
 dev = torch.device('cuda:0')
 import os
+ITERS = int(os.environ.get('ITERS', '6'))
 CFGS = tuple(int(c) for c in os.environ.get('CFGS', '7,11').split(','))
 lib = _lib.load()
 
@@ -43,6 +44,8 @@ def main():
                 continue
             a = torch.randn(M, K, device=dev).bfloat16()
             w = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
+            if os.environ.get('DATA') == 'zero':       # all-zero operands: the same instruction stream at a fraction of the switching power (is the kernel power-limited?)
+                a.zero_(); w.zero_()
             b = torch.randn(N, device=dev)
             out = torch.zeros(M, N, device=dev, dtype=out_dt)
             line = f'{name:9s} N {N:4d} K {K:4d}: '
@@ -51,7 +54,7 @@ def main():
             for _ in range(int(os.environ.get('ROUNDS', '7'))):
                 for cfg in CFGS:
                     lib.sf_gemm_force_config(cfg)
-                    times[cfg].append(timeit(lambda: ops.gemm(a, w, b, out, gelu=gelu, residual=out if res else None), iters=6))
+                    times[cfg].append(timeit(lambda: ops.gemm(a, w, b, out, gelu=gelu, residual=out if res else None), iters=ITERS))
             for cfg in CFGS:
                 us = sorted(times[cfg])[len(times[cfg]) // 2]
                 line += f' c{cfg} {us:6.1f}us {2.0 * M * N * K / us / 1e6:5.0f}TF |'
