@@ -423,7 +423,11 @@ template <int V> using mq_ic = std::integral_constant<int, V>;
 template <int OUT, bool GELU, bool HAS_RES>
 __global__ __launch_bounds__(512, 2) void gemm_mxfp8_pp_kernel(MxArgs p) {
   constexpr bool OUT_BF16 = OUT == 1;
-  constexpr int EPI_VM = OUT == 2 ? 54 : 32;                     // vector-memory operations of one epilogue (OUT 2: 64, capped by the 6-bit counter: 9 + 54 = 63)
+  // WIDEMX (MXFP8 output without residual - fc1 + GELU): the accumulator blocks are computed TRANSPOSED (W fragment as the A operand: lanes = tokens, a lane's 16
+  // registers = 16 of the 32 features of one scale block, the lane 32 away holds the other 16), so that the quantisation needs one cross-lane step per block and no
+  // fp32 staging (the fp8 bytes alone pass through the slab, 2 KiB per 32 tokens): 8 row stores of 16 bytes + 4 scale stores of 2 bytes per wave instead of 32 + 32 (was 1370 us for fc1 of the 13-segment batch against 677 for qkv)
+  constexpr bool WIDEMX = OUT == 2 && !HAS_RES;
+  constexpr int EPI_VM = WIDEMX ? 12 : (OUT == 2 ? 54 : 32);     // vector-memory operations of one epilogue (OUT 2 with residual: 64, capped by the 6-bit counter: 9 + 54 = 63)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -578,7 +582,8 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_pp_kernel(MxArgs p) {
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          acc[HA * 2 + i][HB] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i][kk], bf[kk], acc[HA * 2 + i][HB], 0, 0, 0, sav[i][kk], 0, sbv[kk]);
+          acc[HA * 2 + i][HB] = WIDEMX ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bf[kk], a[i][kk], acc[HA * 2 + i][HB], 0, 0, 0, sbv[kk], 0, sav[i][kk])
+                                       : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i][kk], bf[kk], acc[HA * 2 + i][HB], 0, 0, 0, sav[i][kk], 0, sbv[kk]);
       // the MFMAs are pure to the optimiser: with the run-time branches of the read segments around, LLVM sinks them towards their next use (the next
       // k-tile's MFMAs on the same accumulator) - out of the matrix segment, with every fragment live across phases; an opaque use pins them here
       asm volatile("" : "+v"(acc[HA * 2][HB]), "+v"(acc[HA * 2 + 1][HB]));
@@ -670,7 +675,77 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_pp_kernel(MxArgs p) {
     if (!ld_ok) mq_wait_vmcnt<0>();                                // a dry iterator's pieces must have landed before this workgroup's LDS can be handed on
     const int64_t em0 = m0; const int en0 = n0;
     extra = 0;
-    if (en0 + wn * 64 < p.N) {
+    if (WIDEMX) {
+      if (en0 + wn * 64 < p.N) {
+        extra = 1;
+        int etid = threadIdx.x;
+        asm volatile("" : "+v"(etid));
+        const int el = etid & 63, el31 = el & 31, ehi = el >> 5;
+        float4 bia[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            bia[j][g] = has_bias ? *reinterpret_cast<const float4*>(bslab + (j * 32 + g * 8 + ehi * 4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);   // landed long ago
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the slab is reused below
+        const int64_t row0 = em0 + wm * 128 + el31;
+        const int colblock = (en0 + wn * 64) >> 5;                                    // even: the wave's two scale bytes of a row are adjacent
+        const uint32_t sc_base = (uint32_t)((int64_t)(colblock >> 2) * p.ldsc + (colblock & 3));
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+          const int64_t row = row0 + ib * 32;
+          uint32_t be2 = 0;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            float f[16];
+            float amax = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              sf_f32x2_t g0 = {acc[ib][j][g * 4 + 0] + bia[j][g].x, acc[ib][j][g * 4 + 1] + bia[j][g].y};
+              sf_f32x2_t g1 = {acc[ib][j][g * 4 + 2] + bia[j][g].z, acc[ib][j][g * 4 + 3] + bia[j][g].w};
+              if (GELU) gelu_erf4(g0, g1);
+              const uint32_t p01 = pack_bf2(g0.x, g0.y), p23 = pack_bf2(g1.x, g1.y);   // quantised from the bf16-rounded value, as sf_quantize_mxfp8 would
+              f[g * 4 + 0] = __uint_as_float(p01 << 16); f[g * 4 + 1] = __uint_as_float(p01 & 0xffff0000u);
+              f[g * 4 + 2] = __uint_as_float(p23 << 16); f[g * 4 + 3] = __uint_as_float(p23 & 0xffff0000u);
+              amax = fmaxf(fmaxf(amax, fmaxf(fabsf(f[g * 4 + 0]), fabsf(f[g * 4 + 1]))), fmaxf(fabsf(f[g * 4 + 2]), fabsf(f[g * 4 + 3])));
+            }
+            {                                                                          // the block's other 16 values live in the lane 32 away
+              const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
+              amax = fmaxf(__uint_as_float(sw2[0]), __uint_as_float(sw2[1]));
+            }
+            int be = (int)((__float_as_uint(amax) >> 23) & 0xff) - 8;
+            be = be < 1 ? 1 : (be > 254 ? 254 : be);
+            const float inv = __uint_as_float((uint32_t)(254 - be) << 23);
+            be2 |= (uint32_t)be << (8 * j);
+            uint32_t d[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f[g * 4 + 0] * inv, 448.f, -448.f), __builtin_amdgcn_fmed3f(f[g * 4 + 1] * inv, 448.f, -448.f), 0, false);
+              w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f[g * 4 + 2] * inv, 448.f, -448.f), __builtin_amdgcn_fmed3f(f[g * 4 + 3] * inv, 448.f, -448.f), w, true);
+              d[g] = (uint32_t)w;
+            }
+            // lanes 0-31 hold features g * 8 + 0..3, lanes 32-63 g * 8 + 4..7: permlane32_swap(x, z) = {x.lo | z.lo, x.hi | z.hi} puts features 0..15 of the block into
+            // the low lane and 16..31 into the high lane, in order
+            const auto s02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+            const auto s13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+            mx_u32x4 o; o.x = s02[0]; o.y = s02[1]; o.z = s13[0]; o.w = s13[1];
+            // through the wave's 2-KiB slab (32 tokens x 64 bytes, 16-byte chunk c of row t at slot c ^ ((t >> 1) & 3)): stored from the registers a row would go
+            // out as 32-byte pieces, 32 write requests per instruction (measured: slower than the 4-byte stores it replaced); from the slab a store is 16 rows x 64 bytes
+            *reinterpret_cast<mx_u32x4*>(bslab + el31 * 64 + (((j * 2 + ehi) ^ ((el31 >> 1) & 3)) << 4)) = o;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int tr = h * 16 + (el >> 2);
+            const mx_u32x4 o = *reinterpret_cast<const mx_u32x4*>(bslab + tr * 64 + (((el & 3) ^ ((tr >> 1) & 3)) << 4));
+            __builtin_amdgcn_raw_buffer_store_b128(o, rc, (uint32_t)((em0 + wm * 128 + ib * 32 + tr) * p.ldc + en0 + wn * 64 + (el & 3) * 16), 0, SF_MX_STORE_AUX);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          // the row's two scale bytes (blocks j = 0, 1) from the low lane; the high lane and rows >= M (they would land in the next plane) get an offset the range check drops
+          __builtin_amdgcn_raw_buffer_store_b16((unsigned short)be2, rsc, (ehi == 0 && row < p.M) ? sc_base + (uint32_t)row * 4u : 0xffffffffu, 0, 0);
+        }
+      }
+    } else if (en0 + wn * 64 < p.N) {
       extra = 1;
       int etid = threadIdx.x;
       asm volatile("" : "+v"(etid));
