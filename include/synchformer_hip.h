@@ -184,6 +184,15 @@ int sf_attention_cls_partial(const uint16_t* q, const uint16_t* k, const uint16_
 /* Merge those partials: out[seq*out_seq_rows + out_row, head*64 + d] = sum_p o_p[d] 2^(m_p-M) / sum_p l_p 2^(m_p-M). */
 int sf_attention_cls_combine(const float* partials, int n_part, uint16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row,
                              int64_t n_seq, int heads, void* stream);
+/* The two above writing MXFP8 - e4m3 bytes out_q (rows, heads * 64), row stride ldq bytes, and E8M0 bytes out_s in the scale planes [heads * 64 / 128][rows][4]
+ * (plane stride splane bytes): the A-operand layout of sf_gemm_mxfp8 / sf_gemm_mx_res_ln768.  Bytes and scales equal sf_quantize_mxfp8 applied to the bf16 output
+ * of sf_attention_cls_partial / sf_attention_cls_combine (the fine-tuning forward's attention output is only ever that operand).  head_dim 64, an even number of
+ * heads; sf_attention_cls_partial_mx: 192 <= n_tok <= 207 (the 13-key-tile space attention of DividedSpaceTimeBlock, vit_helper.py:368). */
+int sf_attention_cls_partial_mx(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld, uint8_t* out_q, int64_t ldq, uint8_t* out_s, int64_t splane,
+                                int64_t n_seq, int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok, int cls_row, int heads,
+                                float scale, float* cls_partial, void* stream);
+int sf_attention_cls_combine_mx(const float* partials, int n_part, uint8_t* out_q, int64_t ldq, uint8_t* out_s, int64_t splane, int64_t out_seq_rows, int out_row,
+                                int64_t n_seq, int heads, void* stream);
 
 /* The temporal half of DividedSpaceTimeBlock in ONE launch (vit_helper.py:366 `self.timeattn(self.norm3(x), ..., 'b (f n) d', '(b n) f d')`,
  * DividedAttention.forward vit_helper.py:97-150): qkv projection (vit_helper.py:107) of every PATCH token + the 8-frame attention over

@@ -25,6 +25,9 @@ struct AttnArgs {
   float* cls_part;
   // optional key mask (vis_mask / aud_mask token masks, vit_helper.py:34-42): key_keep[row] == 0 -> that K/V row gets -inf
   const uint8_t* key_keep;
+  // optional MXFP8 output (attn_mfma_kernel<64, 13, true>, sf_attention_cls_partial_mx): e4m3 bytes (rows, heads * 64) + one E8M0 byte per row and 32 columns in
+  // the scale planes [heads * 64 / 128][rows][4] (plane stride `splane` bytes) - the A operand layout of sf_gemm_mxfp8 / sf_gemm_mx_res_ln768
+  uint8_t* out_q = nullptr; int64_t ldq = 0; uint8_t* out_s = nullptr; int64_t splane = 0;
 };
 
 // ======================================================================================================
@@ -691,8 +694,21 @@ __device__ __forceinline__ uint4 att_ld16(const bf16_t* p) {
   return *reinterpret_cast<const uint4*>(p);
 }
 
-template <int D, int NKT>
+// e4m3 bytes of four bf16-exact values scaled by `inv` (a power of two), as sf_quantize_mxfp8 produces them
+__device__ __forceinline__ uint32_t att_fp8x4(const float* f, float inv) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f[0] * inv, 448.f, -448.f), __builtin_amdgcn_fmed3f(f[1] * inv, 448.f, -448.f), 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f[2] * inv, 448.f, -448.f), __builtin_amdgcn_fmed3f(f[3] * inv, 448.f, -448.f), w, true);
+  return (uint32_t)w;
+}
+// E8M0 byte of a block with absolute maximum `amax` (>= 0): exponent - 8 (448 = 1.75 * 2^8), clamped to [1, 254] - sf_quantize_mxfp8's rule
+__device__ __forceinline__ int att_mx_exp(float amax) {
+  const int be = (int)((__float_as_uint(amax) >> 23) & 0xff) - 8;
+  return be < 1 ? 1 : (be > 254 ? 254 : be);
+}
+
+template <int D, int NKT, bool MXO = false>
 __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
+  static_assert(!MXO || D == 64, "the MXFP8 output is written per 64-wide head");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_lds = smem;
   char* v_lds = smem + AttLds<D>::K_BYTES;
@@ -887,6 +903,36 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[2 + dt * 16 + fg * 4 + r] = o[dt][r];
     }
+    if constexpr (MXO) {
+      // MXFP8 output: the head's 64 dims are two scale blocks; block b = dim tiles 2b, 2b + 1, 8 values in this lane and 8 in each of the lanes fg' != fg of
+      // the same query (16 and 32 lanes away).  Quantised from the bf16-rounded value, exactly as sf_quantize_mxfp8 would from the bf16 output.  Lane pairs
+      // (fg, fg ^ 1) swap one dword so that every lane stores 8 contiguous bytes; lane fg = 0 stores the query's two scale bytes.
+      const uint32_t row = (uint32_t)(rel_first + __mul24(qo < nq ? qo : nq - 1, p.tok_stride));
+      uint8_t* qrow = p.out_q + (seq_base + row) * p.ldq + hcol + (fg & 1) * 16 + (fg >> 1) * 8;
+      uint32_t be2 = 0;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float f[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t p01 = pack_bf2(o[2 * b + h][0] * linv, o[2 * b + h][1] * linv), p23 = pack_bf2(o[2 * b + h][2] * linv, o[2 * b + h][3] * linv);
+          f[h * 4 + 0] = __uint_as_float(p01 << 16); f[h * 4 + 1] = __uint_as_float(p01 & 0xffff0000u);
+          f[h * 4 + 2] = __uint_as_float(p23 << 16); f[h * 4 + 3] = __uint_as_float(p23 & 0xffff0000u);
+        }
+        float amax = fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))), fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7]))));
+        amax = fmaxf(amax, __shfl_xor(amax, 16, 64)); amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        const int be = att_mx_exp(amax);
+        const float inv = __uint_as_float((uint32_t)(254 - be) << 23);
+        be2 |= (uint32_t)be << (8 * b);
+        const uint32_t d_lo = att_fp8x4(f, inv), d_hi = att_fp8x4(f + 4, inv);      // dims 32 b + fg * 4 + 0..3 and 32 b + 16 + fg * 4 + 0..3
+        const uint32_t got = (uint32_t)__shfl_xor((int)((fg & 1) ? d_lo : d_hi), 16, 64);
+        uint2 w;
+        if (fg & 1) { w.x = got; w.y = d_hi; } else { w.x = d_lo; w.y = got; }
+        if (qo < nq) *reinterpret_cast<uint2*>(qrow + b * 32) = w;
+      }
+      if (qo < nq && fg == 0)
+        *reinterpret_cast<uint16_t*>(p.out_s + (int64_t)(head >> 1) * p.splane + (seq_base + row) * 4 + (head & 1) * 2) = (uint16_t)be2;
+    } else
     if ((SF_ATT_ABL & 1) ? (linv == 1.2345e30f) : (qo < nq)) {
       bf16_t* orow = p.out + seq_base * p.ldo + hcol + (__umul24((uint32_t)(rel_first + __mul24(qo, p.tok_stride)), (uint32_t)p.ldo) + fg * 4);
 #pragma unroll
@@ -900,9 +946,9 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
   }
 }
 
-template <int D, int NKT>
+template <int D, int NKT, bool MXO = false>
 static int launch_attn_mfma(const AttnArgs& a, int64_t n_seq, hipStream_t s) {
-  auto kern = attn_mfma_kernel<D, NKT>;
+  auto kern = attn_mfma_kernel<D, NKT, MXO>;
   if (int rc = sf_prepare_kernel((const void*)kern, AttLds<D>::TOTAL, "sf_attention")) return rc;
   const int64_t blocks = n_seq * a.n_groups * a.heads;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), AttLds<D>::TOTAL, s, a);
@@ -956,9 +1002,64 @@ extern "C" int sf_attention_cls_combine(const float* partials, int n_part, uint1
   return 0;
 }
 
+// ... the same merge written as MXFP8 (the CLS row of sf_attention_cls_partial_mx's output): thread d holds dim d, a scale block is one half-wave
+__global__ __launch_bounds__(64) void attn_cls_combine64_mx_kernel(const float* __restrict__ part, int n_part, uint8_t* __restrict__ out_q, int64_t ldq,
+                                                                    uint8_t* __restrict__ out_s, int64_t splane, int64_t out_seq_rows, int out_row, int heads) {
+  const int head = blockIdx.x % heads, d = threadIdx.x;
+  const int64_t seq = blockIdx.x / heads;
+  const float* pp = part + (int64_t)blockIdx.x * n_part * 66;
+  float M = -INFINITY;
+  for (int i = 0; i < n_part; ++i) M = fmaxf(M, pp[i * 66]);
+  float L = 0.f, O = 0.f;
+  for (int i = 0; i < n_part; ++i) {
+    const float w = __builtin_amdgcn_exp2f(pp[i * 66] - M);
+    L += pp[i * 66 + 1] * w;
+    O += pp[i * 66 + 2 + d] * w;
+  }
+  const float x = __uint_as_float((uint32_t)f2bf(O / L) << 16);
+  float amax = fabsf(x);
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  const int be = att_mx_exp(amax);
+  const float inv = __uint_as_float((uint32_t)(254 - be) << 23);
+  const int64_t row = seq * out_seq_rows + out_row;
+  out_q[row * ldq + head * 64 + d] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(x * inv, 448.f, -448.f), 0.f, 0, false) & 0xff);
+  if ((d & 31) == 0) out_s[(int64_t)(head >> 1) * splane + row * 4 + (head & 1) * 2 + (d >> 5)] = (uint8_t)be;
+}
+
+extern "C" int sf_attention_cls_combine_mx(const float* partials, int n_part, uint8_t* out_q, int64_t ldq, uint8_t* out_s, int64_t splane, int64_t out_seq_rows,
+                                           int out_row, int64_t n_seq, int heads, void* stream) {
+  SF_CHECK_ARG(partials && out_q && out_s && n_part >= 1 && heads >= 1 && (heads % 2) == 0, "sf_attention_cls_combine_mx: bad arguments (heads must be even: 128-column scale planes)");
+  if (n_seq <= 0) return 0;
+  hipLaunchKernelGGL(attn_cls_combine64_mx_kernel, dim3((unsigned)(n_seq * heads)), dim3(64), 0, (hipStream_t)stream, partials, n_part, out_q, ldq, out_s, splane,
+                     out_seq_rows, out_row, heads);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
 static int attention_impl(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ldo, int64_t n_seq,
                           int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok, int cls_row, int heads,
                           int head_dim, float scale, float* cls_partial, void* stream, const uint8_t* key_keep = nullptr);
+
+// sf_attention_cls_partial writing MXFP8 (FT path: the attention output is only ever the A operand of the MX projection - was bf16 output + sf_quantize_mxfp8, a 0.75 GB
+// round trip per block on the 13-segment batch).  head_dim 64, 193..208 keys (13 key tiles: the space attention), an even number of heads; the CLS row comes from
+// sf_attention_cls_combine_mx.  Bytes and scales equal sf_quantize_mxfp8 of sf_attention_cls_partial's output.
+extern "C" int sf_attention_cls_partial_mx(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, uint8_t* out_q, int64_t ldq, uint8_t* out_s, int64_t splane,
+                                           int64_t n_seq, int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok, int cls_row,
+                                           int heads, float scale, float* cls_partial, void* stream) {
+  SF_CHECK_ARG(q && k && v && out_q && out_s && cls_partial && cls_row >= 0, "sf_attention_cls_partial_mx: null pointer / no CLS row");
+  SF_CHECK_ARG((n_tok + 1 + 15) / 16 == 13 && (n_tok % 16) != 0, "sf_attention_cls_partial_mx: n_tok %d outside 192..207 (13 key tiles with a free query slot)", n_tok);
+  SF_CHECK_ARG((heads % 2) == 0 && (ld % 8) == 0 && (ldq % 8) == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)out_q % 8) == 0 &&
+               ((uintptr_t)out_s % 2) == 0, "sf_attention_cls_partial_mx: alignment / even head count");
+  SF_CHECK_ARG(seq_rows >= 1 && seq_rows < (1 << 24) && ld < (1 << 24) && seq_rows * ld < ((int64_t)1 << 31), "sf_attention_cls_partial_mx: a sequence must span < 2^31 elements");
+  if (n_seq <= 0) return 0;
+  AttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.ld = ld; a.out = nullptr; a.ldo = 0; a.seq_rows = seq_rows;
+  a.n_groups = n_groups; a.row0 = row0; a.group_stride = group_stride; a.tok_stride = tok_stride; a.n_tok = n_tok;
+  a.cls_row = cls_row; a.heads = heads; a.scale = scale; a.cls_part = cls_partial; a.key_keep = nullptr;
+  a.out_q = out_q; a.ldq = ldq; a.out_s = out_s; a.splane = splane;
+  return launch_attn_mfma<64, 13, true>(a, n_seq, (hipStream_t)stream);
+}
 
 extern "C" int sf_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ldo, int64_t n_seq,
                             int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok, int cls_row, int heads,

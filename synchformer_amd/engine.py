@@ -80,6 +80,7 @@ class SynchformerEngine:
         self.fp8_towers = bool(fp8_towers)
         self.pe_tokens = os.environ.get('SF_PE_TOKENS', '1') != '0'      # patch embedding on the token layout (identity row maps, persistent GEMM)
         self.fuse_mx_time = True                     # fp8 towers: sf_qkv_time_attention_mx instead of sf_gemm_mxfp8 + the time attention kernels
+        self.fuse_mx_attn = os.environ.get('SF_MX_ATTN', '1') != '0'   # fp8 towers: the space attention writes MXFP8 itself (sf_attention_cls_partial_mx; off = bf16 output + sf_quantize_mxfp8)
         self.fuse_mx_ln = True                       # fp8 towers: sf_gemm_mx_res_ln768 instead of sf_gemm_mxfp8 + sf_layernorm768_mxfp8 (tests switch it off to compare)
         self.capture_blocks = None          # tests: a dict -> the fp32 residual stream after each visual block is cloned into it (key = block index)
         self._ws = {}
@@ -381,6 +382,8 @@ class SynchformerEngine:
             cq = self._buf('CQ', n * D, torch.uint8).view(n, D)
             cs = self._buf('CS', 6 * n_p * 4, torch.uint8).view(6, n_p, 4)
             qkv_cls = self._buf('qkv_cls', n * 3 * D, torch.bfloat16).view(n, 3 * D)
+        fuse_attn = self.fuse_mx_attn and tok_keep is None and os.environ.get('SF_CLS_FUSION', 'space') != 'none'
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         nb = len(self.v_blocks)
         for bi, b in enumerate(self.v_blocks):
             mx = b['mx']
@@ -402,8 +405,14 @@ class SynchformerEngine:
                 ops.gemm_mxfp8(xq, xs, mx['t_proj'].q, mx['t_proj'].s, mx['t_proj'].b, X, residual=X)
                 ops.layernorm_mxfp8(X, b['norm1'].g, b['norm1'].b, xq, xs, EPS_VIS)
             ops.gemm_mxfp8(xq, xs, mx['s_qkv'].q, mx['s_qkv'].s, mx['s_qkv'].b, qkv)
-            divided('space')
-            ops.quantize_mxfp8(xn, xq, xs)
+            if fuse_attn:
+                # the space attention writes the projection's MXFP8 operand itself (sf_attention_cls_partial_mx): no bf16 output, no quantisation pass
+                ops.attention_cls_partial_mx(q, k, v, xq, xs, part, n_seq=n, seq_rows=VIS_L, n_groups=8, row0=1, group_stride=196, tok_stride=1, n_tok=196,
+                                             cls_row=0, heads=12, scale=0.125)
+                ops.attention_cls_combine_mx(part, xq, xs, n_part=8, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
+            else:
+                divided('space')
+                ops.quantize_mxfp8(xn, xq, xs)
             if fuse:
                 ops.gemm_mx_res_ln(xq, xs, mx['s_proj'].q, mx['s_proj'].s, mx['s_proj'].b, X, b['norm2'].g, b['norm2'].b, xq, xs, EPS_VIS)
             else:

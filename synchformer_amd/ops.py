@@ -320,6 +320,28 @@ def qkv_time_attention_mx(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tenso
     return out
 
 
+def attention_cls_partial_mx(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_q: torch.Tensor, out_s: torch.Tensor, partials: torch.Tensor, *, n_seq: int,
+                             seq_rows: int, n_groups: int, row0: int, group_stride: int, tok_stride: int, n_tok: int, cls_row: int, heads: int, scale: float):
+    """`attention_cls_partial` (head_dim 64, 192 <= n_tok <= 207) writing MXFP8: out_q uint8 (rows, heads*64), out_s uint8 scale planes (heads*64/128, rows_padded, 4)
+    as `mx_scale_planes` lays them out - byte for byte what `quantize_mxfp8` makes of the bf16 output."""
+    assert q.dtype == k.dtype == v.dtype == torch.bfloat16 and out_q.dtype == out_s.dtype == torch.uint8 and partials.dtype == torch.float32
+    assert _ld(q) == _ld(k) == _ld(v) and partials.numel() >= n_seq * heads * n_groups * 66 and out_s.dim() == 3 and out_s.shape[0] * 2 == heads
+    rc = _lib.load().sf_attention_cls_partial_mx(_dev(q, 'q'), _dev(k, 'k'), _dev(v, 'v'), _ld(q), _dev(out_q, 'out_q'), _ld(out_q), _dev(out_s, 'out_s'), out_s.stride(0),
+                                                 n_seq, seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, float(scale),
+                                                 _dev(partials, 'partials'), _stream())
+    _lib.check(rc, 'sf_attention_cls_partial_mx')
+    return out_q
+
+
+def attention_cls_combine_mx(partials: torch.Tensor, out_q: torch.Tensor, out_s: torch.Tensor, *, n_part: int, n_seq: int, out_seq_rows: int, out_row: int, heads: int):
+    """`attention_cls_combine` writing the CLS rows as MXFP8 into the buffers of `attention_cls_partial_mx`."""
+    assert out_q.dtype == out_s.dtype == torch.uint8 and out_s.dim() == 3 and out_s.shape[0] * 2 == heads
+    rc = _lib.load().sf_attention_cls_combine_mx(_dev(partials, 'partials'), n_part, _dev(out_q, 'out_q'), _ld(out_q), _dev(out_s, 'out_s'), out_s.stride(0), out_seq_rows,
+                                                 out_row, n_seq, heads, _stream())
+    _lib.check(rc, 'sf_attention_cls_combine_mx')
+    return out_q
+
+
 def attention_cls_combine(partials: torch.Tensor, out: torch.Tensor, *, n_part: int, n_seq: int, out_seq_rows: int, out_row: int, heads: int):
     rc = _lib.load().sf_attention_cls_combine(_dev(partials, 'partials'), n_part, _dev(out, 'out'), _ld(out), out_seq_rows, out_row, n_seq, heads,
                                               _stream())

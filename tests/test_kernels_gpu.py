@@ -216,6 +216,32 @@ def test_divided_attention(gpu, mode):
     torch.testing.assert_close(o2[:, 0], ref[:, 0], rtol=2e-2, atol=2e-2)
 
 
+def test_space_attention_mxfp8_output(gpu):
+    """sf_attention_cls_partial_mx + sf_attention_cls_combine_mx == the bf16 kernels followed by sf_quantize_mxfp8, byte for byte (bytes and scale planes; rows the
+    kernels do not own keep their fill)."""
+    from synchformer_amd import ops
+    N, L = 3, 1569
+    qkv = _bf(_rand(N * L, 2304, seed=23, scale=1.5)).to(gpu)
+    qkv[5:9] *= 40.0                                                        # a few large rows: other scale exponents
+    qkv[:, 1536 + 64:1536 + 96] = 0                                         # one all-zero value block per row: amax = 0 -> scale byte 1
+    q, k, v = qkv[:, :768], qkv[:, 768:1536], qkv[:, 1536:]
+    kw = dict(n_seq=N, seq_rows=L, n_groups=8, row0=1, group_stride=196, tok_stride=1, n_tok=196, cls_row=0, heads=12)
+    out = torch.zeros(N * L, 768, device=gpu, dtype=torch.bfloat16)
+    part = torch.empty(N * 12 * 8 * 66, device=gpu)
+    ops.attention_cls_partial(q, k, v, out, part, head_dim=64, scale=0.125, **kw)
+    ops.attention_cls_combine(part, out, n_part=8, n_seq=N, out_seq_rows=L, out_row=0, heads=12)
+    q0, s0 = torch.empty(N * L, 768, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(N * L, 768, gpu)
+    ops.quantize_mxfp8(out, q0, s0)
+    q1, s1 = torch.full((N * L + 3, 768), 7, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(N * L, 768, gpu)
+    part1 = torch.empty_like(part)
+    ops.attention_cls_partial_mx(q, k, v, q1, s1, part1, scale=0.125, **kw)
+    assert (q1.view(-1, 768)[:N * L].view(N, L, 768)[:, 0] == 7).all()       # the CLS rows belong to the combine kernel
+    ops.attention_cls_combine_mx(part1, q1, s1, n_part=8, n_seq=N, out_seq_rows=L, out_row=0, heads=12)
+    assert torch.equal(part, part1)
+    assert torch.equal(q0, q1[:N * L]) and (q1[N * L:] == 7).all()
+    assert torch.equal(s0[:, :N * L], s1[:, :N * L]) and (s1[:, N * L:] == 0).all()
+
+
 @pytest.mark.parametrize('L,heads,d', [(74, 12, 64), (198, 8, 96), (184, 8, 96), (13, 12, 64), (197, 12, 64), (17, 12, 64)])
 def test_full_attention(gpu, L, heads, d):
     from synchformer_amd import ops
