@@ -115,6 +115,12 @@ int sf_gemm_mx_res_ln768(const uint8_t* A, int64_t lda, const uint8_t* sA, int64
 int sf_qkv_time_attention_mx(const uint8_t* X, int64_t ldx, const uint8_t* sX, int64_t ldsx, const uint8_t* W, int64_t ldw, const uint8_t* sW, int64_t ldsw,
                              const float* bias, const uint16_t* qkv_cls, int64_t ldc, uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_groups,
                              float scale, void* stream);
+/* ... with the attention output (patch rows) written as MXFP8 instead of bf16: out_q e4m3 bytes (rows, 768), row stride ldq bytes; out_s the scale planes [6][rows][4],
+ * splane bytes apart - byte for byte sf_quantize_mxfp8 of sf_qkv_time_attention_mx's bf16 output.  out_q / out_s must not alias X / sX.  The CLS rows come from
+ * sf_attention_cls_combine_mx on cls_partial. */
+int sf_qkv_time_attention_mx_q(const uint8_t* X, int64_t ldx, const uint8_t* sX, int64_t ldsx, const uint8_t* W, int64_t ldw, const uint8_t* sW, int64_t ldsw,
+                               const float* bias, const uint16_t* qkv_cls, int64_t ldc, uint8_t* out_q, int64_t ldq, uint8_t* out_s, int64_t splane,
+                               float* cls_partial, int64_t n_seq, int n_groups, float scale, void* stream);
 
 /* Tuning / test hook (state of the CALLING THREAD only; the launchers stay re-entrant): force the GEMM tile configuration of this thread's subsequent
  * sf_gemm_bf16 calls.  -1 = automatic choice by shape (default); 0 = 128x128x64, 4 waves, two workgroups per CU; 7 = persistent 256x256x64,

@@ -694,18 +694,6 @@ __device__ __forceinline__ uint4 att_ld16(const bf16_t* p) {
   return *reinterpret_cast<const uint4*>(p);
 }
 
-// e4m3 bytes of four bf16-exact values scaled by `inv` (a power of two), as sf_quantize_mxfp8 produces them
-__device__ __forceinline__ uint32_t att_fp8x4(const float* f, float inv) {
-  int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f[0] * inv, 448.f, -448.f), __builtin_amdgcn_fmed3f(f[1] * inv, 448.f, -448.f), 0, false);
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f[2] * inv, 448.f, -448.f), __builtin_amdgcn_fmed3f(f[3] * inv, 448.f, -448.f), w, true);
-  return (uint32_t)w;
-}
-// E8M0 byte of a block with absolute maximum `amax` (>= 0): exponent - 8 (448 = 1.75 * 2^8), clamped to [1, 254] - sf_quantize_mxfp8's rule
-__device__ __forceinline__ int att_mx_exp(float amax) {
-  const int be = (int)((__float_as_uint(amax) >> 23) & 0xff) - 8;
-  return be < 1 ? 1 : (be > 254 ? 254 : be);
-}
-
 template <int D, int NKT, bool MXO = false>
 __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
   static_assert(!MXO || D == 64, "the MXFP8 output is written per 64-wide head");
@@ -921,10 +909,10 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
         }
         float amax = fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))), fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7]))));
         amax = fmaxf(amax, __shfl_xor(amax, 16, 64)); amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
-        const int be = att_mx_exp(amax);
+        const int be = sf_mx_exp(amax);
         const float inv = __uint_as_float((uint32_t)(254 - be) << 23);
         be2 |= (uint32_t)be << (8 * b);
-        const uint32_t d_lo = att_fp8x4(f, inv), d_hi = att_fp8x4(f + 4, inv);      // dims 32 b + fg * 4 + 0..3 and 32 b + 16 + fg * 4 + 0..3
+        const uint32_t d_lo = sf_fp8x4(f, inv), d_hi = sf_fp8x4(f + 4, inv);      // dims 32 b + fg * 4 + 0..3 and 32 b + 16 + fg * 4 + 0..3
         const uint32_t got = (uint32_t)__shfl_xor((int)((fg & 1) ? d_lo : d_hi), 16, 64);
         uint2 w;
         if (fg & 1) { w.x = got; w.y = d_hi; } else { w.x = d_lo; w.y = got; }
@@ -1020,7 +1008,7 @@ __global__ __launch_bounds__(64) void attn_cls_combine64_mx_kernel(const float* 
   float amax = fabsf(x);
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-  const int be = att_mx_exp(amax);
+  const int be = sf_mx_exp(amax);
   const float inv = __uint_as_float((uint32_t)(254 - be) << 23);
   const int64_t row = seq * out_seq_rows + out_row;
   out_q[row * ldq + head * 64 + d] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(x * inv, 448.f, -448.f), 0.f, 0, false) & 0xff);

@@ -67,6 +67,21 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float f16_to_f32(uint16_t h) { return __half2float(__ushort_as_half(h)); }
 
+// ---- MXFP8 quantisation pieces shared by the kernels that write an MX operand themselves (the rule of sf_quantize_mxfp8) ------------
+// E8M0 byte of a 32-element block with absolute maximum `amax` (>= 0): its exponent - 8 (448 = 1.75 * 2^8), clamped to [1, 254]
+__device__ __forceinline__ int sf_mx_exp(float amax) {
+  const int be = (int)((__float_as_uint(amax) >> 23) & 0xff) - 8;
+  return be < 1 ? 1 : (be > 254 ? 254 : be);
+}
+// the reciprocal of that block scale, 2^(127 - be)
+__device__ __forceinline__ float sf_mx_inv(int be) { return __uint_as_float((uint32_t)(254 - be) << 23); }
+// e4m3 bytes of four values scaled by `inv`
+__device__ __forceinline__ uint32_t sf_fp8x4(const float* f, float inv) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f[0] * inv, 448.f, -448.f), __builtin_amdgcn_fmed3f(f[1] * inv, 448.f, -448.f), 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f[2] * inv, 448.f, -448.f), __builtin_amdgcn_fmed3f(f[3] * inv, 448.f, -448.f), w, true);
+  return (uint32_t)w;
+}
+
 // ---- wave reductions ------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

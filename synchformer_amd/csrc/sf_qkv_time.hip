@@ -82,6 +82,8 @@ struct QtArgs {
   // MX: X / W are e4m3 BYTES (ldx / ldw in bytes) with stage-major E8M0 scale planes (one dword per row per 128 k, ldsx / ldsw bytes between planes)
   const uint8_t* sX; int64_t ldsx;
   const uint8_t* sW; int64_t ldsw;
+  // MX, optional: the attention output as MXFP8 (e4m3 bytes, row stride ldq, + E8M0 bytes in the scale planes [6][rows][4], splane bytes apart) instead of bf16 `out`
+  uint8_t* out_q = nullptr; int64_t ldq = 0; uint8_t* out_s = nullptr; int64_t splane = 0;
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 qt_bf2;
@@ -612,6 +614,26 @@ __global__ __launch_bounds__(512, 2) void qkv_time_attn_kernel(QtArgs p) {
           }
           uint4 w;
           w.x = pack_bf2(o[0].x, o[0].y); w.y = pack_bf2(o[1].x, o[1].y); w.z = pack_bf2(o[2].x, o[2].y); w.w = pack_bf2(o[3].x, o[3].y);
+          if (MX && p.out_q) {
+            // MXFP8 output (the operand of the MX projection): a 32-dim scale block is the 8 values of each of the four lanes ds & ~3 .. + 3 (one DPP quad);
+            // quantised from the bf16-rounded values, as sf_quantize_mxfp8 would from the bf16 output
+            const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+            float f[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(wv[i] << 16); f[2 * i + 1] = __uint_as_float(wv[i] & 0xffff0000u); }
+            float amax = fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))), fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7]))));
+            amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(amax), 0xB1, 0xF, 0xF, true)));   // quad_perm [1, 0, 3, 2]
+            amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(amax), 0x4E, 0xF, 0xF, true)));   // quad_perm [2, 3, 0, 1]
+            const int be = sf_mx_exp(amax);
+            const float inv = sf_mx_inv(be);
+            const int be_hi = __shfl_xor(be, 4, 64);                                   // the head's other block (lanes ds ^ 4)
+            if (live) {
+              const int64_t orow = orow0 + (int64_t)(qh * 4 + qq) * p.n_groups;
+              qt_u32x2 q8; q8.x = sf_fp8x4(f, inv); q8.y = sf_fp8x4(f + 4, inv);
+              *reinterpret_cast<qt_u32x2*>(p.out_q + orow * p.ldq + ehead * 64 + ds * 8) = q8;
+              if (ds == 0) *reinterpret_cast<uint16_t*>(p.out_s + (int64_t)(ehead >> 1) * p.splane + orow * 4 + (ehead & 1) * 2) = (uint16_t)(be | (be_hi << 8));
+            }
+          } else
           if (live) {
             typedef __attribute__((ext_vector_type(4))) unsigned int qt_u32x4;
             qt_u32x4* dst = reinterpret_cast<qt_u32x4*>(optr + (int64_t)(qh * 4 + qq) * p.n_groups * p.ldo);
@@ -721,14 +743,37 @@ static int qkv_time_impl(const uint16_t* X, int64_t ldx, const uint16_t* W, int6
 // ldsx bytes apart, one dword per row) - what sf_layernorm768_mxfp8 / sf_gemm_mx_res_ln768 write -, W (2304, 768) e4m3 + sW (6 planes of 2304 dwords).  qkv_cls,
 // out and cls_partial as in sf_qkv_time_attention (bf16 / fp32): the attention itself runs on the bf16-rounded projection, exactly as on the un-fused MX path
 // (sf_gemm_mxfp8 with a bf16 output, then sf_attention).  Replaces sf_gemm_mxfp8 (temporal qkv) + sf_attention (time groups) + sf_attention_cls.
+static int qkv_time_mx_impl(const uint8_t* X, int64_t ldx, const uint8_t* sX, int64_t ldsx, const uint8_t* W, int64_t ldw, const uint8_t* sW,
+                            int64_t ldsw, const float* bias, const uint16_t* qkv_cls, int64_t ldc, uint16_t* out, int64_t ldo, uint8_t* out_q, int64_t ldq, uint8_t* out_s,
+                            int64_t splane, float* cls_partial, int64_t n_seq, int n_groups, float scale, void* stream);
+
 extern "C" int sf_qkv_time_attention_mx(const uint8_t* X, int64_t ldx, const uint8_t* sX, int64_t ldsx, const uint8_t* W, int64_t ldw, const uint8_t* sW,
                                         int64_t ldsw, const float* bias, const uint16_t* qkv_cls, int64_t ldc, uint16_t* out, int64_t ldo, float* cls_partial,
                                         int64_t n_seq, int n_groups, float scale, void* stream) {
-  SF_CHECK_ARG(X && sX && W && sW && qkv_cls && out && cls_partial, "sf_qkv_time_attention_mx: null pointer");
+  SF_CHECK_ARG(out && ((uintptr_t)out % 16) == 0 && (ldo % 8) == 0, "sf_qkv_time_attention_mx: out must be a 16-byte aligned bf16 buffer, ldo a multiple of 8");
+  return qkv_time_mx_impl(X, ldx, sX, ldsx, W, ldw, sW, ldsw, bias, qkv_cls, ldc, out, ldo, nullptr, 0, nullptr, 0, cls_partial, n_seq, n_groups, scale, stream);
+}
+
+// ... with the attention output written as MXFP8 (out_q e4m3 bytes (rows, 768), row stride ldq; out_s the scale planes [6][rows][4], splane bytes apart) - the A operand
+// of the MX projection that follows; byte for byte sf_quantize_mxfp8 of sf_qkv_time_attention_mx's bf16 output.  out_q / out_s must not alias X / sX (other
+// workgroups still read them).  The CLS rows come from sf_attention_cls_combine_mx.
+extern "C" int sf_qkv_time_attention_mx_q(const uint8_t* X, int64_t ldx, const uint8_t* sX, int64_t ldsx, const uint8_t* W, int64_t ldw, const uint8_t* sW,
+                                          int64_t ldsw, const float* bias, const uint16_t* qkv_cls, int64_t ldc, uint8_t* out_q, int64_t ldq, uint8_t* out_s, int64_t splane,
+                                          float* cls_partial, int64_t n_seq, int n_groups, float scale, void* stream) {
+  SF_CHECK_ARG(out_q && out_s && ((uintptr_t)out_q % 8) == 0 && ((uintptr_t)out_s % 2) == 0 && (ldq % 8) == 0 && ldq >= QT_D && out_q != X && out_s != sX,
+               "sf_qkv_time_attention_mx_q: out_q (8-byte aligned, ldq %% 8 == 0) / out_s must be buffers of their own");
+  SF_CHECK_ARG(splane >= n_seq * (1 + 8 * (int64_t)n_groups) * 4, "sf_qkv_time_attention_mx_q: a scale plane holds 4 bytes per row");
+  return qkv_time_mx_impl(X, ldx, sX, ldsx, W, ldw, sW, ldsw, bias, qkv_cls, ldc, nullptr, 0, out_q, ldq, out_s, splane, cls_partial, n_seq, n_groups, scale, stream);
+}
+
+static int qkv_time_mx_impl(const uint8_t* X, int64_t ldx, const uint8_t* sX, int64_t ldsx, const uint8_t* W, int64_t ldw, const uint8_t* sW,
+                            int64_t ldsw, const float* bias, const uint16_t* qkv_cls, int64_t ldc, uint16_t* out, int64_t ldo, uint8_t* out_q, int64_t ldq, uint8_t* out_s,
+                            int64_t splane, float* cls_partial, int64_t n_seq, int n_groups, float scale, void* stream) {
+  SF_CHECK_ARG(X && sX && W && sW && qkv_cls && (out || out_q) && cls_partial, "sf_qkv_time_attention_mx: null pointer");
   SF_CHECK_ARG((n_groups % 4) == 0 && n_groups >= 4, "sf_qkv_time_attention_mx: n_groups must be a multiple of 4 (a wave's four patches share one sequence)");
-  SF_CHECK_ARG((ldx % 16) == 0 && (ldw % 16) == 0 && ldx >= QT_D && ldw >= QT_D && (ldc % 8) == 0 && (ldo % 8) == 0, "sf_qkv_time_attention_mx: bad row strides");
+  SF_CHECK_ARG((ldx % 16) == 0 && (ldw % 16) == 0 && ldx >= QT_D && ldw >= QT_D && (ldc % 8) == 0, "sf_qkv_time_attention_mx: bad row strides");
   SF_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)sX % 4) == 0 && ((uintptr_t)sW % 4) == 0 && ((uintptr_t)qkv_cls % 16) == 0 &&
-                   ((uintptr_t)out % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0) && ((uintptr_t)cls_partial % 8) == 0,
+                   (!bias || ((uintptr_t)bias % 16) == 0) && ((uintptr_t)cls_partial % 8) == 0,
                "sf_qkv_time_attention_mx: operands must be 16-byte aligned (scale planes 4-byte)");
   if (n_seq <= 0) return 0;
   const int64_t seq_rows = 1 + 8 * (int64_t)n_groups;
@@ -742,6 +787,7 @@ extern "C" int sf_qkv_time_attention_mx(const uint8_t* X, int64_t ldx, const uin
   a.X = reinterpret_cast<const bf16_t*>(X); a.ldx = ldx; a.W = reinterpret_cast<const bf16_t*>(W); a.ldw = ldw; a.bias = bias; a.qkv_cls = qkv_cls; a.ldc = ldc;
   a.out = out; a.ldo = ldo; a.cls_part = cls_partial; a.n_seq = n_seq; a.seq_rows = seq_rows; a.n_groups = n_groups; a.scale = scale; a.key_keep = nullptr;
   a.sX = sX; a.ldsx = ldsx; a.sW = sW; a.ldsw = ldsw;
+  a.out_q = out_q; a.ldq = ldq; a.out_s = out_s; a.splane = splane;
   const int64_t tiles_m = (n_seq * n_groups + 31) / 32;
   SF_CHECK_ARG(tiles_m * QT_HEADS < ((int64_t)1 << 31) && n_seq * n_groups < ((int64_t)1 << 31), "sf_qkv_time_attention_mx: too many tiles");
   a.tiles_m = (uint32_t)tiles_m;

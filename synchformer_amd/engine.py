@@ -382,6 +382,8 @@ class SynchformerEngine:
             cq = self._buf('CQ', n * D, torch.uint8).view(n, D)
             cs = self._buf('CS', 6 * n_p * 4, torch.uint8).view(6, n_p, 4)
             qkv_cls = self._buf('qkv_cls', n * 3 * D, torch.bfloat16).view(n, 3 * D)
+            aq = self._buf('AQ', rows * D, torch.uint8).view(rows, D)         # the time attention's output as the projection's MXFP8 operand
+            as_ = self._buf('AS', 6 * rows_p * 4, torch.uint8).view(6, rows_p, 4)
         fuse_attn = self.fuse_mx_attn and tok_keep is None and os.environ.get('SF_CLS_FUSION', 'space') != 'none'
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         nb = len(self.v_blocks)
@@ -393,16 +395,25 @@ class SynchformerEngine:
                 cq.copy_(xq.view(n, VIS_L, D)[:, 0])
                 cs[:, :n].copy_(xs[:, :rows].view(6, n, VIS_L, 4)[:, :, 0])
                 ops.gemm_mxfp8(cq, cs, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, qkv_cls)
-                ops.qkv_time_attention_mx(xq, xs, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, qkv_cls, xn, part, n_seq=n, n_groups=196, scale=0.125)
-                ops.attention_cls_combine(part, xn, n_part=49, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
+                if fuse_attn:
+                    # ... and writes the projection's MXFP8 operand itself, into a second operand buffer (other workgroups still read xq / xs)
+                    ops.qkv_time_attention_mx(xq, xs, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, qkv_cls, aq, part, n_seq=n, n_groups=196, scale=0.125, out_scales=as_)
+                    ops.attention_cls_combine_mx(part, aq, as_, n_part=49, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
+                else:
+                    ops.qkv_time_attention_mx(xq, xs, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, qkv_cls, xn, part, n_seq=n, n_groups=196, scale=0.125)
+                    ops.attention_cls_combine(part, xn, n_part=49, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
             else:
                 ops.gemm_mxfp8(xq, xs, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, qkv)
                 divided('time')
-            ops.quantize_mxfp8(xn, xq, xs)
-            if fuse:
-                ops.gemm_mx_res_ln(xq, xs, mx['t_proj'].q, mx['t_proj'].s, mx['t_proj'].b, X, b['norm1'].g, b['norm1'].b, xq, xs, EPS_VIS)
+            if fuse_time and fuse_attn:
+                tq, ts = aq, as_
             else:
-                ops.gemm_mxfp8(xq, xs, mx['t_proj'].q, mx['t_proj'].s, mx['t_proj'].b, X, residual=X)
+                ops.quantize_mxfp8(xn, xq, xs)
+                tq, ts = xq, xs
+            if fuse:
+                ops.gemm_mx_res_ln(tq, ts, mx['t_proj'].q, mx['t_proj'].s, mx['t_proj'].b, X, b['norm1'].g, b['norm1'].b, xq, xs, EPS_VIS)
+            else:
+                ops.gemm_mxfp8(tq, ts, mx['t_proj'].q, mx['t_proj'].s, mx['t_proj'].b, X, residual=X)
                 ops.layernorm_mxfp8(X, b['norm1'].g, b['norm1'].b, xq, xs, EPS_VIS)
             ops.gemm_mxfp8(xq, xs, mx['s_qkv'].q, mx['s_qkv'].s, mx['s_qkv'].b, qkv)
             if fuse_attn:

@@ -305,14 +305,24 @@ def qkv_time_attention(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Te
 
 
 def qkv_time_attention_mx(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], qkv_cls: torch.Tensor,
-                          out: torch.Tensor, partials: torch.Tensor, *, n_seq: int, n_groups: int, scale: float):
+                          out: torch.Tensor, partials: torch.Tensor, *, n_seq: int, n_groups: int, scale: float, out_scales: Optional[torch.Tensor] = None):
     """qkv_time_attention on MXFP8 operands: x_q (n_seq * (1 + 8 n_groups), 768) uint8 e4m3 + x_s (6, >= rows, 4) scale planes, w_q (2304, 768) + w_s (6, >= 2304, 4);
-    qkv_cls (n_seq, 2304) bf16, out bf16, partials fp32 as in qkv_time_attention."""
-    assert x_q.dtype == w_q.dtype == x_s.dtype == w_s.dtype == torch.uint8 and qkv_cls.dtype == out.dtype == torch.bfloat16 and partials.dtype == torch.float32
+    qkv_cls (n_seq, 2304) bf16, out bf16, partials fp32 as in qkv_time_attention.  With a uint8 `out` and `out_scales` (6, >= rows, 4) the patch rows are written
+    as MXFP8 (= quantize_mxfp8 of the bf16 output; buffers of their own, not x_q / x_s)."""
+    assert x_q.dtype == w_q.dtype == x_s.dtype == w_s.dtype == torch.uint8 and qkv_cls.dtype == torch.bfloat16 and partials.dtype == torch.float32
+    assert (out.dtype == torch.uint8) == (out_scales is not None) and out.dtype in (torch.uint8, torch.bfloat16)
     assert x_q.shape[1] == 768 and tuple(w_q.shape) == (2304, 768) and qkv_cls.shape[0] >= n_seq and qkv_cls.shape[1] == 2304 and out.shape[1] == 768
     rows = n_seq * (1 + 8 * n_groups)
     assert x_q.shape[0] >= rows and out.shape[0] >= rows and x_s.dim() == 3 and w_s.dim() == 3 and x_s.shape[0] == 6 and w_s.shape[0] == 6
     assert x_s.shape[1] >= rows and w_s.shape[1] >= 2304 and x_s.is_contiguous() and w_s.is_contiguous() and partials.numel() >= n_seq * 12 * (n_groups // 4) * 66
+    if out_scales is not None:
+        assert out_scales.dtype == torch.uint8 and out_scales.dim() == 3 and out_scales.shape[0] == 6 and out_scales.shape[1] >= rows and out_scales.is_contiguous()
+        assert out.data_ptr() != x_q.data_ptr() and out_scales.data_ptr() != x_s.data_ptr()
+        rc = _lib.load().sf_qkv_time_attention_mx_q(_dev(x_q, 'x_q'), _ld(x_q), _dev(x_s, 'x_s'), x_s.stride(0), _dev(w_q, 'w_q'), _ld(w_q), _dev(w_s, 'w_s'), w_s.stride(0),
+                                                    _dev(bias, 'bias') if bias is not None else None, _dev(qkv_cls, 'qkv_cls'), _ld(qkv_cls), _dev(out, 'out'), _ld(out),
+                                                    _dev(out_scales, 'out_scales'), out_scales.stride(0), _dev(partials, 'partials'), n_seq, n_groups, float(scale), _stream())
+        _lib.check(rc, 'sf_qkv_time_attention_mx_q')
+        return out
     rc = _lib.load().sf_qkv_time_attention_mx(_dev(x_q, 'x_q'), _ld(x_q), _dev(x_s, 'x_s'), x_s.stride(0), _dev(w_q, 'w_q'), _ld(w_q), _dev(w_s, 'w_s'), w_s.stride(0),
                                               _dev(bias, 'bias') if bias is not None else None, _dev(qkv_cls, 'qkv_cls'), _ld(qkv_cls), _dev(out, 'out'), _ld(out),
                                               _dev(partials, 'partials'), n_seq, n_groups, float(scale), _stream())
@@ -427,7 +437,7 @@ def register_torch_ops():
         return
     from torch.library import custom_op
     # the direct launchers, bound now: ops.via_dispatcher() re-points the module-level names at these custom ops
-    d_ = {n: globals()[n] for n in ('gemm', 'layernorm', 'attention', 'attention_cls', 'im2col_video', 'gemm_res_ln', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'quantize_mxfp8', 'layernorm_mxfp8', 'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention_mx')}
+    d_ = {n: globals()[n] for n in ('gemm', 'layernorm', 'attention', 'attention_cls', 'im2col_video', 'gemm_res_ln', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'quantize_mxfp8', 'layernorm_mxfp8', 'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention_mx', 'attention_cls_partial_mx', 'attention_cls_combine_mx')}
 
     @custom_op('synchformer::gemm_bf16', mutates_args=('out',), device_types='cuda')
     def _gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, residual: Optional[torch.Tensor],
@@ -500,6 +510,21 @@ def register_torch_ops():
                         gamma: torch.Tensor, beta: torch.Tensor, y_q: torch.Tensor, y_s: torch.Tensor, eps: float) -> None:
         d_['gemm_mx_res_ln'](a_q, a_s, w_q, w_s, bias, x, gamma, beta, y_q, y_s, eps)
 
+    @custom_op('synchformer::qkv_time_attention_mx_q', mutates_args=('out_q', 'out_s', 'partials'), device_types='cuda')
+    def _qkv_time_mx_q(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], qkv_cls: torch.Tensor, out_q: torch.Tensor,
+                       out_s: torch.Tensor, partials: torch.Tensor, n_seq: int, n_groups: int, scale: float) -> None:
+        d_['qkv_time_attention_mx'](x_q, x_s, w_q, w_s, bias, qkv_cls, out_q, partials, n_seq=n_seq, n_groups=n_groups, scale=scale, out_scales=out_s)
+
+    @custom_op('synchformer::attention_cls_partial_mx', mutates_args=('out_q', 'out_s', 'partials'), device_types='cuda')
+    def _attn_part_mx(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_q: torch.Tensor, out_s: torch.Tensor, partials: torch.Tensor, n_seq: int, seq_rows: int,
+                      n_groups: int, row0: int, group_stride: int, tok_stride: int, n_tok: int, cls_row: int, heads: int, scale: float) -> None:
+        d_['attention_cls_partial_mx'](q, k, v, out_q, out_s, partials, n_seq=n_seq, seq_rows=seq_rows, n_groups=n_groups, row0=row0, group_stride=group_stride,
+                                       tok_stride=tok_stride, n_tok=n_tok, cls_row=cls_row, heads=heads, scale=scale)
+
+    @custom_op('synchformer::attention_cls_combine_mx', mutates_args=('out_q', 'out_s'), device_types='cuda')
+    def _attn_comb_mx(partials: torch.Tensor, out_q: torch.Tensor, out_s: torch.Tensor, n_part: int, n_seq: int, out_seq_rows: int, out_row: int, heads: int) -> None:
+        d_['attention_cls_combine_mx'](partials, out_q, out_s, n_part=n_part, n_seq=n_seq, out_seq_rows=out_seq_rows, out_row=out_row, heads=heads)
+
     _registered = True
 
 
@@ -510,7 +535,7 @@ class via_dispatcher:
         with ops.via_dispatcher(): logits = engine.forward(vis, aud)
     The results are the same launches on the same buffers (tests/test_e2e_gpu.py compares them bit for bit)."""
     NAMES = ('gemm', 'layernorm', 'gemm_res_ln', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'quantize_mxfp8', 'layernorm_mxfp8',
-             'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention_mx')
+             'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention_mx', 'attention_cls_partial_mx', 'attention_cls_combine_mx')
 
     def __init__(self):
         self.calls = 0
@@ -549,7 +574,10 @@ class via_dispatcher:
             count(t.qkv_time_attention)(x, w, bias, qkv_cls, out, partials, n_seq, n_groups, scale, key_keep)
             return out
 
-        def qkv_time_mx_(x_q, x_s, w_q, w_s, bias, qkv_cls, out, partials, *, n_seq, n_groups, scale):
+        def qkv_time_mx_(x_q, x_s, w_q, w_s, bias, qkv_cls, out, partials, *, n_seq, n_groups, scale, out_scales=None):
+            if out_scales is not None:
+                count(t.qkv_time_attention_mx_q)(x_q, x_s, w_q, w_s, bias, qkv_cls, out, out_scales, partials, n_seq, n_groups, scale)
+                return out
             count(t.qkv_time_attention_mx)(x_q, x_s, w_q, w_s, bias, qkv_cls, out, partials, n_seq, n_groups, scale)
             return out
 
@@ -586,6 +614,15 @@ class via_dispatcher:
             count(t.gemm_mx_res_ln768)(a_q, a_s, w_q, w_s, bias, x, gamma, beta, y_q, y_s, eps)
             return x, y_q, y_s
 
+        def attn_part_mx_(q, k, v, out_q, out_s, partials, *, n_seq, seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, scale):
+            count(t.attention_cls_partial_mx)(q, k, v, out_q, out_s, partials, n_seq, seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, scale)
+            return out_q
+
+        def attn_comb_mx_(partials, out_q, out_s, *, n_part, n_seq, out_seq_rows, out_row, heads):
+            count(t.attention_cls_combine_mx)(partials, out_q, out_s, n_part, n_seq, out_seq_rows, out_row, heads)
+            return out_q
+
+        g.update(attention_cls_partial_mx=attn_part_mx_, attention_cls_combine_mx=attn_comb_mx_)
         g.update(gemm=gemm_, layernorm=layernorm_, gemm_res_ln=gemm_res_ln_, qkv_time_attention=qkv_time_, attention_cls_partial=attn_part_,
                  attention_cls_combine=attn_comb_, quantize_mxfp8=quant_, layernorm_mxfp8=ln_mx_, gemm_mxfp8=gemm_mx_, gemm_mx_res_ln=gemm_mx_ln_,
                  qkv_time_attention_mx=qkv_time_mx_)

@@ -111,6 +111,11 @@ def test_mxfp8_towers_bound(gpu):
     assert (l8.argmax(-1) == torch.from_numpy(g['logits']).argmax(-1)).all()
     # the fused proj / fc2 + residual + LayerNorm + quantisation launches (sf_gemm_mx_res_ln768, the default) against the un-fused pairs: the same
     # products summed in another order - features agree far inside the fp8 path's own noise
+    # the attention kernels writing the projections' MXFP8 operands themselves (sf_attention_cls_partial_mx, sf_qkv_time_attention_mx_q - the default) against
+    # their bf16 outputs + sf_quantize_mxfp8: the same bytes, so the same features bit for bit
+    e8.fuse_mx_attn = False
+    assert torch.equal(e8.extract_vfeats(u8), v8)
+    e8.fuse_mx_attn = True
     e8.fuse_mx_ln = e8.fuse_mx_time = False
     v8u, l8u = e8.extract_vfeats(u8), e8.forward(u8, aud).cpu()
     relu = _rel_rms(v8.cpu(), v8u.cpu())
@@ -124,7 +129,7 @@ def test_forward_through_the_dispatcher(gpu):
     from synchformer_amd import ops, synth
     from synchformer_amd.engine import SynchformerEngine
     for name in ('gemm_bf16', 'layernorm768', 'gemm_res_ln768', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'gemm_mxfp8',
-                 'gemm_mx_res_ln768', 'quantize_mxfp8', 'layernorm768_mxfp8'):
+                 'gemm_mx_res_ln768', 'quantize_mxfp8', 'layernorm768_mxfp8', 'qkv_time_attention_mx_q', 'attention_cls_partial_mx', 'attention_cls_combine_mx'):
         assert hasattr(torch.ops.synchformer, name), name
     for fp8 in (False, True):
         sd = synth.make_state_dict(1337, n_pos=184, n_out=2, head='sync_head') if fp8 else synth.make_state_dict(1337)

@@ -678,6 +678,16 @@ def test_qkv_time_attention_mx(gpu, n_seq):
     torch.testing.assert_close(o[:, 1:], r[:, 1:], rtol=2 ** -6, atol=2 ** -7 * max(1.0, scale))
     assert (o[:, 1:] - r[:, 1:]).abs().gt(1e-3 * max(1.0, scale)).float().mean() < 5e-3
     torch.testing.assert_close(o[:, 0], r[:, 0], rtol=2 ** -6, atol=2 ** -7 * max(1.0, scale))
+    # the MXFP8-output variant (+ the MX combine for the CLS rows) == sf_quantize_mxfp8 of the bf16 output above, byte for byte
+    q0, s0 = torch.empty(rows, D, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(rows, D, gpu)
+    ops.quantize_mxfp8(out, q0, s0)
+    q1, s1 = torch.full((rows + 1, D), 7, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(rows, D, gpu)
+    part1 = torch.zeros_like(part)
+    ops.qkv_time_attention_mx(xq, xs, wq, ws, b, qkv_cls, q1, part1, n_seq=n_seq, n_groups=196, scale=0.125, out_scales=s1)
+    assert torch.equal(part1, part) and (q1[:rows].view(n_seq, L, D)[:, 0] == 7).all()
+    ops.attention_cls_combine_mx(part1, q1, s1, n_part=49, n_seq=n_seq, out_seq_rows=L, out_row=0, heads=12)
+    assert torch.equal(q0, q1[:rows]) and (q1[rows:] == 7).all()
+    assert torch.equal(s0[:, :rows], s1[:, :rows]) and (s1[:, rows:] == 0).all()
 
 
 @pytest.mark.parametrize('sched', [0, 1])
