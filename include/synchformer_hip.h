@@ -29,7 +29,7 @@ extern "C" {
 enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2, SF_U8 = 3 };   /* element types */
 enum { SF_EPI_NONE = 0, SF_EPI_GELU = 1 };                  /* GEMM epilogue activation */
 
-#define SF_ABI_VERSION 3
+#define SF_ABI_VERSION 4
 int sf_abi_version(void);
 const char* sf_last_error(void);
 /* "gfx950" + build flags; lets the host assert it loaded the library it built */

@@ -10,7 +10,7 @@ from pathlib import Path
 
 LIB_DIR = Path(__file__).resolve().parent / 'lib'
 LIB_NAME = 'libsynchformer_hip.so'
-ABI_VERSION = 3     # 3: round 3, second half (sf_gemm_mx_res_ln768, sf_qkv_time_attention_mx, sf_gemm_tn_pp, sf_branch_grad, ... added); 2: sf_gemm_res_ln_force_schedule
+ABI_VERSION = 4     # 4: MXFP8-output attention launches (sf_attention_cls_partial_mx, sf_attention_cls_combine_mx, sf_qkv_time_attention_mx_q); 3: round 3, second half (sf_gemm_mx_res_ln768, sf_qkv_time_attention_mx, sf_gemm_tn_pp, sf_branch_grad, ... added); 2: sf_gemm_res_ln_force_schedule
 
 _i64, _i32, _f32, _ptr = C.c_int64, C.c_int, C.c_float, C.c_void_p
 
