@@ -664,7 +664,7 @@ __global__ __launch_bounds__(256) void attn_cls64_kernel(ClsArgs p) {
 // ======================================================================================================
 #define ATT_MAX_KT 13            // 13 x 16 = 208 keys / queries max
 #ifndef SF_ATT_ABL
-#define SF_ATT_ABL 0             // tools/ablate_attention.sh only: 1 skip stores, 2 skip P V, 4 skip softmax, 8 one query tile per wave
+#define SF_ATT_ABL 0             // tools/ab_pp.sh (SRC=sf_attention) + tools/ab_att_run.sh only: 1 skip stores, 2 skip P V, 4 skip softmax, 8 one query tile per wave, 16 / 32 one K / V fragment read for all key tiles
 #endif
 
 typedef short att_s4 __attribute__((ext_vector_type(4)));
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
       {
 #pragma unroll
         for (int ks = 0; ks < D / 32; ++ks) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + k_lds_off<D>(kt * 16 + fr, ks * 4 + fg));
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + k_lds_off<D>(((SF_ATT_ABL & 16) ? 0 : kt * 16) + fr, ks * 4 + fg));   // (ABL 16: every key tile reads tile 0's fragment - the compiler keeps one read: what do the K fragment reads cost?)
           s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[kt], 0, 0, 0);
         }
       }
@@ -871,10 +871,10 @@ __global__ __launch_bounds__(256, 3) void attn_mfma_kernel(AttnArgs p) {
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt) {
           union { bf16x8 v; att_s4 h[2]; } vb;
-          vb.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4*)(v_lds + v_off[dt] + kk * 32 * AttLds<D>::K_LD));
+          vb.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4*)(v_lds + v_off[dt] + ((SF_ATT_ABL & 32) ? 0 : kk * 32) * AttLds<D>::K_LD));
           vb.h[1] = att_s4{0, 0, 0, 0};
           if (2 * kk + 1 < NKT)                                                       // no 14th key tile: P is zero there, skip the read
-            vb.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4*)(v_lds + v_off[dt] + (kk * 32 + 16) * AttLds<D>::K_LD));
+            vb.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4*)(v_lds + v_off[dt] + (((SF_ATT_ABL & 32) ? 0 : kk * 32) + 16) * AttLds<D>::K_LD));
           o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb.v, pa.v, o[dt], 0, 0, 0);   // O^T tile: (d, query)
         }
       }
