@@ -377,6 +377,19 @@ int sf_attention_group_bwd(const uint16_t* q, const uint16_t* k, const uint16_t*
                            uint16_t* dk, uint16_t* dv, int64_t ldg, uint16_t* cls_part, int64_t n_seq, int64_t seq_rows, int n_groups, int row0,
                            int group_stride, int tok_stride, int n_tok, int cls_row, int heads, int head_dim, float scale, void* stream);
 
+/* sf_attention_group_bwd with the CLS QUERY's backward (sf_attention_cls_bwd's job: vit_helper.py:126, the CLS query attends every key of the sequence) in the same
+ * launch: the CLS query rides as one more query row of every group, normalised with the forward's statistics cls_stats [n_seq][heads][2] = (m in the base-2 domain
+ * incl. the scale, l) from sf_attention_cls_combine_stats, delta = <dO, o> from the forward's output row o[(seq * seq_rows + cls_row) * ldo + ...].  dk / dv (and
+ * cls_part) then hold both contributions - no read-modify-write pass over them - and the CLS query's dq comes out as one partial row per group, dq_cls_part
+ * (n_seq * n_groups, heads * 64) bf16: sf_reduce_groups_bf16 sums them into row cls_row of dq.  n_tok % 16 != 0 (a free query slot). */
+int sf_attention_group_bwd_clsq(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld, const uint16_t* dO, int64_t lddo, uint16_t* dq,
+                                uint16_t* dk, uint16_t* dv, int64_t ldg, uint16_t* cls_part, const float* cls_stats, const uint16_t* o, int64_t ldo,
+                                uint16_t* dq_cls_part, int64_t n_seq, int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok,
+                                int cls_row, int heads, int head_dim, float scale, void* stream);
+/* sf_attention_cls_combine that also writes the merged softmax statistics stats[(seq * heads + head) * 2 + {0, 1}] = (M, L) of the CLS query. */
+int sf_attention_cls_combine_stats(const float* partials, int n_part, uint16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row, int64_t n_seq, int heads,
+                                   float* stats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

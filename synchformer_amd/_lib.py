@@ -86,6 +86,8 @@ SIGNATURES = {
                                _i32, _f32, _ptr],
     'sf_attention_cls_partial': [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _ptr, _ptr],
     'sf_attention_cls_combine': [_ptr, _i32, _ptr, _i64, _i64, _i32, _i64, _i32, _ptr],
+    'sf_attention_cls_combine_stats': [_ptr, _i32, _ptr, _i64, _i64, _i32, _i64, _i32, _ptr, _ptr],
+    'sf_attention_group_bwd_clsq': [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _ptr],
     'sf_attention_cls_partial_mx': [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _ptr, _ptr],
     'sf_attention_cls_combine_mx': [_ptr, _i32, _ptr, _i64, _ptr, _i64, _i64, _i32, _i64, _i32, _ptr],
     'sf_qkv_time_attention': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i32, _f32, _ptr],

@@ -197,6 +197,10 @@ struct AttnBwdArgs {
   int64_t seq_rows;
   int n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads;
   float scale;
+  // optional (attn_group_bwd_kernel, sf_attention_group_bwd_clsq): the CLS QUERY's backward (vit_helper.py:126: it attends every key of the sequence) rides along as
+  // one more query row of every group - with the statistics of its softmax over ALL keys from the forward (cls_stats [seq][head][2] = m in the base-2 domain, l),
+  // its output row `o` (delta = <dO, o>), and its dq as one partial row per group in dq_cls_part (n_seq * n_groups, heads * 64)
+  const float* cls_stats = nullptr; const bf16_t* o = nullptr; int64_t ldo = 0; bf16_t* dq_cls_part = nullptr;
 };
 
 __global__ __launch_bounds__(256) void attn_tiny64_bwd_kernel(AttnBwdArgs p, int64_t total_units) {
@@ -331,7 +335,7 @@ extern "C" int sf_attention_tiny_bwd(const bf16_t* q, const bf16_t* k, const bf1
 #define GB_ROWS 208
 #define GB_MAT (GB_ROWS * GB_LD * 2)                       // 29,952 B per staged matrix
 #define GB_WAVES 16               // one wave per query tile (pass 1) / key tile (pass 2) of the 13; four waves per SIMD hide the dependent LDS round trips of the fragment reads
-#define GB_LDS(WAVES) (4 * GB_MAT + GB_ROWS * 3 * 4 + (WAVES) * 16 * GB_LD * 2)
+#define GB_LDS(WAVES) (4 * GB_MAT + GB_ROWS * 3 * 4 + (WAVES) * 16 * GB_LD * 2 + 16)   // (+ 16: the CLS query's delta, sf_attention_group_bwd_clsq)
 
 __device__ __forceinline__ bf16x4 gb_row_frag(const bf16_t* X, int row, int k0) { return *reinterpret_cast<const bf16x4*>(X + row * GB_LD + k0); }
 // Column fragment X[row0 + 0..3][col0 + lr] of a row-major LDS matrix (lane = 16*lg + lr; row0 is the same for the 16 lanes of a group)
@@ -373,6 +377,17 @@ __global__ __launch_bounds__(GBW * 64) void attn_group_bwd_kernel(AttnBwdArgs p)
   const int hcol = head * 64;
   auto key_row = [&](int j) -> int64_t { return (has_cls && j == 0) ? seq_base + p.cls_row : first + (int64_t)(j - has_cls) * p.tok_stride; };
   auto tok_row = [&](int i) -> int64_t { return first + (int64_t)i * p.tok_stride; };
+  // The CLS query as query row nq (the host guarantees a free slot: nq % 16 != 0).  Its probabilities are normalised with the forward's statistics over ALL keys of the
+  // sequence (this group holds 1/n_groups of them), its delta is <dO, o>; the CLS KEY (key 0 of every group) counts for it in group 0 only.
+  const bool clsq = p.cls_stats != nullptr;
+  const int nqe = nq + (clsq ? 1 : 0);
+  float* cls_d = reinterpret_cast<float*>(outl + GBW * 16 * GB_LD);   // one float behind the staging tiles
+  if (clsq && wave == 0) {
+    const int64_t r = seq_base + p.cls_row;
+    float d = bf2f(p.dO[r * p.lddo + hcol + lane]) * bf2f(p.o[r * p.ldo + hcol + lane]);
+    d = wave_sum(d);
+    if (lane == 0) *cls_d = d;
+  }
 
   // ---- stage K, V (key rows) and Q, dO (query rows): 208 rows x 8 chunks of 16 B each, zero beyond the valid rows -------------
   for (int idx = tid; idx < GB_ROWS * 8; idx += GBW * 64) {
@@ -383,8 +398,8 @@ __global__ __launch_bounds__(GBW * 64) void attn_group_bwd_kernel(AttnBwdArgs p)
       kk = *reinterpret_cast<const uint4*>(p.k + r * p.ld + hcol + ch * 8);
       vv = *reinterpret_cast<const uint4*>(p.v + r * p.ld + hcol + ch * 8);
     }
-    if (row < nq) {
-      const int64_t r = tok_row(row);
+    if (row < nq || (clsq && row == nq)) {                     // slot nq: the CLS query and its dO
+      const int64_t r = row < nq ? tok_row(row) : seq_base + p.cls_row;
       qq = *reinterpret_cast<const uint4*>(p.q + r * p.ld + hcol + ch * 8);
       dd = *reinterpret_cast<const uint4*>(p.dO + r * p.lddo + hcol + ch * 8);
     }
@@ -423,6 +438,7 @@ __global__ __launch_bounds__(GBW * 64) void attn_group_bwd_kernel(AttnBwdArgs p)
         if (kt * 16 + lg * 4 + r >= nk) sc[r] = -INFINITY;
         tmax = fmaxf(tmax, sc[r]);
       }
+      if (clsq && g != 0 && kt == 0 && lg == 0 && qt * 16 + lr == nq) { sc[0] = -INFINITY; tmax = fmaxf(fmaxf(sc[1], sc[2]), sc[3]); }
       tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64)); tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
       const float m_new = fmaxf(m, tmax);                          // finite: key 0 of tile 0 always exists
       if (__any(m_new != m)) {                                     // the running maximum of some query moved: rescale what has been summed under the old one
@@ -455,9 +471,16 @@ __global__ __launch_bounds__(GBW * 64) void attn_group_bwd_kernel(AttnBwdArgs p)
     const float msc = m * sc2;
     l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
     delta += __shfl_xor(delta, 16, 64); delta += __shfl_xor(delta, 32, 64);
-    const float linv = 1.0f / l;
+    float linv = 1.0f / l;
     delta *= linv;
-    if (lg == 0) { float* st = stats + (qt * 16 + lr) * 3; st[0] = msc; st[1] = linv; st[2] = delta; }
+    float st_m = msc, st_linv = linv;
+    if (clsq && qt * 16 + lr == nq) {                            // the CLS query: global statistics; the sums above were taken under this group's running maximum
+      const float* gs = p.cls_stats + (seq * p.heads + head) * 2;
+      st_m = gs[0]; st_linv = 1.0f / gs[1];
+      linv = __builtin_amdgcn_exp2f(msc - st_m) * st_linv;
+      delta = *cls_d;
+    }
+    if (lg == 0) { float* st = stats + (qt * 16 + lr) * 3; st[0] = st_m; st[1] = st_linv; st[2] = delta; }
     // l and delta belong to the lane's query COLUMN (qt*16 + lr); the dQ accumulators hold query ROWS lg*4 + r: fetch the row's values from its column lane
     f32x4 dq[4];
 #pragma unroll
@@ -475,10 +498,12 @@ __global__ __launch_bounds__(GBW * 64) void attn_group_bwd_kernel(AttnBwdArgs p)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = lane + i * 64, row = idx >> 3, ch = idx & 7, qi = qt * 16 + row;
-      if (qi < nq) {
+      if (qi < nqe) {
         const uint2* sp = reinterpret_cast<const uint2*>(myout + row * GB_LD + ch * 8);
         const uint2 a = sp[0], b = sp[1];
-        *reinterpret_cast<uint4*>(p.dq + tok_row(qi) * p.ldg + hcol + ch * 8) = make_uint4(a.x, a.y, b.x, b.y);
+        bf16_t* dst = qi < nq ? p.dq + tok_row(qi) * p.ldg + hcol + ch * 8
+                              : p.dq_cls_part + (seq * p.n_groups + g) * (int64_t)(p.heads * 64) + hcol + ch * 8;   // this group's share of the CLS query's dq
+        *reinterpret_cast<uint4*>(dst) = make_uint4(a.x, a.y, b.x, b.y);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -506,7 +531,8 @@ __global__ __launch_bounds__(GBW * 64) void attn_group_bwd_kernel(AttnBwdArgs p)
       for (int r = 0; r < 4; ++r) {
         const int qi = qt * 16 + lg * 4 + r;
         const float* st = stats + qi * 3;
-        const float pr = (key_ok && qi < nq) ? __builtin_amdgcn_exp2f(fmaf(s2[r], sc2, -st[0])) * st[1] : 0.f;
+        const bool live = key_ok && qi < nqe && !(clsq && g != 0 && qi == nq && kt * 16 + lr == 0);
+        const float pr = live ? __builtin_amdgcn_exp2f(fmaf(s2[r], sc2, -st[0])) * st[1] : 0.f;
         pp[r] = pr;
         ds[r] = pr * (dp2[r] - st[2]) * p.scale;
       }
@@ -542,9 +568,37 @@ __global__ __launch_bounds__(GBW * 64) void attn_group_bwd_kernel(AttnBwdArgs p)
   }
 }
 
+static int attention_group_bwd_impl(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const bf16_t* dO, int64_t lddo, bf16_t* dq,
+                                    bf16_t* dk, bf16_t* dv, int64_t ldg, bf16_t* cls_part, int64_t n_seq, int64_t seq_rows, int n_groups, int row0,
+                                    int group_stride, int tok_stride, int n_tok, int cls_row, int heads, int head_dim, float scale, const float* cls_stats,
+                                    const bf16_t* o, int64_t ldo, bf16_t* dq_cls_part, void* stream);
+
 extern "C" int sf_attention_group_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const bf16_t* dO, int64_t lddo, bf16_t* dq,
                                       bf16_t* dk, bf16_t* dv, int64_t ldg, bf16_t* cls_part, int64_t n_seq, int64_t seq_rows, int n_groups, int row0,
                                       int group_stride, int tok_stride, int n_tok, int cls_row, int heads, int head_dim, float scale, void* stream) {
+  return attention_group_bwd_impl(q, k, v, ld, dO, lddo, dq, dk, dv, ldg, cls_part, n_seq, seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads,
+                                  head_dim, scale, nullptr, nullptr, 0, nullptr, stream);
+}
+
+// sf_attention_group_bwd + the backward of the CLS QUERY (the row sf_attention_cls_bwd handles: it attends all keys of the sequence) in the same launch: the CLS query
+// is one more query row of every group, normalised with the forward's softmax statistics cls_stats [n_seq][heads][2] (m in the base-2 domain incl. the scale, l -
+// sf_attention_cls_combine_stats) and delta = <dO, o> from the forward's output row `o` (row seq * seq_rows + cls_row, stride ldo).  dk / dv of every row then hold
+// BOTH contributions (no read-modify-write pass over them), cls_part includes the CLS query's share of the CLS key, and the CLS query's dq comes out as one partial row
+// per group: dq_cls_part (n_seq * n_groups, heads * 64) bf16, to be summed into row cls_row of dq by sf_reduce_groups_bf16.  Needs n_tok % 16 != 0.
+extern "C" int sf_attention_group_bwd_clsq(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const bf16_t* dO, int64_t lddo, bf16_t* dq,
+                                           bf16_t* dk, bf16_t* dv, int64_t ldg, bf16_t* cls_part, const float* cls_stats, const bf16_t* o, int64_t ldo,
+                                           bf16_t* dq_cls_part, int64_t n_seq, int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride,
+                                           int n_tok, int cls_row, int heads, int head_dim, float scale, void* stream) {
+  SF_CHECK_ARG(cls_stats && o && dq_cls_part && cls_row >= 0 && (n_tok % 16) != 0 && (ldo % 8) == 0,
+               "sf_attention_group_bwd_clsq: needs statistics, the forward output, a partial buffer, a CLS row and a free query slot (n_tok %% 16 != 0)");
+  return attention_group_bwd_impl(q, k, v, ld, dO, lddo, dq, dk, dv, ldg, cls_part, n_seq, seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads,
+                                  head_dim, scale, cls_stats, o, ldo, dq_cls_part, stream);
+}
+
+static int attention_group_bwd_impl(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const bf16_t* dO, int64_t lddo, bf16_t* dq,
+                                    bf16_t* dk, bf16_t* dv, int64_t ldg, bf16_t* cls_part, int64_t n_seq, int64_t seq_rows, int n_groups, int row0,
+                                    int group_stride, int tok_stride, int n_tok, int cls_row, int heads, int head_dim, float scale, const float* cls_stats,
+                                    const bf16_t* o, int64_t ldo, bf16_t* dq_cls_part, void* stream) {
   SF_CHECK_ARG(q && k && v && dO && dq && dk && dv, "sf_attention_group_bwd: null pointer");
   SF_CHECK_ARG(head_dim == 64 && n_tok >= 1 && n_tok + (cls_row >= 0 ? 1 : 0) <= GB_ROWS && (cls_row < 0 || cls_part),
                "sf_attention_group_bwd: head_dim 64, n_tok (+1) <= 208, cls_part with cls_row");
@@ -554,6 +608,7 @@ extern "C" int sf_attention_group_bwd(const bf16_t* q, const bf16_t* k, const bf
   a.q = q; a.k = k; a.v = v; a.ld = ld; a.dO = dO; a.lddo = lddo; a.dq = dq; a.dk = dk; a.dv = dv; a.ldg = ldg; a.cls_part = cls_part;
   a.seq_rows = seq_rows; a.n_groups = n_groups; a.row0 = row0; a.group_stride = group_stride; a.tok_stride = tok_stride; a.n_tok = n_tok;
   a.cls_row = cls_row; a.heads = heads; a.scale = scale;
+  a.cls_stats = cls_stats; a.o = o; a.ldo = ldo; a.dq_cls_part = dq_cls_part;
   const int64_t units = n_seq * n_groups * heads;
   SF_CHECK_ARG(units < ((int64_t)1 << 31), "sf_attention_group_bwd: too many groups");
   static int waves = -1;
@@ -965,7 +1020,7 @@ static int dispatch_attn_mfma(const AttnArgs& a, int64_t n_seq, int nkt, hipStre
 
 // Merge the per-group partials of the CLS query: out[seq*out_seq_rows + out_row, head*64 + d] = sum_p o_p[d] 2^(m_p - M) / sum_p l_p 2^(m_p - M)
 __global__ __launch_bounds__(64) void attn_cls_combine64_kernel(const float* __restrict__ part, int n_part, bf16_t* __restrict__ out, int64_t ldo,
-                                                                 int64_t out_seq_rows, int out_row, int heads) {
+                                                                 int64_t out_seq_rows, int out_row, int heads, float* __restrict__ stats = nullptr) {
   const int head = blockIdx.x % heads, d = threadIdx.x;
   const int64_t seq = blockIdx.x / heads;
   const float* pp = part + (int64_t)blockIdx.x * n_part * 66;
@@ -978,6 +1033,17 @@ __global__ __launch_bounds__(64) void attn_cls_combine64_kernel(const float* __r
     O += pp[i * 66 + 2 + d] * w;
   }
   out[(seq * out_seq_rows + out_row) * ldo + head * 64 + d] = f2bf(O / L);
+  if (stats && d == 0) { stats[(int64_t)blockIdx.x * 2] = M; stats[(int64_t)blockIdx.x * 2 + 1] = L; }   // the merged softmax statistics (the backward's, sf_attention_group_bwd_clsq)
+}
+
+extern "C" int sf_attention_cls_combine_stats(const float* partials, int n_part, uint16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row,
+                                              int64_t n_seq, int heads, float* stats, void* stream) {
+  SF_CHECK_ARG(partials && out && stats && n_part >= 1 && heads >= 1, "sf_attention_cls_combine_stats: bad arguments");
+  if (n_seq <= 0) return 0;
+  hipLaunchKernelGGL(attn_cls_combine64_kernel, dim3((unsigned)(n_seq * heads)), dim3(64), 0, (hipStream_t)stream, partials, n_part, out, ldo,
+                     out_seq_rows, out_row, heads, stats);
+  SF_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int sf_attention_cls_combine(const float* partials, int n_part, uint16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row,
@@ -985,7 +1051,7 @@ extern "C" int sf_attention_cls_combine(const float* partials, int n_part, uint1
   SF_CHECK_ARG(partials && out && n_part >= 1 && heads >= 1, "sf_attention_cls_combine: bad arguments");
   if (n_seq <= 0) return 0;
   hipLaunchKernelGGL(attn_cls_combine64_kernel, dim3((unsigned)(n_seq * heads)), dim3(64), 0, (hipStream_t)stream, partials, n_part, out, ldo,
-                     out_seq_rows, out_row, heads);
+                     out_seq_rows, out_row, heads, (float*)nullptr);
   SF_LAUNCH_CHECK();
   return 0;
 }

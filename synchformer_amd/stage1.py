@@ -75,6 +75,9 @@ class AVCLIPTrainer(FlatTrainer):
         self.drop_path_rate, self.seed, self.fwd_count = float(drop_path_rate or 0.0), int(seed), 0
         self.time_comm, self._comm_ev = False, None                            # bench.py: HIP events around the bucket waits
         self.fused_attn_bwd = True          # False: the gathered batched-GEMM attention backward (kept as a cross-check)
+        # the CLS query's backward of the space attention inside sf_attention_group_bwd (as one more query row per group, on the forward's softmax statistics)
+        # instead of sf_attention_cls_bwd's read-modify-write pass over dk | dv; SF_CLS_IN_GROUP=0 keeps the separate pass
+        self.cls_in_group = os.environ.get('SF_CLS_IN_GROUP', '1') != '0'
         self.two_streams = os.environ.get('SF_STAGE1_TWO_STREAMS', '1') != '0'   # audio tower next to the visual one (forward_backward)
         self._side = None
         self._pre_ln = set()                # workspace buffers whose LayerNorm output _add_branch has already produced (consumed by _ln_into)
@@ -207,7 +210,8 @@ class AVCLIPTrainer(FlatTrainer):
         cls_grp = ops.rowmap(G, G, G * Lg, 0, Lg, 0)
         return G, T, Lg, tok, grp, cls_tok, cls_grp
 
-    def _divided_fwd(self, qkv, att, n, kind):
+    def _divided_fwd(self, qkv, att, n, kind, stats=None):
+        """stats (space only, optional): fp32 (n * H * 2) - the CLS query's merged softmax statistics, kept for sf_attention_group_bwd_clsq."""
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         kw = dict(n_groups=196, row0=1, group_stride=1, tok_stride=196, n_tok=8) if kind == 'time' else \
             dict(n_groups=8, row0=1, group_stride=196, tok_stride=1, n_tok=196)
@@ -217,7 +221,11 @@ class AVCLIPTrainer(FlatTrainer):
             # (segment, head) make the combine launch slower than the pass it replaces (59 us against 44 us, profiled)
             part = self._buf('cls_part', (n * H * 8 * 66,), torch.float32)
             ops.attention_cls_partial(q, k, v, att, part, n_seq=n, seq_rows=VIS_L, cls_row=0, heads=H, head_dim=HD, scale=0.125, **kw)
-            ops.attention_cls_combine(part, att, n_part=8, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=H)
+            if stats is not None:
+                _chk(_lib.load().sf_attention_cls_combine_stats(part.data_ptr(), 8, att.data_ptr(), att.stride(0), VIS_L, 0, n, H, stats.data_ptr(), _st()),
+                     'sf_attention_cls_combine_stats')
+            else:
+                ops.attention_cls_combine(part, att, n_part=8, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=H)
             return
         ops.attention(q, k, v, att, n_seq=n, seq_rows=VIS_L, cls_row=0, heads=H, head_dim=HD, scale=0.125, **kw)
         ops.attention_cls(q, k, v, att, n_seq=n, q_seq_rows=VIS_L, q_row=0, kv_seq_rows=VIS_L, kv_row0=0, n_keys=VIS_L,
@@ -229,8 +237,9 @@ class AVCLIPTrainer(FlatTrainer):
             c = min(step, nseq - s0)
             self.attn_bwd_seq(Gq[s0 * Lg:(s0 + c) * Lg], GdO[s0 * Lg:(s0 + c) * Lg], Gd[s0 * Lg:(s0 + c) * Lg], c, Lg, H, HD)
 
-    def _divided_bwd(self, qkv, dO_b, n, kind):
-        """qkv (n*1569, 2304) bf16 saved, dO_b (n*1569, 768) bf16 -> dqkv (n*1569, 2304) bf16."""
+    def _divided_bwd(self, qkv, dO_b, n, kind, att=None, stats=None):
+        """qkv (n*1569, 2304) bf16 saved, dO_b (n*1569, 768) bf16 -> dqkv (n*1569, 2304) bf16.  att / stats (space, optional): the forward's attention output and the
+        CLS query's softmax statistics - then the CLS query's backward runs inside the group kernel."""
         G, T, Lg, tok, grp, cls_tok, cls_grp = self._group_maps(kind)
         nseq, rows_g, M = n * G, n * G * Lg, n * VIS_L
         if self.fused_attn_bwd:
@@ -239,6 +248,17 @@ class AVCLIPTrainer(FlatTrainer):
             dqkv = self._buf('dqkv', (M, 3 * D), torch.bfloat16)
             part = self._buf('cls_kv_part', (nseq, 2 * D), torch.bfloat16)
             geo = (196, 1, 1, 196, 8) if kind == 'time' else (8, 1, 196, 1, 196)          # n_groups, row0, group_stride, tok_stride, n_tok
+            if kind == 'space' and stats is not None:
+                dqc = self._buf('cls_dq_part', (nseq, D), torch.bfloat16)
+                _chk(_lib.load().sf_attention_group_bwd_clsq(qkv.data_ptr(), qkv[:, D:].data_ptr(), qkv[:, 2 * D:].data_ptr(), qkv.stride(0), dO_b.data_ptr(),
+                                                             dO_b.stride(0), dqkv.data_ptr(), dqkv[:, D:].data_ptr(), dqkv[:, 2 * D:].data_ptr(), dqkv.stride(0),
+                                                             part.data_ptr(), stats.data_ptr(), att.data_ptr(), att.stride(0), dqc.data_ptr(), n, VIS_L, *geo, 0, H, HD,
+                                                             0.125, _st()), 'sf_attention_group_bwd_clsq')
+                # the CLS row: dk | dv = the sum over the groups' slot-0 rows, dq = the sum of the groups' partial rows
+                _chk(_lib.load().sf_reduce_groups_bf16(part.data_ptr(), G * 2 * D, 2 * D, G, dqkv[:, D:].data_ptr(), VIS_L * 3 * D, 2 * D, n, 0, _st()),
+                     'sf_reduce_groups_bf16')
+                _chk(_lib.load().sf_reduce_groups_bf16(dqc.data_ptr(), G * D, D, G, dqkv.data_ptr(), VIS_L * 3 * D, D, n, 0, _st()), 'sf_reduce_groups_bf16')
+                return dqkv
             fn = _lib.load().sf_attention_tiny_bwd if kind == 'time' else _lib.load().sf_attention_group_bwd
             _chk(fn(qkv.data_ptr(), qkv[:, D:].data_ptr(), qkv[:, 2 * D:].data_ptr(), qkv.stride(0), dO_b.data_ptr(), dO_b.stride(0), dqkv.data_ptr(),
                     dqkv[:, D:].data_ptr(), dqkv[:, 2 * D:].data_ptr(), dqkv.stride(0), part.data_ptr(), n, VIS_L, *geo, 0, H, HD, 0.125, _st()),
@@ -345,7 +365,8 @@ class AVCLIPTrainer(FlatTrainer):
                 s['qkv' + key] = self._buf(f'{t}_qkv{key}', (M, 3 * D), torch.bfloat16)
                 ops.gemm(s['h' + key], *self._wb(f'{p}.{att}.qkv'), s['qkv' + key])
                 s['att' + key] = self._buf(f'{t}_att{key}', (M, D), torch.bfloat16)
-                self._divided_fwd(s['qkv' + key], s['att' + key], n, kind)
+                s['cst' + key] = self._buf(f'{t}_cst{key}', (n * H * 2,), torch.float32) if (kind == 'space' and self.cls_in_group and self.fused_attn_bwd) else None
+                self._divided_fwd(s['qkv' + key], s['att' + key], n, kind, stats=s['cst' + key])
                 xn = self._buf(f'{t}_x{key}', (M, D), torch.float32)
                 dp = s['dp_s'] = self._dp_scales(i, 0, n) if kind == 'space' else None     # time attention has no DropPath (vit_helper.py:367-369)
                 if dp is None:
@@ -383,7 +404,7 @@ class AVCLIPTrainer(FlatTrainer):
         for i in reversed(range(self.n_vblocks)):
             p, s = f'{V}.blocks.{i}', sv['blocks'][i]
             self._mlp_bwd(s, dx, s['xs'], p + '.mlp.fc1', p + '.mlp.fc2', M, p + '.norm2', EPS_VIS, dp=s['dp_m'], seq_rows=VIS_L)
-            self._attn_branch_bwd(dx, M, p + '.attn.proj', s['atts'], lambda dO, q=s['qkvs']: self._divided_bwd(q, dO, n, 'space'), s['hs'],
+            self._attn_branch_bwd(dx, M, p + '.attn.proj', s['atts'], lambda dO, q=s['qkvs'], a=s['atts'], c=s['csts']: self._divided_bwd(q, dO, n, 'space', att=a, stats=c), s['hs'],
                                   s['xt'], p + '.norm1', EPS_VIS, p + '.attn.qkv', dp=s['dp_s'], seq_rows=VIS_L)
             self._attn_branch_bwd(dx, M, p + '.timeattn.proj', s['attt'], lambda dO, q=s['qkvt']: self._divided_bwd(q, dO, n, 'time'), s['ht'],
                                   s['x'], p + '.norm3', EPS_VIS, p + '.timeattn.qkv')

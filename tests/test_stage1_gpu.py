@@ -542,3 +542,60 @@ def test_divided_bwd_fused_vs_gathered(gpu, kind):
     rel = ((a - b).norm() / b.norm()).item()
     print(f'{kind}: fused vs gathered rel-L2 {rel:.4f}')
     assert rel < 1.5e-2
+
+
+@pytest.mark.gpu
+def test_space_attention_bwd_cls_query_in_group_kernel(gpu):
+    """sf_attention_group_bwd_clsq (the CLS query's backward as one more query row of every space group, on the forward's softmax statistics) against the path it
+    replaces - sf_attention_group_bwd + sf_attention_cls_bwd's read-modify-write pass: the same dqkv (all rows: dq of the CLS row, dk | dv of every row) up to bf16
+    rounding of partial sums."""
+    from synchformer_amd import ops
+    n, L, Dm, H = 3, 1569, 768, 12
+    torch.manual_seed(21)
+    qkv = (torch.randn(n * L, 3 * Dm, device=gpu) * 0.8).bfloat16()
+    qkv[::L] *= 1.5                                                           # sharper CLS queries / keys
+    dO = (torch.randn(n * L, Dm, device=gpu) * 0.5).bfloat16()
+    q, k, v = qkv[:, :Dm], qkv[:, Dm:2 * Dm], qkv[:, 2 * Dm:]
+    geo = (8, 1, 196, 1, 196)
+    # forward: attention output + the CLS query's merged statistics
+    att = torch.zeros(n * L, Dm, device=gpu, dtype=torch.bfloat16)
+    fpart = torch.empty(n * H * 8 * 66, device=gpu)
+    ops.attention_cls_partial(q, k, v, att, fpart, n_seq=n, seq_rows=L, n_groups=8, row0=1, group_stride=196, tok_stride=1, n_tok=196, cls_row=0, heads=H, head_dim=64,
+                              scale=0.125)
+    stats = torch.empty(n * H * 2, device=gpu)
+    rc = _lib().sf_attention_cls_combine_stats(fpart.data_ptr(), 8, att.data_ptr(), Dm, L, 0, n, H, stats.data_ptr(), _st())
+    assert rc == 0, _lib().sf_last_error()
+    att2 = att.clone()
+    ops.attention_cls_combine(fpart, att2, n_part=8, n_seq=n, out_seq_rows=L, out_row=0, heads=H)
+    assert torch.equal(att, att2)
+
+    def old():
+        d = torch.zeros(n * L, 3 * Dm, device=gpu, dtype=torch.bfloat16)
+        part = torch.zeros(n * 8, 2 * Dm, device=gpu, dtype=torch.bfloat16)
+        assert _lib().sf_attention_group_bwd(qkv.data_ptr(), k.data_ptr(), v.data_ptr(), 3 * Dm, dO.data_ptr(), Dm, d.data_ptr(), d[:, Dm:].data_ptr(),
+                                             d[:, 2 * Dm:].data_ptr(), 3 * Dm, part.data_ptr(), n, L, *geo, 0, H, 64, 0.125, _st()) == 0
+        assert _lib().sf_reduce_groups_bf16(part.data_ptr(), 8 * 2 * Dm, 2 * Dm, 8, d[:, Dm:].data_ptr(), L * 3 * Dm, 2 * Dm, n, 0, _st()) == 0
+        assert _lib().sf_attention_cls_bwd(qkv.data_ptr(), L, 0, k.data_ptr(), v.data_ptr(), 3 * Dm, L, 0, L, dO.data_ptr(), Dm, L, 0, d.data_ptr(), d[:, Dm:].data_ptr(),
+                                           d[:, 2 * Dm:].data_ptr(), 3 * Dm, n, H, 64, 0.125, 1, _st()) == 0
+        return d
+
+    def new():
+        d = torch.zeros(n * L, 3 * Dm, device=gpu, dtype=torch.bfloat16)
+        part = torch.zeros(n * 8, 2 * Dm, device=gpu, dtype=torch.bfloat16)
+        dqc = torch.zeros(n * 8, Dm, device=gpu, dtype=torch.bfloat16)
+        rc = _lib().sf_attention_group_bwd_clsq(qkv.data_ptr(), k.data_ptr(), v.data_ptr(), 3 * Dm, dO.data_ptr(), Dm, d.data_ptr(), d[:, Dm:].data_ptr(),
+                                                d[:, 2 * Dm:].data_ptr(), 3 * Dm, part.data_ptr(), stats.data_ptr(), att.data_ptr(), Dm, dqc.data_ptr(), n, L, *geo, 0, H,
+                                                64, 0.125, _st())
+        assert rc == 0, _lib().sf_last_error()
+        assert _lib().sf_reduce_groups_bf16(part.data_ptr(), 8 * 2 * Dm, 2 * Dm, 8, d[:, Dm:].data_ptr(), L * 3 * Dm, 2 * Dm, n, 0, _st()) == 0
+        assert _lib().sf_reduce_groups_bf16(dqc.data_ptr(), 8 * Dm, Dm, 8, d.data_ptr(), L * 3 * Dm, Dm, n, 0, _st()) == 0
+        return d
+
+    a, b = old().float().cpu().view(n, L, 3, Dm), new().float().cpu().view(n, L, 3, Dm)
+    for name, sl in (('dq of the CLS rows', (slice(None), 0, 0)), ('dk | dv of the CLS rows', (slice(None), 0, slice(1, 3))), ('dq of the patches', (slice(None), slice(1, None), 0)),
+                     ('dk | dv of the patches', (slice(None), slice(1, None), slice(1, 3)))):
+        x, y = a[sl], b[sl]
+        rel = ((x - y).norm() / x.norm()).item()
+        print(f'{name}: rel-L2 {rel:.5f}, max |d| {(x - y).abs().max().item():.5f} (scale {x.abs().max().item():.3f})')
+        assert rel < 6e-3, name
+    assert torch.equal(a[:, 1:, 0], b[:, 1:, 0])                               # the patches' dq does not involve the CLS query at all
