@@ -29,7 +29,7 @@ extern "C" {
 enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2, SF_U8 = 3 };   /* element types */
 enum { SF_EPI_NONE = 0, SF_EPI_GELU = 1 };                  /* GEMM epilogue activation */
 
-#define SF_ABI_VERSION 4
+#define SF_ABI_VERSION 5
 int sf_abi_version(void);
 const char* sf_last_error(void);
 /* "gfx950" + build flags; lets the host assert it loaded the library it built */
@@ -386,6 +386,14 @@ int sf_attention_group_bwd_clsq(const uint16_t* q, const uint16_t* k, const uint
                                 uint16_t* dk, uint16_t* dv, int64_t ldg, uint16_t* cls_part, const float* cls_stats, const uint16_t* o, int64_t ldo,
                                 uint16_t* dq_cls_part, int64_t n_seq, int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok,
                                 int cls_row, int heads, int head_dim, float scale, void* stream);
+/* The same for the tiny time groups (sf_attention_tiny_bwd; statistics from sf_attention_cls_stats = sf_attention_cls + stats[(seq * heads + head) * 2 + {0, 1}]). */
+int sf_attention_tiny_bwd_clsq(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld, const uint16_t* dO, int64_t lddo, uint16_t* dq, uint16_t* dk,
+                               uint16_t* dv, int64_t ldg, uint16_t* cls_part, const float* cls_stats, const uint16_t* o, int64_t ldo, uint16_t* dq_cls_part,
+                               int64_t n_seq, int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok, int cls_row, int heads,
+                               int head_dim, float scale, void* stream);
+int sf_attention_cls_stats(const uint16_t* q, int64_t q_seq_rows, int q_row, const uint16_t* k, const uint16_t* v, int64_t ld, int64_t kv_seq_rows, int kv_row0,
+                           int n_keys, uint16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row, int64_t n_seq, int heads, int head_dim, float scale,
+                           float* stats, void* stream);
 /* sf_attention_cls_combine that also writes the merged softmax statistics stats[(seq * heads + head) * 2 + {0, 1}] = (M, L) of the CLS query. */
 int sf_attention_cls_combine_stats(const float* partials, int n_part, uint16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row, int64_t n_seq, int heads,
                                    float* stats, void* stream);

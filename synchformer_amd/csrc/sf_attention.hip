@@ -234,6 +234,48 @@ __global__ __launch_bounds__(256) void attn_tiny64_bwd_kernel(AttnBwdArgs p, int
   }
   *reinterpret_cast<uint4*>(&q_l[wv][qi][sub * 8]) = qraw;
   *reinterpret_cast<uint4*>(&do_l[wv][qi][sub * 8]) = doraw;
+  // ---- the CLS query (optional, sf_attention_tiny_bwd_clsq): it attends every key of the sequence, so here it is a ninth query on this group's keys, normalised with
+  // the forward's statistics; lane group qi handles key qi, key 8 is computed by every group (used by group 0's lanes in the second pass); the CLS KEY counts for
+  // it in group 0 only.  pc / dsc: its probability and score gradient for this lane group's key, p8 / ds8 for key 8.
+  const bool clsq = p.cls_stats != nullptr;
+  uint4 qc_raw = make_uint4(0, 0, 0, 0), doc_raw = qc_raw;
+  float pc = 0.f, dsc = 0.f, p8 = 0.f, ds8 = 0.f;
+  if (clsq) {
+    const int64_t cr = seq_base + p.cls_row;
+    qc_raw = *reinterpret_cast<const uint4*>(p.q + cr * p.ld + col);
+    doc_raw = *reinterpret_cast<const uint4*>(p.dO + cr * p.lddo + col);
+    const uint4 oc = *reinterpret_cast<const uint4*>(p.o + cr * p.ldo + col);
+    const float* gs = p.cls_stats + (seq * p.heads + head) * 2;
+    const float Mg = gs[0], Linv = 1.0f / gs[1];
+    uint4 ksel = kraw[0], vsel = vraw[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j)
+      if (qi == j) { ksel = kraw[j]; vsel = vraw[j]; }
+    float dl = dot8_bf16(doc_raw, oc), sc_ = dot8_bf16(qc_raw, ksel), dpc = dot8_bf16(doc_raw, vsel), s8 = dot8_bf16(qc_raw, kraw[8]), dp8 = dot8_bf16(doc_raw, vraw[8]);
+#pragma unroll
+    for (int o_ = 1; o_ < 8; o_ <<= 1) {
+      dl += __shfl_xor(dl, o_, 64); sc_ += __shfl_xor(sc_, o_, 64); dpc += __shfl_xor(dpc, o_, 64); s8 += __shfl_xor(s8, o_, 64); dp8 += __shfl_xor(dp8, o_, 64);
+    }
+    const float sc2c = p.scale * 1.44269504088896f;
+    if (qi < nk && !(has_cls && qi == 0 && g != 0)) { pc = __builtin_amdgcn_exp2f(fmaf(sc_, sc2c, -Mg)) * Linv; dsc = pc * (dpc - dl) * p.scale; }
+    if (8 < nk) { p8 = __builtin_amdgcn_exp2f(fmaf(s8, sc2c, -Mg)) * Linv; ds8 = p8 * (dp8 - dl) * p.scale; }
+    // its dq over this group's keys: lane group qi holds ds_qi * k_qi (+ key 8 in group 0's lanes), summed over the lane groups
+    sf_f32x2_t dqc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dqc[i] = sf_f32x2_t{0.f, 0.f};
+    axpy8_bf16(dqc, dsc, ksel);
+    if (qi == 0) axpy8_bf16(dqc, ds8, kraw[8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int o_ = 8; o_ < 64; o_ <<= 1) { dqc[i].x += __shfl_xor(dqc[i].x, o_, 64); dqc[i].y += __shfl_xor(dqc[i].y, o_, 64); }
+    }
+    if (qi == 0) {
+      uint4 w;
+      w.x = pack_bf2(dqc[0].x, dqc[0].y); w.y = pack_bf2(dqc[1].x, dqc[1].y); w.z = pack_bf2(dqc[2].x, dqc[2].y); w.w = pack_bf2(dqc[3].x, dqc[3].y);
+      *reinterpret_cast<uint4*>(p.dq_cls_part + (seq * p.n_groups + g) * (int64_t)(p.heads * 64) + col) = w;
+    }
+  }
   // ---- phase 1: probabilities, dp, ds, dq ---------------------------------------------------------------------------------
   const float sc2 = p.scale * 1.44269504088896f;
   float s[9], dp[9], m = -INFINITY;
@@ -286,6 +328,10 @@ __global__ __launch_bounds__(256) void attn_tiny64_bwd_kernel(AttnBwdArgs p, int
       axpy8_bf16(dka, ds_l[wv][i][j], qv);
       axpy8_bf16(dva, p_l[wv][i][j], dv_);
     }
+    if (clsq) {                                                    // the CLS query's share of this key
+      axpy8_bf16(dka, pass == 0 ? dsc : ds8, qc_raw);
+      axpy8_bf16(dva, pass == 0 ? pc : p8, doc_raw);
+    }
     uint4 wk, wvv;
     wk.x = pack_bf2(dka[0].x, dka[0].y); wk.y = pack_bf2(dka[1].x, dka[1].y); wk.z = pack_bf2(dka[2].x, dka[2].y); wk.w = pack_bf2(dka[3].x, dka[3].y);
     wvv.x = pack_bf2(dva[0].x, dva[0].y); wvv.y = pack_bf2(dva[1].x, dva[1].y); wvv.z = pack_bf2(dva[2].x, dva[2].y); wvv.w = pack_bf2(dva[3].x, dva[3].y);
@@ -301,9 +347,32 @@ __global__ __launch_bounds__(256) void attn_tiny64_bwd_kernel(AttnBwdArgs p, int
   }
 }
 
+static int attention_tiny_bwd_impl(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const bf16_t* dO, int64_t lddo, bf16_t* dq, bf16_t* dk,
+                                   bf16_t* dv, int64_t ldg, bf16_t* cls_part, int64_t n_seq, int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride,
+                                   int n_tok, int cls_row, int heads, int head_dim, float scale, const float* cls_stats, const bf16_t* o, int64_t ldo, bf16_t* dq_cls_part,
+                                   void* stream);
+
 extern "C" int sf_attention_tiny_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const bf16_t* dO, int64_t lddo, bf16_t* dq, bf16_t* dk,
                                      bf16_t* dv, int64_t ldg, bf16_t* cls_part, int64_t n_seq, int64_t seq_rows, int n_groups, int row0,
                                      int group_stride, int tok_stride, int n_tok, int cls_row, int heads, int head_dim, float scale, void* stream) {
+  return attention_tiny_bwd_impl(q, k, v, ld, dO, lddo, dq, dk, dv, ldg, cls_part, n_seq, seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim,
+                                 scale, nullptr, nullptr, 0, nullptr, stream);
+}
+
+// sf_attention_tiny_bwd with the CLS QUERY's backward in the same launch (arguments as sf_attention_group_bwd_clsq; statistics from sf_attention_cls_stats).
+extern "C" int sf_attention_tiny_bwd_clsq(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const bf16_t* dO, int64_t lddo, bf16_t* dq, bf16_t* dk,
+                                          bf16_t* dv, int64_t ldg, bf16_t* cls_part, const float* cls_stats, const bf16_t* o, int64_t ldo, bf16_t* dq_cls_part,
+                                          int64_t n_seq, int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride, int n_tok, int cls_row, int heads,
+                                          int head_dim, float scale, void* stream) {
+  SF_CHECK_ARG(cls_stats && o && dq_cls_part && cls_row >= 0 && (ldo % 8) == 0, "sf_attention_tiny_bwd_clsq: needs statistics, the forward output, a partial buffer and a CLS row");
+  return attention_tiny_bwd_impl(q, k, v, ld, dO, lddo, dq, dk, dv, ldg, cls_part, n_seq, seq_rows, n_groups, row0, group_stride, tok_stride, n_tok, cls_row, heads, head_dim,
+                                 scale, cls_stats, o, ldo, dq_cls_part, stream);
+}
+
+static int attention_tiny_bwd_impl(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const bf16_t* dO, int64_t lddo, bf16_t* dq, bf16_t* dk,
+                                   bf16_t* dv, int64_t ldg, bf16_t* cls_part, int64_t n_seq, int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride,
+                                   int n_tok, int cls_row, int heads, int head_dim, float scale, const float* cls_stats, const bf16_t* o, int64_t ldo, bf16_t* dq_cls_part,
+                                   void* stream) {
   SF_CHECK_ARG(q && k && v && dO && dq && dk && dv, "sf_attention_tiny_bwd: null pointer");
   SF_CHECK_ARG(head_dim == 64 && n_tok >= 1 && n_tok <= 8 && (cls_row < 0 || cls_part), "sf_attention_tiny_bwd: head_dim 64, n_tok <= 8, cls_part with cls_row");
   SF_CHECK_ARG((ld % 8) == 0 && (lddo % 8) == 0 && (ldg % 8) == 0 && n_groups >= 1 && heads >= 1, "sf_attention_tiny_bwd: bad strides / counts");
@@ -312,6 +381,7 @@ extern "C" int sf_attention_tiny_bwd(const bf16_t* q, const bf16_t* k, const bf1
   a.q = q; a.k = k; a.v = v; a.ld = ld; a.dO = dO; a.lddo = lddo; a.dq = dq; a.dk = dk; a.dv = dv; a.ldg = ldg; a.cls_part = cls_part;
   a.seq_rows = seq_rows; a.n_groups = n_groups; a.row0 = row0; a.group_stride = group_stride; a.tok_stride = tok_stride; a.n_tok = n_tok;
   a.cls_row = cls_row; a.heads = heads; a.scale = scale;
+  a.cls_stats = cls_stats; a.o = o; a.ldo = ldo; a.dq_cls_part = dq_cls_part;
   const int64_t units = n_seq * n_groups * heads;
   hipLaunchKernelGGL(attn_tiny64_bwd_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, units);
   SF_LAUNCH_CHECK();
@@ -638,6 +708,7 @@ struct ClsArgs {
   bf16_t* out; int64_t ldo; int64_t out_seq_rows; int out_row;
   int heads; float scale;
   const uint8_t* key_keep;   // optional, indexed by K/V row
+  float* stats = nullptr;    // optional: [seq][head][2] = (softmax maximum in the base-2 domain incl. the scale, sum) - the backward's statistics (sf_attention_*_bwd_clsq)
 };
 
 __global__ __launch_bounds__(256) void attn_cls64_kernel(ClsArgs p) {
@@ -704,6 +775,7 @@ __global__ __launch_bounds__(256) void attn_cls64_kernel(ClsArgs p) {
     wv.x = pack_bf2(o[0] * inv, o[1] * inv); wv.y = pack_bf2(o[2] * inv, o[3] * inv);
     wv.z = pack_bf2(o[4] * inv, o[5] * inv); wv.w = pack_bf2(o[6] * inv, o[7] * inv);
     *reinterpret_cast<uint4*>(p.out + (seq * p.out_seq_rows + p.out_row) * p.ldo + head * 64 + sb * 8) = wv;
+    if (p.stats && sb == 0) { p.stats[(int64_t)blockIdx.x * 2] = M * 1.44269504088896f; p.stats[(int64_t)blockIdx.x * 2 + 1] = L; }
   }
 }
 
@@ -1181,7 +1253,16 @@ extern "C" int sf_attention_masked(const bf16_t* q, const bf16_t* k, const bf16_
 
 static int attention_cls_impl(const bf16_t* q, int64_t q_seq_rows, int q_row, const bf16_t* k, const bf16_t* v, int64_t ld, int64_t kv_seq_rows,
                               int kv_row0, int n_keys, bf16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row, int64_t n_seq, int heads,
-                              int head_dim, float scale, const uint8_t* key_keep, void* stream);
+                              int head_dim, float scale, const uint8_t* key_keep, void* stream, float* stats = nullptr);
+
+// sf_attention_cls that also writes the query's softmax statistics stats[(seq * heads + head) * 2 + {0, 1}] = (maximum in the base-2 domain incl. the scale, sum)
+extern "C" int sf_attention_cls_stats(const bf16_t* q, int64_t q_seq_rows, int q_row, const bf16_t* k, const bf16_t* v, int64_t ld, int64_t kv_seq_rows, int kv_row0,
+                                      int n_keys, bf16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row, int64_t n_seq, int heads, int head_dim, float scale,
+                                      float* stats, void* stream) {
+  SF_CHECK_ARG(stats, "sf_attention_cls_stats: null statistics buffer");
+  return attention_cls_impl(q, q_seq_rows, q_row, k, v, ld, kv_seq_rows, kv_row0, n_keys, out, ldo, out_seq_rows, out_row, n_seq, heads, head_dim,
+                            scale, nullptr, stream, stats);
+}
 
 extern "C" int sf_attention_cls(const bf16_t* q, int64_t q_seq_rows, int q_row, const bf16_t* k, const bf16_t* v,
                                 int64_t ld, int64_t kv_seq_rows, int kv_row0, int n_keys, bf16_t* out, int64_t ldo,
@@ -1200,7 +1281,7 @@ extern "C" int sf_attention_cls_masked(const bf16_t* q, int64_t q_seq_rows, int 
 
 static int attention_cls_impl(const bf16_t* q, int64_t q_seq_rows, int q_row, const bf16_t* k, const bf16_t* v, int64_t ld, int64_t kv_seq_rows,
                               int kv_row0, int n_keys, bf16_t* out, int64_t ldo, int64_t out_seq_rows, int out_row, int64_t n_seq, int heads,
-                              int head_dim, float scale, const uint8_t* key_keep, void* stream) {
+                              int head_dim, float scale, const uint8_t* key_keep, void* stream, float* stats) {
   SF_CHECK_ARG(q && k && v && out, "sf_attention_cls: null pointer");
   SF_CHECK_ARG(head_dim == 64, "sf_attention_cls: head_dim %d not supported (64)", head_dim);
   SF_CHECK_ARG((ld % 8) == 0 && (ldo % 8) == 0 && n_keys >= 1, "sf_attention_cls: bad shape");
@@ -1208,7 +1289,7 @@ static int attention_cls_impl(const bf16_t* q, int64_t q_seq_rows, int q_row, co
   ClsArgs a;
   a.q = q; a.q_seq_rows = q_seq_rows; a.q_row = q_row; a.k = k; a.v = v; a.ld = ld; a.kv_seq_rows = kv_seq_rows;
   a.kv_row0 = kv_row0; a.n_keys = n_keys; a.out = out; a.ldo = ldo; a.out_seq_rows = out_seq_rows; a.out_row = out_row;
-  a.heads = heads; a.scale = scale; a.key_keep = key_keep;
+  a.heads = heads; a.scale = scale; a.key_keep = key_keep; a.stats = stats;
   hipLaunchKernelGGL(attn_cls64_kernel, dim3((unsigned)(n_seq * heads)), dim3(256), 0, (hipStream_t)stream, a);
   SF_LAUNCH_CHECK();
   return 0;

@@ -211,7 +211,7 @@ class AVCLIPTrainer(FlatTrainer):
         return G, T, Lg, tok, grp, cls_tok, cls_grp
 
     def _divided_fwd(self, qkv, att, n, kind, stats=None):
-        """stats (space only, optional): fp32 (n * H * 2) - the CLS query's merged softmax statistics, kept for sf_attention_group_bwd_clsq."""
+        """stats (optional): fp32 (n * H * 2) - the CLS query's softmax statistics over all keys, kept for sf_attention_{group,tiny}_bwd_clsq."""
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         kw = dict(n_groups=196, row0=1, group_stride=1, tok_stride=196, n_tok=8) if kind == 'time' else \
             dict(n_groups=8, row0=1, group_stride=196, tok_stride=1, n_tok=196)
@@ -228,6 +228,10 @@ class AVCLIPTrainer(FlatTrainer):
                 ops.attention_cls_combine(part, att, n_part=8, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=H)
             return
         ops.attention(q, k, v, att, n_seq=n, seq_rows=VIS_L, cls_row=0, heads=H, head_dim=HD, scale=0.125, **kw)
+        if stats is not None:
+            _chk(_lib.load().sf_attention_cls_stats(q.data_ptr(), VIS_L, 0, k.data_ptr(), v.data_ptr(), qkv.stride(0), VIS_L, 0, VIS_L, att.data_ptr(), att.stride(0),
+                                                    VIS_L, 0, n, H, HD, 0.125, stats.data_ptr(), _st()), 'sf_attention_cls_stats')
+            return
         ops.attention_cls(q, k, v, att, n_seq=n, q_seq_rows=VIS_L, q_row=0, kv_seq_rows=VIS_L, kv_row0=0, n_keys=VIS_L,
                           out_seq_rows=VIS_L, out_row=0, heads=H, head_dim=HD, scale=0.125)
 
@@ -239,7 +243,7 @@ class AVCLIPTrainer(FlatTrainer):
 
     def _divided_bwd(self, qkv, dO_b, n, kind, att=None, stats=None):
         """qkv (n*1569, 2304) bf16 saved, dO_b (n*1569, 768) bf16 -> dqkv (n*1569, 2304) bf16.  att / stats (space, optional): the forward's attention output and the
-        CLS query's softmax statistics - then the CLS query's backward runs inside the group kernel."""
+        CLS query's softmax statistics - then the CLS query's backward runs inside the group kernels."""
         G, T, Lg, tok, grp, cls_tok, cls_grp = self._group_maps(kind)
         nseq, rows_g, M = n * G, n * G * Lg, n * VIS_L
         if self.fused_attn_bwd:
@@ -248,12 +252,13 @@ class AVCLIPTrainer(FlatTrainer):
             dqkv = self._buf('dqkv', (M, 3 * D), torch.bfloat16)
             part = self._buf('cls_kv_part', (nseq, 2 * D), torch.bfloat16)
             geo = (196, 1, 1, 196, 8) if kind == 'time' else (8, 1, 196, 1, 196)          # n_groups, row0, group_stride, tok_stride, n_tok
-            if kind == 'space' and stats is not None:
+            if stats is not None:
                 dqc = self._buf('cls_dq_part', (nseq, D), torch.bfloat16)
-                _chk(_lib.load().sf_attention_group_bwd_clsq(qkv.data_ptr(), qkv[:, D:].data_ptr(), qkv[:, 2 * D:].data_ptr(), qkv.stride(0), dO_b.data_ptr(),
+                fq = _lib.load().sf_attention_tiny_bwd_clsq if kind == 'time' else _lib.load().sf_attention_group_bwd_clsq
+                _chk(fq(qkv.data_ptr(), qkv[:, D:].data_ptr(), qkv[:, 2 * D:].data_ptr(), qkv.stride(0), dO_b.data_ptr(),
                                                              dO_b.stride(0), dqkv.data_ptr(), dqkv[:, D:].data_ptr(), dqkv[:, 2 * D:].data_ptr(), dqkv.stride(0),
                                                              part.data_ptr(), stats.data_ptr(), att.data_ptr(), att.stride(0), dqc.data_ptr(), n, VIS_L, *geo, 0, H, HD,
-                                                             0.125, _st()), 'sf_attention_group_bwd_clsq')
+                                                             0.125, _st()), 'sf_attention_*_bwd_clsq')
                 # the CLS row: dk | dv = the sum over the groups' slot-0 rows, dq = the sum of the groups' partial rows
                 _chk(_lib.load().sf_reduce_groups_bf16(part.data_ptr(), G * 2 * D, 2 * D, G, dqkv[:, D:].data_ptr(), VIS_L * 3 * D, 2 * D, n, 0, _st()),
                      'sf_reduce_groups_bf16')
@@ -365,7 +370,7 @@ class AVCLIPTrainer(FlatTrainer):
                 s['qkv' + key] = self._buf(f'{t}_qkv{key}', (M, 3 * D), torch.bfloat16)
                 ops.gemm(s['h' + key], *self._wb(f'{p}.{att}.qkv'), s['qkv' + key])
                 s['att' + key] = self._buf(f'{t}_att{key}', (M, D), torch.bfloat16)
-                s['cst' + key] = self._buf(f'{t}_cst{key}', (n * H * 2,), torch.float32) if (kind == 'space' and self.cls_in_group and self.fused_attn_bwd) else None
+                s['cst' + key] = self._buf(f'{t}_cst{key}', (n * H * 2,), torch.float32) if (self.cls_in_group and self.fused_attn_bwd) else None
                 self._divided_fwd(s['qkv' + key], s['att' + key], n, kind, stats=s['cst' + key])
                 xn = self._buf(f'{t}_x{key}', (M, D), torch.float32)
                 dp = s['dp_s'] = self._dp_scales(i, 0, n) if kind == 'space' else None     # time attention has no DropPath (vit_helper.py:367-369)
@@ -406,7 +411,7 @@ class AVCLIPTrainer(FlatTrainer):
             self._mlp_bwd(s, dx, s['xs'], p + '.mlp.fc1', p + '.mlp.fc2', M, p + '.norm2', EPS_VIS, dp=s['dp_m'], seq_rows=VIS_L)
             self._attn_branch_bwd(dx, M, p + '.attn.proj', s['atts'], lambda dO, q=s['qkvs'], a=s['atts'], c=s['csts']: self._divided_bwd(q, dO, n, 'space', att=a, stats=c), s['hs'],
                                   s['xt'], p + '.norm1', EPS_VIS, p + '.attn.qkv', dp=s['dp_s'], seq_rows=VIS_L)
-            self._attn_branch_bwd(dx, M, p + '.timeattn.proj', s['attt'], lambda dO, q=s['qkvt']: self._divided_bwd(q, dO, n, 'time'), s['ht'],
+            self._attn_branch_bwd(dx, M, p + '.timeattn.proj', s['attt'], lambda dO, q=s['qkvt'], a=s['attt'], c=s['cstt']: self._divided_bwd(q, dO, n, 'time', att=a, stats=c), s['ht'],
                                   s['x'], p + '.norm3', EPS_VIS, p + '.timeattn.qkv')
             if on_ready and i % 3 == 0:                                        # blocks i .. i+2 are final: one ~92 MB bucket
                 on_ready(self._key_range(*[f'{V}.blocks.{j}.' for j in range(i, min(i + 3, self.n_vblocks))]))

@@ -545,6 +545,54 @@ def test_divided_bwd_fused_vs_gathered(gpu, kind):
 
 
 @pytest.mark.gpu
+def test_time_attention_bwd_cls_query_in_tiny_kernel(gpu):
+    """sf_attention_tiny_bwd_clsq (+ sf_attention_cls_stats in the forward) against sf_attention_tiny_bwd + sf_attention_cls_bwd: the same dqkv up to bf16 rounding of
+    partial sums; the forward output of sf_attention_cls_stats equals sf_attention_cls's."""
+    from synchformer_amd import ops
+    n, L, Dm, H, G = 3, 1569, 768, 12, 196
+    torch.manual_seed(22)
+    qkv = (torch.randn(n * L, 3 * Dm, device=gpu) * 0.8).bfloat16()
+    qkv[::L] *= 1.5
+    dO = (torch.randn(n * L, Dm, device=gpu) * 0.5).bfloat16()
+    q, k, v = qkv[:, :Dm], qkv[:, Dm:2 * Dm], qkv[:, 2 * Dm:]
+    geo = (G, 1, 1, 196, 8)
+    att = torch.zeros(n * L, Dm, device=gpu, dtype=torch.bfloat16)
+    ops.attention(q, k, v, att, n_seq=n, seq_rows=L, n_groups=G, row0=1, group_stride=1, tok_stride=196, n_tok=8, cls_row=0, heads=H, head_dim=64, scale=0.125)
+    att2 = att.clone()
+    stats = torch.empty(n * H * 2, device=gpu)
+    assert _lib().sf_attention_cls_stats(q.data_ptr(), L, 0, k.data_ptr(), v.data_ptr(), 3 * Dm, L, 0, L, att.data_ptr(), Dm, L, 0, n, H, 64, 0.125, stats.data_ptr(), _st()) == 0
+    ops.attention_cls(q, k, v, att2, n_seq=n, q_seq_rows=L, q_row=0, kv_seq_rows=L, kv_row0=0, n_keys=L, out_seq_rows=L, out_row=0, heads=H, head_dim=64, scale=0.125)
+    assert torch.equal(att, att2)
+
+    def run(fused):
+        d = torch.zeros(n * L, 3 * Dm, device=gpu, dtype=torch.bfloat16)
+        part = torch.zeros(n * G, 2 * Dm, device=gpu, dtype=torch.bfloat16)
+        head = (qkv.data_ptr(), k.data_ptr(), v.data_ptr(), 3 * Dm, dO.data_ptr(), Dm, d.data_ptr(), d[:, Dm:].data_ptr(), d[:, 2 * Dm:].data_ptr(), 3 * Dm, part.data_ptr())
+        if fused:
+            dqc = torch.zeros(n * G, Dm, device=gpu, dtype=torch.bfloat16)
+            rc = _lib().sf_attention_tiny_bwd_clsq(*head, stats.data_ptr(), att.data_ptr(), Dm, dqc.data_ptr(), n, L, *geo, 0, H, 64, 0.125, _st())
+            assert rc == 0, _lib().sf_last_error()
+        else:
+            assert _lib().sf_attention_tiny_bwd(*head, n, L, *geo, 0, H, 64, 0.125, _st()) == 0
+        assert _lib().sf_reduce_groups_bf16(part.data_ptr(), G * 2 * Dm, 2 * Dm, G, d[:, Dm:].data_ptr(), L * 3 * Dm, 2 * Dm, n, 0, _st()) == 0
+        if fused:
+            assert _lib().sf_reduce_groups_bf16(dqc.data_ptr(), G * Dm, Dm, G, d.data_ptr(), L * 3 * Dm, Dm, n, 0, _st()) == 0
+        else:
+            assert _lib().sf_attention_cls_bwd(qkv.data_ptr(), L, 0, k.data_ptr(), v.data_ptr(), 3 * Dm, L, 0, L, dO.data_ptr(), Dm, L, 0, d.data_ptr(), d[:, Dm:].data_ptr(),
+                                               d[:, 2 * Dm:].data_ptr(), 3 * Dm, n, H, 64, 0.125, 1, _st()) == 0
+        return d.float().cpu().view(n, L, 3, Dm)
+
+    a, b = run(False), run(True)
+    for name, sl in (('dq of the CLS rows', (slice(None), 0, 0)), ('dk | dv of the CLS rows', (slice(None), 0, slice(1, 3))),
+                     ('dk | dv of the patches', (slice(None), slice(1, None), slice(1, 3)))):
+        x, y = a[sl], b[sl]
+        rel = ((x - y).norm() / x.norm()).item()
+        print(f'{name}: rel-L2 {rel:.5f}, max |d| {(x - y).abs().max().item():.5f} (scale {x.abs().max().item():.3f})')
+        assert rel < 8e-3, name
+    assert torch.equal(a[:, 1:, 0], b[:, 1:, 0])
+
+
+@pytest.mark.gpu
 def test_space_attention_bwd_cls_query_in_group_kernel(gpu):
     """sf_attention_group_bwd_clsq (the CLS query's backward as one more query row of every space group, on the forward's softmax statistics) against the path it
     replaces - sf_attention_group_bwd + sf_attention_cls_bwd's read-modify-write pass: the same dqkv (all rows: dq of the CLS row, dk | dv of every row) up to bf16
