@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t to
   for (int j = 0; j < TINY_SLOTS; ++j) {
     const uint4 kk = lds_k[wave][j < nk ? j : nk - 1][sub];
     float d = dot8_bf16(qraw, kk);
-    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+    d = sum8_dpp(d);
     s[j] = j < nk ? d * sc : -INFINITY;
     m = fmaxf(m, s[j]);
   }
@@ -144,12 +144,12 @@ __global__ __launch_bounds__(256) void attn_tiny64_kernel(AttnArgs p, int64_t to
     // (k/v are the registers it loaded), the softmax state and the weighted values are then reduced across the eight row groups.
     const uint4 qc = lds_qc[wave][sub];
     float d = dot8_bf16(qc, lds_k[wave][has_cls + qtok][sub]);          // this row group's own token, back from LDS (keeps registers low)
-    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+    d = sum8_dpp(d);
     const float cs = (qi < p.n_tok && ((keep_bits >> (has_cls + qi)) & 1u)) ? d * sc : -INFINITY;
     float c0 = -INFINITY;
     if (has_cls && g == 0 && (keep_bits & 1u)) {                              // wave-uniform
       float d0 = dot8_bf16(qc, lds_k[wave][0][sub]);
-      d0 += __shfl_xor(d0, 1, 64); d0 += __shfl_xor(d0, 2, 64); d0 += __shfl_xor(d0, 4, 64);
+      d0 = sum8_dpp(d0);
       c0 = d0 * sc;
     }
     float cm = cs;
@@ -252,10 +252,7 @@ __global__ __launch_bounds__(256) void attn_tiny64_bwd_kernel(AttnBwdArgs p, int
     for (int j = 1; j < 8; ++j)
       if (qi == j) { ksel = kraw[j]; vsel = vraw[j]; }
     float dl = dot8_bf16(doc_raw, oc), sc_ = dot8_bf16(qc_raw, ksel), dpc = dot8_bf16(doc_raw, vsel), s8 = dot8_bf16(qc_raw, kraw[8]), dp8 = dot8_bf16(doc_raw, vraw[8]);
-#pragma unroll
-    for (int o_ = 1; o_ < 8; o_ <<= 1) {
-      dl += __shfl_xor(dl, o_, 64); sc_ += __shfl_xor(sc_, o_, 64); dpc += __shfl_xor(dpc, o_, 64); s8 += __shfl_xor(s8, o_, 64); dp8 += __shfl_xor(dp8, o_, 64);
-    }
+    dl = sum8_dpp(dl); sc_ = sum8_dpp(sc_); dpc = sum8_dpp(dpc); s8 = sum8_dpp(s8); dp8 = sum8_dpp(dp8);
     const float sc2c = p.scale * 1.44269504088896f;
     if (qi < nk && !(has_cls && qi == 0 && g != 0)) { pc = __builtin_amdgcn_exp2f(fmaf(sc_, sc2c, -Mg)) * Linv; dsc = pc * (dpc - dl) * p.scale; }
     if (8 < nk) { p8 = __builtin_amdgcn_exp2f(fmaf(s8, sc2c, -Mg)) * Linv; ds8 = p8 * (dp8 - dl) * p.scale; }
@@ -267,8 +264,10 @@ __global__ __launch_bounds__(256) void attn_tiny64_bwd_kernel(AttnBwdArgs p, int
     if (qi == 0) axpy8_bf16(dqc, ds8, kraw[8]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      dqc[i].x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dqc[i].x), 0x128, 0xF, 0xF, true));   // row_ror:8 = the lane 8 away in the 16-lane row
+      dqc[i].y += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dqc[i].y), 0x128, 0xF, 0xF, true));
 #pragma unroll
-      for (int o_ = 8; o_ < 64; o_ <<= 1) { dqc[i].x += __shfl_xor(dqc[i].x, o_, 64); dqc[i].y += __shfl_xor(dqc[i].y, o_, 64); }
+      for (int o_ = 16; o_ < 64; o_ <<= 1) { dqc[i].x += __shfl_xor(dqc[i].x, o_, 64); dqc[i].y += __shfl_xor(dqc[i].y, o_, 64); }
     }
     if (qi == 0) {
       uint4 w;
@@ -282,8 +281,8 @@ __global__ __launch_bounds__(256) void attn_tiny64_bwd_kernel(AttnBwdArgs p, int
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
     float d = dot8_bf16(qraw, kraw[j]), e = dot8_bf16(doraw, vraw[j]);
-    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-    e += __shfl_xor(e, 1, 64); e += __shfl_xor(e, 2, 64); e += __shfl_xor(e, 4, 64);
+    d = sum8_dpp(d);
+    e = sum8_dpp(e);
     s[j] = j < nk ? d * sc2 : -INFINITY;
     dp[j] = e;
     m = fmaxf(m, s[j]);
@@ -730,7 +729,7 @@ __global__ __launch_bounds__(256) void attn_cls64_kernel(ClsArgs p) {
     float d = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) d += qf[e] * kf[e];
-    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+    d = sum8_dpp(d);
     const float s = d * p.scale;
     const float mn = fmaxf(m, s);
     const float corr = __expf(m - mn), e = __expf(s - mn);   // m = -inf first time: corr = 0

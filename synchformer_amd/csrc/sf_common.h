@@ -82,6 +82,15 @@ __device__ __forceinline__ uint32_t sf_fp8x4(const float* f, float inv) {
   return (uint32_t)w;
 }
 
+// Sum over the 8 lanes of an aligned lane group (bit-identical in all eight, same tree as xor-shuffles 1, 2, 4): three DPP adds - quad_perm [1,0,3,2], quad_perm [2,3,0,1],
+// row_half_mirror (lane i <-> 7 - i, i.e. the other quad) - instead of three ds_bpermute round trips through the LDS crossbar.
+__device__ __forceinline__ float sum8_dpp(float x) {
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));
+  return x;
+}
+
 // ---- wave reductions ------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
