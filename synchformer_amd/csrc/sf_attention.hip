@@ -1095,13 +1095,23 @@ __global__ __launch_bounds__(64) void attn_cls_combine64_kernel(const float* __r
   const int head = blockIdx.x % heads, d = threadIdx.x;
   const int64_t seq = blockIdx.x / heads;
   const float* pp = part + (int64_t)blockIdx.x * n_part * 66;
-  float M = -INFINITY;
-  for (int i = 0; i < n_part; ++i) M = fmaxf(M, pp[i * 66]);
-  float L = 0.f, O = 0.f;
-  for (int i = 0; i < n_part; ++i) {
-    const float w = __builtin_amdgcn_exp2f(pp[i * 66] - M);
-    L += pp[i * 66 + 1] * w;
-    O += pp[i * 66 + 2 + d] * w;
+  float M = -INFINITY, L = 0.f, O = 0.f;
+  if (n_part <= 64) {
+    // lane i holds record i's (m, l): one load each, the maximum and the weights by wave reductions, then the 64-wide rows weighted by a lane broadcast - the loads of
+    // the second loop do not wait for anything (the serial two-pass form took 41 us for the 49 records of a time block: dependent scalar-like loads)
+    const float mi = d < n_part ? pp[d * 66] : -INFINITY, li = d < n_part ? pp[d * 66 + 1] : 0.f;
+    M = wave_max(mi);
+    const float wi = d < n_part ? __builtin_amdgcn_exp2f(mi - M) : 0.f;
+    L = wave_sum(li * wi);
+#pragma unroll 7
+    for (int i = 0; i < n_part; ++i) O += pp[i * 66 + 2 + d] * __shfl(wi, i, 64);
+  } else {
+    for (int i = 0; i < n_part; ++i) M = fmaxf(M, pp[i * 66]);
+    for (int i = 0; i < n_part; ++i) {
+      const float w = __builtin_amdgcn_exp2f(pp[i * 66] - M);
+      L += pp[i * 66 + 1] * w;
+      O += pp[i * 66 + 2 + d] * w;
+    }
   }
   out[(seq * out_seq_rows + out_row) * ldo + head * 64 + d] = f2bf(O / L);
   if (stats && d == 0) { stats[(int64_t)blockIdx.x * 2] = M; stats[(int64_t)blockIdx.x * 2 + 1] = L; }   // the merged softmax statistics (the backward's, sf_attention_group_bwd_clsq)
@@ -1133,13 +1143,21 @@ __global__ __launch_bounds__(64) void attn_cls_combine64_mx_kernel(const float* 
   const int head = blockIdx.x % heads, d = threadIdx.x;
   const int64_t seq = blockIdx.x / heads;
   const float* pp = part + (int64_t)blockIdx.x * n_part * 66;
-  float M = -INFINITY;
-  for (int i = 0; i < n_part; ++i) M = fmaxf(M, pp[i * 66]);
-  float L = 0.f, O = 0.f;
-  for (int i = 0; i < n_part; ++i) {
-    const float w = __builtin_amdgcn_exp2f(pp[i * 66] - M);
-    L += pp[i * 66 + 1] * w;
-    O += pp[i * 66 + 2 + d] * w;
+  float M = -INFINITY, L = 0.f, O = 0.f;
+  if (n_part <= 64) {                                            // (the same arithmetic, in the same order, as attn_cls_combine64_kernel: the outputs must agree bit for bit)
+    const float mi = d < n_part ? pp[d * 66] : -INFINITY, li = d < n_part ? pp[d * 66 + 1] : 0.f;
+    M = wave_max(mi);
+    const float wi = d < n_part ? __builtin_amdgcn_exp2f(mi - M) : 0.f;
+    L = wave_sum(li * wi);
+#pragma unroll 7
+    for (int i = 0; i < n_part; ++i) O += pp[i * 66 + 2 + d] * __shfl(wi, i, 64);
+  } else {
+    for (int i = 0; i < n_part; ++i) M = fmaxf(M, pp[i * 66]);
+    for (int i = 0; i < n_part; ++i) {
+      const float w = __builtin_amdgcn_exp2f(pp[i * 66] - M);
+      L += pp[i * 66 + 1] * w;
+      O += pp[i * 66 + 2 + d] * w;
+    }
   }
   const float x = __uint_as_float((uint32_t)f2bf(O / L) << 16);
   float amax = fabsf(x);
