@@ -388,6 +388,52 @@ def build_workload(name, args, dev, rank, world, local):
     return {'step_fn': step_fn, 'vis': vis, 'aud': aud, 'B': B, 'S': S, 'serial': serial, 'trainer': None if args.dropin else trainer, 'eng': eng}
 
 
+def power_probe(step_fn, vis, aud, seconds=2.0):
+    """Socket power and shader clock while the forward runs (rank 0, single GPU, AFTER the timed region): `rocm-smi -P -c` sampled from a thread next to ~2 s of the
+    same steps.  The step is power-limited on MI355X (profiles/r03_power.md): the clock this reports is what `roofline.frac` has to be read against.  None if
+    rocm-smi is not there or prints something else."""
+    import re, subprocess, threading
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                txt = subprocess.run(['rocm-smi', '-P', '-c'], capture_output=True, text=True, timeout=5).stdout
+                pw = re.search(r'GPU\[0\].*Package Power \(W\): ([0-9.]+)', txt)
+                ck = re.search(r'GPU\[0\].*sclk clock level: \S+ \((\d+)Mhz\)', txt)
+                if pw and ck:
+                    samples.append((time.perf_counter(), float(pw.group(1)), int(ck.group(1))))
+            except Exception:                                          # noqa: BLE001 - an instrument, never an error of the benchmark
+                return
+            time.sleep(0.2)
+    try:
+        cap = None
+        txt = subprocess.run(['rocm-smi', '--showmaxpower'], capture_output=True, text=True, timeout=10).stdout
+        m = re.search(r'GPU\[0\].*Max Graphics Package Power \(W\): ([0-9.]+)', txt)
+        cap = float(m.group(1)) if m else None
+        th = threading.Thread(target=poll, daemon=True)
+        t0 = time.perf_counter()
+        th.start()
+        n = 0
+        while time.perf_counter() - t0 < seconds:
+            step_fn(vis, aud)
+            torch.cuda.synchronize()
+            n += 1
+        t1 = time.perf_counter()
+        stop.set()
+        th.join(timeout=6)
+        mid = [x for x in samples if t0 + 0.6 < x[0] < t1] or samples
+        if not mid:
+            return None
+        med = lambda v: sorted(v)[len(v) // 2]
+        return {'socket_w': med([x[1] for x in mid]), 'sclk_mhz': med([x[2] for x in mid]), 'cap_w': cap, 'samples': len(mid), 'steps': n,
+                'clips_per_s': round(n * vis.shape[0] / (t1 - t0), 1),
+                'what': 'rocm-smi next to a further ~2 s of the same forward, after the timed region; dense MFMA peaks are quoted at 2400 MHz'}
+    except Exception:                                                  # noqa: BLE001
+        stop.set()
+        return None
+
+
 def roofline_of(kernels, by, name):
     """The `roofline` object for workload `name` from the per-kernel entries: the single dominant kernel (by time) + the family aggregate."""
     dom = kernels[0]
@@ -533,6 +579,10 @@ def main():
                                    'Stage-1: 7 buckets launched under the backward, the wait is for what did not overlap)'}
         if roofline_error:
             out['roofline_error'] = roofline_error
+        if name == 'infer' and world == 1 and not args.no_kernel_timing and not args.graph:
+            pw = power_probe(step_fn, w['vis'], w['aud'])
+            if pw:
+                out['power'] = pw
         if kernels:
             dom, agg = roofline_of(kernels, by, name)
             traffic, tsrc = pmc_traffic() if name == 'infer' else (None, None)
