@@ -394,13 +394,19 @@ def power_probe(step_fn, vis, aud, seconds=2.0):
     rocm-smi is not there or prints something else."""
     import re, subprocess, threading
     samples, stop = [], threading.Event()
+    gi = '0'                                                         # rocm-smi's index of the device this process calls cuda:0
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        first = os.environ.get(var, '').split(',')[0].strip()
+        if first.isdigit():
+            gi = first
+            break
 
     def poll():
         while not stop.is_set():
             try:
                 txt = subprocess.run(['rocm-smi', '-P', '-c'], capture_output=True, text=True, timeout=5).stdout
-                pw = re.search(r'GPU\[0\].*Package Power \(W\): ([0-9.]+)', txt)
-                ck = re.search(r'GPU\[0\].*sclk clock level: \S+ \((\d+)Mhz\)', txt)
+                pw = re.search(r'GPU\[' + gi + r'\].*Package Power \(W\): ([0-9.]+)', txt)
+                ck = re.search(r'GPU\[' + gi + r'\].*sclk clock level: \S+ \((\d+)Mhz\)', txt)
                 if pw and ck:
                     samples.append((time.perf_counter(), float(pw.group(1)), int(ck.group(1))))
             except Exception:                                          # noqa: BLE001 - an instrument, never an error of the benchmark
@@ -409,7 +415,7 @@ def power_probe(step_fn, vis, aud, seconds=2.0):
     try:
         cap = None
         txt = subprocess.run(['rocm-smi', '--showmaxpower'], capture_output=True, text=True, timeout=10).stdout
-        m = re.search(r'GPU\[0\].*Max Graphics Package Power \(W\): ([0-9.]+)', txt)
+        m = re.search(r'GPU\[' + gi + r'\].*Max Graphics Package Power \(W\): ([0-9.]+)', txt)
         cap = float(m.group(1)) if m else None
         th = threading.Thread(target=poll, daemon=True)
         t0 = time.perf_counter()
@@ -427,7 +433,7 @@ def power_probe(step_fn, vis, aud, seconds=2.0):
             return None
         med = lambda v: sorted(v)[len(v) // 2]
         return {'socket_w': med([x[1] for x in mid]), 'sclk_mhz': med([x[2] for x in mid]), 'cap_w': cap, 'samples': len(mid), 'steps': n,
-                'clips_per_s': round(n * vis.shape[0] / (t1 - t0), 1),
+                'clips_per_s': round(n * vis.shape[0] / (t1 - t0), 1), 'rocm_smi_gpu': int(gi),
                 'what': 'rocm-smi next to a further ~2 s of the same forward, after the timed region; dense MFMA peaks are quoted at 2400 MHz'}
     except Exception:                                                  # noqa: BLE001
         stop.set()
