@@ -29,7 +29,7 @@ extern "C" {
 enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2, SF_U8 = 3 };   /* element types */
 enum { SF_EPI_NONE = 0, SF_EPI_GELU = 1 };                  /* GEMM epilogue activation */
 
-#define SF_ABI_VERSION 5
+#define SF_ABI_VERSION 6
 int sf_abi_version(void);
 const char* sf_last_error(void);
 /* "gfx950" + build flags; lets the host assert it loaded the library it built */
@@ -252,6 +252,12 @@ int sf_layernorm768_bwd(const float* x, int64_t ldx, const int64_t* x_map, const
 int sf_layernorm768_bwd_bf16(const float* x, int64_t ldx, const int64_t* x_map, const float* gamma, const uint16_t* dy, int64_t lddy,
                         const int64_t* dy_map, float* dx, int64_t lddx, const int64_t* dx_map, int accumulate_dx, float* dgamma,
                         float* dbeta, int accumulate_dparams, float* workspace, int64_t rows, float eps, void* stream);
+/* sf_layernorm768_bwd (identity row maps, dy fp32 or bf16 by dy_dtype) that also writes the head of the NEXT residual branch's backward from the updated dx - what
+ * sf_branch_grad would compute in another pass over it: y_next = bf16(seq_scale[row / seq_rows] * dx) (seq_scale NULL = 1: no stochastic depth on that branch) and
+ * dbias_next[c] = sum_r seq_scale * dx[r, c] (fp32, assigned).  workspace: fp32, 3 * 768 * ceil(rows / 4) elements. */
+int sf_layernorm768_bwd_branch(const float* x, int64_t ldx, const float* gamma, const void* dy, int dy_dtype, int64_t lddy, float* dx, int64_t lddx,
+                               int accumulate_dx, float* dgamma, float* dbeta, int accumulate_dparams, uint16_t* y_next, int64_t ldyn, const float* seq_scale,
+                               int64_t seq_rows, float* dbias_next, float* workspace, int64_t rows, float eps, void* stream);
 /* out[c] (=|+=) sum_r x[r, c] (bias gradients); x fp32|bf16; workspace fp32 cols * ceil(rows / 64). */
 int sf_colsum(const void* x, int x_dtype, int64_t ldx, int64_t rows, int cols, float* out, int accumulate, float* workspace, void* stream);
 /* out[l, c] (=|+=) sum_b x[b*L + l, c]: gradient of the broadcast positional / token table. */

@@ -10,7 +10,7 @@ from pathlib import Path
 
 LIB_DIR = Path(__file__).resolve().parent / 'lib'
 LIB_NAME = 'libsynchformer_hip.so'
-ABI_VERSION = 5     # 5: the CLS query inside the grouped attention backward kernels (sf_attention_{group,tiny}_bwd_clsq, sf_attention_cls(_combine)_stats); 4: MXFP8-output attention launches (sf_attention_cls_partial_mx, sf_attention_cls_combine_mx, sf_qkv_time_attention_mx_q); 3: round 3, second half (sf_gemm_mx_res_ln768, sf_qkv_time_attention_mx, sf_gemm_tn_pp, sf_branch_grad, ... added); 2: sf_gemm_res_ln_force_schedule
+ABI_VERSION = 6     # 6: sf_layernorm768_bwd_branch; 5: the CLS query inside the grouped attention backward kernels (sf_attention_{group,tiny}_bwd_clsq, sf_attention_cls(_combine)_stats); 4: MXFP8-output attention launches (sf_attention_cls_partial_mx, sf_attention_cls_combine_mx, sf_qkv_time_attention_mx_q); 3: round 3, second half (sf_gemm_mx_res_ln768, sf_qkv_time_attention_mx, sf_gemm_tn_pp, sf_branch_grad, ... added); 2: sf_gemm_res_ln_force_schedule
 
 _i64, _i32, _f32, _ptr = C.c_int64, C.c_int, C.c_float, C.c_void_p
 
@@ -86,6 +86,7 @@ SIGNATURES = {
                                _i32, _f32, _ptr],
     'sf_attention_cls_partial': [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _ptr, _ptr],
     'sf_attention_cls_combine': [_ptr, _i32, _ptr, _i64, _i64, _i32, _i64, _i32, _ptr],
+    'sf_layernorm768_bwd_branch': [_ptr, _i64, _ptr, _ptr, _i32, _i64, _ptr, _i64, _i32, _ptr, _ptr, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _f32, _ptr],
     'sf_attention_tiny_bwd_clsq': [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _ptr],
     'sf_attention_cls_stats': [_ptr, _i64, _i32, _ptr, _ptr, _i64, _i64, _i32, _i32, _ptr, _i64, _i64, _i32, _i64, _i32, _i32, _f32, _ptr, _ptr],
     'sf_attention_cls_combine_stats': [_ptr, _i32, _ptr, _i64, _i64, _i32, _i64, _i32, _ptr, _ptr],

@@ -221,12 +221,16 @@ template <bool DY_BF16>
 __global__ __launch_bounds__(256) void layernorm768_bwd_kernel(const float* __restrict__ x, int64_t ldx, RowMap xmap, const float* __restrict__ gamma,
                                                                 const void* __restrict__ dy, int64_t lddy, RowMap dymap, float* __restrict__ dx,
                                                                 int64_t lddx, RowMap dxmap, int accumulate, float* __restrict__ part, int64_t rows,
-                                                                float eps, int rpw) {
-  __shared__ float red[4][2][768];
+                                                                float eps, int rpw, bf16_t* __restrict__ ynext = nullptr, int64_t ldyn = 0,
+                                                                const float* __restrict__ seq_scale = nullptr, int64_t seq_rows = 1) {
+  // ynext (sf_layernorm768_bwd_branch): the updated dx row is also the input of the NEXT residual branch's backward - written here as that branch's dY operand,
+  // bf16(scale[row / seq_rows] * dx), with its fp32 column sums (the branch's output-bias gradient) as a third partial plane: sf_branch_grad's pass over dx saved
+  __shared__ float red[4][3][768];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float4 dg[3], db[3];
+  const int planes = ynext ? 3 : 2;
+  float4 dg[3], db[3], dn[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) { dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i]; }
+  for (int i = 0; i < 3; ++i) { dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i]; dn[i] = dg[i]; }
   for (int it = 0; it < rpw; ++it) {
     const int64_t r = ((int64_t)blockIdx.x * rpw + it) * 4 + wave;
     if (r >= rows) break;
@@ -275,17 +279,25 @@ __global__ __launch_bounds__(256) void layernorm768_bwd_kernel(const float* __re
       float* dp = dr + i * 256 + lane * 4;
       if (accumulate) { const float4 t = *reinterpret_cast<const float4*>(dp); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
       *reinterpret_cast<float4*>(dp) = o;
+      if (ynext) {                                                   // (identity row maps on this path)
+        const float sc = seq_scale ? seq_scale[r / seq_rows] : 1.0f;
+        o.x *= sc; o.y *= sc; o.z *= sc; o.w *= sc;                  // a dropped branch (sc = 0): zero rows, no bias gradient
+        dn[i].x += o.x; dn[i].y += o.y; dn[i].z += o.z; dn[i].w += o.w;
+        uint2 w2; w2.x = pack_bf2(o.x, o.y); w2.y = pack_bf2(o.z, o.w);
+        *reinterpret_cast<uint2*>(ynext + r * ldyn + i * 256 + lane * 4) = w2;
+      }
     }
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     *reinterpret_cast<float4*>(&red[wave][0][i * 256 + lane * 4]) = dg[i];
     *reinterpret_cast<float4*>(&red[wave][1][i * 256 + lane * 4]) = db[i];
+    if (ynext) *reinterpret_cast<float4*>(&red[wave][2][i * 256 + lane * 4]) = dn[i];
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * 768; c += 256) {
+  for (int c = threadIdx.x; c < planes * 768; c += 256) {
     const int k = c / 768, col = c - k * 768;
-    part[((int64_t)blockIdx.x * 2 + k) * 768 + col] = (red[0][k][col] + red[1][k][col]) + (red[2][k][col] + red[3][k][col]);
+    part[((int64_t)blockIdx.x * planes + k) * 768 + col] = (red[0][k][col] + red[1][k][col]) + (red[2][k][col] + red[3][k][col]);
   }
 }
 
@@ -322,20 +334,38 @@ __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __re
 
 static int layernorm768_bwd_impl(const float* x, int64_t ldx, const int64_t* x_map, const float* gamma, const void* dy, bool dy_bf16, int64_t lddy,
                                  const int64_t* dy_map, float* dx, int64_t lddx, const int64_t* dx_map, int accumulate_dx, float* dgamma,
-                                 float* dbeta, int accumulate_dparams, float* workspace, int64_t rows, float eps, void* stream) {
+                                 float* dbeta, int accumulate_dparams, float* workspace, int64_t rows, float eps, void* stream, bf16_t* ynext = nullptr,
+                                 int64_t ldyn = 0, const float* seq_scale = nullptr, int64_t seq_rows = 1, float* dbias_next = nullptr) {
   SF_CHECK_ARG(x && gamma && dy && dx && dgamma && dbeta && workspace, "sf_layernorm768_bwd: null pointer");
   if (rows <= 0) return 0;
+  const int planes = ynext ? 3 : 2;
   const int rpw = rows >= 16384 ? 8 : (rows >= 4096 ? 2 : 1);      // keep >= 1k blocks in flight, <= ~1.4k partial rows at Stage-1 sizes
   const int64_t nblk = (rows + 4 * rpw - 1) / (4 * rpw);
   hipStream_t s = (hipStream_t)stream;
   if (dy_bf16) hipLaunchKernelGGL(layernorm768_bwd_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, x, ldx, sf_rowmap(x_map), gamma, dy, lddy,
-                                  sf_rowmap(dy_map), dx, lddx, sf_rowmap(dx_map), accumulate_dx, workspace, rows, eps, rpw);
+                                  sf_rowmap(dy_map), dx, lddx, sf_rowmap(dx_map), accumulate_dx, workspace, rows, eps, rpw, ynext, ldyn, seq_scale, seq_rows);
   else hipLaunchKernelGGL(layernorm768_bwd_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, x, ldx, sf_rowmap(x_map), gamma, dy, lddy,
-                          sf_rowmap(dy_map), dx, lddx, sf_rowmap(dx_map), accumulate_dx, workspace, rows, eps, rpw);
+                          sf_rowmap(dy_map), dx, lddx, sf_rowmap(dx_map), accumulate_dx, workspace, rows, eps, rpw, ynext, ldyn, seq_scale, seq_rows);
   SF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3(24), dim3(1024), 0, s, workspace, nblk, (int64_t)2 * 768, dgamma, 2 * 768, accumulate_dparams, dbeta, 768);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(24), dim3(1024), 0, s, workspace, nblk, (int64_t)planes * 768, dgamma, 2 * 768, accumulate_dparams, dbeta, 768);
   SF_LAUNCH_CHECK();
+  if (ynext) {
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3(12), dim3(1024), 0, s, workspace + 2 * 768, nblk, (int64_t)planes * 768, dbias_next, 768, 0, (float*)nullptr, 0);
+    SF_LAUNCH_CHECK();
+  }
   return 0;
+}
+
+// sf_layernorm768_bwd(_bf16) with identity row maps that ALSO writes the head of the next residual branch's backward (what sf_branch_grad would compute from the
+// updated dx in another pass): y_next = bf16(seq_scale[row / seq_rows] * dx) (seq_scale NULL = 1) and dbias_next[c] = sum_r seq_scale * dx[r, c] (fp32, assigned).
+// workspace: fp32, 3 * 768 * ceil(rows / 4) elements.
+extern "C" int sf_layernorm768_bwd_branch(const float* x, int64_t ldx, const float* gamma, const void* dy, int dy_dtype, int64_t lddy, float* dx, int64_t lddx,
+                                          int accumulate_dx, float* dgamma, float* dbeta, int accumulate_dparams, uint16_t* y_next, int64_t ldyn,
+                                          const float* seq_scale, int64_t seq_rows, float* dbias_next, float* workspace, int64_t rows, float eps, void* stream) {
+  SF_CHECK_ARG(y_next && dbias_next && (ldyn % 4) == 0 && ((uintptr_t)y_next % 8) == 0 && seq_rows >= 1, "sf_layernorm768_bwd_branch: bad next-branch arguments");
+  SF_CHECK_ARG(dy_dtype == SF_BF16 || dy_dtype == SF_F32, "sf_layernorm768_bwd_branch: dy must be bf16 or f32");
+  return layernorm768_bwd_impl(x, ldx, nullptr, gamma, dy, dy_dtype == SF_BF16, lddy, nullptr, dx, lddx, nullptr, accumulate_dx, dgamma, dbeta, accumulate_dparams,
+                               workspace, rows, eps, stream, y_next, ldyn, seq_scale, seq_rows, dbias_next);
 }
 
 extern "C" int sf_layernorm768_bwd(const float* x, int64_t ldx, const int64_t* x_map, const float* gamma, const float* dy, int64_t lddy,

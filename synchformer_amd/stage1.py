@@ -78,6 +78,9 @@ class AVCLIPTrainer(FlatTrainer):
         # the CLS query's backward of the space attention inside sf_attention_group_bwd (as one more query row per group, on the forward's softmax statistics)
         # instead of sf_attention_cls_bwd's read-modify-write pass over dk | dv; SF_CLS_IN_GROUP=0 keeps the separate pass
         self.cls_in_group = os.environ.get('SF_CLS_IN_GROUP', '1') != '0'
+        # the LayerNorm backward that closes a residual branch also writes the next branch's dY operand and output-bias gradient (sf_layernorm768_bwd_branch)
+        self.fuse_branch = os.environ.get('SF_FUSE_BRANCH', '1') != '0'
+        self._pre_dy = {}
         self.two_streams = os.environ.get('SF_STAGE1_TWO_STREAMS', '1') != '0'   # audio tower next to the visual one (forward_backward)
         self._side = None
         self._pre_ln = set()                # workspace buffers whose LayerNorm output _add_branch has already produced (consumed by _ln_into)
@@ -89,9 +92,21 @@ class AVCLIPTrainer(FlatTrainer):
         return self.p[name + '.weight'], self.p[name + '.bias']
 
     def _lnws(self, rows):
-        return self._buf('ln_ws', (2 * 768 * ((rows + 3) // 4),), torch.float32)
+        return self._buf('ln_ws', (3 * 768 * ((rows + 3) // 4),), torch.float32)
 
-    def _ln_bwd(self, x, name, dy, dx, rows, eps, **kw):
+    def _ln_bwd(self, x, name, dy, dx, rows, eps, next_branch=None, **kw):
+        """next_branch = (dp, seq_rows, bias_key) of the residual branch whose backward runs next on this dx: its dY operand and output-bias gradient are written by
+        this launch (sf_layernorm768_bwd_branch) and _branch_dy finds them done."""
+        if next_branch is not None and self.fuse_branch and kw.get('acc_dx') and not (set(kw) - {'acc_dx'}):
+            dp, seq_rows, bias_key = next_branch
+            dy_b = self._buf('dy_b', (rows, D), torch.bfloat16)
+            _chk(_lib.load().sf_layernorm768_bwd_branch(x.data_ptr(), x.stride(0), self.p[name + '.weight'].data_ptr(), dy.data_ptr(),
+                                                        1 if dy.dtype == torch.bfloat16 else 0, dy.stride(0), dx.data_ptr(), dx.stride(0), 1,
+                                                        self.g[name + '.weight'].data_ptr(), self.g[name + '.bias'].data_ptr(), 0, dy_b.data_ptr(), dy_b.stride(0),
+                                                        dp.data_ptr() if dp is not None else None, max(1, seq_rows), self.g[bias_key].data_ptr(),
+                                                        self._lnws(rows).data_ptr(), rows, float(eps), _st()), 'sf_layernorm768_bwd_branch')
+            self._pre_dy[self._ws_prefix] = (bias_key, rows)
+            return
         ln_bwd(x, self.p[name + '.weight'], dy, dx, self.g[name + '.weight'], self.g[name + '.bias'], self._lnws(rows), rows, eps, **kw)
 
     def _gelu_fwd(self, pre, act):
@@ -133,6 +148,8 @@ class AVCLIPTrainer(FlatTrainer):
         """Head of a residual branch's backward: dY = bf16(dp[segment] * dx) for the branch's output Linear, and that Linear's bias gradient (fp32 column
         sums of the scaled gradient) into g[bias_key], in one pass over dx (sf_branch_grad)."""
         dy_b = self._buf('dy_b', (rows, D), torch.bfloat16)
+        if self._pre_dy.pop(self._ws_prefix, None) == (bias_key, rows):        # written by the LayerNorm backward that last updated dx
+            return dy_b
         ws = self._buf('colsum_ws', (D * ((rows + 63) // 64),), torch.float32)
         _chk(_lib.load().sf_branch_grad(dx.data_ptr(), dx.stride(0), dp.data_ptr() if dp is not None else None, max(1, seq_rows), dy_b.data_ptr(), dy_b.stride(0),
                                         rows, D, self.g[bias_key].data_ptr(), 0, ws.data_ptr(), _st()), 'sf_branch_grad')
@@ -185,14 +202,14 @@ class AVCLIPTrainer(FlatTrainer):
             self._add_branch(br, dp, seq_rows, rows, x_in, out, next_ln)
         return out
 
-    def _mlp_bwd(self, s, dx, x_in, fc1, fc2, rows, ln_name, eps, dp=None, seq_rows=0):
+    def _mlp_bwd(self, s, dx, x_in, fc1, fc2, rows, ln_name, eps, dp=None, seq_rows=0, next_branch=None):
         """dx (rows, 768) fp32 = gradient of the block output; adds the MLP branch's contribution through LN(x_in) into dx."""
         dy_b = self._branch_dy(dx, dp, seq_rows, rows, fc2 + '.bias')                                     # gradient of the (scaled) branch + fc2's bias gradient
         dact = self._lin_bwd(fc2, dy_b, s['act'], rows, tag='act', bias_done=True, dx_dtype=torch.bfloat16)   # consumed by the bf16 GELU backward only
         dpre = self._buf('dpre', (rows, FF), torch.bfloat16)
         self._gelu_bwd(s['pre'], dact, dpre)
         dh = self._lin_bwd(fc1, dpre, s['h2'], rows, tag='h', dx_dtype=torch.bfloat16)                      # read once, by the LN backward
-        self._ln_bwd(x_in, ln_name, dh, dx, rows, eps, acc_dx=True)
+        self._ln_bwd(x_in, ln_name, dh, dx, rows, eps, next_branch=next_branch, acc_dx=True)
 
     # ---- divided space-time attention ---------------------------------------------------------------------------------
     @staticmethod
@@ -294,7 +311,7 @@ class AVCLIPTrainer(FlatTrainer):
                                               dqkv[:, 2 * D:].data_ptr(), dqkv.stride(0), n_seq, H, HD, 0.125, int(accumulate), _st()),
              'sf_attention_cls_bwd')
 
-    def _attn_branch_bwd(self, dx, rows, proj, att_saved, qkv_fn, h_saved, x_in, ln_name, eps, qkv_names, dp=None, seq_rows=0):
+    def _attn_branch_bwd(self, dx, rows, proj, att_saved, qkv_fn, h_saved, x_in, ln_name, eps, qkv_names, dp=None, seq_rows=0, next_branch=None):
         """Common tail of an attention residual branch: dx -> proj backward -> attention backward (qkv_fn) -> qkv linear(s)
         backward -> LN backward accumulated into dx.  `dp`: per-segment stochastic-depth scales of this branch (None = branch always kept)."""
         dy_b = self._branch_dy(dx, dp, seq_rows, rows, proj + '.bias')
@@ -306,7 +323,7 @@ class AVCLIPTrainer(FlatTrainer):
             dh = self._buf('dx_qkvsum', (rows, D), torch.float32)
             for j, nm in enumerate(qkv_names):
                 self._lin_bwd(nm, dqkv[:, j * D:(j + 1) * D], h_saved, rows, dx_out=dh, acc_dx=j > 0)
-        self._ln_bwd(x_in, ln_name, dh, dx, rows, eps, acc_dx=True)
+        self._ln_bwd(x_in, ln_name, dh, dx, rows, eps, next_branch=next_branch, acc_dx=True)
 
     # ---- aggregator layer (BaseEncoderLayer over nn.TransformerEncoderLayer, motionformer.py:301-334) -----------------
     def _agg_fwd(self, Z, n_seq, L, p, tag):
@@ -408,11 +425,18 @@ class AVCLIPTrainer(FlatTrainer):
             on_ready(self._key_range(V + '.norm.', V + '.spatial_attn_agg.'))
         for i in reversed(range(self.n_vblocks)):
             p, s = f'{V}.blocks.{i}', sv['blocks'][i]
-            self._mlp_bwd(s, dx, s['xs'], p + '.mlp.fc1', p + '.mlp.fc2', M, p + '.norm2', EPS_VIS, dp=s['dp_m'], seq_rows=VIS_L)
+            # every branch's closing LayerNorm backward also writes the head of the branch that follows on dx: space after MLP, time after space, the previous
+            # block's MLP after time
+            nb_prev = None
+            if i > 0:
+                pp_, sp_ = f'{V}.blocks.{i - 1}', sv['blocks'][i - 1]
+                nb_prev = (sp_['dp_m'], VIS_L, pp_ + '.mlp.fc2.bias')
+            self._mlp_bwd(s, dx, s['xs'], p + '.mlp.fc1', p + '.mlp.fc2', M, p + '.norm2', EPS_VIS, dp=s['dp_m'], seq_rows=VIS_L,
+                          next_branch=(s['dp_s'], VIS_L, p + '.attn.proj.bias'))
             self._attn_branch_bwd(dx, M, p + '.attn.proj', s['atts'], lambda dO, q=s['qkvs'], a=s['atts'], c=s['csts']: self._divided_bwd(q, dO, n, 'space', att=a, stats=c), s['hs'],
-                                  s['xt'], p + '.norm1', EPS_VIS, p + '.attn.qkv', dp=s['dp_s'], seq_rows=VIS_L)
+                                  s['xt'], p + '.norm1', EPS_VIS, p + '.attn.qkv', dp=s['dp_s'], seq_rows=VIS_L, next_branch=(None, 0, p + '.timeattn.proj.bias'))
             self._attn_branch_bwd(dx, M, p + '.timeattn.proj', s['attt'], lambda dO, q=s['qkvt'], a=s['attt'], c=s['cstt']: self._divided_bwd(q, dO, n, 'time', att=a, stats=c), s['ht'],
-                                  s['x'], p + '.norm3', EPS_VIS, p + '.timeattn.qkv')
+                                  s['x'], p + '.norm3', EPS_VIS, p + '.timeattn.qkv', next_branch=nb_prev)
             if on_ready and i % 3 == 0:                                        # blocks i .. i+2 are final: one ~92 MB bucket
                 on_ready(self._key_range(*[f'{V}.blocks.{j}.' for j in range(i, min(i + 3, self.n_vblocks))]))
         # token table: row 0 = cls_token + pos[0]; row 1 + f*196 + p = pos[1 + p] + temp[f]  (video_model_builder.py:248-254)
@@ -493,7 +517,8 @@ class AVCLIPTrainer(FlatTrainer):
         self._ln_bwd(sv['x_last'], A + '.ast.layernorm', dZ, dx, n * P, EPS_AST, x_map=sv['tokmap'], dy_map=sv['z_map'], dx_map=sv['tokmap'])
         for i in reversed(range(self.n_alayers)):
             p, s = f'{A}.ast.encoder.layer.{i}', sv['layers'][i]
-            self._mlp_bwd(s, dx, s['x2'], p + '.intermediate.dense', p + '.output.dense', M, p + '.layernorm_after', EPS_AST)
+            self._mlp_bwd(s, dx, s['x2'], p + '.intermediate.dense', p + '.output.dense', M, p + '.layernorm_after', EPS_AST,
+                          next_branch=(None, 0, p + '.attention.output.dense.bias'))
 
             def full_bwd(dO, q=s['qkv']):
                 dqkv = self._buf('dqkv', (M, 3 * D), torch.bfloat16)
@@ -506,7 +531,8 @@ class AVCLIPTrainer(FlatTrainer):
                     self.attn_bwd_seq(q, dO, dqkv, n, L, H, HD)
                 return dqkv
             self._attn_branch_bwd(dx, M, p + '.attention.output.dense', s['att'], full_bwd, s['h1'], s['x'], p + '.layernorm_before', EPS_AST,
-                                  [f'{p}.attention.attention.{nm}' for nm in ('query', 'key', 'value')])
+                                  [f'{p}.attention.attention.{nm}' for nm in ('query', 'key', 'value')],
+                                  next_branch=(None, 0, f'{A}.ast.encoder.layer.{i - 1}.output.dense.bias') if i > 0 else None)
         e = A + '.ast.embeddings'
         gtab = self._buf('gtab', (VIS_L, D), torch.float32)[:L]
         self._seqsum(dx, n, L, gtab)

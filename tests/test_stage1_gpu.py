@@ -647,3 +647,40 @@ def test_space_attention_bwd_cls_query_in_group_kernel(gpu):
         print(f'{name}: rel-L2 {rel:.5f}, max |d| {(x - y).abs().max().item():.5f} (scale {x.abs().max().item():.3f})')
         assert rel < 6e-3, name
     assert torch.equal(a[:, 1:, 0], b[:, 1:, 0])                               # the patches' dq does not involve the CLS query at all
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,scaled,bf16', [(1569 * 3, True, True), (1000, False, False), (1569 * 12, True, True)])
+def test_layernorm_bwd_with_next_branch_head(gpu, rows, scaled, bf16):
+    """sf_layernorm768_bwd_branch == sf_layernorm768_bwd(_bf16) followed by sf_branch_grad on the updated dx: the same dx and dgamma | dbeta, the next branch's dY
+    operand bit for bit (it is bf16(scale * dx) of the same fp32 value), its bias gradient up to the summation order."""
+    torch.manual_seed(5)
+    x = torch.randn(rows, 768, device=gpu) * 1.5 + 0.2
+    gam = 1 + 0.1 * torch.randn(768, device=gpu)
+    dy = torch.randn(rows, 768, device=gpu) * 0.3
+    if bf16:
+        dy = dy.bfloat16()
+    dx0 = torch.randn(rows, 768, device=gpu) * 0.2
+    n_seq = rows // 1569 if scaled else 1
+    sc = None
+    if scaled:
+        sc = torch.tensor([0.0 if i % 3 == 1 else 1.25 for i in range(n_seq)], device=gpu)
+    ws = torch.empty(3 * 768 * ((rows + 3) // 4), device=gpu)
+    # reference: two launches
+    dx_a, dg_a, db_a = dx0.clone(), torch.zeros(768, device=gpu), torch.zeros(768, device=gpu)
+    fn = _lib().sf_layernorm768_bwd_bf16 if bf16 else _lib().sf_layernorm768_bwd
+    assert fn(x.data_ptr(), 768, None, gam.data_ptr(), dy.data_ptr(), 768, None, dx_a.data_ptr(), 768, None, 1, dg_a.data_ptr(), db_a.data_ptr(), 0, ws.data_ptr(), rows,
+              1e-6, _st()) == 0
+    y_a, bias_a = torch.zeros(rows, 768, device=gpu, dtype=torch.bfloat16), torch.zeros(768, device=gpu)
+    ws2 = torch.empty(768 * ((rows + 63) // 64), device=gpu)
+    assert _lib().sf_branch_grad(dx_a.data_ptr(), 768, sc.data_ptr() if scaled else None, 1569 if scaled else 1, y_a.data_ptr(), 768, rows, 768, bias_a.data_ptr(), 0,
+                                 ws2.data_ptr(), _st()) == 0
+    # fused
+    dx_b, dg_b, db_b = dx0.clone(), torch.zeros(768, device=gpu), torch.zeros(768, device=gpu)
+    y_b, bias_b = torch.zeros(rows, 768, device=gpu, dtype=torch.bfloat16), torch.full((768,), 7.0, device=gpu)
+    rc = _lib().sf_layernorm768_bwd_branch(x.data_ptr(), 768, gam.data_ptr(), dy.data_ptr(), 1 if bf16 else 0, 768, dx_b.data_ptr(), 768, 1, dg_b.data_ptr(), db_b.data_ptr(), 0,
+                                           y_b.data_ptr(), 768, sc.data_ptr() if scaled else None, 1569 if scaled else 1, bias_b.data_ptr(), ws.data_ptr(), rows, 1e-6, _st())
+    assert rc == 0, _lib().sf_last_error()
+    assert torch.equal(dx_a, dx_b) and torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b)
+    assert torch.equal(y_a, y_b)
+    torch.testing.assert_close(bias_b, bias_a, rtol=1e-4, atol=1e-3)
