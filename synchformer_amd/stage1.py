@@ -411,6 +411,7 @@ class AVCLIPTrainer(FlatTrainer):
         return out
 
     def _bwd_visual(self, dout, on_ready=None):
+        self._pre_dy.pop(self._ws_prefix, None)                              # (no branch head of an earlier, interrupted backward)
         sv = self.sv_v
         n = sv['n']
         M = n * VIS_L
@@ -504,6 +505,7 @@ class AVCLIPTrainer(FlatTrainer):
         return out
 
     def _bwd_audio(self, dout):
+        self._pre_dy.pop(self._ws_prefix, None)
         sv = self.sv_a
         n, nt = sv['n'], sv['nt']
         L, P = AUD_L, AUD_P
