@@ -427,7 +427,11 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_pp_kernel(MxArgs p) {
   // registers = 16 of the 32 features of one scale block, the lane 32 away holds the other 16), so that the quantisation needs one cross-lane step per block and no
   // fp32 staging (the fp8 bytes alone pass through the slab, 2 KiB per 32 tokens): 8 row stores of 16 bytes + 4 scale stores of 2 bytes per wave instead of 32 + 32 (was 1370 us for fc1 of the 13-segment batch against 677 for qkv)
   constexpr bool WIDEMX = OUT == 2 && !HAS_RES;
-  constexpr int EPI_VM = WIDEMX ? 12 : (OUT == 2 ? 54 : 32);     // vector-memory operations of one epilogue (OUT 2 with residual: 64, capped by the 6-bit counter: 9 + 54 = 63)
+  // WIDEBF (bf16 output without residual - the spatial qkv projection): the same transposed blocks, bf16 pairs through the 2-KiB slab, 16-byte row stores (16 per wave
+  // instead of 32 stores of 8 bytes behind an fp32 slab round trip); bit-identical to the general epilogue
+  constexpr bool WIDEBF = OUT == 1 && !HAS_RES;
+  constexpr bool TRANSPOSED = WIDEMX || WIDEBF;
+  constexpr int EPI_VM = WIDEMX ? 12 : (WIDEBF ? 16 : (OUT == 2 ? 54 : 32));     // vector-memory operations of one epilogue (OUT 2 with residual: 64, capped by the 6-bit counter: 9 + 54 = 63)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_pp_kernel(MxArgs p) {
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          acc[HA * 2 + i][HB] = WIDEMX ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bf[kk], a[i][kk], acc[HA * 2 + i][HB], 0, 0, 0, sbv[kk], 0, sav[i][kk])
+          acc[HA * 2 + i][HB] = TRANSPOSED ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bf[kk], a[i][kk], acc[HA * 2 + i][HB], 0, 0, 0, sbv[kk], 0, sav[i][kk])
                                        : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i][kk], bf[kk], acc[HA * 2 + i][HB], 0, 0, 0, sav[i][kk], 0, sbv[kk]);
       // the MFMAs are pure to the optimiser: with the run-time branches of the read segments around, LLVM sinks them towards their next use (the next
       // k-tile's MFMAs on the same accumulator) - out of the matrix segment, with every fragment live across phases; an opaque use pins them here
@@ -675,7 +679,45 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_pp_kernel(MxArgs p) {
     if (!ld_ok) mq_wait_vmcnt<0>();                                // a dry iterator's pieces must have landed before this workgroup's LDS can be handed on
     const int64_t em0 = m0; const int en0 = n0;
     extra = 0;
-    if (WIDEMX) {
+    if (WIDEBF) {
+      if (en0 + wn * 64 < p.N) {
+        extra = 1;
+        int etid = threadIdx.x;
+        asm volatile("" : "+v"(etid));
+        const int el = etid & 63, el31 = el & 31, ehi = el >> 5;
+        float4 bia[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            bia[j][g] = has_bias ? *reinterpret_cast<const float4*>(bslab + (j * 32 + g * 8 + ehi * 4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);   // landed long ago
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the slab is reused below
+        // slab: 32 tokens x 64 bytes (32 features of block j as bf16); 16-byte chunk g (features g * 8 .. + 7: the low lane's four, then the high lane's four) of row t at
+        // slot g ^ ((t >> 1) & 3)
+        const int wr_off = el31 * 64 + ehi * 8, wsw = (el31 >> 1) & 3;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              sf_f32x2_t g0 = {acc[ib][j][g * 4 + 0] + bia[j][g].x, acc[ib][j][g * 4 + 1] + bia[j][g].y};
+              sf_f32x2_t g1 = {acc[ib][j][g * 4 + 2] + bia[j][g].z, acc[ib][j][g * 4 + 3] + bia[j][g].w};
+              if (GELU) gelu_erf4(g0, g1);
+              mx_u32x2 w2; w2.x = pack_bf2(g0.x, g0.y); w2.y = pack_bf2(g1.x, g1.y);
+              *reinterpret_cast<mx_u32x2*>(bslab + wr_off + ((g ^ wsw) << 4)) = w2;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int tr = h * 16 + (el >> 2);
+              const mx_u32x4 o = *reinterpret_cast<const mx_u32x4*>(bslab + tr * 64 + (((el & 3) ^ ((tr >> 1) & 3)) << 4));
+              __builtin_amdgcn_raw_buffer_store_b128(o, rc, (uint32_t)((em0 + wm * 128 + ib * 32 + tr) * p.ldc + en0 + wn * 64 + j * 32 + (el & 3) * 8) * 2u, 0, SF_MX_STORE_AUX);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          }
+      }
+    } else if (WIDEMX) {
       if (en0 + wn * 64 < p.N) {
         extra = 1;
         int etid = threadIdx.x;
