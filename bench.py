@@ -199,7 +199,7 @@ class GemmTimer:
                 return box['rc']
             n0 = len(self.records)
             rc = self._rec(run, 2.0 * M * N * K, M * K * 2 + N * K * 2 + 2 * M * N * 2, 'gemm_bf16_pp_kernel<true, true, false, true>', f'N={N} K={K}')
-            if rc == 1:                                                # outside config 11's range: nothing was launched (the caller takes the two-launch path)
+            if rc == -2:                                               # SF_NOT_APPLICABLE: outside config 11's range: nothing was launched (the caller takes the two-launch path)
                 del self.records[n0:]
             return rc
 

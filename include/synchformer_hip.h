@@ -132,8 +132,9 @@ void sf_gemm_force_config(int cfg);
  * under the kernel symbol rocprofv3 reports for that configuration. */
 int sf_gemm_bf16_auto_config(int64_t M, int64_t N, int64_t K, int has_residual);
 /* fc1 of a trained MLP in one launch (Stage-1 towers; vit_helper.py Mlp / modeling_ast.py ASTIntermediate): pre = A W^T + bias and act = gelu(pre), both bf16 with
- * row stride ldc, both kept for the backward.  Returns 1 without launching when the shape is outside config 11's range (K % 128 == 0, K >= 256, N % 64 == 0,
- * M, N >= 256, aligned): the caller then runs sf_gemm_bf16 + sf_gelu_fwd. */
+ * row stride ldc, both kept for the backward.  Returns SF_NOT_APPLICABLE (-2: no hipError_t, no argument error) without launching when the shape is outside
+ * config 11's range (K % 128 == 0, K >= 256, N % 64 == 0, M, N >= 256, aligned): the caller then runs sf_gemm_bf16 + sf_gelu_fwd. */
+#define SF_NOT_APPLICABLE (-2)
 int sf_gemm_bf16_gelu_dual(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, uint16_t* pre, uint16_t* act, int64_t ldc,
                            int64_t M, int64_t N, int64_t K, void* stream);
 /* The same kind of hook for sf_gemm_res_ln768's main-loop schedule: -1 default (quadrant-phased, round 3), 0 = round 2's loop (one stage of prefetch),

@@ -27,12 +27,19 @@ def _stale(target: Path, deps) -> bool:
     return (not target.exists()) or any(d.stat().st_mtime > target.stat().st_mtime for d in deps)
 
 
+def _flags_txt() -> str:
+    return ' '.join(CFLAGS + EXTRA)
+
+
 def needs_build() -> bool:
-    return _stale(OUT, sources() + _headers())
+    """Stale if a source / header is newer than the library OR the library was built under other flags (an SF_EXTRA_FLAGS ablation build must never be
+    served as the product library by a later plain build() / _lib.load())."""
+    stamp = OBJ / '.flags'
+    return _stale(OUT, sources() + _headers()) or not stamp.exists() or stamp.read_text() != _flags_txt()
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
-    if not force and not needs_build() and not EXTRA:
+    if not force and not needs_build():
         return OUT
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not Path(hipcc).exists():
@@ -40,7 +47,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     OBJ.mkdir(parents=True, exist_ok=True)
     hdrs = _headers()
     stamp = OBJ / '.flags'
-    flags_txt = ' '.join(CFLAGS + EXTRA)
+    flags_txt = _flags_txt()
     if not stamp.exists() or stamp.read_text() != flags_txt:
         force = True
     jobs = []

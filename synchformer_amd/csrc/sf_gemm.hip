@@ -895,8 +895,8 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
 }
 
 // fc1 of a TRAINED MLP in one launch: pre = A W^T + bias (bf16) AND act = gelu(pre) (bf16), both kept for the backward (was sf_gemm_bf16 -> sf_gelu_fwd).
-// Config 11 only: K % 128 == 0, K >= 256, N % 64 == 0, 16-byte aligned rows, outputs below 4 GiB; returns 1 (nothing launched) when the shape is outside
-// that range, so the caller can take the two-launch path.
+// Config 11 only: K % 128 == 0, K >= 256, N % 64 == 0, 16-byte aligned rows, outputs below 4 GiB; returns SF_NOT_APPLICABLE (-2, nothing launched; cannot collide with a
+// hipError_t such as hipErrorInvalidValue = 1 coming back from the launch) when the shape is outside that range, so the caller can take the two-launch path.
 extern "C" int sf_gemm_bf16_gelu_dual(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, bf16_t* pre, bf16_t* act, int64_t ldc,
                                       int64_t M, int64_t N, int64_t K, void* stream) {
   SF_CHECK_ARG(A && W && pre && act, "sf_gemm_bf16_gelu_dual: null pointer");
@@ -911,7 +911,7 @@ extern "C" int sf_gemm_bf16_gelu_dual(const bf16_t* A, int64_t lda, const bf16_t
   a.M = M; a.N = (int)N; a.K = (int)K;
   a.tiles_n = 0; a.tiles_total = 0; a.nchunk = 0; a.wk = 64;
   a.batch_inner = 0; a.sA0 = a.sA1 = a.sW0 = a.sW1 = a.sC0 = a.sC1 = 0;
-  if (!ok || !sf_gemm_pp_supported(a)) return 1;
+  if (!ok || !sf_gemm_pp_supported(a)) return SF_NOT_APPLICABLE;
   return sf_gemm_pp_dispatch(a, true, true, false, (hipStream_t)stream);
 }
 

@@ -384,15 +384,27 @@ class Synchformer(torch.nn.Module):
 
     # -- engine cache ---------------------------------------------------------------------------------------
     def _split_keys(self):
-        # (storage, version) of every parameter, extractor side and sync side.  The parameter LISTS are cached (the module tree does not change; walking
-        # named_parameters() of ~700 tensors three to four times per forward cost a few ms of host time per training step); the versions are read fresh.
+        # (storage, version) of every parameter, extractor side and sync side.  The parameter LISTS are cached (walking named_parameters() of ~700 tensors
+        # three to four times per forward cost a few ms of host time per training step) as (owner module, name, Parameter) and VERIFIED on every call with one
+        # flat identity loop: a Parameter OBJECT that was replaced - load_state_dict(assign=True), `m.weight = nn.Parameter(..)`, parametrize / prune,
+        # set_overwrite_module_params_on_conversion - is no longer what its owner holds, so the lists are rebuilt and the engine sees the new storage.
         lists = self.__dict__.get('_sf_param_lists')
+        if lists is not None:
+            for group in lists:
+                for owner, pname, p in group:
+                    if owner._parameters.get(pname) is not p:
+                        lists = None
+                        break
+                if lists is None:
+                    break
         if lists is None:
+            owners = dict(self.named_modules())
             frozen, sync = [], []
             for n, p in self.named_parameters():
-                (sync if n.startswith(('vproj.', 'aproj.', 'transformer.')) else frozen).append(p)
+                mod, _, pname = n.rpartition('.')
+                (sync if n.startswith(('vproj.', 'aproj.', 'transformer.')) else frozen).append((owners[mod], pname, p))
             lists = self.__dict__['_sf_param_lists'] = (frozen, sync)
-        return (tuple((p.data_ptr(), p._version) for p in lists[0]), tuple((p.data_ptr(), p._version) for p in lists[1]))
+        return (tuple((p.data_ptr(), p._version) for _, _, p in lists[0]), tuple((p.data_ptr(), p._version) for _, _, p in lists[1]))
 
     def _engine(self, need_sync: bool = True) -> SynchformerEngine:
         """The engine is keyed on the EXTRACTOR parameters only (214.8M weights, the multi-GB workspaces): an optimizer step on
@@ -478,8 +490,8 @@ class Synchformer(torch.nn.Module):
                 raise NotImplementedError(f'Loss {loss_fn} not implemented')
         return loss
 
-    def load_state_dict(self, sd: Mapping[str, Any], strict: bool = True):
-        """sync_model.py:101-114: a longer checkpoint pos_emb is trimmed, a shorter one is an error."""
+    def load_state_dict(self, sd: Mapping[str, Any], strict: bool = True, assign: bool = False):
+        """sync_model.py:101-114: a longer checkpoint pos_emb is trimmed, a shorter one is an error (`assign` = the newer nn.Module keyword, passed through)."""
         if 'transformer.pos_emb_cfg.pos_emb' in sd:
             weight_len = sd['transformer.pos_emb_cfg.pos_emb'].shape[1]
             self_len = self.transformer.pos_emb_cfg.pos_emb.shape[1]
@@ -491,7 +503,8 @@ class Synchformer(torch.nn.Module):
                 raise ValueError(f'Cant load state dict with shorter seq len ({weight_len} vs {self_len})')
         self._sf_engine = None
         object.__setattr__(self, '_sf_trainer_key', None)      # the train step re-reads its parameter copies (the trainer and its dropout counter stay)
-        return super().load_state_dict(sd, strict)
+        self.__dict__.pop('_sf_param_lists', None)
+        return super().load_state_dict(sd, strict, assign=assign) if assign else super().load_state_dict(sd, strict)
 
 
 class AVCLIP(torch.nn.Module):

@@ -168,6 +168,12 @@ class AVCLIPTrainer(FlatTrainer):
         self._pre_ln.add(self._ws_prefix + bufname)
         return out
 
+    def _clear_pre_ln(self):
+        """Forget the pre-computed LayerNorms of THIS tower's workspaces (the two towers run on two streams with their own `_ws_prefix`): after an
+        interrupted forward a stale key would make a later _ln_into skip its LayerNorm and read the previous step's buffer."""
+        pre = self._ws_prefix
+        self._pre_ln = {k for k in self._pre_ln if (not k.startswith(pre) if pre else k.startswith('a:'))}
+
     def _ln_into(self, x, name, bufname, rows, eps):
         """LayerNorm `name` of x into the workspace buffer `bufname` (bf16) - unless _add_branch already produced it together with x."""
         y = self._buf(bufname, (rows, D), torch.bfloat16)
@@ -186,9 +192,9 @@ class AVCLIPTrainer(FlatTrainer):
         s['act'] = self._buf(f'{tag}_act', (rows, FF), torch.bfloat16)
         w1, b1 = self._wb(fc1)
         # fc1 + GELU with both the pre-activation and the activation kept, in one launch where the quadrant-phased kernel applies (the big visual MLPs)
-        rc = 1 if rows < 8192 else _lib.load().sf_gemm_bf16_gelu_dual(s['h2'].data_ptr(), s['h2'].stride(0), w1.data_ptr(), w1.stride(0), b1.data_ptr(),
+        rc = _lib.SF_NOT_APPLICABLE if rows < 8192 else _lib.load().sf_gemm_bf16_gelu_dual(s['h2'].data_ptr(), s['h2'].stride(0), w1.data_ptr(), w1.stride(0), b1.data_ptr(),
                                                                        s['pre'].data_ptr(), s['act'].data_ptr(), FF, rows, FF, D, _st())
-        if rc == 1:
+        if rc == _lib.SF_NOT_APPLICABLE:                       # shape outside config 11's range: nothing was launched; any other non-zero code is an error
             ops.gemm(s['h2'], w1, b1, s['pre'])
             self._gelu_fwd(s['pre'], s['act'])
         else:
@@ -371,6 +377,7 @@ class AVCLIPTrainer(FlatTrainer):
         """vid (n, 16, 3, 224, 224) u8|f16|bf16|f32 -> aggregator outputs (n*8, 768) fp32 (saved state in self.sv_v)."""
         n = vid.shape[0]
         M = n * VIS_L
+        self._clear_pre_ln()                                                 # (no LayerNorm left over from an earlier, interrupted forward)
         sv = self.sv_v = dict(n=n, blocks=[])
         sv['patches'] = self._buf('v_patches', (n * VIS_P, 1536), torch.bfloat16)
         ops.im2col_video(vid.contiguous(), sv['patches'])
@@ -467,6 +474,7 @@ class AVCLIPTrainer(FlatTrainer):
     def _fwd_audio(self, spec):
         """spec (n, F=128, Ta=66) fp32 -> aggregator outputs (n*6, 768) fp32."""
         n, Fa, Ta = spec.shape
+        self._clear_pre_ln()
         nf, nt = (Fa - 16) // 10 + 1, (Ta - 16) // 10 + 1
         P, L = nf * nt, nf * nt + 2
         if (P, L, nf + 1) != (AUD_P, AUD_L, AGG_A):

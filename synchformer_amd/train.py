@@ -209,7 +209,9 @@ class FlatTrainer:
         tn = self.tn_wgrad and N % 128 == 0 and K % 128 == 0 and M >= 512 and dy_b.stride(0) % 8 == 0 and x_b.stride(0) % 8 == 0
         split = _wgrad_split(tiles) if M >= 8192 else (max(1, min(_wgrad_split(tiles), m_pad // 128)) if tn else 1)   # short M: >= 128 rows per chunk
         kc = ((m_pad // split + 63) // 64) * 64
-        if tn and self.tn_pp and N % 256 == 0 and K % 256 == 0 and M >= 8192:
+        # (sf_gemm_tn_pp addresses its operands with 32-bit byte offsets: beyond 4 GiB of dY / X rows the split-K kernel below, which has no such limit, takes over)
+        pp_rows = (M + 127) // 128 * 128 + 128 * self.n_cu
+        if tn and self.tn_pp and N % 256 == 0 and K % 256 == 0 and M >= 8192 and pp_rows * max(dy_b.stride(0), x_b.stride(0)) * 2 < (1 << 32):
             # the big weight gradients: quadrant-phased 256 x 256 kernel (sf_gemm_tn_pp), as many chunks as fill the chip once with 256 x 256 tiles
             t256 = (N // 256) * (K // 256)
             sp = max(1, self.n_cu // t256)

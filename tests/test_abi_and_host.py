@@ -138,6 +138,28 @@ def test_module_mirror_schema_and_api():
     assert 'model.sync_model' not in sys.modules
 
 
+def test_engine_cache_key_sees_replaced_parameter_objects():
+    """the cached parameter lists must not keep serving a Parameter OBJECT that its owner no longer holds
+    (load_state_dict(assign=True), `m.weight = nn.Parameter(..)`): the engine key has to change with the new storage."""
+    import synchformer_amd as sa
+    from synchformer_amd import synth
+    m = sa.instantiate_from_config(sa.sync_yaml_model_config())
+    k0 = m._split_keys()
+    assert m._split_keys() == k0                                                 # stable while nothing changes
+    m.vproj.weight = torch.nn.Parameter(torch.zeros(768, 768))                   # sync side, new object
+    k1 = m._split_keys()
+    assert k1[1] != k0[1] and k1[0] == k0[0]
+    sd = {k: v.clone() for k, v in synth.make_state_dict(5).items()}
+    m.load_state_dict(sd, strict=True, assign=True)                              # every Parameter object replaced
+    k2 = m._split_keys()
+    assert k2[0] != k1[0] and k2[1] != k1[1]
+    ptrs = {p.data_ptr() for p in m.parameters()}
+    assert {dp for dp, _ in k2[0] + k2[1]} == ptrs                               # ... and the key is made of the NEW storages
+    with torch.no_grad():
+        m.aproj.bias.add_(1.0)                                                   # in-place update: same object, version bump
+    assert m._split_keys()[1] != k2[1]
+
+
 def test_shard_range():
     from synchformer_amd.dist import shard_range
     for n in (0, 1, 7, 16, 33):

@@ -843,7 +843,7 @@ def test_gemm_gelu_dual(gpu):
     assert (pre[M:] == 3.0).all() and (act[M:] == 5.0).all(), 'rows beyond M were written'
     ref = a.float() @ w.float().t() + b
     torch.testing.assert_close(act[:M].float(), torch.nn.functional.gelu(ref), rtol=1e-2, atol=2e-2)
-    assert lib.sf_gemm_bf16_gelu_dual(a.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), pre.data_ptr(), act.data_ptr(), N, M, N, 192, st) == 1     # K % 128 != 0
+    assert lib.sf_gemm_bf16_gelu_dual(a.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), pre.data_ptr(), act.data_ptr(), N, M, N, 192, st) == -2    # K % 128 != 0
 
 
 def test_gemm_ktile_major_weight(gpu):
