@@ -568,9 +568,9 @@ class SynchformerEngine:
         ops.gemm(fb, proj.w, proj.b, out)
         return out.view(B, n_tok, D)
 
-    def global_transformer(self, v: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
+    def global_transformer(self, v: torch.Tensor, a: torch.Tensor, apply_head: bool = True) -> torch.Tensor:
         """GlobalTransformer.forward (sync_model.py:150-173).  v (B, Sv, 768), a (B, Sa, 768) fp32 on device (already
-        projected) -> logits fp32 (B, n_out)."""
+        projected) -> logits fp32 (B, n_out); apply_head=False (`attempt_to_apply_heads=False`, :170-172): ln_f of every token, fp32 (B, L, 768)."""
         B, Sv, Sa = v.shape[0], v.shape[1], a.shape[1]
         L = 2 + Sv + Sa
         table = self._sync_table(Sv, Sa)
@@ -593,6 +593,10 @@ class SynchformerEngine:
         for b in self.s_blocks:   # Block.forward (modules/transformer.py:93-97)
             self._encoder_layer(X, rows, xn, big, b['ln1'], b['qkv'], full_attn, b['proj'], b['ln2'], b['fc1'], b['fc2'],
                                 EPS_SYNC)
+        if not apply_head:
+            tokens = torch.empty(rows, D, device=self.dev, dtype=torch.float32)
+            ops.layernorm(X, self.s_lnf.g, self.s_lnf.b, tokens, EPS_SYNC, rows=rows)
+            return tokens.view(B, L, D)
         cls = xn[:B]
         ops.layernorm(X, self.s_lnf.g, self.s_lnf.b, cls, EPS_SYNC, rows=B, in_map=ops.rowmap(1, 1, L, 0, 0, 0))
         logits = torch.empty(B, self.n_out, device=self.dev, dtype=torch.float32)

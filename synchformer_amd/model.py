@@ -247,8 +247,9 @@ class GlobalTransformer(torch.nn.Module):
         super().__init__()
         if n_embd != 768 or n_head != 8:
             raise NotImplementedError('native sync transformer is built for n_embd=768, n_head=8 (configs/sync.yaml:44-46)')
-        if tok_pdrop and tok_pdrop > 0:
-            raise NotImplementedError('tok_pdrop > 0 (whole-token dropout) is not used by the three configs')
+        # whole-token dropout (sync_model.py:131-134, 160-161) acts in train() mode only: the value is kept, evaluation ignores it like the reference's
+        # Dropout1d in eval(); a TRAINING forward with tok_pdrop > 0 is refused (none of the configs sets it: sync.yaml:42, ft_synchability.yaml)
+        self.tok_pdrop = float(tok_pdrop or 0.0)
         self.n_layer, self.n_head, self.n_embd = n_layer, n_head, n_embd
         self.pdrops = dict(embd_pdrop=embd_pdrop, resid_pdrop=resid_pdrop, attn_pdrop=attn_pdrop)
         n_pos = pos_emb_cfg['params']['block_shape'][0] if pos_emb_cfg is not None else 198
@@ -270,11 +271,13 @@ class GlobalTransformer(torch.nn.Module):
         _reorder_like(self, [k[len('transformer.'):] for k in schema])
 
     def forward(self, v: torch.Tensor, a: torch.Tensor, targets=None, attempt_to_apply_heads=True):
-        if not attempt_to_apply_heads:
-            raise NotImplementedError('attempt_to_apply_heads=False is only used by subclasses of the reference')
+        """sync_model.py:150-173: logits (B, n_out) - or, with attempt_to_apply_heads=False, ln_f of ALL tokens (B, 2 + Sv + Sa, 768), which is what the
+        reference's subclass asks its parent for (sync_model.py:187)."""
+        if self.training and self.tok_pdrop > 0 and torch.is_grad_enabled():
+            raise NotImplementedError('tok_pdrop > 0 in a training forward (whole-token dropout) is not built; the configs use 0.0')
         eng = _engine_for(self, 'transformer.')
         B = v.shape[0]
-        return eng.global_transformer(v.reshape(B, -1, self.n_embd).float(), a.reshape(B, -1, self.n_embd).float())
+        return eng.global_transformer(v.reshape(B, -1, self.n_embd).float(), a.reshape(B, -1, self.n_embd).float(), apply_head=bool(attempt_to_apply_heads))
 
 
 class GlobalTransformerWithSyncabilityHead(GlobalTransformer):
@@ -454,6 +457,8 @@ class Synchformer(torch.nn.Module):
             raise NotImplementedError('only Stage-2 training with frozen extractors (is_trainable: False, configs/sync.yaml:7,19) has a '
                                       'backward; requires_grad_(False) the extractors as scripts/train_utils.py:199-204 does')
         pd = getattr(self.transformer, 'pdrops', {}) if self.transformer.training else {}
+        if self.transformer.training and getattr(self.transformer, 'tok_pdrop', 0.0) > 0:
+            raise NotImplementedError('tok_pdrop > 0 in a training forward (whole-token dropout, sync_model.py:160-161) is not built; the configs use 0.0')
         if any(not p.requires_grad for p in trainable.values()):
             raise NotImplementedError('partially frozen sync transformer is not supported')
         eng = self._engine(need_sync=False)

@@ -525,6 +525,31 @@ def register_torch_ops():
     def _attn_comb_mx(partials: torch.Tensor, out_q: torch.Tensor, out_s: torch.Tensor, n_part: int, n_seq: int, out_seq_rows: int, out_row: int, heads: int) -> None:
         d_['attention_cls_combine_mx'](partials, out_q, out_s, n_part=n_part, n_seq=n_seq, out_seq_rows=out_seq_rows, out_row=out_row, heads=heads)
 
+    # Meta / FakeTensor implementations: every op is an out-variant (mutates its outputs, returns nothing), so the abstract implementation has no output
+    # to describe - it only checks what the launcher would refuse (dtype / rank of the outputs), which lets FakeTensorMode, torch.library.opcheck and
+    # torch.compile's tracing pass through these ops without touching a device.
+    def _fake(check=None):
+        def impl(*args):
+            if check is not None:
+                check(*args)
+            return None
+        return impl
+
+    def _chk_gemm(a, w, bias, out, residual, gelu):
+        n = w.shape[1] if w.dim() == 3 else w.shape[0]
+        torch._check(a.dim() == 2 and out.dim() == 2 and out.shape[0] == a.shape[0] and out.shape[1] == n, lambda: 'synchformer::gemm_bf16: out must be (M, N)')
+        torch._check(a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16, lambda: 'synchformer::gemm_bf16: bf16 operands')
+        torch._check(out.dtype in (torch.bfloat16, torch.float32), lambda: 'synchformer::gemm_bf16: out is bf16 or fp32')
+
+    def _chk_ln(x, gamma, beta, out, eps):
+        torch._check(x.shape[-1] == 768 and out.shape[-1] == 768 and x.dtype == torch.float32, lambda: 'synchformer::layernorm768: fp32 (rows, 768) in, 768 columns out')
+
+    _gemm.register_fake(_fake(_chk_gemm))
+    _ln.register_fake(_fake(_chk_ln))
+    for op_ in (_attn, _attn_cls, _im2col, _gemm_res_ln, _qkv_time, _qkv_time_mx, _attn_part, _attn_comb, _quant, _ln_mx, _gemm_mx, _gemm_mx_res_ln, _qkv_time_mx_q,
+                _attn_part_mx, _attn_comb_mx):
+        op_.register_fake(_fake())
+
     _registered = True
 
 

@@ -160,6 +160,29 @@ def test_engine_cache_key_sees_replaced_parameter_objects():
     assert m._split_keys()[1] != k2[1]
 
 
+def test_custom_ops_have_fake_implementations():
+    """the dispatcher ops carry abstract (Meta / FakeTensor) implementations, so tracing passes through them without a device."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from synchformer_amd import ops
+    ops.register_torch_ops()
+    t = torch.ops.synchformer
+    with FakeTensorMode():
+        a = torch.empty(256, 768, dtype=torch.bfloat16, device='cuda')
+        w = torch.empty(2304, 768, dtype=torch.bfloat16, device='cuda')
+        out = torch.empty(256, 2304, dtype=torch.bfloat16, device='cuda')
+        x = torch.empty(256, 768, device='cuda')
+        g = torch.empty(768, device='cuda')
+        assert t.gemm_bf16(a, w, None, out, None, False) is None
+        assert t.layernorm768(x, g, g, a, 1e-6) is None
+        assert t.gemm_res_ln768(a, torch.empty(768, 768, dtype=torch.bfloat16, device='cuda'), g, x, g, g, a, 1e-6) is None
+        with pytest.raises(RuntimeError, match='out must be'):
+            t.gemm_bf16(a, w, None, x, None, False)
+    for name in ('gemm_bf16', 'layernorm768', 'attention', 'attention_cls', 'im2col_video', 'gemm_res_ln768', 'qkv_time_attention', 'attention_cls_partial',
+                 'attention_cls_combine', 'quantize_mxfp8', 'layernorm768_mxfp8', 'gemm_mxfp8', 'gemm_mx_res_ln768', 'qkv_time_attention_mx',
+                 'qkv_time_attention_mx_q', 'attention_cls_partial_mx', 'attention_cls_combine_mx'):
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(f'synchformer::{name}', 'Meta'), name
+
+
 def test_shard_range():
     from synchformer_amd.dist import shard_range
     for n in (0, 1, 7, 16, 33):

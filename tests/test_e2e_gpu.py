@@ -182,6 +182,12 @@ def test_oracle_small(gpu):
         ol = O.global_transformer(O._lin(v, sd, 'vproj').reshape(3, -1, 768), O._lin(a, sd, 'aproj').reshape(3, -1, 768), sd)
     gl = eng.sync_transformer(v.to(gpu), a.to(gpu)).cpu()
     assert (gl - ol).abs().max().item() < 1.5e-2, (gl - ol).abs().max().item()
+    # attempt_to_apply_heads=False (sync_model.py:170-172, what GlobalTransformerWithSyncabilityHead asks its parent for, :187): ln_f of EVERY token
+    pv, pa = O._lin(v, sd, 'vproj').reshape(3, -1, 768), O._lin(a, sd, 'aproj').reshape(3, -1, 768)
+    with torch.no_grad():
+        ot = O.global_transformer(pv, pa, sd, apply_head=False)
+    gt = eng.global_transformer(pv.to(gpu), pa.to(gpu), apply_head=False).cpu()
+    assert gt.shape == ot.shape == (3, 198, 768) and _rel_rms(gt, ot) < 1.5e-2, _rel_rms(gt, ot)
 
 
 def test_chunking_invariance(gpu):
