@@ -41,7 +41,7 @@ FLOP_PER_CLIP_EXECUTED = 5.725e12 - 0.247e12 - 0.014e12
 PEAK_BF16 = 2.5e15                # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_MXFP8 = 5.0e15               # dense MX-fp8 MFMA peak
 HBM_ACHIEVABLE = 6.3e12           # achievable HBM3E stream rate (MI355X_MICROARCH.md: 6.29 TB/s measured of 8 TB/s)
-TRAFFIC_FILE = 'profiles/r03_bench_roofline.json'
+TRAFFIC_FILE = 'profiles/r04_bench_roofline.json'
 
 
 def parse():
@@ -245,13 +245,21 @@ class GemmTimer:
         return out, by
 
 
-def pmc_traffic():
-    """HBM bytes per GEMM-family launch from the committed PMC passes of this same command (tools/profile_bench.sh -> profiles/*_bench_roofline.json;
-    counters cannot be read from inside the benchmark process).  (value, source) or (None, None)."""
-    for f in (TRAFFIC_FILE, 'profiles/r02_bench_roofline.json', 'profiles/r01_bench_roofline.json'):
+def pmc_traffic(kernel=None):
+    """HBM bytes per launch from the committed PMC passes of this same command (tools/profile_bench.sh -> profiles/*_bench_roofline.json; counters cannot
+    be read from inside the benchmark process): the NAMED kernel's own FETCH_SIZE (x2, gfx950) + WRITE_SIZE when the file carries a per-kernel table
+    (r04 on), else the GEMM-family average labelled as such.  (value, source) or (None, None)."""
+    for f in (TRAFFIC_FILE, 'profiles/r03_bench_roofline.json', 'profiles/r02_bench_roofline.json', 'profiles/r01_bench_roofline.json'):
         try:
             with open(ROOT / f) as fh:
-                return round(json.load(fh)['traffic_bytes_per_launch']), f'{f} (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)'
+                d = json.load(fh)
+            norm = lambda x: x.replace(' ', '')
+            for sym, e in (d.get('per_kernel') or {}).items():
+                if kernel and norm(sym).startswith(norm(kernel)):
+                    return round(e['traffic_bytes_per_launch']), (f'{f}: counter bytes of {sym} itself, {e["launches"]} launches (static: rocprofv3 --pmc FETCH_SIZE x2 / '
+                                                                  'WRITE_SIZE passes of this command, not measured in this run)')
+            return round(d['traffic_bytes_per_launch']), (f'{f}: AVERAGE over all GEMM-family launches, not the named kernel alone (static: rocprofv3 --pmc FETCH_SIZE / '
+                                                          'WRITE_SIZE passes of this command, not measured in this run)')
         except (OSError, KeyError, ValueError):
             continue
     return None, None
@@ -432,8 +440,11 @@ def power_probe(step_fn, vis, aud, seconds=2.0):
         if not mid:
             return None
         med = lambda v: sorted(v)[len(v) // 2]
-        return {'socket_w': med([x[1] for x in mid]), 'sclk_mhz': med([x[2] for x in mid]), 'cap_w': cap, 'samples': len(mid), 'steps': n,
-                'clips_per_s': round(n * vis.shape[0] / (t1 - t0), 1), 'rocm_smi_gpu': int(gi),
+        w_med, cps = med([x[1] for x in mid]), n * vis.shape[0] / (t1 - t0)
+        return {'socket_w': w_med, 'sclk_mhz': med([x[2] for x in mid]), 'cap_w': cap, 'samples': len(mid), 'steps': n,
+                'clips_per_s': round(cps, 1), 'rocm_smi_gpu': int(gi),
+                # the step is power-limited (time = joules / cap): J/clip is the figure a kernel change has to move (track it per item)
+                'joules_per_clip': round(w_med / cps, 3),
                 'what': 'rocm-smi next to a further ~2 s of the same forward, after the timed region; dense MFMA peaks are quoted at 2400 MHz'}
     except Exception:                                                  # noqa: BLE001
         stop.set()
@@ -449,6 +460,64 @@ def roofline_of(kernels, by, name):
     peak = PEAK_MXFP8 if fam == 'mxfp8' else PEAK_BF16
     return dom, {'tflops': round(fl / (ms * 1e-3) / 1e12, 1), 'frac': round(fl / (ms * 1e-3) / peak, 4), 'launch_count': n, 'ms': ms,
                  'flop': fl, 'bytes': nb, 'peak': peak / 1e12}
+
+
+def host_leg(eng, dev, B, steps, barrier, max_over_ranks, headline_clips_per_s, world):
+    """`workloads.infer_from_host`: the same 16-clip forward fed from PINNED HOST memory - raw uint8 frames (B, 125, 3, 224, 224) and
+    16 kHz waveforms (B, 80000) fp32, i.e. what the decoder hands over BEFORE GenerateMultipleSegments / RGB normalisation / mel (dataset/transforms.py:402-499,
+    647-669, 815-889; the reference moves the already transformed batch in prepare_inputs, scripts/train_utils.py:359-369).  H2D of batch i+1 runs on a copy
+    stream under the forward of batch i (synchformer_amd.frontend.HostClipPipeline); segmenting, RGB front-end and the mel front-end run on the device INSIDE
+    the timed region.  Reported beside the HBM-resident headline, never as `value`."""
+    from synchformer_amd.frontend import HostClipPipeline, MelFrontend
+    T, n_samp = 125, 80000
+    g = torch.Generator().manual_seed(1337)
+    host = []
+    for _ in range(2):                                                     # two distinct pinned batches, alternated
+        f = torch.randint(0, 256, (B, T, 3, 224, 224), generator=g, dtype=torch.uint8).pin_memory()
+        wv = (torch.rand(B, n_samp, generator=g) * 2.0 - 1.0).pin_memory()
+        host.append((f, wv))
+    mel = MelFrontend(dev)
+    pipe = HostClipPipeline(eng, mel, B, T, n_samp)
+    nbytes = host[0][0].numel() + host[0][1].numel() * 4
+    # (a) the transfer alone
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(4):
+        pipe.frames[0].copy_(host[i & 1][0], non_blocking=True)
+        pipe.wave[0].copy_(host[i & 1][1], non_blocking=True)
+    e1.record()
+    torch.cuda.synchronize()
+    h2d_ms = e0.elapsed_time(e1) / 4
+    # (b) the pipelined step: warm-up, then exactly `steps` steps between barriers
+    pipe.stage(*host[0])
+    for i in range(2):
+        logits = pipe.step(*host[(i + 1) & 1])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        logits = pipe.step(*host[i & 1])
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    pipe.step()                                                            # drain the staged batch
+    torch.cuda.synchronize()
+    assert torch.isfinite(logits).all()
+    # (c) no overlap: transfer, then forward, on one stream
+    barrier()
+    t1 = time.perf_counter()
+    for i in range(steps):
+        pipe.frames[0].copy_(host[i & 1][0], non_blocking=True)
+        pipe.wave[0].copy_(host[i & 1][1], non_blocking=True)
+        logits = eng.forward_clips(pipe.frames[0], pipe.wave[0], mel)
+    barrier()
+    dt_serial = max_over_ranks(time.perf_counter() - t1)
+    cps = B * world * steps / dt
+    return {'metric': 'clips/sec (14-seg offset pred), inputs in pinned host memory', 'clips_per_gpu': B, 'steps': steps,
+            'clips_per_s': round(cps, 3), 'ms_per_step': round(1e3 * dt / steps, 3), 'ratio_to_hbm_resident_headline': round(cps / headline_clips_per_s, 4),
+            'h2d_bytes_per_clip': nbytes // B, 'h2d_alone_ms_per_batch': round(h2d_ms, 3), 'h2d_GBps': round(nbytes / h2d_ms / 1e6, 1),
+            'unpipelined_clips_per_s': round(B * world * steps / dt_serial, 3),
+            'what': 'uint8 frames (B,125,3,224,224) + fp32 waveforms (B,80000) in pinned host buffers; H2D on a copy stream double-buffered against compute; '
+                    'segmenting + RGB normalisation + log-mel on the device inside the timed region (HostClipPipeline -> engine.forward_clips)'}
 
 
 def run_steps(w, steps, barrier, world, dist):
@@ -591,7 +660,7 @@ def main():
                 out['power'] = pw
         if kernels:
             dom, agg = roofline_of(kernels, by, name)
-            traffic, tsrc = pmc_traffic() if name == 'infer' else (None, None)
+            traffic, tsrc = pmc_traffic(dom['name']) if name == 'infer' else (None, None)
             out['roofline'] = {
                 'bound': dom['bound'], 'kernel': dom['name'], 'achieved': dom['tflops'] if dom['bound'] == 'mfma' else dom['algorithmic_TBps'],
                 'peak': (agg['peak'] if dom['bound'] == 'mfma' else 8.0), 'unit': 'TFLOP/s' if dom['bound'] == 'mfma' else 'TB/s',
@@ -623,9 +692,17 @@ def main():
                     emit()
                 os._exit(0)
         threading.Thread(target=watchdog, daemon=True).start()
+        wl_out = {}
+        try:
+            hl = host_leg(w['eng'], dev, B, max(args.workload_steps, 3), barrier, max_over_ranks, value, world)
+            if rank == 0:
+                wl_out['infer_from_host'] = hl
+        except Exception as ex:                                    # noqa: BLE001 - reported in the line, the headline number stands
+            if world > 1:
+                raise
+            wl_out['infer_from_host'] = {'error': f'{type(ex).__name__}: {ex}'[:300]}
         del w, step_fn, logits
         torch.cuda.empty_cache()
-        wl_out = {}
         for wn in ('train', 'stage1', 'ft'):
             try:
                 ww = build_workload(wn, args, dev, rank, world, local)

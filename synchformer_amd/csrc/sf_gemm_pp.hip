@@ -61,6 +61,31 @@ __device__ __forceinline__ void pp_dma2(uint32_t v0, uint32_t v1, const void* sb
       : "v"(v0), "v"(v1), "s"(sbase), "s"(l0)
       : "memory", "scc");
 }
+// the same with a cache-policy suffix on the two loads (measurement builds: -DSF_PP_A_POLN=1 streams the A panels through L2 without displacing the
+// chunk's weight slice; " sc1" / " sc0 sc1" = the other policies of the instruction)
+#ifndef SF_PP_A_POLN
+#define SF_PP_A_POLN 0                 // 0 default policy | 1 nt | 2 sc1 | 3 sc0 sc1
+#endif
+#if SF_PP_A_POLN == 1
+#define SF_PP_A_POL " nt"
+#elif SF_PP_A_POLN == 2
+#define SF_PP_A_POL " sc1"
+#elif SF_PP_A_POLN == 3
+#define SF_PP_A_POL " sc0 sc1"
+#else
+#define SF_PP_A_POL ""
+#endif
+__device__ __forceinline__ void pp_dma2_a(uint32_t v0, uint32_t v1, const void* sbase, uint32_t l0) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %4\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %3" SF_PP_A_POL "\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3" SF_PP_A_POL "\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(v0), "v"(v1), "s"(sbase), "s"(l0)
+      : "memory", "scc");
+}
 // one 256-byte piece: 64 lanes x 4 bytes (the wave's 64 bias values) to the wave-uniform LDS byte address l0
 __device__ __forceinline__ void pp_dma_row256(const void* gsrc, uint32_t l0) {
   uint32_t keep;
@@ -179,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
       const uint32_t real = lds_wave + ST * Q_STAGE + (isA ? h : 2 + h) * Q_HALF;
       const uint32_t l = ld_ok ? real : slab_dummy;
       if ((SF_PP_ABL & 2) && !decltype(SUREc)::value) {}
-      else if (isA) pp_dma2(oA[h][0], oA[h][1], curA, l);
+      else if (isA) pp_dma2_a(oA[h][0], oA[h][1], curA, l);
       else pp_dma2(oW[h][0], oW[h][1], curW, l);
       if (PART == 3 && ld_ok) {
         if (++ld_kt == nk) {

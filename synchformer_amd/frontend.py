@@ -105,3 +105,72 @@ class MelFrontend:
                                                torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, 'sf_mel_frontend_clips')
         return out.reshape(B, n_seg, 1, self.n_mels, self.pad_to)
+
+
+class HostClipPipeline:
+    """Raw clips from HOST memory to logits, with the host-to-device transfer of batch i+1 overlapped with the forward of batch i.
+
+    The reference's step starts at `prepare_inputs` (scripts/train_utils.py:359-369: `batch['video']` / `batch['audio']` -> device) behind a CPU
+    DataLoader that has already segmented, normalised and mel-transformed the clip (dataset/transforms.py:402-499, 647-669, 815-889).  Here the host
+    hands over what the decoder produced - uint8 frames (B, T, 3, 224, 224) and the 16 kHz waveform (B, n_samples) fp32 - in PINNED buffers; the
+    transfer runs on a copy stream into one of two device slots while the compute stream works on the other (`engine.forward_clips`: segments read
+    in place, RGB normalisation inside the patch gather, log-mel on the device).  The 50 %-overlapping segments are never materialised, so a 14-segment
+    clip crosses PCIe as 125 frames (18.8 MB) instead of 224 (33.7 MB as uint8, 67.4 MB as the reference's fp16).
+
+        pipe = HostClipPipeline(engine, MelFrontend(dev), B, T, n_samples)
+        pipe.stage(frames0, wave0)                      # batch 0 starts moving
+        for next_frames, next_wave in batches[1:]:
+            logits = pipe.step(next_frames, next_wave)  # forward of the staged batch || H2D of the next one
+        logits = pipe.step()                            # last batch
+    The logits of a step are valid on the compute (= current) stream; a slot is overwritten only after the forward that read it has finished
+    (event hand-off in both directions, no host synchronisation inside step())."""
+
+    def __init__(self, engine, mel: 'MelFrontend', B: int, T: int = 125, n_samples: int = 80000, H: int = 224, W: int = 224, **segment_kw):
+        self.eng, self.mel, self.dev = engine, mel, engine.dev
+        self.segment_kw = segment_kw
+        self.frames = [torch.empty(B, T, 3, H, W, device=self.dev, dtype=torch.uint8) for _ in range(2)]
+        self.wave = [torch.empty(B, n_samples, device=self.dev, dtype=torch.float32) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=self.dev)
+        self.loaded = [torch.cuda.Event(), torch.cuda.Event()]             # H2D into slot i done (recorded on the copy stream)
+        self.released = [torch.cuda.Event(), torch.cuda.Event()]           # forward reading slot i done (recorded on the compute stream)
+        self._fresh = [True, True]                                         # slot never read yet: nothing to wait for
+        self._staged = None                                                # slot holding the batch the next step() consumes
+        self._next = 0
+
+    @staticmethod
+    def pinned_like(frames: torch.Tensor, wave: torch.Tensor):
+        """Pinned host copies of a batch (what a DataLoader with pin_memory=True hands over)."""
+        return frames.contiguous().pin_memory(), wave.to(torch.float32).contiguous().pin_memory()
+
+    def stage(self, frames_host: torch.Tensor, wave_host: torch.Tensor):
+        """Start the transfer of one batch into the free slot (non-blocking for pinned sources)."""
+        if self._staged is not None and self._next == self._staged:
+            raise RuntimeError('HostClipPipeline: both slots are in use - call step() before staging another batch')
+        if frames_host.shape != self.frames[0].shape or wave_host.shape != self.wave[0].shape or frames_host.dtype != torch.uint8:
+            raise ValueError(f'HostClipPipeline: expected uint8 frames {tuple(self.frames[0].shape)} and fp32 wave {tuple(self.wave[0].shape)}')
+        i = self._next
+        with torch.cuda.stream(self.copy_stream):
+            if not self._fresh[i]:
+                self.copy_stream.wait_event(self.released[i])              # the forward that last read this slot
+            self.frames[i].copy_(frames_host, non_blocking=True)
+            self.wave[i].copy_(wave_host, non_blocking=True)
+            self.loaded[i].record(self.copy_stream)
+        if self._staged is None:
+            self._staged = i
+        self._next = i ^ 1
+
+    def step(self, next_frames_host: torch.Tensor = None, next_wave_host: torch.Tensor = None) -> torch.Tensor:
+        """Forward of the staged batch; if a next batch is given its transfer is issued FIRST so that it runs under this forward."""
+        if self._staged is None:
+            raise RuntimeError('HostClipPipeline: nothing staged')
+        i = self._staged
+        if next_frames_host is not None:
+            self._next = i ^ 1
+            self.stage(next_frames_host, next_wave_host)
+        main = torch.cuda.current_stream(self.dev)
+        main.wait_event(self.loaded[i])
+        logits = self.eng.forward_clips(self.frames[i], self.wave[i], self.mel, **self.segment_kw)
+        self.released[i].record(main)
+        self._fresh[i] = False
+        self._staged = (i ^ 1) if next_frames_host is not None else None
+        return logits

@@ -133,6 +133,40 @@ def make_spectrogram(B: int, S: int = 14, seed: int = 1337, F: int = 128, Ta: in
     return torch.from_numpy(0.5 * g.standard_normal(size=(B, S, 1, F, Ta), dtype=np.float32))
 
 
+def make_structured_clip(c: int, S: int = 14, seed: int = 1337, T: int = 16, H: int = 224, W: int = 224, F: int = 128, Ta: int = 66):
+    """Clip `c` of a synthetic evaluation set whose clips DIFFER in structure (the U{0..255} noise clips of make_video_u8 are statistically identical, so
+    every clip lands on nearly the same logits): per clip a patch-level colour field (14 x 14 blocks of 16 x 16 pixels) that drifts over the frames at
+    clip-specific rates, under pixel noise of a clip-specific amplitude; the spectrogram carries clip-specific ridges (a band of mel bins pulsing with a
+    clip-specific period and phase) over noise.  Video values come from integer arithmetic on Philox draws only, the spectrogram from float32 adds /
+    multiplies of Philox normals: bit-reproducible wherever numpy is (the fixtures hold the reference's outputs for exactly these tensors).
+    -> (vis (S, T, 3, H, W) uint8, aud (S, 1, F, Ta) fp32)."""
+    g = _rng(seed, f'sclip{c}')
+    gh, gw = H // 16, W // 16
+    amp = int(g.integers(8, 97))
+    base = g.integers(0, 256, size=(3, gh, gw), dtype=np.int64)
+    drift = g.integers(-6, 7, size=(3, gh, gw), dtype=np.int64)
+    seg_step = int(g.integers(1, 9))
+    t_idx = (np.arange(S, dtype=np.int64)[:, None] * 8 + np.arange(T, dtype=np.int64)[None, :])                 # absolute frame index (50 % overlapping segments)
+    field = (base[None, None] + drift[None, None] * (t_idx[:, :, None, None, None] * seg_step // 4)) % 256      # (S, T, 3, gh, gw)
+    field = np.repeat(np.repeat(field.astype(np.int16), 16, axis=3), 16, axis=4)
+    noise = g.integers(-amp, amp + 1, size=(S, T, 3, H, W), dtype=np.int16)
+    noise += field
+    vis = np.clip(noise, 0, 255, out=noise).astype(np.uint8)
+    spec = (0.35 * g.standard_normal(size=(S, 1, F, Ta), dtype=np.float32)).astype(np.float32)
+    f0, bw = int(g.integers(0, F - 24)), int(g.integers(6, 24))
+    period, phase = int(g.integers(3, 17)), int(g.integers(0, 16))
+    level = np.float32(0.5 + 0.125 * int(g.integers(0, 9)))
+    cols = ((np.arange(S, dtype=np.int64)[:, None] * 32 + np.arange(Ta, dtype=np.int64)[None, :] + phase) % period) < max(1, period // 3)   # (S, Ta)
+    spec[:, 0, f0:f0 + bw, :] += level * cols[:, None, :].astype(np.float32)
+    return torch.from_numpy(vis), torch.from_numpy(spec)
+
+
+def make_structured_clips(c0: int, n: int, S: int = 14, seed: int = 1337):
+    """Clips c0 .. c0 + n - 1 of the structured evaluation set: (vis (n, S, 16, 3, 224, 224) uint8, aud (n, S, 1, 128, 66) fp32)."""
+    clips = [make_structured_clip(c, S, seed) for c in range(c0, c0 + n)]
+    return torch.stack([v for v, _ in clips]), torch.stack([a for _, a in clips])
+
+
 def make_masks(B: int, S: int = 14, seed: int = 1337, T: int = 16, H: int = 224, W: int = 224, F: int = 128, Ta: int = 66):
     """Deterministic content masks for Synchformer.forward(vis_mask=, aud_mask=) (True = kept): per segment a few boxes that are NOT
     aligned to the 16-pixel patch grid and span some frames (all channels), plus isolated single elements - those exercise the

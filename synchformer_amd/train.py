@@ -128,6 +128,9 @@ class FlatTrainer:
         self.tn_wgrad = os.environ.get('SF_TN_WGRAD', '1') != '0'      # weight gradients straight from row-major operands (sf_gemm_tn_splitk)
         self.tn_pp = os.environ.get('SF_TN_PP', '1') != '0'            # ... the big ones on the quadrant-phased 256 x 256 kernel (sf_gemm_tn_pp)
         self.n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count if torch.cuda.is_available() else 256
+        # SF_WGRAD_SIDE=1: the big weight gradients next to their dgrad on a low-priority side stream (one per workspace prefix = per tower stream), _lin_bwd
+        self.wgrad_side = os.environ.get('SF_WGRAD_SIDE', '0') != '0'
+        self._wgrad_streams: Dict[str, tuple] = {}
         self.norm = torch.zeros(1, device=self.dev, dtype=torch.float32)
         self.loss = torch.zeros(1, device=self.dev, dtype=torch.float32)
         self._ws: Dict[str, torch.Tensor] = {}
@@ -217,8 +220,28 @@ class FlatTrainer:
             sp = max(1, self.n_cu // t256)
             kc2 = ((M + sp - 1) // sp + 127) // 128 * 128
             sp = (M + kc2 - 1) // kc2
+            want_b = dy_f32 is None and not bias_done
+            if self.wgrad_side and need_dx:
+                # dgrad and wgrad of one Linear are independent: the dgrad goes FIRST on the compute stream - with two clips its N = 768 grid is 516 tiles = 2.016
+                # rounds of the 256 CUs, so its third round leaves the chip nearly empty - and the weight gradient (one round of chunk items + its reduction) runs
+                # NEXT TO it on a low-priority side stream, filling the CUs the dgrad's workgroups leave.  The compute stream waits for the side stream before
+                # anything else is launched, so every later kernel (and every gradient-bucket hook) sees g[W] / g[b] final and no workspace is overwritten early.
+                main = torch.cuda.current_stream(self.dev)
+                ws, ev_in, ev_out = self._wgrad_stream()
+                ev_in.record(main)
+                dx = self._lin_dgrad(dy_b, M, N, K, wkey, need_dx, dx_out, tag, acc_dx, dx_dtype)
+                with torch.cuda.stream(ws):
+                    ws.wait_event(ev_in)
+                    part = self._buf('wgrad_part_s', (sp * N, K), torch.float32)        # (allocated under the side stream: its own blocks)
+                    bpart = self._buf('bgrad_part_s', (sp, N), torch.float32) if want_b else None
+                    _chk(_lib.load().sf_gemm_tn_pp(dy_b.data_ptr(), dy_b.stride(0), x_b.data_ptr(), x_b.stride(0), part.data_ptr(),
+                                                   bpart.data_ptr() if bpart is not None else None, M, N, K, sp, kc2, _st()), 'sf_gemm_tn_pp')
+                    self._wgrad_sum(part, bpart, sp, N, K, wkey, bkey, acc_bias)
+                    ev_out.record(ws)
+                main.wait_event(ev_out)
+                return dx
             part = self._buf('wgrad_part', (sp * N, K), torch.float32)
-            bpart = self._buf('bgrad_part', (sp, N), torch.float32) if dy_f32 is None and not bias_done else None
+            bpart = self._buf('bgrad_part', (sp, N), torch.float32) if want_b else None
             _chk(_lib.load().sf_gemm_tn_pp(dy_b.data_ptr(), dy_b.stride(0), x_b.data_ptr(), x_b.stride(0), part.data_ptr(),
                                            bpart.data_ptr() if bpart is not None else None, M, N, K, sp, kc2, _st()), 'sf_gemm_tn_pp')
             self._wgrad_sum(part, bpart, sp, N, K, wkey, bkey, acc_bias)
@@ -246,6 +269,13 @@ class FlatTrainer:
         else:
             ops.gemm(dyT, xT, None, self.g[wkey].view(N, K), M=N)
         return self._lin_dgrad(dy_b, M, N, K, wkey, need_dx, dx_out, tag, acc_dx, dx_dtype)
+
+    def _wgrad_stream(self):
+        t = self._wgrad_streams.get(self._ws_prefix)
+        if t is None:
+            prio = int(os.environ.get('SF_WGRAD_PRIO', '1'))              # lower priority than the compute stream (clamped to the device's range by torch)
+            t = self._wgrad_streams[self._ws_prefix] = (torch.cuda.Stream(device=self.dev, priority=prio), torch.cuda.Event(), torch.cuda.Event())
+        return t
 
     def _wgrad_sum(self, part, bpart, split, N, K, wkey, bkey, acc_bias):
         """g[W] = sum of the split-K chunk planes, g[b] (=|+=) sum of the bias partials - one launch (sf_wgrad_sum)."""

@@ -6,6 +6,7 @@ Inputs and weights are regenerated from seeds by `synchformer_amd.synth` (numpy 
 so the fixtures hold only seeds + expected OUTPUTS (data, not reference source).  The reference cannot
 travel to the GPU box; these files can.
 """
+import os
 import sys
 from pathlib import Path
 
@@ -416,6 +417,40 @@ def e2e_masked(B=1, S=2, gain=2.0):
     print('masked logits', logits, 'unmasked', logits_nomask, 'max diff', float((logits - logits_nomask).abs().max()))
 
 
+LOGITS_HEAD_SCALE = 5.0   # 'trained' variant: off_head.weight x this on top of gain-2 weights -> top logit ~ 10 like the released model's (README.md:79)
+
+
+def logits_state_dict(variant):
+    """The two inits of the logits_only fixture: 'gain1' = the reference-like init scale of the other fixtures; 'trained' = gain-2 weights with the offset
+    head scaled so that the logits have the scale of a TRAINED model (top logit ~ 10-12, README.md:79) and clips of different content land on
+    different classes with trained-size margins.  tests/test_e2e_gpu.py rebuilds the same dict on the GPU box."""
+    if variant == 'gain1':
+        return synth.make_state_dict(SEED)
+    sd = synth.make_state_dict(SEED, gain=2.0)
+    sd['transformer.off_head.weight'] = sd['transformer.off_head.weight'] * LOGITS_HEAD_SCALE
+    return sd
+
+
+def logits_only(n_clips=32, per=2, variants=('gain1', 'trained')):
+    """Acc@1-parity proxy at scale: `n_clips` STRUCTURED clips (synth.make_structured_clips: clips differ in content) through the REAL
+    reference, logits only (n_clips x 21 floats per variant), at the reference-like init AND at a trained-scale init.  The GPU test asserts max |dlogit|,
+    100 % argmax agreement and the +-1-class agreement of calc_cls_metrics (scripts/train_utils.py:632)."""
+    out = dict(seed=np.int64(SEED), n_clips=np.int64(n_clips), head_scale=np.float64(LOGITS_HEAD_SCALE))
+    for variant in variants:
+        model = ref_import.build_reference_synchformer()
+        model.load_state_dict(logits_state_dict(variant), strict=True)
+        model.eval()
+        rows = []
+        for c0 in range(0, n_clips, per):
+            u8, aud = synth.make_structured_clips(c0, min(per, n_clips - c0), 14, SEED)
+            with torch.no_grad():
+                _, logits = model(rgb_frontend_ref(u8).float(), aud)
+            rows.append(logits.numpy())
+            print(variant, c0, logits.argmax(1).tolist(), logits.max(1).values.tolist(), flush=True)
+        out['logits_' + variant] = np.concatenate(rows, 0)
+    np.savez_compressed(HERE / f'logits_only_{n_clips}.npz', **out)
+
+
 def checkpoints():
     """what the REAL reference constructors hold after reading the synthetic checkpoint files of ckpt_fixtures.py -
     `MotionFormer(ckpt_path='...epoch_best.pt')` (motionformer.py:52-80, 156-173), `AST(ckpt_path='...epoch_best.pt')` (ast.py:58-60, 113-131) and
@@ -497,3 +532,5 @@ if __name__ == '__main__':
         e2e_masked(1, 2)
     if 'checkpoints' in which:
         checkpoints()
+    if 'logits_only' in which:                                            # ~25 min of CPU (64 reference forwards); not in the default list
+        logits_only(int(os.environ.get('N_CLIPS', '32')))

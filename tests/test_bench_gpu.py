@@ -45,10 +45,13 @@ def test_bench_two_ranks_all_workloads(gpu, backend):
     d = _run_bench(*extra)
     _check_headline(d, backend)
     assert 'workloads_error' not in d, d.get('workloads_error')
-    assert set(d['workloads']) == {'train', 'stage1', 'ft'}
+    assert set(d['workloads']) == {'infer_from_host', 'train', 'stage1', 'ft'}
     for name, w in d['workloads'].items():
         assert 'error' not in w, f'{name}: {w.get("error")}'
         assert w['clips_per_s'] > 0 and w['ms_per_step'] > 0
+        if name == 'infer_from_host':                                         # pinned host inputs, H2D under compute: a ratio to the HBM-resident headline
+            assert 0 < w['ratio_to_hbm_resident_headline'] < 1.5 and w['h2d_bytes_per_clip'] == 125 * 3 * 224 * 224 + 80000 * 4
+            continue
         comm = w['comm_exposed_ms_last_step_by_rank']                         # HIP events around the gradient-bucket waits, one entry per rank
         assert len(comm) == 2 and all(c >= 0 for c in comm), (name, comm)
 

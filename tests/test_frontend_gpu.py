@@ -56,3 +56,35 @@ def test_device_side_segmenting_matches_host_slicing(gpu):
     assert torch.equal(ref, got)
     with pytest.raises(RuntimeError, match='do not fit'):
         mel.segments(wave[:, :70000].to(gpu), r['a_start'], r['a_stride'], 14, r['a_size'])
+
+
+def test_host_clip_pipeline_equals_direct_forward(gpu):
+    """HostClipPipeline (pinned host buffers -> copy stream -> two device slots -> forward_clips) returns, batch after batch, exactly what forward_clips returns
+    on the same clips uploaded by hand - including when a slot is reused (the third batch overwrites the first one's slot only after its forward)."""
+    from synchformer_amd import synth
+    from synchformer_amd.engine import SynchformerEngine
+    from synchformer_amd.frontend import HostClipPipeline, MelFrontend
+    eng = SynchformerEngine(synth.make_state_dict(1337, gain=2.0), gpu, seg_chunk=28)
+    mel = MelFrontend(gpu)
+    B, T, n_samp = 2, 125, 80000
+    g = torch.Generator().manual_seed(11)
+    batches = [HostClipPipeline.pinned_like(torch.randint(0, 256, (B, T, 3, 224, 224), generator=g, dtype=torch.uint8),
+                                            torch.rand(B, n_samp, generator=g) * 2 - 1) for _ in range(4)]
+    want = [eng.forward_clips(f.to(gpu), w.to(gpu), mel).clone() for f, w in batches]
+    assert not torch.equal(want[0], want[1])
+    pipe = HostClipPipeline(eng, mel, B, T, n_samp)
+    pipe.stage(*batches[0])
+    got = []
+    for i in range(4):
+        nxt = batches[i + 1] if i + 1 < 4 else (None, None)
+        got.append(pipe.step(*nxt).clone())
+    torch.cuda.synchronize()
+    for i in range(4):
+        assert torch.equal(got[i], want[i]), i
+    with pytest.raises(RuntimeError, match='nothing staged'):
+        pipe.step()
+    pipe.stage(*batches[0]); pipe.stage(*batches[1])
+    with pytest.raises(RuntimeError, match='both slots'):
+        pipe.stage(*batches[2])
+    with pytest.raises(ValueError, match='expected uint8'):
+        HostClipPipeline(eng, mel, B, T, n_samp).stage(batches[0][0][:1], batches[0][1])

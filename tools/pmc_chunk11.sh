@@ -1,0 +1,25 @@
+#!/bin/bash
+# GPU box: config-11 GEMM shapes under different column-chunk sweeps (SF_GEMM_NCHUNK): time + FETCH_SIZE (x2) + L2 hit.  CHUNKS="0 3 4 5 6 7 8"
+R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
+cd /tmp && export TMPDIR=/tmp
+export CFGS=11 KMAJOR=0 SHAPES=${SHAPES:-qkv,fc1+gelu}
+for c in ${CHUNKS:-0 3 4 5 6 7 8}; do
+  echo "=== SF_GEMM_NCHUNK=$c"
+  SF_GEMM_NCHUNK=$c ROUNDS=3 ITERS=20 python $R/tools/bench_gemm.py 224 2>&1 | grep " N "
+  for grp in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+    rm -rf /tmp/abf
+    SF_GEMM_NCHUNK=$c ROUNDS=1 ITERS=4 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/abf -o f -- python $R/tools/bench_gemm.py 224 > /tmp/abf.log 2>&1
+    f=$(find /tmp/abf -name '*counter_collection.csv' | head -1)
+    python - "$f" <<'PY'
+import csv, sys, collections
+tot = collections.defaultdict(float); n = collections.Counter()
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r['Kernel_Name'].split('(')[0].replace('void ', '')[:64]
+    if 'gemm' not in k: continue
+    tot[(k, r['Counter_Name'])] += float(r['Counter_Value']); n[(k, r['Counter_Name'])] += 1
+for k in sorted({k for k, _ in tot}):
+    if (k, 'FETCH_SIZE') in tot: print(f'  {k}: fetch x2 {tot[(k, "FETCH_SIZE")] * 2 / 1024 / n[(k, "FETCH_SIZE")]:.0f} MiB/launch')
+    if (k, 'TCC_HIT_sum') in tot: print(f'  {k}: L2 hit {100 * tot[(k, "TCC_HIT_sum")] / (tot[(k, "TCC_HIT_sum")] + tot[(k, "TCC_MISS_sum")]):.1f} %')
+PY
+  done
+done

@@ -43,7 +43,7 @@ if bench:
 lines += ['| kernel | calls | total ms | avg us | % |', '|---|---|---|---|---|']
 for r in stats[:16]:
     lines.append(f'| `{short(r["Name"])}` | {r["Calls"]} | {float(r["TotalDurationNs"]) / 1e6:.1f} | {float(r["AverageNs"]) / 1e3:.1f} | {float(r["Percentage"]):.1f} |')
-gem = [r for r in stats if 'gemm_bf16' in r['Name'] or 'gemm_res_ln768' in r['Name'] or 'qkv_time_attn' in r['Name']]
+gem = [r for r in stats if 'gemm_bf16' in r['Name'] or 'gemm_res_ln768' in r['Name'] or 'qkv_time_attn' in r['Name'] or 'qkv_space_attn' in r['Name']]
 if gem:
     calls_g = sum(int(r['Calls']) for r in gem)
     tot_g = sum(float(r['TotalDurationNs']) for r in gem) / 1e6
@@ -66,13 +66,17 @@ for k, c in sorted(pmc.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE', 0))
     bank = 100 * c.get('SQ_LDS_BANK_CONFLICT', 0) / max(c.get('SQ_LDS_IDX_ACTIVE', 0), 1)
     lines.append(f'| `{k[:70]}` | {n} | {fetch:.0f} | {write:.0f} | {mfma:.1f} | {wait:.1f} | {hit:.1f} | {bank:.1f} |')
 # HBM traffic of the roofline kernel (all sf_gemm_bf16 launches), per launch: FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, KiB -> bytes
-gk = [(k, c) for k, c in pmc.items() if ('gemm_bf16' in k or 'gemm_res_ln768' in k or 'qkv_time_attn' in k) and calls[k]]
+gk = [(k, c) for k, c in pmc.items() if ('gemm_bf16' in k or 'gemm_res_ln768' in k or 'qkv_time_attn' in k or 'qkv_space_attn' in k) and calls[k]]
 if gk:
     n_l = sum(calls[k] for k, _ in gk)
     fetch_b = sum(c.get('FETCH_SIZE', 0) for _, c in gk) * 2 * 1024
     write_b = sum(c.get('WRITE_SIZE', 0) for _, c in gk) * 1024
+    # per kernel symbol (the name rocprofv3 prints = the name bench.py files its live timings under): bench.py attaches the NAMED kernel's own counter bytes
+    # to `roofline.traffic`, not the family average
+    per = {k: {'launches': calls[k], 'hbm_read_bytes_per_launch': c.get('FETCH_SIZE', 0) * 2 * 1024 / calls[k], 'hbm_write_bytes_per_launch': c.get('WRITE_SIZE', 0) * 1024 / calls[k],
+               'traffic_bytes_per_launch': (c.get('FETCH_SIZE', 0) * 2 + c.get('WRITE_SIZE', 0)) * 1024 / calls[k]} for k, c in gk}
     roof = {'kernel': 'sf_gemm_bf16 + sf_gemm_res_ln768 + sf_qkv_time_attention (all launches)', 'launches_profiled': n_l, 'hbm_read_bytes_per_launch': fetch_b / n_l,
-            'hbm_write_bytes_per_launch': write_b / n_l, 'traffic_bytes_per_launch': (fetch_b + write_b) / n_l,
+            'hbm_write_bytes_per_launch': write_b / n_l, 'traffic_bytes_per_launch': (fetch_b + write_b) / n_l, 'per_kernel': per,
             'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_bench.sh (FETCH_SIZE x2 per MI355X_MICROARCH.md)'}
     Path(f'{dst}_roofline.json').write_text(json.dumps(roof, indent=1) + '\n')
     lines += ['', f'HBM traffic of the `sf_gemm_bf16` launches from the PMC passes: {fetch_b / n_l / 1e6:.0f} MB read (x2-corrected) + '
