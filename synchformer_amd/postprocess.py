@@ -45,3 +45,25 @@ def topk_offsets(off_logits: torch.Tensor, grid: torch.Tensor, k: int = 5) -> Li
     k = min(logits.shape[-1], k)
     top_logits, top_idx = torch.topk(logits, k)
     return [[(float(probs[b, i]), float(top_logits[b, j]), float(grid[i]), int(i)) for j, i in enumerate(top_idx[b])] for b in range(logits.shape[0])]
+
+
+def offset_accuracy(targets: torch.Tensor, logits: torch.Tensor, topk=(1, 5)) -> dict:
+    """The accuracy figures of the reference's `calc_cls_metrics` (scripts/train_utils.py:632-705) that define the benchmark's "Acc@1":
+    `accuracy_k` = target among the k largest logits, and `accuracy_k_tol1` = target, target - 1 or target + 1 (clamped to the class range: an offset
+    one 0.2 s grid step away counts, README.md:109-111) among the k largest.  (The mAP / ROC-AUC / d-prime part of that function is dataset
+    statistics, not part of the path.)  targets (n,) int, logits (n, C) -> {'accuracy_1': .., 'accuracy_1_tol1': .., ...}."""
+    logits = logits.detach().float().cpu()
+    targets = targets.detach().long().cpu()
+    if logits.dim() != 2 or targets.shape != logits.shape[:1]:
+        raise ValueError(f'expected (n, C) logits and (n,) targets, got {tuple(logits.shape)} / {tuple(targets.shape)}')
+    n, c = logits.shape
+    ks = [min(k, c) for k in topk]
+    preds = torch.topk(logits, k=max(ks), dim=1).indices                              # (n, kmax), best first (train_utils.py:665)
+    t = targets.unsqueeze(-1).expand_as(preds)
+    hit = preds == t
+    hit_tol = hit | (preds == (t - 1).clamp(0, c - 1)) | (preds == (t + 1).clamp(0, c - 1))   # (train_utils.py:694-698)
+    out = {}
+    for k in ks:
+        out[f'accuracy_{k}'] = float(hit[:, :k].any(dim=1).sum()) / max(n, 1)
+        out[f'accuracy_{k}_tol1'] = float(hit_tol[:, :k].any(dim=1).sum()) / max(n, 1)
+    return out

@@ -436,17 +436,25 @@ def logits_only(n_clips=32, per=2, variants=('gain1', 'trained')):
     reference, logits only (n_clips x 21 floats per variant), at the reference-like init AND at a trained-scale init.  The GPU test asserts max |dlogit|,
     100 % argmax agreement and the +-1-class agreement of calc_cls_metrics (scripts/train_utils.py:632)."""
     out = dict(seed=np.int64(SEED), n_clips=np.int64(n_clips), head_scale=np.float64(LOGITS_HEAD_SCALE))
+    part = Path(os.environ.get('LOGITS_PARTIAL', '/tmp/logits_only_partial.npz'))          # resumable: ~1.3 min of CPU per reference forward
+    done = dict(np.load(part)) if part.exists() else {}
     for variant in variants:
-        model = ref_import.build_reference_synchformer()
-        model.load_state_dict(logits_state_dict(variant), strict=True)
-        model.eval()
+        model = None
         rows = []
         for c0 in range(0, n_clips, per):
-            u8, aud = synth.make_structured_clips(c0, min(per, n_clips - c0), 14, SEED)
-            with torch.no_grad():
-                _, logits = model(rgb_frontend_ref(u8).float(), aud)
-            rows.append(logits.numpy())
-            print(variant, c0, logits.argmax(1).tolist(), logits.max(1).values.tolist(), flush=True)
+            key = f'{variant}_{c0}'
+            if key not in done:
+                if model is None:
+                    model = ref_import.build_reference_synchformer()
+                    model.load_state_dict(logits_state_dict(variant), strict=True)
+                    model.eval()
+                u8, aud = synth.make_structured_clips(c0, min(per, n_clips - c0), 14, SEED)
+                with torch.no_grad():
+                    _, logits = model(rgb_frontend_ref(u8).float(), aud)
+                done[key] = logits.numpy()
+                np.savez(part, **done)
+            rows.append(done[key])
+            print(variant, c0, rows[-1].argmax(1).tolist(), rows[-1].max(1).tolist(), flush=True)
         out['logits_' + variant] = np.concatenate(rows, 0)
     np.savez_compressed(HERE / f'logits_only_{n_clips}.npz', **out)
 
