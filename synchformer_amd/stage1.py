@@ -759,6 +759,8 @@ class AVCLIPTrainFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, trainer: AVCLIPTrainer, vis, aud, *params):
         ctx.trainer = trainer
+        ctx.fwd_count0 = trainer.fwd_count
+        ctx.save_for_backward(vis, aud)
         loss = trainer.forward_backward(vis, aud).clone()
         trainer.generation = ctx.generation = getattr(trainer, 'generation', 0) + 1
         return loss
@@ -767,7 +769,13 @@ class AVCLIPTrainFunction(torch.autograd.Function):
     def backward(ctx, gout):
         tr = ctx.trainer
         if ctx.generation != tr.generation:
-            # the gradients live in the trainer's ONE flat buffer: a later grad-enabled forward has overwritten them
-            raise RuntimeError('AVCLIP: backward() of a loss whose gradients were overwritten by a later grad-enabled forward of the same '
-                               'module; call backward() before the next forward (or run that forward under torch.no_grad())')
+            # The gradients live in the trainer's ONE flat buffer and a later grad-enabled forward of the same module has overwritten them (forward, forward,
+            # backward, backward).  The step is re-run from the kept inputs under the same stochastic-depth masks (counter restored) - the price of that call
+            # pattern is one more forward + backward; the usual forward -> backward order never takes this branch.
+            vis, aud = ctx.saved_tensors
+            keep = tr.fwd_count
+            tr.fwd_count = ctx.fwd_count0
+            tr.forward_backward(vis, aud)
+            tr.fwd_count = keep
+            tr.generation += 1
         return (None, None, None) + tuple(tr.g[k] * gout for k in tr.keys)

@@ -601,6 +601,8 @@ class SyncTrainFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, trainer: SyncTrainer, vfeat, afeat, *params):
         ctx.trainer = trainer
+        ctx.fwd_count0 = trainer.fwd_count                         # the dropout masks of this pass are a function of (seed, this counter, site)
+        ctx.save_for_backward(vfeat, afeat)                        # (B, S, t, 768) frozen features: a few MB - kept for a recomputation, see backward
         logits = trainer._forward(vfeat, afeat).clone()
         trainer.generation = ctx.generation = getattr(trainer, 'generation', 0) + 1
         return logits
@@ -609,8 +611,14 @@ class SyncTrainFunction(torch.autograd.Function):
     def backward(ctx, dlogits):
         tr = ctx.trainer
         if ctx.generation != tr.generation:
-            # the saved activations live in the trainer's shared workspaces: a later grad-enabled forward has overwritten them
-            raise RuntimeError('Synchformer: backward() through a forward whose saved activations were overwritten by a later grad-enabled '
-                               'forward of the same module; call backward() before the next forward (or run that forward under torch.no_grad())')
+            # The saved activations live in the trainer's shared workspaces and a later grad-enabled forward of the same module has overwritten them
+            # (forward, forward, backward, backward - e.g. two losses of one step).  nn.Module semantics ask for this to work, so the forward is re-run from
+            # the kept inputs under the SAME dropout masks (counter restored) before the backward - activation checkpointing, paid only by this call pattern.
+            vfeat, afeat = ctx.saved_tensors
+            keep = tr.fwd_count
+            tr.fwd_count = ctx.fwd_count0
+            tr._forward(vfeat, afeat)
+            tr.fwd_count = keep
+            tr.generation += 1                                     # the workspaces now belong to THIS pass; any other pending pass recomputes in its turn
         tr._backward(dlogits.contiguous().float())
         return (None, None, None) + tuple(tr.g[k].clone() for k in tr.keys)

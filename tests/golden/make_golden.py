@@ -456,6 +456,11 @@ def logits_only(n_clips=32, per=2, variants=('gain1', 'trained')):
             rows.append(done[key])
             print(variant, c0, rows[-1].argmax(1).tolist(), rows[-1].max(1).tolist(), flush=True)
         out['logits_' + variant] = np.concatenate(rows, 0)
+    import zlib
+    for c in (0, n_clips - 1):                                                # input pins: the GPU box must regenerate exactly these clips
+        u8, aud = synth.make_structured_clip(c, 14, SEED)
+        out[f'crc_vis_{c}'] = np.int64(zlib.crc32(u8.numpy().tobytes()))
+        out[f'crc_aud_{c}'] = np.int64(zlib.crc32(aud.numpy().tobytes()))
     np.savez_compressed(HERE / f'logits_only_{n_clips}.npz', **out)
 
 

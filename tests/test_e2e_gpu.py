@@ -400,3 +400,50 @@ def test_dropin_module_forward_with_masks(gpu):
     assert abs(float(loss) - float(torch.nn.functional.cross_entropy(ref, tgt))) < 1e-6
     with pytest.raises(AssertionError, match='for_loop'):
         m(u8.to(gpu), aud.to(gpu), for_loop=True, vis_mask=vm.to(gpu))
+
+
+def test_logits_only_32_clips_reference_parity(gpu):
+    """Acc@1-parity proxy at scale: 32 STRUCTURED clips (synth.make_structured_clips: clips differ in content) at the benchmarked launch
+    geometry - two batches of 16 clips, each ONE 224-segment chunk - against the REAL reference's logits (tests/golden/logits_only_32.npz, made by
+    tests/golden/make_golden.py logits_only), at the reference-like init ('gain1') and at a trained-scale init ('trained': gain-2 weights, offset head x5, top
+    logit ~ 10 as in README.md:79).  Bars: max |dlogit| <= 1.5e-2 ('gain1', logit std 0.5) / <= 1.5 % of the logit range ('trained'); argmax agreement wherever
+    the reference's own top-2 margin exceeds twice the bar (a tie inside the bar is not a prediction), and the metric the reference reports - accuracy_1 and
+    accuracy_1_tol1 of calc_cls_metrics (scripts/train_utils.py:632) - with the reference's argmax as the target."""
+    import zlib
+    from synchformer_amd import synth
+    from synchformer_amd.engine import SynchformerEngine
+    from synchformer_amd.postprocess import offset_accuracy
+    g = np.load(GOLD / 'logits_only_32.npz')
+    n = int(g['n_clips'])
+    for c in (0, n - 1):
+        u8, aud = synth.make_structured_clip(c, 14, int(g['seed']))
+        assert zlib.crc32(u8.numpy().tobytes()) == int(g[f'crc_vis_{c}']) and zlib.crc32(aud.numpy().tobytes()) == int(g[f'crc_aud_{c}']), c
+    report = {}
+    for variant in ('gain1', 'trained'):
+        if variant == 'gain1':
+            sd = synth.make_state_dict(int(g['seed']))
+        else:
+            sd = synth.make_state_dict(int(g['seed']), gain=2.0)
+            sd['transformer.off_head.weight'] = sd['transformer.off_head.weight'] * float(g['head_scale'])
+        eng = SynchformerEngine(sd, gpu, seg_chunk=224)
+        got = []
+        for c0 in range(0, n, 16):
+            u8, aud = synth.make_structured_clips(c0, min(16, n - c0), 14, int(g['seed']))
+            got.append(eng.forward(u8.to(gpu), aud.to(gpu)).cpu())
+        got = torch.cat(got)
+        ref = torch.from_numpy(g['logits_' + variant])
+        rng = float(ref.max() - ref.min())
+        bar = 1.5e-2 if variant == 'gain1' else 1.5e-2 * rng
+        err = float((got - ref).abs().max())
+        top2 = torch.topk(ref, 2, dim=1).values
+        decided = (top2[:, 0] - top2[:, 1]) > 2 * bar                         # clips on which the reference itself prefers one class by more than the bars
+        agree = got.argmax(1) == ref.argmax(1)
+        acc = offset_accuracy(ref.argmax(1), got, topk=(1, 5))
+        report[variant] = dict(err=err, bar=bar, range=rng, decided=int(decided.sum()), agree=int(agree.sum()), **acc)
+        assert err <= bar, report
+        assert bool(agree[decided].all()), report
+        assert acc['accuracy_1_tol1'] >= acc['accuracy_1'] and acc['accuracy_5'] == 1.0, report
+        assert len(set(ref.argmax(1).tolist())) >= (3 if variant == 'trained' else 1), 'the clips must not all land on one class'
+        del eng
+        torch.cuda.empty_cache()
+    print('logits_only parity:', report)

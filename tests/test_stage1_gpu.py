@@ -351,6 +351,22 @@ def test_avclip_dropin_training_loop(gpu):
     assert float(ev['losses']['segment_contrastive_loss']) < ev0 - 1e-3
     out = m(vis, aud)                                                         # grad-enabled forward in eval mode: the train kernels with DropPath off
     assert m._sf_trainer.drop_path_rate == 0.0 and abs(float(out['losses']['segment_contrastive_loss']) - float(ev['losses']['segment_contrastive_loss'])) < 5e-3
+    # forward, forward, backward: the first pass's gradients were overwritten in the trainer's flat buffer - its backward re-runs the step from the kept
+    # inputs under the same stochastic-depth masks and hands over exactly what forward -> backward gives
+    m.train()
+    tr = m._sf_trainer
+    w = getattr(m.v_encoder.blocks, '7').mlp.fc1.weight
+    opt.zero_grad(set_to_none=True)
+    c0 = tr.fwd_count
+    sum(m(vis, aud)['losses'].values()).backward()
+    want = w.grad.clone()
+    opt.zero_grad(set_to_none=True)
+    tr.fwd_count = c0
+    la = sum(m(vis, aud)['losses'].values())
+    lb = sum(m(vis.flip(1), aud)['losses'].values())
+    la.backward()
+    assert torch.equal(w.grad, want) and tr.fwd_count == c0 + 2
+    del lb
 
 
 def _gather_head_worker(rank, world, port, q, backend='gloo'):

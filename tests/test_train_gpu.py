@@ -544,18 +544,38 @@ def test_dropin_autocast_gradscaler_loop(gpu):
     assert id(model._sf_engine[1]) in engines and l_eval.item() < losses[0]
 
 
-def test_two_forwards_before_backward_raise(gpu):
-    """The autograd bridge keeps its activations in the trainer's shared workspaces: a backward through a forward that a later
-    grad-enabled forward has overwritten must fail loudly, not return the other forward's gradients."""
+@pytest.mark.parametrize('dropout', [False, True])
+def test_two_forwards_before_backward_recompute(gpu, dropout):
+    """nn.Module semantics: forward, forward, backward, backward must work.  The autograd bridge keeps its activations in the trainer's shared
+    workspaces, so the backward of a pass that a later grad-enabled forward has overwritten re-runs that pass from its kept inputs under the SAME
+    dropout masks (counter restored): the accumulated gradients equal, bit for bit, those of forward -> backward, forward -> backward."""
     from synchformer_amd import synth
-    model = _frozen_train_model(gpu, dropout=False)
+    model = _frozen_train_model(gpu, dropout=dropout)
     u8, aud = synth.make_video_u8(1, 14, 1337).to(gpu), synth.make_spectrogram(1, 14, 1337).to(gpu)
     tgt = torch.zeros(1, dtype=torch.int64, device=gpu)
+    train = [p_ for p_ in model.parameters() if p_.requires_grad]
+
+    def grads():
+        return [p_.grad.clone() for p_ in train]
+
+    l0, _ = model(u8, aud, tgt)                                                          # builds the trainer
+    l0.backward()
+    tr = model._sf_trainer
+    model.zero_grad(set_to_none=True)
+    tr.fwd_count = 0
+    la, _ = model(u8, aud, tgt); la.backward()
+    lb, _ = model(u8, aud, tgt + 1); lb.backward()
+    want = grads()
+    model.zero_grad(set_to_none=True)
+    tr.fwd_count = 0
     l1, _ = model(u8, aud, tgt)
     l2, _ = model(u8, aud, tgt + 1)
-    with pytest.raises(RuntimeError, match='overwritten by a later grad-enabled forward'):
-        l1.backward()
-    l2.backward()                                                                        # the latest forward is fine
+    assert torch.equal(l1, la) and torch.equal(l2, lb)
+    l1.backward()                                                                        # overwritten by the second forward: recomputed
+    l2.backward()                                                                        # ... which in turn overwrote the second pass: recomputed too
+    got = grads()
+    assert all(torch.equal(g_, w_) for g_, w_ in zip(got, want))
+    assert tr.fwd_count == 2
     with torch.no_grad():
         model(u8, aud, tgt)                                                              # a no_grad forward in between does not invalidate
     l3, _ = model(u8, aud, tgt)
