@@ -550,6 +550,8 @@ def register_torch_ops():
                 _attn_part_mx, _attn_comb_mx):
         op_.register_fake(_fake())
 
+    from . import functional as _functional                                 # the functional ops with autograd (synchformer::linear, ::layer_norm768)
+    _functional.register()
     _registered = True
 
 

@@ -857,3 +857,44 @@ def test_gemm_ktile_major_weight(gpu):
     assert torch.equal(o0, o1)
     with pytest.raises(RuntimeError, match='k-tile-major'):
         ops.gemm(a[:100], ops.ktile_major_weight(w), b, o1[:100])
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
+
+
+def test_functional_ops_autograd(gpu):
+    """torch.ops.synchformer.linear / layer_norm768 (synchformer_amd/functional.py): functional dispatcher ops with an autograd formula on the train steps'
+    backward kernels, an autocast rule and FakeTensor implementations - forward and every gradient against fp32 torch on the same (bf16-rounded) operands."""
+    from synchformer_amd import functional as SF
+    g = torch.Generator().manual_seed(7)
+    B, L, K, N = 2, 520, 768, 2304
+    x = torch.randn(B, L, K, generator=g).to(gpu).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(K, generator=g)).to(gpu).requires_grad_(True)
+    beta = (0.1 * torch.randn(K, generator=g)).to(gpu).requires_grad_(True)
+    w = (0.02 * torch.randn(N, K, generator=g)).to(gpu).requires_grad_(True)
+    b = (0.02 * torch.randn(N, generator=g)).to(gpu).requires_grad_(True)
+    dy = torch.randn(B, L, N, generator=g).to(gpu)
+    with torch.autocast('cuda', dtype=torch.bfloat16):                          # the rules: layer_norm768 sees fp32, linear sees bf16
+        h = SF.layer_norm768(x, gamma, beta, 1e-6)
+        y = SF.linear(h, w, b)
+    assert h.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and y.shape == (B, L, N)
+    (y.float() * dy).sum().backward()
+    got = [t.grad.clone() for t in (x, gamma, beta, w, b)]
+    # fp32 torch on the operands the kernels saw: bf16(h), bf16(w), bf16(dy)
+    xr, gr, br, wr, bb = (t.detach().clone().requires_grad_(True) for t in (x, gamma, beta, w, b))
+    hr = torch.nn.functional.layer_norm(xr, (K,), gr, br, 1e-6)
+    h_b = hr.detach().bfloat16().float().requires_grad_(True)
+    yr = torch.nn.functional.linear(h_b, wr.detach().bfloat16().float().requires_grad_(True), bb)
+    assert (y.float() - yr).abs().max().item() < 3e-2 and _rel(h.float(), hr) < 4e-3
+    dyb = dy.bfloat16().float()
+    wq = wr.detach().bfloat16().float()
+    dh = dyb.reshape(-1, N) @ wq                                               # dX of the linear
+    dw_ref = dyb.reshape(-1, N).t() @ h_b.detach().reshape(-1, K)
+    db_ref = dyb.reshape(-1, N).sum(0)
+    hr.backward(dh.reshape(B, L, K).bfloat16().float())                         # the LayerNorm backward receives dX as autograd hands it over (bf16 here)
+    assert _rel(got[3], dw_ref) < 5e-3 and _rel(got[4], db_ref) < 5e-3, (_rel(got[3], dw_ref), _rel(got[4], db_ref))
+    assert _rel(got[0], xr.grad) < 1e-2 and _rel(got[1], gr.grad) < 1e-2 and _rel(got[2], br.grad) < 1e-2, [_rel(a, b_) for a, b_ in zip(got[:3], (xr.grad, gr.grad, br.grad))]
+    torch.library.opcheck(torch.ops.synchformer.linear.default, (x.detach().bfloat16(), w.detach().bfloat16(), b.detach()), test_utils=('test_schema', 'test_faketensor'))
+    with pytest.raises(NotImplementedError, match='N % 128'):
+        SF.linear(x.detach()[:, :, :64].contiguous().requires_grad_(True), torch.zeros(100, 64, device=gpu, requires_grad=True)).float().sum().backward()
