@@ -29,7 +29,7 @@ extern "C" {
 enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2, SF_U8 = 3 };   /* element types */
 enum { SF_EPI_NONE = 0, SF_EPI_GELU = 1 };                  /* GEMM epilogue activation */
 
-#define SF_ABI_VERSION 6
+#define SF_ABI_VERSION 7
 int sf_abi_version(void);
 const char* sf_last_error(void);
 /* "gfx950" + build flags; lets the host assert it loaded the library it built */
@@ -200,6 +200,18 @@ int sf_attention_cls_partial_mx(const uint16_t* q, const uint16_t* k, const uint
                                 float scale, float* cls_partial, void* stream);
 int sf_attention_cls_combine_mx(const float* partials, int n_part, uint8_t* out_q, int64_t ldq, uint8_t* out_s, int64_t splane, int64_t out_seq_rows, int out_row,
                                 int64_t n_seq, int heads, void* stream);
+
+/* The spatial half of DividedSpaceTimeBlock in ONE launch (round 4; vit_helper.py:370 `self.attn(self.norm1(x), ..., 'b (f n) d', '(b f) n d')`, DividedAttention.forward
+ * vit_helper.py:97-150): qkv projection (vit_helper.py:107) of every PATCH token + the per-frame attention over [CLS key; the frame's 196 patches] in the GEMM's epilogue -
+ * the 2304-wide projection never reaches HBM.  Work item = (frame, head pair): the frame's first 192 token rows x q | k | v of two heads on the matrix cores, the four
+ * left-over tokens of each frame and the CLS row joined from `side`.
+ * X (n_seq * 1569, 768) bf16 = norm1(x), rows [CLS; frame-major patches] per sequence; W (2304, 768) bf16 = qkv.weight, bias 2304 fp32 or NULL;
+ * side (n_seq * 33, 2304) bf16 = the same projection (sf_gemm_bf16 on gathered rows) of [the CLS row; for frame f = 0..7 its tokens 192..195]: row seq * 33 and rows
+ * seq * 33 + 1 + 4 f + i; out (rows as X, 768) bf16: patch rows only, must not alias X; cls_partial [n_seq][12][8][66] fp32: the CLS query's softmax partial per
+ * frame, as sf_attention_cls_partial writes them (merge with sf_attention_cls_combine, n_part = 8).  n_tok must be 196.  No token-mask variant: masked forwards take
+ * sf_gemm_bf16 + sf_attention_cls_partial_masked.  Replaces sf_gemm_bf16 (spatial qkv) + sf_attention_cls_partial (space groups). */
+int sf_qkv_space_attention(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
+                           uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, void* stream);
 
 /* The temporal half of DividedSpaceTimeBlock in ONE launch (vit_helper.py:366 `self.timeattn(self.norm3(x), ..., 'b (f n) d', '(b n) f d')`,
  * DividedAttention.forward vit_helper.py:97-150): qkv projection (vit_helper.py:107) of every PATCH token + the 8-frame attention over

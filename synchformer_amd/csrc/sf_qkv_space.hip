@@ -1,0 +1,431 @@
+// Motionformer SPACE attention fused into its qkv projection (gfx950): one launch computes, for every patch token, the spatial q | k | v of
+// DividedSpaceTimeBlock (vit_helper.py:370 -> DividedAttention.forward, vit_helper.py:97-150 with the '(b f) n d' regrouping of :341-342) and the
+// per-frame attention over [CLS key; the frame's 196 patches] in the GEMM's epilogue.  Un-fused (sf_gemm_bf16 -> sf_attention_cls_partial) the 2304-wide
+// projection goes to HBM (1.62 GB at 224 segments) and is read back; fused, only the 768-wide attention output is written.
+//
+//   * Work item = (frame, HEAD PAIR).  A frame's group is 196 tokens = 6 x 32 + 4: the GEMM tile is the frame's first 192 token rows (contiguous in X) x the
+//     q | k | v of two heads (384 features) = 6 x 12 = 72 blocks of 32 x 32, nine per wave (2 x 4 waves of 96 rows x 96 features) - no padded rows, the operand
+//     bytes per MAC of the 256 x 256 tile.  The four left-over tokens of every frame and the CLS row are projected up front by a small GEMM of the caller
+//     (`side`: 33 rows per sequence); they join as queries 192-195 / keys 193-196 / key 0 in the epilogue.
+//   * Main loop: 64-deep k-tiles in two 72-KiB stages (A 24 KiB | W0 | W1 | W2 of 16 KiB, W part j = feature block j of each of the four wave columns), THREE phases per
+//     k-tile - one feature block each, 12 MFMAs of 32x32x16 per wave and phase with the wave's 12 A fragments held in registers - accumulators transposed
+//     (C^T = W X^T: a lane ends with one token's features).  LDS-DMA pieces (9 per wave and k-tile) run about one stage ahead behind COUNTED waits, the wm = 1
+//     waves one barrier behind the wm = 0 waves - the schedule of sf_qkv_time.hip / sf_gemm_pp.hip:
+//         phase 0 of k-tile kt: issue W1, A1, A2 of kt+1 (no wait) | phase 1: issue W2 of kt+1, vmcnt(9): W2 of kt landed | phase 2: issue W0, A0 of kt+2,
+//         vmcnt(5): A, W0, W1 of kt+1 landed;   every part is refilled two phases after its last fragment read, data is read one phase after its wait.
+//   * Epilogue: accumulators (+ bias) -> bf16 -> LDS as K | V | Q of both heads in the row-major, XOR-swizzled layout of attn_mfma_kernel (sf_attention.hip); the side rows
+//     arrive by LDS-DMA during the main loop; then the arithmetic of that kernel, waves 0-3 on the first head, 4-7 on the second (S^T = K Q^T on v_mfma_f32_16x16x32_bf16,
+//     in-lane base-2 softmax, P V with ds_read_b64_tr_b16 V fragments), the CLS query's softmax partial of the frame in the free 197th query slot
+//     ([seq][head][8][66] records for sf_attention_cls_combine).  The attention arrays take 156 of the 160 KiB: the next tile's operands are NOT prefetched under it.
+//   * persistent, one workgroup per CU; every XCD owns a contiguous range of frames and sweeps it once per chunk of head pairs (pair fastest inside a chunk).
+#include "sf_common.h"
+#include <type_traits>
+#include <stdlib.h>
+#include "../../include/synchformer_hip.h"
+
+#define QS_TOK 196                     // tokens of a space group (one frame)
+#define QS_ROWS 192                    // ... of which the GEMM tile computes the first 192
+#define QS_D 768
+#define QS_A_BYTES (QS_ROWS * 128)     // 24 KiB: 192 rows x 64 k (bf16)
+#define QS_W_PART (128 * 128)          // 16 KiB: 4 wave columns x 32 features x 64 k
+#define QS_STAGE (QS_A_BYTES + 3 * QS_W_PART)   // 72 KiB
+#define QS_SIDE_OFF (2 * QS_STAGE)     // 144 KiB: landing area of the side rows (240 x 16 B) during the main loop
+#define QS_ARR (208 * 128)             // one K / V / Q array of the attention: 208 rows of 128 B
+#define QS_BIAS_OFF (6 * QS_ARR)       // 156 KiB: the tile's 384 bias floats (behind the attention arrays: lives through main loop AND epilogue)
+#define QS_LDS (160 * 1024)
+#ifndef QS_ABL
+#define QS_ABL 0                       // measurement builds: 1 no attention (epilogue part 2 skipped), 2 no MFMAs in the main loop
+#endif
+
+struct QsArgs {
+  const bf16_t* X; int64_t ldx;
+  const bf16_t* W; int64_t ldw;
+  const float* bias;
+  const bf16_t* side; int64_t lds_;    // (n_seq * 33, 2304) bf16: row seq * 33 = the CLS row's q | k | v, row seq * 33 + 1 + 4 f + i = token 192 + i of frame f
+  bf16_t* out; int64_t ldo;
+  float* cls_part;                     // [n_seq][12][8][66]
+  int64_t seq_rows;
+  uint32_t n_frames;                   // n_seq * 8
+  uint32_t pair_chunk;                 // head pairs per sweep over an XCD's frames (divides 6)
+  float scale;
+};
+
+typedef short qs_s4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) qs_s4 qs_lds_s4;
+
+__device__ __forceinline__ void qs_dma1(uint32_t voff, const void* sbase, uint32_t lds) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void qs_dma_dword_addr(const void* gaddr, uint32_t lds) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gaddr), "s"(lds) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void qs_wait_vmcnt() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
+}
+__device__ __forceinline__ void qs_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ uint32_t qs_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+__device__ __forceinline__ int qs_arr_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }   // = k_lds_off<64> of sf_attention.hip
+
+template <int V> using qs_ic = std::integral_constant<int, V>;
+
+__global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;                         // 2 x 4 waves, wave tile 96 token rows x 96 features
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // persistent schedule: block b sits on XCD b % 8; every XCD owns a contiguous range of frames and walks (frame, head pair) in chunks of `hc` pairs
+  const uint32_t xcd = blockIdx.x & 7u, li = blockIdx.x >> 3, per_xcd_blocks = gridDim.x >> 3;
+  const uint32_t f8 = (p.n_frames + 7u) >> 3;
+  const uint32_t fr0 = min(xcd * f8, p.n_frames), fr1 = min(fr0 + f8, p.n_frames);
+  const uint32_t hc = p.pair_chunk, chunk_tiles = (fr1 - fr0) * hc, t_end = (fr1 - fr0) * 6u;
+  uint32_t t = li;
+  if (t >= t_end) return;
+
+  // ---- tile-invariant lane offsets of the LDS-DMA pieces -----------------------------------------------------------------------------
+  // A piece pc of this wave = tile rows (3 wave + pc) * 8 .. + 7; lane (r = lane >> 3, chunk slot = lane & 7) -> LDS row-linear, source chunk XOR-swizzled
+  uint32_t voff_a[3], voff_w[3][2];
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc) {
+    const int r = (wave * 3 + pc) * 8 + (lane >> 3);
+    voff_a[pc] = (uint32_t)((int64_t)r * p.ldx * 2 + ((((lane & 7) ^ ((r >> 1) & 7))) << 4));
+  }
+  // W part j, piece pc of this wave = part rows (2 wave + pc) * 8 .. + 7; part row pr = 32 wn' + rr <-> tile column wn' * 96 + 32 j + rr <-> row
+  // which * 768 + hd * 64 + feat of W (the head pair's offset rides in the SGPR base)
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) {
+      const int pr = (wave * 2 + pc) * 8 + (lane >> 3);
+      const int c = (pr >> 5) * 96 + j * 32 + (pr & 31);
+      const int hd = c / 192, within = c - hd * 192;
+      const int grow = (within >> 6) * QS_D + hd * 64 + (within & 63);
+      voff_w[j][pc] = (uint32_t)((int64_t)grow * p.ldw * 2 + ((((lane & 7) ^ ((pr >> 1) & 7))) << 4));
+    }
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(qs_lds_addr(smem));
+  const uint32_t lds_a_w = __builtin_amdgcn_readfirstlane(lds0 + wave * 3072);
+  const uint32_t lds_w_w = __builtin_amdgcn_readfirstlane(lds0 + QS_A_BYTES + wave * 2048);
+
+  const char* xbase; const char* wbase;
+  uint32_t fr; int hp;
+  auto set_tile = [&](uint32_t tt) {
+    const uint32_t c = tt / chunk_tiles, r = tt - c * chunk_tiles;
+    fr = fr0 + r / hc; hp = (int)(c * hc + r % hc);
+    const int64_t seq = fr >> 3; const int f = (int)(fr & 7u);
+    xbase = reinterpret_cast<const char*>(p.X + (seq * p.seq_rows + 1 + (int64_t)f * QS_TOK) * p.ldx);
+    wbase = reinterpret_cast<const char*>(p.W + (int64_t)hp * 128 * p.ldw);
+  };
+  auto issue_a = [&](int pc, int S, int kt) { qs_dma1(voff_a[pc], xbase + kt * 128, lds_a_w + S * QS_STAGE + pc * 1024); };
+  auto issue_w = [&](int j, int S, int kt) {
+    qs_dma1(voff_w[j][0], wbase + kt * 128, lds_w_w + S * QS_STAGE + j * QS_W_PART);
+    qs_dma1(voff_w[j][1], wbase + kt * 128, lds_w_w + S * QS_STAGE + j * QS_W_PART + 1024);
+  };
+
+  constexpr int nk = QS_D / 64;                                     // 12 k-tiles
+  const float sc2 = p.scale * 1.44269504088896f;                   // softmax in base 2
+  uint32_t tcount = 0;
+
+  for (;;) {
+    set_tile(t);
+    const int64_t seq = fr >> 3; const int f = (int)(fr & 7u);
+    // ---- prologue: bias, side rows, k-tile 0 and W0 | A0 of k-tile 1 (the previous tile's attention is over: barrier at the bottom of the loop) ----------
+    if (wave < 6) {                                                 // 6 x 64 bias floats: tile columns 64 wave .. + 63 = (head hd = wave / 3, q | k | v = wave % 3)
+      if (p.bias) qs_dma_dword_addr(p.bias + (wave % 3) * QS_D + (hp * 2 + wave / 3) * 64 + lane, lds0 + QS_BIAS_OFF + wave * 256);
+    }
+    if (wave < 4) {                                                 // side rows: chunk x = ((hd * 5 + srow) * 3 + which) * 8 + ch, 240 chunks of 16 B
+      const int x = wave * 64 + lane;
+      if (x < 240) {
+        const int ch = x & 7, w3 = (x >> 3) % 3, hs = (x >> 3) / 3, srow = hs % 5, hd = hs / 5;
+        const int64_t srow_g = seq * 33 + (srow == 0 ? 0 : 1 + f * 4 + (srow - 1));
+        const uint32_t voff = (uint32_t)(((srow == 0 ? 0 : 1 + f * 4 + (srow - 1)) * p.lds_ + w3 * QS_D + hd * 64 + ch * 8) * 2);
+        (void)srow_g;
+        qs_dma1(voff, reinterpret_cast<const char*>(p.side + seq * 33 * p.lds_ + hp * 128), lds0 + QS_SIDE_OFF + wave * 1024);
+      }
+    }
+    issue_w(0, 0, 0); issue_a(0, 0, 0);
+    issue_w(1, 0, 0); issue_a(1, 0, 0); issue_a(2, 0, 0);
+    issue_w(2, 0, 0);
+    issue_w(0, 1, 1); issue_a(0, 1, 1);
+    qs_wait_vmcnt<5>();                                             // bias, side rows, A | W0 | W1 of k-tile 0 (this wave's pieces) have landed
+    qs_barrier();
+
+    // accumulators start at the bias: block (j, i) = features 96 wn + 32 j + 8 g + 4 hi + r of the tile, tokens 96 wm + 32 i + l31
+    f32x16 acc[3][3];
+    {
+      const float* bs = reinterpret_cast<const float*>(smem + QS_BIAS_OFF);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b4 = p.bias ? *reinterpret_cast<const float4*>(bs + wn * 96 + j * 32 + g * 8 + hi * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { acc[j][i][g * 4 + 0] = b4.x; acc[j][i][g * 4 + 1] = b4.y; acc[j][i][g * 4 + 2] = b4.z; acc[j][i][g * 4 + 3] = b4.w; }
+        }
+    }
+    {
+      int fo[4];
+      {
+        int ptid = threadIdx.x;
+        asm volatile("" : "+v"(ptid));
+        const int pl31 = ptid & 31, phi = (ptid & 63) >> 5;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fo[kk] = pl31 * 128 + (((kk * 2 + phi) ^ ((pl31 >> 1) & 7)) << 4);
+      }
+      const int a_base = wm * 96 * 128, w_base = QS_A_BYTES + wn * 32 * 128;
+      bf16x8 xf[3][4], wf[4];
+      auto read_w = [&](const char* st, int j) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) wf[kk] = *reinterpret_cast<const bf16x8*>(st + w_base + j * QS_W_PART + fo[kk]);
+      };
+      auto mma = [&](auto Jc) {
+        constexpr int J = decltype(Jc)::value;
+        __builtin_amdgcn_s_setprio(1);
+        if (!(QS_ABL & 2)) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[J][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk], xf[i][kk], acc[J][i], 0, 0, 0);
+        } else asm volatile("" :: "v"(wf[0]), "v"(wf[3]), "v"(xf[0][0]), "v"(xf[2][3]));
+        asm volatile("" : "+v"(acc[J][0]), "+v"(acc[J][1]), "+v"(acc[J][2]));   // pins the (pure) MFMAs inside their matrix segment
+        __builtin_amdgcn_s_setprio(0);
+      };
+      // one k-tile held in stage S; ld1 / ld2: k-tiles kt+1 / kt+2 exist
+      auto ktile = [&](auto Sc, int kt, bool ld1, bool ld2) {
+        constexpr int S = decltype(Sc)::value;
+        const char* st = smem + S * QS_STAGE;
+        // ---- phase 0: feature block 0 ----
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) xf[i][kk] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 4096 + fo[kk]);
+        read_w(st, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ld1) { issue_w(1, S ^ 1, kt + 1); issue_a(1, S ^ 1, kt + 1); issue_a(2, S ^ 1, kt + 1); }      // W1, A1, A2 of k-tile kt+1
+        qs_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(qs_ic<0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        qs_barrier();
+        // ---- phase 1: feature block 1 ----
+        read_w(st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ld1) { issue_w(2, S ^ 1, kt + 1); qs_wait_vmcnt<9>(); } else qs_wait_vmcnt<0>();               // W2 of k-tile kt+1 issued; W2 of this k-tile has landed
+        qs_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(qs_ic<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        qs_barrier();
+        // ---- phase 2: feature block 2 ----
+        read_w(st, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ld2) { issue_w(0, S, kt + 2); issue_a(0, S, kt + 2); qs_wait_vmcnt<5>(); }                     // W0, A0 of k-tile kt+2; A | W0 | W1 of k-tile kt+1 have landed
+        else if (ld1) qs_wait_vmcnt<2>();
+        else qs_wait_vmcnt<0>();
+        qs_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(qs_ic<2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        qs_barrier();
+      };
+      if (wm == 1) qs_barrier();                                    // waves 4-7 run one barrier behind waves 0-3
+      for (int kt = 0; kt < nk; kt += 2) {
+        ktile(qs_ic<0>{}, kt, true, kt + 2 < nk);
+        ktile(qs_ic<1>{}, kt + 1, kt + 2 < nk, kt + 3 < nk);
+      }
+      if (wm == 0) qs_barrier();                                    // re-align; every wave is done with both stages
+    }
+
+    // ---- epilogue (1): accumulators -> bf16 -> the attention's K | V | Q arrays (they overlay the operand stages) ---------------------------------------
+    {
+      int etid = threadIdx.x;
+      asm volatile("" : "+v"(etid));
+      const int el31 = etid & 31, ehi = (etid & 63) >> 5;
+      // the side rows first: they sit at 144 KiB, inside the second head's Q array - copy them out before anything is written there
+      uint4 sv = make_uint4(0u, 0u, 0u, 0u);
+      if (etid < 240) sv = *reinterpret_cast<const uint4*>(smem + QS_SIDE_OFF + etid * 16);
+      qs_barrier();
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int cb = (wn * 3 + j) * 32;                           // first tile column of the block (wave-uniform)
+        const int hd = cb / 192, within = cb - hd * 192, which = within >> 6, feat0 = within & 63;
+        const int arr = hd * 3 * QS_ARR + (which == 1 ? 0 : (which == 2 ? QS_ARR : 2 * QS_ARR));          // K | V | Q per head
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int row = wm * 96 + i * 32 + el31 + (which ? 1 : 0);                                      // key 0 is the CLS row
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            uint2 w;
+            w.x = pack_bf2(acc[j][i][g * 4 + 0], acc[j][i][g * 4 + 1]);
+            w.y = pack_bf2(acc[j][i][g * 4 + 2], acc[j][i][g * 4 + 3]);
+            *reinterpret_cast<uint2*>(smem + arr + qs_arr_off(row, (feat0 >> 3) + g) + ehi * 8) = w;
+          }
+        }
+      }
+      if (etid < 240) {                                             // side rows: CLS -> key 0 / the free query slot 196; left-over token i -> query 192 + i, key 193 + i
+        const int ch = etid & 7, w3 = (etid >> 3) % 3, hs = (etid >> 3) / 3, srow = hs % 5, hd = hs / 5;
+        const int arr = hd * 3 * QS_ARR + (w3 == 1 ? 0 : (w3 == 2 ? QS_ARR : 2 * QS_ARR));
+        const int row = w3 == 0 ? (srow == 0 ? QS_TOK : QS_ROWS + srow - 1) : (srow == 0 ? 0 : QS_ROWS + srow);
+        *reinterpret_cast<uint4*>(smem + arr + qs_arr_off(row, ch)) = sv;
+      }
+      if (etid >= 256 && etid < 256 + 176) {                        // V rows 197 .. 207 of both heads = 0: P is zero there and must meet finite values
+        const int x = etid - 256, ch = x & 7, rr = (x >> 3) % 11, hd = (x >> 3) / 11;
+        *reinterpret_cast<uint4*>(smem + hd * 3 * QS_ARR + QS_ARR + qs_arr_off(QS_TOK + 1 + rr, ch)) = make_uint4(0u, 0u, 0u, 0u);
+      }
+      qs_barrier();
+    }
+
+    // ---- epilogue (2): the space attention of (frame, head) - waves 0-3 the pair's first head, waves 4-7 the second (attn_mfma_kernel<64, 13>) ------------
+    if (!(QS_ABL & 1)) {
+      int atid = threadIdx.x;
+      asm volatile("" : "+v"(atid));
+      const int alane = atid & 63, fr_ = alane & 15, fg = alane >> 4;
+      const int h = wave >> 2, w4 = wave & 3, head = hp * 2 + h;
+      const char* k_lds = smem + h * 3 * QS_ARR;
+      const char* v_lds = k_lds + QS_ARR;
+      const char* q_lds = k_lds + 2 * QS_ARR;
+      constexpr int NKT = 13, nq = QS_TOK, nkeys = QS_TOK + 1;
+      int v_off[4];
+      {
+        const int krow = fg * 4 + (fr_ >> 2), c1 = (fr_ & 3) >> 1, hb = (fr_ & 1) * 8;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) v_off[dt] = qs_arr_off(krow, dt * 2 + c1) + hb;
+      }
+      const int wq = (w4 + (int)tcount) & 3;                        // 13 query tiles over 4 waves: the wave with four rotates from tile to tile
+      bf16_t* obase = p.out + (seq * p.seq_rows + 1 + (int64_t)f * QS_TOK) * p.ldo + head * 64;
+#pragma unroll 1
+      for (int tq = 0; tq < 4; ++tq) {
+        const int qt = wq + 4 * tq;
+        if (qt >= NKT) break;
+        bf16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(q_lds + qs_arr_off(qt * 16 + fr_, ks * 4 + fg));
+        f32x4 s[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + qs_arr_off(kt * 16 + fr_, ks * 4 + fg));
+            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+          }
+        }
+        const bool cls_slot = qt * 16 + fr_ == nq;                  // this lane's query column is the CLS query
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if ((NKT - 1) * 16 + fg * 4 + r >= nkeys) s[NKT - 1][r] = -INFINITY;
+        if (cls_slot && f != 0 && fg == 0) s[0][0] = -INFINITY;     // the CLS key itself is counted by frame 0's record only
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float msc = m * sc2;
+        const float msafe = m == -INFINITY ? 0.f : msc;
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc2, -msafe));
+            s[kt][r] = e; l += e;
+          }
+        l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+        const float linv = 1.0f / l;
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < (NKT + 1) / 2; ++kk) {
+          union { bf16x8 v; uint32_t u[4]; } pa;
+          pa.u[0] = pack_bf2(s[2 * kk][0], s[2 * kk][1]);
+          pa.u[1] = pack_bf2(s[2 * kk][2], s[2 * kk][3]);
+          if (2 * kk + 1 < NKT) {
+            constexpr int dummy = 0; (void)dummy;
+            const int t1 = 2 * kk + 1 < NKT ? 2 * kk + 1 : 0;
+            pa.u[2] = pack_bf2(s[t1][0], s[t1][1]);
+            pa.u[3] = pack_bf2(s[t1][2], s[t1][3]);
+          } else { pa.u[2] = 0; pa.u[3] = 0; }
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            union { bf16x8 v; qs_s4 hh[2]; } vb;
+            vb.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((qs_lds_s4*)(v_lds + v_off[dt] + kk * 32 * 128));
+            vb.hh[1] = qs_s4{0, 0, 0, 0};
+            if (2 * kk + 1 < NKT) vb.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((qs_lds_s4*)(v_lds + v_off[dt] + (kk * 32 + 16) * 128));
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb.v, pa.v, o[dt], 0, 0, 0);
+          }
+        }
+        const int qo = qt * 16 + fr_;
+        if (cls_slot) {                                             // unnormalised partial of the CLS query over this frame's keys
+          float* part = p.cls_part + ((seq * 12 + head) * 8 + f) * 66;
+          if (fg == 0) { part[0] = msc; part[1] = l; }
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[2 + dt * 16 + fg * 4 + r] = o[dt][r];
+        }
+        if (qo < nq) {
+          bf16_t* orow = obase + (int64_t)qo * p.ldo + fg * 4;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            uint2 w;
+            w.x = pack_bf2(o[dt][0] * linv, o[dt][1] * linv);
+            w.y = pack_bf2(o[dt][2] * linv, o[dt][3] * linv);
+            *reinterpret_cast<uint2*>(orow + dt * 16) = w;
+          }
+        }
+      }
+    }
+    qs_barrier();                                                   // every wave is out of the attention arrays: the next tile's operands may land
+    t += per_xcd_blocks;
+    ++tcount;
+    if (t >= t_end) break;
+  }
+}
+
+// X (n_seq * seq_rows, 768) bf16 = norm1(x), seq_rows = 1 + 8 * 196 rows [CLS; frame-major patches] per sequence; W (2304, 768) bf16 = attn.qkv.weight, bias 2304 fp32 or
+// NULL; side (n_seq * 33, 2304) bf16 = the same projection of [the CLS row; per frame f its tokens 192 .. 195] (row seq * 33, rows seq * 33 + 1 + 4 f + i), computed by the
+// caller with sf_gemm_bf16 on a gathered copy of those rows; out (rows as X, 768) bf16: the PATCH rows are written (row 0 of every sequence comes from
+// sf_attention_cls_combine on cls_partial [n_seq][12][8][66] fp32, one record per frame as sf_attention_cls_partial writes them).  out must not alias X (other workgroups
+// still read X).  Reference: vit_helper.py:97-150 with the '(b f) n d' groups of :341-342, heads = 12, head dim 64, q scaled by `scale` (vit_helper.py:113).
+extern "C" int sf_qkv_space_attention(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
+                                      uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, void* stream) {
+  SF_CHECK_ARG(X && W && side && out && cls_partial, "sf_qkv_space_attention: null pointer");
+  SF_CHECK_ARG(n_tok == QS_TOK, "sf_qkv_space_attention: built for 196-token frames (8 frames per sequence), got %d", n_tok);
+  SF_CHECK_ARG((ldx % 8) == 0 && (ldw % 8) == 0 && (lds_ % 8) == 0 && (ldo % 4) == 0 && ldx >= QS_D && ldw >= QS_D && lds_ >= 3 * QS_D && ldo >= QS_D,
+               "sf_qkv_space_attention: bad row strides");
+  SF_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)side % 16) == 0 && ((uintptr_t)out % 8) == 0 && (!bias || ((uintptr_t)bias % 16) == 0) &&
+                   ((uintptr_t)cls_partial % 8) == 0, "sf_qkv_space_attention: operands must be 16-byte aligned");
+  SF_CHECK_ARG((const void*)X != (const void*)out, "sf_qkv_space_attention: out must not alias X");
+  if (n_seq <= 0) return 0;
+  const int64_t seq_rows = 1 + 8 * (int64_t)QS_TOK;
+  SF_CHECK_ARG((int64_t)QS_TOK * ldx * 2 < ((int64_t)1 << 32) && (int64_t)3 * QS_D * ldw * 2 < ((int64_t)1 << 32) && (int64_t)33 * lds_ * 2 < ((int64_t)1 << 32),
+               "sf_qkv_space_attention: a frame of X, W and a sequence's side rows must stay below 4 GiB (32-bit lane offsets)");
+  SF_CHECK_ARG(n_seq * 8 * 6 < ((int64_t)1 << 31), "sf_qkv_space_attention: too many tiles");
+  if (int rc = sf_prepare_kernel((const void*)qkv_space_attn_kernel, QS_LDS, "sf_qkv_space_attention")) return rc;
+  const int n_cu = sf_cu_count("sf_qkv_space_attention");
+  if (n_cu <= 0) return -1;
+  QsArgs a;
+  a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.side = side; a.lds_ = lds_; a.out = out; a.ldo = ldo; a.cls_part = cls_partial;
+  a.seq_rows = seq_rows; a.n_frames = (uint32_t)(n_seq * 8); a.scale = scale;
+  static int env_hc = -1;
+  if (env_hc < 0) { const char* e = getenv("SF_QS_PAIR_CHUNK"); env_hc = e ? atoi(e) : 3; if (env_hc < 1 || 6 % env_hc) env_hc = 3; }
+  a.pair_chunk = (uint32_t)env_hc;
+  int64_t blocks = (n_cu / 8) * 8;
+  const int64_t need = ((n_seq * 8 * 6 + 7) / 8) * 8;
+  if (blocks > need) blocks = need;
+  hipLaunchKernelGGL(qkv_space_attn_kernel, dim3((unsigned)blocks), dim3(512), QS_LDS, (hipStream_t)stream, a);
+  SF_LAUNCH_CHECK();
+  return 0;
+}

@@ -88,6 +88,7 @@ class SynchformerEngine:
         self.fuse_ln = os.environ.get('SF_FUSE_LN', '1') != '0'            # A/B switches of the full-row GEMM + residual + LayerNorm kernel
         self.fuse_ln_fc2 = os.environ.get('SF_FUSE_LN_FC2', '1') != '0'   # K = 3072: 1932 us fused vs 1708 + 277 us (profiles/r02_gemm_ln.md)
         self.fuse_time = os.environ.get('SF_FUSE_TIME', '1') != '0'       # temporal qkv projection + time attention in one launch (sf_qkv_time_attention)
+        self.fuse_space = os.environ.get('SF_FUSE_SPACE', '1') != '0'     # spatial qkv projection + space attention in one launch (sf_qkv_space_attention, round 4)
         self._a_side = None
         self.load_weights(state_dict)
 
@@ -322,6 +323,10 @@ class SynchformerEngine:
         # fc2 stays un-fused because the norm after it is the row-mapped final norm below.
         fuse_ln = self.fuse_ln and rows >= 128 * 64
         fuse_time = self.fuse_time and rows >= 128 * 64
+        fuse_space = self.fuse_space and rows >= 128 * 64 and tok_keep is None and fuse_mode != 'none'   # (token masks take the un-fused, masked launches)
+        if fuse_space:
+            side_in = self._buf('side_in', n * 33 * D, torch.bfloat16).view(n * 33, D)
+            side = self._buf('side', n * 33 * 3 * D, torch.bfloat16).view(n * 33, 3 * D)
         att = big[:rows * D].view(rows, D)                                        # the time block's attention output (its qkv never exists)
         qkv_cls = self._buf('qkv_cls', n * 3 * D, torch.bfloat16).view(n, 3 * D)
         nb = len(self.v_blocks)
@@ -344,12 +349,22 @@ class SynchformerEngine:
             else:
                 ops.gemm(t_out, b['t_proj'].w, b['t_proj'].b, X, residual=X)
                 ops.layernorm(X, b['norm1'].g, b['norm1'].b, xn, EPS_VIS)
-            ops.gemm(xn, b['s_qkv'].w, b['s_qkv'].b, qkv)
-            divided('space')
-            if fuse_ln:
-                ops.gemm_res_ln(xn, b['s_proj'].wk, b['s_proj'].b, X, b['norm2'].g, b['norm2'].b, xn, EPS_VIS)
+            if fuse_space:
+                # spatial qkv + space attention in one launch (sf_qkv_space_attention): the 2304-wide projection never reaches HBM.  The rows the launch does not
+                # project itself - the CLS row and the last 4 tokens of every frame (196 = 6 x 32 + 4) - go through a 33-rows-per-segment GEMM up front.
+                ops.space_side_rows(xn, side_in, n)
+                ops.gemm(side_in, b['s_qkv'].w, b['s_qkv'].b, side)
+                ops.qkv_space_attention(xn, b['s_qkv'].w, b['s_qkv'].b, side, att, part, n_seq=n, scale=0.125)
+                ops.attention_cls_combine(part, att, n_part=8, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
+                s_out = att
             else:
-                ops.gemm(xn, b['s_proj'].w, b['s_proj'].b, X, residual=X)
+                ops.gemm(xn, b['s_qkv'].w, b['s_qkv'].b, qkv)
+                divided('space')
+                s_out = xn
+            if fuse_ln:
+                ops.gemm_res_ln(s_out, b['s_proj'].wk, b['s_proj'].b, X, b['norm2'].g, b['norm2'].b, xn, EPS_VIS)
+            else:
+                ops.gemm(s_out, b['s_proj'].w, b['s_proj'].b, X, residual=X)
                 ops.layernorm(X, b['norm2'].g, b['norm2'].b, xn, EPS_VIS)
             ops.gemm(xn, b['fc1'].w, b['fc1'].b, hid, gelu=True)
             if fuse_ln and self.fuse_ln_fc2 and bi + 1 < nb:

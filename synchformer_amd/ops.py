@@ -304,6 +304,38 @@ def qkv_time_attention(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Te
     return out
 
 
+def copy_rows_bf16(src: torch.Tensor, dst: torch.Tensor, rows: int, cols: int, src_map: RowMap = None, dst_map: RowMap = None):
+    """dst[dst_map(r), :cols] = src[src_map(r), :cols] for r < rows (bf16, cols % 8 == 0; sf_copy_rows_bf16)."""
+    assert src.dtype == dst.dtype == torch.bfloat16
+    rc = _lib.load().sf_copy_rows_bf16(_dev(src, 'src'), _ld(src), _map(src_map), _dev(dst, 'dst'), _ld(dst), _map(dst_map), rows, cols, _stream())
+    _lib.check(rc, 'sf_copy_rows_bf16')
+    return dst
+
+
+def space_side_rows(x: torch.Tensor, side_in: torch.Tensor, n_seq: int, seq_rows: int = 1569, n_tok: int = 196):
+    """The rows qkv_space_attention does NOT project itself, gathered for one small GEMM: per sequence [the CLS row; for frame f its tokens 192 .. 195] ->
+    side_in (n_seq * 33, 768) bf16 (row seq * 33, rows seq * 33 + 1 + 4 f + i)."""
+    per = 1 + 8 * (n_tok - 192)
+    copy_rows_bf16(x, side_in, n_seq, 768, rowmap(1, 1, seq_rows, 0, 0, 0), rowmap(1, 1, per, 0, 0, 0))
+    copy_rows_bf16(x, side_in, n_seq * 32, 768, rowmap(32, 4, seq_rows, n_tok, 1, 1 + 192), rowmap(32, 32, per, 0, 1, 1))
+    return side_in
+
+
+def qkv_space_attention(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, *, n_seq: int,
+                        scale: float, n_tok: int = 196):
+    """Spatial qkv projection + space attention of every patch token in one launch (sf_qkv_space_attention): x (n_seq * 1569, 768) bf16, w (2304, 768) bf16,
+    side (n_seq * 33, 2304) bf16 = the projection of the rows of space_side_rows(); out: patch rows of the attention output (a buffer of its own), partials: the CLS
+    query's softmax partials, one per frame, for attention_cls_combine(n_part=8)."""
+    assert x.dtype == w.dtype == side.dtype == out.dtype == torch.bfloat16 and partials.dtype == torch.float32
+    rows = n_seq * (1 + 8 * n_tok)
+    assert x.shape[1] == 768 and tuple(w.shape) == (2304, 768) and side.shape[0] >= n_seq * 33 and side.shape[1] == 2304 and out.shape[1] == 768
+    assert x.shape[0] >= rows and out.shape[0] >= rows and partials.numel() >= n_seq * 12 * 8 * 66 and x.data_ptr() != out.data_ptr()
+    rc = _lib.load().sf_qkv_space_attention(_dev(x, 'x'), _ld(x), _dev(w, 'w'), _ld(w), _dev(bias, 'bias') if bias is not None else None, _dev(side, 'side'), _ld(side),
+                                            _dev(out, 'out'), _ld(out), _dev(partials, 'partials'), n_seq, n_tok, float(scale), _stream())
+    _lib.check(rc, 'sf_qkv_space_attention')
+    return out
+
+
 def qkv_time_attention_mx(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], qkv_cls: torch.Tensor,
                           out: torch.Tensor, partials: torch.Tensor, *, n_seq: int, n_groups: int, scale: float, out_scales: Optional[torch.Tensor] = None):
     """qkv_time_attention on MXFP8 operands: x_q (n_seq * (1 + 8 n_groups), 768) uint8 e4m3 + x_s (6, >= rows, 4) scale planes, w_q (2304, 768) + w_s (6, >= 2304, 4);

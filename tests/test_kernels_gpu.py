@@ -898,3 +898,60 @@ def test_functional_ops_autograd(gpu):
     torch.library.opcheck(torch.ops.synchformer.linear.default, (x.detach().bfloat16(), w.detach().bfloat16(), b.detach()), test_utils=('test_schema', 'test_faketensor'))
     with pytest.raises(NotImplementedError, match='N % 128'):
         SF.linear(x.detach()[:, :, :64].contiguous().requires_grad_(True), torch.zeros(100, 64, device=gpu, requires_grad=True)).float().sum().backward()
+
+
+@pytest.mark.parametrize('n_seq', [3, 40])
+def test_qkv_space_attention(gpu, n_seq):
+    """sf_qkv_space_attention (spatial qkv projection + space attention + CLS-query partials in one launch; the side rows from a 33-rows-per-segment GEMM) against
+    the un-fused sequence it replaces: sf_gemm_bf16 -> sf_attention_cls_partial (space groups, CLS key first) + sf_attention_cls_combine.  Both round the projection
+    to bf16 before the attention but sum over k in different tile orders: a few q / k / v elements land one bf16 ulp apart, so the outputs agree to one ulp of their
+    magnitude, not bit for bit.  Repetitions are bit-identical (race screen of the LDS-DMA schedule).  n_seq = 3: 144 work items, fewer than CUs; 40: several rounds."""
+    from synchformer_amd import ops
+    L, D = 1569, 768
+    rows = n_seq * L
+    x = _bf(_rand(rows, D, seed=150)).to(gpu)
+    w, b = _bf(_rand(3 * D, D, seed=151, scale=0.05)).to(gpu), (0.1 * _rand(3 * D, seed=152)).to(gpu)
+    # un-fused
+    qkv = torch.empty(rows, 3 * D, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(x, w, b, qkv)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    ref = torch.zeros(rows, D, device=gpu, dtype=torch.bfloat16)
+    part_ref = torch.zeros(n_seq * 12 * 8 * 66, device=gpu)
+    ops.attention_cls_partial(q, k, v, ref, part_ref, n_seq=n_seq, seq_rows=L, n_groups=8, row0=1, group_stride=196, tok_stride=1, n_tok=196, cls_row=0, heads=12,
+                              head_dim=64, scale=0.125)
+    ops.attention_cls_combine(part_ref, ref, n_part=8, n_seq=n_seq, out_seq_rows=L, out_row=0, heads=12)
+    # fused
+    side_in = torch.empty(n_seq * 33, D, device=gpu, dtype=torch.bfloat16)
+    ops.space_side_rows(x, side_in, n_seq)
+    xv = x.view(n_seq, L, D)
+    assert torch.equal(side_in.view(n_seq, 33, D)[:, 0], xv[:, 0])
+    assert torch.equal(side_in.view(n_seq, 33, D)[:, 1:].reshape(n_seq, 8, 4, D), xv[:, 1:].reshape(n_seq, 8, 196, D)[:, :, 192:])
+    side = torch.empty(n_seq * 33, 3 * D, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(side_in, w, b, side)
+
+    def fused():
+        out = torch.full((rows, D), 7.0, device=gpu, dtype=torch.bfloat16)
+        part = torch.zeros(n_seq * 12 * 8 * 66, device=gpu)
+        ops.qkv_space_attention(x, w, b, side, out, part, n_seq=n_seq, scale=0.125)
+        return out, part
+    out, part = fused()
+    for rep in range(3):
+        o2, p2 = fused()
+        assert torch.equal(o2, out), f'repetition {rep}: {(o2 != out).sum().item()} output elements differ'
+        assert torch.equal(p2, part), f'repetition {rep}: {(p2 != part).sum().item()} partial elements differ'
+    assert (out.view(n_seq, L, D)[:, 0] == 7.0).all(), 'the fused kernel must not touch the CLS rows'
+    ops.attention_cls_combine(part, out, n_part=8, n_seq=n_seq, out_seq_rows=L, out_row=0, heads=12)
+    o, r = out.float().view(n_seq, L, D), ref.float().view(n_seq, L, D)
+    torch.testing.assert_close(o[:, 1:], r[:, 1:], rtol=2 ** -7, atol=2 ** -7)
+    assert (o[:, 1:] - r[:, 1:]).abs().gt(1e-3).float().mean() < 2e-3                    # ... and those are rare
+    torch.testing.assert_close(o[:, 0], r[:, 0], rtol=2 ** -6, atol=2 ** -7)
+    # and against fp32 torch on the bf16 projection (independent of the un-fused attention kernel): per frame, keys [CLS; the frame's 196 tokens]
+    qf = qkv.float().view(n_seq, L, 3, 12, 64)[:2]
+    qq, kk, vv = qf[:, :, 0], qf[:, :, 1], qf[:, :, 2]                                   # (n, L, 12, 64)
+    m = qq.shape[0]
+    pk = torch.cat([kk[:, :1].unsqueeze(1).expand(-1, 8, -1, -1, -1), kk[:, 1:].reshape(m, 8, 196, 12, 64)], 2)   # (n, 8, 197, 12, 64)
+    pv = torch.cat([vv[:, :1].unsqueeze(1).expand(-1, 8, -1, -1, -1), vv[:, 1:].reshape(m, 8, 196, 12, 64)], 2)
+    pq = qq[:, 1:].reshape(m, 8, 196, 12, 64)
+    att = torch.einsum('nfqhd,nfkhd->nfhqk', pq, pk) * 0.125
+    po = torch.einsum('nfhqk,nfkhd->nfqhd', att.softmax(-1), pv).reshape(m, 8 * 196, D)
+    torch.testing.assert_close(o[:2, 1:], po, rtol=2 ** -7, atol=2 ** -7)
