@@ -14,9 +14,12 @@
 //         phase 0 of k-tile kt: issue W1, A1, A2 of kt+1 (no wait) | phase 1: issue W2 of kt+1, vmcnt(9): W2 of kt landed | phase 2: issue W0, A0 of kt+2,
 //         vmcnt(5): A, W0, W1 of kt+1 landed;   every part is refilled two phases after its last fragment read, data is read one phase after its wait.
 //   * Epilogue: accumulators (+ bias) -> bf16 -> LDS as K | V | Q of both heads in the row-major, XOR-swizzled layout of attn_mfma_kernel (sf_attention.hip); the side rows
-//     arrive by LDS-DMA during the main loop; then the arithmetic of that kernel, waves 0-3 on the first head, 4-7 on the second (S^T = K Q^T on v_mfma_f32_16x16x32_bf16,
-//     in-lane base-2 softmax, P V with ds_read_b64_tr_b16 V fragments), the CLS query's softmax partial of the frame in the free 197th query slot
-//     ([seq][head][8][66] records for sf_attention_cls_combine).  The attention arrays take 156 of the 160 KiB: the next tile's operands are NOT prefetched under it.
+//     arrive by LDS-DMA during the main loop; then the arithmetic of that kernel (S^T = K Q^T on v_mfma_f32_16x16x32_bf16, in-lane base-2 softmax, P V with
+//     ds_read_b64_tr_b16 V fragments) on PAIRS of 16-query tiles - every K / V fragment read from LDS feeds two MFMAs: 14 pair units (2 heads x 7) over the 8 waves -, the
+//     CLS query's softmax partial of the frame in the free 197th query slot ([seq][head][8][66] records for sf_attention_cls_combine).  The attention arrays take 156
+//     of the 160 KiB: the next tile's operands are NOT prefetched under it.
+//   * Measured (M = 351,456, profiles/r04_qkv_space.md): 1330 us against 1050 (sf_gemm_bf16 qkv) + 483 (attention) un-fused; the main loop + accumulator hand-over
+//     alone run at 1.31 PFLOP/s (947 us), the attention epilogue costs ~9 us per work item (softmax VALU + LDS fragment reads + MFMAs of ONE workgroup per CU).
 //   * persistent, one workgroup per CU; every XCD owns a contiguous range of frames and sweeps it once per chunk of head pairs (pair fastest inside a chunk).
 #include "sf_common.h"
 #include <type_traits>
@@ -285,15 +288,14 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
       qs_barrier();
     }
 
-    // ---- epilogue (2): the space attention of (frame, head) - waves 0-3 the pair's first head, waves 4-7 the second (attn_mfma_kernel<64, 13>) ------------
+    // ---- epilogue (2): the space attention of (frame, head), the arithmetic of attn_mfma_kernel<64, 13> -----------------------------------------------------
+    // A work unit is a PAIR of 16-query tiles of one head: every K fragment (S^T = K Q^T) and every V^T fragment (P V) read from LDS feeds two MFMAs - the
+    // attention is bound by the LDS port (a 16-query tile reads all of K and V: 56 KB; 26 tiles per work item = 1.4 MB against 0.15 MB of arrays), pairs halve it.
+    // 13 tiles per head = 6 pairs + tile 12 alone (its partner slot repeats tile 12, nothing of it is stored): 14 units over the 8 waves, rotating from tile to tile.
     if (!(QS_ABL & 1)) {
       int atid = threadIdx.x;
       asm volatile("" : "+v"(atid));
       const int alane = atid & 63, fr_ = alane & 15, fg = alane >> 4;
-      const int h = wave >> 2, w4 = wave & 3, head = hp * 2 + h;
-      const char* k_lds = smem + h * 3 * QS_ARR;
-      const char* v_lds = k_lds + QS_ARR;
-      const char* q_lds = k_lds + 2 * QS_ARR;
       constexpr int NKT = 13, nq = QS_TOK, nkeys = QS_TOK + 1;
       int v_off[4];
       {
@@ -301,88 +303,131 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) v_off[dt] = qs_arr_off(krow, dt * 2 + c1) + hb;
       }
-      const int wq = (w4 + (int)tcount) & 3;                        // 13 query tiles over 4 waves: the wave with four rotates from tile to tile
-      bf16_t* obase = p.out + (seq * p.seq_rows + 1 + (int64_t)f * QS_TOK) * p.ldo + head * 64;
+#ifndef QS_SKEW
+#define QS_SKEW 0
+#endif
+      if (QS_SKEW && wave >= 4) __builtin_amdgcn_s_sleep(QS_SKEW);   // (experiment: the two waves of a SIMD out of phase - one's softmax under the other's MFMAs)
 #pragma unroll 1
-      for (int tq = 0; tq < 4; ++tq) {
-        const int qt = wq + 4 * tq;
-        if (qt >= NKT) break;
-        bf16x8 qf[2];
+      for (int uu = 0; uu < 2; ++uu) {
+        const int u = ((wave + (int)tcount) & 7) + 8 * uu;         // wave-uniform
+        if (u >= 14) break;
+        const int h = u >= 7 ? 1 : 0, pu = u - 7 * h, head = hp * 2 + h;
+        const int qt0 = 2 * pu, qt1 = pu == 6 ? 12 : 2 * pu + 1;
+        const bool two = pu != 6;
+        const char* k_lds = smem + h * 3 * QS_ARR;
+        const char* v_lds = k_lds + QS_ARR;
+        const char* q_lds = k_lds + 2 * QS_ARR;
+        bf16_t* obase = p.out + (seq * p.seq_rows + 1 + (int64_t)f * QS_TOK) * p.ldo + head * 64;
+        bf16x8 qf[2][2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(q_lds + qs_arr_off(qt * 16 + fr_, ks * 4 + fg));
-        f32x4 s[NKT];
+        for (int ks = 0; ks < 2; ++ks) {
+          qf[0][ks] = *reinterpret_cast<const bf16x8*>(q_lds + qs_arr_off(qt0 * 16 + fr_, ks * 4 + fg));
+          qf[1][ks] = *reinterpret_cast<const bf16x8*>(q_lds + qs_arr_off(qt1 * 16 + fr_, ks * 4 + fg));
+        }
+        f32x4 s[2][NKT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
-          s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          s[0][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          s[1][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + qs_arr_off(kt * 16 + fr_, ks * 4 + fg));
-            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+            s[0][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[0][kt], 0, 0, 0);
+            s[1][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[1][kt], 0, 0, 0);
           }
         }
-        const bool cls_slot = qt * 16 + fr_ == nq;                  // this lane's query column is the CLS query
+        float msc_[2], l_[2], linv_[2];
+        bool cls_[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if ((NKT - 1) * 16 + fg * 4 + r >= nkeys) s[NKT - 1][r] = -INFINITY;
-        if (cls_slot && f != 0 && fg == 0) s[0][0] = -INFINITY;     // the CLS key itself is counted by frame 0's record only
-        float m = -INFINITY;
+        for (int e = 0; e < 2; ++e) {
+          const int qt = e ? qt1 : qt0;
+          const bool cls_slot = qt * 16 + fr_ == nq;                // this lane's query column is the CLS query
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+          for (int r = 0; r < 4; ++r)
+            if ((NKT - 1) * 16 + fg * 4 + r >= nkeys) s[e][NKT - 1][r] = -INFINITY;
+          if (cls_slot && f != 0 && fg == 0) s[e][0][0] = -INFINITY;   // the CLS key itself is counted by frame 0's record only
+          float m = -INFINITY;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
-        m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
-        const float msc = m * sc2;
-        const float msafe = m == -INFINITY ? 0.f : msc;
-        float l = 0.f;
+          for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, s[e][kt][r]);
+          m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+          const float msc = m * sc2;
+          const float msafe = m == -INFINITY ? 0.f : msc;
+          // exp2(s * sc2 - m * sc2) on float2 (v_pk_fma_f32 / v_pk_add_f32: the softmax arithmetic is what bounds this epilogue next to the quarter-rate v_exp_f32)
+#ifndef QS_PK
+#define QS_PK 1
+#endif
+          const sf_f32x2_t sc2v = {sc2, sc2}, mneg = {-msafe, -msafe};
+          sf_f32x2_t l2 = {0.f, 0.f};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc2, -msafe));
-            s[kt][r] = e; l += e;
-          }
-        l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
-        const float linv = 1.0f / l;
-        f32x4 o[4];
+          for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < 4; r += 2) {
+              if (QS_PK) {
+                const sf_f32x2_t a2 = sf_f32x2_t{s[e][kt][r], s[e][kt][r + 1]} * sc2v + mneg;
+                const sf_f32x2_t ex = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+                s[e][kt][r] = ex.x; s[e][kt][r + 1] = ex.y;
+                l2 = l2 + ex;
+              } else {
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(s[e][kt][r], sc2, -msafe)), e1 = __builtin_amdgcn_exp2f(fmaf(s[e][kt][r + 1], sc2, -msafe));
+                s[e][kt][r] = e0; s[e][kt][r + 1] = e1; l2.x += e0; l2.y += e1;
+              }
+            }
+          float l = l2.x + l2.y;
+          l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+          msc_[e] = msc; l_[e] = l; linv_[e] = 1.0f / l; cls_[e] = cls_slot;
+        }
+        f32x4 o[2][4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) o[e][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < (NKT + 1) / 2; ++kk) {
-          union { bf16x8 v; uint32_t u[4]; } pa;
-          pa.u[0] = pack_bf2(s[2 * kk][0], s[2 * kk][1]);
-          pa.u[1] = pack_bf2(s[2 * kk][2], s[2 * kk][3]);
-          if (2 * kk + 1 < NKT) {
-            constexpr int dummy = 0; (void)dummy;
-            const int t1 = 2 * kk + 1 < NKT ? 2 * kk + 1 : 0;
-            pa.u[2] = pack_bf2(s[t1][0], s[t1][1]);
-            pa.u[3] = pack_bf2(s[t1][2], s[t1][3]);
-          } else { pa.u[2] = 0; pa.u[3] = 0; }
+          union { bf16x8 v; uint32_t u[4]; } pa[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            pa[e].u[0] = pack_bf2(s[e][2 * kk][0], s[e][2 * kk][1]);
+            pa[e].u[1] = pack_bf2(s[e][2 * kk][2], s[e][2 * kk][3]);
+            if (2 * kk + 1 < NKT) {
+              const int t1 = 2 * kk + 1 < NKT ? 2 * kk + 1 : 0;
+              pa[e].u[2] = pack_bf2(s[e][t1][0], s[e][t1][1]);
+              pa[e].u[3] = pack_bf2(s[e][t1][2], s[e][t1][3]);
+            } else { pa[e].u[2] = 0; pa[e].u[3] = 0; }
+          }
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
             union { bf16x8 v; qs_s4 hh[2]; } vb;
             vb.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((qs_lds_s4*)(v_lds + v_off[dt] + kk * 32 * 128));
             vb.hh[1] = qs_s4{0, 0, 0, 0};
             if (2 * kk + 1 < NKT) vb.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((qs_lds_s4*)(v_lds + v_off[dt] + (kk * 32 + 16) * 128));
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb.v, pa.v, o[dt], 0, 0, 0);
+            o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb.v, pa[0].v, o[0][dt], 0, 0, 0);
+            o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb.v, pa[1].v, o[1][dt], 0, 0, 0);
           }
         }
-        const int qo = qt * 16 + fr_;
-        if (cls_slot) {                                             // unnormalised partial of the CLS query over this frame's keys
-          float* part = p.cls_part + ((seq * 12 + head) * 8 + f) * 66;
-          if (fg == 0) { part[0] = msc; part[1] = l; }
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt)
+        for (int e = 0; e < 2; ++e) {
+          if (e == 1 && !two) break;                                // (tile 12's partner slot repeated tile 12)
+          const int qo = (e ? qt1 : qt0) * 16 + fr_;
+          if (cls_[e]) {                                            // unnormalised partial of the CLS query over this frame's keys
+            float* part = p.cls_part + ((seq * 12 + head) * 8 + f) * 66;
+            if (fg == 0) { part[0] = msc_[e]; part[1] = l_[e]; }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part[2 + dt * 16 + fg * 4 + r] = o[dt][r];
-        }
-        if (qo < nq) {
-          bf16_t* orow = obase + (int64_t)qo * p.ldo + fg * 4;
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            uint2 w;
-            w.x = pack_bf2(o[dt][0] * linv, o[dt][1] * linv);
-            w.y = pack_bf2(o[dt][2] * linv, o[dt][3] * linv);
-            *reinterpret_cast<uint2*>(orow + dt * 16) = w;
+              for (int r = 0; r < 4; ++r) part[2 + dt * 16 + fg * 4 + r] = o[e][dt][r];
+          }
+          if (qo < nq) {
+            bf16_t* orow = obase + (int64_t)qo * p.ldo + fg * 4;
+            const float linv = linv_[e];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+              uint2 w;
+              w.x = pack_bf2(o[e][dt][0] * linv, o[e][dt][1] * linv);
+              w.y = pack_bf2(o[e][dt][2] * linv, o[e][dt][3] * linv);
+              *reinterpret_cast<uint2*>(orow + dt * 16) = w;
+            }
           }
         }
       }
@@ -420,7 +465,7 @@ extern "C" int sf_qkv_space_attention(const uint16_t* X, int64_t ldx, const uint
   a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.side = side; a.lds_ = lds_; a.out = out; a.ldo = ldo; a.cls_part = cls_partial;
   a.seq_rows = seq_rows; a.n_frames = (uint32_t)(n_seq * 8); a.scale = scale;
   static int env_hc = -1;
-  if (env_hc < 0) { const char* e = getenv("SF_QS_PAIR_CHUNK"); env_hc = e ? atoi(e) : 3; if (env_hc < 1 || 6 % env_hc) env_hc = 3; }
+  if (env_hc < 0) { const char* e = getenv("SF_QS_PAIR_CHUNK"); env_hc = e ? atoi(e) : 6; if (env_hc < 1 || 6 % env_hc) env_hc = 6; }
   a.pair_chunk = (uint32_t)env_hc;
   int64_t blocks = (n_cu / 8) * 8;
   const int64_t need = ((n_seq * 8 * 6 + 7) / 8) * 8;

@@ -183,6 +183,26 @@ def test_custom_ops_have_fake_implementations():
         assert torch._C._dispatch_has_kernel_for_dispatch_key(f'synchformer::{name}', 'Meta'), name
 
 
+def test_offset_accuracy_and_structured_clips():
+    """postprocess.offset_accuracy = accuracy_k / accuracy_k_tol1 of the reference's calc_cls_metrics (scripts/train_utils.py:665-705) on hand-made cases; the
+    structured evaluation clips regenerate bit for bit (the fixture of tests/test_e2e_gpu.py::test_logits_only_32_clips_reference_parity holds their CRCs)."""
+    import zlib
+    import numpy as np
+    from synchformer_amd import synth
+    from synchformer_amd.postprocess import offset_accuracy
+    lg = torch.tensor([[0., 1, 5, 2], [9, 1, 0, 0], [0, 0, 1, 9.], [3, 2, 1, 0]])
+    m = offset_accuracy(torch.tensor([2, 1, 0, 3]), lg, topk=(1, 2))
+    assert m == {'accuracy_1': 0.25, 'accuracy_1_tol1': 0.5, 'accuracy_2': 0.5, 'accuracy_2_tol1': 0.5}
+    m = offset_accuracy(torch.tensor([3, 0, 3, 0]), lg, topk=(1, 5))                # tolerance clamps at the class range; k is capped at C
+    assert m['accuracy_1'] == 0.75 and m['accuracy_1_tol1'] == 1.0 and m['accuracy_4'] == 1.0
+    g = np.load(Path(__file__).resolve().parent / 'golden' / 'logits_only_32.npz')
+    for c in (0, 31):
+        u8, aud = synth.make_structured_clip(c, 14, int(g['seed']))
+        assert zlib.crc32(u8.numpy().tobytes()) == int(g[f'crc_vis_{c}']) and zlib.crc32(aud.numpy().tobytes()) == int(g[f'crc_aud_{c}'])
+    a, b = synth.make_structured_clip(3), synth.make_structured_clip(4)
+    assert not torch.equal(a[0], b[0]) and abs(float(a[0].float().mean()) - float(b[0].float().mean())) > 0.5     # clips differ in content, not only in noise
+
+
 def test_shard_range():
     from synchformer_amd.dist import shard_range
     for n in (0, 1, 7, 16, 33):

@@ -377,7 +377,14 @@ def test_masked_forward_on_the_fused_schedule(gpu):
     print(f'masked fused vs un-fused: {d:.5f}; distance to the unmasked logits {dn:.3f}')
     assert d < 1e-2 and dn > 0.05
     ones = eng.forward(u8.to(gpu), aud.to(gpu), torch.ones_like(vm).to(gpu), torch.ones_like(am).to(gpu))
-    assert torch.equal(ones, nomask)
+    # a masked forward takes sf_gemm_bf16 + sf_attention_cls_partial_masked for the space half (sf_qkv_space_attention has no mask variant): bit-equal to the unmasked
+    # forward on the same launches, within a few bf16 ulps of the projection of the fused launch
+    assert (ones - nomask).abs().max().item() < 1e-2
+    eng.fuse_space = False
+    try:
+        assert torch.equal(ones, eng.forward(u8.to(gpu), aud.to(gpu)))
+    finally:
+        eng.fuse_space = True
 
 
 def test_dropin_module_forward_with_masks(gpu):
@@ -406,9 +413,10 @@ def test_logits_only_32_clips_reference_parity(gpu):
     """Acc@1-parity proxy at scale: 32 STRUCTURED clips (synth.make_structured_clips: clips differ in content) at the benchmarked launch
     geometry - two batches of 16 clips, each ONE 224-segment chunk - against the REAL reference's logits (tests/golden/logits_only_32.npz, made by
     tests/golden/make_golden.py logits_only), at the reference-like init ('gain1') and at a trained-scale init ('trained': gain-2 weights, offset head x5, top
-    logit ~ 10 as in README.md:79).  Bars: max |dlogit| <= 1.5e-2 ('gain1', logit std 0.5) / <= 1.5 % of the logit range ('trained'); argmax agreement wherever
-    the reference's own top-2 margin exceeds twice the bar (a tie inside the bar is not a prediction), and the metric the reference reports - accuracy_1 and
-    accuracy_1_tol1 of calc_cls_metrics (scripts/train_utils.py:632) - with the reference's argmax as the target."""
+    logit ~ 10 as in README.md:79).  Bars: max |dlogit| <= 1e-2 ('gain1', logit std 0.54) / <= 0.75 % of the logit range ('trained'); argmax agreement on >= 90 % of
+    the clips with every disagreement a TIE inside the numerical error (the picked class within 2 x max |dlogit| of the reference's top logit: these synthetic clips put
+    two or three classes within 0.002-0.02 of each other), and the metric the reference reports - accuracy_1 / accuracy_1_tol1 / accuracy_5 of calc_cls_metrics
+    (scripts/train_utils.py:632) - with the reference's argmax as the target.  Measured: 30 / 32 and 31 / 32 agree, accuracy_5 = 1."""
     import zlib
     from synchformer_amd import synth
     from synchformer_amd.engine import SynchformerEngine
@@ -433,16 +441,17 @@ def test_logits_only_32_clips_reference_parity(gpu):
         got = torch.cat(got)
         ref = torch.from_numpy(g['logits_' + variant])
         rng = float(ref.max() - ref.min())
-        bar = 1.5e-2 if variant == 'gain1' else 1.5e-2 * rng
+        bar = 1e-2 if variant == 'gain1' else 7.5e-3 * rng                     # measured: 6.3e-3 (logit std 0.54) / 0.095 = 0.5 % of the 19-wide logit range
         err = float((got - ref).abs().max())
-        top2 = torch.topk(ref, 2, dim=1).values
-        decided = (top2[:, 0] - top2[:, 1]) > 2 * bar                         # clips on which the reference itself prefers one class by more than the bars
         agree = got.argmax(1) == ref.argmax(1)
+        # a disagreement is only acceptable as a TIE inside the numerical error: the class the HIP path picked must be within 2 x err of the reference's top logit
+        picked = ref.gather(1, got.argmax(1, keepdim=True)).squeeze(1)
+        gap = ref.max(1).values - picked
         acc = offset_accuracy(ref.argmax(1), got, topk=(1, 5))
-        report[variant] = dict(err=err, bar=bar, range=rng, decided=int(decided.sum()), agree=int(agree.sum()), **acc)
+        report[variant] = dict(err=err, bar=bar, range=rng, agree=int(agree.sum()), worst_gap_of_a_flip=float(gap.max()), **acc)
         assert err <= bar, report
-        assert bool(agree[decided].all()), report
-        assert acc['accuracy_1_tol1'] >= acc['accuracy_1'] and acc['accuracy_5'] == 1.0, report
+        assert float(gap.max()) <= 2 * err + 1e-6, report
+        assert int(agree.sum()) >= int(0.9 * n) and acc['accuracy_5'] == 1.0 and acc['accuracy_1_tol1'] >= acc['accuracy_1'], report
         assert len(set(ref.argmax(1).tolist())) >= (3 if variant == 'trained' else 1), 'the clips must not all land on one class'
         del eng
         torch.cuda.empty_cache()
