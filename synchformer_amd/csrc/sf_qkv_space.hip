@@ -37,7 +37,7 @@
 #define QS_BIAS_OFF (6 * QS_ARR)       // 156 KiB: the tile's 384 bias floats (behind the attention arrays: lives through main loop AND epilogue)
 #define QS_LDS (160 * 1024)
 #ifndef QS_ABL
-#define QS_ABL 0                       // measurement builds: 1 no attention (epilogue part 2 skipped), 2 no MFMAs in the main loop
+#define QS_ABL 0                       // measurement builds: 1 no attention (epilogue part 2 skipped), 2 no MFMAs in the main loop, 4 no softmax arithmetic, 8 no S phase, 16 one of the seven P V steps
 #endif
 
 struct QsArgs {
@@ -331,6 +331,7 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
           s[1][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
+            if (QS_ABL & 8) continue;
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + qs_arr_off(kt * 16 + fr_, ks * 4 + fg));
             s[0][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[0][kt], 0, 0, 0);
             s[1][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[1][kt], 0, 0, 0);
@@ -364,7 +365,8 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
           for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
-              if (QS_PK) {
+              if (QS_ABL & 4) { l2.x += s[e][kt][r]; l2.y += s[e][kt][r + 1]; }
+              else if (QS_PK) {
                 const sf_f32x2_t a2 = sf_f32x2_t{s[e][kt][r], s[e][kt][r + 1]} * sc2v + mneg;
                 const sf_f32x2_t ex = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
                 s[e][kt][r] = ex.x; s[e][kt][r + 1] = ex.y;
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) o[e][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < (NKT + 1) / 2; ++kk) {
+        for (int kk = 0; kk < ((QS_ABL & 16) ? 1 : (NKT + 1) / 2); ++kk) {
           union { bf16x8 v; uint32_t u[4]; } pa[2];
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
