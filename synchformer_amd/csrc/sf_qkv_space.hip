@@ -86,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;                         // 2 x 4 waves, wave tile 96 token rows x 96 features
-  const int l31 = lane & 31, hi = lane >> 5;
+  const int hi = lane >> 5;
 
   // persistent schedule: block b sits on XCD b % 8; every XCD owns a contiguous range of frames and walks (frame, head pair) in chunks of `hc` pairs
   const uint32_t xcd = blockIdx.x & 7u, li = blockIdx.x >> 3, per_xcd_blocks = gridDim.x >> 3;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
     issue_w(1, 0, 0); issue_a(1, 0, 0); issue_a(2, 0, 0);
     issue_w(2, 0, 0);
     issue_w(0, 1, 1); issue_a(0, 1, 1);
-    qs_wait_vmcnt<5>();                                             // bias, side rows, A | W0 | W1 of k-tile 0 (this wave's pieces) have landed
+    if (!(QS_ABL & 32)) qs_wait_vmcnt<5>();                         // bias, side rows, A | W0 | W1 of k-tile 0 (this wave's pieces) have landed   (ABL 32: WRONG results - what does this wait cost?)
     qs_barrier();
 
     // accumulators start at the bias: block (j, i) = features 96 wn + 32 j + 8 g + 4 hi + r of the tile, tokens 96 wm + 32 i + l31
@@ -307,13 +307,10 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
 #define QS_SKEW 0
 #endif
       if (QS_SKEW && wave >= 4) __builtin_amdgcn_s_sleep(QS_SKEW);   // (experiment: the two waves of a SIMD out of phase - one's softmax under the other's MFMAs)
-#pragma unroll 1
-      for (int uu = 0; uu < 2; ++uu) {
-        const int u = ((wave + (int)tcount) & 7) + 8 * uu;         // wave-uniform
-        if (u >= 14) break;
-        const int h = u >= 7 ? 1 : 0, pu = u - 7 * h, head = hp * 2 + h;
-        const int qt0 = 2 * pu, qt1 = pu == 6 ? 12 : 2 * pu + 1;
-        const bool two = pu != 6;
+      // one work unit: NT = 2 query tiles (qt0, qt1) of head h sharing every K / V fragment, or tile 12 alone (NT = 1)
+      auto unit = [&](auto NTc, const int h, const int qt0, const int qt1) {
+        constexpr int NT = decltype(NTc)::value;
+        const int head = hp * 2 + h;
         const char* k_lds = smem + h * 3 * QS_ARR;
         const char* v_lds = k_lds + QS_ARR;
         const char* q_lds = k_lds + 2 * QS_ARR;
@@ -322,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           qf[0][ks] = *reinterpret_cast<const bf16x8*>(q_lds + qs_arr_off(qt0 * 16 + fr_, ks * 4 + fg));
-          qf[1][ks] = *reinterpret_cast<const bf16x8*>(q_lds + qs_arr_off(qt1 * 16 + fr_, ks * 4 + fg));
+          if (NT == 2) qf[1][ks] = *reinterpret_cast<const bf16x8*>(q_lds + qs_arr_off(qt1 * 16 + fr_, ks * 4 + fg));
         }
         f32x4 s[2][NKT];
 #pragma unroll
@@ -334,13 +331,13 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
             if (QS_ABL & 8) continue;
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + qs_arr_off(kt * 16 + fr_, ks * 4 + fg));
             s[0][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[0][kt], 0, 0, 0);
-            s[1][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[1][kt], 0, 0, 0);
+            if (NT == 2) s[1][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[1][kt], 0, 0, 0);
           }
         }
         float msc_[2], l_[2], linv_[2];
         bool cls_[2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < NT; ++e) {
           const int qt = e ? qt1 : qt0;
           const bool cls_slot = qt * 16 + fr_ == nq;                // this lane's query column is the CLS query
 #pragma unroll
@@ -382,14 +379,14 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
         }
         f32x4 o[2][4];
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
+        for (int e = 0; e < NT; ++e)
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) o[e][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < ((QS_ABL & 16) ? 1 : (NKT + 1) / 2); ++kk) {
           union { bf16x8 v; uint32_t u[4]; } pa[2];
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
+          for (int e = 0; e < NT; ++e) {
             pa[e].u[0] = pack_bf2(s[e][2 * kk][0], s[e][2 * kk][1]);
             pa[e].u[1] = pack_bf2(s[e][2 * kk][2], s[e][2 * kk][3]);
             if (2 * kk + 1 < NKT) {
@@ -405,12 +402,11 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
             vb.hh[1] = qs_s4{0, 0, 0, 0};
             if (2 * kk + 1 < NKT) vb.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((qs_lds_s4*)(v_lds + v_off[dt] + (kk * 32 + 16) * 128));
             o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb.v, pa[0].v, o[0][dt], 0, 0, 0);
-            o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb.v, pa[1].v, o[1][dt], 0, 0, 0);
+            if (NT == 2) o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb.v, pa[1].v, o[1][dt], 0, 0, 0);
           }
         }
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          if (e == 1 && !two) break;                                // (tile 12's partner slot repeated tile 12)
+        for (int e = 0; e < NT; ++e) {
           const int qo = (e ? qt1 : qt0) * 16 + fr_;
           if (cls_[e]) {                                            // unnormalised partial of the CLS query over this frame's keys
             float* part = p.cls_part + ((seq * 12 + head) * 8 + f) * 66;
@@ -432,6 +428,15 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
             }
           }
         }
+      };
+#pragma unroll 1
+      for (int uu = 0; uu < 2; ++uu) {
+        // 12 pair units (6 per head) + the two single tiles (12 of each head) as units 12, 13; wave w takes units (w + tile count) mod 8 and that + 8: the
+        // four units u, u + 4, u + 8, u + 12 share a SIMD (waves w, w + 4), so the two SIMDs with four units are the ones that hold a single: 7 | 7 | 6 | 6 tiles
+        const int u = ((wave + (int)tcount) & 7) + 8 * uu;         // wave-uniform
+        if (u >= 14) break;
+        if (u < 12) { const int h = u >= 6 ? 1 : 0, pu = u - 6 * h; unit(qs_ic<2>{}, h, 2 * pu, 2 * pu + 1); }
+        else unit(qs_ic<1>{}, u - 12, 12, 12);
       }
     }
     qs_barrier();                                                   // every wave is out of the attention arrays: the next tile's operands may land
