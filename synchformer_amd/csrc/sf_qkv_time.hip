@@ -725,7 +725,7 @@ static int qkv_time_impl(const uint16_t* X, int64_t ldx, const uint16_t* W, int6
   SF_CHECK_ARG(tiles_m * QT_HEADS < ((int64_t)1 << 31) && n_seq * n_groups < ((int64_t)1 << 31), "sf_qkv_time_attention: too many tiles");
   a.tiles_m = (uint32_t)tiles_m;
   static int env_hc = -1;
-  if (env_hc < 0) { const char* e = getenv("SF_QT_HEAD_CHUNK"); env_hc = e ? atoi(e) : 6; if (env_hc < 1 || QT_HEADS % env_hc) env_hc = 6; }
+  if (env_hc < 0) { const char* e = getenv("SF_QT_HEAD_CHUNK"); env_hc = e ? atoi(e) : 12; if (env_hc < 1 || QT_HEADS % env_hc) env_hc = 12; }   // round 4: all 12 heads per sweep (1276-1283 us against 1288-1293 for chunks of 6 on the quadrant-phased loop; r02 measured the opposite on the old loop)
   a.head_chunk = (uint32_t)env_hc;
   int64_t blocks = (n_cu / 8) * 8;
   const int64_t need = ((tiles_m * QT_HEADS + 7) / 8) * 8;
