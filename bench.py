@@ -112,7 +112,7 @@ class GemmTimer:
 
     def __enter__(self):
         ops = self.ops
-        self.orig = {k: getattr(ops, k) for k in ('gemm', 'gemm_res_ln', 'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention', 'qkv_time_attention_mx', 'qkv_space_attention')}
+        self.orig = {k: getattr(ops, k) for k in ('gemm', 'gemm_res_ln', 'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention', 'qkv_time_attention_mx', 'qkv_space_attention', 'qkv_space_attention_mx')}
         o = self.orig
 
         def timed(a, w, bias, out, *, M=None, **kw):
@@ -177,7 +177,16 @@ class GemmTimer:
             return self._rec(lambda: o['qkv_space_attention'](x, w, bias, side, out, partials, n_seq=n_seq, scale=scale, n_tok=n_tok),
                              2.0 * m * n * k, nbytes, 'qkv_space_attn_kernel', 'N=2304 K=768')
 
+        def timed_qs_mx(x_q, x_s, w_q, w_s, bias, side, out, partials, *, n_seq, scale, out_scales=None, n_tok=196):
+            if not self.enabled:
+                return o['qkv_space_attention_mx'](x_q, x_s, w_q, w_s, bias, side, out, partials, n_seq=n_seq, scale=scale, out_scales=out_scales, n_tok=n_tok)
+            m, n, k = n_seq * 8 * 192, 2304, 768
+            nbytes = n_seq * 8 * n_tok * k + n * k + (n_seq * 8 * n_tok + n) * k // 32 + n_seq * 8 * n_tok * 768 * out.element_size()
+            return self._rec(lambda: o['qkv_space_attention_mx'](x_q, x_s, w_q, w_s, bias, side, out, partials, n_seq=n_seq, scale=scale, out_scales=out_scales, n_tok=n_tok),
+                             2.0 * m * n * k, nbytes, 'qkv_space_attn_mx_kernel', 'N=2304 K=768', 'mxfp8')
+
         ops.qkv_space_attention = timed_qs
+        ops.qkv_space_attention_mx = timed_qs_mx
         ops.gemm, ops.gemm_res_ln, ops.gemm_mxfp8, ops.gemm_mx_res_ln, ops.qkv_time_attention = timed, timed_ln, timed_mx, timed_mxln, timed_qt
         ops.qkv_time_attention_mx = timed_qt_mx
         # the train steps call three GEMM entry points straight on the C ABI (weight gradients, fc1 + GELU with two outputs): wrap those on the library object

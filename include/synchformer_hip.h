@@ -213,6 +213,15 @@ int sf_attention_cls_combine_mx(const float* partials, int n_part, uint8_t* out_
 int sf_qkv_space_attention(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
                            uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, void* stream);
 
+/* sf_qkv_space_attention on MXFP8 operands (fp8 towers): X (rows, 768) / W (2304, 768) e4m3 bytes with stage-major scale planes (6 planes, one dword per row, ldsx / ldsw
+ * bytes apart: what sf_gemm_mx_res_ln768 / sf_quantize_mxfp8 write); side (n_seq * 33, 2304) bf16 from sf_gemm_mxfp8 on gathered copies of the side rows and their scale
+ * dwords.  Output EITHER out (bf16) OR out_q / out_s (e4m3 bytes (rows, 768), row stride ldq, + E8M0 bytes in the scale planes [6][rows][4], splane bytes apart: byte for
+ * byte sf_quantize_mxfp8 of the bf16 output; buffers of their own, not X / sX); the other pointer NULL.  cls_partial as in sf_qkv_space_attention.  Replaces sf_gemm_mxfp8
+ * (spatial qkv, bf16 output) + sf_attention_cls_partial(_mx) on the MX path. */
+int sf_qkv_space_attention_mx(const uint8_t* X, int64_t ldx, const uint8_t* sX, int64_t ldsx, const uint8_t* W, int64_t ldw, const uint8_t* sW, int64_t ldsw,
+                              const float* bias, const uint16_t* side, int64_t lds_, uint16_t* out, int64_t ldo, uint8_t* out_q, int64_t ldq, uint8_t* out_s,
+                              int64_t splane, float* cls_partial, int64_t n_seq, int n_tok, float scale, void* stream);
+
 /* The temporal half of DividedSpaceTimeBlock in ONE launch (vit_helper.py:366 `self.timeattn(self.norm3(x), ..., 'b (f n) d', '(b n) f d')`,
  * DividedAttention.forward vit_helper.py:97-150): qkv projection (vit_helper.py:107) of every PATCH token + the 8-frame attention over
  * [CLS key; the patch's 8 frames] in the GEMM's epilogue - the 2304-wide projection never reaches HBM.

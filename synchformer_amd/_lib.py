@@ -33,6 +33,7 @@ SIGNATURES = {
     'sf_qkv_time_attention_mx_q': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i32, _f32, _ptr],
     'sf_gemm_mx_res_ln768': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _f32, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr],
     'sf_qkv_space_attention': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i32, _f32, _ptr],
+    'sf_qkv_space_attention_mx': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i32, _f32, _ptr],
     'sf_gemm_force_config': [_i32],
     'sf_gemm_bf16_auto_config': [_i64, _i64, _i64, _i32],
     'sf_gemm_bf16_gelu_dual': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr],

@@ -51,7 +51,18 @@ struct QsArgs {
   uint32_t n_frames;                   // n_seq * 8
   uint32_t pair_chunk;                 // head pairs per sweep over an XCD's frames (divides 6)
   float scale;
+  // MX (template parameter): X / W are e4m3 BYTES (ldx / ldw in bytes) with stage-major E8M0 scale planes (one dword per row per 128 k, ldsx / ldsw bytes between planes)
+  const uint8_t* sX = nullptr; int64_t ldsx = 0;
+  const uint8_t* sW = nullptr; int64_t ldsw = 0;
+  // MX, optional: the attention output as MXFP8 (e4m3 bytes, row stride ldq, + E8M0 bytes in the scale planes [6][rows][4], splane bytes apart) instead of bf16 `out`
+  uint8_t* out_q = nullptr; int64_t ldq = 0; uint8_t* out_s = nullptr; int64_t splane = 0;
 };
+#define QS_SC_OFF (148 * 1024)         // MX: the k-tile's scale dwords, two parities x (192 token rows | 3 x 128 part rows of W) = 2 x 2304 B
+#define QS_SC_BYTES 2304
+#ifndef QS_MXOUT
+#define QS_MXOUT 1
+#endif
+typedef __attribute__((ext_vector_type(8))) int qs_i32x8;
 
 typedef short qs_s4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) qs_s4 qs_lds_s4;
@@ -81,7 +92,9 @@ __device__ __forceinline__ int qs_arr_off(int row, int chunk) { return row * 128
 
 template <int V> using qs_ic = std::integral_constant<int, V>;
 
-__global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
+template <bool MX>
+__device__ __forceinline__ void qkv_space_attn_body(const QsArgs& p) {
+  constexpr int ESZ = MX ? 1 : 2;                                 // bytes per operand element
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,49 +111,79 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
 
   // ---- tile-invariant lane offsets of the LDS-DMA pieces -----------------------------------------------------------------------------
   // A piece pc of this wave = tile rows (3 wave + pc) * 8 .. + 7; lane (r = lane >> 3, chunk slot = lane & 7) -> LDS row-linear, source chunk XOR-swizzled
-  uint32_t voff_a[3], voff_w[3][2];
-#pragma unroll
-  for (int pc = 0; pc < 3; ++pc) {
-    const int r = (wave * 3 + pc) * 8 + (lane >> 3);
-    voff_a[pc] = (uint32_t)((int64_t)r * p.ldx * 2 + ((((lane & 7) ^ ((r >> 1) & 7))) << 4));
-  }
-  // W part j, piece pc of this wave = part rows (2 wave + pc) * 8 .. + 7; part row pr = 32 wn' + rr <-> tile column wn' * 96 + 32 j + rr <-> row
-  // which * 768 + hd * 64 + feat of W (the head pair's offset rides in the SGPR base)
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int pc = 0; pc < 2; ++pc) {
-      const int pr = (wave * 2 + pc) * 8 + (lane >> 3);
-      const int c = (pr >> 5) * 96 + j * 32 + (pr & 31);
-      const int hd = c / 192, within = c - hd * 192;
-      const int grow = (within >> 6) * QS_D + hd * 64 + (within & 63);
-      voff_w[j][pc] = (uint32_t)((int64_t)grow * p.ldw * 2 + ((((lane & 7) ^ ((pr >> 1) & 7))) << 4));
-    }
+  uint32_t voff_a = 0, voff_w[3] = {0, 0, 0}, sc_voff = 0;         // lane offsets of the LDS-DMA pieces: re-derived at the top of every tile (not kept live across the attention)
+  const uint32_t a8 = (uint32_t)(8 * p.ldx * ESZ), w8 = (uint32_t)(8 * p.ldw * ESZ);
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane(qs_lds_addr(smem));
   const uint32_t lds_a_w = __builtin_amdgcn_readfirstlane(lds0 + wave * 3072);
   const uint32_t lds_w_w = __builtin_amdgcn_readfirstlane(lds0 + QS_A_BYTES + wave * 2048);
 
   const char* xbase; const char* wbase;
-  uint32_t fr; int hp;
+  uint32_t fr; int hp; int64_t xrow0;
   auto set_tile = [&](uint32_t tt) {
     const uint32_t c = tt / chunk_tiles, r = tt - c * chunk_tiles;
     fr = fr0 + r / hc; hp = (int)(c * hc + r % hc);
     const int64_t seq = fr >> 3; const int f = (int)(fr & 7u);
-    xbase = reinterpret_cast<const char*>(p.X + (seq * p.seq_rows + 1 + (int64_t)f * QS_TOK) * p.ldx);
-    wbase = reinterpret_cast<const char*>(p.W + (int64_t)hp * 128 * p.ldw);
+    xrow0 = seq * p.seq_rows + 1 + (int64_t)f * QS_TOK;
+    xbase = reinterpret_cast<const char*>(p.X) + xrow0 * p.ldx * ESZ;
+    wbase = reinterpret_cast<const char*>(p.W) + (int64_t)hp * 128 * p.ldw * ESZ;
   };
-  auto issue_a = [&](int pc, int S, int kt) { qs_dma1(voff_a[pc], xbase + kt * 128, lds_a_w + S * QS_STAGE + pc * 1024); };
+  // MX: the scale dwords of a k-tile - 192 token rows (768 contiguous bytes of plane kt of sX) and the tile's 384 W rows (12 runs of 32 rows of plane kt of sW, in
+  // part order: area index j * 128 + 32 wn' + rr) - as 16-byte LDS-DMA lanes: 48 + 96 lanes = three pieces.  EVERY wave issues exactly one of them (wave % 3; the
+  // copies land the same bytes on the same addresses), so that all waves count the same number of vector-memory operations per k-tile
+  const int sc_seg = wave % 3;
+  const int sc_lanes = sc_seg == 0 ? 48 : (sc_seg == 1 ? 64 : 32);
+  // tile-invariant lane offsets (row strides are multiples of 128 bytes - launcher check -, so the low 7 bits of an offset are its chunk slot: the piece 8 rows
+  // further down is (offset ^ 64) + 8 rows, computed at issue time instead of held in a register per piece).
+  // A piece pc of this wave = tile rows (3 wave + pc) * 8 .. + 7; lane (r = lane >> 3, chunk slot = lane & 7) -> LDS row-linear, source chunk XOR-swizzled.
+  // W part j, piece pc of this wave = part rows (2 wave + pc) * 8 .. + 7; part row pr = 32 wn' + rr <-> tile column wn' * 96 + 32 j + rr <-> row
+  // which * 768 + hd * 64 + feat of W (the head pair's offset rides in the SGPR base)
+  auto derive_offsets = [&]() {
+    int dtid = threadIdx.x;
+    asm volatile("" : "+v"(dtid));
+    const int dl = dtid & 63;
+    {
+      const int r = wave * 3 * 8 + (dl >> 3);
+      voff_a = (uint32_t)((int64_t)r * p.ldx * ESZ + ((((dl & 7) ^ ((r >> 1) & 7))) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int pr = wave * 2 * 8 + (dl >> 3);
+      const int c = (pr >> 5) * 96 + j * 32 + (pr & 31);
+      const int hd = c / 192, within = c - hd * 192;
+      const int grow = (within >> 6) * QS_D + hd * 64 + (within & 63);
+      voff_w[j] = (uint32_t)((int64_t)grow * p.ldw * ESZ + ((((dl & 7) ^ ((pr >> 1) & 7))) << 4));
+    }
+    if (MX) {
+      if (sc_seg == 0) sc_voff = (uint32_t)dl * 16u;
+      else {
+        const int L = (sc_seg == 1 ? 0 : 64) + dl, run = L >> 3, j = run >> 2, wnp = run & 3;
+        const int c = wnp * 96 + j * 32 + (L & 7) * 4;
+        const int hd = c / 192, within = c - hd * 192;
+        sc_voff = (uint32_t)(((within >> 6) * QS_D + hd * 64 + (within & 63)) * 4);
+      }
+    }
+  };
+  const uint32_t sc_lds = __builtin_amdgcn_readfirstlane(lds0 + QS_SC_OFF + (sc_seg == 0 ? 0 : (sc_seg == 1 ? 768 : 768 + 1024)));
+  auto issue_sc = [&](int kt) {
+    const char* base = sc_seg == 0 ? reinterpret_cast<const char*>(p.sX) + (int64_t)kt * p.ldsx + xrow0 * 4
+                                   : reinterpret_cast<const char*>(p.sW) + (int64_t)kt * p.ldsw + (int64_t)hp * 512;
+    if (lane < sc_lanes) qs_dma1(sc_voff, base, sc_lds + (kt & 1) * QS_SC_BYTES);
+  };
+  auto issue_a = [&](int pc, int S, int kt) {                       // piece pc: 8 pc rows further down; the chunk swizzle flips bit 2 with every 8 rows
+    qs_dma1(((pc & 1) ? (voff_a ^ 64u) : voff_a) + (uint32_t)pc * a8, xbase + kt * 128, lds_a_w + S * QS_STAGE + pc * 1024);
+  };
   auto issue_w = [&](int j, int S, int kt) {
-    qs_dma1(voff_w[j][0], wbase + kt * 128, lds_w_w + S * QS_STAGE + j * QS_W_PART);
-    qs_dma1(voff_w[j][1], wbase + kt * 128, lds_w_w + S * QS_STAGE + j * QS_W_PART + 1024);
+    qs_dma1(voff_w[j], wbase + kt * 128, lds_w_w + S * QS_STAGE + j * QS_W_PART);
+    qs_dma1((voff_w[j] ^ 64u) + w8, wbase + kt * 128, lds_w_w + S * QS_STAGE + j * QS_W_PART + 1024);
   };
 
-  constexpr int nk = QS_D / 64;                                     // 12 k-tiles
+  constexpr int nk = MX ? QS_D / 128 : QS_D / 64;                   // 12 k-tiles of 64 bf16 / 6 of 128 fp8: 128 bytes per row either way
   const float sc2 = p.scale * 1.44269504088896f;                   // softmax in base 2
   uint32_t tcount = 0;
 
   for (;;) {
     set_tile(t);
+    derive_offsets();
     const int64_t seq = fr >> 3; const int f = (int)(fr & 7u);
     // ---- prologue: bias, side rows, k-tile 0 and W0 | A0 of k-tile 1 (the previous tile's attention is over: barrier at the bottom of the loop) ----------
     if (wave < 6) {                                                 // 6 x 64 bias floats: tile columns 64 wave .. + 63 = (head hd = wave / 3, q | k | v = wave % 3)
@@ -156,6 +199,7 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
         qs_dma1(voff, reinterpret_cast<const char*>(p.side + seq * 33 * p.lds_ + hp * 128), lds0 + QS_SIDE_OFF + wave * 1024);
       }
     }
+    if (MX) issue_sc(0);
     issue_w(0, 0, 0); issue_a(0, 0, 0);
     issue_w(1, 0, 0); issue_a(1, 0, 0); issue_a(2, 0, 0);
     issue_w(2, 0, 0);
@@ -177,29 +221,47 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
         }
     }
     {
-      int fo[4];
+      int fo[4], fs_x = 0, fs_w = 0, shi = 0;                       // (MX: addresses of this lane's scale dwords - its token row of block 0, row l31 of its W part 0 - and 8 * (lane >> 5))
       {
         int ptid = threadIdx.x;
         asm volatile("" : "+v"(ptid));
         const int pl31 = ptid & 31, phi = (ptid & 63) >> 5;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) fo[kk] = pl31 * 128 + (((kk * 2 + phi) ^ ((pl31 >> 1) & 7)) << 4);
+        if (MX) { fs_x = QS_SC_OFF + (wm * 96 + pl31) * 4; fs_w = QS_SC_OFF + 768 + (wn * 32 + pl31) * 4; shi = phi * 8; }
       }
       const int a_base = wm * 96 * 128, w_base = QS_A_BYTES + wn * 32 * 128;
-      bf16x8 xf[3][4], wf[4];
-      auto read_w = [&](const char* st, int j) {
+      // fragments as 32-byte pairs (kk = 2 k2, 2 k2 + 1): the two 16-byte reads a lane supplies to ONE 64-deep scaled MFMA sit in eight consecutive registers, no copies
+      union QsFrag { bf16x8 h[2]; qs_i32x8 v; };
+      QsFrag xf[3][2], wf[2];
+      uint32_t sx[3] = {0u, 0u, 0u}, sw = 0u;                        // MX: this lane's scale dwords of the k-tile (token row of block i; W row of the current part), >> shi
+      auto read_w = [&](const char* st, int j, int par) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) wf[kk] = *reinterpret_cast<const bf16x8*>(st + w_base + j * QS_W_PART + fo[kk]);
+        for (int kk = 0; kk < 4; ++kk) wf[kk >> 1].h[kk & 1] = *reinterpret_cast<const bf16x8*>(st + w_base + j * QS_W_PART + fo[kk]);
+        if (MX) sw = *reinterpret_cast<const uint32_t*>(smem + fs_w + j * 512 + par * QS_SC_BYTES) >> shi;
       };
       auto mma = [&](auto Jc) {
         constexpr int J = decltype(Jc)::value;
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (MX) {
+          // a 128-byte LDS row = 128 fp8 k: fragments 2 k2 and 2 k2 + 1 are the 2 x 16 bytes a lane supplies to ONE 64-deep scaled MFMA (as qkv_time_attn_kernel<true, true>)
+#pragma unroll
+          // scale operands: the k-tile's dword of the row, shifted by 8 * (lane >> 5) so that BYTE 2 k2 is this half-wave's 32-k block of MFMA k2 - selected by the
+          // instruction's op_sel (byte index of the scale register), no extraction arithmetic inside the matrix segment
+          for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              if (k2 == 0) acc[J][i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[0].v, xf[i][0].v, acc[J][i], 0 /* e4m3 */, 0 /* e4m3 */, 0, (int)sw, 0, (int)sx[i]);
+              else acc[J][i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[1].v, xf[i][1].v, acc[J][i], 0, 0, 2, (int)sw, 2, (int)sx[i]);
+            }
+          }
+        } else
         if (!(QS_ABL & 2)) {
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) acc[J][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk], xf[i][kk], acc[J][i], 0, 0, 0);
-        } else asm volatile("" :: "v"(wf[0]), "v"(wf[3]), "v"(xf[0][0]), "v"(xf[2][3]));
+            for (int i = 0; i < 3; ++i) acc[J][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk >> 1].h[kk & 1], xf[i][kk >> 1].h[kk & 1], acc[J][i], 0, 0, 0);
+        } else asm volatile("" :: "v"(wf[0].v), "v"(wf[1].v), "v"(xf[0][0].v), "v"(xf[2][1].v));
         asm volatile("" : "+v"(acc[J][0]), "+v"(acc[J][1]), "+v"(acc[J][2]));   // pins the (pure) MFMAs inside their matrix segment
         __builtin_amdgcn_s_setprio(0);
       };
@@ -211,8 +273,12 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) xf[i][kk] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 4096 + fo[kk]);
-        read_w(st, 0);
+          for (int kk = 0; kk < 4; ++kk) xf[i][kk >> 1].h[kk & 1] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 4096 + fo[kk]);
+        read_w(st, 0, S);                                            // (nk is even: the parity of k-tile kt is the stage S)
+        if (MX) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) sx[i] = *reinterpret_cast<const uint32_t*>(smem + fs_x + i * 128 + S * QS_SC_BYTES) >> shi;
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (ld1) { issue_w(1, S ^ 1, kt + 1); issue_a(1, S ^ 1, kt + 1); issue_a(2, S ^ 1, kt + 1); }      // W1, A1, A2 of k-tile kt+1
         qs_barrier();
@@ -221,16 +287,17 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         qs_barrier();
         // ---- phase 1: feature block 1 ----
-        read_w(st, 1);
+        read_w(st, 1, S);
         __builtin_amdgcn_sched_barrier(0);
-        if (ld1) { issue_w(2, S ^ 1, kt + 1); qs_wait_vmcnt<9>(); } else qs_wait_vmcnt<0>();               // W2 of k-tile kt+1 issued; W2 of this k-tile has landed
+        // (MX: the scale piece of k-tile kt+1 goes in FRONT of W2 - the phase-2 wait below then retires it with A | W0 | W1 - into the other parity's area, last read in phase 0 of kt-1)
+        if (ld1) { if (MX) issue_sc(kt + 1); issue_w(2, S ^ 1, kt + 1); if (MX) qs_wait_vmcnt<10>(); else qs_wait_vmcnt<9>(); } else qs_wait_vmcnt<0>();   // W2 of k-tile kt+1 issued; W2 of this k-tile has landed
         qs_barrier();
         __builtin_amdgcn_sched_barrier(0);
         mma(qs_ic<1>{});
         __builtin_amdgcn_sched_barrier(0);
         qs_barrier();
         // ---- phase 2: feature block 2 ----
-        read_w(st, 2);
+        read_w(st, 2, S);
         __builtin_amdgcn_sched_barrier(0);
         if (ld2) { issue_w(0, S, kt + 2); issue_a(0, S, kt + 2); qs_wait_vmcnt<5>(); }                     // W0, A0 of k-tile kt+2; A | W0 | W1 of k-tile kt+1 have landed
         else if (ld1) qs_wait_vmcnt<2>();
@@ -242,6 +309,7 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
         qs_barrier();
       };
       if (wm == 1) qs_barrier();                                    // waves 4-7 run one barrier behind waves 0-3
+#pragma unroll 1
       for (int kt = 0; kt < nk; kt += 2) {
         ktile(qs_ic<0>{}, kt, true, kt + 2 < nk);
         ktile(qs_ic<1>{}, kt + 1, kt + 2 < nk, kt + 3 < nk);
@@ -416,6 +484,35 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) part[2 + dt * 16 + fg * 4 + r] = o[e][dt][r];
           }
+          if (MX && QS_MXOUT && p.out_q) {
+            // MXFP8 output (the A operand of the MX projection that follows), exactly as attn_mfma_kernel<64, 13, true>: the head's 64 dims are two scale blocks; block b =
+            // dim tiles 2b, 2b + 1, 8 values in this lane and 8 in each of the lanes fg' != fg of the same query (16 and 32 lanes away); quantised from the bf16-rounded value
+            const float linv = linv_[e];
+            const int64_t row = xrow0 + (qo < nq ? qo : nq - 1);
+            uint8_t* qrow = p.out_q + row * p.ldq + head * 64 + (fg & 1) * 16 + (fg >> 1) * 8;
+            uint32_t be2 = 0;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              float fv[8];
+#pragma unroll
+              for (int hh = 0; hh < 2; ++hh) {
+                const uint32_t p01 = pack_bf2(o[e][2 * b + hh][0] * linv, o[e][2 * b + hh][1] * linv), p23 = pack_bf2(o[e][2 * b + hh][2] * linv, o[e][2 * b + hh][3] * linv);
+                fv[hh * 4 + 0] = __uint_as_float(p01 << 16); fv[hh * 4 + 1] = __uint_as_float(p01 & 0xffff0000u);
+                fv[hh * 4 + 2] = __uint_as_float(p23 << 16); fv[hh * 4 + 3] = __uint_as_float(p23 & 0xffff0000u);
+              }
+              float amax = fmaxf(fmaxf(fmaxf(fabsf(fv[0]), fabsf(fv[1])), fmaxf(fabsf(fv[2]), fabsf(fv[3]))), fmaxf(fmaxf(fabsf(fv[4]), fabsf(fv[5])), fmaxf(fabsf(fv[6]), fabsf(fv[7]))));
+              amax = fmaxf(amax, __shfl_xor(amax, 16, 64)); amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+              const int be = sf_mx_exp(amax);
+              const float inv = sf_mx_inv(be);
+              be2 |= (uint32_t)be << (8 * b);
+              const uint32_t d_lo = sf_fp8x4(fv, inv), d_hi = sf_fp8x4(fv + 4, inv);      // dims 32 b + fg * 4 + 0..3 and 32 b + 16 + fg * 4 + 0..3
+              const uint32_t got = (uint32_t)__shfl_xor((int)((fg & 1) ? d_lo : d_hi), 16, 64);
+              uint2 w;
+              if (fg & 1) { w.x = got; w.y = d_hi; } else { w.x = d_lo; w.y = got; }
+              if (qo < nq) *reinterpret_cast<uint2*>(qrow + b * 32) = w;
+            }
+            if (qo < nq && fg == 0) *reinterpret_cast<uint16_t*>(p.out_s + (int64_t)(head >> 1) * p.splane + row * 4 + (head & 1) * 2) = (uint16_t)be2;
+          } else
           if (qo < nq) {
             bf16_t* orow = obase + (int64_t)qo * p.ldo + fg * 4;
             const float linv = linv_[e];
@@ -445,6 +542,9 @@ __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) {
     if (t >= t_end) break;
   }
 }
+
+__global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) { qkv_space_attn_body<false>(p); }
+__global__ __launch_bounds__(512, 2) void qkv_space_attn_mx_kernel(QsArgs p) { qkv_space_attn_body<true>(p); }
 
 // X (n_seq * seq_rows, 768) bf16 = norm1(x), seq_rows = 1 + 8 * 196 rows [CLS; frame-major patches] per sequence; W (2304, 768) bf16 = attn.qkv.weight, bias 2304 fp32 or
 // NULL; side (n_seq * 33, 2304) bf16 = the same projection of [the CLS row; per frame f its tokens 192 .. 195] (row seq * 33, rows seq * 33 + 1 + 4 f + i), computed by the
@@ -478,6 +578,45 @@ extern "C" int sf_qkv_space_attention(const uint16_t* X, int64_t ldx, const uint
   const int64_t need = ((n_seq * 8 * 6 + 7) / 8) * 8;
   if (blocks > need) blocks = need;
   hipLaunchKernelGGL(qkv_space_attn_kernel, dim3((unsigned)blocks), dim3(512), QS_LDS, (hipStream_t)stream, a);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// The same launch on MXFP8 operands (fp8 towers of the synchronizability fine-tune): X (rows, 768) e4m3 bytes with its stage-major scale planes sX (6 planes, ldsx bytes
+// apart, one dword per row) - what sf_gemm_mx_res_ln768 writes -, W (2304, 768) e4m3 + sW (6 planes of 2304 dwords); side (n_seq * 33, 2304) bf16 as in
+// sf_qkv_space_attention (from sf_gemm_mxfp8 on gathered copies of the rows and of their scale dwords).  The attention runs on the bf16-rounded projection, exactly as on the
+// un-fused MX path (sf_gemm_mxfp8 with a bf16 output, then sf_attention_cls_partial(_mx)).  Output: EITHER out (bf16, patch rows) OR out_q / out_s (e4m3 bytes (rows, 768) +
+// the scale planes [6][rows][4], splane bytes apart: byte for byte sf_quantize_mxfp8 of the bf16 output - the A operand of the MX projection that follows; buffers of
+// their own, not X / sX).  Replaces sf_gemm_mxfp8 (spatial qkv) + sf_attention_cls_partial_mx.
+extern "C" int sf_qkv_space_attention_mx(const uint8_t* X, int64_t ldx, const uint8_t* sX, int64_t ldsx, const uint8_t* W, int64_t ldw, const uint8_t* sW, int64_t ldsw,
+                                         const float* bias, const uint16_t* side, int64_t lds_, uint16_t* out, int64_t ldo, uint8_t* out_q, int64_t ldq, uint8_t* out_s,
+                                         int64_t splane, float* cls_partial, int64_t n_seq, int n_tok, float scale, void* stream) {
+  SF_CHECK_ARG(X && sX && W && sW && side && cls_partial && ((out != nullptr) != (out_q != nullptr)), "sf_qkv_space_attention_mx: null pointer (exactly one of out / out_q)");
+  SF_CHECK_ARG(n_tok == QS_TOK, "sf_qkv_space_attention_mx: built for 196-token frames (8 frames per sequence), got %d", n_tok);
+  SF_CHECK_ARG((ldx % 16) == 0 && (ldw % 16) == 0 && ldx >= QS_D && ldw >= QS_D && (lds_ % 8) == 0 && lds_ >= 3 * QS_D, "sf_qkv_space_attention_mx: bad row strides");
+  SF_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)sX % 16) == 0 && ((uintptr_t)sW % 16) == 0 && ((uintptr_t)side % 16) == 0 &&
+                   (!bias || ((uintptr_t)bias % 16) == 0) && ((uintptr_t)cls_partial % 8) == 0, "sf_qkv_space_attention_mx: operands must be 16-byte aligned");
+  if (out) SF_CHECK_ARG(((uintptr_t)out % 8) == 0 && (ldo % 4) == 0 && ldo >= QS_D, "sf_qkv_space_attention_mx: out must be an 8-byte aligned bf16 buffer");
+  if (out_q) SF_CHECK_ARG(out_s && ((uintptr_t)out_q % 8) == 0 && ((uintptr_t)out_s % 2) == 0 && (ldq % 8) == 0 && ldq >= QS_D && out_q != X && out_s != sX,
+                          "sf_qkv_space_attention_mx: out_q (8-byte aligned, ldq %% 8 == 0) / out_s must be buffers of their own");
+  if (n_seq <= 0) return 0;
+  const int64_t seq_rows = 1 + 8 * (int64_t)QS_TOK;
+  if (out_q) SF_CHECK_ARG(splane >= n_seq * seq_rows * 4, "sf_qkv_space_attention_mx: a scale plane holds 4 bytes per row");
+  SF_CHECK_ARG((ldsx % 16) == 0 && (ldsw % 16) == 0 && ldsx >= n_seq * seq_rows * 4 && ldsw >= 3 * QS_D * 4, "sf_qkv_space_attention_mx: scale planes must hold one dword per row of X / W");
+  SF_CHECK_ARG((int64_t)QS_TOK * ldx < ((int64_t)1 << 32) && (int64_t)3 * QS_D * ldw < ((int64_t)1 << 32) && (int64_t)33 * lds_ * 2 < ((int64_t)1 << 32),
+               "sf_qkv_space_attention_mx: a frame of X, W and a sequence's side rows must stay below 4 GiB (32-bit lane offsets)");
+  SF_CHECK_ARG(n_seq * 8 * 6 < ((int64_t)1 << 31), "sf_qkv_space_attention_mx: too many tiles");
+  if (int rc = sf_prepare_kernel((const void*)qkv_space_attn_mx_kernel, QS_LDS, "sf_qkv_space_attention_mx")) return rc;
+  const int n_cu = sf_cu_count("sf_qkv_space_attention_mx");
+  if (n_cu <= 0) return -1;
+  QsArgs a;
+  a.X = reinterpret_cast<const bf16_t*>(X); a.ldx = ldx; a.W = reinterpret_cast<const bf16_t*>(W); a.ldw = ldw; a.bias = bias; a.side = side; a.lds_ = lds_;
+  a.out = out; a.ldo = ldo; a.cls_part = cls_partial; a.seq_rows = seq_rows; a.n_frames = (uint32_t)(n_seq * 8); a.scale = scale; a.pair_chunk = 6;
+  a.sX = sX; a.ldsx = ldsx; a.sW = sW; a.ldsw = ldsw; a.out_q = out_q; a.ldq = ldq; a.out_s = out_s; a.splane = splane;
+  int64_t blocks = (n_cu / 8) * 8;
+  const int64_t need = ((n_seq * 8 * 6 + 7) / 8) * 8;
+  if (blocks > need) blocks = need;
+  hipLaunchKernelGGL(qkv_space_attn_mx_kernel, dim3((unsigned)blocks), dim3(512), QS_LDS, (hipStream_t)stream, a);
   SF_LAUNCH_CHECK();
   return 0;
 }

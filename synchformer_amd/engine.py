@@ -400,6 +400,23 @@ class SynchformerEngine:
             aq = self._buf('AQ', rows * D, torch.uint8).view(rows, D)         # the time attention's output as the projection's MXFP8 operand
             as_ = self._buf('AS', 6 * rows_p * 4, torch.uint8).view(6, rows_p, 4)
         fuse_attn = self.fuse_mx_attn and tok_keep is None and os.environ.get('SF_CLS_FUSION', 'space') != 'none'
+        # round 4: spatial qkv + space attention in one launch on the MX operands as well (sf_qkv_space_attention_mx, MXFP8 output); the side rows - CLS + the
+        # last 4 tokens of every frame - go through sf_gemm_mxfp8 on gathered copies of the rows and of their scale dwords
+        fuse_space = self.fuse_space and fuse_attn and rows >= 128 * 64
+        if fuse_space:
+            if not fuse_time:
+                aq = self._buf('AQ', rows * D, torch.uint8).view(rows, D)
+                as_ = self._buf('AS', 6 * rows_p * 4, torch.uint8).view(6, rows_p, 4)
+            n33 = n * 33
+            n33_p = ((n33 + 255) // 256) * 256
+            sq = self._buf('SQ', n33 * D, torch.uint8).view(n33, D)
+            ss = self._buf('SS', 6 * n33_p * 4, torch.uint8).view(6, n33_p, 4)
+            side = self._buf('side', n33 * 3 * D, torch.bfloat16).view(n33, 3 * D)
+            idx = self._ws.get('side_idx')
+            if idx is None or idx.numel() != n33:
+                seq = torch.arange(n, device=self.dev).view(n, 1) * VIS_L
+                left = 1 + torch.arange(8, device=self.dev).view(8, 1) * 196 + 192 + torch.arange(4, device=self.dev).view(1, 4)
+                idx = self._ws['side_idx'] = torch.cat([seq, seq + left.reshape(1, 32)], 1).reshape(-1)
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         nb = len(self.v_blocks)
         for bi, b in enumerate(self.v_blocks):
@@ -430,8 +447,19 @@ class SynchformerEngine:
             else:
                 ops.gemm_mxfp8(tq, ts, mx['t_proj'].q, mx['t_proj'].s, mx['t_proj'].b, X, residual=X)
                 ops.layernorm_mxfp8(X, b['norm1'].g, b['norm1'].b, xq, xs, EPS_VIS)
-            ops.gemm_mxfp8(xq, xs, mx['s_qkv'].q, mx['s_qkv'].s, mx['s_qkv'].b, qkv)
-            if fuse_attn:
+            if fuse_space:
+                torch.index_select(xq, 0, idx, out=sq)
+                ss[:, :n33].copy_(xs.index_select(1, idx))
+                ops.gemm_mxfp8(sq, ss, mx['s_qkv'].q, mx['s_qkv'].s, mx['s_qkv'].b, side)
+                ops.qkv_space_attention_mx(xq, xs, mx['s_qkv'].q, mx['s_qkv'].s, mx['s_qkv'].b, side, aq, part, n_seq=n, scale=0.125, out_scales=as_)
+                ops.attention_cls_combine_mx(part, aq, as_, n_part=8, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
+                pq, ps = aq, as_
+            else:
+                ops.gemm_mxfp8(xq, xs, mx['s_qkv'].q, mx['s_qkv'].s, mx['s_qkv'].b, qkv)
+                pq, ps = xq, xs
+            if fuse_space:
+                pass
+            elif fuse_attn:
                 # the space attention writes the projection's MXFP8 operand itself (sf_attention_cls_partial_mx): no bf16 output, no quantisation pass
                 ops.attention_cls_partial_mx(q, k, v, xq, xs, part, n_seq=n, seq_rows=VIS_L, n_groups=8, row0=1, group_stride=196, tok_stride=1, n_tok=196,
                                              cls_row=0, heads=12, scale=0.125)
@@ -440,9 +468,9 @@ class SynchformerEngine:
                 divided('space')
                 ops.quantize_mxfp8(xn, xq, xs)
             if fuse:
-                ops.gemm_mx_res_ln(xq, xs, mx['s_proj'].q, mx['s_proj'].s, mx['s_proj'].b, X, b['norm2'].g, b['norm2'].b, xq, xs, EPS_VIS)
+                ops.gemm_mx_res_ln(pq, ps, mx['s_proj'].q, mx['s_proj'].s, mx['s_proj'].b, X, b['norm2'].g, b['norm2'].b, xq, xs, EPS_VIS)
             else:
-                ops.gemm_mxfp8(xq, xs, mx['s_proj'].q, mx['s_proj'].s, mx['s_proj'].b, X, residual=X)
+                ops.gemm_mxfp8(pq, ps, mx['s_proj'].q, mx['s_proj'].s, mx['s_proj'].b, X, residual=X)
                 ops.layernorm_mxfp8(X, b['norm2'].g, b['norm2'].b, xq, xs, EPS_VIS)
             ops.gemm_mxfp8(xq, xs, mx['fc1'].q, mx['fc1'].s, mx['fc1'].b, hq, gelu=True, out_scales=hs)
             if fuse and bi + 1 < nb:

@@ -336,6 +336,30 @@ def qkv_space_attention(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.T
     return out
 
 
+def qkv_space_attention_mx(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out: torch.Tensor,
+                           partials: torch.Tensor, *, n_seq: int, scale: float, out_scales: Optional[torch.Tensor] = None, n_tok: int = 196):
+    """qkv_space_attention on MXFP8 operands: x_q (n_seq * 1569, 768) uint8 e4m3 + x_s (6, >= rows, 4) scale planes, w_q (2304, 768) + w_s (6, >= 2304, 4); side
+    (n_seq * 33, 2304) bf16.  With a uint8 `out` and `out_scales` (6, >= rows, 4) the patch rows are written as MXFP8 (= quantize_mxfp8 of the bf16 output; buffers of
+    their own, not x_q / x_s), else `out` is bf16."""
+    assert x_q.dtype == w_q.dtype == x_s.dtype == w_s.dtype == torch.uint8 and side.dtype == torch.bfloat16 and partials.dtype == torch.float32
+    assert (out.dtype == torch.uint8) == (out_scales is not None) and out.dtype in (torch.uint8, torch.bfloat16)
+    rows = n_seq * (1 + 8 * n_tok)
+    assert x_q.shape[1] == 768 and tuple(w_q.shape) == (2304, 768) and side.shape[0] >= n_seq * 33 and side.shape[1] == 2304 and out.shape[1] == 768
+    assert x_q.shape[0] >= rows and out.shape[0] >= rows and x_s.dim() == 3 and w_s.dim() == 3 and x_s.shape[0] == 6 and w_s.shape[0] == 6
+    assert x_s.shape[1] >= rows and w_s.shape[1] >= 2304 and x_s.is_contiguous() and w_s.is_contiguous() and partials.numel() >= n_seq * 12 * 8 * 66
+    if out_scales is not None:
+        assert out_scales.dtype == torch.uint8 and out_scales.dim() == 3 and out_scales.shape[0] == 6 and out_scales.shape[1] >= rows and out_scales.is_contiguous()
+        assert out.data_ptr() != x_q.data_ptr() and out_scales.data_ptr() != x_s.data_ptr()
+    rc = _lib.load().sf_qkv_space_attention_mx(_dev(x_q, 'x_q'), _ld(x_q), _dev(x_s, 'x_s'), x_s.stride(0), _dev(w_q, 'w_q'), _ld(w_q), _dev(w_s, 'w_s'), w_s.stride(0),
+                                               _dev(bias, 'bias') if bias is not None else None, _dev(side, 'side'), _ld(side),
+                                               _dev(out, 'out') if out_scales is None else None, _ld(out) if out_scales is None else 0,
+                                               _dev(out, 'out') if out_scales is not None else None, _ld(out) if out_scales is not None else 0,
+                                               _dev(out_scales, 'out_scales') if out_scales is not None else None, out_scales.stride(0) if out_scales is not None else 0,
+                                               _dev(partials, 'partials'), n_seq, n_tok, float(scale), _stream())
+    _lib.check(rc, 'sf_qkv_space_attention_mx')
+    return out
+
+
 def qkv_time_attention_mx(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], qkv_cls: torch.Tensor,
                           out: torch.Tensor, partials: torch.Tensor, *, n_seq: int, n_groups: int, scale: float, out_scales: Optional[torch.Tensor] = None):
     """qkv_time_attention on MXFP8 operands: x_q (n_seq * (1 + 8 n_groups), 768) uint8 e4m3 + x_s (6, >= rows, 4) scale planes, w_q (2304, 768) + w_s (6, >= 2304, 4);

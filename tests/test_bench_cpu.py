@@ -8,7 +8,7 @@ def test_gemm_timer_wrappers_accept_the_ops_keywords():
     from synchformer_amd import ops
     gt = bench.GemmTimer()
     with gt:
-        for name in ('gemm', 'gemm_res_ln', 'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention', 'qkv_time_attention_mx', 'qkv_space_attention'):
+        for name in ('gemm', 'gemm_res_ln', 'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention', 'qkv_time_attention_mx', 'qkv_space_attention', 'qkv_space_attention_mx'):
             wrapped, orig = getattr(ops, name), gt.orig[name]
             po, pw = inspect.signature(orig).parameters, inspect.signature(wrapped).parameters
             has_kw = any(p.kind == inspect.Parameter.VAR_KEYWORD for p in pw.values())

@@ -955,3 +955,71 @@ def test_qkv_space_attention(gpu, n_seq):
     att = torch.einsum('nfqhd,nfkhd->nfhqk', pq, pk) * 0.125
     po = torch.einsum('nfhqk,nfkhd->nfqhd', att.softmax(-1), pv).reshape(m, 8 * 196, D)
     torch.testing.assert_close(o[:2, 1:], po, rtol=2 ** -7, atol=2 ** -7)
+
+
+def _space_side_index(n_seq, dev):
+    """row ids of [CLS; tokens 192..195 of each of the 8 frames] per sequence (33 per sequence), as synchformer_amd.ops.space_side_rows gathers them"""
+    seq = torch.arange(n_seq, device=dev).view(n_seq, 1) * 1569
+    left = 1 + torch.arange(8, device=dev).view(8, 1) * 196 + 192 + torch.arange(4, device=dev).view(1, 4)
+    return torch.cat([seq, seq + left.reshape(1, 32)], 1).reshape(-1)
+
+
+@pytest.mark.parametrize('n_seq', [3, 40])
+def test_qkv_space_attention_mx(gpu, n_seq):
+    """sf_qkv_space_attention_mx against the un-fused MX sequence it replaces: sf_gemm_mxfp8 (bf16 output) -> sf_attention_cls_partial (space groups) + combine, on operands
+    whose block scales differ widely along K and across rows (a wrong scale byte, a swapped k half or a wrong row of the scale dwords cannot hide).  Both round the
+    projection to bf16 before the attention; the MX products are exact in fp32 up to summation order, so the outputs agree to one bf16 ulp of their magnitude.  Repetitions
+    are bit-identical; the MXFP8 output form is byte for byte sf_quantize_mxfp8 of the bf16 output."""
+    from synchformer_amd import ops
+    L, D = 1569, 768
+    rows = n_seq * L
+    g = torch.Generator().manual_seed(190 + n_seq)
+    x = _bf(torch.randn(rows, D, generator=g) * torch.exp2(torch.randint(-3, 3, (rows, D // 32), generator=g).float()).repeat_interleave(32, 1)).to(gpu)
+    w = _bf(torch.randn(3 * D, D, generator=g) * 0.03 * torch.exp2(torch.randint(-2, 2, (3 * D, D // 32), generator=g).float()).repeat_interleave(32, 1)).to(gpu)
+    b = (0.1 * _rand(3 * D, seed=192)).to(gpu)
+    xq, xs = torch.empty(rows, D, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(rows, D, gpu)
+    wq, ws = torch.empty(3 * D, D, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(3 * D, D, gpu)
+    ops.quantize_mxfp8(x, xq, xs)
+    ops.quantize_mxfp8(w, wq, ws)
+    # un-fused
+    qkv = torch.empty(rows, 3 * D, device=gpu, dtype=torch.bfloat16)
+    ops.gemm_mxfp8(xq, xs, wq, ws, b, qkv)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    ref = torch.zeros(rows, D, device=gpu, dtype=torch.bfloat16)
+    part_ref = torch.zeros(n_seq * 12 * 8 * 66, device=gpu)
+    ops.attention_cls_partial(q, k, v, ref, part_ref, n_seq=n_seq, seq_rows=L, n_groups=8, row0=1, group_stride=196, tok_stride=1, n_tok=196, cls_row=0, heads=12,
+                              head_dim=64, scale=0.125)
+    # fused: side rows = gathered copies of the rows and of their scale dwords through the MX GEMM
+    idx = _space_side_index(n_seq, gpu)
+    sq = xq.index_select(0, idx).contiguous()
+    ss = ops.mx_scale_planes(n_seq * 33, D, gpu)
+    ss[:, :n_seq * 33] = xs.index_select(1, idx)
+    side = torch.empty(n_seq * 33, 3 * D, device=gpu, dtype=torch.bfloat16)
+    ops.gemm_mxfp8(sq, ss, wq, ws, b, side)
+    assert torch.equal(side, qkv.index_select(0, idx))
+
+    def fused():
+        out = torch.full((rows, D), 7.0, device=gpu, dtype=torch.bfloat16)
+        part = torch.zeros(n_seq * 12 * 8 * 66, device=gpu)
+        ops.qkv_space_attention_mx(xq, xs, wq, ws, b, side, out, part, n_seq=n_seq, scale=0.125)
+        return out, part
+    out, part = fused()
+    for rep in range(3):
+        o2, p2 = fused()
+        assert torch.equal(o2, out), f'repetition {rep}: {(o2 != out).sum().item()} output elements differ'
+        assert torch.equal(p2, part), f'repetition {rep}: {(p2 != part).sum().item()} partial elements differ'
+    assert (out.view(n_seq, L, D)[:, 0] == 7.0).all(), 'the fused kernel must not touch the CLS rows'
+    o, r = out.float().view(n_seq, L, D), ref.float().view(n_seq, L, D)
+    scale = r.abs().max().item()
+    torch.testing.assert_close(o[:, 1:], r[:, 1:], rtol=2 ** -6, atol=2 ** -7 * max(1.0, scale))
+    assert (o[:, 1:] - r[:, 1:]).abs().gt(1e-3 * max(1.0, scale)).float().mean() < 5e-3
+    torch.testing.assert_close(part.view(-1, 66)[:, 2:], part_ref.view(-1, 66)[:, 2:], rtol=2e-2, atol=2e-2 * max(1.0, scale))
+    # the MXFP8 output form
+    oq, os_ = torch.zeros(rows, D, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(rows, D, gpu)
+    part2 = torch.zeros_like(part)
+    ops.qkv_space_attention_mx(xq, xs, wq, ws, b, side, oq, part2, n_seq=n_seq, scale=0.125, out_scales=os_)
+    wq_, ws_ = torch.zeros(rows, D, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(rows, D, gpu)
+    ops.quantize_mxfp8(out, wq_, ws_)
+    patch = torch.ones(n_seq, L, dtype=torch.bool, device=gpu); patch[:, 0] = False
+    patch = patch.reshape(-1)
+    assert torch.equal(oq[patch], wq_[patch]) and torch.equal(os_[:, :rows][:, patch], ws_[:, :rows][:, patch]) and torch.equal(part2, part)
