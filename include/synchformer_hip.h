@@ -138,7 +138,10 @@ int sf_gemm_bf16_auto_config(int64_t M, int64_t N, int64_t K, int has_residual);
 int sf_gemm_bf16_gelu_dual(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, uint16_t* pre, uint16_t* act, int64_t ldc,
                            int64_t M, int64_t N, int64_t K, void* stream);
 /* The same kind of hook for sf_gemm_res_ln768's main-loop schedule: -1 default (quadrant-phased, round 3), 0 = round 2's loop (one stage of prefetch),
- * 1 = quadrant-phased.  Both sum every accumulator in the same order: bit-identical outputs (the tests compare them). */
+ * 1 = quadrant-phased.  Both sum every accumulator in the same order: bit-identical outputs (the tests compare them).
+ * 2 = round 4's 192-row tiles in two 384-column passes on the fused spatial kernel's main loop (row-major W, K % 128 == 0, lda and ldw multiples of
+ * 64; other operands fall back to schedule 1): X differs from schedules 0/1 only by fp32 summation order, Y by at most one bf16 rounding.  The
+ * environment variable SF_RL_SCHED=2 selects it when nothing is forced. */
 void sf_gemm_res_ln_force_schedule(int sched);
 void sf_qkv_time_force_schedule(int sched);        /* the same for sf_qkv_time_attention */
 void sf_gemm_mx_force_schedule(int sched);         /* ... and for sf_gemm_mxfp8 (quadrant-phased needs K % 256 == 0) */

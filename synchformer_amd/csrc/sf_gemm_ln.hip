@@ -497,6 +497,11 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
 static thread_local int g_rl_force_sched = -1;   // test hook (per calling thread): -1 default, 0 round 2's loop, 1 quadrant-phased
 extern "C" void sf_gemm_res_ln_force_schedule(int sched) { g_rl_force_sched = sched; }
 
+int sf_gemm_res_ln768_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, const float* R, int64_t ldr, float* X, int64_t ldx,
+                                const float* gamma, const float* beta, float eps, uint16_t* Y, int64_t ldy, int64_t M, int64_t K, void* stream);
+#ifndef SF_RL_DEFAULT_SCHED
+#define SF_RL_DEFAULT_SCHED SF_RL_PP
+#endif
 extern "C" int sf_gemm_res_ln768(const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, const float* bias, const float* R, int64_t ldr,
                                  float* X, int64_t ldx, const float* gamma, const float* beta, float eps, bf16_t* Y, int64_t ldy, int64_t M,
                                  int64_t K, void* stream) {
@@ -510,6 +515,15 @@ extern "C" int sf_gemm_res_ln768(const bf16_t* A, int64_t lda, const bf16_t* W, 
                    ((uintptr_t)Y % 8) == 0 && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0),
                "sf_gemm_res_ln768: operands must be 16-byte aligned");
   if (M <= 0) return 0;
+  // Round 4, schedule 2 (sf_gemm_ln2.hip: 192 complete rows per workgroup in two column passes on the 192 x 384 main loop of sf_qkv_space_attention): taken for a
+  // ROW-MAJOR weight when selected (sf_gemm_res_ln_force_schedule(2), or SF_RL_SCHED=2) and the shape fits (K % 128 == 0, lda / ldw multiples of 64)
+  {
+    static int sched2 = -1;
+    if (sched2 < 0) { const char* e = getenv("SF_RL_SCHED"); sched2 = (e ? atoi(e) : SF_RL_DEFAULT_SCHED) == 2 ? 1 : 0; }
+    const bool want2 = g_rl_force_sched == 2 || (g_rl_force_sched < 0 && sched2);
+    if (want2 && !w_kmajor && (K % 128) == 0 && K >= 128 && (lda % 64) == 0 && (ldw % 64) == 0 && ldw >= K)
+      return sf_gemm_res_ln768_v2_launch(A, lda, W, ldw, bias, R, ldr, X, ldx, gamma, beta, eps, Y, ldy, M, K, stream);
+  }
   const int64_t m_pad = ((M + RL_BM - 1) / RL_BM) * RL_BM;
   // 32-bit byte offsets: buffer descriptors for R / X / Y (rows >= M are dropped by the hardware range check) and the lane offsets of the
   // LDS-DMA (16 rows of A or W plus the k offset)

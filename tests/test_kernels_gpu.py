@@ -358,6 +358,52 @@ def test_gemm_res_ln_schedules_bitwise(gpu, M, K):
             assert torch.equal(x1, x0) and torch.equal(y1, y0), f'repetition {rep}'
 
 
+@pytest.mark.parametrize('M,K', [(192 * 300 + 37, 768), (192 * 270 + 191, 3072), (192 * 256 + 1, 768), (100, 768), (192, 3072)])
+def test_gemm_res_ln_schedule2(gpu, M, K):
+    """Schedule 2 of sf_gemm_res_ln768 (round 4: 192-row tiles, two 384-column passes, the residual and the chunk exchange through LDS) against
+    fp32 torch and against schedule 1 on the same operands: X to fp32 summation order, Y to one bf16 rounding; rows beyond M untouched; A rows beyond
+    M poisoned (the ragged last tile clamps its reads); five repetitions bit-identical (a screen for LDS-DMA / ds_read ordering races)."""
+    from synchformer_amd import ops, _lib
+    lib = _lib.load()
+    a, w = _bf(_rand(M + 5, K, seed=71)), _bf(_rand(768, K, seed=72, scale=0.05))
+    a[M:] = float('nan')
+    b, r = _rand(768, seed=73), _rand(M, 768, seed=74, scale=2.0) + 0.5
+    gam, bet = 1.0 + 0.1 * _rand(768, seed=75), 0.1 * _rand(768, seed=76)
+    x_ref = a[:M].float() @ w.float().t() + b + r
+    y_ref = torch.nn.functional.layer_norm(x_ref, (768,), gam, bet, 1e-6)
+    ag, wg, bg, gg, btg = a.to(gpu), w.to(gpu), b.to(gpu), gam.to(gpu), bet.to(gpu)
+
+    def run(sched):
+        lib.sf_gemm_res_ln_force_schedule(sched)
+        try:
+            x = torch.full((M + 3, 768), 7.0, device=gpu)
+            x[:M] = r.to(gpu)
+            y = torch.full((M + 3, 768), 3.0, device=gpu, dtype=torch.bfloat16)
+            ops.gemm_res_ln(ag, wg, bg, x, gg, btg, y, 1e-6, M=M)
+        finally:
+            lib.sf_gemm_res_ln_force_schedule(-1)
+        return x, y
+    x, y = run(2)
+    torch.testing.assert_close(x[:M].cpu(), x_ref, rtol=1e-4, atol=3e-4)
+    torch.testing.assert_close(y[:M].float().cpu(), y_ref, rtol=1e-2, atol=1e-2)
+    assert (x[M:] == 7.0).all() and (y[M:] == 3.0).all(), 'rows beyond M were written'
+    x1, y1 = run(1)
+    torch.testing.assert_close(x[:M], x1[:M], rtol=1e-5, atol=2e-5)
+    assert ((y[:M].float() - y1[:M].float()).abs() <= 2.0 ** -7 * y1[:M].float().abs() + 1e-4).all()
+    for rep in range(5):
+        xr, yr = run(2)
+        assert torch.equal(xr, x) and torch.equal(yr, y), f'repetition {rep}'
+    # in place: Y aliasing A (K = 768 only: the engine's XN buffer) -- each tile reads all of its A rows before its first Y store
+    if K == 768:
+        lib.sf_gemm_res_ln_force_schedule(2)
+        try:
+            buf, x2 = ag[:M].clone(), r.to(gpu)
+            ops.gemm_res_ln(buf, wg, bg, x2, gg, btg, buf, 1e-6)
+        finally:
+            lib.sf_gemm_res_ln_force_schedule(-1)
+        assert torch.equal(x2, x[:M]) and torch.equal(buf, y[:M])
+
+
 def test_gemm_res_ln_in_place_operand(gpu):
     """Y aliasing A (the engine's XN buffer holds the attention output going in and the normalised rows coming out) and X aliasing R."""
     from synchformer_amd import ops

@@ -34,7 +34,7 @@ def main():
             x = torch.randn(M, 768, device=dev)
             y = torch.empty(M, 768, device=dev, dtype=torch.bfloat16)
             wk = ops.kmajor_weight(w)
-            t = {'gemm': [], 'ln': [], 'fused': [], 'fused_k': [], 'r2_k': []}
+            t = {'gemm': [], 'ln': [], 'fused': [], 'fused_k': [], 'r2_k': [], 's2': []}
             lib = _lib.load()
             for _ in range(7):      # interleaved rounds, median
                 t['gemm'].append(timeit(lambda: ops.gemm(a, w, b, x, residual=x)))
@@ -46,13 +46,15 @@ def main():
                     t['r2_k'].append(timeit(lambda: ops.gemm_res_ln(a, wk, b, x, g, bt, y, 1e-6)))
                 except RuntimeError:
                     t['r2_k'].append(float('nan'))
+                lib.sf_gemm_res_ln_force_schedule(2)
+                t['s2'].append(timeit(lambda: ops.gemm_res_ln(a, w, b, x, g, bt, y, 1e-6)))
                 lib.sf_gemm_res_ln_force_schedule(-1)
                 x.normal_()
             med = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
             fl = 2.0 * M * 768 * K
             byts = M * K * 2 + M * 768 * (4 + 4 + 2)
             print(f"{name:5s} K {K:4d}: gemm+res {med['gemm']:7.1f} us ({fl / med['gemm'] / 1e6:5.0f} TF) + layernorm {med['ln']:6.1f} us = "
-                  f"{med['gemm'] + med['ln']:7.1f} us | fused {med['fused']:7.1f} us ({fl / med['fused'] / 1e6:5.0f} TF, {byts / med['fused'] / 1e6:5.2f} TB/s algorithmic) | k-major W {med['fused_k']:7.1f} us ({fl / med['fused_k'] / 1e6:5.0f} TF) | round-2 loop, k-major W {med['r2_k']:7.1f} us",
+                  f"{med['gemm'] + med['ln']:7.1f} us | fused {med['fused']:7.1f} us ({fl / med['fused'] / 1e6:5.0f} TF, {byts / med['fused'] / 1e6:5.2f} TB/s algorithmic) | k-major W {med['fused_k']:7.1f} us ({fl / med['fused_k'] / 1e6:5.0f} TF) | round-2 loop, k-major W {med['r2_k']:7.1f} us | schedule 2 (192-row tiles, two column passes) {med['s2']:7.1f} us ({fl / med['s2'] / 1e6:5.0f} TF)",
                   flush=True)
 
 
