@@ -112,7 +112,7 @@ class GemmTimer:
 
     def __enter__(self):
         ops = self.ops
-        self.orig = {k: getattr(ops, k) for k in ('gemm', 'gemm_res_ln', 'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention', 'qkv_time_attention_mx', 'qkv_space_attention', 'qkv_space_attention_mx')}
+        self.orig = {k: getattr(ops, k) for k in ('gemm', 'gemm_res_ln', 'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention', 'qkv_time_attention2', 'qkv_time_attention_mx', 'qkv_space_attention', 'qkv_space_attention_mx')}
         o = self.orig
 
         def timed(a, w, bias, out, *, M=None, **kw):
@@ -185,6 +185,15 @@ class GemmTimer:
             return self._rec(lambda: o['qkv_space_attention_mx'](x_q, x_s, w_q, w_s, bias, side, out, partials, n_seq=n_seq, scale=scale, out_scales=out_scales, n_tok=n_tok),
                              2.0 * m * n * k, nbytes, 'qkv_space_attn_mx_kernel', 'N=2304 K=768', 'mxfp8')
 
+        def timed_qt2(x, w, bias, side, out, partials, *, n_seq, scale, n_tok=196):
+            if not self.enabled:
+                return o['qkv_time_attention2'](x, w, bias, side, out, partials, n_seq=n_seq, scale=scale, n_tok=n_tok)
+            m, n, k = n_seq * 8 * 192, 2304, 768                                       # the rows the launch projects itself (the other 33 per sequence: the side GEMM)
+            nbytes = n_seq * 8 * n_tok * k * 2 + n * k * 2 + n_seq * 8 * n_tok * 768 * 2   # A + W read, the 768-wide attention output written
+            return self._rec(lambda: o['qkv_time_attention2'](x, w, bias, side, out, partials, n_seq=n_seq, scale=scale, n_tok=n_tok),
+                             2.0 * m * n * k, nbytes, 'qkv_time2_attn_kernel', 'N=2304 K=768')
+
+        ops.qkv_time_attention2 = timed_qt2
         ops.qkv_space_attention = timed_qs
         ops.qkv_space_attention_mx = timed_qs_mx
         ops.gemm, ops.gemm_res_ln, ops.gemm_mxfp8, ops.gemm_mx_res_ln, ops.qkv_time_attention = timed, timed_ln, timed_mx, timed_mxln, timed_qt

@@ -29,7 +29,7 @@ extern "C" {
 enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2, SF_U8 = 3 };   /* element types */
 enum { SF_EPI_NONE = 0, SF_EPI_GELU = 1 };                  /* GEMM epilogue activation */
 
-#define SF_ABI_VERSION 7
+#define SF_ABI_VERSION 8
 int sf_abi_version(void);
 const char* sf_last_error(void);
 /* "gfx950" + build flags; lets the host assert it loaded the library it built */
@@ -224,6 +224,16 @@ int sf_qkv_space_attention(const uint16_t* X, int64_t ldx, const uint16_t* W, in
 int sf_qkv_space_attention_mx(const uint8_t* X, int64_t ldx, const uint8_t* sX, int64_t ldsx, const uint8_t* W, int64_t ldw, const uint8_t* sW, int64_t ldsw,
                               const float* bias, const uint16_t* side, int64_t lds_, uint16_t* out, int64_t ldo, uint8_t* out_q, int64_t ldq, uint8_t* out_s,
                               int64_t splane, float* cls_partial, int64_t n_seq, int n_tok, float scale, void* stream);
+
+/* sf_qkv_time_attention on the 192 x 384 main loop of sf_qkv_space_attention (round 4; same reference lines as sf_qkv_time_attention below).  Work item = (sequence,
+ * block of 24 patches, head pair): the block's 24 patches x 8 frames x q | k | v of two heads on the matrix cores, then per patch the attention over [CLS key; its 8 frames];
+ * the 4 left-over patches of a sequence (196 = 8 x 24 + 4) and the CLS row come from `side`, the (n_seq * 33, 2304) buffer sf_qkv_space_attention takes (row seq * 33 = the
+ * CLS row's q | k | v, rows seq * 33 + 1 + 4 f + i = token 192 + i of frame f).  out (rows as X, 768) bf16: patch rows only, must not alias X; cls_partial
+ * [n_seq][12][33][66] fp32: the CLS query's softmax partials, four per block (records 4 tb .. 4 tb + 3) + record 32 (the left-over patches and the CLS key itself) -
+ * merge with sf_attention_cls_combine, n_part = 33.  n_tok must be 196; ldx and ldw multiples of 64 elements.  No key-mask variant (sf_qkv_time_attention_masked keeps that).  Replaces sf_gemm_bf16 (CLS rows) +
+ * sf_qkv_time_attention. */
+int sf_qkv_time_attention2(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
+                           uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, void* stream);
 
 /* The temporal half of DividedSpaceTimeBlock in ONE launch (vit_helper.py:366 `self.timeattn(self.norm3(x), ..., 'b (f n) d', '(b n) f d')`,
  * DividedAttention.forward vit_helper.py:97-150): qkv projection (vit_helper.py:107) of every PATCH token + the 8-frame attention over

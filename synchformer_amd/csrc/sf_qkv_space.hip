@@ -513,6 +513,22 @@ __device__ __forceinline__ void qkv_space_attn_body(const QsArgs& p) {
             }
             if (qo < nq && fg == 0) *reinterpret_cast<uint16_t*>(p.out_s + (int64_t)(head >> 1) * p.splane + row * 4 + (head & 1) * 2) = (uint16_t)be2;
           } else
+#ifndef QS_OUT_LINES
+#define QS_OUT_LINES 0   // (measured: 1319 us against 1312 us - the space attention is long enough to retire its 8-byte stores; sf_qkv_time2.hip gains 28 us from the same change)
+#endif
+          if (QS_OUT_LINES) {
+            // through the tile's own 16 Q rows (dead: only this unit read them): the accumulator layout would store 8 bytes per lane, 32 bytes apart - every 128-byte line of
+            // `out` (one token, one head) in 16 pieces over 4 instructions; read back row-wise below, 8 lanes x 16 bytes write one complete line
+            const float linv = linv_[e];
+            char* qrows = const_cast<char*>(q_lds);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+              uint2 w;
+              w.x = pack_bf2(o[e][dt][0] * linv, o[e][dt][1] * linv);
+              w.y = pack_bf2(o[e][dt][2] * linv, o[e][dt][3] * linv);
+              *reinterpret_cast<uint2*>(qrows + qs_arr_off(qo, dt * 2 + (fg >> 1)) + (fg & 1) * 8) = w;
+            }
+          } else
           if (qo < nq) {
             bf16_t* orow = obase + (int64_t)qo * p.ldo + fg * 4;
             const float linv = linv_[e];
@@ -524,6 +540,16 @@ __device__ __forceinline__ void qkv_space_attn_body(const QsArgs& p) {
               *reinterpret_cast<uint2*>(orow + dt * 16) = w;
             }
           }
+        }
+        if (QS_OUT_LINES && !(MX && QS_MXOUT && p.out_q)) {
+#pragma unroll
+          for (int e = 0; e < NT; ++e)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int row = (e ? qt1 : qt0) * 16 + (alane >> 3) + 8 * j, ch = alane & 7;
+              const uint4 w = *reinterpret_cast<const uint4*>(q_lds + qs_arr_off(row, ch));
+              if (row < nq) *reinterpret_cast<uint4*>(obase + (int64_t)row * p.ldo + ch * 8) = w;
+            }
         }
       };
 #pragma unroll 1
@@ -555,9 +581,9 @@ extern "C" int sf_qkv_space_attention(const uint16_t* X, int64_t ldx, const uint
                                       uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, void* stream) {
   SF_CHECK_ARG(X && W && side && out && cls_partial, "sf_qkv_space_attention: null pointer");
   SF_CHECK_ARG(n_tok == QS_TOK, "sf_qkv_space_attention: built for 196-token frames (8 frames per sequence), got %d", n_tok);
-  SF_CHECK_ARG((ldx % 8) == 0 && (ldw % 8) == 0 && (lds_ % 8) == 0 && (ldo % 4) == 0 && ldx >= QS_D && ldw >= QS_D && lds_ >= 3 * QS_D && ldo >= QS_D,
-               "sf_qkv_space_attention: bad row strides");
-  SF_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)side % 16) == 0 && ((uintptr_t)out % 8) == 0 && (!bias || ((uintptr_t)bias % 16) == 0) &&
+  SF_CHECK_ARG((ldx % 64) == 0 && (ldw % 64) == 0 && (lds_ % 8) == 0 && (ldo % 8) == 0 && ldx >= QS_D && ldw >= QS_D && lds_ >= 3 * QS_D && ldo >= QS_D,
+               "sf_qkv_space_attention: bad row strides (ldx / ldw multiples of 64 elements: the chunk slot lives in the low 7 bits of a piece's byte offset)");
+  SF_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)side % 16) == 0 && ((uintptr_t)out % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0) &&
                    ((uintptr_t)cls_partial % 8) == 0, "sf_qkv_space_attention: operands must be 16-byte aligned");
   SF_CHECK_ARG((const void*)X != (const void*)out, "sf_qkv_space_attention: out must not alias X");
   if (n_seq <= 0) return 0;
@@ -593,10 +619,10 @@ extern "C" int sf_qkv_space_attention_mx(const uint8_t* X, int64_t ldx, const ui
                                          int64_t splane, float* cls_partial, int64_t n_seq, int n_tok, float scale, void* stream) {
   SF_CHECK_ARG(X && sX && W && sW && side && cls_partial && ((out != nullptr) != (out_q != nullptr)), "sf_qkv_space_attention_mx: null pointer (exactly one of out / out_q)");
   SF_CHECK_ARG(n_tok == QS_TOK, "sf_qkv_space_attention_mx: built for 196-token frames (8 frames per sequence), got %d", n_tok);
-  SF_CHECK_ARG((ldx % 16) == 0 && (ldw % 16) == 0 && ldx >= QS_D && ldw >= QS_D && (lds_ % 8) == 0 && lds_ >= 3 * QS_D, "sf_qkv_space_attention_mx: bad row strides");
+  SF_CHECK_ARG((ldx % 128) == 0 && (ldw % 128) == 0 && ldx >= QS_D && ldw >= QS_D && (lds_ % 8) == 0 && lds_ >= 3 * QS_D, "sf_qkv_space_attention_mx: bad row strides (ldx / ldw multiples of 128 bytes)");
   SF_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)sX % 16) == 0 && ((uintptr_t)sW % 16) == 0 && ((uintptr_t)side % 16) == 0 &&
                    (!bias || ((uintptr_t)bias % 16) == 0) && ((uintptr_t)cls_partial % 8) == 0, "sf_qkv_space_attention_mx: operands must be 16-byte aligned");
-  if (out) SF_CHECK_ARG(((uintptr_t)out % 8) == 0 && (ldo % 4) == 0 && ldo >= QS_D, "sf_qkv_space_attention_mx: out must be an 8-byte aligned bf16 buffer");
+  if (out) SF_CHECK_ARG(((uintptr_t)out % 16) == 0 && (ldo % 8) == 0 && ldo >= QS_D, "sf_qkv_space_attention_mx: out must be a 16-byte aligned bf16 buffer");
   if (out_q) SF_CHECK_ARG(out_s && ((uintptr_t)out_q % 8) == 0 && ((uintptr_t)out_s % 2) == 0 && (ldq % 8) == 0 && ldq >= QS_D && out_q != X && out_s != sX,
                           "sf_qkv_space_attention_mx: out_q (8-byte aligned, ldq %% 8 == 0) / out_s must be buffers of their own");
   if (n_seq <= 0) return 0;

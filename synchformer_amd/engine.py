@@ -89,6 +89,7 @@ class SynchformerEngine:
         self.fuse_ln_fc2 = os.environ.get('SF_FUSE_LN_FC2', '1') != '0'   # K = 3072: 1932 us fused vs 1708 + 277 us (profiles/r02_gemm_ln.md)
         self.fuse_time = os.environ.get('SF_FUSE_TIME', '1') != '0'       # temporal qkv projection + time attention in one launch (sf_qkv_time_attention)
         self.fuse_space = os.environ.get('SF_FUSE_SPACE', '1') != '0'     # spatial qkv projection + space attention in one launch (sf_qkv_space_attention, round 4)
+        self.fuse_time2 = os.environ.get('SF_FUSE_TIME2', '1') != '0'     # the temporal launch on the spatial kernel's 192 x 384 main loop (sf_qkv_time_attention2, round 4)
         self._a_side = None
         self.load_weights(state_dict)
 
@@ -324,7 +325,8 @@ class SynchformerEngine:
         fuse_ln = self.fuse_ln and rows >= 128 * 64
         fuse_time = self.fuse_time and rows >= 128 * 64
         fuse_space = self.fuse_space and rows >= 128 * 64 and tok_keep is None and fuse_mode != 'none'   # (token masks take the un-fused, masked launches)
-        if fuse_space:
+        fuse_time2 = fuse_time and self.fuse_time2 and tok_keep is None and fuse_mode != 'none'        # (key masks: sf_qkv_time_attention's flags)
+        if fuse_space or fuse_time2:
             side_in = self._buf('side_in', n * 33 * D, torch.bfloat16).view(n * 33, D)
             side = self._buf('side', n * 33 * 3 * D, torch.bfloat16).view(n * 33, 3 * D)
         att = big[:rows * D].view(rows, D)                                        # the time block's attention output (its qkv never exists)
@@ -333,7 +335,15 @@ class SynchformerEngine:
         for bi, b in enumerate(self.v_blocks):
             if bi == 0 or not fuse_ln:
                 ops.layernorm(X, b['norm3'].g, b['norm3'].b, xn, EPS_VIS)
-            if fuse_time:
+            if fuse_time2:
+                # temporal qkv + time attention in one launch on 24-patch blocks (sf_qkv_time_attention2); the rows it does not project itself - the CLS row and
+                # patches 192..195 of every frame (196 = 8 x 24 + 4): the same 33 rows per segment as in the spatial half - go through a small GEMM up front.
+                ops.space_side_rows(xn, side_in, n)
+                ops.gemm(side_in, b['t_qkv'].w, b['t_qkv'].b, side)
+                ops.qkv_time_attention2(xn, b['t_qkv'].w, b['t_qkv'].b, side, att, part, n_seq=n, scale=0.125)
+                ops.attention_cls_combine(part, att, n_part=33, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
+                t_out = att
+            elif fuse_time:
                 # temporal qkv + time attention in one launch (sf_qkv_time_attention): the 2304-wide projection never reaches HBM.  The CLS rows'
                 # own projection (their k / v are every patch's first key, their q is the global CLS query) is a 224-row GEMM up front.
                 ops.gemm(xn.view(n, VIS_L, D)[:, 0], b['t_qkv'].w, b['t_qkv'].b, qkv_cls)

@@ -336,6 +336,21 @@ def qkv_space_attention(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.T
     return out
 
 
+def qkv_time_attention2(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, *, n_seq: int,
+                        scale: float, n_tok: int = 196):
+    """Temporal qkv projection + time attention of every patch token in one launch on the 192 x 384 main loop (sf_qkv_time_attention2): x (n_seq * 1569, 768) bf16,
+    w (2304, 768) bf16, side (n_seq * 33, 2304) bf16 = the projection of the rows of space_side_rows(); out: patch rows of the attention output (a buffer of its own),
+    partials: the CLS query's softmax partials, 33 per sequence and head, for attention_cls_combine(n_part=33)."""
+    assert x.dtype == w.dtype == side.dtype == out.dtype == torch.bfloat16 and partials.dtype == torch.float32
+    rows = n_seq * (1 + 8 * n_tok)
+    assert x.shape[1] == 768 and tuple(w.shape) == (2304, 768) and side.shape[0] >= n_seq * 33 and side.shape[1] == 2304 and out.shape[1] == 768
+    assert x.shape[0] >= rows and out.shape[0] >= rows and partials.numel() >= n_seq * 12 * 33 * 66 and x.data_ptr() != out.data_ptr()
+    rc = _lib.load().sf_qkv_time_attention2(_dev(x, 'x'), _ld(x), _dev(w, 'w'), _ld(w), _dev(bias, 'bias') if bias is not None else None, _dev(side, 'side'), _ld(side),
+                                            _dev(out, 'out'), _ld(out), _dev(partials, 'partials'), n_seq, n_tok, float(scale), _stream())
+    _lib.check(rc, 'sf_qkv_time_attention2')
+    return out
+
+
 def qkv_space_attention_mx(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out: torch.Tensor,
                            partials: torch.Tensor, *, n_seq: int, scale: float, out_scales: Optional[torch.Tensor] = None, n_tok: int = 196):
     """qkv_space_attention on MXFP8 operands: x_q (n_seq * 1569, 768) uint8 e4m3 + x_s (6, >= rows, 4) scale planes, w_q (2304, 768) + w_s (6, >= 2304, 4); side

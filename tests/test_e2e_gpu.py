@@ -387,11 +387,11 @@ def test_masked_forward_on_the_fused_schedule(gpu):
     # a masked forward takes sf_gemm_bf16 + sf_attention_cls_partial_masked for the space half (sf_qkv_space_attention has no mask variant): bit-equal to the unmasked
     # forward on the same launches, within a few bf16 ulps of the projection of the fused launch
     assert (ones - nomask).abs().max().item() < 1e-2
-    eng.fuse_space = False
+    eng.fuse_space = eng.fuse_time2 = False                       # (... and sf_qkv_time_attention with its key flags instead of sf_qkv_time_attention2)
     try:
         assert torch.equal(ones, eng.forward(u8.to(gpu), aud.to(gpu)))
     finally:
-        eng.fuse_space = True
+        eng.fuse_space = eng.fuse_time2 = True
 
 
 def test_dropin_module_forward_with_masks(gpu):

@@ -1003,6 +1003,70 @@ def test_qkv_space_attention(gpu, n_seq):
     torch.testing.assert_close(o[:2, 1:], po, rtol=2 ** -7, atol=2 ** -7)
 
 
+@pytest.mark.parametrize('n_seq', [3, 40])
+def test_qkv_time_attention2(gpu, n_seq):
+    """sf_qkv_time_attention2 (temporal qkv projection + time attention + CLS-query partials on the 192 x 384 main loop; 24-patch blocks, the 4 left-over patches
+    and the CLS row from the 33-rows-per-segment side GEMM) against the un-fused sequence: sf_gemm_bf16 -> sf_attention_cls_partial (time groups, CLS key first) +
+    sf_attention_cls_combine, against sf_qkv_time_attention, and against fp32 torch on the bf16 projection.  All round the projection to bf16 before the attention; this
+    kernel rounds the probabilities to bf16 for the P V MFMA (as the space attention does): outputs agree to one bf16 ulp of their magnitude.  Repetitions bit-identical."""
+    from synchformer_amd import ops
+    L, D = 1569, 768
+    rows = n_seq * L
+    x = _bf(_rand(rows, D, seed=160)).to(gpu)
+    w, b = _bf(_rand(3 * D, D, seed=161, scale=0.05)).to(gpu), (0.1 * _rand(3 * D, seed=162)).to(gpu)
+    qkv = torch.empty(rows, 3 * D, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(x, w, b, qkv)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    ref = torch.zeros(rows, D, device=gpu, dtype=torch.bfloat16)
+    part_ref = torch.zeros(n_seq * 12 * 196 * 66, device=gpu)
+    ops.attention_cls_partial(q, k, v, ref, part_ref, n_seq=n_seq, seq_rows=L, n_groups=196, row0=1, group_stride=1, tok_stride=196, n_tok=8, cls_row=0, heads=12,
+                              head_dim=64, scale=0.125)
+    ops.attention_cls_combine(part_ref, ref, n_part=196, n_seq=n_seq, out_seq_rows=L, out_row=0, heads=12)
+    side_in = torch.empty(n_seq * 33, D, device=gpu, dtype=torch.bfloat16)
+    ops.space_side_rows(x, side_in, n_seq)
+    side = torch.empty(n_seq * 33, 3 * D, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(side_in, w, b, side)
+
+    def fused():
+        out = torch.full((rows, D), 7.0, device=gpu, dtype=torch.bfloat16)
+        part = torch.zeros(n_seq * 12 * 33 * 66, device=gpu)
+        ops.qkv_time_attention2(x, w, b, side, out, part, n_seq=n_seq, scale=0.125)
+        return out, part
+    out, part = fused()
+    for rep in range(3):
+        o2, p2 = fused()
+        assert torch.equal(o2, out), f'repetition {rep}: {(o2 != out).sum().item()} output elements differ'
+        assert torch.equal(p2, part), f'repetition {rep}: {(p2 != part).sum().item()} partial elements differ'
+    assert (out.view(n_seq, L, D)[:, 0] == 7.0).all(), 'the fused kernel must not touch the CLS rows'
+    ops.attention_cls_combine(part, out, n_part=33, n_seq=n_seq, out_seq_rows=L, out_row=0, heads=12)
+    o, r = out.float().view(n_seq, L, D), ref.float().view(n_seq, L, D)
+    # (9 keys per query: P rounded to bf16 - 2^-9 relative on up to 9 terms of |v| <= ~4 - does not average out as over 197 keys: a handful of 48 M elements reach 0.012)
+    torch.testing.assert_close(o[:, 1:], r[:, 1:], rtol=2 ** -7, atol=2 ** -6)
+    assert (o[:, 1:] - r[:, 1:]).abs().mean() < 1e-3                                      # (9 keys per query: the bf16 rounding of P does not average out as over 197)
+    torch.testing.assert_close(o[:, 0], r[:, 0], rtol=2 ** -6, atol=2 ** -7)
+    # the round-3 fused launch on the same operands
+    qkv_cls = torch.empty(n_seq, 3 * D, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(x.view(n_seq, L, D)[:, 0], w, b, qkv_cls)
+    o3 = torch.zeros(rows, D, device=gpu, dtype=torch.bfloat16)
+    p3 = torch.zeros(n_seq * 12 * 49 * 66, device=gpu)
+    ops.qkv_time_attention(x, w, b, qkv_cls, o3, p3, n_seq=n_seq, n_groups=196, scale=0.125)
+    ops.attention_cls_combine(p3, o3, n_part=49, n_seq=n_seq, out_seq_rows=L, out_row=0, heads=12)
+    torch.testing.assert_close(o, o3.float().view(n_seq, L, D), rtol=2 ** -6, atol=2 ** -6)
+    # fp32 torch on the bf16 projection: per patch, keys [CLS; the patch's 8 frames]; the CLS query over all 1569 keys
+    qf = qkv.float().view(n_seq, L, 3, 12, 64)[:2]
+    qq, kk, vv = qf[:, :, 0], qf[:, :, 1], qf[:, :, 2]                                   # (n, L, 12, 64)
+    m = qq.shape[0]
+    tk = torch.cat([kk[:, :1].unsqueeze(1).expand(-1, 196, -1, -1, -1), kk[:, 1:].reshape(m, 8, 196, 12, 64).transpose(1, 2)], 2)   # (n, 196, 9, 12, 64)
+    tv = torch.cat([vv[:, :1].unsqueeze(1).expand(-1, 196, -1, -1, -1), vv[:, 1:].reshape(m, 8, 196, 12, 64).transpose(1, 2)], 2)
+    tq = qq[:, 1:].reshape(m, 8, 196, 12, 64).transpose(1, 2)                            # (n, 196, 8, 12, 64)
+    att = torch.einsum('npqhd,npkhd->nphqk', tq, tk) * 0.125
+    po = torch.einsum('nphqk,npkhd->npqhd', att.softmax(-1), tv).transpose(1, 2).reshape(m, 8 * 196, D)
+    torch.testing.assert_close(o[:2, 1:], po, rtol=2 ** -7, atol=2 ** -6)
+    ca = torch.einsum('nhd,nkhd->nhk', qq[:, 0], kk) * 0.125
+    co = torch.einsum('nhk,nkhd->nhd', ca.softmax(-1), vv).reshape(m, D)
+    torch.testing.assert_close(o[:2, 0], co, rtol=2 ** -6, atol=2 ** -7)
+
+
 def _space_side_index(n_seq, dev):
     """row ids of [CLS; tokens 192..195 of each of the 8 frames] per sequence (33 per sequence), as synchformer_amd.ops.space_side_rows gathers them"""
     seq = torch.arange(n_seq, device=dev).view(n_seq, 1) * 1569

@@ -43,7 +43,7 @@ if bench:
 lines += ['| kernel | calls | total ms | avg us | % |', '|---|---|---|---|---|']
 for r in stats[:16]:
     lines.append(f'| `{short(r["Name"])}` | {r["Calls"]} | {float(r["TotalDurationNs"]) / 1e6:.1f} | {float(r["AverageNs"]) / 1e3:.1f} | {float(r["Percentage"]):.1f} |')
-gem = [r for r in stats if 'gemm_bf16' in r['Name'] or 'gemm_res_ln768' in r['Name'] or 'qkv_time_attn' in r['Name'] or 'qkv_space_attn' in r['Name']]
+gem = [r for r in stats if 'gemm_bf16' in r['Name'] or 'gemm_res_ln768' in r['Name'] or 'qkv_time_attn' in r['Name'] or 'qkv_time2_attn' in r['Name'] or 'qkv_space_attn' in r['Name']]
 if gem:
     calls_g = sum(int(r['Calls']) for r in gem)
     tot_g = sum(float(r['TotalDurationNs']) for r in gem) / 1e6
@@ -66,7 +66,7 @@ for k, c in sorted(pmc.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE', 0))
     bank = 100 * c.get('SQ_LDS_BANK_CONFLICT', 0) / max(c.get('SQ_LDS_IDX_ACTIVE', 0), 1)
     lines.append(f'| `{k[:70]}` | {n} | {fetch:.0f} | {write:.0f} | {mfma:.1f} | {wait:.1f} | {hit:.1f} | {bank:.1f} |')
 # HBM traffic of the roofline kernel (all sf_gemm_bf16 launches), per launch: FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, KiB -> bytes
-gk = [(k, c) for k, c in pmc.items() if ('gemm_bf16' in k or 'gemm_res_ln768' in k or 'qkv_time_attn' in k or 'qkv_space_attn' in k) and calls[k]]
+gk = [(k, c) for k, c in pmc.items() if ('gemm_bf16' in k or 'gemm_res_ln768' in k or 'qkv_time_attn' in k or 'qkv_time2_attn' in k or 'qkv_space_attn' in k) and calls[k]]
 if gk:
     n_l = sum(calls[k] for k, _ in gk)
     fetch_b = sum(c.get('FETCH_SIZE', 0) for _, c in gk) * 2 * 1024
