@@ -508,7 +508,7 @@ def register_torch_ops():
         return
     from torch.library import custom_op
     # the direct launchers, bound now: ops.via_dispatcher() re-points the module-level names at these custom ops
-    d_ = {n: globals()[n] for n in ('gemm', 'layernorm', 'attention', 'attention_cls', 'im2col_video', 'gemm_res_ln', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'quantize_mxfp8', 'layernorm_mxfp8', 'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention_mx', 'attention_cls_partial_mx', 'attention_cls_combine_mx')}
+    d_ = {n: globals()[n] for n in ('gemm', 'layernorm', 'attention', 'attention_cls', 'im2col_video', 'gemm_res_ln', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'quantize_mxfp8', 'layernorm_mxfp8', 'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention_mx', 'attention_cls_partial_mx', 'attention_cls_combine_mx', 'qkv_time_attention2', 'qkv_space_attention', 'qkv_space_attention_mx', 'space_side_rows')}
 
     @custom_op('synchformer::gemm_bf16', mutates_args=('out',), device_types='cuda')
     def _gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, residual: Optional[torch.Tensor],
@@ -596,6 +596,31 @@ def register_torch_ops():
     def _attn_comb_mx(partials: torch.Tensor, out_q: torch.Tensor, out_s: torch.Tensor, n_part: int, n_seq: int, out_seq_rows: int, out_row: int, heads: int) -> None:
         d_['attention_cls_combine_mx'](partials, out_q, out_s, n_part=n_part, n_seq=n_seq, out_seq_rows=out_seq_rows, out_row=out_row, heads=heads)
 
+    # round 4: both halves of DividedSpaceTimeBlock's attention as one launch each on the 192 x 384 main loop, and the gather of their 33 side rows per segment
+    @custom_op('synchformer::qkv_time_attention2', mutates_args=('out', 'partials'), device_types='cuda')
+    def _qkv_time2(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, n_seq: int,
+                   scale: float) -> None:
+        d_['qkv_time_attention2'](x, w, bias, side, out, partials, n_seq=n_seq, scale=scale)
+
+    @custom_op('synchformer::qkv_space_attention', mutates_args=('out', 'partials'), device_types='cuda')
+    def _qkv_space(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, n_seq: int,
+                   scale: float) -> None:
+        d_['qkv_space_attention'](x, w, bias, side, out, partials, n_seq=n_seq, scale=scale)
+
+    @custom_op('synchformer::qkv_space_attention_mx', mutates_args=('out', 'partials'), device_types='cuda')
+    def _qkv_space_mx(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out: torch.Tensor,
+                      partials: torch.Tensor, n_seq: int, scale: float) -> None:
+        d_['qkv_space_attention_mx'](x_q, x_s, w_q, w_s, bias, side, out, partials, n_seq=n_seq, scale=scale)
+
+    @custom_op('synchformer::qkv_space_attention_mx_q', mutates_args=('out_q', 'out_s', 'partials'), device_types='cuda')
+    def _qkv_space_mx_q(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out_q: torch.Tensor,
+                        out_s: torch.Tensor, partials: torch.Tensor, n_seq: int, scale: float) -> None:
+        d_['qkv_space_attention_mx'](x_q, x_s, w_q, w_s, bias, side, out_q, partials, n_seq=n_seq, scale=scale, out_scales=out_s)
+
+    @custom_op('synchformer::space_side_rows', mutates_args=('out',), device_types='cuda')
+    def _side_rows(x: torch.Tensor, out: torch.Tensor, n_seq: int) -> None:
+        d_['space_side_rows'](x, out, n_seq)
+
     # Meta / FakeTensor implementations: every op is an out-variant (mutates its outputs, returns nothing), so the abstract implementation has no output
     # to describe - it only checks what the launcher would refuse (dtype / rank of the outputs), which lets FakeTensorMode, torch.library.opcheck and
     # torch.compile's tracing pass through these ops without touching a device.
@@ -618,7 +643,7 @@ def register_torch_ops():
     _gemm.register_fake(_fake(_chk_gemm))
     _ln.register_fake(_fake(_chk_ln))
     for op_ in (_attn, _attn_cls, _im2col, _gemm_res_ln, _qkv_time, _qkv_time_mx, _attn_part, _attn_comb, _quant, _ln_mx, _gemm_mx, _gemm_mx_res_ln, _qkv_time_mx_q,
-                _attn_part_mx, _attn_comb_mx):
+                _attn_part_mx, _attn_comb_mx, _qkv_time2, _qkv_space, _qkv_space_mx, _qkv_space_mx_q, _side_rows):
         op_.register_fake(_fake())
 
     from . import functional as _functional                                 # the functional ops with autograd (synchformer::linear, ::layer_norm768)
@@ -633,7 +658,8 @@ class via_dispatcher:
         with ops.via_dispatcher(): logits = engine.forward(vis, aud)
     The results are the same launches on the same buffers (tests/test_e2e_gpu.py compares them bit for bit)."""
     NAMES = ('gemm', 'layernorm', 'gemm_res_ln', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'quantize_mxfp8', 'layernorm_mxfp8',
-             'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention_mx', 'attention_cls_partial_mx', 'attention_cls_combine_mx')
+             'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention_mx', 'attention_cls_partial_mx', 'attention_cls_combine_mx', 'qkv_time_attention2',
+             'qkv_space_attention', 'qkv_space_attention_mx', 'space_side_rows')
 
     def __init__(self):
         self.calls = 0
@@ -720,7 +746,27 @@ class via_dispatcher:
             count(t.attention_cls_combine_mx)(partials, out_q, out_s, n_part, n_seq, out_seq_rows, out_row, heads)
             return out_q
 
-        g.update(attention_cls_partial_mx=attn_part_mx_, attention_cls_combine_mx=attn_comb_mx_)
+        def qkv_time2_(x, w, bias, side, out, partials, *, n_seq, scale, n_tok=196):
+            count(t.qkv_time_attention2)(x, w, bias, side, out, partials, n_seq, scale)
+            return out
+
+        def qkv_space_(x, w, bias, side, out, partials, *, n_seq, scale, n_tok=196):
+            count(t.qkv_space_attention)(x, w, bias, side, out, partials, n_seq, scale)
+            return out
+
+        def qkv_space_mx_(x_q, x_s, w_q, w_s, bias, side, out, partials, *, n_seq, scale, out_scales=None, n_tok=196):
+            if out_scales is not None:
+                count(t.qkv_space_attention_mx_q)(x_q, x_s, w_q, w_s, bias, side, out, out_scales, partials, n_seq, scale)
+                return out
+            count(t.qkv_space_attention_mx)(x_q, x_s, w_q, w_s, bias, side, out, partials, n_seq, scale)
+            return out
+
+        def side_rows_(x, out, n_seq):
+            count(t.space_side_rows)(x, out, n_seq)
+            return out
+
+        g.update(attention_cls_partial_mx=attn_part_mx_, attention_cls_combine_mx=attn_comb_mx_, qkv_time_attention2=qkv_time2_, qkv_space_attention=qkv_space_,
+                 qkv_space_attention_mx=qkv_space_mx_, space_side_rows=side_rows_)
         g.update(gemm=gemm_, layernorm=layernorm_, gemm_res_ln=gemm_res_ln_, qkv_time_attention=qkv_time_, attention_cls_partial=attn_part_,
                  attention_cls_combine=attn_comb_, quantize_mxfp8=quant_, layernorm_mxfp8=ln_mx_, gemm_mxfp8=gemm_mx_, gemm_mx_res_ln=gemm_mx_ln_,
                  qkv_time_attention_mx=qkv_time_mx_)

@@ -136,7 +136,8 @@ def test_forward_through_the_dispatcher(gpu):
     from synchformer_amd import ops, synth
     from synchformer_amd.engine import SynchformerEngine
     for name in ('gemm_bf16', 'layernorm768', 'gemm_res_ln768', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'gemm_mxfp8',
-                 'gemm_mx_res_ln768', 'quantize_mxfp8', 'layernorm768_mxfp8', 'qkv_time_attention_mx_q', 'attention_cls_partial_mx', 'attention_cls_combine_mx'):
+                 'gemm_mx_res_ln768', 'quantize_mxfp8', 'layernorm768_mxfp8', 'qkv_time_attention_mx_q', 'attention_cls_partial_mx', 'attention_cls_combine_mx',
+                 'qkv_time_attention2', 'qkv_space_attention', 'qkv_space_attention_mx_q', 'space_side_rows'):
         assert hasattr(torch.ops.synchformer, name), name
     for fp8 in (False, True):
         sd = synth.make_state_dict(1337, n_pos=184, n_out=2, head='sync_head') if fp8 else synth.make_state_dict(1337)
