@@ -26,6 +26,7 @@ struct GemmArgs {
   // strided batch (blockIdx.y = b0 * batch_inner + b1): element offsets added to A / W / C per batch index
   int batch_inner;
   int64_t sA0, sA1, sW0, sW1, sC0, sC1;
+  uint32_t stagger = 0;   // config 11: the workgroups that own one tile fewer than their XCD's first start this many x ~1.2 us late (SF_PP_STAGGER)
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst_wave_base) {

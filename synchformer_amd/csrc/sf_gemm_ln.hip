@@ -60,6 +60,8 @@ struct ResLnArgs {
   int K;
   float eps;
   uint32_t tiles;
+  uint32_t phases;
+  uint32_t stagger;                                               // measurement hook (SF_RL_STAGGER): every other workgroup of an XCD starts stagger x ~1.2 us late
 };
 
 // ABL: ablation mask of the measurement builds (tools/bench_gemm_ln.py, SF_RL_ABL): 1 = no residual loads, 2 = no X stores, 4 = no Y stores,
@@ -90,6 +92,12 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
   const int nk = p.K / RL_BK;
   uint32_t t = blockIdx.x;
   if (t >= p.tiles) return;
+  // the workgroups that own one tile fewer than workgroup 0 (tiles % gridDim.x != 0) start late: their epilogues then fall into the others' main loops
+  if (p.phases <= 1u) {
+    if ((p.tiles - 1u - blockIdx.x) / gridDim.x < (p.tiles - 1u) / gridDim.x) for (uint32_t i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(32);
+  } else {
+    for (uint32_t i = 0, n = ((blockIdx.x >> 3) % p.phases) * p.stagger; i < n; ++i) __builtin_amdgcn_s_sleep(32);
+  }
 
   int64_t m0 = (int64_t)t * RL_BM;
   const void* sa; uint32_t voff_a0;
@@ -539,6 +547,8 @@ extern "C" int sf_gemm_res_ln768(const bf16_t* A, int64_t lda, const bf16_t* W, 
   const int64_t tiles = m_pad / RL_BM;
   SF_CHECK_ARG(tiles < ((int64_t)1 << 31), "sf_gemm_res_ln768: too many tiles");
   a.tiles = (uint32_t)tiles;
+  { static int st = -1; if (st < 0) { const char* e = getenv("SF_RL_STAGGER"); st = e ? atoi(e) : 12; if (st < 0) st = 0; } a.stagger = (uint32_t)st; }
+  { static int ph = -1; if (ph < 0) { const char* e = getenv("SF_RL_PHASES"); ph = e ? atoi(e) : 1; if (ph < 1) ph = 1; } a.phases = (uint32_t)ph; }
   int64_t blocks = tiles < n_cu ? tiles : n_cu;                    // one persistent workgroup per CU
   static int abl = -1, max_blocks = -1, sched = -1;
   if (max_blocks < 0) { const char* e = getenv("SF_RL_BLOCKS"); max_blocks = e ? atoi(e) : 0; }   // measurement hook: fewer resident workgroups

@@ -49,6 +49,7 @@ struct MxResLnArgs {
   int K;
   float eps;
   uint32_t tiles;
+  uint32_t stagger;                                               // as in sf_gemm_ln.hip: the workgroups with one tile fewer start stagger x ~1.2 us late (SF_RL_STAGGER)
 };
 
 // 64 dwords (one per lane) -> 256 consecutive bytes of LDS
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_res_ln768_kernel(MxResLnArgs p
   const int nk = p.K / XL_BK;                                      // even (K % 128 == 0)
   uint32_t t = blockIdx.x;
   if (t >= p.tiles) return;
+  if ((p.tiles - 1u - blockIdx.x) / gridDim.x < (p.tiles - 1u) / gridDim.x) for (uint32_t i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(32);
 
   int64_t m0 = (int64_t)t * RL_BM;
   const void* sa; uint32_t voff_a0;
@@ -487,6 +489,7 @@ extern "C" int sf_gemm_mx_res_ln768(const uint8_t* A, int64_t lda, const uint8_t
   const int64_t tiles = m_pad / RL_BM;
   SF_CHECK_ARG(tiles < ((int64_t)1 << 31), "sf_gemm_mx_res_ln768: too many tiles");
   a.tiles = (uint32_t)tiles;
+  { static int st = -1; if (st < 0) { const char* e = getenv("SF_RL_STAGGER"); st = e ? atoi(e) : 12; if (st < 0) st = 0; } a.stagger = (uint32_t)st; }
   const int64_t blocks = tiles < n_cu ? tiles : n_cu;              // one persistent workgroup per CU
   if (int rc = sf_prepare_kernel((const void*)gemm_mx_res_ln768_kernel, RP_LDS, "sf_gemm_mx_res_ln768")) return rc;
   hipLaunchKernelGGL(gemm_mx_res_ln768_kernel, dim3((unsigned)blocks), dim3(512), RP_LDS, (hipStream_t)stream, a);

@@ -157,6 +157,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 
   // ---- load iterator: runs 6 half-tiles ahead of the reads over the workgroup's whole k-tile sequence ---------------------------
   const int nk = p.K / 64;
+  if (li >= t_end) return;
+  if (t_end && (t_end - 1u - li) / per_xcd_blocks < (t_end - 1u) / per_xcd_blocks) for (uint32_t i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(32);
   uint32_t ld_t = li;
   bool ld_ok = ld_t < t_end;
   if (!ld_ok) return;
@@ -507,6 +509,7 @@ static int launch_gemm_pp(GemmArgs a, hipStream_t s) {
   a.tiles_total = (uint32_t)total;
   static int env_chunk = -2;
   if (env_chunk == -2) { const char* e = getenv("SF_GEMM_NCHUNK"); env_chunk = e ? atoi(e) : -1; }
+  { static int st = -1; if (st < 0) { const char* e = getenv("SF_PP_STAGGER"); st = e ? atoi(e) : 0; if (st < 0) st = 0; } a.stagger = (uint32_t)st; }
   if (env_chunk >= 0) a.nchunk = (uint32_t)env_chunk;
   else a.nchunk = a.K <= 1024 ? (uint32_t)(2400000 / (512 * a.K) > 0 ? 2400000 / (512 * a.K) : 1) : 0u;
   int64_t blocks = (n_cus / 8) * 8;                          // one workgroup per CU, a multiple of the 8 XCDs
