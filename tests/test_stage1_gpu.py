@@ -86,12 +86,12 @@ def test_meanpool_l2norm_bwd(gpu, n, t):
     assert (dx.double() - xr.grad).abs().max().item() < 1e-5 * max(1.0, xr.grad.abs().max().item())
 
 
-def _setup(gpu, B, S, gain, drop_path_rate=0.0):
+def _setup(gpu, B, S, gain, drop_path_rate=0.0, seed=1337):
     from synchformer_amd import synth
     from synchformer_amd.stage1 import AVCLIPTrainer
-    sd = {k: v for k, v in synth.make_state_dict(1337, gain=gain).items() if k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}
+    sd = {k: v for k, v in synth.make_state_dict(seed, gain=gain).items() if k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}
     tr = AVCLIPTrainer(sd, gpu, lr=1e-4, drop_path_rate=drop_path_rate)
-    return sd, tr, synth.make_video_u8(B, S, 1337), synth.make_spectrogram(B, S, 1337)
+    return sd, tr, synth.make_video_u8(B, S, seed), synth.make_spectrogram(B, S, seed)
 
 
 def _compare(tr, ref_grads, rel_bar=6e-2, verbose=True):
@@ -118,10 +118,12 @@ def _compare(tr, ref_grads, rel_bar=6e-2, verbose=True):
     assert abs(n2_got ** 0.5 / n2_ref ** 0.5 - 1) < 1e-2
 
 
-def test_avclip_grads_match_oracle(gpu):
-    """B=1, S=3 (three segments = a 3x3 contrastive problem), gain-2 weights: HIP backward vs autograd through the fp32 oracle."""
+@pytest.mark.parametrize('seed', [1337, 7])
+def test_avclip_grads_match_oracle(gpu, seed):
+    """B=1, S=3 (three segments = a 3x3 contrastive problem), gain-2 weights: HIP backward vs autograd through the fp32 oracle.  Two seeds (weights AND inputs): the
+    per-tensor bar of _compare is the loosest in the suite and must not hold for one draw only."""
     from oracle import synchformer_cpu as O
-    sd, tr, u8, aud = _setup(gpu, 1, 3, 2.0)
+    sd, tr, u8, aud = _setup(gpu, 1, 3, 2.0, seed=seed)
     loss = tr.forward_backward(u8.to(gpu), aud.to(gpu))
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not k.startswith('vfeat_extractor.patch_embed.')}
     full = dict(sd)
