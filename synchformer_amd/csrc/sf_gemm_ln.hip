@@ -547,7 +547,7 @@ extern "C" int sf_gemm_res_ln768(const bf16_t* A, int64_t lda, const bf16_t* W, 
   const int64_t tiles = m_pad / RL_BM;
   SF_CHECK_ARG(tiles < ((int64_t)1 << 31), "sf_gemm_res_ln768: too many tiles");
   a.tiles = (uint32_t)tiles;
-  { static int st = -1; if (st < 0) { const char* e = getenv("SF_RL_STAGGER"); st = e ? atoi(e) : 12; if (st < 0) st = 0; } a.stagger = (uint32_t)st; }
+  { static int st = -1; if (st < 0) { const char* e = getenv("SF_RL_STAGGER"); st = e ? atoi(e) : 12; if (st < 0) st = 0; } a.stagger = K >= 768 ? (uint32_t)st : 0u; }   // (a tile of a shorter k-loop is shorter than the delay)
   { static int ph = -1; if (ph < 0) { const char* e = getenv("SF_RL_PHASES"); ph = e ? atoi(e) : 1; if (ph < 1) ph = 1; } a.phases = (uint32_t)ph; }
   int64_t blocks = tiles < n_cu ? tiles : n_cu;                    // one persistent workgroup per CU
   static int abl = -1, max_blocks = -1, sched = -1;

@@ -489,7 +489,7 @@ extern "C" int sf_gemm_mx_res_ln768(const uint8_t* A, int64_t lda, const uint8_t
   const int64_t tiles = m_pad / RL_BM;
   SF_CHECK_ARG(tiles < ((int64_t)1 << 31), "sf_gemm_mx_res_ln768: too many tiles");
   a.tiles = (uint32_t)tiles;
-  { static int st = -1; if (st < 0) { const char* e = getenv("SF_RL_STAGGER"); st = e ? atoi(e) : 12; if (st < 0) st = 0; } a.stagger = (uint32_t)st; }
+  { static int st = -1; if (st < 0) { const char* e = getenv("SF_RL_STAGGER"); st = e ? atoi(e) : 12; if (st < 0) st = 0; } a.stagger = K >= 768 ? (uint32_t)st : 0u; }   // (a tile of a shorter k-loop is shorter than the delay)
   const int64_t blocks = tiles < n_cu ? tiles : n_cu;              // one persistent workgroup per CU
   if (int rc = sf_prepare_kernel((const void*)gemm_mx_res_ln768_kernel, RP_LDS, "sf_gemm_mx_res_ln768")) return rc;
   hipLaunchKernelGGL(gemm_mx_res_ln768_kernel, dim3((unsigned)blocks), dim3(512), RP_LDS, (hipStream_t)stream, a);
