@@ -479,6 +479,8 @@ def power_probe(step_fn, vis, aud, seconds=2.0):
                 'clips_per_s': round(cps, 1), 'rocm_smi_gpu': int(gi),
                 # the step is power-limited (time = joules / cap): J/clip is the figure a kernel change has to move (track it per item)
                 'joules_per_clip': round(w_med / cps, 3),
+                # (rocm-smi answering slowly puts every sample into the gaps between steps: an idle reading says nothing about the step)
+                'suspect': bool(len(mid) < 3 or (cap is not None and w_med < 0.6 * cap)),
                 'what': 'rocm-smi next to a further ~2 s of the same forward, after the timed region; dense MFMA peaks are quoted at 2400 MHz'}
     except Exception:                                                  # noqa: BLE001
         stop.set()
