@@ -245,7 +245,12 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
         read_w(std::integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
         if (more1) pp_issue_w(2, S ^ 1);
+#ifndef SF_RL_A_EARLY
+#define SF_RL_A_EARLY 1   // the A piece of k-step kt+2 (the only piece of a stage that comes from HBM: ~2 us; W hits L2) is issued HERE, a phase earlier than its stage's W third 0: its slot - A of
+#endif                    // this k-step - is free since phase 0 (fragments in registers, the wm = 1 waves one barrier behind have read them too), and the pieces issued behind it are needed late enough
+        if (SF_RL_A_EARLY && more2) pp_issue_a(S);
         if (!more1 || (ABL & 8)) rl_wait_vmcnt<0>();               // W third 2 has landed
+        else if (SF_RL_A_EARLY && more2) { if (behind) rl_wait_vmcnt<8 + 48>(); else rl_wait_vmcnt<8>(); }
         else if (behind) rl_wait_vmcnt<7 + 48>();
         else rl_wait_vmcnt<7>();
         rl_barrier();
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(512, 2) void gemm_res_ln768_kernel(ResLnArgs p) {
           asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(fw[ks]));
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (more2) { pp_issue_a(S); pp_issue_w(0, S); }
+        if (more2) { if (!SF_RL_A_EARLY) pp_issue_a(S); pp_issue_w(0, S); }
         pp_advance();
         if (more1) {                                               // A | W third 0 of the next k-step have landed
           if (ABL & 8) rl_wait_vmcnt<0>();
