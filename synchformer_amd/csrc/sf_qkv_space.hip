@@ -537,7 +537,12 @@ __device__ __forceinline__ void qkv_space_attn_body(const QsArgs& p) {
               uint2 w;
               w.x = pack_bf2(o[e][dt][0] * linv, o[e][dt][1] * linv);
               w.y = pack_bf2(o[e][dt][2] * linv, o[e][dt][3] * linv);
-              *reinterpret_cast<uint2*>(orow + dt * 16) = w;
+#ifndef QS_OUT_NT
+#define QS_OUT_NT 0   // the nt hint on the output stores: measured 1345 us against 1300 us on the 8-byte stores of the accumulator layout (partial lines), see QS_OUT_LINES for whole lines
+#endif
+              typedef unsigned int qs_u2 __attribute__((ext_vector_type(2)));
+              const qs_u2 wv = {w.x, w.y};
+              if (QS_OUT_NT) __builtin_nontemporal_store(wv, reinterpret_cast<qs_u2*>(orow + dt * 16)); else *reinterpret_cast<qs_u2*>(orow + dt * 16) = wv;
             }
           }
         }
@@ -548,7 +553,12 @@ __device__ __forceinline__ void qkv_space_attn_body(const QsArgs& p) {
             for (int j = 0; j < 2; ++j) {
               const int row = (e ? qt1 : qt0) * 16 + (alane >> 3) + 8 * j, ch = alane & 7;
               const uint4 w = *reinterpret_cast<const uint4*>(q_lds + qs_arr_off(row, ch));
-              if (row < nq) *reinterpret_cast<uint4*>(obase + (int64_t)row * p.ldo + ch * 8) = w;
+              if (row < nq) {
+                typedef unsigned int qs_u4 __attribute__((ext_vector_type(4)));
+                const qs_u4 wv = {w.x, w.y, w.z, w.w};
+                if (QS_OUT_NT) __builtin_nontemporal_store(wv, reinterpret_cast<qs_u4*>(obase + (int64_t)row * p.ldo + ch * 8));
+                else *reinterpret_cast<qs_u4*>(obase + (int64_t)row * p.ldo + ch * 8) = wv;
+              }
             }
         }
       };

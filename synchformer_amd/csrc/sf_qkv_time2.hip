@@ -433,7 +433,14 @@ __global__ __launch_bounds__(512, 2) void qkv_time2_attn_kernel(Qt2Args p) {
               const int rr = (alane >> 3) + 8 * j, ch = alane & 7;    // tile row rr = (patch 2 qt + j, frame alane >> 3)
               const uint4 w = *reinterpret_cast<const uint4*>(qrows + qt2_arr_off(qt[e] * 16 + rr, ch));
               bf16_t* dst = p.out + (orow0 + (int64_t)(alane >> 3) * QT2_NP + 2 * qt[e] + j) * p.ldo + head * 64 + ch * 8;
-              if (!(QT2_ABL & 32) || l[e] == 12345.678f) *reinterpret_cast<uint4*>(dst) = w;
+#ifndef QT2_OUT_NT
+#define QT2_OUT_NT 1   // the attention output with the nt hint: written once, read once by the next launch
+#endif
+              if (!(QT2_ABL & 32) || l[e] == 12345.678f) {
+                typedef unsigned int qt2_u4 __attribute__((ext_vector_type(4)));
+                const qt2_u4 wv = {w.x, w.y, w.z, w.w};
+                if (QT2_OUT_NT) __builtin_nontemporal_store(wv, reinterpret_cast<qt2_u4*>(dst)); else *reinterpret_cast<qt2_u4*>(dst) = wv;
+              }
             }
           }
         }
