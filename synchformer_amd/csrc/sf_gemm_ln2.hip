@@ -8,9 +8,12 @@
 //   pass 0: X[:, 0:384] = acc + bias + R is written (fp32);
 //   pass 1: X[:, 384:768] likewise; then per row the first half is read back (the same wave wrote it: 1.5 KB out of L2), mean and CENTERED variance over all 768 values,
 //           and Y = LayerNorm(X) * gamma + beta leaves as bf16.
-// Epilogue data path: the accumulators are transposed (a lane holds one token's features), so they go through LDS in three chunks of 64 rows x 384 fp32 (row stride 1552 B:
-// float4 writes of 32 token lanes hit every bank group equally) and come back ROW-wise - a wave owns 8 rows of a chunk, a lane 4 (+2) consecutive floats of a row - so that the
-// residual loads and the X / Y stores are whole 1-KiB / 512-byte row segments.  No cross-workgroup exchange, no atomics.
+// Epilogue data path: the accumulators are transposed (a lane holds one token's features), so they go through LDS in six chunks of 32 rows x 384 fp32 (row stride 1552 B,
+// two buffers; the fp32 residual of chunk n+1 lands by LDS-DMA while chunk n is processed and the four waves that hold the chunk ADD their accumulators to it in LDS) and come
+// back ROW-wise - a wave owns 4 rows of a chunk, a lane 4 (+4) consecutive floats of a row - so that the residual loads and the X / Y stores are whole row segments.  No
+// cross-workgroup exchange, no atomics.
+// MEASURED SLOWER than schedule 1 (proj 991 us against 672 us, fc2 2003 us against 1551 us at 224 segments: the epilogue is not hidden under a main loop, 7.15 rounds of
+// tiles; profiles/r04_experiments.md section 6): kept as the tested alternative behind sf_gemm_res_ln_force_schedule(2) / SF_RL_SCHED=2, not used by the engine.
 #include "sf_common.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -23,8 +26,7 @@
 #define G2_W_PART (128 * 128)           // 16 KiB: 4 wave columns x 32 features x 64 k
 #define G2_STAGE (G2_A_BYTES + 3 * G2_W_PART)   // 72 KiB
 #define G2_CH_LD 1552                   // bytes per staged fp32 row: 384 floats + 16
-#define G2_STAT_OFF (2 * G2_STAGE)      // 144 KiB: 192 row sums of pass 0
-#define G2_BIAS_OFF (G2_STAT_OFF + 1024) // the pass's 384 bias floats
+#define G2_BIAS_OFF (2 * G2_STAGE + 1024) // 145 KiB: the pass's 384 bias floats
 #define G2_GB_OFF (G2_BIAS_OFF + 1536)  // gamma | beta (768 floats each), staged once per workgroup
 #define G2_LDS (160 * 1024)
 #ifndef G2_ABL
