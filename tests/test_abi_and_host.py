@@ -47,6 +47,17 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b'multiple of 64' in lib.sf_last_error()
     rc = lib.sf_attention(p, p, p, 8, p, 8, 1, 1, 1, 0, 0, 1, 300, -1, 1, 64, 1.0, None)
     assert rc == -1 and b'out of range' in lib.sf_last_error()
+    # the round-4 fused launches: 196-token frames only, row strides that keep a piece's chunk slot in the low 7 bits of its byte offset, out != X
+    q = p + 32
+    rc = lib.sf_qkv_time_attention2(p, 768, p, 768, None, p, 2304, q, 768, q, 1, 100, 0.125, None)
+    assert rc == -1 and b'196 patches' in lib.sf_last_error()
+    rc = lib.sf_qkv_time_attention2(p, 776, p, 768, None, p, 2304, q, 768, q, 1, 196, 0.125, None)
+    assert rc == -1 and b'row strides' in lib.sf_last_error()
+    rc = lib.sf_qkv_time_attention2(p, 768, p, 768, None, p, 2304, p, 768, q, 1, 196, 0.125, None)
+    assert rc == -1 and b'alias' in lib.sf_last_error()
+    rc = lib.sf_qkv_space_attention(p, 768, p, 768, None, p, 2304, q, 768, q, 1, 197, 0.125, None)
+    assert rc == -1 and b'196-token' in lib.sf_last_error()
+    assert lib.sf_qkv_time_attention2(p, 768, p, 768, None, p, 2304, q, 768, q, 0, 196, 0.125, None) == 0      # nothing to do
 
 
 def test_no_cpu_fallback():
