@@ -890,6 +890,9 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
     case 10: if (!fast || w_kmajor || M * lda * 2 >= ((int64_t)1 << 32) || N * ldw * 2 >= ((int64_t)1 << 32)) {
               sf_set_error("sf_gemm_bf16: config 10 needs N %% 64 == 0, a row-major weight and operands below 4 GiB"); return -1; }
             return dispatch_gemm_w4(a, obf, gelu, res, s);
+    case 12: if (!fast || !obf || res || !sf_gemm_r4_supported(a)) {
+              sf_set_error("sf_gemm_bf16: config 12 needs a bf16 output without residual, N %% 128 == 0, K %% 128 == 0, K >= 256, row strides %% 64 == 0, a row-major weight"); return -1; }
+            return sf_gemm_r4_dispatch(a, gelu, s);
     default: sf_set_error("sf_gemm_bf16: unknown tile config %d", cfg); return -1;
   }
 }

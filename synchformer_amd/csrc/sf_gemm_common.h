@@ -160,3 +160,6 @@ __device__ __forceinline__ void wait_vmcnt_barrier() {
 // config 11 (sf_gemm_pp.hip): the quadrant-phased persistent 256 x 256 x 64 kernel
 bool sf_gemm_pp_supported(const GemmArgs& a);
 int sf_gemm_pp_dispatch(const GemmArgs& a, bool out_bf16, bool gelu, bool res, hipStream_t s);
+// config 12 (sf_gemm_w4.hip): the same tile on four waves with register-resident fragments (bf16 output, optional GELU, no residual)
+bool sf_gemm_r4_supported(const GemmArgs& a);
+int sf_gemm_r4_dispatch(const GemmArgs& a, bool gelu, hipStream_t s);

@@ -867,6 +867,38 @@ def test_gemm_pp_bitwise_equals_config7(gpu, M, N, K, gelu, res):
         assert torch.equal(run(11, True), ref), 'k-tile-major weight'
 
 
+@pytest.mark.parametrize('M,N,K,gelu,bias', [
+    (256 * 9 + 77, 768, 768, False, True),          # ragged last row tile, several tiles per workgroup on a small grid
+    (256 * 40 + 1, 3072, 768, True, True),          # fc1 + GELU
+    (256 * 3, 2304, 256, False, False),             # the shortest K (two k-tile pairs), no bias
+    (8192 + 130, 768, 3072, True, True),            # long K
+    (300, 128, 384, False, True),                   # one tile, N < 256: the wn = 1 waves of the tile's second column half have nothing to store
+])
+def test_gemm_r4_bitwise_equals_config11(gpu, M, N, K, gelu, bias):
+    """Config 12 (sf_gemm_w4.hip: four waves, register-resident fragments, one LDS-DMA piece behind every fourth MFMA) multiplies the same 32x32x16 blocks in the
+    same k order as config 11 and runs the same bias / exact-erf GELU / bf16 rounding on them: bit-identical outputs on every repetition (the repetitions screen
+    for LDS-DMA / ds_read ordering races of the landing ring); rows beyond M stay untouched."""
+    from synchformer_amd import ops, _lib
+    a, w = _bf(_rand(M, K, seed=150)).to(gpu), _bf(_rand(N, K, seed=151, scale=0.05)).to(gpu)
+    b = _rand(N, seed=152).to(gpu) if bias else None
+    lib = _lib.load()
+
+    def run(cfg):
+        lib.sf_gemm_force_config(cfg)
+        try:
+            out = torch.full((M + 3, N), 7.0, device=gpu, dtype=torch.bfloat16)
+            ops.gemm(a, w, b, out, M=M, gelu=gelu)
+        finally:
+            lib.sf_gemm_force_config(-1)
+        return out
+    ref = run(11)
+    assert torch.isfinite(ref.float()).all()
+    for rep in range(6):
+        got = run(12)
+        assert torch.equal(got[M:], torch.full((3, N), 7.0, device=gpu, dtype=torch.bfloat16)), 'rows beyond M were written'
+        assert torch.equal(got, ref), f'repetition {rep}: {(got.float() - ref.float()).abs().max().item()}'
+
+
 def test_gemm_gelu_dual(gpu):
     """sf_gemm_bf16_gelu_dual (fc1 of a trained MLP: pre-activation AND gelu(pre) from one launch of config 11): the pre-activation is bit-identical to
     sf_gemm_bf16's bf16 output on config 11, the activation to its GELU epilogue; shapes outside config 11's range return 1 without launching."""
