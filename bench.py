@@ -363,6 +363,7 @@ WORKLOAD_DOC = {
 def build_workload(name, args, dev, rank, world, local):
     """-> dict(step_fn, vis, aud, B, S, serial(on), trainer)"""
     from synchformer_amd import synth
+    from synchformer_amd.dist import scaled_lr                            # base learning rate x number of GPUs (scripts/train_utils.py:218)
     from synchformer_amd.engine import SynchformerEngine
     B = args.batch if (args.batch is not None and name == args.workload) else (2 if name == 'stage1' else 16)
     trainer, eng, mel = None, None, None
@@ -376,7 +377,7 @@ def build_workload(name, args, dev, rank, world, local):
             p_.requires_grad = False
         model.train(); model.vfeat_extractor.eval(); model.afeat_extractor.eval()
         ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if world > 1 else model
-        opt = torch.optim.Adam([p_ for p_ in model.parameters() if p_.requires_grad], lr=2e-6 * world, betas=(0.9, 0.999), eps=1e-7)
+        opt = torch.optim.Adam([p_ for p_ in model.parameters() if p_.requires_grad], lr=scaled_lr(2e-6, world), betas=(0.9, 0.999), eps=1e-7)
         scaler = torch.amp.GradScaler('cuda')
         targets = synth.make_targets(B, 21, seed=1337 + rank).to(dev)
 
@@ -395,14 +396,14 @@ def build_workload(name, args, dev, rank, world, local):
         # configs/ft_synchability.yaml - frozen extractors, GlobalTransformerWithSyncabilityHead over 13 segments (184 tokens), 2-way head, batch 16 per
         # GPU; the extractors' qkv / proj / fc1 / fc2 run on MXFP8 operands (v_mfma_scale_f32_32x32x64_f8f6f4)
         from synchformer_amd.train import SyncTrainer
-        trainer = SyncTrainer(synth.make_state_dict(1337, n_pos=184, n_out=2, head='sync_head'), dev, lr=2e-6 * world, seg_chunk=args.seg_chunk,
+        trainer = SyncTrainer(synth.make_state_dict(1337, n_pos=184, n_out=2, head='sync_head'), dev, lr=scaled_lr(2e-6, world), seg_chunk=args.seg_chunk,
                               embd_pdrop=0.1, resid_pdrop=0.1, attn_pdrop=0.1, seed=1337 + rank, fp8_towers=True)
         eng = trainer.engine
         targets = synth.make_targets(B, 2, seed=1337 + rank).to(dev)
         step_fn = lambda v, a: trainer.train_step(v, a, targets)
     elif name == 'train':
         from synchformer_amd.train import SyncTrainer
-        trainer = SyncTrainer(synth.make_state_dict(1337), dev, lr=2e-6 * world, seg_chunk=args.seg_chunk, embd_pdrop=0.1, resid_pdrop=0.1,
+        trainer = SyncTrainer(synth.make_state_dict(1337), dev, lr=scaled_lr(2e-6, world), seg_chunk=args.seg_chunk, embd_pdrop=0.1, resid_pdrop=0.1,
                               attn_pdrop=0.1, seed=1337 + rank)
         eng = trainer.engine
         targets = synth.make_targets(B, 21, seed=1337 + rank).to(dev)
@@ -411,7 +412,7 @@ def build_workload(name, args, dev, rank, world, local):
         # Stage-1 AVCLIP train step (configs/segment_avclip.yaml: base_batch_size 2 clips x 14 segments per GPU, both towers trainable)
         from synchformer_amd.stage1 import AVCLIPTrainer
         sd = {k: v for k, v in synth.make_state_dict(1337).items() if k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}
-        trainer = AVCLIPTrainer(sd, dev, lr=1e-4, drop_path_rate=0.2, seed=1337 + rank)     # train mode: DropPath 0.2 like the reference's towers
+        trainer = AVCLIPTrainer(sd, dev, lr=scaled_lr(1e-4, world), drop_path_rate=0.2, seed=1337 + rank)     # train mode: DropPath 0.2 like the reference's towers
         step_fn = lambda v, a: trainer.train_step(v, a).reshape(1)
     else:
         # headline: the step starts from what the north star names - 224 x 224 uint8 frames and 16 kHz WAVEFORM segments (B, 14, 10240), both resident in HBM; the
@@ -556,6 +557,50 @@ def host_leg(eng, dev, B, steps, barrier, max_over_ranks, headline_clips_per_s, 
                     'segmenting + RGB normalisation + log-mel on the device inside the timed region (HostClipPipeline -> engine.forward_clips)'}
 
 
+def single_clip_and_dispatcher_legs(w, B, steps):
+    """Two reported side numbers of the headline engine (rank 0, one GPU, after the timed region):
+    * `latency_b1_ms` - BASELINE configs[0] is a ONE-clip workload (example.py:174-176): wall time of one 14-segment forward incl. the mel front-end, eager (ctypes
+      launches) and replayed as one captured HIP graph (engine.capture), median of 15;
+    * `dispatcher_route` - the same B-clip and 1-clip forwards with every launch of the default schedule going through the PyTorch dispatcher
+      (`torch.ops.synchformer.*`, ops.via_dispatcher) instead of straight into the C ABI: what "registered as PyTorch-ROCm custom ops" costs per step."""
+    from synchformer_amd import ops
+    eng, mel = w['eng'], w['mel']
+    v1, a1 = w['vis'][:1].contiguous(), w['aud'][:1].contiguous()
+
+    def med_ms(fn, n=15):
+        fn(); fn()
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return round(1e3 * sorted(ts)[len(ts) // 2], 3)
+
+    def batch_ms(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return round(1e3 * (time.perf_counter() - t0) / n, 3)
+    eager_b1 = med_ms(lambda: eng.forward(v1, mel(a1)))
+    direct_bB = batch_ms(lambda: eng.forward(w['vis'], mel(w['aud'])), steps)
+    with ops.via_dispatcher() as vd:
+        disp_b1 = med_ms(lambda: eng.forward(v1, mel(a1)))
+        disp_bB = batch_ms(lambda: eng.forward(w['vis'], mel(w['aud'])), steps)
+        calls = vd.calls
+    cap = eng.capture(v1, mel(a1))
+    graph_b1 = med_ms(lambda: cap(v1, mel(a1)))
+    return {'latency_b1_ms': {'eager': eager_b1, 'hip_graph': graph_b1, 'clips': 1, 'segments': w['S'],
+                              'what': 'one 14-segment clip, uint8 frames + waveform resident in HBM -> logits (mel front-end included), median of 15 synchronised forwards'},
+            'dispatcher_route': {'ms_per_step_direct': direct_bB, 'ms_per_step_dispatcher': disp_bB, 'overhead_frac': round(disp_bB / direct_bB - 1.0, 4),
+                                 'latency_b1_ms_dispatcher': disp_b1, 'latency_b1_ms_direct': eager_b1, 'clips_per_gpu': B, 'dispatcher_calls_counted': calls,
+                                 'what': 'every launch of the default schedule through torch.ops.synchformer.* (ops.via_dispatcher) against the direct ctypes path, same engine'}}
+
+
 def run_steps(w, steps, barrier, world, dist):
     barrier()
     t0 = time.perf_counter()
@@ -578,6 +623,18 @@ def main():
     local = 0 if args.single_device else int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    # one launcher process per GPU: keep its threads on the CPUs of the NUMA node that GPU hangs off (8 Python launchers on a 256-cpu host otherwise migrate across
+    # sockets and every hipLaunchKernel crosses the fabric).  Advisory: silently skipped where sysfs does not say or affinity cannot be set.
+    numa_node = -1
+    if world > 1 and not args.single_device:
+        from synchformer_amd.dist import numa_cpus_of_gpu
+        nc = numa_cpus_of_gpu(local)
+        if nc:
+            try:
+                os.sched_setaffinity(0, nc[1])
+                numa_node = nc[0]
+            except OSError:
+                pass
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -632,6 +689,7 @@ def main():
         timed_trainer.time_comm = False
         comm_ms = [round(x, 3) for x in gather_ranks(timed_trainer.exposed_comm_ms())]     # last step's stall on the gradient buckets
     per_rank = [round(B * args.steps / x, 3) for x in gather_ranks(dt_local)]
+    numa_nodes = [int(x) for x in gather_ranks(float(numa_node))] if world > 1 else []
     dt = max_over_ranks(dt_local)
 
     # ---- roofline pass: the same K steps again with every GEMM-family launch bracketed by HIP events on its launch stream.  The
@@ -685,6 +743,8 @@ def main():
         }
         if args.dropin:
             out['config']['dropin'] = 'nn.Module + autocast + GradScaler + clip_grad_norm_ + torch.optim.Adam' + (' + DistributedDataParallel' if world > 1 else '')
+        if world > 1:
+            out['launcher_numa_node_by_rank'] = numa_nodes
         if comm_ms:
             out['comm'] = {'exposed_ms_last_step_by_rank': comm_ms,
                            'what': 'time the compute stream waited for the gradient all-reduce (Stage-2: one flat 90 MB bucket after the backward; '
@@ -702,6 +762,8 @@ def main():
                 'bound': dom['bound'], 'kernel': dom['name'], 'achieved': dom['tflops'] if dom['bound'] == 'mfma' else dom['algorithmic_TBps'],
                 'peak': (agg['peak'] if dom['bound'] == 'mfma' else 8.0), 'unit': 'TFLOP/s' if dom['bound'] == 'mfma' else 'TB/s',
                 'frac': dom['frac'] if dom['bound'] == 'mfma' else round(dom['algorithmic_TBps'] / 8.0, 4),
+                # the PATH-level figure - clips/s x 5.725 TFLOP per clip / (N x 2.5 PFLOP/s bf16) - beside the dominant kernel's own fraction above
+                'path_frac': out['path_mfma_frac'], 'path_peak_TFLOPs': PEAK_BF16 * world / 1e12,
                 'avg_launch_us': dom['avg_us'], 'launches': dom['launches'],
                 'traffic': traffic, 'traffic_source': tsrc,
                 'kernels': kernels,
@@ -738,6 +800,13 @@ def main():
             if world > 1:
                 raise
             wl_out['infer_from_host'] = {'error': f'{type(ex).__name__}: {ex}'[:300]}
+        if world == 1:
+            try:
+                extra = single_clip_and_dispatcher_legs(w, B, max(args.workload_steps, 3))
+                out['latency_b1_ms'] = extra['latency_b1_ms']
+                wl_out['dispatcher_route'] = extra['dispatcher_route']
+            except Exception as ex:                                # noqa: BLE001
+                out['latency_b1_ms'] = {'error': f'{type(ex).__name__}: {ex}'[:300]}
         del w, step_fn, logits
         torch.cuda.empty_cache()
         for wn in ('train', 'stage1', 'ft'):

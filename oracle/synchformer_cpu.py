@@ -4,7 +4,7 @@ A plain fp32 restatement (torch CPU ops, functional style, own layout) of the re
 `Synchformer.forward()`.  Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
 import this; the shipped package (`synchformer_amd/`) never does and fails loudly without its HIP library.
 
-Pinning: `tests/test_oracle_vs_reference.py` runs this file against the REAL reference imported from
+Pinning: `tests/test_oracle_cpu.py::test_oracle_matches_real_reference` runs this file against the REAL reference imported from
 /root/reference (build container only) and `tests/golden/*.npz` hold outputs of the real reference on
 seeded inputs/weights (`tests/golden/make_golden.py`), so the oracle is pinned both ways.  The mel
 front-end (`mel_frontend`) restates torchaudio's MelSpectrogram, which is absent from /root/reference and

@@ -387,6 +387,7 @@ int sf_gemm_res_ln768_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* 
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.R = R; a.ldr = ldr; a.X = X; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.Y = Y; a.ldy = ldy;
   a.M = M; a.K = (int)K; a.eps = eps; a.tiles = (uint32_t)tiles;
   int64_t blocks = (n_cu / 8) * 8;
+  if (blocks < 8) blocks = 8;                                    // (a device / partition with fewer than 8 CUs: never an empty grid)
   const int64_t need = ((tiles + 7) / 8) * 8;
   if (blocks > need) blocks = need;
   hipLaunchKernelGGL(gemm_res_ln768_v2_kernel, dim3((unsigned)blocks), dim3(512), G2_LDS, (hipStream_t)stream, a);

@@ -852,6 +852,7 @@ static int mx_launch(MxArgs a, hipStream_t s) {
   // column-chunked sweeps as in the bf16 kernel: keep the weight slice of a sweep (nchunk * 256 rows * K bytes) within ~2.4 MB of the XCD's L2
   a.nchunk = a.K <= 2048 ? (uint32_t)(2400000 / (256 * a.K) > 0 ? 2400000 / (256 * a.K) : 1) : 0u;
   int64_t blocks = (n_cu / 8) * 8;
+  if (blocks < 8) blocks = 8;                                    // (a device / partition with fewer than 8 CUs: never an empty grid)
   const int64_t need = ((total + 7) / 8) * 8;
   if (blocks > need) blocks = need;
   static int env_sched = -1;

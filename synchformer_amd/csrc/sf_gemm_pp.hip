@@ -513,6 +513,7 @@ static int launch_gemm_pp(GemmArgs a, hipStream_t s) {
   if (env_chunk >= 0) a.nchunk = (uint32_t)env_chunk;
   else a.nchunk = a.K <= 1024 ? (uint32_t)(2400000 / (512 * a.K) > 0 ? 2400000 / (512 * a.K) : 1) : 0u;
   int64_t blocks = (n_cus / 8) * 8;                          // one workgroup per CU, a multiple of the 8 XCDs
+  if (blocks < 8) blocks = 8;                                    // (a device / partition with fewer than 8 CUs: never an empty grid)
   const int64_t need = ((total + 7) / 8) * 8;
   if (blocks > need) blocks = need;
 #if SF_PP_ABL & 32

@@ -193,9 +193,7 @@ __device__ __forceinline__ void qkv_space_attn_body(const QsArgs& p) {
       const int x = wave * 64 + lane;
       if (x < 240) {
         const int ch = x & 7, w3 = (x >> 3) % 3, hs = (x >> 3) / 3, srow = hs % 5, hd = hs / 5;
-        const int64_t srow_g = seq * 33 + (srow == 0 ? 0 : 1 + f * 4 + (srow - 1));
         const uint32_t voff = (uint32_t)(((srow == 0 ? 0 : 1 + f * 4 + (srow - 1)) * p.lds_ + w3 * QS_D + hd * 64 + ch * 8) * 2);
-        (void)srow_g;
         qs_dma1(voff, reinterpret_cast<const char*>(p.side + seq * 33 * p.lds_ + hp * 128), lds0 + QS_SIDE_OFF + wave * 1024);
       }
     }
@@ -610,7 +608,8 @@ extern "C" int sf_qkv_space_attention(const uint16_t* X, int64_t ldx, const uint
   static int env_hc = -1;
   if (env_hc < 0) { const char* e = getenv("SF_QS_PAIR_CHUNK"); env_hc = e ? atoi(e) : 6; if (env_hc < 1 || 6 % env_hc) env_hc = 6; }
   a.pair_chunk = (uint32_t)env_hc;
-  int64_t blocks = (n_cu / 8) * 8;
+  int64_t blocks = (n_cu / 8) * 8;                               // one workgroup per CU, a multiple of the 8 XCD slots of the tile schedule (blockIdx % 8) ...
+  if (blocks < 8) blocks = 8;                                    // ... and never an empty grid on a device / partition with fewer than 8 CUs
   const int64_t need = ((n_seq * 8 * 6 + 7) / 8) * 8;
   if (blocks > need) blocks = need;
   hipLaunchKernelGGL(qkv_space_attn_kernel, dim3((unsigned)blocks), dim3(512), QS_LDS, (hipStream_t)stream, a);
@@ -649,7 +648,8 @@ extern "C" int sf_qkv_space_attention_mx(const uint8_t* X, int64_t ldx, const ui
   a.X = reinterpret_cast<const bf16_t*>(X); a.ldx = ldx; a.W = reinterpret_cast<const bf16_t*>(W); a.ldw = ldw; a.bias = bias; a.side = side; a.lds_ = lds_;
   a.out = out; a.ldo = ldo; a.cls_part = cls_partial; a.seq_rows = seq_rows; a.n_frames = (uint32_t)(n_seq * 8); a.scale = scale; a.pair_chunk = 6;
   a.sX = sX; a.ldsx = ldsx; a.sW = sW; a.ldsw = ldsw; a.out_q = out_q; a.ldq = ldq; a.out_s = out_s; a.splane = splane;
-  int64_t blocks = (n_cu / 8) * 8;
+  int64_t blocks = (n_cu / 8) * 8;                               // one workgroup per CU, a multiple of the 8 XCD slots of the tile schedule (blockIdx % 8) ...
+  if (blocks < 8) blocks = 8;                                    // ... and never an empty grid on a device / partition with fewer than 8 CUs
   const int64_t need = ((n_seq * 8 * 6 + 7) / 8) * 8;
   if (blocks > need) blocks = need;
   hipLaunchKernelGGL(qkv_space_attn_mx_kernel, dim3((unsigned)blocks), dim3(512), QS_LDS, (hipStream_t)stream, a);

@@ -728,6 +728,7 @@ static int qkv_time_impl(const uint16_t* X, int64_t ldx, const uint16_t* W, int6
   if (env_hc < 0) { const char* e = getenv("SF_QT_HEAD_CHUNK"); env_hc = e ? atoi(e) : 12; if (env_hc < 1 || QT_HEADS % env_hc) env_hc = 12; }   // round 4: all 12 heads per sweep (1276-1283 us against 1288-1293 for chunks of 6 on the quadrant-phased loop; r02 measured the opposite on the old loop)
   a.head_chunk = (uint32_t)env_hc;
   int64_t blocks = (n_cu / 8) * 8;
+  if (blocks < 8) blocks = 8;                                    // (a device / partition with fewer than 8 CUs: never an empty grid)
   const int64_t need = ((tiles_m * QT_HEADS + 7) / 8) * 8;
   if (blocks > need) blocks = need;
   static int env_sched = -1;
@@ -793,6 +794,7 @@ static int qkv_time_mx_impl(const uint8_t* X, int64_t ldx, const uint8_t* sX, in
   a.tiles_m = (uint32_t)tiles_m;
   a.head_chunk = 6;
   int64_t blocks = (n_cu / 8) * 8;
+  if (blocks < 8) blocks = 8;                                    // (a device / partition with fewer than 8 CUs: never an empty grid)
   const int64_t need = ((tiles_m * QT_HEADS + 7) / 8) * 8;
   if (blocks > need) blocks = need;
   hipLaunchKernelGGL((qkv_time_attn_kernel<true, true>), dim3((unsigned)blocks), dim3(512), QT_LDS, (hipStream_t)stream, a);

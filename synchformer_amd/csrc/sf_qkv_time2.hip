@@ -570,6 +570,7 @@ extern "C" int sf_qkv_time_attention2(const uint16_t* X, int64_t ldx, const uint
   if (env_st < 0) { const char* e = getenv("SF_QT2_STAGGER"); env_st = e ? atoi(e) : 0; if (env_st < 0) env_st = 0; }
   a.stagger = (uint32_t)env_st;
   int64_t blocks = (n_cu / 8) * 8;
+  if (blocks < 8) blocks = 8;                                    // (a device / partition with fewer than 8 CUs: never an empty grid)
   const int64_t need = ((n_seq * 9 * 6 + 7) / 8) * 8;
   if (blocks > need) blocks = need;
   hipLaunchKernelGGL(qkv_time2_attn_kernel, dim3((unsigned)blocks), dim3(512), QT2_LDS, (hipStream_t)stream, a);

@@ -94,3 +94,71 @@ def reduce_scatter_pair(da_all: torch.Tensor, db_all: torch.Tensor, n: int) -> T
         dist.all_reduce(packed, op=dist.ReduceOp.SUM)
         out = packed[rank]
     return out[0], out[1]
+
+
+def scaled_lr(base_lr: float, world: int) -> float:
+    """The reference scales the base learning rate by the number of GPUs (scripts/train_utils.py:218 `base_learning_rate * num_gpus`)."""
+    return base_lr * max(int(world), 1)
+
+
+def scaled_warmup(warmup: int, world: int) -> int:
+    """... and divides the warm-up length of the Stage-1 schedule by the world size (train_clip_src/training/train_clip.py:312)."""
+    return int(warmup // max(int(world), 1))
+
+
+class BucketedAllReduce:
+    """Mean all-reduce of a flat gradient buffer in BUCKETS that leave while the backward is still producing the rest (Stage-1: 7 buckets of the 857 MB
+    buffer): `launch(lo, hi)` starts an asynchronous SUM all-reduce of flat[lo:hi] as soon as that range is final (on RCCL it runs on the
+    collective's own stream behind an event on the compute stream), `finish()` waits for all of them and divides by the world size - element for element the
+    sums of ONE all-reduce over the whole buffer (DDP semantics).  Without a process group both calls do nothing."""
+
+    def __init__(self, flat: torch.Tensor):
+        self.flat = flat
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.handles = []
+        self.spans = []
+
+    def launch(self, lo: int, hi: int):
+        if hi <= lo:
+            return
+        self.spans.append((lo, hi))
+        if self.world > 1:
+            self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+
+    def finish(self) -> torch.Tensor:
+        self.wait()
+        if self.world > 1:
+            self.flat.div_(self.world)
+        return self.flat
+
+    def covered(self) -> bool:
+        """True when the launched buckets tile the buffer exactly once (no gap, no overlap)."""
+        pos = 0
+        for lo, hi in sorted(self.spans):
+            if lo != pos:
+                return False
+            pos = hi
+        return pos == self.flat.numel()
+
+
+def numa_cpus_of_gpu(index: int):
+    """The CPUs of the NUMA node a GPU hangs off (sysfs; None when the platform does not say).  bench.py pins each rank's launcher thread there: eight Python
+    launchers on a 256-cpu host otherwise wander across sockets, and every hipLaunchKernel of a rank crosses the fabric to its GPU."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0'
+        node = int(open(f'/sys/bus/pci/devices/{bdf}/numa_node').read().strip())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f'/sys/devices/system/node/node{node}/cpulist').read().strip().split(','):
+            a, _, b = part.partition('-')
+            cpus.update(range(int(a), int(b or a) + 1))
+        return node, sorted(cpus)
+    except Exception:                                                       # noqa: BLE001 - advisory only
+        return None

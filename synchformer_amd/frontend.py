@@ -123,7 +123,12 @@ class HostClipPipeline:
             logits = pipe.step(next_frames, next_wave)  # forward of the staged batch || H2D of the next one
         logits = pipe.step()                            # last batch
     The logits of a step are valid on the compute (= current) stream; a slot is overwritten only after the forward that read it has finished
-    (event hand-off in both directions, no host synchronisation inside step())."""
+    (event hand-off in both directions, no host synchronisation inside step()).
+
+    LIFETIME OF THE HOST BUFFERS: stage() / step() only ENQUEUE the host-to-device copies (non_blocking from pinned memory), so the caller's frames_host /
+    wave_host must stay untouched until that transfer has completed.  stage() returns the event recorded behind the two copies (also `pipe.loaded[slot]`);
+    a loader that recycles its pinned buffers calls `pipe.wait_staged()` (host-side wait for the most recent stage()) or `event.synchronize()` /
+    `event.query()` on the returned event before it overwrites them."""
 
     def __init__(self, engine, mel: 'MelFrontend', B: int, T: int = 125, n_samples: int = 80000, H: int = 224, W: int = 224, **segment_kw):
         self.eng, self.mel, self.dev = engine, mel, engine.dev
@@ -142,12 +147,13 @@ class HostClipPipeline:
         """Pinned host copies of a batch (what a DataLoader with pin_memory=True hands over)."""
         return frames.contiguous().pin_memory(), wave.to(torch.float32).contiguous().pin_memory()
 
-    def stage(self, frames_host: torch.Tensor, wave_host: torch.Tensor):
-        """Start the transfer of one batch into the free slot (non-blocking for pinned sources)."""
+    def stage(self, frames_host: torch.Tensor, wave_host: torch.Tensor) -> 'torch.cuda.Event':
+        """Start the transfer of one batch into the free slot (non-blocking for pinned sources); returns the event recorded behind the copies."""
         if self._staged is not None and self._next == self._staged:
             raise RuntimeError('HostClipPipeline: both slots are in use - call step() before staging another batch')
-        if frames_host.shape != self.frames[0].shape or wave_host.shape != self.wave[0].shape or frames_host.dtype != torch.uint8:
-            raise ValueError(f'HostClipPipeline: expected uint8 frames {tuple(self.frames[0].shape)} and fp32 wave {tuple(self.wave[0].shape)}')
+        if frames_host.shape != self.frames[0].shape or wave_host.shape != self.wave[0].shape or frames_host.dtype != torch.uint8 or wave_host.dtype != torch.float32:
+            raise ValueError(f'HostClipPipeline: expected uint8 frames {tuple(self.frames[0].shape)} and fp32 wave {tuple(self.wave[0].shape)} '
+                             f'(got {frames_host.dtype} {tuple(frames_host.shape)}, {wave_host.dtype} {tuple(wave_host.shape)}; a non-fp32 wave would take a converting copy)')
         i = self._next
         with torch.cuda.stream(self.copy_stream):
             if not self._fresh[i]:
@@ -158,6 +164,14 @@ class HostClipPipeline:
         if self._staged is None:
             self._staged = i
         self._next = i ^ 1
+        self._last_loaded = self.loaded[i]
+        return self.loaded[i]
+
+    def wait_staged(self):
+        """Block the HOST until the most recent stage() has left the caller's host buffers (they may be recycled afterwards)."""
+        ev = getattr(self, '_last_loaded', None)
+        if ev is not None:
+            ev.synchronize()
 
     def step(self, next_frames_host: torch.Tensor = None, next_wave_host: torch.Tensor = None) -> torch.Tensor:
         """Forward of the staged batch; if a next batch is given its transfer is issued FIRST so that it runs under this forward."""

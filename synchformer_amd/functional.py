@@ -9,7 +9,11 @@ HIP kernels at operator granularity, so code outside this package can compose an
 Both are functional (fresh output tensor), carry FakeTensor implementations, an autograd formula on the backward kernels of the train steps (dgrad on
 sf_gemm_bf16 against a bf16 W^T copy, wgrad + bias gradient on sf_gemm_tn_splitk straight from the row-major operands, sf_layernorm768_bwd) and an autocast
 rule (inputs cast to bf16 / fp32 the way `torch.autocast('cuda')` treats linear / layer_norm, train_sync.py:178).  HIP device only - there is no CPU kernel,
-a CPU tensor raises in the launcher.  Shapes the backward serves: weight (N, K) with N % 128 == 0 and K % 128 == 0, at least 512 rows."""
+a CPU tensor raises in the launcher.  Shapes the backward serves: weight (N, K) with N % 128 == 0 and K % 128 == 0, at least 512 rows - checked when the
+FORWARD records its autograd node (setup_context), not first at backward time.
+Output dtype contract: `linear` ALWAYS returns bf16 (the kernels' operand / output type), also for fp32 inputs outside autocast - unlike nn.Linear, which would return
+fp32 there; cast the result if fp32 is needed.  Gradients come back in the dtype of the input they belong to, and only the ones autograd asks for are computed
+(`ctx.needs_input_grad`); the bf16 W^T operand of the data gradient is cached per weight version."""
 from typing import Optional
 
 import torch
@@ -46,49 +50,76 @@ def register():
         torch._check(x.shape[-1] == weight.shape[1], lambda: 'synchformer::linear: x (..., K) against weight (N, K)')
         return x.new_empty((*x.shape[:-1], weight.shape[0]), dtype=torch.bfloat16)
 
+    _wt_cache = {}                                                # (data_ptr, version, shape) -> bf16 W^T: one transpose per optimizer step, not one per backward
+
+    def _wT(weight, w, N, K, dev):
+        key = (weight.data_ptr(), weight._version, N, K)
+        wT = _wt_cache.get(key)
+        if wT is None:
+            if len(_wt_cache) >= 16:
+                _wt_cache.clear()
+            wT = torch.empty(K, N, device=dev, dtype=torch.bfloat16)
+            transpose(w, K, 0, 0, wT, N, 0, 0, N, K, N)
+            _wt_cache[key] = wT
+        return wT
+
+    def _bwd_shapes_ok(M, N, K):
+        return not (N % 128 or K % 128 or M < 512)
+
     @custom_op('synchformer::linear_backward', mutates_args=(), device_types='cuda')
-    def _linear_bwd(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, need_bias: bool) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def _linear_bwd(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, need_dx: bool, need_dw: bool, need_bias: bool) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """-> (dx, dw, db); a gradient that was not asked for comes back as an EMPTY tensor and its launches are skipped."""
         dy2, x2 = _rows(dy).to(torch.bfloat16).contiguous(), _rows(x).to(torch.bfloat16).contiguous()
         w = weight.to(torch.bfloat16).contiguous()
         M, (N, K) = x2.shape[0], w.shape
-        if N % 128 or K % 128 or M < 512:
+        if not _bwd_shapes_ok(M, N, K):
             raise NotImplementedError(f'synchformer::linear backward serves N % 128 == 0, K % 128 == 0, >= 512 rows (got M {M}, N {N}, K {K})')
         dev = x.device
-        # dX = dY W: the forward kernel on a bf16 W^T copy
-        wT = torch.empty(K, N, device=dev, dtype=torch.bfloat16)
-        transpose(w, K, 0, 0, wT, N, 0, 0, N, K, N)
-        dx = torch.empty(M, K, device=dev, dtype=torch.float32)
-        ops.gemm(dy2, wT, None, dx)
-        # dW = dY^T X (+ the bias gradient from the same launch): split-K partial planes summed by sf_seqsum
-        m_pad = ((M + 63) // 64) * 64
-        tiles = (N // 128) * (K // 128)
-        split = _wgrad_split(tiles) if M >= 8192 else max(1, min(_wgrad_split(tiles), m_pad // 128))
-        kc = ((m_pad // split + 63) // 64) * 64
-        part = torch.empty(split * N, K, device=dev, dtype=torch.float32)
-        bpart = torch.empty(split, N, device=dev, dtype=torch.float32)
-        lib = _lib.load()
-        _chk(lib.sf_gemm_tn_splitk(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), part.data_ptr(), bpart.data_ptr(), M, N, K, split, kc, _st()),
-             'sf_gemm_tn_splitk')
-        dw = torch.empty(N, K, device=dev, dtype=torch.float32)
-        db = torch.empty(N, device=dev, dtype=torch.float32)
-        _chk(lib.sf_seqsum(part.data_ptr(), K, split, N, K, dw.data_ptr(), 0, _st()), 'sf_seqsum')
-        _chk(lib.sf_seqsum(bpart.data_ptr(), N, split, 1, N, db.data_ptr(), 0, _st()), 'sf_seqsum')
-        return dx.view(*x.shape[:-1], K), dw, db
+        dx = torch.empty(0, device=dev, dtype=torch.float32)       # (three distinct empties: a custom op may not return one tensor twice)
+        if need_dx:                                                # dX = dY W: the forward kernel on a bf16 W^T copy
+            dx = torch.empty(M, K, device=dev, dtype=torch.float32)
+            ops.gemm(dy2, _wT(weight, w, N, K, dev), None, dx)
+            dx = dx.view(*x.shape[:-1], K)
+        dw, db = torch.empty(0, device=dev, dtype=torch.float32), torch.empty(0, device=dev, dtype=torch.float32)
+        if need_dw or need_bias:                                   # dW = dY^T X (+ the bias gradient from the same launch): split-K partial planes summed by sf_seqsum
+            m_pad = ((M + 63) // 64) * 64
+            tiles = (N // 128) * (K // 128)
+            split = _wgrad_split(tiles) if M >= 8192 else max(1, min(_wgrad_split(tiles), m_pad // 128))
+            kc = ((m_pad // split + 63) // 64) * 64
+            part = torch.empty(split * N, K, device=dev, dtype=torch.float32)
+            bpart = torch.empty(split, N, device=dev, dtype=torch.float32)
+            lib = _lib.load()
+            _chk(lib.sf_gemm_tn_splitk(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), part.data_ptr(), bpart.data_ptr(), M, N, K, split, kc, _st()),
+                 'sf_gemm_tn_splitk')
+            if need_dw:
+                dw = torch.empty(N, K, device=dev, dtype=torch.float32)
+                _chk(lib.sf_seqsum(part.data_ptr(), K, split, N, K, dw.data_ptr(), 0, _st()), 'sf_seqsum')
+            if need_bias:
+                db = torch.empty(N, device=dev, dtype=torch.float32)
+                _chk(lib.sf_seqsum(bpart.data_ptr(), N, split, 1, N, db.data_ptr(), 0, _st()), 'sf_seqsum')
+        return dx, dw, db
 
     @_linear_bwd.register_fake
-    def _(dy, x, weight, need_bias):
-        return (x.new_empty(x.shape, dtype=torch.float32), weight.new_empty(weight.shape, dtype=torch.float32),
-                weight.new_empty((weight.shape[0],), dtype=torch.float32))
+    def _(dy, x, weight, need_dx, need_dw, need_bias):
+        e = lambda: x.new_empty((0,), dtype=torch.float32)         # noqa: E731
+        return (x.new_empty(x.shape, dtype=torch.float32) if need_dx else e(), weight.new_empty(weight.shape, dtype=torch.float32) if need_dw else e(),
+                weight.new_empty((weight.shape[0],), dtype=torch.float32) if need_bias else e())
 
     def _linear_setup(ctx, inputs, output):
         x, weight, bias = inputs
+        M, (N, K) = x.numel() // max(x.shape[-1], 1), weight.shape
+        if not _bwd_shapes_ok(M, N, K):                            # (setup_context only runs when some input requires grad: fail where the graph is built)
+            raise NotImplementedError(f'synchformer::linear: the backward serves N % 128 == 0, K % 128 == 0, >= 512 rows (got M {M}, N {N}, K {K}); '
+                                      'call it under torch.no_grad() or use torch.nn.functional.linear for this shape')
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
 
     def _linear_backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        dx, dw, db = torch.ops.synchformer.linear_backward(dy, x, weight, ctx.has_bias)
-        return dx.to(x.dtype), dw.to(weight.dtype), (db if ctx.has_bias else None)
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dx, dw, db = torch.ops.synchformer.linear_backward(dy, x, weight, need_dx, need_dw, need_db)
+        return (dx.to(x.dtype) if need_dx else None), (dw.to(weight.dtype) if need_dw else None), (db if need_db else None)
 
     _linear.register_autograd(_linear_backward, setup_context=_linear_setup)
     register_autocast('synchformer::linear', 'cuda', torch.bfloat16)          # like torch.nn.functional.linear under autocast

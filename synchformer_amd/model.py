@@ -273,8 +273,8 @@ class GlobalTransformer(torch.nn.Module):
     def forward(self, v: torch.Tensor, a: torch.Tensor, targets=None, attempt_to_apply_heads=True):
         """sync_model.py:150-173: logits (B, n_out) - or, with attempt_to_apply_heads=False, ln_f of ALL tokens (B, 2 + Sv + Sa, 768), which is what the
         reference's subclass asks its parent for (sync_model.py:187)."""
-        if self.training and self.tok_pdrop > 0 and torch.is_grad_enabled():
-            raise NotImplementedError('tok_pdrop > 0 in a training forward (whole-token dropout) is not built; the configs use 0.0')
+        if self.training and self.tok_pdrop > 0:                          # (the reference's Dropout1d drops tokens in train() mode whatever the grad mode, sync_model.py:131-134,160-161)
+            raise NotImplementedError('tok_pdrop > 0 in a training-mode forward (whole-token dropout) is not built; the configs use 0.0')
         eng = _engine_for(self, 'transformer.')
         B = v.shape[0]
         return eng.global_transformer(v.reshape(B, -1, self.n_embd).float(), a.reshape(B, -1, self.n_embd).float(), apply_head=bool(attempt_to_apply_heads))

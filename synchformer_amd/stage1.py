@@ -686,23 +686,19 @@ class AVCLIPTrainer(FlatTrainer):
         With a process group the 859 MB of gradients leave in 7 buckets while the backward is still running: the audio
         tower + logit_scale right after its (short) backward, then norm/aggregator, four 3-block groups in reverse order and the token
         tables of the visual tower as they become final; RCCL runs them on its own stream behind an event on the compute stream."""
-        import torch.distributed as dist
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        handles = []
-
-        def reduce_range(span):
-            if world > 1:
-                handles.append(dist.all_reduce(self.flat_g[span[0]:span[1]], async_op=True))
-        loss = self.forward_backward(vis, aud, on_ready=reduce_range)
+        from .dist import BucketedAllReduce
+        red = BucketedAllReduce(self.flat_g)
+        world = red.world
+        loss = self.forward_backward(vis, aud, on_ready=lambda span: red.launch(span[0], span[1]))
         if world > 1 and self.time_comm:                                       # exposed communication = how long the compute stream stalls on the buckets
             self._comm_ev = self._comm_ev or (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self._comm_ev[0].record()
-        for h in handles:
-            h.wait()
+        red.wait()
         if world > 1:
             if self.time_comm:
                 self._comm_ev[1].record()
-            self.flat_g.div_(world)                                            # DDP semantics: mean over ranks
+            assert red.covered(), 'the gradient buckets do not tile the flat buffer'
+        red.finish()                                                           # DDP semantics: mean over ranks
         self.optimizer_step(lr)
         return loss
 

@@ -16,11 +16,11 @@ ROOT = Path(__file__).resolve().parent.parent
 pytestmark = pytest.mark.gpu
 
 
-def _run_bench(*extra, timeout=900):
+def _run_bench(*extra, timeout=900, gpus=2, steps=2):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
         env.pop(k, None)
-    cmd = [sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--workload-steps', '1', '--no-cpu-baseline', *extra]
+    cmd = [sys.executable, str(ROOT / 'bench.py'), '--gpus', str(gpus), '--steps', str(steps), '--warmup', '1', '--workload-steps', '1', '--no-cpu-baseline', *extra]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=str(ROOT))
     assert r.returncode == 0, f'bench.py failed (rc {r.returncode}):\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}'
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
@@ -63,3 +63,19 @@ def test_bench_two_ranks_train_workload_as_headline(gpu, workload):
     assert d['config']['clips_per_gpu'] == (2 if workload == 'stage1' else 16)
     comm = d['comm']['exposed_ms_last_step_by_rank']
     assert len(comm) == 2 and all(c >= 0 for c in comm)
+
+
+@pytest.mark.parametrize('workload', ['infer', 'stage1', 'train'])
+def test_bench_eight_ranks_single_device(gpu, workload):
+    """The size the driver's scaling run uses - EIGHT ranks - as a tested path before the first 8-GPU run: `bench.py --gpus 8` through torch.distributed.run with all
+    ranks on cuda:0 over gloo, one clip per rank; the inference headline (replicas, barrier + MAX-over-ranks timing, per-rank rates) and the two train steps whose
+    collectives span the world (Stage-1: 7 gradient buckets under the backward; Stage-2: the flat 90 MB bucket), with the learning rate scaled by the world size."""
+    d = _run_bench('--dist-backend', 'gloo', '--single-device', '--workload', workload, '--batch', '1', '--no-kernel-timing', '--no-workloads', gpus=8, steps=1, timeout=1500)
+    assert d['n_gpus'] == 8 and d['steps'] == 1 and d['scaling'] == 'weak' and d['rccl_ranks'] == 0
+    assert len(d['clips_per_s_by_rank']) == 8 and all(x > 0 for x in d['clips_per_s_by_rank'])
+    assert 0 < d['value'] <= sum(d['clips_per_s_by_rank']) * 1.001
+    assert d['config']['clips_per_gpu'] == 1 and d['config']['parallelism'] == ('replicas x8' if workload == 'infer' else 'dp8')
+    assert d['launcher_numa_node_by_rank'] == [-1] * 8                     # (--single-device: no pinning)
+    if workload != 'infer':
+        comm = d['comm']['exposed_ms_last_step_by_rank']
+        assert len(comm) == 8 and all(c >= 0 for c in comm)

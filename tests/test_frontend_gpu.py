@@ -88,3 +88,13 @@ def test_host_clip_pipeline_equals_direct_forward(gpu):
         pipe.stage(*batches[2])
     with pytest.raises(ValueError, match='expected uint8'):
         HostClipPipeline(eng, mel, B, T, n_samp).stage(batches[0][0][:1], batches[0][1])
+    with pytest.raises(ValueError, match='expected uint8'):                                  # a non-fp32 wave would take a converting (synchronous) copy
+        HostClipPipeline(eng, mel, B, T, n_samp).stage(batches[0][0], batches[0][1].double())
+    # the recycling contract: stage() hands back the event behind its copies; after wait_staged() the host buffers may be overwritten
+    p2 = HostClipPipeline(eng, mel, B, T, n_samp)
+    f_host, w_host = batches[3][0].clone().pin_memory(), batches[3][1].clone().pin_memory()
+    ev = p2.stage(f_host, w_host)
+    p2.wait_staged()
+    assert ev.query()
+    f_host.zero_(); w_host.zero_()
+    assert torch.equal(p2.step(), want[3])
