@@ -169,9 +169,9 @@ class GemmTimer:
             return self._rec(lambda: o['qkv_time_attention_mx'](x_q, x_s, w_q, w_s, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale, **kw),
                              2.0 * m * n * k, nbytes, 'qkv_time_attn_kernel<true, true>', 'N=2304 K=768', 'mxfp8')
 
-        def timed_qs(x, w, bias, side, out, partials, *, n_seq, scale, n_tok=196):
-            if not self.enabled:
-                return o['qkv_space_attention'](x, w, bias, side, out, partials, n_seq=n_seq, scale=scale, n_tok=n_tok)
+        def timed_qs(x, w, bias, side, out, partials, *, n_seq, scale, n_tok=196, key_keep=None):
+            if not self.enabled or key_keep is not None:
+                return o['qkv_space_attention'](x, w, bias, side, out, partials, n_seq=n_seq, scale=scale, n_tok=n_tok, key_keep=key_keep)
             m, n, k = n_seq * 8 * 192, 2304, 768                                       # the rows the launch projects itself (the other 33 per sequence: the side GEMM)
             nbytes = n_seq * 8 * n_tok * k * 2 + n * k * 2 + n_seq * 8 * n_tok * 768 * 2   # A + W read, the 768-wide attention output written
             return self._rec(lambda: o['qkv_space_attention'](x, w, bias, side, out, partials, n_seq=n_seq, scale=scale, n_tok=n_tok),
@@ -185,9 +185,9 @@ class GemmTimer:
             return self._rec(lambda: o['qkv_space_attention_mx'](x_q, x_s, w_q, w_s, bias, side, out, partials, n_seq=n_seq, scale=scale, out_scales=out_scales, n_tok=n_tok),
                              2.0 * m * n * k, nbytes, 'qkv_space_attn_mx_kernel', 'N=2304 K=768', 'mxfp8')
 
-        def timed_qt2(x, w, bias, side, out, partials, *, n_seq, scale, n_tok=196):
-            if not self.enabled:
-                return o['qkv_time_attention2'](x, w, bias, side, out, partials, n_seq=n_seq, scale=scale, n_tok=n_tok)
+        def timed_qt2(x, w, bias, side, out, partials, *, n_seq, scale, n_tok=196, key_keep=None):
+            if not self.enabled or key_keep is not None:
+                return o['qkv_time_attention2'](x, w, bias, side, out, partials, n_seq=n_seq, scale=scale, n_tok=n_tok, key_keep=key_keep)
             m, n, k = n_seq * 8 * 192, 2304, 768                                       # the rows the launch projects itself (the other 33 per sequence: the side GEMM)
             nbytes = n_seq * 8 * n_tok * k * 2 + n * k * 2 + n_seq * 8 * n_tok * 768 * 2   # A + W read, the 768-wide attention output written
             return self._rec(lambda: o['qkv_time_attention2'](x, w, bias, side, out, partials, n_seq=n_seq, scale=scale, n_tok=n_tok),

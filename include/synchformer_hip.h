@@ -29,7 +29,7 @@ extern "C" {
 enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2, SF_U8 = 3 };   /* element types */
 enum { SF_EPI_NONE = 0, SF_EPI_GELU = 1 };                  /* GEMM epilogue activation */
 
-#define SF_ABI_VERSION 8
+#define SF_ABI_VERSION 9
 int sf_abi_version(void);
 const char* sf_last_error(void);
 /* "gfx950" + build flags; lets the host assert it loaded the library it built */
@@ -211,10 +211,16 @@ int sf_attention_cls_combine_mx(const float* partials, int n_part, uint8_t* out_
  * X (n_seq * 1569, 768) bf16 = norm1(x), rows [CLS; frame-major patches] per sequence; W (2304, 768) bf16 = qkv.weight, bias 2304 fp32 or NULL;
  * side (n_seq * 33, 2304) bf16 = the same projection (sf_gemm_bf16 on gathered rows) of [the CLS row; for frame f = 0..7 its tokens 192..195]: row seq * 33 and rows
  * seq * 33 + 1 + 4 f + i; out (rows as X, 768) bf16: patch rows only, must not alias X; cls_partial [n_seq][12][8][66] fp32: the CLS query's softmax partial per
- * frame, as sf_attention_cls_partial writes them (merge with sf_attention_cls_combine, n_part = 8).  n_tok must be 196.  No token-mask variant: masked forwards take
- * sf_gemm_bf16 + sf_attention_cls_partial_masked.  Replaces sf_gemm_bf16 (spatial qkv) + sf_attention_cls_partial (space groups). */
+ * frame, as sf_attention_cls_partial writes them (merge with sf_attention_cls_combine, n_part = 8).  n_tok must be 196.  Replaces sf_gemm_bf16 (spatial qkv) +
+ * sf_attention_cls_partial (space groups). */
 int sf_qkv_space_attention(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
                            uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, void* stream);
+/* ... with TOKEN MASKS (round 5; Synchformer.forward(vis_mask=...), model/sync_model.py:72-80 -> the -inf key masks of vit_helper.py:107-141,
+ * video_model_builder.py:185-225): key_keep holds one byte per row of X (what sf_token_mask_video writes); a row with flag 0 is a masked KEY for every query of its
+ * frame's group and for the CLS query - its own output row is still computed, as in the reference.  An all-ones mask is bit-identical to sf_qkv_space_attention.
+ * Replaces sf_gemm_bf16 + sf_attention_cls_partial_masked on masked forwards. */
+int sf_qkv_space_attention_masked(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
+                                  uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, const uint8_t* key_keep, void* stream);
 
 /* sf_qkv_space_attention on MXFP8 operands (fp8 towers): X (rows, 768) / W (2304, 768) e4m3 bytes with stage-major scale planes (6 planes, one dword per row, ldsx / ldsw
  * bytes apart: what sf_gemm_mx_res_ln768 / sf_quantize_mxfp8 write); side (n_seq * 33, 2304) bf16 from sf_gemm_mxfp8 on gathered copies of the side rows and their scale
@@ -230,10 +236,13 @@ int sf_qkv_space_attention_mx(const uint8_t* X, int64_t ldx, const uint8_t* sX, 
  * the 4 left-over patches of a sequence (196 = 8 x 24 + 4) and the CLS row come from `side`, the (n_seq * 33, 2304) buffer sf_qkv_space_attention takes (row seq * 33 = the
  * CLS row's q | k | v, rows seq * 33 + 1 + 4 f + i = token 192 + i of frame f).  out (rows as X, 768) bf16: patch rows only, must not alias X; cls_partial
  * [n_seq][12][33][66] fp32: the CLS query's softmax partials, four per block (records 4 tb .. 4 tb + 3) + record 32 (the left-over patches and the CLS key itself) -
- * merge with sf_attention_cls_combine, n_part = 33.  n_tok must be 196; ldx and ldw multiples of 64 elements.  No key-mask variant (sf_qkv_time_attention_masked keeps that).  Replaces sf_gemm_bf16 (CLS rows) +
- * sf_qkv_time_attention. */
+ * merge with sf_attention_cls_combine, n_part = 33.  n_tok must be 196; ldx and ldw multiples of 64 elements.  Replaces sf_gemm_bf16 (CLS rows) + sf_qkv_time_attention. */
 int sf_qkv_time_attention2(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
                            uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, void* stream);
+/* ... with TOKEN MASKS (round 5; same reference lines as sf_qkv_space_attention_masked): key_keep[row] == 0 masks that KEY for the queries of its patch's 8-frame group
+ * and for the CLS query; an all-ones mask is bit-identical to sf_qkv_time_attention2.  Replaces sf_qkv_time_attention_masked on masked forwards. */
+int sf_qkv_time_attention2_masked(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
+                                  uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, const uint8_t* key_keep, void* stream);
 
 /* The temporal half of DividedSpaceTimeBlock in ONE launch (vit_helper.py:366 `self.timeattn(self.norm3(x), ..., 'b (f n) d', '(b n) f d')`,
  * DividedAttention.forward vit_helper.py:97-150): qkv projection (vit_helper.py:107) of every PATCH token + the 8-frame attention over

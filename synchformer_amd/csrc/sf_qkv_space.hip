@@ -35,6 +35,7 @@
 #define QS_SIDE_OFF (2 * QS_STAGE)     // 144 KiB: landing area of the side rows (240 x 16 B) during the main loop
 #define QS_ARR (208 * 128)             // one K / V / Q array of the attention: 208 rows of 128 B
 #define QS_BIAS_OFF (6 * QS_ARR)       // 156 KiB: the tile's 384 bias floats (behind the attention arrays: lives through main loop AND epilogue)
+#define QS_MASK_OFF (QS_BIAS_OFF + 1536) // MASK variant: one float per key of the frame's group (0 = kept, -inf = masked), 208 floats; key 0 = the CLS key
 #define QS_LDS (160 * 1024)
 #ifndef QS_ABL
 #define QS_ABL 0                       // measurement builds: 1 no attention (epilogue part 2 skipped), 2 no MFMAs in the main loop, 4 no softmax arithmetic, 8 no S phase, 16 one of the seven P V steps
@@ -56,6 +57,8 @@ struct QsArgs {
   const uint8_t* sW = nullptr; int64_t ldsw = 0;
   // MX, optional: the attention output as MXFP8 (e4m3 bytes, row stride ldq, + E8M0 bytes in the scale planes [6][rows][4], splane bytes apart) instead of bf16 `out`
   uint8_t* out_q = nullptr; int64_t ldq = 0; uint8_t* out_s = nullptr; int64_t splane = 0;
+  // MASK (template parameter): token flags, one byte per row of X; a row with flag 0 is a masked KEY (score -inf) for every query of its frame and for the CLS query
+  const uint8_t* key_keep = nullptr;
 };
 #define QS_SC_OFF (148 * 1024)         // MX: the k-tile's scale dwords, two parities x (192 token rows | 3 x 128 part rows of W) = 2 x 2304 B
 #define QS_SC_BYTES 2304
@@ -92,7 +95,7 @@ __device__ __forceinline__ int qs_arr_off(int row, int chunk) { return row * 128
 
 template <int V> using qs_ic = std::integral_constant<int, V>;
 
-template <bool MX>
+template <bool MX, bool MASK = false>
 __device__ __forceinline__ void qkv_space_attn_body(const QsArgs& p) {
   constexpr int ESZ = MX ? 1 : 2;                                 // bytes per operand element
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -323,6 +326,9 @@ __device__ __forceinline__ void qkv_space_attn_body(const QsArgs& p) {
       // the side rows first: they sit at 144 KiB, inside the second head's Q array - copy them out before anything is written there
       uint4 sv = make_uint4(0u, 0u, 0u, 0u);
       if (etid < 240) sv = *reinterpret_cast<const uint4*>(smem + QS_SIDE_OFF + etid * 16);
+      // MASK: the group's key flags -> additive score terms (the S accumulators START at them: 0 or -inf, no arithmetic in the softmax); the byte loads fly under the hand-over
+      uint8_t kflag = 1;
+      if (MASK && etid >= 256 && etid < 256 + QS_TOK + 1) { const int k = etid - 256; kflag = k == 0 ? p.key_keep[seq * p.seq_rows] : p.key_keep[xrow0 + k - 1]; }
       qs_barrier();
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
@@ -346,6 +352,10 @@ __device__ __forceinline__ void qkv_space_attn_body(const QsArgs& p) {
         const int arr = hd * 3 * QS_ARR + (w3 == 1 ? 0 : (w3 == 2 ? QS_ARR : 2 * QS_ARR));
         const int row = w3 == 0 ? (srow == 0 ? QS_TOK : QS_ROWS + srow - 1) : (srow == 0 ? 0 : QS_ROWS + srow);
         *reinterpret_cast<uint4*>(smem + arr + qs_arr_off(row, ch)) = sv;
+      }
+      if (MASK && etid >= 256 && etid < 256 + 208) {
+        const int k = etid - 256;
+        reinterpret_cast<float*>(smem + QS_MASK_OFF)[k] = (k <= QS_TOK && kflag) ? 0.f : -INFINITY;
       }
       if (etid >= 256 && etid < 256 + 176) {                        // V rows 197 .. 207 of both heads = 0: P is zero there and must meet finite values
         const int x = etid - 256, ch = x & 7, rr = (x >> 3) % 11, hd = (x >> 3) / 11;
@@ -391,7 +401,8 @@ __device__ __forceinline__ void qkv_space_attn_body(const QsArgs& p) {
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
           s[0][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-          s[1][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (MASK) { const float4 mk = *reinterpret_cast<const float4*>(smem + QS_MASK_OFF + (kt * 16 + fg * 4) * 4); s[0][kt] = f32x4{mk.x, mk.y, mk.z, mk.w}; }   // keys kt * 16 + fg * 4 + r
+          s[1][kt] = s[0][kt];
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
             if (QS_ABL & 8) continue;
@@ -579,14 +590,15 @@ __device__ __forceinline__ void qkv_space_attn_body(const QsArgs& p) {
 
 __global__ __launch_bounds__(512, 2) void qkv_space_attn_kernel(QsArgs p) { qkv_space_attn_body<false>(p); }
 __global__ __launch_bounds__(512, 2) void qkv_space_attn_mx_kernel(QsArgs p) { qkv_space_attn_body<true>(p); }
+__global__ __launch_bounds__(512, 2) void qkv_space_attn_masked_kernel(QsArgs p) { qkv_space_attn_body<false, true>(p); }
 
 // X (n_seq * seq_rows, 768) bf16 = norm1(x), seq_rows = 1 + 8 * 196 rows [CLS; frame-major patches] per sequence; W (2304, 768) bf16 = attn.qkv.weight, bias 2304 fp32 or
 // NULL; side (n_seq * 33, 2304) bf16 = the same projection of [the CLS row; per frame f its tokens 192 .. 195] (row seq * 33, rows seq * 33 + 1 + 4 f + i), computed by the
 // caller with sf_gemm_bf16 on a gathered copy of those rows; out (rows as X, 768) bf16: the PATCH rows are written (row 0 of every sequence comes from
 // sf_attention_cls_combine on cls_partial [n_seq][12][8][66] fp32, one record per frame as sf_attention_cls_partial writes them).  out must not alias X (other workgroups
 // still read X).  Reference: vit_helper.py:97-150 with the '(b f) n d' groups of :341-342, heads = 12, head dim 64, q scaled by `scale` (vit_helper.py:113).
-extern "C" int sf_qkv_space_attention(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
-                                      uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, void* stream) {
+static int qs_launch(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
+                     uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, const uint8_t* key_keep, void* stream) {
   SF_CHECK_ARG(X && W && side && out && cls_partial, "sf_qkv_space_attention: null pointer");
   SF_CHECK_ARG(n_tok == QS_TOK, "sf_qkv_space_attention: built for 196-token frames (8 frames per sequence), got %d", n_tok);
   SF_CHECK_ARG((ldx % 64) == 0 && (ldw % 64) == 0 && (lds_ % 8) == 0 && (ldo % 8) == 0 && ldx >= QS_D && ldw >= QS_D && lds_ >= 3 * QS_D && ldo >= QS_D,
@@ -599,12 +611,12 @@ extern "C" int sf_qkv_space_attention(const uint16_t* X, int64_t ldx, const uint
   SF_CHECK_ARG((int64_t)QS_TOK * ldx * 2 < ((int64_t)1 << 32) && (int64_t)3 * QS_D * ldw * 2 < ((int64_t)1 << 32) && (int64_t)33 * lds_ * 2 < ((int64_t)1 << 32),
                "sf_qkv_space_attention: a frame of X, W and a sequence's side rows must stay below 4 GiB (32-bit lane offsets)");
   SF_CHECK_ARG(n_seq * 8 * 6 < ((int64_t)1 << 31), "sf_qkv_space_attention: too many tiles");
-  if (int rc = sf_prepare_kernel((const void*)qkv_space_attn_kernel, QS_LDS, "sf_qkv_space_attention")) return rc;
+  if (int rc = sf_prepare_kernel(key_keep ? (const void*)qkv_space_attn_masked_kernel : (const void*)qkv_space_attn_kernel, QS_LDS, "sf_qkv_space_attention")) return rc;
   const int n_cu = sf_cu_count("sf_qkv_space_attention");
   if (n_cu <= 0) return -1;
   QsArgs a;
   a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.side = side; a.lds_ = lds_; a.out = out; a.ldo = ldo; a.cls_part = cls_partial;
-  a.seq_rows = seq_rows; a.n_frames = (uint32_t)(n_seq * 8); a.scale = scale;
+  a.seq_rows = seq_rows; a.n_frames = (uint32_t)(n_seq * 8); a.scale = scale; a.key_keep = key_keep;
   static int env_hc = -1;
   if (env_hc < 0) { const char* e = getenv("SF_QS_PAIR_CHUNK"); env_hc = e ? atoi(e) : 6; if (env_hc < 1 || 6 % env_hc) env_hc = 6; }
   a.pair_chunk = (uint32_t)env_hc;
@@ -612,9 +624,22 @@ extern "C" int sf_qkv_space_attention(const uint16_t* X, int64_t ldx, const uint
   if (blocks < 8) blocks = 8;                                    // ... and never an empty grid on a device / partition with fewer than 8 CUs
   const int64_t need = ((n_seq * 8 * 6 + 7) / 8) * 8;
   if (blocks > need) blocks = need;
-  hipLaunchKernelGGL(qkv_space_attn_kernel, dim3((unsigned)blocks), dim3(512), QS_LDS, (hipStream_t)stream, a);
+  if (key_keep) hipLaunchKernelGGL(qkv_space_attn_masked_kernel, dim3((unsigned)blocks), dim3(512), QS_LDS, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(qkv_space_attn_kernel, dim3((unsigned)blocks), dim3(512), QS_LDS, (hipStream_t)stream, a);
   SF_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int sf_qkv_space_attention(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
+                                      uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, void* stream) {
+  return qs_launch(X, ldx, W, ldw, bias, side, lds_, out, ldo, cls_partial, n_seq, n_tok, scale, nullptr, stream);
+}
+// The same launch with TOKEN MASKS (Synchformer.forward(vis_mask=...), sync_model.py:72-80 -> the -inf key masks of vit_helper.py:107-141): key_keep holds one byte per
+// row of X; a row with flag 0 is a masked KEY for every query of its frame's group and for the CLS query (its own output row is still computed, as in the reference).
+// The flags become additive terms (0 / -inf) the score accumulators start from: an all-ones mask is bit-identical to sf_qkv_space_attention.
+extern "C" int sf_qkv_space_attention_masked(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
+                                             uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, const uint8_t* key_keep, void* stream) {
+  SF_CHECK_ARG(key_keep, "sf_qkv_space_attention_masked: null key_keep (call sf_qkv_space_attention for an unmasked forward)");
+  return qs_launch(X, ldx, W, ldw, bias, side, lds_, out, ldo, cls_partial, n_seq, n_tok, scale, key_keep, stream);
 }
 
 // The same launch on MXFP8 operands (fp8 towers of the synchronizability fine-tune): X (rows, 768) e4m3 bytes with its stage-major scale planes sX (6 planes, ldsx bytes

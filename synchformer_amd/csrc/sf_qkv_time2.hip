@@ -22,7 +22,7 @@
 //   * The 4 left-over patches of a sequence (tokens 192..195 of every frame: rows seq * 33 + 1 + 4 f + i of `side`, the buffer sf_qkv_space_attention takes) are a ninth,
 //     GEMM-less item per (sequence, head pair): 32 array rows loaded from `side`, 4 patch units, and the CLS query's record 32 over these 32 keys AND the CLS key itself.
 //   * persistent, one workgroup per CU; every XCD owns a contiguous range of (sequence, block) row tiles and sweeps it once per chunk of head pairs.
-// No token-mask variant (masked forwards keep sf_qkv_time_attention's key flags), bf16 operands only (the MXFP8 path keeps sf_qkv_time_attention_mx).
+// Token masks: sf_qkv_time_attention2_masked (template parameter MASK: the key flags become the starting values of the score accumulators).
 #include "sf_common.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -39,6 +39,7 @@
 #define QT2_CB_OFF (6 * QT2_ARR)         // 144 KiB: CLS blocks Kc[2] | Vc[2] | Qc[2], 16 rows of 128 B each, row 0 = the sequence's CLS k / v / q of the head, rows 1..15 zero
 #define QT2_BIAS_OFF (QT2_CB_OFF + 6 * 2048)       // 156 KiB: the tile's 384 bias floats
 #define QT2_LAND_OFF (QT2_BIAS_OFF + 1536)         // 768 B: landing area of the CLS row's q | k | v of both heads (48 x 16 B, lane-linear)
+#define QT2_MASK_OFF (QT2_LAND_OFF + 768)           // MASK variant: one float per array row (patch-major, 192) + the CLS key at index 192: 0 = kept, -inf = masked
 #define QT2_LDS (160 * 1024)
 #define QT2_NPART 33                     // CLS-query records per (sequence, head): 4 per block (one per wave pair: 3 key tiles each) + 1 of the left-over item
 #ifndef QT2_ABL
@@ -57,6 +58,7 @@ struct Qt2Args {
   uint32_t pair_chunk;                   // head pairs per sweep over an XCD's row tiles (divides 6)
   float scale;
   uint32_t stagger;
+  const uint8_t* key_keep = nullptr;     // MASK (template parameter): token flags, one byte per row of X; flag 0 = a masked KEY (for its patch's group and for the CLS query)
 };
 
 typedef short qt2_s4 __attribute__((ext_vector_type(4)));
@@ -88,7 +90,8 @@ __device__ __forceinline__ int qt2_arr_off(int row, int chunk) { return row * 12
 
 template <int V> using qt2_ic = std::integral_constant<int, V>;
 
-__global__ __launch_bounds__(512, 2) void qkv_time2_attn_kernel(Qt2Args p) {
+template <bool MASK>
+__device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -271,6 +274,12 @@ __global__ __launch_bounds__(512, 2) void qkv_time2_attn_kernel(Qt2Args p) {
         int etid = threadIdx.x;
         asm volatile("" : "+v"(etid));
         const int el31 = etid & 31, ehi = (etid & 63) >> 5;
+        // MASK: the item's key flags -> additive score terms (0 / -inf) the S accumulators start from; the byte loads fly under the hand-over stores
+        uint8_t kflag = 1;
+        if (MASK && etid < QT2_ROWS + 1) {
+          const int fr = etid / QT2_TP, pl = etid - fr * QT2_TP;
+          kflag = etid == QT2_ROWS ? p.key_keep[seq * p.seq_rows] : p.key_keep[seq * p.seq_rows + 1 + (int64_t)fr * QT2_NP + tb * QT2_TP + pl];
+        }
         int rowp[3];                                                // array row of this lane's token of row block i: tile row R = 24 fr + pl -> 8 pl + fr
 #pragma unroll
         for (int i = 0; i < 3; ++i) { const int R = wm * 96 + i * 32 + el31, fr = R / QT2_TP; rowp[i] = (R - fr * QT2_TP) * 8 + fr; }
@@ -294,6 +303,10 @@ __global__ __launch_bounds__(512, 2) void qkv_time2_attn_kernel(Qt2Args p) {
           const int ch = etid & 7, w3 = (etid >> 3) % 3, hd = (etid >> 3) / 3;
           const uint4 sv = *reinterpret_cast<const uint4*>(smem + QT2_LAND_OFF + etid * 16);
           *reinterpret_cast<uint4*>(smem + QT2_CB_OFF + (w3 == 1 ? 0 : (w3 == 2 ? 2 : 4)) * 2048 + hd * 2048 + ch * 16) = sv;
+        }
+        if (MASK && etid < QT2_ROWS + 1) {
+          const int fr = etid / QT2_TP, pl = etid - fr * QT2_TP;
+          reinterpret_cast<float*>(smem + QT2_MASK_OFF)[etid == QT2_ROWS ? QT2_ROWS : pl * 8 + fr] = kflag ? 0.f : -INFINITY;
         }
         qt2_barrier();
       }
@@ -320,6 +333,11 @@ __global__ __launch_bounds__(512, 2) void qkv_time2_attn_kernel(Qt2Args p) {
         const int ch = stid & 7, w3 = (stid >> 3) % 3, hd = (stid >> 3) / 3;
         *reinterpret_cast<uint4*>(smem + QT2_CB_OFF + (w3 == 1 ? 0 : (w3 == 2 ? 2 : 4)) * 2048 + hd * 2048 + ch * 16) = cv;
       }
+      if (MASK && stid >= 64 && stid < 64 + 33) {                   // rows 8 i + f = token 192 + i of frame f, and the CLS key
+        const int r = stid - 64;
+        const uint8_t kf = r == 32 ? p.key_keep[seq * p.seq_rows] : p.key_keep[seq * p.seq_rows + 1 + (int64_t)(r & 7) * QT2_NP + QT2_ROWS + (r >> 3)];
+        reinterpret_cast<float*>(smem + QT2_MASK_OFF)[r == 32 ? QT2_ROWS : r] = kf ? 0.f : -INFINITY;
+      }
       qt2_barrier();
     }
 
@@ -344,6 +362,11 @@ __global__ __launch_bounds__(512, 2) void qkv_time2_attn_kernel(Qt2Args p) {
           k_lds[e] = smem + h * 3 * QT2_ARR;
           kc[e] = smem + QT2_CB_OFF + h * 2048;
           s0[e] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (MASK) {                                               // rows fg * 4 + r of the unit's tile; row 0 of the CLS block = the CLS key
+            const float4 mk = *reinterpret_cast<const float4*>(smem + QT2_MASK_OFF + (qt[e] * 16 + fg * 4) * 4);
+            s0[e] = f32x4{mk.x, mk.y, mk.z, mk.w};
+            s1[e][0] = reinterpret_cast<const float*>(smem + QT2_MASK_OFF)[QT2_ROWS];
+          }
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -366,7 +389,10 @@ __global__ __launch_bounds__(512, 2) void qkv_time2_attn_kernel(Qt2Args p) {
 #pragma unroll
         for (int e = 0; e < NU; ++e) m[e] = fmaxf(m[e], __shfl_xor(m[e], 16, 64));
 #pragma unroll
-        for (int e = 0; e < NU; ++e) m[e] = fmaxf(m[e], __shfl_xor(m[e], 32, 64)) * sc2;      // (finite: every query sees its own 8 frames and the CLS key)
+        for (int e = 0; e < NU; ++e) {                              // (finite without masks: every query sees its own 8 frames and the CLS key)
+          m[e] = fmaxf(m[e], __shfl_xor(m[e], 32, 64)) * sc2;
+          if (MASK && m[e] == -INFINITY) m[e] = 0.f;                // every key of the group masked: exp2(-inf) = 0 everywhere, l = 0 (a NaN row, as softmax over an all-masked row gives)
+        }
 #pragma unroll
         for (int e = 0; e < NU; ++e) {
           l[e] = 0.f;
@@ -463,6 +489,10 @@ __global__ __launch_bounds__(512, 2) void qkv_time2_attn_kernel(Qt2Args p) {
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
           s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (MASK) {
+            if (kt < NK) { const float4 mk = *reinterpret_cast<const float4*>(smem + QT2_MASK_OFF + ((kt0 + kt) * 16 + fg * 4) * 4); s[kt] = f32x4{mk.x, mk.y, mk.z, mk.w}; }
+            else s[kt][0] = reinterpret_cast<const float*>(smem + QT2_MASK_OFF)[QT2_ROWS];
+          }
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
             const bf16x8 kf = kt < NK ? *reinterpret_cast<const bf16x8*>(k_lds + qt2_arr_off((kt0 + kt) * 16 + fr_, ks * 4 + fg))
@@ -482,11 +512,12 @@ __global__ __launch_bounds__(512, 2) void qkv_time2_attn_kernel(Qt2Args p) {
           for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
         m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
         const float msc = m * sc2;
+        const float msafe = (MASK && m == -INFINITY) ? 0.f : msc;   // every key of the record masked: m = -inf, l = 0 goes to the combine (as sf_attention_cls_partial_masked writes it)
         float l = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc2, -msc)); s[kt][r] = e; l += e; }
+          for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc2, -msafe)); s[kt][r] = e; l += e; }
         l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
         f32x4 o[4];
 #pragma unroll
@@ -539,12 +570,15 @@ __global__ __launch_bounds__(512, 2) void qkv_time2_attn_kernel(Qt2Args p) {
   }
 }
 
+__global__ __launch_bounds__(512, 2) void qkv_time2_attn_kernel(Qt2Args p) { qkv_time2_attn_body<false>(p); }
+__global__ __launch_bounds__(512, 2) void qkv_time2_attn_masked_kernel(Qt2Args p) { qkv_time2_attn_body<true>(p); }
+
 // X (n_seq * 1569, 768) bf16 = norm3(x), rows [CLS; frame-major patches] per sequence; W (2304, 768) bf16 = timeattn.qkv.weight, bias 2304 fp32 or NULL; side
 // (n_seq * 33, 2304) bf16 = the same projection of [the CLS row; per frame f its tokens 192 .. 195] (row seq * 33, rows seq * 33 + 1 + 4 f + i) - the buffer layout of
 // sf_qkv_space_attention; out (rows as X, 768) bf16: the PATCH rows are written (row 0 of every sequence comes from sf_attention_cls_combine on cls_partial
 // [n_seq][12][33][66] fp32, n_part = 33).  out must not alias X.  Reference: vit_helper.py:97-150 with the '(b n) f d' groups of :343-344, 12 heads x 64, q scaled by `scale`.
-extern "C" int sf_qkv_time_attention2(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
-                                      uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, void* stream) {
+static int qt2_launch(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
+                      uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, const uint8_t* key_keep, void* stream) {
   SF_CHECK_ARG(X && W && side && out && cls_partial, "sf_qkv_time_attention2: null pointer");
   SF_CHECK_ARG(n_tok == QT2_NP, "sf_qkv_time_attention2: built for 196 patches per frame (8 frames per sequence), got %d", n_tok);
   SF_CHECK_ARG((ldx % 64) == 0 && (ldw % 64) == 0 && (lds_ % 8) == 0 && (ldo % 8) == 0 && ldx >= QT2_D && ldw >= QT2_D && lds_ >= 3 * QT2_D && ldo >= QT2_D,
@@ -557,12 +591,12 @@ extern "C" int sf_qkv_time_attention2(const uint16_t* X, int64_t ldx, const uint
   SF_CHECK_ARG(seq_rows * ldx * 2 < ((int64_t)1 << 32) && (int64_t)3 * QT2_D * ldw * 2 < ((int64_t)1 << 32) && (int64_t)33 * lds_ * 2 < ((int64_t)1 << 32),
                "sf_qkv_time_attention2: a sequence of X, W and a sequence's side rows must stay below 4 GiB (32-bit lane offsets)");
   SF_CHECK_ARG(n_seq * 9 * 6 < ((int64_t)1 << 31), "sf_qkv_time_attention2: too many tiles");
-  if (int rc = sf_prepare_kernel((const void*)qkv_time2_attn_kernel, QT2_LDS, "sf_qkv_time_attention2")) return rc;
+  if (int rc = sf_prepare_kernel(key_keep ? (const void*)qkv_time2_attn_masked_kernel : (const void*)qkv_time2_attn_kernel, QT2_LDS, "sf_qkv_time_attention2")) return rc;
   const int n_cu = sf_cu_count("sf_qkv_time_attention2");
   if (n_cu <= 0) return -1;
   Qt2Args a;
   a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.side = side; a.lds_ = lds_; a.out = out; a.ldo = ldo; a.cls_part = cls_partial;
-  a.seq_rows = seq_rows; a.n_rt = (uint32_t)(n_seq * 9); a.scale = scale;
+  a.seq_rows = seq_rows; a.n_rt = (uint32_t)(n_seq * 9); a.scale = scale; a.key_keep = key_keep;
   static int env_hc = -1;
   if (env_hc < 0) { const char* e = getenv("SF_QT2_PAIR_CHUNK"); env_hc = e ? atoi(e) : 6; if (env_hc < 1 || 6 % env_hc) env_hc = 6; }
   a.pair_chunk = (uint32_t)env_hc;
@@ -573,7 +607,20 @@ extern "C" int sf_qkv_time_attention2(const uint16_t* X, int64_t ldx, const uint
   if (blocks < 8) blocks = 8;                                    // (a device / partition with fewer than 8 CUs: never an empty grid)
   const int64_t need = ((n_seq * 9 * 6 + 7) / 8) * 8;
   if (blocks > need) blocks = need;
-  hipLaunchKernelGGL(qkv_time2_attn_kernel, dim3((unsigned)blocks), dim3(512), QT2_LDS, (hipStream_t)stream, a);
+  if (key_keep) hipLaunchKernelGGL(qkv_time2_attn_masked_kernel, dim3((unsigned)blocks), dim3(512), QT2_LDS, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(qkv_time2_attn_kernel, dim3((unsigned)blocks), dim3(512), QT2_LDS, (hipStream_t)stream, a);
   SF_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int sf_qkv_time_attention2(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
+                                      uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, void* stream) {
+  return qt2_launch(X, ldx, W, ldw, bias, side, lds_, out, ldo, cls_partial, n_seq, n_tok, scale, nullptr, stream);
+}
+// The same launch with TOKEN MASKS (Synchformer.forward(vis_mask=...), sync_model.py:72-80 -> vit_helper.py:107-141): key_keep holds one byte per row of X; a row with flag
+// 0 is a masked KEY for the queries of its patch's 8-frame group and for the CLS query.  The flags become additive terms (0 / -inf) the score accumulators start from:
+// an all-ones mask is bit-identical to sf_qkv_time_attention2.
+extern "C" int sf_qkv_time_attention2_masked(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
+                                             uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, const uint8_t* key_keep, void* stream) {
+  SF_CHECK_ARG(key_keep, "sf_qkv_time_attention2_masked: null key_keep (call sf_qkv_time_attention2 for an unmasked forward)");
+  return qt2_launch(X, ldx, W, ldw, bias, side, lds_, out, ldo, cls_partial, n_seq, n_tok, scale, key_keep, stream);
 }

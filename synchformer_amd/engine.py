@@ -324,8 +324,9 @@ class SynchformerEngine:
         # fc2 stays un-fused because the norm after it is the row-mapped final norm below.
         fuse_ln = self.fuse_ln and rows >= 128 * 64
         fuse_time = self.fuse_time and rows >= 128 * 64
-        fuse_space = self.fuse_space and rows >= 128 * 64 and tok_keep is None and fuse_mode != 'none'   # (token masks take the un-fused, masked launches)
-        fuse_time2 = fuse_time and self.fuse_time2 and tok_keep is None and fuse_mode != 'none'        # (key masks: sf_qkv_time_attention's flags)
+        # (round 5: token-masked forwards run the same fused launches - sf_qkv_space_attention_masked / sf_qkv_time_attention2_masked take the key flags)
+        fuse_space = self.fuse_space and rows >= 128 * 64 and fuse_mode != 'none'
+        fuse_time2 = fuse_time and self.fuse_time2 and fuse_mode != 'none'
         if fuse_space or fuse_time2:
             side_in = self._buf('side_in', n * 33 * D, torch.bfloat16).view(n * 33, D)
             side = self._buf('side', n * 33 * 3 * D, torch.bfloat16).view(n * 33, 3 * D)
@@ -340,7 +341,7 @@ class SynchformerEngine:
                 # patches 192..195 of every frame (196 = 8 x 24 + 4): the same 33 rows per segment as in the spatial half - go through a small GEMM up front.
                 ops.space_side_rows(xn, side_in, n)
                 ops.gemm(side_in, b['t_qkv'].w, b['t_qkv'].b, side)
-                ops.qkv_time_attention2(xn, b['t_qkv'].w, b['t_qkv'].b, side, att, part, n_seq=n, scale=0.125)
+                ops.qkv_time_attention2(xn, b['t_qkv'].w, b['t_qkv'].b, side, att, part, n_seq=n, scale=0.125, key_keep=tok_keep)
                 ops.attention_cls_combine(part, att, n_part=33, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
                 t_out = att
             elif fuse_time:
@@ -364,7 +365,7 @@ class SynchformerEngine:
                 # project itself - the CLS row and the last 4 tokens of every frame (196 = 6 x 32 + 4) - go through a 33-rows-per-segment GEMM up front.
                 ops.space_side_rows(xn, side_in, n)
                 ops.gemm(side_in, b['s_qkv'].w, b['s_qkv'].b, side)
-                ops.qkv_space_attention(xn, b['s_qkv'].w, b['s_qkv'].b, side, att, part, n_seq=n, scale=0.125)
+                ops.qkv_space_attention(xn, b['s_qkv'].w, b['s_qkv'].b, side, att, part, n_seq=n, scale=0.125, key_keep=tok_keep)
                 ops.attention_cls_combine(part, att, n_part=8, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
                 s_out = att
             else:

@@ -13,15 +13,17 @@ forward on CPU tensors raises.  Out-of-scope options of the reference constructo
 extractors, joint/trajectory attention - SURVEY §2 rows 4b/5/6) raise NotImplementedError
 naming the option.
 """
+import contextlib
 import importlib
 import logging
+import os
 import sys
 import types
 from typing import Any, Mapping, Optional
 
 import torch
 
-from . import synth
+from . import ops, synth
 from .engine import SynchformerEngine
 
 # reference dotted path -> class name in this module (nested `target:` strings of configs/*.yaml)
@@ -369,6 +371,7 @@ def _engine_for(module: torch.nn.Module, prefix: str) -> SynchformerEngine:
 
 class Synchformer(torch.nn.Module):
     """model/sync_model.py:23-114 - same constructor, forward contract and state-dict schema."""
+    dispatcher_route = os.environ.get('SF_DISPATCHER', '1') != '0'      # forward() launches through torch.ops.synchformer.* (see forward)
 
     def __init__(self, afeat_extractor, vfeat_extractor, aproj, vproj, transformer):
         super().__init__()
@@ -436,14 +439,19 @@ class Synchformer(torch.nn.Module):
         if aud_mask is not None and for_loop:
             raise AssertionError('cont_mask is not supported with for_loop=True')       # ast.py:153
         vis_in = vis
-        # the two extractors are independent (sync_model.py:45-52): the audio tower runs on a second stream next to the visual one
-        trainable = self._trainable_params()
-        training = torch.is_grad_enabled() and any(p.requires_grad for p in trainable.values())
-        vis, aud = self._engine(need_sync=not training).both_towers(lambda: self.extract_vfeats(vis_in, for_loop, vis_mask=vis_mask), aud, aud_mask)
-        if training:
-            logits = self._train_forward(vis, aud, trainable)
-        else:
-            logits = self._engine().sync_transformer(vis, aud)
+        # "registered as PyTorch-ROCm custom ops" (SURVEY 8b(1)): the drop-in module's launches go through the PyTorch dispatcher - torch.ops.synchformer.*, visible
+        # to profilers / dispatch modes / torch.library consumers - unless `dispatcher_route` is switched off.  Measured cost (bench.py `workloads.dispatcher_route`):
+        # -0.1 % at 16 clips (noise), +0.5 % on a single clip; the engine's own loops (bench.py, SyncTrainer) keep the direct ctypes path.
+        route = ops.via_dispatcher() if self.dispatcher_route else contextlib.nullcontext()
+        with route:
+            # the two extractors are independent (sync_model.py:45-52): the audio tower runs on a second stream next to the visual one
+            trainable = self._trainable_params()
+            training = torch.is_grad_enabled() and any(p.requires_grad for p in trainable.values())
+            vis, aud = self._engine(need_sync=not training).both_towers(lambda: self.extract_vfeats(vis_in, for_loop, vis_mask=vis_mask), aud, aud_mask)
+            if training:
+                logits = self._train_forward(vis, aud, trainable)
+            else:
+                logits = self._engine().sync_transformer(vis, aud)
         return self.compute_loss(logits, targets, loss_fn), logits
 
     # -- Stage-2 training (extractors frozen, train_utils.py:199-204) ---------------------------------------

@@ -322,14 +322,22 @@ def space_side_rows(x: torch.Tensor, side_in: torch.Tensor, n_seq: int, seq_rows
 
 
 def qkv_space_attention(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, *, n_seq: int,
-                        scale: float, n_tok: int = 196):
+                        scale: float, n_tok: int = 196, key_keep: Optional[torch.Tensor] = None):
     """Spatial qkv projection + space attention of every patch token in one launch (sf_qkv_space_attention): x (n_seq * 1569, 768) bf16, w (2304, 768) bf16,
     side (n_seq * 33, 2304) bf16 = the projection of the rows of space_side_rows(); out: patch rows of the attention output (a buffer of its own), partials: the CLS
-    query's softmax partials, one per frame, for attention_cls_combine(n_part=8)."""
+    query's softmax partials, one per frame, for attention_cls_combine(n_part=8).  key_keep (uint8, one flag per row of x; 0 = masked key): the token-mask form
+    (sf_qkv_space_attention_masked)."""
     assert x.dtype == w.dtype == side.dtype == out.dtype == torch.bfloat16 and partials.dtype == torch.float32
     rows = n_seq * (1 + 8 * n_tok)
     assert x.shape[1] == 768 and tuple(w.shape) == (2304, 768) and side.shape[0] >= n_seq * 33 and side.shape[1] == 2304 and out.shape[1] == 768
     assert x.shape[0] >= rows and out.shape[0] >= rows and partials.numel() >= n_seq * 12 * 8 * 66 and x.data_ptr() != out.data_ptr()
+    if key_keep is not None:
+        assert key_keep.dtype == torch.uint8 and key_keep.numel() >= rows and key_keep.is_contiguous()
+        rc = _lib.load().sf_qkv_space_attention_masked(_dev(x, 'x'), _ld(x), _dev(w, 'w'), _ld(w), _dev(bias, 'bias') if bias is not None else None, _dev(side, 'side'),
+                                                       _ld(side), _dev(out, 'out'), _ld(out), _dev(partials, 'partials'), n_seq, n_tok, float(scale),
+                                                       _dev(key_keep, 'key_keep'), _stream())
+        _lib.check(rc, 'sf_qkv_space_attention_masked')
+        return out
     rc = _lib.load().sf_qkv_space_attention(_dev(x, 'x'), _ld(x), _dev(w, 'w'), _ld(w), _dev(bias, 'bias') if bias is not None else None, _dev(side, 'side'), _ld(side),
                                             _dev(out, 'out'), _ld(out), _dev(partials, 'partials'), n_seq, n_tok, float(scale), _stream())
     _lib.check(rc, 'sf_qkv_space_attention')
@@ -337,7 +345,7 @@ def qkv_space_attention(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.T
 
 
 def qkv_time_attention2(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, *, n_seq: int,
-                        scale: float, n_tok: int = 196):
+                        scale: float, n_tok: int = 196, key_keep: Optional[torch.Tensor] = None):
     """Temporal qkv projection + time attention of every patch token in one launch on the 192 x 384 main loop (sf_qkv_time_attention2): x (n_seq * 1569, 768) bf16,
     w (2304, 768) bf16, side (n_seq * 33, 2304) bf16 = the projection of the rows of space_side_rows(); out: patch rows of the attention output (a buffer of its own),
     partials: the CLS query's softmax partials, 33 per sequence and head, for attention_cls_combine(n_part=33)."""
@@ -345,6 +353,13 @@ def qkv_time_attention2(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.T
     rows = n_seq * (1 + 8 * n_tok)
     assert x.shape[1] == 768 and tuple(w.shape) == (2304, 768) and side.shape[0] >= n_seq * 33 and side.shape[1] == 2304 and out.shape[1] == 768
     assert x.shape[0] >= rows and out.shape[0] >= rows and partials.numel() >= n_seq * 12 * 33 * 66 and x.data_ptr() != out.data_ptr()
+    if key_keep is not None:                                # token masks (sf_qkv_time_attention2_masked): uint8, one flag per row of x, 0 = masked key
+        assert key_keep.dtype == torch.uint8 and key_keep.numel() >= rows and key_keep.is_contiguous()
+        rc = _lib.load().sf_qkv_time_attention2_masked(_dev(x, 'x'), _ld(x), _dev(w, 'w'), _ld(w), _dev(bias, 'bias') if bias is not None else None, _dev(side, 'side'),
+                                                       _ld(side), _dev(out, 'out'), _ld(out), _dev(partials, 'partials'), n_seq, n_tok, float(scale),
+                                                       _dev(key_keep, 'key_keep'), _stream())
+        _lib.check(rc, 'sf_qkv_time_attention2_masked')
+        return out
     rc = _lib.load().sf_qkv_time_attention2(_dev(x, 'x'), _ld(x), _dev(w, 'w'), _ld(w), _dev(bias, 'bias') if bias is not None else None, _dev(side, 'side'), _ld(side),
                                             _dev(out, 'out'), _ld(out), _dev(partials, 'partials'), n_seq, n_tok, float(scale), _stream())
     _lib.check(rc, 'sf_qkv_time_attention2')
@@ -661,10 +676,19 @@ class via_dispatcher:
              'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention_mx', 'attention_cls_partial_mx', 'attention_cls_combine_mx', 'qkv_time_attention2',
              'qkv_space_attention', 'qkv_space_attention_mx', 'space_side_rows')
 
+    _depth = 0                                                    # re-entrant: an inner `with` inside an active one changes nothing
+    calls_total = 0                                               # launches that went through torch.ops.synchformer.* since import (all instances)
+
     def __init__(self):
         self.calls = 0
+        self._nested = False
 
     def __enter__(self):
+        if via_dispatcher._depth > 0:
+            via_dispatcher._depth += 1
+            self._nested = True
+            return self
+        via_dispatcher._depth = 1
         register_torch_ops()
         g = globals()
         o = self.orig = {n: g[n] for n in self.NAMES}
@@ -673,6 +697,7 @@ class via_dispatcher:
         def count(fn):
             def run(*a):
                 self.calls += 1
+                via_dispatcher.calls_total += 1
                 return fn(*a)
             return run
 
@@ -746,11 +771,15 @@ class via_dispatcher:
             count(t.attention_cls_combine_mx)(partials, out_q, out_s, n_part, n_seq, out_seq_rows, out_row, heads)
             return out_q
 
-        def qkv_time2_(x, w, bias, side, out, partials, *, n_seq, scale, n_tok=196):
+        def qkv_time2_(x, w, bias, side, out, partials, *, n_seq, scale, n_tok=196, key_keep=None):
+            if key_keep is not None:                                # (the registered schema carries no key flags: masked forwards take the direct path)
+                return o['qkv_time_attention2'](x, w, bias, side, out, partials, n_seq=n_seq, scale=scale, n_tok=n_tok, key_keep=key_keep)
             count(t.qkv_time_attention2)(x, w, bias, side, out, partials, n_seq, scale)
             return out
 
-        def qkv_space_(x, w, bias, side, out, partials, *, n_seq, scale, n_tok=196):
+        def qkv_space_(x, w, bias, side, out, partials, *, n_seq, scale, n_tok=196, key_keep=None):
+            if key_keep is not None:
+                return o['qkv_space_attention'](x, w, bias, side, out, partials, n_seq=n_seq, scale=scale, n_tok=n_tok, key_keep=key_keep)
             count(t.qkv_space_attention)(x, w, bias, side, out, partials, n_seq, scale)
             return out
 
@@ -773,4 +802,8 @@ class via_dispatcher:
         return self
 
     def __exit__(self, *exc):
+        via_dispatcher._depth -= 1
+        if self._nested:
+            self._nested = False
+            return
         globals().update(self.orig)

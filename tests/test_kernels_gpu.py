@@ -1046,6 +1046,86 @@ def test_qkv_space_attention(gpu, n_seq):
 
 
 @pytest.mark.parametrize('n_seq', [3, 40])
+def test_qkv_fused_attention_key_masks(gpu, n_seq):
+    """Round 5: the token-mask forms of the two fused attention launches (sf_qkv_space_attention_masked, sf_qkv_time_attention2_masked; vit_helper.py:107-141 with the
+    masks of sync_model.py:72-80) against the un-fused masked launches they replace on masked forwards - sf_gemm_bf16 + sf_attention_cls_partial_masked (space groups)
+    and sf_qkv_time_attention_masked - and the all-ones mask bit-identical to the unmasked launch.  The mask drops random tokens, one whole frame (a CLS partial record
+    with every key masked: m = -inf, l = 0 through the combine) and one patch in all its 8 frames (a time group whose only key is the CLS key)."""
+    from synchformer_amd import ops
+    L, D = 1569, 768
+    rows = n_seq * L
+    x = _bf(_rand(rows, D, seed=160)).to(gpu)
+    w, b = _bf(_rand(3 * D, D, seed=161, scale=0.05)).to(gpu), (0.1 * _rand(3 * D, seed=162)).to(gpu)
+    g = torch.Generator().manual_seed(163)
+    keep = (torch.rand(n_seq, L, generator=g) > 0.3)
+    keep[:, 0] = True                                                   # the CLS token is never masked (sf_token_mask_video leaves it 1)
+    keep[1, 1 + 3 * 196:1 + 4 * 196] = False                            # sequence 1: frame 3 completely masked
+    keep[2, 1 + 50::196] = False                                        # sequence 2: patch 50 masked in every frame
+    keep[0, 1 + 194::196] = False                                       # ... and a left-over patch (tokens 192..195 go through the side rows)
+    keep = keep.reshape(rows).to(torch.uint8).to(gpu)
+    ones = torch.ones(rows, device=gpu, dtype=torch.uint8)
+    side_in = torch.empty(n_seq * 33, D, device=gpu, dtype=torch.bfloat16)
+    ops.space_side_rows(x, side_in, n_seq)
+    side = torch.empty(n_seq * 33, 3 * D, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(side_in, w, b, side)
+    qkv = torch.empty(rows, 3 * D, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(x, w, b, qkv)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+
+    # ---- space
+    def space(kk):
+        out = torch.full((rows, D), 7.0, device=gpu, dtype=torch.bfloat16)
+        part = torch.zeros(n_seq * 12 * 8 * 66, device=gpu)
+        ops.qkv_space_attention(x, w, b, side, out, part, n_seq=n_seq, scale=0.125, key_keep=kk)
+        return out, part
+    o_none, p_none = space(None)
+    o_ones, p_ones = space(ones)
+    assert torch.equal(o_ones, o_none) and torch.equal(p_ones, p_none), 'an all-ones mask must be bit-identical to the unmasked launch'
+    o_m, p_m = space(keep)
+    o_m2, p_m2 = space(keep)
+    assert torch.equal(o_m, o_m2) and torch.equal(p_m, p_m2)
+    assert (o_m.float() - o_none.float()).abs().max() > 0.05
+    ref = torch.zeros(rows, D, device=gpu, dtype=torch.bfloat16)
+    part_ref = torch.zeros(n_seq * 12 * 8 * 66, device=gpu)
+    ops.attention_cls_partial(q, k, v, ref, part_ref, n_seq=n_seq, seq_rows=L, n_groups=8, row0=1, group_stride=196, tok_stride=1, n_tok=196, cls_row=0, heads=12,
+                              head_dim=64, scale=0.125, key_keep=keep)
+    ops.attention_cls_combine(part_ref, ref, n_part=8, n_seq=n_seq, out_seq_rows=L, out_row=0, heads=12)
+    ops.attention_cls_combine(p_m, o_m, n_part=8, n_seq=n_seq, out_seq_rows=L, out_row=0, heads=12)
+    o, r = o_m.float().view(n_seq, L, D), ref.float().view(n_seq, L, D)
+    assert torch.isfinite(o).all()
+    # (both round the projection to bf16 but sum over k in different tile orders: a few q / k / v elements land one bf16 ulp apart; with a third of the keys gone a
+    #  softmax averages over fewer of them than in test_qkv_space_attention - one more ulp of head room, and the large deviations stay rare)
+    torch.testing.assert_close(o[:, 1:], r[:, 1:], rtol=2 ** -6, atol=2 ** -6)
+    assert (o[:, 1:] - r[:, 1:]).abs().gt(2e-3).float().mean() < 2e-3
+    torch.testing.assert_close(o[:, 0], r[:, 0], rtol=2 ** -6, atol=2 ** -7)
+
+    # ---- time
+    def time2(kk):
+        out = torch.full((rows, D), 7.0, device=gpu, dtype=torch.bfloat16)
+        part = torch.zeros(n_seq * 12 * 33 * 66, device=gpu)
+        ops.qkv_time_attention2(x, w, b, side, out, part, n_seq=n_seq, scale=0.125, key_keep=kk)
+        return out, part
+    t_none, tp_none = time2(None)
+    t_ones, tp_ones = time2(ones)
+    assert torch.equal(t_ones, t_none) and torch.equal(tp_ones, tp_none)
+    t_m, tp_m = time2(keep)
+    t_m2, tp_m2 = time2(keep)
+    assert torch.equal(t_m, t_m2) and torch.equal(tp_m, tp_m2)
+    assert (t_m.float() - t_none.float()).abs().max() > 0.05
+    qkv_cls = torch.empty(n_seq, 3 * D, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(x.view(n_seq, L, D)[:, 0], w, b, qkv_cls)
+    ref_t = torch.zeros(rows, D, device=gpu, dtype=torch.bfloat16)
+    part_t = torch.zeros(n_seq * 12 * 49 * 66, device=gpu)
+    ops.qkv_time_attention(x, w, b, qkv_cls, ref_t, part_t, n_seq=n_seq, n_groups=196, scale=0.125, key_keep=keep)
+    ops.attention_cls_combine(part_t, ref_t, n_part=49, n_seq=n_seq, out_seq_rows=L, out_row=0, heads=12)
+    ops.attention_cls_combine(tp_m, t_m, n_part=33, n_seq=n_seq, out_seq_rows=L, out_row=0, heads=12)
+    o, r = t_m.float().view(n_seq, L, D), ref_t.float().view(n_seq, L, D)
+    assert torch.isfinite(o).all()
+    torch.testing.assert_close(o[:, 1:], r[:, 1:], rtol=2 ** -6, atol=2 ** -6)     # (P rounded to bf16 for the P V MFMA here, 9 keys per query: as test_qkv_time_attention2)
+    torch.testing.assert_close(o[:, 0], r[:, 0], rtol=2 ** -6, atol=2 ** -7)
+
+
+@pytest.mark.parametrize('n_seq', [3, 40])
 def test_qkv_time_attention2(gpu, n_seq):
     """sf_qkv_time_attention2 (temporal qkv projection + time attention + CLS-query partials on the 192 x 384 main loop; 24-patch blocks, the 4 left-over patches
     and the CLS row from the 33-rows-per-segment side GEMM) against the un-fused sequence: sf_gemm_bf16 -> sf_attention_cls_partial (time groups, CLS key first) +
