@@ -222,6 +222,14 @@ int sf_qkv_space_attention(const uint16_t* X, int64_t ldx, const uint16_t* W, in
 int sf_qkv_space_attention_masked(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
                                   uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, const uint8_t* key_keep, void* stream);
 
+/* The rows the two fused attention launches do not project themselves, gathered for their small GEMM in ONE launch (round 5; was two sf_copy_rows_bf16 launches, and three
+ * torch index ops on the MXFP8 path): out row seq * 33 <- X row seq * (1 + 8 n_tok) (the CLS row), out row seq * 33 + 1 + 4 f + i <- token n_tok - 4 + i of frame f.
+ * row_bytes per row (1536 = a bf16 row of 768; 768 = the e4m3 bytes of an MXFP8 operand), strides in BYTES; with sX / sOut the rows' scale dwords of n_planes stage-major
+ * planes as well (plane k at sX + k ldsx, one dword per row -> sOut + k ldso).  Reference: the CLS row and the tokens of vit_helper.py:100-158 that 196 = 6 x 32 + 4 = 8 x 24
+ * + 4 leaves over. */
+int sf_side_rows(const void* X, int64_t ldx_bytes, void* out, int64_t ldo_bytes, int row_bytes, const uint8_t* sX, int64_t ldsx, uint8_t* sOut, int64_t ldso,
+                 int n_planes, int64_t n_seq, int n_tok, void* stream);
+
 /* sf_qkv_space_attention on MXFP8 operands (fp8 towers): X (rows, 768) / W (2304, 768) e4m3 bytes with stage-major scale planes (6 planes, one dword per row, ldsx / ldsw
  * bytes apart: what sf_gemm_mx_res_ln768 / sf_quantize_mxfp8 write); side (n_seq * 33, 2304) bf16 from sf_gemm_mxfp8 on gathered copies of the side rows and their scale
  * dwords.  Output EITHER out (bf16) OR out_q / out_s (e4m3 bytes (rows, 768), row stride ldq, + E8M0 bytes in the scale planes [6][rows][4], splane bytes apart: byte for
@@ -243,6 +251,13 @@ int sf_qkv_time_attention2(const uint16_t* X, int64_t ldx, const uint16_t* W, in
  * and for the CLS query; an all-ones mask is bit-identical to sf_qkv_time_attention2.  Replaces sf_qkv_time_attention_masked on masked forwards. */
 int sf_qkv_time_attention2_masked(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias, const uint16_t* side, int64_t lds_,
                                   uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, const uint8_t* key_keep, void* stream);
+
+/* sf_qkv_time_attention2 on MXFP8 operands (round 5: the temporal half of the fp8 towers on the round-4 schedule; arguments as sf_qkv_space_attention_mx, cls_partial
+ * [n_seq][12][33][66]).  Output EITHER out (bf16) OR out_q / out_s (byte for byte sf_quantize_mxfp8 of the bf16 output).  Replaces sf_gemm_mxfp8 (CLS rows) +
+ * sf_qkv_time_attention_mx(_q). */
+int sf_qkv_time_attention2_mx(const uint8_t* X, int64_t ldx, const uint8_t* sX, int64_t ldsx, const uint8_t* W, int64_t ldw, const uint8_t* sW, int64_t ldsw,
+                              const float* bias, const uint16_t* side, int64_t lds_, uint16_t* out, int64_t ldo, uint8_t* out_q, int64_t ldq, uint8_t* out_s,
+                              int64_t splane, float* cls_partial, int64_t n_seq, int n_tok, float scale, void* stream);
 
 /* The temporal half of DividedSpaceTimeBlock in ONE launch (vit_helper.py:366 `self.timeattn(self.norm3(x), ..., 'b (f n) d', '(b n) f d')`,
  * DividedAttention.forward vit_helper.py:97-150): qkv projection (vit_helper.py:107) of every PATCH token + the 8-frame attention over

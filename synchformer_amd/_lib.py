@@ -10,7 +10,7 @@ from pathlib import Path
 
 LIB_DIR = Path(__file__).resolve().parent / 'lib'
 LIB_NAME = 'libsynchformer_hip.so'
-ABI_VERSION = 9     # 9: key-mask forms of the round-4 fused attention launches (sf_qkv_space_attention_masked, sf_qkv_time_attention2_masked), sf_gemm_bf16 config 12; 8: sf_qkv_time_attention2; 7: sf_qkv_space_attention (round 4); 6: sf_layernorm768_bwd_branch; 5: the CLS query inside the grouped attention backward kernels (sf_attention_{group,tiny}_bwd_clsq, sf_attention_cls(_combine)_stats); 4: MXFP8-output attention launches (sf_attention_cls_partial_mx, sf_attention_cls_combine_mx, sf_qkv_time_attention_mx_q); 3: round 3, second half (sf_gemm_mx_res_ln768, sf_qkv_time_attention_mx, sf_gemm_tn_pp, sf_branch_grad, ... added); 2: sf_gemm_res_ln_force_schedule
+ABI_VERSION = 9     # 9: key-mask forms of the round-4 fused attention launches (sf_qkv_space_attention_masked, sf_qkv_time_attention2_masked), sf_qkv_time_attention2_mx, sf_side_rows, sf_gemm_bf16 config 12; 8: sf_qkv_time_attention2; 7: sf_qkv_space_attention (round 4); 6: sf_layernorm768_bwd_branch; 5: the CLS query inside the grouped attention backward kernels (sf_attention_{group,tiny}_bwd_clsq, sf_attention_cls(_combine)_stats); 4: MXFP8-output attention launches (sf_attention_cls_partial_mx, sf_attention_cls_combine_mx, sf_qkv_time_attention_mx_q); 3: round 3, second half (sf_gemm_mx_res_ln768, sf_qkv_time_attention_mx, sf_gemm_tn_pp, sf_branch_grad, ... added); 2: sf_gemm_res_ln_force_schedule
 SF_NOT_APPLICABLE = -2   # include/synchformer_hip.h: "this launcher does not serve the shape, nothing was launched" (never a hipError_t)
 
 _i64, _i32, _f32, _ptr = C.c_int64, C.c_int, C.c_float, C.c_void_p
@@ -34,6 +34,8 @@ SIGNATURES = {
     'sf_gemm_mx_res_ln768': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _f32, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr],
     'sf_qkv_space_attention': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i32, _f32, _ptr],
     'sf_qkv_time_attention2': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i32, _f32, _ptr],
+    'sf_qkv_time_attention2_mx': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i32, _f32, _ptr],
+    'sf_side_rows': [_ptr, _i64, _ptr, _i64, _i32, _ptr, _i64, _ptr, _i64, _i32, _i64, _i32, _ptr],
     'sf_qkv_space_attention_masked': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i32, _f32, _ptr, _ptr],
     'sf_qkv_time_attention2_masked': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i32, _f32, _ptr, _ptr],
     'sf_qkv_space_attention_mx': [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i32, _f32, _ptr],

@@ -39,6 +39,12 @@
 #define QT2_CB_OFF (6 * QT2_ARR)         // 144 KiB: CLS blocks Kc[2] | Vc[2] | Qc[2], 16 rows of 128 B each, row 0 = the sequence's CLS k / v / q of the head, rows 1..15 zero
 #define QT2_BIAS_OFF (QT2_CB_OFF + 6 * 2048)       // 156 KiB: the tile's 384 bias floats
 #define QT2_LAND_OFF (QT2_BIAS_OFF + 1536)         // 768 B: landing area of the CLS row's q | k | v of both heads (48 x 16 B, lane-linear)
+// MX variant (fp8 towers): the k-tile's scale dwords need 2 x 2304 B next to two full operand stages - the six 2-KiB CLS blocks shrink to their only non-zero row each
+// (CBX: 6 x 128 B) plus ONE shared zero row, rows 1..15 of a block being an address select, and the scales land where the blocks were
+#define QT2_CBX_OFF QT2_CB_OFF                      // MX: row 0 of block b (K h0, K h1, V h0, V h1, Q h0, Q h1) at + b * 128
+#define QT2_ZROW_OFF (QT2_CB_OFF + 6 * 128)         // MX: 128 zero bytes
+#define QT2_SC_OFF (QT2_CB_OFF + 1024)              // MX: two parities x (192 token rows | 3 x 128 part rows of W) scale dwords = 2 x 2304 B
+#define QT2_SC_BYTES 2304
 #define QT2_MASK_OFF (QT2_LAND_OFF + 768)           // MASK variant: one float per array row (patch-major, 192) + the CLS key at index 192: 0 = kept, -inf = masked
 #define QT2_LDS (160 * 1024)
 #define QT2_NPART 33                     // CLS-query records per (sequence, head): 4 per block (one per wave pair: 3 key tiles each) + 1 of the left-over item
@@ -59,7 +65,13 @@ struct Qt2Args {
   float scale;
   uint32_t stagger;
   const uint8_t* key_keep = nullptr;     // MASK (template parameter): token flags, one byte per row of X; flag 0 = a masked KEY (for its patch's group and for the CLS query)
+  // MX (template parameter): X / W are e4m3 BYTES (ldx / ldw in bytes) with stage-major E8M0 scale planes (one dword per row per 128 k, ldsx / ldsw bytes between planes);
+  // the attention output leaves as bf16 `out` OR as MXFP8 (e4m3 bytes, row stride ldq, + E8M0 bytes in the scale planes [6][rows][4], splane bytes apart)
+  const uint8_t* sX = nullptr; int64_t ldsx = 0;
+  const uint8_t* sW = nullptr; int64_t ldsw = 0;
+  uint8_t* out_q = nullptr; int64_t ldq = 0; uint8_t* out_s = nullptr; int64_t splane = 0;
 };
+typedef __attribute__((ext_vector_type(8))) int qt2_i32x8;
 
 typedef short qt2_s4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) qt2_s4 qt2_lds_s4;
@@ -90,8 +102,9 @@ __device__ __forceinline__ int qt2_arr_off(int row, int chunk) { return row * 12
 
 template <int V> using qt2_ic = std::integral_constant<int, V>;
 
-template <bool MASK>
+template <bool MASK, bool MX = false>
 __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
+  constexpr int ESZ = MX ? 1 : 2;                                  // bytes per operand element
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -109,14 +122,16 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
   // row tile start (group * 8 + xcd) * stagger * ~1.2 us apart
   for (uint32_t i = 0, n = ((li / hc) * 8u + xcd) * p.stagger; i < n; ++i) __builtin_amdgcn_s_sleep(32);
 
-  uint32_t voff_a = 0, voff_w[3] = {0, 0, 0};                      // lane offsets of the LDS-DMA pieces: re-derived at the top of every tile (not kept live across the attention)
-  const uint32_t a8 = (uint32_t)(8 * p.ldx * 2), w8 = (uint32_t)(8 * p.ldw * 2);
+  uint32_t voff_a = 0, voff_w[3] = {0, 0, 0}, sc_voff = 0, cls_voff = 0;   // lane offsets of the LDS-DMA pieces: re-derived at the top of every tile (not kept live across the attention)
+  const int sc_seg = wave % 3;
+  const int sc_lanes = sc_seg == 0 ? 48 : (sc_seg == 1 ? 64 : 32);
+  const uint32_t a8 = (uint32_t)(8 * p.ldx * ESZ), w8 = (uint32_t)(8 * p.ldw * ESZ);
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane(qt2_lds_addr(smem));
   const uint32_t lds_a_w = __builtin_amdgcn_readfirstlane(lds0 + wave * 3072);
   const uint32_t lds_w_w = __builtin_amdgcn_readfirstlane(lds0 + QT2_A_BYTES + wave * 2048);
 
   // the CLS blocks start as zeros; only their row 0 is ever written again
-  for (int x = tid; x < 6 * 2048 / 16; x += 512) *reinterpret_cast<uint4*>(smem + QT2_CB_OFF + x * 16) = make_uint4(0u, 0u, 0u, 0u);
+  for (int x = tid; x < (MX ? 1024 : 6 * 2048) / 16; x += 512) *reinterpret_cast<uint4*>(smem + QT2_CB_OFF + x * 16) = make_uint4(0u, 0u, 0u, 0u);
   qt2_barrier();                                                   // (a left-over item writes row 0 of the blocks before its first barrier)
 
   const char* xbase; const char* wbase;
@@ -126,8 +141,8 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
     const uint32_t rt = rt0 + r / hc;
     hp = (int)(c * hc + r % hc);
     seq = rt / 9u; tb = (int)(rt - (uint32_t)seq * 9u);
-    xbase = reinterpret_cast<const char*>(p.X) + (seq * p.seq_rows + 1 + (int64_t)tb * QT2_TP) * p.ldx * 2;
-    wbase = reinterpret_cast<const char*>(p.W) + (int64_t)hp * 128 * p.ldw * 2;
+    xbase = reinterpret_cast<const char*>(p.X) + (seq * p.seq_rows + 1 + (int64_t)tb * QT2_TP) * p.ldx * ESZ;
+    wbase = reinterpret_cast<const char*>(p.W) + (int64_t)hp * 128 * p.ldw * ESZ;
   };
   // A piece pc of this wave = tile rows (3 wave + pc) * 8 .. + 7 = patches 8 pc .. + 7 of the block in frame `wave`: source row 196 wave + 8 pc + (lane >> 3) past the block's
   // first row; lane (r = lane >> 3, chunk slot = lane & 7) -> LDS row-linear, source chunk XOR-swizzled by the TILE row (row strides are multiples of 128 bytes - launcher
@@ -140,7 +155,7 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
     const int dl = dtid & 63;
     {
       const int r = wave * 3 * 8 + (dl >> 3);
-      voff_a = (uint32_t)((int64_t)(wave * QT2_NP + (dl >> 3)) * p.ldx * 2 + ((((dl & 7) ^ ((r >> 1) & 7))) << 4));
+      voff_a = (uint32_t)((int64_t)(wave * QT2_NP + (dl >> 3)) * p.ldx * ESZ + ((((dl & 7) ^ ((r >> 1) & 7))) << 4));
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -148,8 +163,27 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
       const int c = (pr >> 5) * 96 + j * 32 + (pr & 31);
       const int hd = c / 192, within = c - hd * 192;
       const int grow = (within >> 6) * QT2_D + hd * 64 + (within & 63);
-      voff_w[j] = (uint32_t)((int64_t)grow * p.ldw * 2 + ((((dl & 7) ^ ((pr >> 1) & 7))) << 4));
+      voff_w[j] = (uint32_t)((int64_t)grow * p.ldw * ESZ + ((((dl & 7) ^ ((pr >> 1) & 7))) << 4));
     }
+    { const int ch = dl & 7, w3 = (dl >> 3) % 3, hd = (dl >> 3) / 3; cls_voff = (uint32_t)((w3 * QT2_D + hd * 64 + ch * 8) * 2); }   // wave 7, lanes 0..47: the CLS row's q | k | v chunk
+    if (MX) {
+      // the k-tile's scale dwords as 16-byte LDS-DMA lanes, three pieces; EVERY wave issues one (wave % 3; copies land the same bytes) so that all waves count alike:
+      // piece 0 = the tile's 192 token rows in tile order (frame fr: 24 rows = 6 lanes, source rows 196 fr .. past the block's first row), pieces 1 | 2 = the 384 W rows
+      // in part order (area index j * 128 + 32 wn' + rr), exactly sf_qkv_space_attention_mx's
+      if (sc_seg == 0) sc_voff = (uint32_t)((dl / 6) * QT2_NP * 4 + (dl % 6) * 16);
+      else {
+        const int L = (sc_seg == 1 ? 0 : 64) + dl, run = L >> 3, j = run >> 2, wnp = run & 3;
+        const int c = wnp * 96 + j * 32 + (L & 7) * 4;
+        const int hd = c / 192, within = c - hd * 192;
+        sc_voff = (uint32_t)(((within >> 6) * QT2_D + hd * 64 + (within & 63)) * 4);
+      }
+    }
+  };
+  const uint32_t sc_lds = __builtin_amdgcn_readfirstlane(lds0 + QT2_SC_OFF + (sc_seg == 0 ? 0 : (sc_seg == 1 ? 768 : 768 + 1024)));
+  auto issue_sc = [&](int kt) {
+    const char* base = sc_seg == 0 ? reinterpret_cast<const char*>(p.sX) + (int64_t)kt * p.ldsx + (seq * p.seq_rows + 1 + (int64_t)tb * QT2_TP) * 4
+                                   : reinterpret_cast<const char*>(p.sW) + (int64_t)kt * p.ldsw + (int64_t)hp * 512;
+    if (lane < sc_lanes) qt2_dma1(sc_voff, base, sc_lds + (kt & 1) * QT2_SC_BYTES);
   };
   auto issue_a = [&](int pc, int S, int kt) {                       // piece pc: 8 rows further down; the chunk swizzle flips bit 2 with every 8 rows
     qt2_dma1(((pc & 1) ? (voff_a ^ 64u) : voff_a) + (uint32_t)pc * a8, xbase + kt * 128, lds_a_w + S * QT2_STAGE + pc * 1024);
@@ -159,9 +193,15 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
     qt2_dma1((voff_w[j] ^ 64u) + w8, wbase + kt * 128, lds_w_w + S * QT2_STAGE + j * QT2_W_PART + 1024);
   };
 
-  constexpr int nk = QT2_D / 64;                                    // 12 k-tiles
+  constexpr int nk = MX ? QT2_D / 128 : QT2_D / 64;                 // 12 k-tiles of 64 bf16 / 6 of 128 fp8: 128 bytes per row either way
   const float sc2 = p.scale * 1.44269504088896f;                   // softmax in base 2
   uint32_t tcount = 0;
+  // a CLS block's 16-byte chunk: block blk (0 K | 2 V | 4 Q) of head h, row 0..15 (only row 0 is ever non-zero).  bf16 kernel: six 2-KiB blocks in the arrays' swizzled
+  // layout; MX kernel: row 0 of every block in CBX, rows 1..15 all the ONE zero row (an address select per lane)
+  auto cb_ptr = [&](int blk, int h, int row, int chunk) -> const char* {
+    if (!MX) return smem + QT2_CB_OFF + (blk + h) * 2048 + qt2_arr_off(row, chunk);
+    return smem + (row == 0 ? QT2_CBX_OFF + (blk + h) * 128 : QT2_ZROW_OFF) + (chunk << 4);
+  };
 
   for (;;) {
     set_tile(t);
@@ -172,16 +212,14 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
       if (wave < 6) {                                               // 6 x 64 bias floats: tile columns 64 wave .. + 63 = (head hd = wave / 3, q | k | v = wave % 3)
         if (p.bias) qt2_dma_dword_addr(p.bias + (wave % 3) * QT2_D + (hp * 2 + wave / 3) * 64 + lane, lds0 + QT2_BIAS_OFF + wave * 256);
       } else if (wave == 7) {                                       // CLS row: chunk x = (hd * 3 + which) * 8 + ch, 48 chunks of 16 B
-        if (lane < 48) {
-          const int ch = lane & 7, w3 = (lane >> 3) % 3, hd = (lane >> 3) / 3;
-          qt2_dma1((uint32_t)((w3 * QT2_D + hd * 64 + ch * 8) * 2), reinterpret_cast<const char*>(p.side + seq * 33 * p.lds_ + hp * 128), lds0 + QT2_LAND_OFF);
-        }
+        if (lane < 48) qt2_dma1(cls_voff, reinterpret_cast<const char*>(p.side + seq * 33 * p.lds_ + hp * 128), lds0 + QT2_LAND_OFF);
       }
+      if (MX) issue_sc(0);
       issue_w(0, 0, 0); issue_a(0, 0, 0);
       issue_w(1, 0, 0); issue_a(1, 0, 0); issue_a(2, 0, 0);
       issue_w(2, 0, 0);
       issue_w(0, 1, 1); issue_a(0, 1, 1);
-      qt2_wait_vmcnt<5>();                                          // bias, CLS row, A | W0 | W1 of k-tile 0 (this wave's pieces) have landed
+      qt2_wait_vmcnt<5>();                                          // bias, CLS row, (scales,) A | W0 | W1 of k-tile 0 (this wave's pieces) have landed
       qt2_barrier();
 
       // accumulators start at the bias: block (j, i) = features 96 wn + 32 j + 8 g + 4 hi + r of the tile, tokens 96 wm + 32 i + l31
@@ -198,42 +236,64 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
           }
       }
       {
-        int fo[4];
+        int fo[4], fs_x = 0, fs_w = 0, shi = 0;                     // (MX: addresses of this lane's scale dwords - its token row of block 0, row l31 of its W part 0 - and 8 * (lane >> 5))
         {
           int ptid = threadIdx.x;
           asm volatile("" : "+v"(ptid));
           const int pl31 = ptid & 31, phi = (ptid & 63) >> 5;
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) fo[kk] = pl31 * 128 + (((kk * 2 + phi) ^ ((pl31 >> 1) & 7)) << 4);
+          if (MX) { fs_x = QT2_SC_OFF + (wm * 96 + pl31) * 4; fs_w = QT2_SC_OFF + 768 + (wn * 32 + pl31) * 4; shi = phi * 8; }
         }
         const int a_base = wm * 96 * 128, w_base = QT2_A_BYTES + wn * 32 * 128;
-        bf16x8 xf[3][4], wf[4];
-        auto read_w = [&](const char* st, int j) {
+        // fragments as 32-byte pairs (kk = 2 k2, 2 k2 + 1): the two 16-byte reads a lane supplies to ONE 64-deep scaled MFMA sit in eight consecutive registers
+        union Qt2Frag { bf16x8 h[2]; qt2_i32x8 v; };
+        Qt2Frag xf[3][2], wf[2];
+        uint32_t sx[3] = {0u, 0u, 0u}, sw = 0u;                      // MX: this lane's scale dwords of the k-tile (token row of block i; W row of the current part), >> shi
+        auto read_w = [&](const char* st, int j, int par) {
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) wf[kk] = *reinterpret_cast<const bf16x8*>(st + w_base + j * QT2_W_PART + fo[kk]);
+          for (int kk = 0; kk < 4; ++kk) wf[kk >> 1].h[kk & 1] = *reinterpret_cast<const bf16x8*>(st + w_base + j * QT2_W_PART + fo[kk]);
+          if (MX) sw = *reinterpret_cast<const uint32_t*>(smem + fs_w + j * 512 + par * QT2_SC_BYTES) >> shi;
         };
         auto mma = [&](auto Jc) {
           constexpr int J = decltype(Jc)::value;
           __builtin_amdgcn_s_setprio(1);
+          if constexpr (MX) {
+            // a 128-byte LDS row = 128 fp8 k: fragments 2 k2 and 2 k2 + 1 are the 2 x 16 bytes a lane supplies to ONE 64-deep scaled MFMA; scale operands: the k-tile's dword of
+            // the row shifted by 8 * (lane >> 5), BYTE 2 k2 selected by the instruction's op_sel (as sf_qkv_space_attention_mx)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+                if (k2 == 0) acc[J][i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[0].v, xf[i][0].v, acc[J][i], 0 /* e4m3 */, 0 /* e4m3 */, 0, (int)sw, 0, (int)sx[i]);
+                else acc[J][i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[1].v, xf[i][1].v, acc[J][i], 0, 0, 2, (int)sw, 2, (int)sx[i]);
+              }
+            }
+          } else
           if (!(QT2_ABL & 2)) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-              for (int i = 0; i < 3; ++i) acc[J][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk], xf[i][kk], acc[J][i], 0, 0, 0);
-          } else asm volatile("" :: "v"(wf[0]), "v"(wf[3]), "v"(xf[0][0]), "v"(xf[2][3]));
+              for (int i = 0; i < 3; ++i) acc[J][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk >> 1].h[kk & 1], xf[i][kk >> 1].h[kk & 1], acc[J][i], 0, 0, 0);
+          } else asm volatile("" :: "v"(wf[0].v), "v"(wf[1].v), "v"(xf[0][0].v), "v"(xf[2][1].v));
           asm volatile("" : "+v"(acc[J][0]), "+v"(acc[J][1]), "+v"(acc[J][2]));   // pins the (pure) MFMAs inside their matrix segment
           __builtin_amdgcn_s_setprio(0);
         };
         // one k-tile held in stage S; ld1 / ld2: k-tiles kt+1 / kt+2 exist (the schedule of sf_qkv_space.hip:
-        //   phase 0: issue W1, A1, A2 of kt+1 (no wait) | phase 1: issue W2 of kt+1, vmcnt(9): W2 of kt landed | phase 2: issue W0, A0 of kt+2, vmcnt(5): A, W0, W1 of kt+1 landed)
+        //   phase 0: issue W1, A1, A2 of kt+1 (no wait) | phase 1: issue (MX: the scale piece and) W2 of kt+1, vmcnt(9 | MX 10): W2 of kt landed | phase 2: issue W0, A0 of kt+2,
+        //   vmcnt(5): A, W0, W1 (and the scales) of kt+1 landed)
         auto ktile = [&](auto Sc, int kt, bool ld1, bool ld2) {
           constexpr int S = decltype(Sc)::value;
           const char* st = smem + S * QT2_STAGE;
 #pragma unroll
           for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) xf[i][kk] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 4096 + fo[kk]);
-          read_w(st, 0);
+            for (int kk = 0; kk < 4; ++kk) xf[i][kk >> 1].h[kk & 1] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 4096 + fo[kk]);
+          read_w(st, 0, S);                                          // (nk is even: the parity of k-tile kt is the stage S)
+          if (MX) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) sx[i] = *reinterpret_cast<const uint32_t*>(smem + fs_x + i * 128 + S * QT2_SC_BYTES) >> shi;
+          }
           __builtin_amdgcn_sched_barrier(0);
           if (ld1) { issue_w(1, S ^ 1, kt + 1); issue_a(1, S ^ 1, kt + 1); issue_a(2, S ^ 1, kt + 1); }
           qt2_barrier();
@@ -241,15 +301,15 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
           mma(qt2_ic<0>{});
           __builtin_amdgcn_sched_barrier(0);
           qt2_barrier();
-          read_w(st, 1);
+          read_w(st, 1, S);
           __builtin_amdgcn_sched_barrier(0);
-          if (ld1) { issue_w(2, S ^ 1, kt + 1); qt2_wait_vmcnt<9>(); } else qt2_wait_vmcnt<0>();
+          if (ld1) { if (MX) issue_sc(kt + 1); issue_w(2, S ^ 1, kt + 1); if (MX) qt2_wait_vmcnt<10>(); else qt2_wait_vmcnt<9>(); } else qt2_wait_vmcnt<0>();
           qt2_barrier();
           __builtin_amdgcn_sched_barrier(0);
           mma(qt2_ic<1>{});
           __builtin_amdgcn_sched_barrier(0);
           qt2_barrier();
-          read_w(st, 2);
+          read_w(st, 2, S);
           __builtin_amdgcn_sched_barrier(0);
           if (ld2) { issue_w(0, S, kt + 2); issue_a(0, S, kt + 2); qt2_wait_vmcnt<5>(); }
           else if (ld1) qt2_wait_vmcnt<2>();
@@ -302,7 +362,7 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
         if (etid < 48) {                                            // the CLS row: q -> Qc, k -> Kc, v -> Vc, row 0 of the head's block (row 0: chunk slot = chunk)
           const int ch = etid & 7, w3 = (etid >> 3) % 3, hd = (etid >> 3) / 3;
           const uint4 sv = *reinterpret_cast<const uint4*>(smem + QT2_LAND_OFF + etid * 16);
-          *reinterpret_cast<uint4*>(smem + QT2_CB_OFF + (w3 == 1 ? 0 : (w3 == 2 ? 2 : 4)) * 2048 + hd * 2048 + ch * 16) = sv;
+          *reinterpret_cast<uint4*>(const_cast<char*>(cb_ptr(w3 == 1 ? 0 : (w3 == 2 ? 2 : 4), hd, 0, ch))) = sv;
         }
         if (MASK && etid < QT2_ROWS + 1) {
           const int fr = etid / QT2_TP, pl = etid - fr * QT2_TP;
@@ -331,7 +391,7 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
       }
       if (stid < 48) {
         const int ch = stid & 7, w3 = (stid >> 3) % 3, hd = (stid >> 3) / 3;
-        *reinterpret_cast<uint4*>(smem + QT2_CB_OFF + (w3 == 1 ? 0 : (w3 == 2 ? 2 : 4)) * 2048 + hd * 2048 + ch * 16) = cv;
+        *reinterpret_cast<uint4*>(const_cast<char*>(cb_ptr(w3 == 1 ? 0 : (w3 == 2 ? 2 : 4), hd, 0, ch))) = cv;
       }
       if (MASK && stid >= 64 && stid < 64 + 33) {                   // rows 8 i + f = token 192 + i of frame f, and the CLS key
         const int r = stid - 64;
@@ -352,15 +412,15 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
       // the units: NU independent dependency chains (LDS read -> MFMA -> cross-lane max -> exp2 -> cross-lane sum -> MFMA -> store) overlap in one wave
       auto patch_units = [&](auto NUc, const int u0, const int ustep) {
         constexpr int NU = decltype(NUc)::value;
-        const char* k_lds[NU]; const char* kc[NU];
-        int qt[NU];
+        const char* k_lds[NU];
+        int qt[NU], hh_[NU];
         f32x4 s0[NU], s1[NU];
 #pragma unroll
         for (int e = 0; e < NU; ++e) {
           const int u = u0 + e * ustep, h = u >= 12 ? 1 : 0;
           qt[e] = u - 12 * h;
           k_lds[e] = smem + h * 3 * QT2_ARR;
-          kc[e] = smem + QT2_CB_OFF + h * 2048;
+          hh_[e] = h;
           s0[e] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[e] = f32x4{0.f, 0.f, 0.f, 0.f};
           if (MASK) {                                               // rows fg * 4 + r of the unit's tile; row 0 of the CLS block = the CLS key
             const float4 mk = *reinterpret_cast<const float4*>(smem + QT2_MASK_OFF + (qt[e] * 16 + fg * 4) * 4);
@@ -374,7 +434,7 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
           for (int e = 0; e < NU; ++e) {
             const bf16x8 qf = *reinterpret_cast<const bf16x8*>(k_lds[e] + 2 * QT2_ARR + qt2_arr_off(qt[e] * 16 + fr_, ks * 4 + fg));
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds[e] + qt2_arr_off(qt[e] * 16 + fr_, ks * 4 + fg));
-            const bf16x8 cf = *reinterpret_cast<const bf16x8*>(kc[e] + qt2_arr_off(fr_, ks * 4 + fg));
+            const bf16x8 cf = *reinterpret_cast<const bf16x8*>(cb_ptr(0, hh_[e], fr_, ks * 4 + fg));
             s0[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, s0[e], 0, 0, 0);       // S^T: rows = keys fg * 4 + r of the tile, column = query fr_
             s1[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf, qf, s1[e], 0, 0, 0);       // row 0 (fg = 0, r = 0) = the CLS key
           }
@@ -415,7 +475,7 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
           for (int dt = 0; dt < 4; ++dt) {
             union { bf16x8 v; qt2_s4 hh[2]; } vb;
             vb.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((qt2_lds_s4*)(k_lds[e] + QT2_ARR + qt2_arr_off(qt[e] * 16 + krow, dt * 2 + c1) + hb));
-            vb.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((qt2_lds_s4*)(kc[e] + 2 * 2048 + qt2_arr_off(krow, dt * 2 + c1) + hb));
+            vb.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((qt2_lds_s4*)(cb_ptr(2, hh_[e], krow, dt * 2 + c1) + hb));
             o[e][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb.v, pa.v, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           }
         }
@@ -458,6 +518,25 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
             for (int j = 0; j < 2; ++j) {
               const int rr = (alane >> 3) + 8 * j, ch = alane & 7;    // tile row rr = (patch 2 qt + j, frame alane >> 3)
               const uint4 w = *reinterpret_cast<const uint4*>(qrows + qt2_arr_off(qt[e] * 16 + rr, ch));
+              if (MX && p.out_q) {
+                // MXFP8 output (the A operand of the MX projection that follows), byte for byte sf_quantize_mxfp8 of the bf16 row: the head's 64 dims are two scale blocks,
+                // block b = this lane's quad (chunks 4 b .. 4 b + 3); quantised from the bf16-rounded values the bf16 launch would have stored
+                const int64_t row = orow0 + (int64_t)(alane >> 3) * QT2_NP + 2 * qt[e] + j;
+                float fv[8];
+                fv[0] = __uint_as_float(w.x << 16); fv[1] = __uint_as_float(w.x & 0xffff0000u); fv[2] = __uint_as_float(w.y << 16); fv[3] = __uint_as_float(w.y & 0xffff0000u);
+                fv[4] = __uint_as_float(w.z << 16); fv[5] = __uint_as_float(w.z & 0xffff0000u); fv[6] = __uint_as_float(w.w << 16); fv[7] = __uint_as_float(w.w & 0xffff0000u);
+                float amax = fmaxf(fmaxf(fmaxf(fabsf(fv[0]), fabsf(fv[1])), fmaxf(fabsf(fv[2]), fabsf(fv[3]))), fmaxf(fmaxf(fabsf(fv[4]), fabsf(fv[5])), fmaxf(fabsf(fv[6]), fabsf(fv[7]))));
+                amax = fmaxf(amax, __shfl_xor(amax, 1, 64)); amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+                const int be = sf_mx_exp(amax);
+                const float inv = sf_mx_inv(be);
+                uint2 d; d.x = sf_fp8x4(fv, inv); d.y = sf_fp8x4(fv + 4, inv);
+                const int be_hi = __shfl_xor(be, 4, 64);              // the head's other block (lanes ch and ch ^ 4 of the row)
+                if (!(QT2_ABL & 32) || l[e] == 12345.678f) {
+                  *reinterpret_cast<uint2*>(p.out_q + row * p.ldq + head * 64 + ch * 8) = d;
+                  if (ch == 0) *reinterpret_cast<uint16_t*>(p.out_s + (int64_t)(head >> 1) * p.splane + row * 4 + (head & 1) * 2) = (uint16_t)(be | (be_hi << 8));
+                }
+                continue;
+              }
               bf16_t* dst = p.out + (orow0 + (int64_t)(alane >> 3) * QT2_NP + 2 * qt[e] + j) * p.ldo + head * 64 + ch * 8;
 #ifndef QT2_OUT_NT
 #define QT2_OUT_NT 1   // the attention output with the nt hint: written once, read once by the next launch
@@ -479,12 +558,9 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
         const int head = hp * 2 + h;
         const char* k_lds = smem + h * 3 * QT2_ARR;
         const char* v_lds = k_lds + QT2_ARR;
-        const char* kc = smem + QT2_CB_OFF + h * 2048;
-        const char* vc = kc + 2 * 2048;
-        const char* qc = kc + 4 * 2048;
         bf16x8 qf[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qc + qt2_arr_off(fr_, ks * 4 + fg));      // column 0 = the CLS query (columns 1..15: zero rows)
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(cb_ptr(4, h, fr_, ks * 4 + fg));      // column 0 = the CLS query (columns 1..15: zero rows)
         f32x4 s[NKT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -496,7 +572,7 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
             const bf16x8 kf = kt < NK ? *reinterpret_cast<const bf16x8*>(k_lds + qt2_arr_off((kt0 + kt) * 16 + fr_, ks * 4 + fg))
-                                      : *reinterpret_cast<const bf16x8*>(kc + qt2_arr_off(fr_, ks * 4 + fg));
+                                      : *reinterpret_cast<const bf16x8*>(cb_ptr(0, h, fr_, ks * 4 + fg));
             s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
           }
         }
@@ -537,10 +613,10 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
             union { bf16x8 v; qt2_s4 hh[2]; } vb;
             const int ta = 2 * kk, tb_ = 2 * kk + 1;
             vb.hh[0] = ta < NK ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((qt2_lds_s4*)(v_lds + qt2_arr_off((kt0 + ta) * 16 + krow, dt * 2 + c1) + hb))
-                               : __builtin_amdgcn_ds_read_tr16_b64_v4i16((qt2_lds_s4*)(vc + qt2_arr_off(krow, dt * 2 + c1) + hb));
+                               : __builtin_amdgcn_ds_read_tr16_b64_v4i16((qt2_lds_s4*)(cb_ptr(2, h, krow, dt * 2 + c1) + hb));
             vb.hh[1] = qt2_s4{0, 0, 0, 0};
             if (tb_ < NKT) vb.hh[1] = tb_ < NK ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((qt2_lds_s4*)(v_lds + qt2_arr_off((kt0 + tb_) * 16 + krow, dt * 2 + c1) + hb))
-                                               : __builtin_amdgcn_ds_read_tr16_b64_v4i16((qt2_lds_s4*)(vc + qt2_arr_off(krow, dt * 2 + c1) + hb));
+                                               : __builtin_amdgcn_ds_read_tr16_b64_v4i16((qt2_lds_s4*)(cb_ptr(2, h, krow, dt * 2 + c1) + hb));
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb.v, pa.v, o[dt], 0, 0, 0);
           }
         }
@@ -572,6 +648,7 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
 
 __global__ __launch_bounds__(512, 2) void qkv_time2_attn_kernel(Qt2Args p) { qkv_time2_attn_body<false>(p); }
 __global__ __launch_bounds__(512, 2) void qkv_time2_attn_masked_kernel(Qt2Args p) { qkv_time2_attn_body<true>(p); }
+__global__ __launch_bounds__(512, 2) void qkv_time2_attn_mx_kernel(Qt2Args p) { qkv_time2_attn_body<false, true>(p); }
 
 // X (n_seq * 1569, 768) bf16 = norm3(x), rows [CLS; frame-major patches] per sequence; W (2304, 768) bf16 = timeattn.qkv.weight, bias 2304 fp32 or NULL; side
 // (n_seq * 33, 2304) bf16 = the same projection of [the CLS row; per frame f its tokens 192 .. 195] (row seq * 33, rows seq * 33 + 1 + 4 f + i) - the buffer layout of
@@ -623,4 +700,45 @@ extern "C" int sf_qkv_time_attention2_masked(const uint16_t* X, int64_t ldx, con
                                              uint16_t* out, int64_t ldo, float* cls_partial, int64_t n_seq, int n_tok, float scale, const uint8_t* key_keep, void* stream) {
   SF_CHECK_ARG(key_keep, "sf_qkv_time_attention2_masked: null key_keep (call sf_qkv_time_attention2 for an unmasked forward)");
   return qt2_launch(X, ldx, W, ldw, bias, side, lds_, out, ldo, cls_partial, n_seq, n_tok, scale, key_keep, stream);
+}
+
+// The same launch on MXFP8 operands (fp8 towers of the synchronizability fine-tune, round 5: the temporal half gets the schedule the spatial half got in round 4): X (rows,
+// 768) e4m3 bytes with its stage-major scale planes sX (6 planes, ldsx bytes apart, one dword per row) - what sf_gemm_mx_res_ln768 / sf_layernorm768_mxfp8 write -, W (2304,
+// 768) e4m3 + sW (6 planes of 2304 dwords); side (n_seq * 33, 2304) bf16 as in sf_qkv_time_attention2 (from sf_gemm_mxfp8 on gathered copies of the rows and of their scale
+// dwords: sf_side_rows).  The attention runs on the bf16-rounded projection, exactly as sf_qkv_time_attention_mx does.  Output: EITHER out (bf16, patch rows) OR out_q / out_s
+// (e4m3 bytes (rows, 768) + the scale planes [6][rows][4], splane bytes apart: byte for byte sf_quantize_mxfp8 of the bf16 output - the A operand of the MX projection that
+// follows; buffers of their own, not X / sX).  cls_partial [n_seq][12][33][66] (merge with sf_attention_cls_combine(_mx), n_part = 33).  Replaces sf_gemm_mxfp8 (CLS rows) +
+// sf_qkv_time_attention_mx(_q).
+extern "C" int sf_qkv_time_attention2_mx(const uint8_t* X, int64_t ldx, const uint8_t* sX, int64_t ldsx, const uint8_t* W, int64_t ldw, const uint8_t* sW, int64_t ldsw,
+                                         const float* bias, const uint16_t* side, int64_t lds_, uint16_t* out, int64_t ldo, uint8_t* out_q, int64_t ldq, uint8_t* out_s,
+                                         int64_t splane, float* cls_partial, int64_t n_seq, int n_tok, float scale, void* stream) {
+  SF_CHECK_ARG(X && sX && W && sW && side && cls_partial && ((out != nullptr) != (out_q != nullptr)), "sf_qkv_time_attention2_mx: null pointer (exactly one of out / out_q)");
+  SF_CHECK_ARG(n_tok == QT2_NP, "sf_qkv_time_attention2_mx: built for 196 patches per frame (8 frames per sequence), got %d", n_tok);
+  SF_CHECK_ARG((ldx % 128) == 0 && (ldw % 128) == 0 && ldx >= QT2_D && ldw >= QT2_D && (lds_ % 8) == 0 && lds_ >= 3 * QT2_D, "sf_qkv_time_attention2_mx: bad row strides (ldx / ldw multiples of 128 bytes)");
+  SF_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)sX % 16) == 0 && ((uintptr_t)sW % 16) == 0 && ((uintptr_t)side % 16) == 0 &&
+                   (!bias || ((uintptr_t)bias % 16) == 0) && ((uintptr_t)cls_partial % 8) == 0, "sf_qkv_time_attention2_mx: operands must be 16-byte aligned");
+  if (out) SF_CHECK_ARG(((uintptr_t)out % 16) == 0 && (ldo % 8) == 0 && ldo >= QT2_D, "sf_qkv_time_attention2_mx: out must be a 16-byte aligned bf16 buffer");
+  if (out_q) SF_CHECK_ARG(out_s && ((uintptr_t)out_q % 8) == 0 && ((uintptr_t)out_s % 2) == 0 && (ldq % 8) == 0 && ldq >= QT2_D && out_q != X && out_s != sX,
+                          "sf_qkv_time_attention2_mx: out_q (8-byte aligned, ldq %% 8 == 0) / out_s must be buffers of their own");
+  if (n_seq <= 0) return 0;
+  const int64_t seq_rows = 1 + 8 * (int64_t)QT2_NP;
+  if (out_q) SF_CHECK_ARG(splane >= n_seq * seq_rows * 4, "sf_qkv_time_attention2_mx: a scale plane holds 4 bytes per row");
+  SF_CHECK_ARG((ldsx % 16) == 0 && (ldsw % 16) == 0 && ldsx >= n_seq * seq_rows * 4 && ldsw >= 3 * QT2_D * 4, "sf_qkv_time_attention2_mx: scale planes must hold one dword per row of X / W");
+  SF_CHECK_ARG(seq_rows * ldx < ((int64_t)1 << 32) && (int64_t)3 * QT2_D * ldw < ((int64_t)1 << 32) && (int64_t)33 * lds_ * 2 < ((int64_t)1 << 32),
+               "sf_qkv_time_attention2_mx: a sequence of X, W and a sequence's side rows must stay below 4 GiB (32-bit lane offsets)");
+  SF_CHECK_ARG(n_seq * 9 * 6 < ((int64_t)1 << 31), "sf_qkv_time_attention2_mx: too many tiles");
+  if (int rc = sf_prepare_kernel((const void*)qkv_time2_attn_mx_kernel, QT2_LDS, "sf_qkv_time_attention2_mx")) return rc;
+  const int n_cu = sf_cu_count("sf_qkv_time_attention2_mx");
+  if (n_cu <= 0) return -1;
+  Qt2Args a;
+  a.X = reinterpret_cast<const bf16_t*>(X); a.ldx = ldx; a.W = reinterpret_cast<const bf16_t*>(W); a.ldw = ldw; a.bias = bias; a.side = side; a.lds_ = lds_;
+  a.out = out; a.ldo = ldo; a.cls_part = cls_partial; a.seq_rows = seq_rows; a.n_rt = (uint32_t)(n_seq * 9); a.scale = scale; a.pair_chunk = 6; a.stagger = 0;
+  a.sX = sX; a.ldsx = ldsx; a.sW = sW; a.ldsw = ldsw; a.out_q = out_q; a.ldq = ldq; a.out_s = out_s; a.splane = splane;
+  int64_t blocks = (n_cu / 8) * 8;
+  if (blocks < 8) blocks = 8;
+  const int64_t need = ((n_seq * 9 * 6 + 7) / 8) * 8;
+  if (blocks > need) blocks = need;
+  hipLaunchKernelGGL(qkv_time2_attn_mx_kernel, dim3((unsigned)blocks), dim3(512), QT2_LDS, (hipStream_t)stream, a);
+  SF_LAUNCH_CHECK();
+  return 0;
 }

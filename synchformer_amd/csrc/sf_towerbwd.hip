@@ -30,6 +30,38 @@ extern "C" int sf_copy_rows_bf16(const uint16_t* src, int64_t ld_src, const int6
   return 0;
 }
 
+// ---- the SIDE rows of the fused attention launches in one gather ----------------------------------------------------------------------------------------------
+// sf_qkv_space_attention / sf_qkv_time_attention2 do not project 33 rows of every sequence themselves - the CLS row and tokens 192..195 of each of the 8 frames (196 = 6 x 32 + 4
+// = 8 x 24 + 4); they go through one small GEMM on a gathered copy.  One launch, a workgroup per destination row: row seq * 33 <- X row seq * seq_rows, row seq * 33 + 1 + 4 f
+// + i <- X row seq * seq_rows + 1 + n_tok f + (n_tok - 4) + i; row_bytes per row (1536: bf16; 768: the e4m3 bytes of an MXFP8 operand), and with sX the rows' E8M0 scale
+// dwords of every stage-major plane as well (plane k: sX + k * ldsx -> sO + k * ldso, one dword per row).  Was two sf_copy_rows_bf16 launches (bf16) / three torch index ops
+// per half block (MXFP8).
+__global__ __launch_bounds__(128) void side_rows_kernel(const char* __restrict__ X, int64_t ldx, char* __restrict__ out, int64_t ldo, int chunks, const char* __restrict__ sX,
+                                                        int64_t ldsx, char* __restrict__ sO, int64_t ldso, int n_planes, int64_t seq_rows, int n_tok) {
+  const int64_t d = blockIdx.x, seq = d / 33;
+  const int r = (int)(d - seq * 33);
+  const int64_t srow = seq * seq_rows + (r == 0 ? 0 : 1 + (int64_t)((r - 1) >> 2) * n_tok + (n_tok - 4) + ((r - 1) & 3));
+  const char* s = X + srow * ldx;
+  char* o = out + d * ldo;
+  for (int c = threadIdx.x; c < chunks; c += 128) *(uint4*)(o + c * 16) = *(const uint4*)(s + c * 16);
+  if (sX && (int)threadIdx.x < n_planes) *(uint32_t*)(sO + (int64_t)threadIdx.x * ldso + d * 4) = *(const uint32_t*)(sX + (int64_t)threadIdx.x * ldsx + srow * 4);
+}
+
+extern "C" int sf_side_rows(const void* X, int64_t ldx_bytes, void* out, int64_t ldo_bytes, int row_bytes, const uint8_t* sX, int64_t ldsx, uint8_t* sOut, int64_t ldso,
+                            int n_planes, int64_t n_seq, int n_tok, void* stream) {
+  SF_CHECK_ARG(X && out && row_bytes >= 16 && (row_bytes % 16) == 0 && (ldx_bytes % 16) == 0 && (ldo_bytes % 16) == 0 && ldx_bytes >= row_bytes && ldo_bytes >= row_bytes &&
+                   ((uintptr_t)X % 16) == 0 && ((uintptr_t)out % 16) == 0, "sf_side_rows: rows of whole 16-byte chunks, 16-byte aligned");
+  SF_CHECK_ARG(n_tok >= 4 && n_planes >= 0 && n_planes <= 128, "sf_side_rows: bad n_tok / n_planes");
+  SF_CHECK_ARG((sX == nullptr) == (sOut == nullptr) && (!sX || (n_planes >= 1 && (ldsx % 4) == 0 && (ldso % 4) == 0 && ((uintptr_t)sX % 4) == 0 && ((uintptr_t)sOut % 4) == 0)),
+               "sf_side_rows: scale planes come in pairs (source, destination), one dword per row");
+  if (n_seq <= 0) return 0;
+  SF_CHECK_ARG(n_seq * 33 < ((int64_t)1 << 31), "sf_side_rows: too many rows");
+  hipLaunchKernelGGL(side_rows_kernel, dim3((unsigned)(n_seq * 33)), dim3(128), 0, (hipStream_t)stream, (const char*)X, ldx_bytes, (char*)out, ldo_bytes, row_bytes / 16,
+                     (const char*)sX, ldsx, (char*)sOut, ldso, n_planes, 1 + 8 * (int64_t)n_tok, n_tok);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
 // out[s * out_seq_stride + c] (=|+=) sum_{g < G} in[s * in_seq_stride + g * in_group_stride + c]   (strides in elements)
 // One workgroup per (sequence, 512 columns): 64 column chunks of 16 bytes x 16 group slices, then a tree over the slices in LDS.  (The first version ran one thread per
 // column over all G groups with 2-byte loads: 70 us for the 196 time groups' 17 MB - the launch is latency, not bytes.)  General strides / ragged columns take the

@@ -411,30 +411,32 @@ class SynchformerEngine:
             aq = self._buf('AQ', rows * D, torch.uint8).view(rows, D)         # the time attention's output as the projection's MXFP8 operand
             as_ = self._buf('AS', 6 * rows_p * 4, torch.uint8).view(6, rows_p, 4)
         fuse_attn = self.fuse_mx_attn and tok_keep is None and os.environ.get('SF_CLS_FUSION', 'space') != 'none'
-        # round 4: spatial qkv + space attention in one launch on the MX operands as well (sf_qkv_space_attention_mx, MXFP8 output); the side rows - CLS + the
-        # last 4 tokens of every frame - go through sf_gemm_mxfp8 on gathered copies of the rows and of their scale dwords
+        # round 4: spatial qkv + space attention in one launch on the MX operands as well (sf_qkv_space_attention_mx, MXFP8 output); round 5: the temporal half on the same
+        # schedule (sf_qkv_time_attention2_mx).  The side rows - CLS + the last 4 tokens of every frame - go through sf_gemm_mxfp8 on copies of the rows AND of their scale
+        # dwords gathered by one launch (sf_side_rows)
         fuse_space = self.fuse_space and fuse_attn and rows >= 128 * 64
-        if fuse_space:
+        fuse_time2 = fuse_time and fuse_attn and self.fuse_time2 and rows >= 128 * 64
+        if fuse_space or fuse_time2:
             if not fuse_time:
                 aq = self._buf('AQ', rows * D, torch.uint8).view(rows, D)
                 as_ = self._buf('AS', 6 * rows_p * 4, torch.uint8).view(6, rows_p, 4)
             n33 = n * 33
-            n33_p = ((n33 + 255) // 256) * 256
+            n33p = ((n33 + 255) // 256) * 256
             sq = self._buf('SQ', n33 * D, torch.uint8).view(n33, D)
-            ss = self._buf('SS', 6 * n33_p * 4, torch.uint8).view(6, n33_p, 4)
+            ss = self._buf('SS', 6 * n33p * 4, torch.uint8).view(6, n33p, 4)
             side = self._buf('side', n33 * 3 * D, torch.bfloat16).view(n33, 3 * D)
-            idx = self._ws.get('side_idx')
-            if idx is None or idx.numel() != n33:
-                seq = torch.arange(n, device=self.dev).view(n, 1) * VIS_L
-                left = 1 + torch.arange(8, device=self.dev).view(8, 1) * 196 + 192 + torch.arange(4, device=self.dev).view(1, 4)
-                idx = self._ws['side_idx'] = torch.cat([seq, seq + left.reshape(1, 32)], 1).reshape(-1)
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         nb = len(self.v_blocks)
         for bi, b in enumerate(self.v_blocks):
             mx = b['mx']
             if bi == 0 or not fuse:
                 ops.layernorm_mxfp8(X, b['norm3'].g, b['norm3'].b, xq, xs, EPS_VIS)
-            if fuse_time:
+            if fuse_time2:
+                ops.space_side_rows_mx(xq, xs, sq, ss, n)
+                ops.gemm_mxfp8(sq, ss, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, side)
+                ops.qkv_time_attention2_mx(xq, xs, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, side, aq, part, n_seq=n, scale=0.125, out_scales=as_)
+                ops.attention_cls_combine_mx(part, aq, as_, n_part=33, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
+            elif fuse_time:
                 cq.copy_(xq.view(n, VIS_L, D)[:, 0])
                 cs[:, :n].copy_(xs[:, :rows].view(6, n, VIS_L, 4)[:, :, 0])
                 ops.gemm_mxfp8(cq, cs, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, qkv_cls)
@@ -459,8 +461,7 @@ class SynchformerEngine:
                 ops.gemm_mxfp8(tq, ts, mx['t_proj'].q, mx['t_proj'].s, mx['t_proj'].b, X, residual=X)
                 ops.layernorm_mxfp8(X, b['norm1'].g, b['norm1'].b, xq, xs, EPS_VIS)
             if fuse_space:
-                torch.index_select(xq, 0, idx, out=sq)
-                ss[:, :n33].copy_(xs.index_select(1, idx))
+                ops.space_side_rows_mx(xq, xs, sq, ss, n)
                 ops.gemm_mxfp8(sq, ss, mx['s_qkv'].q, mx['s_qkv'].s, mx['s_qkv'].b, side)
                 ops.qkv_space_attention_mx(xq, xs, mx['s_qkv'].q, mx['s_qkv'].s, mx['s_qkv'].b, side, aq, part, n_seq=n, scale=0.125, out_scales=as_)
                 ops.attention_cls_combine_mx(part, aq, as_, n_part=8, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)

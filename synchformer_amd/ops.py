@@ -313,12 +313,26 @@ def copy_rows_bf16(src: torch.Tensor, dst: torch.Tensor, rows: int, cols: int, s
 
 
 def space_side_rows(x: torch.Tensor, side_in: torch.Tensor, n_seq: int, seq_rows: int = 1569, n_tok: int = 196):
-    """The rows qkv_space_attention does NOT project itself, gathered for one small GEMM: per sequence [the CLS row; for frame f its tokens 192 .. 195] ->
-    side_in (n_seq * 33, 768) bf16 (row seq * 33, rows seq * 33 + 1 + 4 f + i)."""
-    per = 1 + 8 * (n_tok - 192)
-    copy_rows_bf16(x, side_in, n_seq, 768, rowmap(1, 1, seq_rows, 0, 0, 0), rowmap(1, 1, per, 0, 0, 0))
-    copy_rows_bf16(x, side_in, n_seq * 32, 768, rowmap(32, 4, seq_rows, n_tok, 1, 1 + 192), rowmap(32, 32, per, 0, 1, 1))
+    """The rows qkv_space_attention / qkv_time_attention2 do NOT project themselves, gathered for one small GEMM: per sequence [the CLS row; for frame f its tokens 192 .. 195]
+    -> side_in (n_seq * 33, 768) bf16 (row seq * 33, rows seq * 33 + 1 + 4 f + i).  One launch (sf_side_rows)."""
+    assert x.dtype == side_in.dtype == torch.bfloat16 and x.shape[1] == side_in.shape[1] == 768 and seq_rows == 1 + 8 * n_tok
+    assert x.shape[0] >= n_seq * seq_rows and side_in.shape[0] >= n_seq * 33
+    rc = _lib.load().sf_side_rows(_dev(x, 'x'), _ld(x) * 2, _dev(side_in, 'side_in'), _ld(side_in) * 2, 1536, None, 0, None, 0, 0, n_seq, n_tok, _stream())
+    _lib.check(rc, 'sf_side_rows')
     return side_in
+
+
+def space_side_rows_mx(x_q: torch.Tensor, x_s: torch.Tensor, side_q: torch.Tensor, side_s: torch.Tensor, n_seq: int, n_tok: int = 196):
+    """space_side_rows of an MXFP8 operand: the e4m3 rows x_q (rows, 768) uint8 AND their E8M0 scale dwords x_s (6, >= rows, 4) -> side_q (n_seq * 33, 768), side_s
+    (6, >= n_seq * 33, 4), in the same launch."""
+    assert x_q.dtype == x_s.dtype == side_q.dtype == side_s.dtype == torch.uint8 and x_q.shape[1] == side_q.shape[1] == 768
+    assert x_s.dim() == 3 and side_s.dim() == 3 and x_s.shape[0] == side_s.shape[0] == 6 and x_s.is_contiguous() and side_s.is_contiguous()
+    rows = n_seq * (1 + 8 * n_tok)
+    assert x_q.shape[0] >= rows and x_s.shape[1] >= rows and side_q.shape[0] >= n_seq * 33 and side_s.shape[1] >= n_seq * 33
+    rc = _lib.load().sf_side_rows(_dev(x_q, 'x_q'), _ld(x_q), _dev(side_q, 'side_q'), _ld(side_q), 768, _dev(x_s, 'x_s'), x_s.stride(0), _dev(side_s, 'side_s'),
+                                  side_s.stride(0), 6, n_seq, n_tok, _stream())
+    _lib.check(rc, 'sf_side_rows')
+    return side_q, side_s
 
 
 def qkv_space_attention(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, *, n_seq: int,
@@ -387,6 +401,29 @@ def qkv_space_attention_mx(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tens
                                                _dev(out_scales, 'out_scales') if out_scales is not None else None, out_scales.stride(0) if out_scales is not None else 0,
                                                _dev(partials, 'partials'), n_seq, n_tok, float(scale), _stream())
     _lib.check(rc, 'sf_qkv_space_attention_mx')
+    return out
+
+
+def qkv_time_attention2_mx(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out: torch.Tensor,
+                           partials: torch.Tensor, *, n_seq: int, scale: float, out_scales: Optional[torch.Tensor] = None, n_tok: int = 196):
+    """qkv_time_attention2 on MXFP8 operands (arguments as qkv_space_attention_mx; partials: 33 records per sequence and head for attention_cls_combine(_mx)(n_part=33)).
+    With a uint8 `out` and `out_scales` (6, >= rows, 4) the patch rows are written as MXFP8 (= quantize_mxfp8 of the bf16 output), else `out` is bf16."""
+    assert x_q.dtype == w_q.dtype == x_s.dtype == w_s.dtype == torch.uint8 and side.dtype == torch.bfloat16 and partials.dtype == torch.float32
+    assert (out.dtype == torch.uint8) == (out_scales is not None) and out.dtype in (torch.uint8, torch.bfloat16)
+    rows = n_seq * (1 + 8 * n_tok)
+    assert x_q.shape[1] == 768 and tuple(w_q.shape) == (2304, 768) and side.shape[0] >= n_seq * 33 and side.shape[1] == 2304 and out.shape[1] == 768
+    assert x_q.shape[0] >= rows and out.shape[0] >= rows and x_s.dim() == 3 and w_s.dim() == 3 and x_s.shape[0] == 6 and w_s.shape[0] == 6
+    assert x_s.shape[1] >= rows and w_s.shape[1] >= 2304 and x_s.is_contiguous() and w_s.is_contiguous() and partials.numel() >= n_seq * 12 * 33 * 66
+    if out_scales is not None:
+        assert out_scales.dtype == torch.uint8 and out_scales.dim() == 3 and out_scales.shape[0] == 6 and out_scales.shape[1] >= rows and out_scales.is_contiguous()
+        assert out.data_ptr() != x_q.data_ptr() and out_scales.data_ptr() != x_s.data_ptr()
+    rc = _lib.load().sf_qkv_time_attention2_mx(_dev(x_q, 'x_q'), _ld(x_q), _dev(x_s, 'x_s'), x_s.stride(0), _dev(w_q, 'w_q'), _ld(w_q), _dev(w_s, 'w_s'), w_s.stride(0),
+                                               _dev(bias, 'bias') if bias is not None else None, _dev(side, 'side'), _ld(side),
+                                               _dev(out, 'out') if out_scales is None else None, _ld(out) if out_scales is None else 0,
+                                               _dev(out, 'out') if out_scales is not None else None, _ld(out) if out_scales is not None else 0,
+                                               _dev(out_scales, 'out_scales') if out_scales is not None else None, out_scales.stride(0) if out_scales is not None else 0,
+                                               _dev(partials, 'partials'), n_seq, n_tok, float(scale), _stream())
+    _lib.check(rc, 'sf_qkv_time_attention2_mx')
     return out
 
 
@@ -523,7 +560,7 @@ def register_torch_ops():
         return
     from torch.library import custom_op
     # the direct launchers, bound now: ops.via_dispatcher() re-points the module-level names at these custom ops
-    d_ = {n: globals()[n] for n in ('gemm', 'layernorm', 'attention', 'attention_cls', 'im2col_video', 'gemm_res_ln', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'quantize_mxfp8', 'layernorm_mxfp8', 'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention_mx', 'attention_cls_partial_mx', 'attention_cls_combine_mx', 'qkv_time_attention2', 'qkv_space_attention', 'qkv_space_attention_mx', 'space_side_rows')}
+    d_ = {n: globals()[n] for n in ('gemm', 'layernorm', 'attention', 'attention_cls', 'im2col_video', 'gemm_res_ln', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'quantize_mxfp8', 'layernorm_mxfp8', 'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention_mx', 'attention_cls_partial_mx', 'attention_cls_combine_mx', 'qkv_time_attention2', 'qkv_space_attention', 'qkv_space_attention_mx', 'space_side_rows', 'space_side_rows_mx', 'qkv_time_attention2_mx')}
 
     @custom_op('synchformer::gemm_bf16', mutates_args=('out',), device_types='cuda')
     def _gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, residual: Optional[torch.Tensor],
@@ -636,6 +673,20 @@ def register_torch_ops():
     def _side_rows(x: torch.Tensor, out: torch.Tensor, n_seq: int) -> None:
         d_['space_side_rows'](x, out, n_seq)
 
+    @custom_op('synchformer::space_side_rows_mx', mutates_args=('side_q', 'side_s'), device_types='cuda')
+    def _side_rows_mx(x_q: torch.Tensor, x_s: torch.Tensor, side_q: torch.Tensor, side_s: torch.Tensor, n_seq: int) -> None:
+        d_['space_side_rows_mx'](x_q, x_s, side_q, side_s, n_seq)
+
+    @custom_op('synchformer::qkv_time_attention2_mx', mutates_args=('out', 'partials'), device_types='cuda')
+    def _qkv_time2_mx(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out: torch.Tensor,
+                      partials: torch.Tensor, n_seq: int, scale: float) -> None:
+        d_['qkv_time_attention2_mx'](x_q, x_s, w_q, w_s, bias, side, out, partials, n_seq=n_seq, scale=scale)
+
+    @custom_op('synchformer::qkv_time_attention2_mx_q', mutates_args=('out_q', 'out_s', 'partials'), device_types='cuda')
+    def _qkv_time2_mx_q(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out_q: torch.Tensor,
+                        out_s: torch.Tensor, partials: torch.Tensor, n_seq: int, scale: float) -> None:
+        d_['qkv_time_attention2_mx'](x_q, x_s, w_q, w_s, bias, side, out_q, partials, n_seq=n_seq, scale=scale, out_scales=out_s)
+
     # Meta / FakeTensor implementations: every op is an out-variant (mutates its outputs, returns nothing), so the abstract implementation has no output
     # to describe - it only checks what the launcher would refuse (dtype / rank of the outputs), which lets FakeTensorMode, torch.library.opcheck and
     # torch.compile's tracing pass through these ops without touching a device.
@@ -658,7 +709,7 @@ def register_torch_ops():
     _gemm.register_fake(_fake(_chk_gemm))
     _ln.register_fake(_fake(_chk_ln))
     for op_ in (_attn, _attn_cls, _im2col, _gemm_res_ln, _qkv_time, _qkv_time_mx, _attn_part, _attn_comb, _quant, _ln_mx, _gemm_mx, _gemm_mx_res_ln, _qkv_time_mx_q,
-                _attn_part_mx, _attn_comb_mx, _qkv_time2, _qkv_space, _qkv_space_mx, _qkv_space_mx_q, _side_rows):
+                _attn_part_mx, _attn_comb_mx, _qkv_time2, _qkv_space, _qkv_space_mx, _qkv_space_mx_q, _side_rows, _side_rows_mx, _qkv_time2_mx, _qkv_time2_mx_q):
         op_.register_fake(_fake())
 
     from . import functional as _functional                                 # the functional ops with autograd (synchformer::linear, ::layer_norm768)
@@ -674,7 +725,7 @@ class via_dispatcher:
     The results are the same launches on the same buffers (tests/test_e2e_gpu.py compares them bit for bit)."""
     NAMES = ('gemm', 'layernorm', 'gemm_res_ln', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'quantize_mxfp8', 'layernorm_mxfp8',
              'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention_mx', 'attention_cls_partial_mx', 'attention_cls_combine_mx', 'qkv_time_attention2',
-             'qkv_space_attention', 'qkv_space_attention_mx', 'space_side_rows')
+             'qkv_space_attention', 'qkv_space_attention_mx', 'space_side_rows', 'space_side_rows_mx', 'qkv_time_attention2_mx')
 
     _depth = 0                                                    # re-entrant: an inner `with` inside an active one changes nothing
     calls_total = 0                                               # launches that went through torch.ops.synchformer.* since import (all instances)
@@ -794,8 +845,19 @@ class via_dispatcher:
             count(t.space_side_rows)(x, out, n_seq)
             return out
 
+        def side_rows_mx_(x_q, x_s, side_q, side_s, n_seq):
+            count(t.space_side_rows_mx)(x_q, x_s, side_q, side_s, n_seq)
+            return side_q, side_s
+
+        def qkv_time2_mx_(x_q, x_s, w_q, w_s, bias, side, out, partials, *, n_seq, scale, out_scales=None, n_tok=196):
+            if out_scales is not None:
+                count(t.qkv_time_attention2_mx_q)(x_q, x_s, w_q, w_s, bias, side, out, out_scales, partials, n_seq, scale)
+                return out
+            count(t.qkv_time_attention2_mx)(x_q, x_s, w_q, w_s, bias, side, out, partials, n_seq, scale)
+            return out
+
         g.update(attention_cls_partial_mx=attn_part_mx_, attention_cls_combine_mx=attn_comb_mx_, qkv_time_attention2=qkv_time2_, qkv_space_attention=qkv_space_,
-                 qkv_space_attention_mx=qkv_space_mx_, space_side_rows=side_rows_)
+                 qkv_space_attention_mx=qkv_space_mx_, space_side_rows=side_rows_, space_side_rows_mx=side_rows_mx_, qkv_time_attention2_mx=qkv_time2_mx_)
         g.update(gemm=gemm_, layernorm=layernorm_, gemm_res_ln=gemm_res_ln_, qkv_time_attention=qkv_time_, attention_cls_partial=attn_part_,
                  attention_cls_combine=attn_comb_, quantize_mxfp8=quant_, layernorm_mxfp8=ln_mx_, gemm_mxfp8=gemm_mx_, gemm_mx_res_ln=gemm_mx_ln_,
                  qkv_time_attention_mx=qkv_time_mx_)

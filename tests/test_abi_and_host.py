@@ -191,7 +191,7 @@ def test_custom_ops_have_fake_implementations():
     for name in ('gemm_bf16', 'layernorm768', 'attention', 'attention_cls', 'im2col_video', 'gemm_res_ln768', 'qkv_time_attention', 'attention_cls_partial',
                  'attention_cls_combine', 'quantize_mxfp8', 'layernorm768_mxfp8', 'gemm_mxfp8', 'gemm_mx_res_ln768', 'qkv_time_attention_mx',
                  'qkv_time_attention_mx_q', 'attention_cls_partial_mx', 'attention_cls_combine_mx', 'qkv_time_attention2', 'qkv_space_attention',
-                 'qkv_space_attention_mx', 'qkv_space_attention_mx_q', 'space_side_rows'):
+                 'qkv_space_attention_mx', 'qkv_space_attention_mx_q', 'space_side_rows', 'space_side_rows_mx', 'qkv_time_attention2_mx', 'qkv_time_attention2_mx_q'):
         assert torch._C._dispatch_has_kernel_for_dispatch_key(f'synchformer::{name}', 'Meta'), name
 
 

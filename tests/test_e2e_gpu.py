@@ -113,16 +113,20 @@ def test_mxfp8_towers_bound(gpu):
     # products summed in another order - features agree far inside the fp8 path's own noise
     # the attention kernels writing the projections' MXFP8 operands themselves (sf_attention_cls_partial_mx, sf_qkv_time_attention_mx_q - the default) against
     # their bf16 outputs + sf_quantize_mxfp8: the same bytes, so the same features bit for bit
-    # (compared on the un-fused space launches: sf_qkv_space_attention_mx - the default since round 4 - sums the projection in another tile order)
-    e8.fuse_space = False
+    # (compared on round 3's launches: sf_qkv_space_attention_mx - the default since round 4 - and sf_qkv_time_attention2_mx - round 5 - sum the projection in another tile order)
+    e8.fuse_space = e8.fuse_time2 = False
     v8s = e8.extract_vfeats(u8)
     rels = _rel_rms(v8.cpu(), v8s.cpu())
-    print(f'mxfp8 towers, fused vs un-fused spatial qkv + space attention: vfeat rel-RMS {rels:.5f}')
+    print(f'mxfp8 towers, round-5 fused launches vs round 3\'s (spatial qkv + space attention un-fused, sf_qkv_time_attention_mx): vfeat rel-RMS {rels:.5f}')
     assert 0 < rels < 3e-2
     e8.fuse_mx_attn = False
     assert torch.equal(e8.extract_vfeats(u8), v8s)
     e8.fuse_mx_attn = True
-    e8.fuse_space = True
+    e8.fuse_space = True                                                  # the temporal half alone on the round-5 launch
+    relt = _rel_rms(e8.extract_vfeats(u8).cpu(), v8.cpu())
+    e8.fuse_time2 = True
+    print(f'mxfp8 towers, sf_qkv_time_attention2_mx vs sf_qkv_time_attention_mx (space fused in both): vfeat rel-RMS {relt:.5f}')
+    assert 0 < relt < 3e-2
     e8.fuse_mx_ln = e8.fuse_mx_time = False
     v8u, l8u = e8.extract_vfeats(u8), e8.forward(u8, aud).cpu()
     relu = _rel_rms(v8.cpu(), v8u.cpu())

@@ -1197,6 +1197,70 @@ def _space_side_index(n_seq, dev):
 
 
 @pytest.mark.parametrize('n_seq', [3, 40])
+def test_qkv_time_attention2_mx(gpu, n_seq):
+    """sf_qkv_time_attention2_mx (round 5: the temporal half of the fp8 towers on the 192 x 384 main loop) against the launch it replaces, sf_qkv_time_attention_mx with the
+    CLS rows' projection from a small MX GEMM, on operands whose block scales differ widely along K and across rows.  Both round the projection to bf16 before the
+    attention; this kernel rounds the probabilities to bf16 for the P V MFMA (9 keys per query): one bf16 ulp of head room, as test_qkv_time_attention2.  Repetitions are
+    bit-identical; the MXFP8 output form is byte for byte sf_quantize_mxfp8 of the bf16 output; the side rows (e4m3 bytes AND scale dwords) come from ONE sf_side_rows launch."""
+    from synchformer_amd import ops
+    L, D = 1569, 768
+    rows = n_seq * L
+    g = torch.Generator().manual_seed(290 + n_seq)
+    x = _bf(torch.randn(rows, D, generator=g) * torch.exp2(torch.randint(-3, 3, (rows, D // 32), generator=g).float()).repeat_interleave(32, 1)).to(gpu)
+    w = _bf(torch.randn(3 * D, D, generator=g) * 0.03 * torch.exp2(torch.randint(-2, 2, (3 * D, D // 32), generator=g).float()).repeat_interleave(32, 1)).to(gpu)
+    b = (0.1 * _rand(3 * D, seed=292)).to(gpu)
+    xq, xs = torch.empty(rows, D, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(rows, D, gpu)
+    wq, ws = torch.empty(3 * D, D, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(3 * D, D, gpu)
+    ops.quantize_mxfp8(x, xq, xs)
+    ops.quantize_mxfp8(w, wq, ws)
+    # the side rows: one gather of the e4m3 rows and of their scale dwords == index_select of both
+    idx = _space_side_index(n_seq, gpu)
+    sq, ss = torch.zeros(n_seq * 33, D, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(n_seq * 33, D, gpu)
+    ops.space_side_rows_mx(xq, xs, sq, ss, n_seq)
+    assert torch.equal(sq, xq.index_select(0, idx)) and torch.equal(ss[:, :n_seq * 33], xs.index_select(1, idx))
+    side = torch.empty(n_seq * 33, 3 * D, device=gpu, dtype=torch.bfloat16)
+    ops.gemm_mxfp8(sq, ss, wq, ws, b, side)
+    # reference: round 3's fused MX launch
+    cq = xq.view(n_seq, L, D)[:, 0].contiguous()
+    cs = ops.mx_scale_planes(n_seq, D, gpu)
+    cs[:, :n_seq] = xs[:, :rows].view(6, n_seq, L, 4)[:, :, 0]
+    qkv_cls = torch.empty(n_seq, 3 * D, device=gpu, dtype=torch.bfloat16)
+    ops.gemm_mxfp8(cq, cs, wq, ws, b, qkv_cls)
+    assert torch.equal(qkv_cls, side.view(n_seq, 33, 3 * D)[:, 0])
+    ref = torch.zeros(rows, D, device=gpu, dtype=torch.bfloat16)
+    part_ref = torch.zeros(n_seq * 12 * 49 * 66, device=gpu)
+    ops.qkv_time_attention_mx(xq, xs, wq, ws, b, qkv_cls, ref, part_ref, n_seq=n_seq, n_groups=196, scale=0.125)
+    ops.attention_cls_combine(part_ref, ref, n_part=49, n_seq=n_seq, out_seq_rows=L, out_row=0, heads=12)
+
+    def fused():
+        out = torch.full((rows, D), 7.0, device=gpu, dtype=torch.bfloat16)
+        part = torch.zeros(n_seq * 12 * 33 * 66, device=gpu)
+        ops.qkv_time_attention2_mx(xq, xs, wq, ws, b, side, out, part, n_seq=n_seq, scale=0.125)
+        return out, part
+    out, part = fused()
+    for rep in range(3):
+        o2, p2 = fused()
+        assert torch.equal(o2, out), f'repetition {rep}: {(o2 != out).sum().item()} output elements differ'
+        assert torch.equal(p2, part), f'repetition {rep}: {(p2 != part).sum().item()} partial elements differ'
+    assert (out.view(n_seq, L, D)[:, 0] == 7.0).all(), 'the fused kernel must not touch the CLS rows'
+    # the MXFP8 output form: byte for byte the quantisation of the bf16 output (patch rows)
+    oq, os_ = torch.zeros(rows, D, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(rows, D, gpu)
+    part2 = torch.zeros_like(part)
+    ops.qkv_time_attention2_mx(xq, xs, wq, ws, b, side, oq, part2, n_seq=n_seq, scale=0.125, out_scales=os_)
+    wq_, ws_ = torch.zeros(rows, D, device=gpu, dtype=torch.uint8), ops.mx_scale_planes(rows, D, gpu)
+    ops.quantize_mxfp8(out, wq_, ws_)
+    patch = torch.ones(n_seq, L, dtype=torch.bool, device=gpu); patch[:, 0] = False
+    patch = patch.reshape(-1)
+    assert torch.equal(oq[patch], wq_[patch]) and torch.equal(os_[:, :rows][:, patch], ws_[:, :rows][:, patch]) and torch.equal(part2, part)
+    ops.attention_cls_combine(part, out, n_part=33, n_seq=n_seq, out_seq_rows=L, out_row=0, heads=12)
+    o, r = out.float().view(n_seq, L, D), ref.float().view(n_seq, L, D)
+    scale = r.abs().max().item()
+    torch.testing.assert_close(o[:, 1:], r[:, 1:], rtol=2 ** -5, atol=2 ** -6 * max(1.0, scale))
+    assert (o[:, 1:] - r[:, 1:]).abs().gt(2e-3 * max(1.0, scale)).float().mean() < 1e-2
+    torch.testing.assert_close(o[:, 0], r[:, 0], rtol=2 ** -5, atol=2 ** -6 * max(1.0, scale))
+
+
+@pytest.mark.parametrize('n_seq', [3, 40])
 def test_qkv_space_attention_mx(gpu, n_seq):
     """sf_qkv_space_attention_mx against the un-fused MX sequence it replaces: sf_gemm_mxfp8 (bf16 output) -> sf_attention_cls_partial (space groups) + combine, on operands
     whose block scales differ widely along K and across rows (a wrong scale byte, a swapped k half or a wrong row of the scale dwords cannot hide).  Both round the
