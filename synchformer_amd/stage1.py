@@ -358,13 +358,14 @@ class AVCLIPTrainer(FlatTrainer):
         dy_b = self._buf('dy_b', (n_seq, D), torch.bfloat16)
         cast_bf16(dy, dy_b, n_seq, D)
         dO_b = self._lin_bwd(p + '.self_attn.out_proj', dy_b, s['att'], n_seq, tag='h', dy_f32=dy, dx_dtype=torch.bfloat16)
-        dqkv = self._buf('dqkv', (rows, 3 * D), torch.bfloat16, zero=True)   # dq of rows 1.. stays zero (only row 0 queries)
+        dqkv = self._buf('dqkv', (rows, 3 * D), torch.bfloat16)
+        dqkv.view(n_seq, L, 3 * D)[:, 1:, :D].zero_()                        # dq of rows 1.. is zero (only row 0 queries); dk | dv of every row and dq of row 0 come from _cls_bwd ('=')
         self._cls_bwd(s['qkv'], dO_b, dqkv, n_seq, L, L, do_seq_rows=1, accumulate=False)
         dzn = self._lin_bwd(p + '.self_attn.in_proj', dqkv, s['zn'], rows, tag='h', wkey=p + '.self_attn.in_proj_weight',
                             bkey=p + '.self_attn.in_proj_bias')
-        dZ = self._buf('agg_dZ', (rows, D), torch.float32, zero=True)
-        dZ.view(n_seq, L, D)[:, 0].copy_(dy)                                 # residual path of row 0 (data movement only)
-        self._ln_bwd(s['Z'], p + '.norm1', dzn, dZ, rows, EPS_VIS, acc_dx=True)
+        dZ = self._buf('agg_dZ', (rows, D), torch.float32)
+        self._ln_bwd(s['Z'], p + '.norm1', dzn, dZ, rows, EPS_VIS)              # writes every row ('=': no zero fill of the buffer first)
+        dZ.view(n_seq, L, D)[:, 0].add_(dy)                                  # + the residual path of row 0
         return dZ
 
     # ---- visual tower -------------------------------------------------------------------------------------------------------
@@ -427,7 +428,9 @@ class AVCLIPTrainer(FlatTrainer):
         gz = self._buf('gz', (AGG_V, D), torch.float32)
         self._seqsum(dZ, n * 8, AGG_V, gz)
         self.g[agg + '.cls_token'].view(D).copy_(gz[0])
-        dx = self._buf('v_dx', (M, D), torch.float32, zero=True)               # CLS rows are dropped before the final norm: grad 0
+        dx = self._buf('v_dx', (M, D), torch.float32)
+        dx.view(n, VIS_L, D)[:, 0].zero_()                                     # CLS rows are dropped before the final norm: grad 0 (28 rows, not a 135 MB fill; the
+                                                                               # row-mapped LayerNorm backward below writes every patch row)
         self._ln_bwd(sv['x_last'], V + '.norm', dZ, dx, n * VIS_P, EPS_VIS, x_map=sv['in_map'], dy_map=sv['z_map'], dx_map=sv['in_map'])
         if on_ready:
             on_ready(self._key_range(V + '.norm.', V + '.spatial_attn_agg.'))
@@ -523,7 +526,8 @@ class AVCLIPTrainer(FlatTrainer):
         gz = self._buf('gz', (AGG_V, D), torch.float32)
         self._seqsum(dZ, n * nt, AGG_A, gz)
         self.g[agg + '.cls_token'].view(D).copy_(gz[0])
-        dx = self._buf('a_dx', (M, D), torch.float32, zero=True)
+        dx = self._buf('a_dx', (M, D), torch.float32)
+        dx.view(n, L, D)[:, :L - P].zero_()                                # the cls / distillation rows take no gradient from the final norm (the patch rows are all written below)
         self._ln_bwd(sv['x_last'], A + '.ast.layernorm', dZ, dx, n * P, EPS_AST, x_map=sv['tokmap'], dy_map=sv['z_map'], dx_map=sv['tokmap'])
         for i in reversed(range(self.n_alayers)):
             p, s = f'{A}.ast.encoder.layer.{i}', sv['layers'][i]
@@ -624,7 +628,10 @@ class AVCLIPTrainer(FlatTrainer):
         B, S = vis.shape[:2]
         n = B * S
         self.clamp_logit_scale()
-        self.flat_g.zero_()
+        # (round 5: no flat_g.zero_() - an 857 MB fill per step: every one of the 449 gradients is written with '=' by the backward before anything reads it, proven by
+        #  poisoning the buffer with NaN - tools/s1_grad_coverage.py: 0 of 449 still NaN; the alignment gaps between parameters keep the zeros they were allocated with)
+        if os.environ.get('SF_S1_POISON') == '1':
+            self.flat_g.fill_(float('nan'))
         self.fwd_count += 1                                                    # a fresh set of stochastic-depth masks per forward pass
         aud3 = aud.reshape(n, aud.shape[-2], aud.shape[-1])
         if not self.two_streams:
