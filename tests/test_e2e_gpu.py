@@ -248,6 +248,25 @@ def test_benchmarked_geometry_parity(gpu):
     assert (logits[:2] - torch.from_numpy(g['logits'])).abs().max().item() < 1.5e-2
 
 
+def test_full_size_clip_permutation_equivariance(gpu):
+    """A size-independent property at the benchmarked geometry (16 clips x 14 segments, one 224-segment chunk): offset prediction is per clip (sync_model.py:38-70: no
+    operation mixes clips), so permuting the clips of a batch permutes the logits - a clip's logits do not depend on its batch position or neighbours, although every
+    launch of the path tiles ACROSS clips (a 256-row GEMM tile, a 128-row fused tile and a 24-patch attention block all straddle segment boundaries).  Not bitwise: the
+    fused GEMM + LayerNorm kernel rotates its k-loop per workgroup, so a row's fp32 summation order depends on where its tile falls; bar (gain-2 weights, where clips
+    differ by ~0.2): 1.6e-2, twice test_benchmarked_geometry_parity's gain-1 bar.  The same forward twice IS bitwise (fixed schedule, no atomics)."""
+    from synchformer_amd import synth
+    eng, _ = _engine(gpu, gain=2.0)
+    u8, aud = synth.make_video_u8(16, 14, 2024).to(gpu), synth.make_spectrogram(16, 14, 2024).to(gpu)
+    base = eng.forward(u8, aud).clone()
+    assert torch.equal(eng.forward(u8, aud), base)
+    perm = torch.tensor([11, 3, 7, 0, 15, 9, 1, 13, 5, 2, 14, 8, 6, 12, 4, 10], device=gpu)
+    got = eng.forward(u8[perm].contiguous(), aud[perm].contiguous())
+    d = (got - base[perm]).abs().max().item()
+    spread = (base - base.mean(0, keepdim=True)).abs().max().item()
+    print(f'clip permutation at 16 x 14: max |logits(perm) - perm(logits)| {d:.2e}; clips differ by up to {spread:.3f}')
+    assert d < 1.6e-2 and spread > 5 * d, (d, spread)
+
+
 def test_dropin_module_matches_golden(gpu):
     """The reference-shaped plugin path: instantiate_from_config(sync.yaml model) -> load_state_dict -> model(vis, aud, targets)
     returns (loss, logits) like Synchformer.forward (sync_model.py:38-70); checked against the real reference's outputs."""
