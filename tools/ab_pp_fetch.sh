@@ -3,9 +3,9 @@
 R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 cd /tmp && export TMPDIR=/tmp
 export CFGS=11 KMAJOR=0 ROUNDS=1 ITERS=4 SHAPES=${SHAPES:-qkv,fc1+gelu}
-for so in $(ls $R/synchformer_amd/lib/ab/libsf_*.so | sort -V); do
+for so in $(ls $R/tools/ab_build/libsf_*.so | sort -V); do
   i=$(basename $so .so | sed s/libsf_//)
-  echo "=== variant $i: '$(cat $R/synchformer_amd/lib/ab/flags_$i.txt)'"
+  echo "=== variant $i: '$(cat $R/tools/ab_build/flags_$i.txt)'"
   for grp in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
     rm -rf /tmp/abf
     SYNCHFORMER_HIP_LIB=$so rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/abf -o f -- python $R/tools/bench_gemm.py ${SEGS:-224} > /tmp/abf.log 2>&1
