@@ -58,6 +58,30 @@ def test_argument_validation_without_gpu():
     rc = lib.sf_qkv_space_attention(p, 768, p, 768, None, p, 2304, q, 768, q, 1, 197, 0.125, None)
     assert rc == -1 and b'196-token' in lib.sf_last_error()
     assert lib.sf_qkv_time_attention2(p, 768, p, 768, None, p, 2304, q, 768, q, 0, 196, 0.125, None) == 0      # nothing to do
+    # round 5: the token-mask forms want their flags; the MXFP8 form exactly one output form and 128-byte operand rows; sf_side_rows whole 16-byte chunks and paired planes
+    rc = lib.sf_qkv_time_attention2_masked(p, 768, p, 768, None, p, 2304, q, 768, q, 1, 196, 0.125, None, None)
+    assert rc == -1 and b'null key_keep' in lib.sf_last_error()
+    rc = lib.sf_qkv_space_attention_masked(p, 768, p, 768, None, p, 2304, q, 768, q, 1, 196, 0.125, None, None)
+    assert rc == -1 and b'null key_keep' in lib.sf_last_error()
+    rc = lib.sf_qkv_space_attention_masked(p, 768, p, 768, None, p, 2304, p, 768, q, 1, 196, 0.125, p, None)
+    assert rc == -1 and b'alias' in lib.sf_last_error()
+    rc = lib.sf_qkv_time_attention2_mx(p, 768, p, 6400, p, 768, p, 9216, None, p, 2304, q, 768, q, 768, q, 6400, q, 1, 196, 0.125, None)
+    assert rc == -1 and b'exactly one of out' in lib.sf_last_error()
+    rc = lib.sf_qkv_time_attention2_mx(p, 776, p, 6400, p, 768, p, 9216, None, p, 2304, q, 768, None, 0, None, 0, q, 1, 196, 0.125, None)
+    assert rc == -1 and b'row strides' in lib.sf_last_error()
+    assert lib.sf_qkv_time_attention2_mx(p, 768, p, 6400, p, 768, p, 9216, None, p, 2304, q, 768, None, 0, None, 0, q, 0, 196, 0.125, None) == 0
+    rc = lib.sf_side_rows(p, 1536, q, 1536, 1530, None, 0, None, 0, 0, 1, 196, None)
+    assert rc == -1 and b'16-byte' in lib.sf_last_error()
+    rc = lib.sf_side_rows(p, 768, q, 768, 768, p, 6400, None, 0, 6, 1, 196, None)
+    assert rc == -1 and b'come in pairs' in lib.sf_last_error()
+    assert lib.sf_side_rows(p, 1536, q, 1536, 1536, None, 0, None, 0, 0, 0, 196, None) == 0
+    # config 12 of sf_gemm_bf16 serves bf16 outputs without residual only
+    lib.sf_gemm_force_config(12)
+    try:
+        rc = lib.sf_gemm_bf16(p, 768, p, 768, None, q, 0, 768, None, None, 0, None, 0, 256, 768, 768, None)      # c_dtype 0 = fp32
+        assert rc == -1 and b'config 12' in lib.sf_last_error()
+    finally:
+        lib.sf_gemm_force_config(-1)
 
 
 def test_no_cpu_fallback():
