@@ -1,5 +1,7 @@
 """Build libsynchformer_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
-One object per .hip source (compiled in parallel, rebuilt only when the source or a header changed), then one link."""
+One object per .hip source (compiled in parallel, rebuilt only when the source or a header changed), then one link.
+Then libsynchformer_torch.so: the host-only TORCH_LIBRARY registration (csrc/sf_torch_library.cpp, g++ against the installed torch's headers) that
+`torch.ops.load_library` loads - it links against libsynchformer_hip.so next to it (RPATH $ORIGIN)."""
 import os
 import shutil
 import subprocess
@@ -9,6 +11,8 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / 'csrc'
 OUT = PKG / 'lib' / 'libsynchformer_hip.so'
+TORCH_OUT = PKG / 'lib' / 'libsynchformer_torch.so'
+TORCH_SRC = CSRC / 'sf_torch_library.cpp'
 OBJ = PKG / 'lib' / 'obj'
 CFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 # extra -D flags for throw-away ablation builds (tools/ab_*.sh); the product build has none
@@ -35,11 +39,32 @@ def needs_build() -> bool:
     """Stale if a source / header is newer than the library OR the library was built under other flags (an SF_EXTRA_FLAGS ablation build must never be
     served as the product library by a later plain build() / _lib.load())."""
     stamp = OBJ / '.flags'
-    return _stale(OUT, sources() + _headers()) or not stamp.exists() or stamp.read_text() != _flags_txt()
+    return _stale(OUT, sources() + _headers()) or not stamp.exists() or stamp.read_text() != _flags_txt() or _stale(TORCH_OUT, [TORCH_SRC, OUT] + _headers())
+
+
+def build_torch_library(verbose: bool = True) -> Path:
+    """The dispatcher library (TORCH_LIBRARY(synchformer) + TORCH_LIBRARY_IMPL(..., CUDA)): host C++ only, ~10 s with g++."""
+    import torch                                                       # headers, libraries and the C++ ABI flag of the interpreter that will load it
+    from torch.utils import cpp_extension as ce
+    cxx = shutil.which('g++') or shutil.which('c++')
+    if cxx is None:
+        raise RuntimeError('g++ not found; cannot build libsynchformer_torch.so')
+    tlib = ce.library_paths()[0]
+    cmd = [cxx, '-O2', '-std=c++17', '-fPIC', '-shared', '-Wall', '-D__HIP_PLATFORM_AMD__', '-DUSE_ROCM', f'-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}',
+           *[f'-I{p}' for p in ce.include_paths()], '-I/opt/rocm/include', str(TORCH_SRC), '-o', str(TORCH_OUT.with_suffix('.so.tmp')),
+           f'-L{tlib}', '-ltorch', '-ltorch_cpu', '-lc10', '-lc10_hip', '-ltorch_hip', f'-L{OUT.parent}', '-lsynchformer_hip', '-Wl,-rpath,$ORIGIN']
+    if verbose:
+        print('[build]', ' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(TORCH_OUT.with_suffix('.so.tmp'), TORCH_OUT)
+    return TORCH_OUT
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
     if not force and not needs_build():
+        return OUT
+    if not force and not _stale(OUT, sources() + _headers()) and (OBJ / '.flags').exists() and (OBJ / '.flags').read_text() == _flags_txt():
+        build_torch_library(verbose)                                    # only the dispatcher library is stale
         return OUT
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not Path(hipcc).exists():
@@ -72,6 +97,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         print('[build]', ' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(tmp, OUT)
+    build_torch_library(verbose)
     return OUT
 
 

@@ -554,142 +554,29 @@ def cross_entropy(logits: torch.Tensor, targets: torch.Tensor, loss: torch.Tenso
 _registered = False
 
 
+# the operators libsynchformer_torch.so defines (csrc/sf_torch_library.cpp)
+DISPATCHER_OPS = ('gemm_bf16', 'layernorm768', 'gemm_res_ln768', 'attention', 'attention_cls', 'attention_cls_partial', 'attention_cls_combine', 'im2col_video',
+                  'qkv_time_attention', 'qkv_time_attention2', 'qkv_space_attention', 'qkv_time_attention2_masked', 'qkv_space_attention_masked', 'space_side_rows',
+                  'space_side_rows_mx', 'quantize_mxfp8', 'layernorm768_mxfp8', 'gemm_mxfp8', 'gemm_mx_res_ln768', 'qkv_time_attention_mx', 'qkv_time_attention_mx_q',
+                  'attention_cls_partial_mx', 'attention_cls_combine_mx', 'qkv_space_attention_mx', 'qkv_space_attention_mx_q', 'qkv_time_attention2_mx',
+                  'qkv_time_attention2_mx_q')
+
+
 def register_torch_ops():
+    """Load the dispatcher library: `libsynchformer_torch.so` (csrc/sf_torch_library.cpp) DEFINES `torch.ops.synchformer.*` with TORCH_LIBRARY and implements
+    them for the CUDA (= HIP on ROCm) dispatch key with TORCH_LIBRARY_IMPL, each operator one call into the C ABI on the current HIP stream.  Python adds what has no
+    device code: the Meta / FakeTensor implementations (every op is an out-variant - it mutates its outputs and returns nothing -, so the abstract implementation only
+    checks what the launcher would refuse) and the two functional ops with autograd (synchformer_amd/functional.py).  Raises if the library is not built - there is no
+    Python-side fallback registration."""
     global _registered
     if _registered:
         return
-    from torch.library import custom_op
-    # the direct launchers, bound now: ops.via_dispatcher() re-points the module-level names at these custom ops
-    d_ = {n: globals()[n] for n in ('gemm', 'layernorm', 'attention', 'attention_cls', 'im2col_video', 'gemm_res_ln', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'quantize_mxfp8', 'layernorm_mxfp8', 'gemm_mxfp8', 'gemm_mx_res_ln', 'qkv_time_attention_mx', 'attention_cls_partial_mx', 'attention_cls_combine_mx', 'qkv_time_attention2', 'qkv_space_attention', 'qkv_space_attention_mx', 'space_side_rows', 'space_side_rows_mx', 'qkv_time_attention2_mx')}
+    path = _lib.lib_path().parent / 'libsynchformer_torch.so'
+    if not path.exists():
+        raise RuntimeError(f'{path} not found: the dispatcher library is not built (python -c "import __graft_entry__ as g; g.build()")')
+    _lib.load()                                                             # libsynchformer_hip.so first: the dispatcher library links against it
+    torch.ops.load_library(str(path))
 
-    @custom_op('synchformer::gemm_bf16', mutates_args=('out',), device_types='cuda')
-    def _gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, residual: Optional[torch.Tensor],
-              gelu: bool) -> None:
-        d_['gemm'](a, w, bias, out, residual=residual, gelu=gelu)
-
-    @custom_op('synchformer::layernorm768', mutates_args=('out',), device_types='cuda')
-    def _ln(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, eps: float) -> None:
-        d_['layernorm'](x, gamma, beta, out, eps)
-
-    @custom_op('synchformer::attention', mutates_args=('out',), device_types='cuda')
-    def _attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, n_seq: int, seq_rows: int, n_groups: int, row0: int,
-              group_stride: int, tok_stride: int, n_tok: int, cls_row: int, heads: int, head_dim: int, scale: float) -> None:
-        d_['attention'](q, k, v, out, n_seq=n_seq, seq_rows=seq_rows, n_groups=n_groups, row0=row0, group_stride=group_stride,
-                  tok_stride=tok_stride, n_tok=n_tok, cls_row=cls_row, heads=heads, head_dim=head_dim, scale=scale)
-
-    @custom_op('synchformer::attention_cls', mutates_args=('out',), device_types='cuda')
-    def _attn_cls(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, n_seq: int, q_seq_rows: int, q_row: int,
-                  kv_seq_rows: int, kv_row0: int, n_keys: int, out_seq_rows: int, out_row: int, heads: int, head_dim: int,
-                  scale: float) -> None:
-        d_['attention_cls'](q, k, v, out, n_seq=n_seq, q_seq_rows=q_seq_rows, q_row=q_row, kv_seq_rows=kv_seq_rows, kv_row0=kv_row0,
-                      n_keys=n_keys, out_seq_rows=out_seq_rows, out_row=out_row, heads=heads, head_dim=head_dim, scale=scale)
-
-    @custom_op('synchformer::im2col_video', mutates_args=('out',), device_types='cuda')
-    def _im2col(vid: torch.Tensor, out: torch.Tensor) -> None:
-        d_['im2col_video'](vid, out)
-
-    # the fused launches the engine's default schedule is made of (rounds 2 / 3)
-    @custom_op('synchformer::gemm_res_ln768', mutates_args=('x', 'y'), device_types='cuda')
-    def _gemm_res_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch.Tensor,
-                     eps: float) -> None:
-        d_['gemm_res_ln'](a, w, bias, x, gamma, beta, y, eps)
-
-    @custom_op('synchformer::qkv_time_attention', mutates_args=('out', 'partials'), device_types='cuda')
-    def _qkv_time(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], qkv_cls: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, n_seq: int,
-                  n_groups: int, scale: float, key_keep: Optional[torch.Tensor]) -> None:
-        d_['qkv_time_attention'](x, w, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale, key_keep=key_keep)
-
-    @custom_op('synchformer::qkv_time_attention_mx', mutates_args=('out', 'partials'), device_types='cuda')
-    def _qkv_time_mx(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], qkv_cls: torch.Tensor, out: torch.Tensor,
-                     partials: torch.Tensor, n_seq: int, n_groups: int, scale: float) -> None:
-        d_['qkv_time_attention_mx'](x_q, x_s, w_q, w_s, bias, qkv_cls, out, partials, n_seq=n_seq, n_groups=n_groups, scale=scale)
-
-    @custom_op('synchformer::attention_cls_partial', mutates_args=('out', 'partials'), device_types='cuda')
-    def _attn_part(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, n_seq: int, seq_rows: int, n_groups: int,
-                   row0: int, group_stride: int, tok_stride: int, n_tok: int, cls_row: int, heads: int, head_dim: int, scale: float,
-                   key_keep: Optional[torch.Tensor]) -> None:
-        d_['attention_cls_partial'](q, k, v, out, partials, n_seq=n_seq, seq_rows=seq_rows, n_groups=n_groups, row0=row0, group_stride=group_stride,
-                              tok_stride=tok_stride, n_tok=n_tok, cls_row=cls_row, heads=heads, head_dim=head_dim, scale=scale, key_keep=key_keep)
-
-    @custom_op('synchformer::attention_cls_combine', mutates_args=('out',), device_types='cuda')
-    def _attn_comb(partials: torch.Tensor, out: torch.Tensor, n_part: int, n_seq: int, out_seq_rows: int, out_row: int, heads: int) -> None:
-        d_['attention_cls_combine'](partials, out, n_part=n_part, n_seq=n_seq, out_seq_rows=out_seq_rows, out_row=out_row, heads=heads)
-
-    @custom_op('synchformer::quantize_mxfp8', mutates_args=('q', 'scales'), device_types='cuda')
-    def _quant(x: torch.Tensor, q: torch.Tensor, scales: torch.Tensor) -> None:
-        d_['quantize_mxfp8'](x, q, scales)
-
-    @custom_op('synchformer::layernorm768_mxfp8', mutates_args=('q', 'scales'), device_types='cuda')
-    def _ln_mx(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, q: torch.Tensor, scales: torch.Tensor, eps: float) -> None:
-        d_['layernorm_mxfp8'](x, gamma, beta, q, scales, eps)
-
-    @custom_op('synchformer::gemm_mxfp8', mutates_args=('out', 'out_scales'), device_types='cuda')
-    def _gemm_mx(a_q: torch.Tensor, a_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor,
-                 out_scales: Optional[torch.Tensor], residual: Optional[torch.Tensor], gelu: bool) -> None:
-        d_['gemm_mxfp8'](a_q, a_s, w_q, w_s, bias, out, residual=residual, gelu=gelu, out_scales=out_scales)
-
-    @custom_op('synchformer::gemm_mx_res_ln768', mutates_args=('x', 'y_q', 'y_s'), device_types='cuda')
-    def _gemm_mx_res_ln(a_q: torch.Tensor, a_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], x: torch.Tensor,
-                        gamma: torch.Tensor, beta: torch.Tensor, y_q: torch.Tensor, y_s: torch.Tensor, eps: float) -> None:
-        d_['gemm_mx_res_ln'](a_q, a_s, w_q, w_s, bias, x, gamma, beta, y_q, y_s, eps)
-
-    @custom_op('synchformer::qkv_time_attention_mx_q', mutates_args=('out_q', 'out_s', 'partials'), device_types='cuda')
-    def _qkv_time_mx_q(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], qkv_cls: torch.Tensor, out_q: torch.Tensor,
-                       out_s: torch.Tensor, partials: torch.Tensor, n_seq: int, n_groups: int, scale: float) -> None:
-        d_['qkv_time_attention_mx'](x_q, x_s, w_q, w_s, bias, qkv_cls, out_q, partials, n_seq=n_seq, n_groups=n_groups, scale=scale, out_scales=out_s)
-
-    @custom_op('synchformer::attention_cls_partial_mx', mutates_args=('out_q', 'out_s', 'partials'), device_types='cuda')
-    def _attn_part_mx(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_q: torch.Tensor, out_s: torch.Tensor, partials: torch.Tensor, n_seq: int, seq_rows: int,
-                      n_groups: int, row0: int, group_stride: int, tok_stride: int, n_tok: int, cls_row: int, heads: int, scale: float) -> None:
-        d_['attention_cls_partial_mx'](q, k, v, out_q, out_s, partials, n_seq=n_seq, seq_rows=seq_rows, n_groups=n_groups, row0=row0, group_stride=group_stride,
-                                       tok_stride=tok_stride, n_tok=n_tok, cls_row=cls_row, heads=heads, scale=scale)
-
-    @custom_op('synchformer::attention_cls_combine_mx', mutates_args=('out_q', 'out_s'), device_types='cuda')
-    def _attn_comb_mx(partials: torch.Tensor, out_q: torch.Tensor, out_s: torch.Tensor, n_part: int, n_seq: int, out_seq_rows: int, out_row: int, heads: int) -> None:
-        d_['attention_cls_combine_mx'](partials, out_q, out_s, n_part=n_part, n_seq=n_seq, out_seq_rows=out_seq_rows, out_row=out_row, heads=heads)
-
-    # round 4: both halves of DividedSpaceTimeBlock's attention as one launch each on the 192 x 384 main loop, and the gather of their 33 side rows per segment
-    @custom_op('synchformer::qkv_time_attention2', mutates_args=('out', 'partials'), device_types='cuda')
-    def _qkv_time2(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, n_seq: int,
-                   scale: float) -> None:
-        d_['qkv_time_attention2'](x, w, bias, side, out, partials, n_seq=n_seq, scale=scale)
-
-    @custom_op('synchformer::qkv_space_attention', mutates_args=('out', 'partials'), device_types='cuda')
-    def _qkv_space(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out: torch.Tensor, partials: torch.Tensor, n_seq: int,
-                   scale: float) -> None:
-        d_['qkv_space_attention'](x, w, bias, side, out, partials, n_seq=n_seq, scale=scale)
-
-    @custom_op('synchformer::qkv_space_attention_mx', mutates_args=('out', 'partials'), device_types='cuda')
-    def _qkv_space_mx(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out: torch.Tensor,
-                      partials: torch.Tensor, n_seq: int, scale: float) -> None:
-        d_['qkv_space_attention_mx'](x_q, x_s, w_q, w_s, bias, side, out, partials, n_seq=n_seq, scale=scale)
-
-    @custom_op('synchformer::qkv_space_attention_mx_q', mutates_args=('out_q', 'out_s', 'partials'), device_types='cuda')
-    def _qkv_space_mx_q(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out_q: torch.Tensor,
-                        out_s: torch.Tensor, partials: torch.Tensor, n_seq: int, scale: float) -> None:
-        d_['qkv_space_attention_mx'](x_q, x_s, w_q, w_s, bias, side, out_q, partials, n_seq=n_seq, scale=scale, out_scales=out_s)
-
-    @custom_op('synchformer::space_side_rows', mutates_args=('out',), device_types='cuda')
-    def _side_rows(x: torch.Tensor, out: torch.Tensor, n_seq: int) -> None:
-        d_['space_side_rows'](x, out, n_seq)
-
-    @custom_op('synchformer::space_side_rows_mx', mutates_args=('side_q', 'side_s'), device_types='cuda')
-    def _side_rows_mx(x_q: torch.Tensor, x_s: torch.Tensor, side_q: torch.Tensor, side_s: torch.Tensor, n_seq: int) -> None:
-        d_['space_side_rows_mx'](x_q, x_s, side_q, side_s, n_seq)
-
-    @custom_op('synchformer::qkv_time_attention2_mx', mutates_args=('out', 'partials'), device_types='cuda')
-    def _qkv_time2_mx(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out: torch.Tensor,
-                      partials: torch.Tensor, n_seq: int, scale: float) -> None:
-        d_['qkv_time_attention2_mx'](x_q, x_s, w_q, w_s, bias, side, out, partials, n_seq=n_seq, scale=scale)
-
-    @custom_op('synchformer::qkv_time_attention2_mx_q', mutates_args=('out_q', 'out_s', 'partials'), device_types='cuda')
-    def _qkv_time2_mx_q(x_q: torch.Tensor, x_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, bias: Optional[torch.Tensor], side: torch.Tensor, out_q: torch.Tensor,
-                        out_s: torch.Tensor, partials: torch.Tensor, n_seq: int, scale: float) -> None:
-        d_['qkv_time_attention2_mx'](x_q, x_s, w_q, w_s, bias, side, out_q, partials, n_seq=n_seq, scale=scale, out_scales=out_s)
-
-    # Meta / FakeTensor implementations: every op is an out-variant (mutates its outputs, returns nothing), so the abstract implementation has no output
-    # to describe - it only checks what the launcher would refuse (dtype / rank of the outputs), which lets FakeTensorMode, torch.library.opcheck and
-    # torch.compile's tracing pass through these ops without touching a device.
     def _fake(check=None):
         def impl(*args):
             if check is not None:
@@ -706,11 +593,11 @@ def register_torch_ops():
     def _chk_ln(x, gamma, beta, out, eps):
         torch._check(x.shape[-1] == 768 and out.shape[-1] == 768 and x.dtype == torch.float32, lambda: 'synchformer::layernorm768: fp32 (rows, 768) in, 768 columns out')
 
-    _gemm.register_fake(_fake(_chk_gemm))
-    _ln.register_fake(_fake(_chk_ln))
-    for op_ in (_attn, _attn_cls, _im2col, _gemm_res_ln, _qkv_time, _qkv_time_mx, _attn_part, _attn_comb, _quant, _ln_mx, _gemm_mx, _gemm_mx_res_ln, _qkv_time_mx_q,
-                _attn_part_mx, _attn_comb_mx, _qkv_time2, _qkv_space, _qkv_space_mx, _qkv_space_mx_q, _side_rows, _side_rows_mx, _qkv_time2_mx, _qkv_time2_mx_q):
-        op_.register_fake(_fake())
+    torch.library.register_fake('synchformer::gemm_bf16')(_fake(_chk_gemm))
+    torch.library.register_fake('synchformer::layernorm768')(_fake(_chk_ln))
+    for name in DISPATCHER_OPS:
+        if name not in ('gemm_bf16', 'layernorm768'):
+            torch.library.register_fake('synchformer::' + name)(_fake())
 
     from . import functional as _functional                                 # the functional ops with autograd (synchformer::linear, ::layer_norm768)
     _functional.register()
@@ -823,14 +710,16 @@ class via_dispatcher:
             return out_q
 
         def qkv_time2_(x, w, bias, side, out, partials, *, n_seq, scale, n_tok=196, key_keep=None):
-            if key_keep is not None:                                # (the registered schema carries no key flags: masked forwards take the direct path)
-                return o['qkv_time_attention2'](x, w, bias, side, out, partials, n_seq=n_seq, scale=scale, n_tok=n_tok, key_keep=key_keep)
+            if key_keep is not None:
+                count(t.qkv_time_attention2_masked)(x, w, bias, side, out, partials, n_seq, scale, key_keep)
+                return out
             count(t.qkv_time_attention2)(x, w, bias, side, out, partials, n_seq, scale)
             return out
 
         def qkv_space_(x, w, bias, side, out, partials, *, n_seq, scale, n_tok=196, key_keep=None):
             if key_keep is not None:
-                return o['qkv_space_attention'](x, w, bias, side, out, partials, n_seq=n_seq, scale=scale, n_tok=n_tok, key_keep=key_keep)
+                count(t.qkv_space_attention_masked)(x, w, bias, side, out, partials, n_seq, scale, key_keep)
+                return out
             count(t.qkv_space_attention)(x, w, bias, side, out, partials, n_seq, scale)
             return out
 

@@ -212,11 +212,30 @@ def test_custom_ops_have_fake_implementations():
         assert t.gemm_res_ln768(a, torch.empty(768, 768, dtype=torch.bfloat16, device='cuda'), g, x, g, g, a, 1e-6) is None
         with pytest.raises(RuntimeError, match='out must be'):
             t.gemm_bf16(a, w, None, x, None, False)
-    for name in ('gemm_bf16', 'layernorm768', 'attention', 'attention_cls', 'im2col_video', 'gemm_res_ln768', 'qkv_time_attention', 'attention_cls_partial',
-                 'attention_cls_combine', 'quantize_mxfp8', 'layernorm768_mxfp8', 'gemm_mxfp8', 'gemm_mx_res_ln768', 'qkv_time_attention_mx',
-                 'qkv_time_attention_mx_q', 'attention_cls_partial_mx', 'attention_cls_combine_mx', 'qkv_time_attention2', 'qkv_space_attention',
-                 'qkv_space_attention_mx', 'qkv_space_attention_mx_q', 'space_side_rows', 'space_side_rows_mx', 'qkv_time_attention2_mx', 'qkv_time_attention2_mx_q'):
+    assert len(ops.DISPATCHER_OPS) == 27
+    for name in ops.DISPATCHER_OPS:
         assert torch._C._dispatch_has_kernel_for_dispatch_key(f'synchformer::{name}', 'Meta'), name
+
+
+def test_dispatcher_library_is_a_torch_library():
+    """SURVEY 8b(1) to the letter: the operators are DEFINED by a compiled library (TORCH_LIBRARY(synchformer) in csrc/sf_torch_library.cpp) that `torch.ops.load_library`
+    loads, and IMPLEMENTED for the CUDA dispatch key (= HIP on PyTorch-ROCm) by TORCH_LIBRARY_IMPL - not by Python `custom_op` registrations; loading needs no GPU.  A CPU
+    tensor reaches no kernel: the dispatcher has no CPU implementation to fall back to."""
+    from synchformer_amd import _lib, ops
+    ops.register_torch_ops()
+    so = str(_lib.lib_path().parent / 'libsynchformer_torch.so')
+    assert so in torch.ops.loaded_libraries
+    for name in ops.DISPATCHER_OPS:
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(f'synchformer::{name}', 'CUDA'), name
+        assert not torch._C._dispatch_has_kernel_for_dispatch_key(f'synchformer::{name}', 'CPU'), name
+    sch = str(torch.ops.synchformer.gemm_res_ln768.default._schema)
+    assert 'Tensor(a!) x' in sch and 'Tensor(b!) y' in sch and sch.endswith('-> ()'), sch
+    assert 'Tensor key_keep' in str(torch.ops.synchformer.qkv_space_attention_masked.default._schema)
+    a = torch.zeros(256, 768, dtype=torch.bfloat16)
+    with pytest.raises(NotImplementedError, match="CPU"):
+        torch.ops.synchformer.gemm_bf16(a, a, None, torch.zeros(256, 256, dtype=torch.bfloat16), None, False)
+    # the functional ops with autograd live on the same namespace, registered from Python
+    assert hasattr(torch.ops.synchformer, 'linear') and hasattr(torch.ops.synchformer, 'layer_norm768')
 
 
 def test_offset_accuracy_and_structured_clips():

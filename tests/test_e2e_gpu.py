@@ -135,8 +135,9 @@ def test_mxfp8_towers_bound(gpu):
 
 
 def test_forward_through_the_dispatcher(gpu):
-    """north_star: "registered as PyTorch-ROCm custom ops".  The fused launches of the default schedule are `torch.ops.synchformer.*` custom ops; with
-    ops.via_dispatcher() the engine's forward - bf16 and MXFP8 towers - runs through the PyTorch dispatcher and gives the same bits as the direct C-ABI path."""
+    """north_star: "registered as PyTorch-ROCm custom ops".  The fused launches of the default schedule are `torch.ops.synchformer.*` operators of the compiled
+    dispatcher library (TORCH_LIBRARY in csrc/sf_torch_library.cpp, round 5); with ops.via_dispatcher() the engine's forward - bf16 and MXFP8 towers, masked and
+    unmasked - runs through the PyTorch dispatcher and gives the same bits as the direct ctypes path."""
     from synchformer_amd import ops, synth
     from synchformer_amd.engine import SynchformerEngine
     for name in ('gemm_bf16', 'layernorm768', 'gemm_res_ln768', 'qkv_time_attention', 'attention_cls_partial', 'attention_cls_combine', 'gemm_mxfp8',
@@ -153,6 +154,18 @@ def test_forward_through_the_dispatcher(gpu):
             disp = eng.forward(u8, aud).clone()
         assert d.calls > 100, d.calls          # (launches with row maps or an explicit M keep the direct path)
         assert torch.equal(direct, disp)
+        # round 3's launches (SF_FUSE_SPACE / SF_FUSE_TIME2 off) are operators of the same library
+        eng.fuse_space = eng.fuse_time2 = False
+        direct3 = eng.forward(u8, aud).clone()
+        with ops.via_dispatcher():
+            assert torch.equal(eng.forward(u8, aud), direct3)
+        eng.fuse_space = eng.fuse_time2 = True
+        if not fp8:                            # token masks: the *_masked operators (round 5)
+            vm, am = synth.make_masks(6, S, 7)
+            dm = eng.forward(u8, aud, vm.to(gpu), am.to(gpu)).clone()
+            with ops.via_dispatcher() as d2:
+                assert torch.equal(eng.forward(u8, aud, vm.to(gpu), am.to(gpu)), dm)
+            assert d2.calls > 100 and not torch.equal(dm, direct)
 
 
 @pytest.mark.parametrize('fp8', [False, True])
