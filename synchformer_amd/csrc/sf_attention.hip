@@ -206,6 +206,7 @@ struct AttnBwdArgs {
 __global__ __launch_bounds__(256) void attn_tiny64_bwd_kernel(AttnBwdArgs p, int64_t total_units) {
   __shared__ __attribute__((aligned(16))) bf16_t q_l[4][8][64], do_l[4][8][64];
   __shared__ float ds_l[4][8][12], p_l[4][8][12];
+  __shared__ __attribute__((aligned(16))) uint4 k_l[4][TINY_SLOTS][8], v_l[4][TINY_SLOTS][8];   // keys / values: fetched once per wave, like the forward
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t unit = (int64_t)blockIdx.x * 4 + wv;
   if (unit >= total_units) return;
@@ -224,16 +225,22 @@ __global__ __launch_bounds__(256) void attn_tiny64_bwd_kernel(AttnBwdArgs p, int
   const uint4 doraw = *reinterpret_cast<const uint4*>(p.dO + qrow * p.lddo + col);
   const int has_cls = p.cls_row >= 0 ? 1 : 0;
   const int nk = p.n_tok + has_cls;
-  uint4 kraw[9], vraw[9];
-#pragma unroll
-  for (int j = 0; j < 9; ++j) {
-    const int jj = j < nk ? j : nk - 1;
-    const int64_t row = (has_cls && jj == 0) ? seq_base + p.cls_row : first + (int64_t)(jj - has_cls) * p.tok_stride;
-    kraw[j] = *reinterpret_cast<const uint4*>(p.k + row * p.ld + col);
-    vraw[j] = *reinterpret_cast<const uint4*>(p.v + row * p.ld + col);
+  // lane (r, sub) fetches 16 bytes of ITS token's key and value (lanes 0-7 / 8-15 the CLS key / value as well) and every query lane reads key j's slice back from
+  // wave-private LDS: 4 vector loads per lane instead of 18 eight-fold redundant ones and 72 fewer live registers (the forward's layout, attn_tiny64_kernel)
+  {
+    const uint4 kmine = *reinterpret_cast<const uint4*>(p.k + qrow * p.ld + col);
+    const uint4 vmine = *reinterpret_cast<const uint4*>(p.v + qrow * p.ld + col);
+    if (has_cls && qi < 2) {
+      const uint4 c = *reinterpret_cast<const uint4*>((qi == 0 ? p.k : p.v) + (seq_base + p.cls_row) * p.ld + col);
+      if (qi == 0) k_l[wv][0][sub] = c; else v_l[wv][0][sub] = c;
+    }
+    if (q_valid) { k_l[wv][has_cls + qi][sub] = kmine; v_l[wv][has_cls + qi][sub] = vmine; }
   }
   *reinterpret_cast<uint4*>(&q_l[wv][qi][sub * 8]) = qraw;
   *reinterpret_cast<uint4*>(&do_l[wv][qi][sub * 8]) = doraw;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#define TINY_K(j) k_l[wv][(j) < nk ? (j) : nk - 1][sub]
+#define TINY_V(j) v_l[wv][(j) < nk ? (j) : nk - 1][sub]
   // ---- the CLS query (optional, sf_attention_tiny_bwd_clsq): it attends every key of the sequence, so here it is a ninth query on this group's keys, normalised with
   // the forward's statistics; lane group qi handles key qi, key 8 is computed by every group (used by group 0's lanes in the second pass); the CLS KEY counts for
   // it in group 0 only.  pc / dsc: its probability and score gradient for this lane group's key, p8 / ds8 for key 8.
@@ -247,11 +254,8 @@ __global__ __launch_bounds__(256) void attn_tiny64_bwd_kernel(AttnBwdArgs p, int
     const uint4 oc = *reinterpret_cast<const uint4*>(p.o + cr * p.ldo + col);
     const float* gs = p.cls_stats + (seq * p.heads + head) * 2;
     const float Mg = gs[0], Linv = 1.0f / gs[1];
-    uint4 ksel = kraw[0], vsel = vraw[0];
-#pragma unroll
-    for (int j = 1; j < 8; ++j)
-      if (qi == j) { ksel = kraw[j]; vsel = vraw[j]; }
-    float dl = dot8_bf16(doc_raw, oc), sc_ = dot8_bf16(qc_raw, ksel), dpc = dot8_bf16(doc_raw, vsel), s8 = dot8_bf16(qc_raw, kraw[8]), dp8 = dot8_bf16(doc_raw, vraw[8]);
+    const uint4 ksel = TINY_K(qi), vsel = TINY_V(qi), k8 = TINY_K(8), v8 = TINY_V(8);
+    float dl = dot8_bf16(doc_raw, oc), sc_ = dot8_bf16(qc_raw, ksel), dpc = dot8_bf16(doc_raw, vsel), s8 = dot8_bf16(qc_raw, k8), dp8 = dot8_bf16(doc_raw, v8);
     dl = sum8_dpp(dl); sc_ = sum8_dpp(sc_); dpc = sum8_dpp(dpc); s8 = sum8_dpp(s8); dp8 = sum8_dpp(dp8);
     const float sc2c = p.scale * 1.44269504088896f;
     if (qi < nk && !(has_cls && qi == 0 && g != 0)) { pc = __builtin_amdgcn_exp2f(fmaf(sc_, sc2c, -Mg)) * Linv; dsc = pc * (dpc - dl) * p.scale; }
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256) void attn_tiny64_bwd_kernel(AttnBwdArgs p, int
 #pragma unroll
     for (int i = 0; i < 4; ++i) dqc[i] = sf_f32x2_t{0.f, 0.f};
     axpy8_bf16(dqc, dsc, ksel);
-    if (qi == 0) axpy8_bf16(dqc, ds8, kraw[8]);
+    if (qi == 0) axpy8_bf16(dqc, ds8, k8);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       dqc[i].x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dqc[i].x), 0x128, 0xF, 0xF, true));   // row_ror:8 = the lane 8 away in the 16-lane row
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256) void attn_tiny64_bwd_kernel(AttnBwdArgs p, int
   float s[9], dp[9], m = -INFINITY;
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
-    float d = dot8_bf16(qraw, kraw[j]), e = dot8_bf16(doraw, vraw[j]);
+    float d = dot8_bf16(qraw, TINY_K(j)), e = dot8_bf16(doraw, TINY_V(j));
     d = sum8_dpp(d);
     e = sum8_dpp(e);
     s[j] = j < nk ? d * sc2 : -INFINITY;
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(256) void attn_tiny64_bwd_kernel(AttnBwdArgs p, int
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
     const float ds = s[j] * (dp[j] - delta) * p.scale;
-    axpy8_bf16(dqa, ds, kraw[j]);
+    axpy8_bf16(dqa, ds, TINY_K(j));
     if (sub == 0) { ds_l[wv][qi][j] = ds; p_l[wv][qi][j] = s[j]; }
   }
   if (q_valid) {
@@ -345,6 +349,8 @@ __global__ __launch_bounds__(256) void attn_tiny64_bwd_kernel(AttnBwdArgs p, int
     }
   }
 }
+#undef TINY_K
+#undef TINY_V
 
 static int attention_tiny_bwd_impl(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const bf16_t* dO, int64_t lddo, bf16_t* dq, bf16_t* dk,
                                    bf16_t* dv, int64_t ldg, bf16_t* cls_part, int64_t n_seq, int64_t seq_rows, int n_groups, int row0, int group_stride, int tok_stride,

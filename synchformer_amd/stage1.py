@@ -83,6 +83,8 @@ class AVCLIPTrainer(FlatTrainer):
         self._pre_dy = {}
         self.two_streams = os.environ.get('SF_STAGE1_TWO_STREAMS', '1') != '0'   # audio tower next to the visual one (forward_backward)
         self._side = None
+        self._ls_host = self._ls_ev = None  # pinned host mirror of logit_scale + the event behind its copy (forward_backward / _head)
+        self._ls_pending = False
         self._pre_ln = set()                # workspace buffers whose LayerNorm output _add_branch has already produced (consumed by _ln_into)
         self.n_vblocks = len([k for k in keys if k.startswith(V + '.blocks.') and k.endswith('.norm1.weight')])
         self.n_alayers = len([k for k in keys if k.endswith('.layernorm_before.weight')])
@@ -585,7 +587,13 @@ class AVCLIPTrainer(FlatTrainer):
         """AVCLIP.compute_loss (open_clip/model.py:506-525) + its backward -> (dvfeat, dafeat) fp32 (n, 768); fills g[logit_scale]."""
         from .dist import all_gather_pair, reduce_scatter_pair
         n = vfeat.shape[0]
-        s = float(self.p['logit_scale'])                                        # host scalar (one sync per step)
+        # the temperature is a by-value launch argument.  Its device -> pinned-host copy was queued BEFORE this step's forward (forward_backward), so waiting for it
+        # here waits for the previous step's optimizer only - the launcher stays a whole forward ahead of the GPU instead of draining the queue in mid-step
+        if self._ls_pending:
+            self._ls_ev.synchronize()
+            s, self._ls_pending = float(self._ls_host), False
+        else:                                                                   # _head called on its own (tests): read it now
+            s = float(self.p['logit_scale'])
         world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
         gathered = self.gather_for_loss and world > 1
         v_all, a_all = all_gather_pair(vfeat, afeat) if gathered else (vfeat, afeat)      # one 172 KB message for both modalities
@@ -628,6 +636,11 @@ class AVCLIPTrainer(FlatTrainer):
         B, S = vis.shape[:2]
         n = B * S
         self.clamp_logit_scale()
+        if self._ls_host is None:
+            self._ls_host, self._ls_ev = torch.empty((), dtype=torch.float32).pin_memory(), torch.cuda.Event()
+        self._ls_host.copy_(self.p['logit_scale'].detach().reshape(()), non_blocking=True)
+        self._ls_ev.record()
+        self._ls_pending = True
         # (round 5: no flat_g.zero_() - an 857 MB fill per step: every one of the 449 gradients is written with '=' by the backward before anything reads it, proven by
         #  poisoning the buffer with NaN - tools/s1_grad_coverage.py: 0 of 449 still NaN; the alignment gaps between parameters keep the zeros they were allocated with)
         if os.environ.get('SF_S1_POISON') == '1':
