@@ -406,19 +406,36 @@ static int attention_tiny_bwd_impl(const bf16_t* q, const bf16_t* k, const bf16_
 //   pass 2 (key tiles over the waves):   dK and dV, with p = exp2(s*c - m) / l rebuilt from the statistics.
 // The CLS key's dk | dv share goes to cls_part like in the tiny-group kernel.
 // ------------------------------------------------------------------------------------------------------
-#define GB_LD 72                 // bf16 per LDS row: 64 + 8 pad (144 B: 8-byte aligned fragments, 36-dword stride)
+#ifndef GB_ABL
+#define GB_ABL 0                 // measurement builds (tools/ab_pp.sh with SRC=sf_attention): 1 = no pass-1 tile loop, 2 = no pass-2 tile loop, 4 = no staging loads
+#endif
+#define GB_LD 80                 // bf16 per LDS row of the staged K | Q | dO: 160 B (64 + 16 pad), chunk bit 0 flipped in rows 8-15 of every tile (gb_off)
+#define GB_LDV 72                // bf16 per LDS row of the staged V (read as row fragments only) and of the per-wave output staging tiles: 144 B
 #define GB_ROWS 208
-#define GB_MAT (GB_ROWS * GB_LD * 2)                       // 29,952 B per staged matrix
+#define GB_MAT (GB_ROWS * GB_LD * 2)                       // 33,280 B per staged K / Q / dO
+#define GB_MATV (GB_ROWS * GB_LDV * 2)                     // 29,952 B for V
 #define GB_WAVES 16               // one wave per query tile (pass 1) / key tile (pass 2) of the 13; four waves per SIMD hide the dependent LDS round trips of the fragment reads
-#define GB_LDS(WAVES) (4 * GB_MAT + GB_ROWS * 3 * 4 + (WAVES) * 16 * GB_LD * 2 + 16)   // (+ 16: the CLS query's delta, sf_attention_group_bwd_clsq)
+#define GB_ST 4                  // floats per query in the LDS statistics: m (base-2 domain), 1/l, delta, pad (one ds_read_b128)
+#define GB_OUTW(WAVES) ((WAVES) < 13 ? (WAVES) : 13)      // waves that ever own a tile (208 rows = 13 tiles) and therefore an output staging tile
+#define GB_LDS(WAVES) (3 * GB_MAT + GB_MATV + GB_ROWS * GB_ST * 4 + GB_OUTW(WAVES) * 16 * GB_LDV * 2 + 16)   // 163,088 B of 163,840 (+ 16: the CLS query's delta)
 
-__device__ __forceinline__ bf16x4 gb_row_frag(const bf16_t* X, int row, int k0) { return *reinterpret_cast<const bf16x4*>(X + row * GB_LD + k0); }
+// Element offset of X[row][k] in a staged K / Q / dO.  The kernel reads these matrices two ways, and one row stride cannot serve both without bank conflicts:
+//   * row fragments (ds_read_b128; 16 lanes = 16 consecutive rows, the same 16-byte chunk): 36-dword rows (round 3) put the 16 rows on 16 different 4-bank groups;
+//   * ds_read_b64_tr_b16 column fragments (32 lanes = 8 consecutive rows x 32 B): 36-dword rows wrap row 7 onto row 0's banks - measured: 33 % of the kernel's
+//     LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r05_round.md).  40-dword rows put the eight 8-dword blocks on the
+//     eight 8-bank groups exactly, but rows r and r + 8 of a row-fragment read then share their banks.
+// 40-dword rows AND 16-byte chunk c stored at slot c ^ ((row >> 3) & 1): rows 8-15 of a tile move by four banks into the groups rows 0-7 leave free (row
+// fragments conflict-free), the column fragments of a 32-lane pass all carry the same flip (their 32-byte blocks only swap halves).  The flip touches chunk bit 0
+// only - k-step (chunk bits 2) and column tile (chunk bits 1-2) stay immediate offsets of one lane address.
+__device__ __forceinline__ int gb_off(int row, int k) { return row * GB_LD + ((((k >> 3) ^ ((row >> 3) & 1)) << 3) | (k & 7)); }
+__device__ __forceinline__ bf16x4 gb_row_frag(const bf16_t* X, int row, int k0) { return *reinterpret_cast<const bf16x4*>(X + gb_off(row, k0)); }
+__device__ __forceinline__ bf16x4 gb_row_frag_v(const bf16_t* V, int row, int k0) { return *reinterpret_cast<const bf16x4*>(V + row * GB_LDV + k0); }
 // Column fragment X[row0 + 0..3][col0 + lr] of a row-major LDS matrix (lane = 16*lg + lr; row0 is the same for the 16 lanes of a group)
 // with ONE ds_read_b64_tr_b16: the lane points at the 8 bytes X[row0 + (lr >> 2)][col0 + 4*(lr & 3) .. +3] and the hardware hands lane i
 // element (i & 3) of lanes (i >> 2) + 4 j (was: four 2-byte reads + packing per fragment).
 typedef short gb_s4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x4 gb_col_frag(const bf16_t* X, int row0, int col0, int lr) {
-  const bf16_t* src = X + (row0 + (lr >> 2)) * GB_LD + col0 + (lr & 3) * 4;
+  const bf16_t* src = X + gb_off(row0 + (lr >> 2), col0 + (lr & 3) * 4);
   const gb_s4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gb_s4*)src);
   return __builtin_bit_cast(bf16x4, r);
 }
@@ -428,17 +445,36 @@ __device__ __forceinline__ bf16x4 gb_pack(const f32x4& v) {
   return r.f;
 }
 
-template <int GBW>
+// X32 (the product): the same passes on v_mfma_f32_16x16x32_bf16 - half the matrix instructions.  Its A / B operands hold 8 consecutive k per lane (k = (l >> 4)*8 + e);
+// the contraction index of the second-stage products (keys for dQ, queries for dK / dV) is only summed over, so TWO probability tiles - key (query) tiles 2j and 2j + 1,
+// each in the C layout "rows (l >> 4)*4 + r" - are laid side by side as one operand: slots e < 4 = tile 2j, e >= 4 = tile 2j + 1, and the other operand is the two
+// ds_read_b64_tr_b16 column fragments of the same two tiles concatenated the same way.  The first-stage products (contraction over the 64 head dimensions) read 16-byte
+// row fragments.  A missing odd tile (13 = 6 pairs + 1) is a zero half.
+__device__ __forceinline__ bf16x8 gb_row_frag8(const bf16_t* X, int row, int k0) { return *reinterpret_cast<const bf16x8*>(X + gb_off(row, k0)); }
+__device__ __forceinline__ bf16x8 gb_row_frag8_v(const bf16_t* V, int row, int k0) { return *reinterpret_cast<const bf16x8*>(V + row * GB_LDV + k0); }
+__device__ __forceinline__ bf16x8 gb_cat(const bf16x4& lo, const bf16x4& hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+template <int GBW, bool X32>
 __global__ __launch_bounds__(GBW * 64) void attn_group_bwd_kernel(AttnBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* Kr = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* Vr = Kr + GB_ROWS * GB_LD;
-  bf16_t* Qr = Vr + GB_ROWS * GB_LD;
+  bf16_t* Vr = Kr + GB_ROWS * GB_LD;                          // (144-byte rows: GB_LDV)
+  bf16_t* Qr = Vr + GB_ROWS * GB_LDV;
   bf16_t* Dr = Qr + GB_ROWS * GB_LD;                          // dO
-  float* stats = reinterpret_cast<float*>(smem + 4 * GB_MAT);   // [208][3]: m (base-2 domain), 1/l, delta
-  bf16_t* outl = reinterpret_cast<bf16_t*>(smem + 4 * GB_MAT + GB_ROWS * 3 * 4);
+  float* stats = reinterpret_cast<float*>(smem + 3 * GB_MAT + GB_MATV);   // [208][GB_ST]: m (base-2 domain), 1/l, delta
+  bf16_t* outl = reinterpret_cast<bf16_t*>(smem + 3 * GB_MAT + GB_MATV + GB_ROWS * GB_ST * 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
+  // the lane's element offsets inside a 16-row tile (gb_off spelled out once, so that tile, k-step and column tile are immediate offsets of ONE address register each):
+  // its row-fragment chunk (row lr, chunk lg), the same in V's 144-byte rows, and its ds_read_b64_tr_b16 piece (row lg*4 + lr/4, 8 bytes at (lr & 3) * 4)
+  const int l_row = lr * GB_LD + ((lg ^ ((lr >> 3) & 1)) << 3), l_rowv = lr * GB_LDV + lg * 8;
+  const int l_tr = (lg * 4 + (lr >> 2)) * GB_LD + (((((lr & 3) >> 1) ^ ((lg >> 1) & 1))) << 3) + (lr & 1) * 4;
+  auto row8 = [&](const bf16_t* X, int tile, int ks) { return *reinterpret_cast<const bf16x8*>(X + tile * 16 * GB_LD + l_row + ks * 32); };
+  auto row8v = [&](int tile, int ks) { return *reinterpret_cast<const bf16x8*>(Vr + tile * 16 * GB_LDV + l_rowv + ks * 32); };
+  auto col4 = [&](const bf16_t* X, int tile, int dt) {
+    const gb_s4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gb_s4*)(X + tile * 16 * GB_LD + l_tr + dt * 16));
+    return __builtin_bit_cast(bf16x4, r);
+  };
   const int64_t unit = blockIdx.x;
   const int head = (int)(unit % p.heads);
   const int64_t sg = unit / p.heads;
@@ -456,7 +492,7 @@ __global__ __launch_bounds__(GBW * 64) void attn_group_bwd_kernel(AttnBwdArgs p)
   // sequence (this group holds 1/n_groups of them), its delta is <dO, o>; the CLS KEY (key 0 of every group) counts for it in group 0 only.
   const bool clsq = p.cls_stats != nullptr;
   const int nqe = nq + (clsq ? 1 : 0);
-  float* cls_d = reinterpret_cast<float*>(outl + GBW * 16 * GB_LD);   // one float behind the staging tiles
+  float* cls_d = reinterpret_cast<float*>(outl + GB_OUTW(GBW) * 16 * GB_LDV);   // one float behind the staging tiles
   if (clsq && wave == 0) {
     const int64_t r = seq_base + p.cls_row;
     float d = bf2f(p.dO[r * p.lddo + hcol + lane]) * bf2f(p.o[r * p.ldo + hcol + lane]);
@@ -468,79 +504,146 @@ __global__ __launch_bounds__(GBW * 64) void attn_group_bwd_kernel(AttnBwdArgs p)
   for (int idx = tid; idx < GB_ROWS * 8; idx += GBW * 64) {
     const int row = idx >> 3, ch = idx & 7;
     uint4 kk = make_uint4(0, 0, 0, 0), vv = kk, qq = kk, dd = kk;
-    if (row < nk) {
+    if (!(GB_ABL & 4) && row < nk) {
       const int64_t r = key_row(row);
       kk = *reinterpret_cast<const uint4*>(p.k + r * p.ld + hcol + ch * 8);
       vv = *reinterpret_cast<const uint4*>(p.v + r * p.ld + hcol + ch * 8);
     }
-    if (row < nq || (clsq && row == nq)) {                     // slot nq: the CLS query and its dO
+    if (!(GB_ABL & 4) && (row < nq || (clsq && row == nq))) {  // slot nq: the CLS query and its dO
       const int64_t r = row < nq ? tok_row(row) : seq_base + p.cls_row;
       qq = *reinterpret_cast<const uint4*>(p.q + r * p.ld + hcol + ch * 8);
       dd = *reinterpret_cast<const uint4*>(p.dO + r * p.lddo + hcol + ch * 8);
     }
-    // 144-byte rows are only 8-byte aligned at odd rows: store as two 8-byte halves
-    uint2* dk_ = reinterpret_cast<uint2*>(Kr + row * GB_LD + ch * 8); dk_[0] = make_uint2(kk.x, kk.y); dk_[1] = make_uint2(kk.z, kk.w);
-    uint2* dv_ = reinterpret_cast<uint2*>(Vr + row * GB_LD + ch * 8); dv_[0] = make_uint2(vv.x, vv.y); dv_[1] = make_uint2(vv.z, vv.w);
-    uint2* dq_ = reinterpret_cast<uint2*>(Qr + row * GB_LD + ch * 8); dq_[0] = make_uint2(qq.x, qq.y); dq_[1] = make_uint2(qq.z, qq.w);
-    uint2* dd_ = reinterpret_cast<uint2*>(Dr + row * GB_LD + ch * 8); dd_[0] = make_uint2(dd.x, dd.y); dd_[1] = make_uint2(dd.z, dd.w);
+    *reinterpret_cast<uint4*>(Kr + gb_off(row, ch * 8)) = kk;
+    *reinterpret_cast<uint4*>(Vr + row * GB_LDV + ch * 8) = vv;
+    *reinterpret_cast<uint4*>(Qr + gb_off(row, ch * 8)) = qq;
+    *reinterpret_cast<uint4*>(Dr + gb_off(row, ch * 8)) = dd;
   }
   __syncthreads();
   const float sc2 = p.scale * 1.44269504088896f;
-  bf16_t* myout = outl + wave * 16 * GB_LD;
+  bf16_t* myout = outl + wave * 16 * GB_LDV;
 
   // ---- pass 1: per query tile - statistics and dQ.  Tiles are S^T: lane's query = qt*16 + lr, its keys = kt*16 + lg*4 + r ---------
   for (int qt = wave; qt < nqt; qt += GBW) {
     // Online softmax over the key tiles (running maximum, accumulators rescaled when it moves): no score or dP tile outlives its key tile, and
     // dQ = scale / l * (sum_k e dP K - delta sum_k e K) is accumulated as those two sums (e = un-normalised probability) - 4 more MFMAs per key tile than
     // forming dS first, but ~90 registers instead of 167, which is what lets 16 waves (every query / key tile its own wave) share the CU.
-    bf16x4 qf[4], df[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) { qf[ks] = gb_row_frag(Qr, qt * 16 + lr, ks * 16 + lg * 4); df[ks] = gb_row_frag(Dr, qt * 16 + lr, ks * 16 + lg * 4); }
     float m = -INFINITY, l = 0.f, delta = 0.f;                    // m is kept equal in the four lanes (lg) of a query column; l, delta are per-lane partials
     f32x4 dq1[4], dq2[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dq1[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dq2[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    for (int kt = 0; kt < nkt; ++kt) {
-      f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (!X32) {
+      bf16x4 qf[4], df[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        sc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb_row_frag(Kr, kt * 16 + lr, ks * 16 + lg * 4), qf[ks], sc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb_row_frag(Vr, kt * 16 + lr, ks * 16 + lg * 4), df[ks], dp, 0, 0, 0);
-      }
-      float tmax = -INFINITY;
+      for (int ks = 0; ks < 4; ++ks) { qf[ks] = gb_row_frag(Qr, qt * 16 + lr, ks * 16 + lg * 4); df[ks] = gb_row_frag(Dr, qt * 16 + lr, ks * 16 + lg * 4); }
+      for (int kt = 0; kt < nkt; ++kt) {
+        f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (kt * 16 + lg * 4 + r >= nk) sc[r] = -INFINITY;
-        tmax = fmaxf(tmax, sc[r]);
-      }
-      if (clsq && g != 0 && kt == 0 && lg == 0 && qt * 16 + lr == nq) { sc[0] = -INFINITY; tmax = fmaxf(fmaxf(sc[1], sc[2]), sc[3]); }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64)); tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float m_new = fmaxf(m, tmax);                          // finite: key 0 of tile 0 always exists
-      if (__any(m_new != m)) {                                     // the running maximum of some query moved: rescale what has been summed under the old one
-        const float alpha = __builtin_amdgcn_exp2f((m - m_new) * sc2);   // first tile: exp2(-inf) = 0
-        l *= alpha; delta *= alpha;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {                              // the accumulators hold query ROWS lg*4 + r: their factor sits in the lanes of that query column
-          const float ar = __shfl(alpha, lg * 4 + r, 64);
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) { dq1[dt][r] *= ar; dq2[dt][r] *= ar; }
+        for (int ks = 0; ks < 4; ++ks) {
+          sc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb_row_frag(Kr, kt * 16 + lr, ks * 16 + lg * 4), qf[ks], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb_row_frag_v(Vr, kt * 16 + lr, ks * 16 + lg * 4), df[ks], dp, 0, 0, 0);
         }
-        m = m_new;
-      }
-      const float msc_ = m * sc2;
-      f32x4 e, edp;
+        float tmax = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        e[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], sc2, -msc_));     // -inf -> 0
-        edp[r] = e[r] * dp[r];
-        l += e[r]; delta += edp[r];
-      }
-      const bf16x4 ef = gb_pack(e), edpf = gb_pack(edp);
+        for (int r = 0; r < 4; ++r) {
+          if (kt * 16 + lg * 4 + r >= nk) sc[r] = -INFINITY;
+          tmax = fmaxf(tmax, sc[r]);
+        }
+        if (clsq && g != 0 && kt == 0 && lg == 0 && qt * 16 + lr == nq) { sc[0] = -INFINITY; tmax = fmaxf(fmaxf(sc[1], sc[2]), sc[3]); }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64)); tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);                          // finite: key 0 of tile 0 always exists
+        if (__any(m_new != m)) {                                     // the running maximum of some query moved: rescale what has been summed under the old one
+          const float alpha = __builtin_amdgcn_exp2f((m - m_new) * sc2);   // first tile: exp2(-inf) = 0
+          l *= alpha; delta *= alpha;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const bf16x4 kc = gb_col_frag(Kr, kt * 16 + lg * 4, dt * 16, lr);
-        dq1[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(edpf, kc, dq1[dt], 0, 0, 0);
-        dq2[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ef, kc, dq2[dt], 0, 0, 0);
+          for (int r = 0; r < 4; ++r) {                              // the accumulators hold query ROWS lg*4 + r: their factor sits in the lanes of that query column
+            const float ar = __shfl(alpha, lg * 4 + r, 64);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { dq1[dt][r] *= ar; dq2[dt][r] *= ar; }
+          }
+          m = m_new;
+        }
+        const float msc_ = m * sc2;
+        f32x4 e, edp;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          e[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], sc2, -msc_));     // -inf -> 0
+          edp[r] = e[r] * dp[r];
+          l += e[r]; delta += edp[r];
+        }
+        const bf16x4 ef = gb_pack(e), edpf = gb_pack(edp);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16x4 kc = col4(Kr, kt, dt);
+          dq1[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(edpf, kc, dq1[dt], 0, 0, 0);
+          dq2[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ef, kc, dq2[dt], 0, 0, 0);
+        }
+      }
+    } else {
+      bf16x8 qf[2], df[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) { qf[ks] = row8(Qr, qt, ks); df[ks] = row8(Dr, qt, ks); }
+      const bf16x4 zero4 = {0, 0, 0, 0};
+      for (int kt = 0; kt < ((GB_ABL & 1) ? 0 : nkt); kt += 2) {
+        const bool two = kt + 1 < nkt;                             // wave-uniform
+        f32x4 sc[2], dp[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { sc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          sc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row8(Kr, kt, ks), qf[ks], sc[0], 0, 0, 0);
+          dp[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row8v(kt, ks), df[ks], dp[0], 0, 0, 0);
+        }
+        if (two) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            sc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row8(Kr, kt + 1, ks), qf[ks], sc[1], 0, 0, 0);
+            dp[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row8v(kt + 1, ks), df[ks], dp[1], 0, 0, 0);
+          }
+        }
+        float tmax = -INFINITY;
+        if ((kt + 2) * 16 > nk || (clsq && g != 0 && kt == 0)) {      // wave-uniform: only the last key pair and the CLS key's tile hold anything to mask
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if ((h == 1 && !two) || (kt + h) * 16 + lg * 4 + r >= nk) sc[h][r] = -INFINITY;
+          if (clsq && g != 0 && kt == 0 && lg == 0 && qt * 16 + lr == nq) sc[0][0] = -INFINITY;   // the CLS key counts for the CLS query in group 0 only
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, sc[h][r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64)); tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);                        // finite: key 0 of tile 0 always exists (for the CLS query of a group > 0: key 1)
+        if (__any(m_new != m)) {
+          const float alpha = __builtin_amdgcn_exp2f((m - m_new) * sc2);
+          l *= alpha; delta *= alpha;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float ar = __shfl(alpha, lg * 4 + r, 64);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { dq1[dt][r] *= ar; dq2[dt][r] *= ar; }
+          }
+          m = m_new;
+        }
+        const float msc_ = m * sc2;
+        f32x4 e[2], edp[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            e[h][r] = __builtin_amdgcn_exp2f(fmaf(sc[h][r], sc2, -msc_));
+            edp[h][r] = e[h][r] * dp[h][r];
+            l += e[h][r]; delta += edp[h][r];
+          }
+        const bf16x8 ef = gb_cat(gb_pack(e[0]), gb_pack(e[1])), edpf = gb_cat(gb_pack(edp[0]), gb_pack(edp[1]));
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16x8 kc = gb_cat(col4(Kr, kt, dt), two ? col4(Kr, kt + 1, dt) : zero4);
+          dq1[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(edpf, kc, dq1[dt], 0, 0, 0);
+          dq2[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, kc, dq2[dt], 0, 0, 0);
+        }
       }
     }
     const float msc = m * sc2;
@@ -555,7 +658,8 @@ __global__ __launch_bounds__(GBW * 64) void attn_group_bwd_kernel(AttnBwdArgs p)
       linv = __builtin_amdgcn_exp2f(msc - st_m) * st_linv;
       delta = *cls_d;
     }
-    if (lg == 0) { float* st = stats + (qt * 16 + lr) * 3; st[0] = st_m; st[1] = st_linv; st[2] = delta; }
+    if (X32 && qt * 16 + lr >= nqe) { st_m = INFINITY; st_linv = 0.f; }   // an empty query slot: p = exp2(s - inf) * 0 = 0 in pass 2 without a per-element test (delta is 0: its dO row is)
+    if (lg == 0) *reinterpret_cast<float4*>(stats + (qt * 16 + lr) * GB_ST) = make_float4(st_m, st_linv, (X32 && qt * 16 + lr >= nqe) ? 0.f : delta, 0.f);
     // l and delta belong to the lane's query COLUMN (qt*16 + lr); the dQ accumulators hold query ROWS lg*4 + r: fetch the row's values from its column lane
     f32x4 dq[4];
 #pragma unroll
@@ -568,13 +672,13 @@ __global__ __launch_bounds__(GBW * 64) void attn_group_bwd_kernel(AttnBwdArgs p)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) myout[(lg * 4 + r) * GB_LD + dt * 16 + lr] = f2bf(dq[dt][r]);
+      for (int r = 0; r < 4; ++r) myout[(lg * 4 + r) * GB_LDV + dt * 16 + lr] = f2bf(dq[dt][r]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = lane + i * 64, row = idx >> 3, ch = idx & 7, qi = qt * 16 + row;
       if (qi < nqe) {
-        const uint2* sp = reinterpret_cast<const uint2*>(myout + row * GB_LD + ch * 8);
+        const uint2* sp = reinterpret_cast<const uint2*>(myout + row * GB_LDV + ch * 8);
         const uint2 a = sp[0], b = sp[1];
         bf16_t* dst = qi < nq ? p.dq + tok_row(qi) * p.ldg + hcol + ch * 8
                               : p.dq_cls_part + (seq * p.n_groups + g) * (int64_t)(p.heads * 64) + hcol + ch * 8;   // this group's share of the CLS query's dq
@@ -590,33 +694,81 @@ __global__ __launch_bounds__(GBW * 64) void attn_group_bwd_kernel(AttnBwdArgs p)
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    bf16x4 kf[4], vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) { kf[ks] = gb_row_frag(Kr, kt * 16 + lr, ks * 16 + lg * 4); vf[ks] = gb_row_frag(Vr, kt * 16 + lr, ks * 16 + lg * 4); }
     const bool key_ok = kt * 16 + lr < nk;
-    for (int qt = 0; qt < nqt; ++qt) {
-      f32x4 s2 = f32x4{0.f, 0.f, 0.f, 0.f}, dp2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (!X32) {
+      bf16x4 kf[4], vf[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        s2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb_row_frag(Qr, qt * 16 + lr, ks * 16 + lg * 4), kf[ks], s2, 0, 0, 0);
-        dp2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb_row_frag(Dr, qt * 16 + lr, ks * 16 + lg * 4), vf[ks], dp2, 0, 0, 0);
-      }
-      f32x4 pp, ds;
+      for (int ks = 0; ks < 4; ++ks) { kf[ks] = gb_row_frag(Kr, kt * 16 + lr, ks * 16 + lg * 4); vf[ks] = gb_row_frag_v(Vr, kt * 16 + lr, ks * 16 + lg * 4); }
+      for (int qt = 0; qt < nqt; ++qt) {
+        f32x4 s2 = f32x4{0.f, 0.f, 0.f, 0.f}, dp2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qi = qt * 16 + lg * 4 + r;
-        const float* st = stats + qi * 3;
-        const bool live = key_ok && qi < nqe && !(clsq && g != 0 && qi == nq && kt * 16 + lr == 0);
-        const float pr = live ? __builtin_amdgcn_exp2f(fmaf(s2[r], sc2, -st[0])) * st[1] : 0.f;
-        pp[r] = pr;
-        ds[r] = pr * (dp2[r] - st[2]) * p.scale;
-      }
-      const bf16x4 pf = gb_pack(pp), dsf = gb_pack(ds);
+        for (int ks = 0; ks < 4; ++ks) {
+          s2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb_row_frag(Qr, qt * 16 + lr, ks * 16 + lg * 4), kf[ks], s2, 0, 0, 0);
+          dp2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb_row_frag(Dr, qt * 16 + lr, ks * 16 + lg * 4), vf[ks], dp2, 0, 0, 0);
+        }
+        f32x4 pp, ds;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pf, gb_col_frag(Dr, qt * 16 + lg * 4, dt * 16, lr), dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsf, gb_col_frag(Qr, qt * 16 + lg * 4, dt * 16, lr), dk[dt], 0, 0, 0);
+        for (int r = 0; r < 4; ++r) {
+          const int qi = qt * 16 + lg * 4 + r;
+          const float* st = stats + qi * GB_ST;
+          const bool live = key_ok && qi < nqe && !(clsq && g != 0 && qi == nq && kt * 16 + lr == 0);
+          const float pr = live ? __builtin_amdgcn_exp2f(fmaf(s2[r], sc2, -st[0])) * st[1] : 0.f;
+          pp[r] = pr;
+          ds[r] = pr * (dp2[r] - st[2]) * p.scale;
+        }
+        const bf16x4 pf = gb_pack(pp), dsf = gb_pack(ds);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pf, col4(Dr, qt, dt), dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsf, col4(Qr, qt, dt), dk[dt], 0, 0, 0);
+        }
       }
+    } else {
+      bf16x8 kf[2], vf[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) { kf[ks] = row8(Kr, kt, ks); vf[ks] = row8v(kt, ks); }
+      const bf16x4 zero4 = {0, 0, 0, 0};
+      const bool fix_keys = kt * 16 + 16 > nk || (clsq && g != 0 && kt == 0);       // wave-uniform
+      for (int qt = 0; qt < ((GB_ABL & 2) ? 0 : nqt); qt += 2) {
+        const bool two = qt + 1 < nqt;                             // wave-uniform
+        // p = exp2(s c - m) / l and ds = p (dp - delta) (the softmax scale is applied to dK once, below), one query tile after the other (a tile's scores are packed to
+        // bf16 before the next tile's are formed: 8 accumulator registers live instead of 16).  Empty query slots carry (m = inf, 1/l = 0) and give p = 0 by themselves;
+        // only the last key tile (keys beyond nk) and the CLS key's tile (CLS query x CLS key outside group 0) need a per-element test
+        bf16x4 pk[2], dsk[2];
+        pk[1] = zero4; dsk[1] = zero4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (h == 1 && !two) break;
+          const int qh = qt + h;
+          f32x4 s2 = f32x4{0.f, 0.f, 0.f, 0.f}, dp2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            s2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row8(Qr, qh, ks), kf[ks], s2, 0, 0, 0);
+            dp2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row8(Dr, qh, ks), vf[ks], dp2, 0, 0, 0);
+          }
+          f32x4 pp, ds;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qi = qh * 16 + lg * 4 + r;
+            const float4 st = *reinterpret_cast<const float4*>(stats + qi * GB_ST);
+            float pr = __builtin_amdgcn_exp2f(fmaf(s2[r], sc2, -st.x)) * st.y;
+            if (fix_keys && (!key_ok || (clsq && g != 0 && qi == nq && kt * 16 + lr == 0))) pr = 0.f;
+            pp[r] = pr;
+            ds[r] = pr * (dp2[r] - st.z);
+          }
+          pk[h] = gb_pack(pp); dsk[h] = gb_pack(ds);
+        }
+        const bf16x8 pf = gb_cat(pk[0], pk[1]), dsf = gb_cat(dsk[0], dsk[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16x8 dcol = gb_cat(col4(Dr, qt, dt), two ? col4(Dr, qt + 1, dt) : zero4);
+          const bf16x8 qcol = gb_cat(col4(Qr, qt, dt), two ? col4(Qr, qt + 1, dt) : zero4);
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, dcol, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, qcol, dk[dt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dk[dt] *= p.scale;
     }
     // dk[dt][r] = dK[key kt*16 + lg*4 + r][d = dt*16 + lr]: two staging rounds (dk, then dv)
 #pragma unroll
@@ -624,13 +776,13 @@ __global__ __launch_bounds__(GBW * 64) void attn_group_bwd_kernel(AttnBwdArgs p)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) myout[(lg * 4 + r) * GB_LD + dt * 16 + lr] = f2bf(which == 0 ? dk[dt][r] : dv[dt][r]);
+        for (int r = 0; r < 4; ++r) myout[(lg * 4 + r) * GB_LDV + dt * 16 + lr] = f2bf(which == 0 ? dk[dt][r] : dv[dt][r]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int idx = lane + i * 64, row = idx >> 3, ch = idx & 7, kj = kt * 16 + row;
         if (kj < nk) {
-          const uint2* sp = reinterpret_cast<const uint2*>(myout + row * GB_LD + ch * 8);
+          const uint2* sp = reinterpret_cast<const uint2*>(myout + row * GB_LDV + ch * 8);
           const uint2 a = sp[0], b = sp[1];
           bf16_t* dst;
           if (has_cls && kj == 0) dst = p.cls_part + (seq * p.n_groups + g) * (int64_t)(2 * p.heads * 64) + which * p.heads * 64 + hcol + ch * 8;
@@ -688,12 +840,17 @@ static int attention_group_bwd_impl(const bf16_t* q, const bf16_t* k, const bf16
   SF_CHECK_ARG(units < ((int64_t)1 << 31), "sf_attention_group_bwd: too many groups");
   static int waves = -1;
   if (waves < 0) { const char* e = getenv("SF_GB_WAVES"); waves = e ? atoi(e) : GB_WAVES; }      // measurement hook: 8 = round 2's workgroup (two tiles per wave)
+  static int x32 = -1;
+  if (x32 < 0) { const char* e = getenv("SF_GB_X32"); x32 = e ? atoi(e) : 1; }                     // measurement hook: 0 = round 3's v_mfma_f32_16x16x16_bf16 passes
   if (waves == 8) {
-    if (int rc = sf_prepare_kernel((const void*)attn_group_bwd_kernel<8>, GB_LDS(8), "sf_attention_group_bwd")) return rc;
-    hipLaunchKernelGGL(attn_group_bwd_kernel<8>, dim3((unsigned)units), dim3(8 * 64), GB_LDS(8), (hipStream_t)stream, a);
+    if (int rc = sf_prepare_kernel((const void*)attn_group_bwd_kernel<8, false>, GB_LDS(8), "sf_attention_group_bwd")) return rc;
+    hipLaunchKernelGGL((attn_group_bwd_kernel<8, false>), dim3((unsigned)units), dim3(8 * 64), GB_LDS(8), (hipStream_t)stream, a);
+  } else if (!x32) {
+    if (int rc = sf_prepare_kernel((const void*)attn_group_bwd_kernel<GB_WAVES, false>, GB_LDS(GB_WAVES), "sf_attention_group_bwd")) return rc;
+    hipLaunchKernelGGL((attn_group_bwd_kernel<GB_WAVES, false>), dim3((unsigned)units), dim3(GB_WAVES * 64), GB_LDS(GB_WAVES), (hipStream_t)stream, a);
   } else {
-    if (int rc = sf_prepare_kernel((const void*)attn_group_bwd_kernel<GB_WAVES>, GB_LDS(GB_WAVES), "sf_attention_group_bwd")) return rc;
-    hipLaunchKernelGGL(attn_group_bwd_kernel<GB_WAVES>, dim3((unsigned)units), dim3(GB_WAVES * 64), GB_LDS(GB_WAVES), (hipStream_t)stream, a);
+    if (int rc = sf_prepare_kernel((const void*)attn_group_bwd_kernel<GB_WAVES, true>, GB_LDS(GB_WAVES), "sf_attention_group_bwd")) return rc;
+    hipLaunchKernelGGL((attn_group_bwd_kernel<GB_WAVES, true>), dim3((unsigned)units), dim3(GB_WAVES * 64), GB_LDS(GB_WAVES), (hipStream_t)stream, a);
   }
   SF_LAUNCH_CHECK();
   return 0;

@@ -6,6 +6,8 @@ Also registered as `torch.ops.synchformer.*` custom ops (see `register_torch_ops
 to the dispatcher, as the reference's callers would expect of a PyTorch-ROCm extension.
 """
 import ctypes as C
+import os
+from pathlib import Path
 from typing import Optional, Sequence
 
 import torch
@@ -572,6 +574,8 @@ def register_torch_ops():
     if _registered:
         return
     path = _lib.lib_path().parent / 'libsynchformer_torch.so'
+    if not path.exists() and os.environ.get('SYNCHFORMER_HIP_LIB'):        # a measurement build given by path (tools/ab_*.sh): the dispatcher library of the package
+        path = Path(__file__).resolve().parent / 'lib' / 'libsynchformer_torch.so'
     if not path.exists():
         raise RuntimeError(f'{path} not found: the dispatcher library is not built (python -c "import __graft_entry__ as g; g.build()")')
     _lib.load()                                                             # libsynchformer_hip.so first: the dispatcher library links against it
