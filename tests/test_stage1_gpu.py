@@ -287,6 +287,25 @@ def test_avclip_train_steps_reduce_loss(gpu):
     assert 'logit_scale' in ck and any(k.startswith('v_encoder.blocks.0.') for k in ck) and len(ck) == 451 - 2
 
 
+def test_temperature_read_without_draining_the_queue(gpu):
+    """forward_backward queues the device -> pinned-host copy of logit_scale BEFORE the forward and `_head` waits for that copy's event only (the launcher used to
+    block on the forward, profiles/r05_round.md section 6).  The value it sees must be the parameter as it stands at the start of THIS step - after the previous
+    optimizer step, after an edit between steps, and clamped (open_clip/model.py:569-572) - i.e. the loss equals the one `_head` computes with a blocking read."""
+    sd, tr, u8, aud = _setup(gpu, 2, 2, 2.0)
+    vis, aud = u8.to(gpu), aud.to(gpu)
+    for scale in (0.07, 0.2, 5.0):                                  # 5.0 is clamped to 0.5
+        tr.p['logit_scale'].fill_(scale)
+        loss = float(tr.forward_backward(vis, aud))
+        assert not tr._ls_pending and abs(float(tr._ls_host) - min(scale, 0.5)) < 1e-7
+        g_async = tr.g['logit_scale'].clone()
+        tr._head(tr.vfeat, tr.afeat)                                # the stand-alone path: float(p['logit_scale']) now
+        assert float(tr.losses.mean()) == loss and torch.equal(tr.g['logit_scale'], g_async), scale
+    l0 = float(tr.train_step(vis, aud, lr=1e-2))                    # a large step moves the parameter: the next step must see the moved value
+    s1 = float(tr.p['logit_scale'])
+    tr.forward_backward(vis, aud)
+    assert abs(float(tr._ls_host) - min(max(s1, 0.001), 0.5)) < 1e-7 and np.isfinite(l0)
+
+
 def test_avclip_train_steps_are_deterministic(gpu):
     """Two trainers from the same weights, seed and inputs take bit-identical steps (no atomics in the gradient path: split-K chunk planes are summed in a fixed
     order, the counted-wait schedules of sf_gemm_tn_pp / sf_gemm_bf16 have no run-to-run freedom): loss and a sample of the updated weights after 3 steps, at
