@@ -85,6 +85,7 @@ class AVCLIPTrainer(FlatTrainer):
         self._side = None
         self._ls_host = self._ls_ev = None  # pinned host mirror of logit_scale + the event behind its copy (forward_backward / _head)
         self._ls_pending = False
+        self._dp_ones = None                # the all-ones vector sf_dropout turns into DropPath scales (_dp_scales)
         self._pre_ln = set()                # workspace buffers whose LayerNorm output _add_branch has already produced (consumed by _ln_into)
         self.n_vblocks = len([k for k in keys if k.startswith(V + '.blocks.') and k.endswith('.norm1.weight')])
         self.n_alayers = len([k for k in keys if k.endswith('.layernorm_before.weight')])
@@ -132,8 +133,10 @@ class AVCLIPTrainer(FlatTrainer):
             return None
         h = (self.seed * 0x9E3779B1 + self.fwd_count * 0x85EBCA6B + (2 * block + site) * 0xC2B2AE35 + 0x27D4EB2F) & 0xFFFFFFFF
         h ^= h >> 15
-        ones = self._buf('dp_ones', (1, ((n + 3) // 4) * 4), torch.float32)
-        ones.fill_(1.0)
+        w = ((n + 3) // 4) * 4
+        if self._dp_ones is None or self._dp_ones.shape[1] != w:              # a constant: written once, not once per site and step (22 fill launches)
+            self._dp_ones = torch.ones(1, w, device=self.dev, dtype=torch.float32)
+        ones = self._dp_ones
         sc = self._buf(f'dp_scale_{block}_{site}', (1, ((n + 3) // 4) * 4), torch.float32)
         from .train import dropout
         dropout(ones, sc, 1, ones.shape[1], p_, (h * 0x2C1B3C6D) & 0xFFFFFFFF)
