@@ -412,7 +412,7 @@ def build_workload(name, args, dev, rank, world, local):
         # Stage-1 AVCLIP train step (configs/segment_avclip.yaml: base_batch_size 2 clips x 14 segments per GPU, both towers trainable)
         from synchformer_amd.stage1 import AVCLIPTrainer
         sd = {k: v for k, v in synth.make_state_dict(1337).items() if k.startswith(('vfeat_extractor.', 'afeat_extractor.'))}
-        trainer = AVCLIPTrainer(sd, dev, lr=scaled_lr(1e-4, world), drop_path_rate=0.2, seed=1337 + rank)     # train mode: DropPath 0.2 like the reference's towers
+        trainer = AVCLIPTrainer(sd, dev, lr=1e-4, drop_path_rate=0.2, seed=1337 + rank)     # train mode: DropPath 0.2 like the reference's towers; Stage 1 does NOT scale its learning rate by the world size (train_clip.py:276,314 pass cfg.training.learning_rate as is; only the warm-up is divided)
         step_fn = lambda v, a: trainer.train_step(v, a).reshape(1)
     else:
         # headline: the step starts from what the north star names - 224 x 224 uint8 frames and 16 kHz WAVEFORM segments (B, 14, 10240), both resident in HBM; the

@@ -97,7 +97,8 @@ def reduce_scatter_pair(da_all: torch.Tensor, db_all: torch.Tensor, n: int) -> T
 
 
 def scaled_lr(base_lr: float, world: int) -> float:
-    """The reference scales the base learning rate by the number of GPUs (scripts/train_utils.py:218 `base_learning_rate * num_gpus`)."""
+    """STAGE 2 ONLY: the reference scales the base learning rate by the number of GPUs (scripts/train_utils.py:218 `base_learning_rate * num_gpus`).  Stage 1 hands
+    cfg.training.learning_rate to its optimizer and scheduler unscaled (train_clip_src/training/train_clip.py:276,314) and only divides the warm-up (`scaled_warmup`)."""
     return base_lr * max(int(world), 1)
 
 

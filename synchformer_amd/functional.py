@@ -13,7 +13,8 @@ a CPU tensor raises in the launcher.  Shapes the backward serves: weight (N, K) 
 FORWARD records its autograd node (setup_context), not first at backward time.
 Output dtype contract: `linear` ALWAYS returns bf16 (the kernels' operand / output type), also for fp32 inputs outside autocast - unlike nn.Linear, which would return
 fp32 there; cast the result if fp32 is needed.  Gradients come back in the dtype of the input they belong to, and only the ones autograd asks for are computed
-(`ctx.needs_input_grad`); the bf16 W^T operand of the data gradient is cached per weight version."""
+(`ctx.needs_input_grad`); the bf16 W^T operand of the data gradient is cached per (leaf weight object, version) - never for autocast's temporaries."""
+import weakref
 from typing import Optional
 
 import torch
@@ -50,17 +51,22 @@ def register():
         torch._check(x.shape[-1] == weight.shape[1], lambda: 'synchformer::linear: x (..., K) against weight (N, K)')
         return x.new_empty((*x.shape[:-1], weight.shape[0]), dtype=torch.bfloat16)
 
-    _wt_cache = {}                                                # (data_ptr, version, shape) -> bf16 W^T: one transpose per optimizer step, not one per backward
+    _wt_cache = weakref.WeakKeyDictionary()                       # weight OBJECT -> (version, bf16 W^T): one transpose per optimizer step, not one per backward
 
     def _wT(weight, w, N, K, dev):
-        key = (weight.data_ptr(), weight._version, N, K)
-        wT = _wt_cache.get(key)
-        if wT is None:
-            if len(_wt_cache) >= 16:
-                _wt_cache.clear()
-            wT = torch.empty(K, N, device=dev, dtype=torch.bfloat16)
-            transpose(w, K, 0, 0, wT, N, 0, 0, N, K, N)
-            _wt_cache[key] = wT
+        """bf16 W^T for dX = dY W.  Cached only for a leaf weight (an nn.Parameter / a frozen tensor the caller keeps alive), keyed on the tensor OBJECT - a
+        dead weight drops its entry, so a recycled device address can never serve another tensor's transpose - and on its version counter (in-place optimizer
+        updates bump it; writes through `.data` do not - do not update weights that way).  Under autocast `weight` is the per-forward bf16 temporary of the cast
+        (not a leaf, version 0, address reused by the allocator step after step): never cached, transposed per backward."""
+        cacheable = weight.is_leaf and weight.grad_fn is None
+        if cacheable:
+            hit = _wt_cache.get(weight)
+            if hit is not None and hit[0] == weight._version and hit[1].shape == (K, N):
+                return hit[1]
+        wT = torch.empty(K, N, device=dev, dtype=torch.bfloat16)
+        transpose(w, K, 0, 0, wT, N, 0, 0, N, K, N)
+        if cacheable:
+            _wt_cache[weight] = (weight._version, wT)
         return wT
 
     def _bwd_shapes_ok(M, N, K):

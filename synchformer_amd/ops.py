@@ -7,6 +7,7 @@ to the dispatcher, as the reference's callers would expect of a PyTorch-ROCm ext
 """
 import ctypes as C
 import os
+import threading
 from pathlib import Path
 from typing import Optional, Sequence
 
@@ -619,6 +620,7 @@ class via_dispatcher:
              'qkv_space_attention', 'qkv_space_attention_mx', 'space_side_rows', 'space_side_rows_mx', 'qkv_time_attention2_mx')
 
     _depth = 0                                                    # re-entrant: an inner `with` inside an active one changes nothing
+    _lock = threading.RLock()                                     # the depth counter and the module-globals swap are one critical section
     calls_total = 0                                               # launches that went through torch.ops.synchformer.* since import (all instances)
 
     def __init__(self):
@@ -626,12 +628,17 @@ class via_dispatcher:
         self._nested = False
 
     def __enter__(self):
-        if via_dispatcher._depth > 0:
-            via_dispatcher._depth += 1
-            self._nested = True
+        with via_dispatcher._lock:
+            if via_dispatcher._depth > 0:
+                via_dispatcher._depth += 1
+                self._nested = True
+                return self
+            register_torch_ops()                                  # raises if libsynchformer_torch.so is missing: the route is then NOT marked active (every later
+            self._swap_in()                                       # `with` raises again instead of silently taking the direct path)
+            via_dispatcher._depth = 1
             return self
-        via_dispatcher._depth = 1
-        register_torch_ops()
+
+    def _swap_in(self):
         g = globals()
         o = self.orig = {n: g[n] for n in self.NAMES}
         t = torch.ops.synchformer
@@ -754,11 +761,11 @@ class via_dispatcher:
         g.update(gemm=gemm_, layernorm=layernorm_, gemm_res_ln=gemm_res_ln_, qkv_time_attention=qkv_time_, attention_cls_partial=attn_part_,
                  attention_cls_combine=attn_comb_, quantize_mxfp8=quant_, layernorm_mxfp8=ln_mx_, gemm_mxfp8=gemm_mx_, gemm_mx_res_ln=gemm_mx_ln_,
                  qkv_time_attention_mx=qkv_time_mx_)
-        return self
 
     def __exit__(self, *exc):
-        via_dispatcher._depth -= 1
-        if self._nested:
-            self._nested = False
-            return
-        globals().update(self.orig)
+        with via_dispatcher._lock:
+            via_dispatcher._depth -= 1
+            if self._nested:
+                self._nested = False
+                return
+            globals().update(self.orig)

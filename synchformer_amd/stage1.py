@@ -645,7 +645,8 @@ class AVCLIPTrainer(FlatTrainer):
         self._ls_ev.record()
         self._ls_pending = True
         # (round 5: no flat_g.zero_() - an 857 MB fill per step: every one of the 449 gradients is written with '=' by the backward before anything reads it, proven by
-        #  poisoning the buffer with NaN - tools/s1_grad_coverage.py: 0 of 449 still NaN; the alignment gaps between parameters keep the zeros they were allocated with)
+        #  poisoning the buffer with NaN - tests/test_stage1_gpu.py::test_backward_overwrites_every_gradient: 0 of 449 still NaN in both stream modes, with and without
+        #  stochastic depth; `_init_flat` packs the parameters back to back, there are no gaps that could keep stale values)
         if os.environ.get('SF_S1_POISON') == '1':
             self.flat_g.fill_(float('nan'))
         self.fwd_count += 1                                                    # a fresh set of stochastic-depth masks per forward pass

@@ -430,3 +430,26 @@ def test_segment_ranges_match_reference_transform():
         assert [r['v_start'] + i * r['v_stride'] for i in range(n_out)] == [int(x) for x in vs[:n_out]], (c[:11], r)
         n_ok += 1
     assert n_ok >= 10
+
+
+def test_via_dispatcher_failed_entry_leaves_the_route_inactive(monkeypatch):
+    """`via_dispatcher.__enter__` used to mark the route active BEFORE loading the dispatcher library; a failed load (library not built) then left the depth
+    counter at 1 for ever, every later `with` was treated as nested and silently took the direct ctypes path.  A failed entry must leave no trace and fail again."""
+    from synchformer_amd import ops
+    assert ops.via_dispatcher._depth == 0
+    orig_gemm = ops.gemm
+
+    def boom():
+        raise RuntimeError('libsynchformer_torch.so not found')
+    monkeypatch.setattr(ops, 'register_torch_ops', boom)
+    for _ in range(2):
+        with pytest.raises(RuntimeError, match='not found'):
+            with ops.via_dispatcher():
+                pass
+        assert ops.via_dispatcher._depth == 0 and ops.gemm is orig_gemm
+    monkeypatch.undo()
+    with ops.via_dispatcher() as d:                                               # and a good entry afterwards swaps the launchers in and out again
+        assert ops.via_dispatcher._depth == 1 and ops.gemm is not orig_gemm
+        with ops.via_dispatcher():
+            assert ops.via_dispatcher._depth == 2
+    assert ops.via_dispatcher._depth == 0 and ops.gemm is orig_gemm and d.calls == 0

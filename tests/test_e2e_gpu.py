@@ -168,6 +168,45 @@ def test_forward_through_the_dispatcher(gpu):
             assert d2.calls > 100 and not torch.equal(dm, direct)
 
 
+def test_dispatcher_operators_check_their_buffers(gpu):
+    """the C ABI sees raw pointers, so the public `torch.ops.synchformer.*` operators must refuse what would become a silent out-of-bounds device access or a
+    reinterpreted buffer - wrong dtype, too few rows, partials too small, out aliasing x - exactly as the ctypes wrappers of ops.py do; and they launch on the tensor's device."""
+    from synchformer_amd import ops
+    ops.register_torch_ops()
+    T = torch.ops.synchformer
+    n = 2
+    rows = n * 1569
+    x = torch.zeros(rows, 768, device=gpu, dtype=torch.bfloat16)
+    w = torch.zeros(2304, 768, device=gpu, dtype=torch.bfloat16)
+    b = torch.zeros(2304, device=gpu)
+    side = torch.zeros(n * 33, 2304, device=gpu, dtype=torch.bfloat16)
+    out = torch.empty_like(x)
+    p_t, p_s = torch.empty(n * 12 * 33 * 66, device=gpu), torch.empty(n * 12 * 8 * 66, device=gpu)
+    T.qkv_time_attention2(x, w, b, side, out, p_t, n, 0.125)                      # the well-formed calls pass
+    T.qkv_space_attention(x, w, b, side, out, p_s, n, 0.125)
+    torch.cuda.synchronize()
+    bad = [
+        (lambda: T.qkv_time_attention2(x.float(), w, b, side, out, p_t, n, 0.125), 'bf16'),                      # fp32 x would be read as bf16
+        (lambda: T.qkv_time_attention2(x, w, b.bfloat16(), side, out, p_t, n, 0.125), 'bias'),                    # bf16 bias would be read as fp32
+        (lambda: T.qkv_time_attention2(x[:rows - 1], w, b, side, out, p_t, n, 0.125), 'rows'),                    # too few rows
+        (lambda: T.qkv_time_attention2(x, w, b, side, out[:100], p_t, n, 0.125), 'rows'),
+        (lambda: T.qkv_time_attention2(x, w, b, side[:n * 33 - 1], out, p_t, n, 0.125), 'side'),
+        (lambda: T.qkv_time_attention2(x, w, b, side, out, p_s, n, 0.125), 'partials'),                           # the spatial launch's (smaller) partials
+        (lambda: T.qkv_time_attention2(x, w, b, side, x, p_t, n, 0.125), 'alias'),
+        (lambda: T.qkv_space_attention(x, w[:, :512], b, side, out, p_s, n, 0.125), r'2304, 768'),
+        (lambda: T.qkv_space_attention(x, w, b, side, out, p_s.double(), n, 0.125), 'fp32'),
+        (lambda: T.qkv_space_attention_masked(x, w, b, side, out, p_s, n, 0.125, torch.ones(rows - 1, device=gpu, dtype=torch.uint8)), 'key_keep'),
+        (lambda: T.space_side_rows(x, side[:, :768].contiguous()[:10], n), 'rows'),
+        (lambda: T.attention_cls_combine(p_s[:100], out, 8, n, 1569, 0, 12), 'partials'),
+        (lambda: T.gemm_bf16(x, w, b.bfloat16(), torch.empty(rows, 2304, device=gpu, dtype=torch.bfloat16), None, False), 'bias'),
+        (lambda: T.gemm_bf16(x, w, b, torch.empty(rows - 1, 2304, device=gpu, dtype=torch.bfloat16), None, False), 'out'),
+    ]
+    for fn, pat in bad:
+        with pytest.raises(RuntimeError, match=pat):
+            fn()
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize('fp8', [False, True])
 def test_forward_soak_bitwise_repeatable(gpu, fp8):
     """Race screen of the whole default schedule: every kernel of the hot path waits for its LDS-DMA operands with hand-counted `vmcnt` waits that hipcc

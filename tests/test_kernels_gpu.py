@@ -988,6 +988,30 @@ def test_functional_ops_autograd(gpu):
     assert dxe.numel() == 0 and dbe.numel() == 0 and _rel(dwe, dw_ref) < 5e-3
 
 
+def test_functional_linear_autocast_training_steps_fresh_dx(gpu):
+    """under autocast `linear_backward` receives the per-forward bf16 cast of the weight - a temporary whose device address the caching allocator
+    reuses step after step and whose version is always 0.  A W^T cache keyed on (data_ptr, version) served the FIRST step's transpose for ever after.  Three SGD
+    steps under autocast with a large learning rate: dX of every step must follow the UPDATED weight (fp32 torch on the same bf16 operands), and the same for a
+    leaf weight updated in place outside autocast (the cached case: the version counter moves)."""
+    from synchformer_amd import functional as SF
+    g = torch.Generator().manual_seed(11)
+    M, K, N = 1024, 768, 768
+    for autocast in (True, False):
+        w = (0.05 * torch.randn(N, K, generator=g)).to(gpu)
+        w = (w if autocast else w.bfloat16()).requires_grad_(True)
+        for step in range(3):
+            x = torch.randn(M, K, generator=g).to(gpu).bfloat16().requires_grad_(True)
+            dy = torch.randn(M, N, generator=g).to(gpu).bfloat16()
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+                y = SF.linear(x, w, None)
+            y.backward(dy)
+            ref = dy.float() @ w.detach().bfloat16().float()
+            assert _rel(x.grad, ref) < 5e-3, (autocast, step, _rel(x.grad, ref))
+            with torch.no_grad():
+                w.add_(torch.randn(N, K, generator=g).to(gpu).to(w.dtype), alpha=0.05)     # a step that changes W by as much as W itself
+            w.grad = None
+
+
 @pytest.mark.parametrize('n_seq', [3, 40])
 def test_qkv_space_attention(gpu, n_seq):
     """sf_qkv_space_attention (spatial qkv projection + space attention + CLS-query partials in one launch; the side rows from a 33-rows-per-segment GEMM) against

@@ -287,6 +287,26 @@ def test_avclip_train_steps_reduce_loss(gpu):
     assert 'logit_scale' in ck and any(k.startswith('v_encoder.blocks.0.') for k in ck) and len(ck) == 451 - 2
 
 
+@pytest.mark.parametrize('two_streams', [True, False])
+@pytest.mark.parametrize('drop_path', [0.0, 0.2])
+def test_backward_overwrites_every_gradient(gpu, monkeypatch, two_streams, drop_path):
+    """since round 5 the flat gradient buffer is not zeroed per step - correctness rests on every one of the 449 gradients being WRITTEN ('=', never '+=', never
+    skipped) by every code path of the backward.  Poison the buffer with NaN before the forward (SF_S1_POISON) and require a NaN-free buffer after the backward: both
+    stream modes, with and without stochastic depth, two steps in a row (the second step starts from the first step's all-reduced-and-consumed values)."""
+    monkeypatch.setenv('SF_S1_POISON', '1')
+    S = 14 if (two_streams and drop_path > 0) else 2                                # the configured 2 x 14 geometry (large-M launches) on the product settings
+    sd, tr, u8, aud = _setup(gpu, 2, S, 1.0, drop_path_rate=drop_path)
+    tr.two_streams = two_streams
+    vis, aud = u8.to(gpu), aud.to(gpu)
+    for step in range(2):
+        tr.forward_backward(vis, aud)
+        torch.cuda.synchronize()
+        nan = torch.isnan(tr.flat_g)
+        bad = [k for k in tr.keys if torch.isnan(tr.g[k]).any()]
+        assert not nan.any(), (step, len(bad), bad[:8], int(nan.sum()))
+        assert sum(tr.g[k].numel() for k in tr.keys) == tr.flat_g.numel()          # packed back to back: no gaps that could hold stale values
+
+
 def test_temperature_read_without_draining_the_queue(gpu):
     """forward_backward queues the device -> pinned-host copy of logit_scale BEFORE the forward and `_head` waits for that copy's event only (the launcher used to
     block on the forward, profiles/r05_round.md section 6).  The value it sees must be the parameter as it stands at the start of THIS step - after the previous
