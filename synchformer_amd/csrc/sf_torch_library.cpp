@@ -8,7 +8,7 @@
 // Each operator mirrors the argument marshalling of the ctypes wrapper of the same name in synchformer_amd/ops.py (the drop-in module and the tests compare the two routes bit
 // for bit); shape / dtype contracts beyond what is needed to form the call are checked by the C ABI itself (sf_last_error()).
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>   // PyTorch-ROCm files HIP devices under DeviceType cuda: the plain c10::hip::HIPGuard refuses them
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -106,7 +106,7 @@ void gemm_bf16(const Tensor& a, const Tensor& w, const OptTensor& bias, Tensor& 
   check_bias(bias, N, "gemm_bf16");
   SF_ARG(out.dim() == 2 && out.size(0) >= a.size(0) && out.size(1) >= N, "gemm_bf16", "out is (>= M, >= N), got ", out.sizes());
   if (residual.has_value()) SF_ARG(is_f32(*residual) && residual->dim() == 2 && residual->size(0) >= a.size(0) && residual->size(1) >= N, "gemm_bf16", "fp32 residual (>= M, >= N)");
-  const c10::hip::HIPGuard guard1_(a.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard1_(a.device());   // the C ABI launches on the CURRENT device
   check(sf_gemm_bf16(bf(dev(a, "a")), ld(a), bf(dev(w, "w")), ldw, f32(devo(bias, "bias")), dev(out, "out"), dtype_code(out), ld(out), nullptr,
                      f32(devo(residual, "residual")), residual.has_value() ? ld(*residual) : 0, nullptr, gelu ? SF_EPI_GELU : SF_EPI_NONE, a.size(0), N, K, stream_of(a)),
         "sf_gemm_bf16");
@@ -115,7 +115,7 @@ void gemm_bf16(const Tensor& a, const Tensor& w, const OptTensor& bias, Tensor& 
 void layernorm768(const Tensor& x, const Tensor& gamma, const Tensor& beta, Tensor& out, double eps) {
   SF_ARG(is_f32(gamma) && is_f32(beta) && gamma.numel() >= 768 && beta.numel() >= 768 && out.size(0) >= x.size(0), "layernorm768", "fp32 gamma / beta of 768, out rows >= x rows");
   TORCH_CHECK(x.scalar_type() == at::kFloat && x.size(1) == 768 && out.size(1) == 768, "synchformer::layernorm768: fp32 (rows, 768) in, 768 columns out");
-  const c10::hip::HIPGuard guard2_(x.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard2_(x.device());   // the C ABI launches on the CURRENT device
   check(sf_layernorm768(f32(dev(x, "x")), ld(x), nullptr, f32(dev(gamma, "gamma")), f32(dev(beta, "beta")), dev(out, "out"), dtype_code(out), ld(out), nullptr, 0, x.size(0),
                         (float)eps, stream_of(x)),
         "sf_layernorm768");
@@ -133,7 +133,7 @@ void gemm_res_ln768(const Tensor& a, const Tensor& w, const OptTensor& bias, Ten
   TORCH_CHECK(x.size(1) == 768 && y.size(1) == 768, "synchformer::gemm_res_ln768: 768 columns");
   SF_ARG(x.size(0) >= a.size(0) && y.size(0) >= a.size(0) && is_f32(gamma) && is_f32(beta) && gamma.numel() >= 768 && beta.numel() >= 768, "gemm_res_ln768", "x / y rows >= a rows, fp32 gamma / beta of 768");
   check_bias(bias, 768, "gemm_res_ln768");
-  const c10::hip::HIPGuard guard3_(a.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard3_(a.device());   // the C ABI launches on the CURRENT device
   check(sf_gemm_res_ln768(bf(dev(a, "a")), ld(a), bf(dev(w, "w")), ldw, f32(devo(bias, "bias")), f32(dev(x, "x")), ld(x), f32m(dev(x, "x")), ld(x), f32(dev(gamma, "gamma")),
                           f32(dev(beta, "beta")), (float)eps, bfm(dev(y, "y")), ld(y), a.size(0), K, stream_of(a)),
         "sf_gemm_res_ln768");
@@ -145,7 +145,7 @@ void attention(const Tensor& q, const Tensor& k, const Tensor& v, Tensor& out, i
   check_packed_qkv("attention", q, k, v);
   SF_ARG(is_bf16(out) && out.size(0) >= n_seq * seq_rows && q.size(0) >= n_seq * seq_rows, "attention", "bf16 out, q / out rows >= n_seq * seq_rows");
   TORCH_CHECK(ld(q) == ld(k) && ld(q) == ld(v), "synchformer::attention: q / k / v are column slices of one packed projection");
-  const c10::hip::HIPGuard guard4_(q.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard4_(q.device());   // the C ABI launches on the CURRENT device
   check(sf_attention(bf(dev(q, "q")), bf(dev(k, "k")), bf(dev(v, "v")), ld(q), bfm(dev(out, "out")), ld(out), n_seq, seq_rows, (int)n_groups, (int)row0, (int)group_stride,
                      (int)tok_stride, (int)n_tok, (int)cls_row, (int)heads, (int)head_dim, (float)scale, stream_of(q)),
         "sf_attention");
@@ -156,7 +156,7 @@ void attention_cls(const Tensor& q, const Tensor& k, const Tensor& v, Tensor& ou
   check_packed_qkv("attention_cls", q, k, v);
   SF_ARG(is_bf16(out) && out.size(0) >= n_seq * out_seq_rows && q.size(0) >= n_seq * q_seq_rows && k.size(0) >= n_seq * kv_seq_rows, "attention_cls", "bf16 out; q / k / out row counts");
   TORCH_CHECK(ld(q) == ld(k) && ld(q) == ld(v), "synchformer::attention_cls: q / k / v are column slices of one packed projection");
-  const c10::hip::HIPGuard guard5_(q.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard5_(q.device());   // the C ABI launches on the CURRENT device
   check(sf_attention_cls(bf(dev(q, "q")), q_seq_rows, (int)q_row, bf(dev(k, "k")), bf(dev(v, "v")), ld(q), kv_seq_rows, (int)kv_row0, (int)n_keys, bfm(dev(out, "out")), ld(out),
                          out_seq_rows, (int)out_row, n_seq, (int)heads, (int)head_dim, (float)scale, stream_of(q)),
         "sf_attention_cls");
@@ -170,14 +170,14 @@ void attention_cls_partial(const Tensor& q, const Tensor& k, const Tensor& v, Te
               "synchformer::attention_cls_partial: packed q / k / v, fp32 partials of n_seq * heads * n_groups * 66 elements");
   if (key_keep.has_value()) {
     TORCH_CHECK(key_keep->scalar_type() == at::kByte && key_keep->numel() >= n_seq * seq_rows, "synchformer::attention_cls_partial: key_keep is uint8, one flag per row");
-    const c10::hip::HIPGuard guard6_(q.device());   // the C ABI launches on the CURRENT device
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard6_(q.device());   // the C ABI launches on the CURRENT device
     check(sf_attention_cls_partial_masked(bf(dev(q, "q")), bf(dev(k, "k")), bf(dev(v, "v")), ld(q), bfm(dev(out, "out")), ld(out), n_seq, seq_rows, (int)n_groups, (int)row0,
                                           (int)group_stride, (int)tok_stride, (int)n_tok, (int)cls_row, (int)heads, (int)head_dim, (float)scale, f32m(dev(partials, "partials")),
                                           u8(dev(*key_keep, "key_keep")), stream_of(q)),
           "sf_attention_cls_partial_masked");
     return;
   }
-  const c10::hip::HIPGuard guard7_(q.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard7_(q.device());   // the C ABI launches on the CURRENT device
   check(sf_attention_cls_partial(bf(dev(q, "q")), bf(dev(k, "k")), bf(dev(v, "v")), ld(q), bfm(dev(out, "out")), ld(out), n_seq, seq_rows, (int)n_groups, (int)row0,
                                  (int)group_stride, (int)tok_stride, (int)n_tok, (int)cls_row, (int)heads, (int)head_dim, (float)scale, f32m(dev(partials, "partials")), stream_of(q)),
         "sf_attention_cls_partial");
@@ -186,7 +186,7 @@ void attention_cls_partial(const Tensor& q, const Tensor& k, const Tensor& v, Te
 void attention_cls_combine(const Tensor& partials, Tensor& out, int64_t n_part, int64_t n_seq, int64_t out_seq_rows, int64_t out_row, int64_t heads) {
   SF_ARG(is_f32(partials) && partials.is_contiguous() && partials.numel() >= n_seq * heads * n_part * 66 && is_bf16(out) && out.size(0) >= (n_seq - 1) * out_seq_rows + out_row + 1 && out.size(1) >= heads * 64,
          "attention_cls_combine", "fp32 partials of n_seq * heads * n_part * 66, bf16 out covering row (n_seq - 1) * out_seq_rows + out_row");
-  const c10::hip::HIPGuard guard8_(out.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard8_(out.device());   // the C ABI launches on the CURRENT device
   check(sf_attention_cls_combine(f32(dev(partials, "partials")), (int)n_part, bfm(dev(out, "out")), ld(out), out_seq_rows, (int)out_row, n_seq, (int)heads, stream_of(out)),
         "sf_attention_cls_combine");
 }
@@ -194,7 +194,7 @@ void attention_cls_combine(const Tensor& partials, Tensor& out, int64_t n_part, 
 void im2col_video(const Tensor& vid, Tensor& out) {
   TORCH_CHECK(vid.is_contiguous() && vid.dim() == 5 && vid.size(1) == 16 && vid.size(2) == 3 && vid.size(3) == 224 && vid.size(4) == 224, "synchformer::im2col_video: (n, 16, 3, 224, 224) contiguous");
   TORCH_CHECK(out.scalar_type() == at::kBFloat16 && out.is_contiguous() && out.size(1) == 1536, "synchformer::im2col_video: out bf16 (n * 1568, 1536) contiguous");
-  const c10::hip::HIPGuard guard9_(vid.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard9_(vid.device());   // the C ABI launches on the CURRENT device
   check(sf_im2col_video(dev(vid, "vid"), dtype_code(vid), bfm(dev(out, "out")), vid.size(0), stream_of(vid)), "sf_im2col_video");
 }
 
@@ -204,13 +204,13 @@ void qkv_time_attention(const Tensor& x, const Tensor& w, const OptTensor& bias,
   check_qkv_time_r3("qkv_time_attention", x, w, bias, qkv_cls, out, partials, n_seq, n_groups, false, false);
   if (key_keep.has_value()) check_key_keep(*key_keep, n_seq * (1 + 8 * n_groups), "qkv_time_attention");
   if (key_keep.has_value()) {
-    const c10::hip::HIPGuard guard10_(x.device());   // the C ABI launches on the CURRENT device
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard10_(x.device());   // the C ABI launches on the CURRENT device
     check(sf_qkv_time_attention_masked(bf(dev(x, "x")), ld(x), bf(dev(w, "w")), ld(w), f32(devo(bias, "bias")), bf(dev(qkv_cls, "qkv_cls")), ld(qkv_cls), bfm(dev(out, "out")),
                                        ld(out), f32m(dev(partials, "partials")), n_seq, (int)n_groups, (float)scale, u8(dev(*key_keep, "key_keep")), stream_of(x)),
           "sf_qkv_time_attention_masked");
     return;
   }
-  const c10::hip::HIPGuard guard11_(x.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard11_(x.device());   // the C ABI launches on the CURRENT device
   check(sf_qkv_time_attention(bf(dev(x, "x")), ld(x), bf(dev(w, "w")), ld(w), f32(devo(bias, "bias")), bf(dev(qkv_cls, "qkv_cls")), ld(qkv_cls), bfm(dev(out, "out")), ld(out),
                               f32m(dev(partials, "partials")), n_seq, (int)n_groups, (float)scale, stream_of(x)),
         "sf_qkv_time_attention");
@@ -218,7 +218,7 @@ void qkv_time_attention(const Tensor& x, const Tensor& w, const OptTensor& bias,
 
 void qkv_time_attention2(const Tensor& x, const Tensor& w, const OptTensor& bias, const Tensor& side, Tensor& out, Tensor& partials, int64_t n_seq, double scale) {
   check_qkv_fused("qkv_time_attention2", x, w, bias, side, out, partials, n_seq, 33, false, false);
-  const c10::hip::HIPGuard guard12_(x.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard12_(x.device());   // the C ABI launches on the CURRENT device
   check(sf_qkv_time_attention2(bf(dev(x, "x")), ld(x), bf(dev(w, "w")), ld(w), f32(devo(bias, "bias")), bf(dev(side, "side")), ld(side), bfm(dev(out, "out")), ld(out),
                                f32m(dev(partials, "partials")), n_seq, 196, (float)scale, stream_of(x)),
         "sf_qkv_time_attention2");
@@ -226,7 +226,7 @@ void qkv_time_attention2(const Tensor& x, const Tensor& w, const OptTensor& bias
 
 void qkv_space_attention(const Tensor& x, const Tensor& w, const OptTensor& bias, const Tensor& side, Tensor& out, Tensor& partials, int64_t n_seq, double scale) {
   check_qkv_fused("qkv_space_attention", x, w, bias, side, out, partials, n_seq, 8, false, false);
-  const c10::hip::HIPGuard guard13_(x.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard13_(x.device());   // the C ABI launches on the CURRENT device
   check(sf_qkv_space_attention(bf(dev(x, "x")), ld(x), bf(dev(w, "w")), ld(w), f32(devo(bias, "bias")), bf(dev(side, "side")), ld(side), bfm(dev(out, "out")), ld(out),
                                f32m(dev(partials, "partials")), n_seq, 196, (float)scale, stream_of(x)),
         "sf_qkv_space_attention");
@@ -236,7 +236,7 @@ void qkv_time_attention2_masked(const Tensor& x, const Tensor& w, const OptTenso
                                 const Tensor& key_keep) {
   check_qkv_fused("qkv_time_attention2_masked", x, w, bias, side, out, partials, n_seq, 33, false, false);
   check_key_keep(key_keep, n_seq * 1569, "qkv_time_attention2_masked");
-  const c10::hip::HIPGuard guard14_(x.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard14_(x.device());   // the C ABI launches on the CURRENT device
   check(sf_qkv_time_attention2_masked(bf(dev(x, "x")), ld(x), bf(dev(w, "w")), ld(w), f32(devo(bias, "bias")), bf(dev(side, "side")), ld(side), bfm(dev(out, "out")), ld(out),
                                       f32m(dev(partials, "partials")), n_seq, 196, (float)scale, u8(dev(key_keep, "key_keep")), stream_of(x)),
         "sf_qkv_time_attention2_masked");
@@ -246,7 +246,7 @@ void qkv_space_attention_masked(const Tensor& x, const Tensor& w, const OptTenso
                                 const Tensor& key_keep) {
   check_qkv_fused("qkv_space_attention_masked", x, w, bias, side, out, partials, n_seq, 8, false, false);
   check_key_keep(key_keep, n_seq * 1569, "qkv_space_attention_masked");
-  const c10::hip::HIPGuard guard15_(x.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard15_(x.device());   // the C ABI launches on the CURRENT device
   check(sf_qkv_space_attention_masked(bf(dev(x, "x")), ld(x), bf(dev(w, "w")), ld(w), f32(devo(bias, "bias")), bf(dev(side, "side")), ld(side), bfm(dev(out, "out")), ld(out),
                                       f32m(dev(partials, "partials")), n_seq, 196, (float)scale, u8(dev(key_keep, "key_keep")), stream_of(x)),
         "sf_qkv_space_attention_masked");
@@ -255,7 +255,7 @@ void qkv_space_attention_masked(const Tensor& x, const Tensor& w, const OptTenso
 void space_side_rows(const Tensor& x, Tensor& out, int64_t n_seq) {
   TORCH_CHECK(x.scalar_type() == at::kBFloat16 && out.scalar_type() == at::kBFloat16 && x.size(1) == 768 && out.size(1) == 768, "synchformer::space_side_rows: bf16 (rows, 768)");
   SF_ARG(n_seq > 0 && x.size(0) >= n_seq * 1569 && out.size(0) >= n_seq * 33, "space_side_rows", "x rows >= n_seq * 1569, out rows >= n_seq * 33");
-  const c10::hip::HIPGuard guard16_(x.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard16_(x.device());   // the C ABI launches on the CURRENT device
   check(sf_side_rows(dev(x, "x"), ld(x) * 2, dev(out, "out"), ld(out) * 2, 1536, nullptr, 0, nullptr, 0, 0, n_seq, 196, stream_of(x)), "sf_side_rows");
 }
 
@@ -265,7 +265,7 @@ void space_side_rows_mx(const Tensor& x_q, const Tensor& x_s, Tensor& side_q, Te
   check_scale_planes(side_s, 6, n_seq * 33, "space_side_rows_mx", "side_s");
   TORCH_CHECK(x_s.dim() == 3 && side_s.dim() == 3 && x_s.size(0) == 6 && side_s.size(0) == 6 && x_s.is_contiguous() && side_s.is_contiguous(),
               "synchformer::space_side_rows_mx: scale planes (6, rows, 4) contiguous");
-  const c10::hip::HIPGuard guard17_(x_q.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard17_(x_q.device());   // the C ABI launches on the CURRENT device
   check(sf_side_rows(dev(x_q, "x_q"), ld(x_q), dev(side_q, "side_q"), ld(side_q), 768, u8(dev(x_s, "x_s")), x_s.stride(0), u8m(dev(side_s, "side_s")), side_s.stride(0), 6, n_seq,
                      196, stream_of(x_q)),
         "sf_side_rows");
@@ -277,7 +277,7 @@ void quantize_mxfp8(const Tensor& x, Tensor& q, Tensor& scales) {
   check_scale_planes(scales, x.size(1) / 128, x.size(0), "quantize_mxfp8", "scales");
   TORCH_CHECK(x.scalar_type() == at::kBFloat16 && q.scalar_type() == at::kByte && scales.scalar_type() == at::kByte && scales.dim() == 3 && scales.is_contiguous(),
               "synchformer::quantize_mxfp8: x bf16, q uint8, scales uint8 (K / 128, rows, 4) contiguous");
-  const c10::hip::HIPGuard guard18_(x.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard18_(x.device());   // the C ABI launches on the CURRENT device
   check(sf_quantize_mxfp8(bf(dev(x, "x")), ld(x), u8m(dev(q, "q")), ld(q), u8m(dev(scales, "scales")), scales.stride(0), x.size(0), x.size(1), stream_of(x)), "sf_quantize_mxfp8");
 }
 
@@ -286,7 +286,7 @@ void layernorm768_mxfp8(const Tensor& x, const Tensor& gamma, const Tensor& beta
   check_scale_planes(scales, 6, x.size(0), "layernorm768_mxfp8", "scales");
   TORCH_CHECK(x.scalar_type() == at::kFloat && x.size(1) == 768 && q.scalar_type() == at::kByte && q.size(1) == 768 && scales.dim() == 3 && scales.is_contiguous(),
               "synchformer::layernorm768_mxfp8: x fp32 (rows, 768), q uint8 (rows, 768), scales (6, rows, 4) contiguous");
-  const c10::hip::HIPGuard guard19_(x.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard19_(x.device());   // the C ABI launches on the CURRENT device
   check(sf_layernorm768_mxfp8(f32(dev(x, "x")), ld(x), f32(dev(gamma, "gamma")), f32(dev(beta, "beta")), u8m(dev(q, "q")), ld(q), u8m(dev(scales, "scales")), scales.stride(0),
                               x.size(0), (float)eps, stream_of(x)),
         "sf_layernorm768_mxfp8");
@@ -298,7 +298,7 @@ void gemm_mxfp8(const Tensor& a_q, const Tensor& a_s, const Tensor& w_q, const T
   const int64_t N = w_q.size(0), K = w_q.size(1);
   TORCH_CHECK(a_q.size(1) == K && a_s.dim() == 3 && w_s.dim() == 3 && a_s.size(0) == K / 128 && w_s.size(0) == K / 128 && a_s.is_contiguous() && w_s.is_contiguous(),
               "synchformer::gemm_mxfp8: operands (rows, K) uint8 with stage-major scale planes (K / 128, rows, 4)");
-  const c10::hip::HIPGuard guard20_(a_q.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard20_(a_q.device());   // the C ABI launches on the CURRENT device
   SF_ARG(is_u8(a_q) && is_u8(w_q) && K % 128 == 0 && out.dim() == 2 && out.size(0) >= a_q.size(0) && out.size(1) >= N, "gemm_mxfp8", "uint8 operands, K a multiple of 128, out (>= M, >= N)");
   check_scale_planes(a_s, K / 128, a_q.size(0), "gemm_mxfp8", "a_s");
   check_scale_planes(w_s, K / 128, N, "gemm_mxfp8", "w_s");
@@ -317,7 +317,7 @@ void gemm_mx_res_ln768(const Tensor& a_q, const Tensor& a_s, const Tensor& w_q, 
   TORCH_CHECK(x.scalar_type() == at::kFloat && x.size(1) == 768 && y_q.size(1) == 768 && w_q.size(0) == 768 && w_q.size(1) == K && a_s.dim() == 3 && w_s.dim() == 3 && y_s.dim() == 3 &&
                   a_s.is_contiguous() && w_s.is_contiguous() && y_s.is_contiguous(),
               "synchformer::gemm_mx_res_ln768: x fp32 (rows, 768), w (768, K), contiguous scale planes");
-  const c10::hip::HIPGuard guard21_(a_q.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard21_(a_q.device());   // the C ABI launches on the CURRENT device
   SF_ARG(is_u8(a_q) && is_u8(w_q) && is_u8(y_q) && K % 128 == 0 && x.size(0) >= a_q.size(0) && y_q.size(0) >= a_q.size(0) && is_f32(gamma) && is_f32(beta) && gamma.numel() >= 768 && beta.numel() >= 768,
          "gemm_mx_res_ln768", "uint8 operands / output, x / y_q rows >= a_q rows, fp32 gamma / beta of 768");
   check_scale_planes(a_s, K / 128, a_q.size(0), "gemm_mx_res_ln768", "a_s");
@@ -335,7 +335,7 @@ void qkv_time_attention_mx(const Tensor& x_q, const Tensor& x_s, const Tensor& w
   check_qkv_time_r3("qkv_time_attention_mx", x_q, w_q, bias, qkv_cls, out, partials, n_seq, n_groups, true, false);
   check_scale_planes(x_s, 6, n_seq * (1 + 8 * n_groups), "qkv_time_attention_mx", "x_s");
   check_scale_planes(w_s, 6, 2304, "qkv_time_attention_mx", "w_s");
-  const c10::hip::HIPGuard guard22_(x_q.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard22_(x_q.device());   // the C ABI launches on the CURRENT device
   check(sf_qkv_time_attention_mx(u8(dev(x_q, "x_q")), ld(x_q), u8(dev(x_s, "x_s")), x_s.stride(0), u8(dev(w_q, "w_q")), ld(w_q), u8(dev(w_s, "w_s")), w_s.stride(0),
                                  f32(devo(bias, "bias")), bf(dev(qkv_cls, "qkv_cls")), ld(qkv_cls), bfm(dev(out, "out")), ld(out), f32m(dev(partials, "partials")), n_seq, (int)n_groups,
                                  (float)scale, stream_of(x_q)),
@@ -349,7 +349,7 @@ void qkv_time_attention_mx_q(const Tensor& x_q, const Tensor& x_s, const Tensor&
   check_scale_planes(w_s, 6, 2304, "qkv_time_attention_mx_q", "w_s");
   check_scale_planes(out_s, 6, n_seq * (1 + 8 * n_groups), "qkv_time_attention_mx_q", "out_s");
   TORCH_CHECK(out_q.data_ptr() != x_q.data_ptr() && out_s.data_ptr() != x_s.data_ptr() && out_s.dim() == 3 && out_s.is_contiguous(), "synchformer::qkv_time_attention_mx_q: out_q / out_s are buffers of their own");
-  const c10::hip::HIPGuard guard23_(x_q.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard23_(x_q.device());   // the C ABI launches on the CURRENT device
   check(sf_qkv_time_attention_mx_q(u8(dev(x_q, "x_q")), ld(x_q), u8(dev(x_s, "x_s")), x_s.stride(0), u8(dev(w_q, "w_q")), ld(w_q), u8(dev(w_s, "w_s")), w_s.stride(0),
                                    f32(devo(bias, "bias")), bf(dev(qkv_cls, "qkv_cls")), ld(qkv_cls), u8m(dev(out_q, "out_q")), ld(out_q), u8m(dev(out_s, "out_s")), out_s.stride(0),
                                    f32m(dev(partials, "partials")), n_seq, (int)n_groups, (float)scale, stream_of(x_q)),
@@ -362,7 +362,7 @@ void attention_cls_partial_mx(const Tensor& q, const Tensor& k, const Tensor& v,
   SF_ARG(is_u8(out_q) && is_u8(out_s) && is_f32(partials) && partials.is_contiguous() && partials.numel() >= n_seq * heads * n_groups * 66 && out_q.size(0) >= n_seq * seq_rows && out_s.size(1) >= n_seq * seq_rows,
          "attention_cls_partial_mx", "uint8 out_q / out_s covering n_seq * seq_rows rows, fp32 partials of n_seq * heads * n_groups * 66");
   TORCH_CHECK(ld(q) == ld(k) && ld(q) == ld(v) && out_s.dim() == 3 && out_s.size(0) * 2 == heads, "synchformer::attention_cls_partial_mx: packed q / k / v, scale planes (heads / 2, rows, 4)");
-  const c10::hip::HIPGuard guard24_(q.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard24_(q.device());   // the C ABI launches on the CURRENT device
   check(sf_attention_cls_partial_mx(bf(dev(q, "q")), bf(dev(k, "k")), bf(dev(v, "v")), ld(q), u8m(dev(out_q, "out_q")), ld(out_q), u8m(dev(out_s, "out_s")), out_s.stride(0), n_seq,
                                     seq_rows, (int)n_groups, (int)row0, (int)group_stride, (int)tok_stride, (int)n_tok, (int)cls_row, (int)heads, (float)scale,
                                     f32m(dev(partials, "partials")), stream_of(q)),
@@ -373,7 +373,7 @@ void attention_cls_combine_mx(const Tensor& partials, Tensor& out_q, Tensor& out
   SF_ARG(is_f32(partials) && partials.is_contiguous() && partials.numel() >= n_seq * heads * n_part * 66 && is_u8(out_q) && is_u8(out_s) && out_q.size(0) >= (n_seq - 1) * out_seq_rows + out_row + 1,
          "attention_cls_combine_mx", "fp32 partials of n_seq * heads * n_part * 66, uint8 outputs covering row (n_seq - 1) * out_seq_rows + out_row");
   TORCH_CHECK(out_s.dim() == 3 && out_s.size(0) * 2 == heads, "synchformer::attention_cls_combine_mx: scale planes (heads / 2, rows, 4)");
-  const c10::hip::HIPGuard guard25_(out_q.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard25_(out_q.device());   // the C ABI launches on the CURRENT device
   check(sf_attention_cls_combine_mx(f32(dev(partials, "partials")), (int)n_part, u8m(dev(out_q, "out_q")), ld(out_q), u8m(dev(out_s, "out_s")), out_s.stride(0), out_seq_rows,
                                     (int)out_row, n_seq, (int)heads, stream_of(out_q)),
         "sf_attention_cls_combine_mx");
@@ -394,7 +394,7 @@ void qkv_mx_launch(F fn, const char* what, const Tensor& x_q, const Tensor& x_s,
   } else {
     TORCH_CHECK(out.scalar_type() == at::kBFloat16, what, ": the bf16 output form");
   }
-  const c10::hip::HIPGuard guard26_(x_q.device());   // the C ABI launches on the CURRENT device
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard26_(x_q.device());   // the C ABI launches on the CURRENT device
   check(fn(u8(dev(x_q, "x_q")), ld(x_q), u8(dev(x_s, "x_s")), x_s.stride(0), u8(dev(w_q, "w_q")), ld(w_q), u8(dev(w_s, "w_s")), w_s.stride(0), f32(devo(bias, "bias")),
            bf(dev(side, "side")), ld(side), q ? nullptr : bfm(dev(out, "out")), q ? 0 : ld(out), q ? u8m(dev(out, "out")) : nullptr, q ? ld(out) : 0,
            q ? u8m(dev(*out_s, "out_s")) : nullptr, q ? out_s->stride(0) : 0, f32m(dev(partials, "partials")), n_seq, 196, (float)scale, stream_of(x_q)),

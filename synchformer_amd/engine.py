@@ -91,6 +91,13 @@ class SynchformerEngine:
         self.fuse_space = os.environ.get('SF_FUSE_SPACE', '1') != '0'     # spatial qkv projection + space attention in one launch (sf_qkv_space_attention, round 4)
         self.fuse_time2 = os.environ.get('SF_FUSE_TIME2', '1') != '0'     # the temporal launch on the spatial kernel's 192 x 384 main loop (sf_qkv_time_attention2, round 4)
         self._a_side = None
+        # Small batches (BASELINE configs[0]: ONE clip = 14 segments, M = 21,966 rows): the launches of a block leave a fifth of the CU-time idle - 172 full-row tiles
+        # of sf_gemm_res_ln768 for 256 CUs, 4.03 / 2.95 / 2.6 rounds in fc1 / the two attention launches - and a tile cannot be made smaller without streaming W
+        # again (profiles/r06_small_m.md).  Up to `vis_split_max` segments the visual tower therefore runs as TWO independent halves of the segments on two HIP
+        # streams (segments are independent until vproj, motionformer.py:200-207): one half's one-round launches run beside the other half's multi-round ones.
+        self.vis_split_max = int(os.environ.get('SF_VIS_SPLIT_MAX', '0'))
+        self._ws_tag = ''
+        self._v_side = None
         self.load_weights(state_dict)
 
     # ------------------------------------------------------------------------------------------------
@@ -209,6 +216,7 @@ class SynchformerEngine:
     # workspace
     # ------------------------------------------------------------------------------------------------
     def _buf(self, name, numel, dtype):
+        name = self._ws_tag + name                                     # (a half of a small batch running on the second visual stream has workspaces of its own)
         t = self._ws.get(name)
         if t is None or t.numel() < numel or t.dtype != dtype:
             t = torch.zeros(numel, device=self.dev, dtype=dtype)
@@ -517,10 +525,33 @@ class SynchformerEngine:
                 raise ValueError(f'vis_mask {tuple(vis_mask.shape)} must have the shape of vis {tuple(vis.shape)}')
             keep = vis_mask.to(self.dev).to(torch.bool).reshape(vid.shape).contiguous()
         out = torch.empty(B * S * 8, D, device=self.dev, dtype=torch.float32)
+        if 2 <= B * S <= self.vis_split_max:
+            h = (B * S + 1) // 2
+            self._two_halves(lambda: self._visual_chunk(vid[:h], out[:h * 8], keep=None if keep is None else keep[:h]),
+                             lambda: self._visual_chunk(vid[h:], out[h * 8:], keep=None if keep is None else keep[h:]))
+            return out.view(B, S, 8, D)
         for s0 in range(0, B * S, self.seg_chunk):
             n = min(self.seg_chunk, B * S - s0)
             self._visual_chunk(vid[s0:s0 + n], out[s0 * 8:(s0 + n) * 8], keep=None if keep is None else keep[s0:s0 + n])
         return out.view(B, S, 8, D)
+
+    def _two_halves(self, first, second):
+        """Run two independent sub-schedules side by side: `first` on the current stream, `second` on the engine's second visual stream with workspaces of its
+        own (`_ws_tag`); fork / join by events, so the pair captures into a HIP graph like any other part of the forward."""
+        if self._v_side is None:
+            self._v_side, self._v_fork, self._v_join = torch.cuda.Stream(device=self.dev), torch.cuda.Event(), torch.cuda.Event()
+        main = torch.cuda.current_stream()
+        self._v_fork.record(main)
+        with torch.cuda.stream(self._v_side):
+            self._v_side.wait_event(self._v_fork)
+            self._ws_tag = 'h1:'
+            try:
+                second()
+            finally:
+                self._ws_tag = ''
+            self._v_join.record(self._v_side)
+        first()
+        main.wait_event(self._v_join)
 
     # ------------------------------------------------------------------------------------------------
     # audio branch

@@ -51,22 +51,25 @@ def register():
         torch._check(x.shape[-1] == weight.shape[1], lambda: 'synchformer::linear: x (..., K) against weight (N, K)')
         return x.new_empty((*x.shape[:-1], weight.shape[0]), dtype=torch.bfloat16)
 
-    _wt_cache = weakref.WeakKeyDictionary()                       # weight OBJECT -> (version, bf16 W^T): one transpose per optimizer step, not one per backward
+    _wt_cache = {}                                                # id(weight) -> (weakref to the weight OBJECT, version, bf16 W^T): one transpose per optimizer step, not one per backward
+                                                                  # (a WeakKeyDictionary cannot hold tensors: it compares keys with ==, which is elementwise)
 
     def _wT(weight, w, N, K, dev):
         """bf16 W^T for dX = dY W.  Cached only for a leaf weight (an nn.Parameter / a frozen tensor the caller keeps alive), keyed on the tensor OBJECT - a
-        dead weight drops its entry, so a recycled device address can never serve another tensor's transpose - and on its version counter (in-place optimizer
-        updates bump it; writes through `.data` do not - do not update weights that way).  Under autocast `weight` is the per-forward bf16 temporary of the cast
-        (not a leaf, version 0, address reused by the allocator step after step): never cached, transposed per backward."""
+        dead weight drops its entry (weakref callback), and a hit must be the same live object, so a recycled device address or a recycled id() can never serve
+        another tensor's transpose - and on its version counter (in-place optimizer updates bump it; writes through `.data` do not - do not update weights that
+        way).  Under autocast `weight` is the per-forward bf16 temporary of the cast (not a leaf, version 0, address reused by the allocator step after step):
+        never cached, transposed per backward."""
         cacheable = weight.is_leaf and weight.grad_fn is None
+        key = id(weight)
         if cacheable:
-            hit = _wt_cache.get(weight)
-            if hit is not None and hit[0] == weight._version and hit[1].shape == (K, N):
-                return hit[1]
+            hit = _wt_cache.get(key)
+            if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2].shape == (K, N):
+                return hit[2]
         wT = torch.empty(K, N, device=dev, dtype=torch.bfloat16)
         transpose(w, K, 0, 0, wT, N, 0, 0, N, K, N)
         if cacheable:
-            _wt_cache[weight] = (weight._version, wT)
+            _wt_cache[key] = (weakref.ref(weight, lambda _r, k=key: _wt_cache.pop(k, None)), weight._version, wT)
         return wT
 
     def _bwd_shapes_ok(M, N, K):

@@ -9,7 +9,8 @@
 //   residency 0: 1 MiB per XCD, shared by the XCD's 32 workgroups (L2 hits) | 1: 128 MiB, 512 KiB per workgroup (thrashes the 4 MiB L2s, fits the 256 MiB
 //   Infinity Cache) | 2: 2 GiB, 8 MiB per workgroup (HBM)
 //   shape 0: a piece = 1 KiB contiguous | 1: 8 rows x 128 B, rows 1536 B apart (an A operand piece of K = 768) | 2: 16 rows x 64 B, rows 1536 B apart
-// build: hipcc --offload-arch=gfx950 -O3 tools/probe/l2_stream.hip -o tools/probe/l2_stream.bin ; run: tools/probe/l2_stream.bin [csv]
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probe/l2_stream.hip -o tools/probe/l2_stream.bin ; run: tools/probe/l2_stream.bin [csv|quick] [stag]   ("stag": only the MFMA-only baseline and
+// the staggered arrangement - phases of 2 pieces | barrier | 8 MFMAs | barrier, a SIMD's second wave one barrier behind: config 11 without its fragment reads)
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -49,7 +50,7 @@ __device__ __forceinline__ uint32_t lane_off(uint32_t shape, uint32_t q, uint32_
   return (rb * 16u + (lane >> 2)) * 1536u + slab * 64u + (lane & 3u) * 16u;
 }
 
-template <int MODE, int D, int MFMA>
+template <int MODE, int D, int MFMA, int STAG = 0>
 __global__ __launch_bounds__((MFMA || D >= 8) ? 512 : 1024) void stream_kernel(Args a) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__((MFMA || D >= 8) ? 512 : 1024) void stream_kernel(A
       }
     for (int j = 0; j < 4; ++j) for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
   }
-  u32x4 r[(MODE >= 2) ? D : 1];
+  u32x4 r[(MODE == 2 || MODE == 3) ? D : 1];
   uint32_t x0 = 0, x1 = 0, x2 = 0, x3 = 0;
 
   __syncthreads();
@@ -88,6 +89,8 @@ __global__ __launch_bounds__((MFMA || D >= 8) ? 512 : 1024) void stream_kernel(A
       uint32_t keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(off), "s"(wg_base), "s"(lds_wave + (uint32_t)slot * 1024u) : "memory");
+    } else if (MODE == 4) {
+      (void)off;                                  // MFMA-only baseline: no memory instruction at all
     } else if (MODE == 2) {
       asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[slot]) : "v"(off), "s"(wg_base) : "memory");
     } else {
@@ -95,7 +98,7 @@ __global__ __launch_bounds__((MFMA || D >= 8) ? 512 : 1024) void stream_kernel(A
     }
   };
   auto retire = [&](int slot) {   // the oldest piece has landed: VGPR modes consume it
-    if (MODE >= 2) {
+    if (MODE == 2 || MODE == 3) {
       asm volatile("" : "+v"(r[slot]));   // ties the use to the position behind the counted wait
       x0 ^= r[slot].x; x1 ^= r[slot].y; x2 ^= r[slot].z; x3 ^= r[slot].w;
     }
@@ -105,20 +108,39 @@ __global__ __launch_bounds__((MFMA || D >= 8) ? 512 : 1024) void stream_kernel(A
     for (int m = 0; m < MFMA; ++m) acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m & 1], fb[(m >> 1) & 1], acc[m & 3], 0, 0, 0);
   };
 #pragma unroll
-  for (int d = 0; d < D - 1; ++d) issue((uint32_t)d, d);
-  uint32_t p = D - 1;
+  for (int d = 0; d < D - 1 - STAG; ++d) issue((uint32_t)d, d);     // prologue: D - 1 pieces in flight (STAG: D - 2, it issues two per phase)
+  uint32_t p = D - 1 - STAG;
+  if constexpr (STAG != 0) {
+    // config 11's arrangement without its LDS fragment reads: a phase = { 2 pieces + counted wait | s_barrier | 2 x MFMA matrix ops | s_barrier }, the waves of the
+    // second half (one per SIMD) run ONE barrier behind the first half: a SIMD's two waves alternate between the matrix segment and the issue segment
+    const bool late = wave >= (nw >> 1);
+    if (late) __builtin_amdgcn_s_barrier();
+    for (; p + D <= total; p += D) {
+#pragma unroll
+      for (int d = 0; d < D; d += 2) {
+        issue(p + d, (d + D - 2) % D);
+        issue(p + d + 1, (d + D - 1) % D);
+        wait_vm<D - 2>();
+        retire(d);
+        retire(d + 1);
+        __builtin_amdgcn_s_barrier();
+        mfmas(); mfmas();
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+  } else
   for (; p + D <= total; p += D) {       // D pieces per trip: slots are compile-time
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       issue(p + d, (d + D - 1) % D);
       wait_vm<D - 1>();
-      if (MODE >= 2) asm volatile("" : "+v"(r[d]));
       retire(d);
       if (MFMA) mfmas();
     }
   }
   wait_vm<0>();
-  if (MODE >= 2) {
+  if (MODE == 2 || MODE == 3) {
 #pragma unroll
     for (int d = 0; d < D; ++d) asm volatile("" : "+v"(r[d]));
   }
@@ -144,6 +166,15 @@ template <int MFMA> static kern_t pick_m(int mode, int d) {
   switch (mode) { case 0: return pick_d<0, MFMA>(d); case 1: return pick_d<1, MFMA>(d); case 2: return pick_d<2, MFMA>(d); case 3: return pick_d<3, MFMA>(d); }
   return nullptr;
 }
+static kern_t pick_stag(int mode, int d) {
+  switch (mode * 100 + d) {
+    case 2: return stream_kernel<0, 2, 4, 1>;    case 4: return stream_kernel<0, 4, 4, 1>;    case 8: return stream_kernel<0, 8, 4, 1>;    case 12: return stream_kernel<0, 12, 4, 1>;
+    case 102: return stream_kernel<1, 2, 4, 1>;  case 104: return stream_kernel<1, 4, 4, 1>;  case 108: return stream_kernel<1, 8, 4, 1>;  case 112: return stream_kernel<1, 12, 4, 1>;
+    case 202: return stream_kernel<2, 2, 4, 1>;  case 204: return stream_kernel<2, 4, 4, 1>;  case 208: return stream_kernel<2, 8, 4, 1>;  case 212: return stream_kernel<2, 12, 4, 1>;
+    case 402: return stream_kernel<4, 2, 4, 1>;  case 404: return stream_kernel<4, 4, 4, 1>;
+  }
+  return nullptr;
+}
 static kern_t pick(int mode, int d, int mfma) { return mfma == 0 ? pick_m<0>(mode, d) : mfma == 4 ? pick_m<4>(mode, d) : pick_m<8>(mode, d); }
 
 int main(int argc, char** argv) {
@@ -160,17 +191,46 @@ int main(int argc, char** argv) {
   }
   uint64_t* out; CK(hipMalloc(&out, ncu * 16)); float* sink; CK(hipMalloc(&sink, 4));
   std::vector<uint64_t> hout(ncu * 2);
-  const char* mode_name[4] = {"buffer_load_x4_lds", "global_load_lds_x4", "global_load_x4_vgpr", "buffer_load_x4_vgpr"};
+  const char* mode_name[5] = {"buffer_load_x4_lds", "global_load_lds_x4", "global_load_x4_vgpr", "buffer_load_x4_vgpr", "no_load"};
   const char* res_name[3] = {"L2", "MALL", "HBM"};
   const char* shape_name[3] = {"1KiB", "8x128B", "16x64B"};
-  printf("%s\n", csv ? "mode,residency,shape,waves,inflight_KiB,mfma_per_piece,us,KB_per_us_per_CU,B_per_clk_per_CU,TB_per_s_chip,GHz"
-                     : "# mode residency shape waves inflight_KiB mfma/piece | us  KB/us/CU  B/clk/CU  TB/s(chip)  GHz");
+  const bool only_stag = argc > 2 && !strcmp(argv[2], "stag");
+  printf("%s\n", csv ? "mode,residency,shape,waves,inflight_KiB,mfma_per_piece,us,KB_per_us_per_CU,B_per_clk_per_CU,TB_per_s_chip,GHz,arrangement"
+                     : "# mode residency shape waves inflight_KiB mfma/piece | us  KB/us/CU  B/clk/CU  TB/s(chip)  GHz  arrangement");
+  auto run_one = [&](kern_t k, int mode, int res, int shape, int waves, int d, int mfma, const char* arrangement) {
+    Args a;
+    a.base = buf; a.out = out; a.sink = sink; a.shape = (uint32_t)shape;
+    if (res == 0) { a.xcd_stride = 1 << 20; a.blk_stride = 0; a.span_mask = (1u << 20) - 1; }
+    else if (res == 1) { a.xcd_stride = (uint64_t)(512 << 10) * (ncu / 8); a.blk_stride = 512 << 10; a.span_mask = (512u << 10) - 1; }
+    else { a.xcd_stride = (uint64_t)(8 << 20) * (ncu / 8); a.blk_stride = 8 << 20; a.span_mask = (8u << 20) - 1; }
+    const uint32_t kib_per_cu = (res == 2 ? 8u : 16u) << 10;   // 8 or 16 MiB per CU and run
+    a.pieces = (kib_per_cu / waves / d) * d + (d - 1);
+    const size_t lds = std::max<size_t>(96 << 10, (size_t)waves * d * 1024);
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    double best_us = 1e30, best_cyc = 0;
+    for (int rep = 0; rep < 4; ++rep) {
+      hipLaunchKernelGGL(k, dim3(ncu), dim3(waves * 64), lds, 0, a);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(hout.data(), out, ncu * 16, hipMemcpyDeviceToHost));
+      uint64_t cyc = 0, wall = 0;
+      for (int b = 0; b < ncu; ++b) { cyc = std::max(cyc, hout[b * 2]); wall = std::max(wall, hout[b * 2 + 1]); }
+      const double us = wall * 0.01;
+      if (rep > 0 && us < best_us) { best_us = us; best_cyc = (double)cyc; }
+    }
+    const double bytes_cu = (double)(a.pieces - (d - 1)) * waves * 1024.0;   // (mode no_load: the bytes the same number of pieces WOULD have carried)
+    const double kbus = bytes_cu / 1e3 / best_us, bclk = bytes_cu / best_cyc, tbs = bytes_cu * ncu / best_us / 1e6, ghz = best_cyc / best_us / 1e3;
+    printf(csv ? "%s,%s,%s,%d,%d,%d,%.1f,%.1f,%.2f,%.2f,%.3f,%s\n" : "%-20s %-4s %-7s %2d %3d %d | %8.1f %7.1f %6.2f %6.2f %5.3f %s\n",
+           mode_name[mode], res_name[res], shape_name[shape], waves, d * waves, mfma, best_us, kbus, bclk, tbs, ghz, arrangement);
+    fflush(stdout);
+  };
+  // (1) free-running waves: every wave issues a piece, waits for its oldest, runs its MFMAs
   for (int mfma : {0, 4, 8})
     for (int res = 0; res < 3; ++res)
       for (int shape = 0; shape < 3; ++shape)
         for (int mode = 0; mode < 4; ++mode)
           for (int waves : {4, 8, 16})
             for (int kib : {8, 16, 32, 64, 96}) {
+              if (only_stag) continue;
               if (quick && (shape != 0 || mfma == 8 || res == 1)) continue;
               if (shape != 0 && (res == 2 || mfma == 8)) continue;
               if (mfma && waves == 16) continue;     // 16 waves of an MFMA kernel do not exist in this repo (>= 128 accumulator registers)
@@ -178,30 +238,21 @@ int main(int argc, char** argv) {
               if (d * waves != kib || d < 1) continue;
               kern_t k = pick(mode, d, mfma);
               if (!k || (mfma && d == 24 && mode >= 2)) continue;   // (that instantiation spills)
-              Args a;
-              a.base = buf; a.out = out; a.sink = sink; a.shape = (uint32_t)shape;
-              if (res == 0) { a.xcd_stride = 1 << 20; a.blk_stride = 0; a.span_mask = (1u << 20) - 1; }
-              else if (res == 1) { a.xcd_stride = (uint64_t)(512 << 10) * (ncu / 8); a.blk_stride = 512 << 10; a.span_mask = (512u << 10) - 1; }
-              else { a.xcd_stride = (uint64_t)(8 << 20) * (ncu / 8); a.blk_stride = 8 << 20; a.span_mask = (8u << 20) - 1; }
-              const uint32_t kib_per_cu = (res == 2 ? 8u : 16u) << 10;   // 8 or 16 MiB per CU and run
-              a.pieces = (kib_per_cu / waves / d) * d + (d - 1);
-              const size_t lds = std::max<size_t>(96 << 10, (size_t)waves * d * 1024);
-              CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-              double best_us = 1e30, best_cyc = 0;
-              for (int rep = 0; rep < 4; ++rep) {
-                hipLaunchKernelGGL(k, dim3(ncu), dim3(waves * 64), lds, 0, a);
-                CK(hipDeviceSynchronize());
-                CK(hipMemcpy(hout.data(), out, ncu * 16, hipMemcpyDeviceToHost));
-                uint64_t cyc = 0, wall = 0;
-                for (int b = 0; b < ncu; ++b) { cyc = std::max(cyc, hout[b * 2]); wall = std::max(wall, hout[b * 2 + 1]); }
-                const double us = wall * 0.01;
-                if (rep > 0 && us < best_us) { best_us = us; best_cyc = (double)cyc; }
-              }
-              const double bytes_cu = (double)(a.pieces - (d - 1)) * waves * 1024.0;
-              const double kbus = bytes_cu / 1e3 / best_us, bclk = bytes_cu / best_cyc, tbs = bytes_cu * ncu / best_us / 1e6, ghz = best_cyc / best_us / 1e3;
-              printf(csv ? "%s,%s,%s,%d,%d,%d,%.1f,%.1f,%.2f,%.2f,%.3f\n" : "%-20s %-4s %-7s %2d %3d %d | %8.1f %7.1f %6.2f %6.2f %5.3f\n",
-                     mode_name[mode], res_name[res], shape_name[shape], waves, kib, mfma, best_us, kbus, bclk, tbs, ghz);
-              fflush(stdout);
+              run_one(k, mode, res, shape, waves, d, mfma, "free");
             }
+  // (2) the matrix pipe alone (no memory instruction): what 4 / 8 MFMAs per "piece" cost at the clock random operands allow - the ceiling of the rows with MFMAs
+  for (int waves : {4, 8}) {
+    run_one(stream_kernel<4, 4, 4, 0>, 4, 0, 0, waves, 4, 4, "free");
+    run_one(stream_kernel<4, 4, 8, 0>, 4, 0, 0, waves, 4, 8, "free");
+  }
+  run_one(stream_kernel<4, 4, 4, 1>, 4, 0, 0, 8, 4, 4, "staggered");
+  // (3) config 11's arrangement without its fragment reads: 8 waves, phases of 2 pieces | barrier | 8 MFMAs | barrier, the second wave of every SIMD one barrier behind
+  for (int res = 0; res < 2; ++res)
+    for (int shape = 0; shape < 2; ++shape)
+      for (int mode = 0; mode < 3; ++mode)
+        for (int d : {2, 4, 8, 12}) {
+          kern_t k = pick_stag(mode, d);
+          if (k) run_one(k, mode, res, shape, 8, d, 4, "staggered");
+        }
   return 0;
 }
