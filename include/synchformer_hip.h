@@ -29,7 +29,7 @@ extern "C" {
 enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2, SF_U8 = 3 };   /* element types */
 enum { SF_EPI_NONE = 0, SF_EPI_GELU = 1 };                  /* GEMM epilogue activation */
 
-#define SF_ABI_VERSION 9
+#define SF_ABI_VERSION 10
 int sf_abi_version(void);
 const char* sf_last_error(void);
 /* "gfx950" + build flags; lets the host assert it loaded the library it built */
@@ -334,6 +334,12 @@ int sf_cross_entropy(const float* logits, int64_t ld, const int64_t* targets, in
  * the backward.  Dropout sites: sync_model.py:166, modules/transformer.py:70,73,90. */
 int sf_dropout(const void* x, int dtype, int64_t ldx, const float* residual, int64_t ldr, void* y, int64_t ldy, int64_t rows, int cols,
                float p, uint32_t seed, void* stream);
+/* Whole-token dropout of the sync transformer's inputs - GlobalTransformer.tok_drop_vis / tok_drop_aud, torch.nn.Dropout1d on (B, S, D) = whole tokens dropped
+ * (model/sync_model.py:131-134, 160-161, train mode with tok_pdrop > 0): y[y_map(r), :] (=|+=) row_scale[r] * x[x_map(r), :], fp32, cols % 4 == 0; row_scale[r] is 0 or
+ * 1 / (1 - p) per token (sf_dropout over a vector of ones); x_map / y_map = 6-integer row maps or NULL (identity).  Forward: the input LayerNorm's rows into the token
+ * matrix on top of the positional table (accumulate = 1); backward: the token matrix's gradient rows, scaled, as the LayerNorm backward's dY (accumulate = 0). */
+int sf_scale_rows_map(const float* x, int64_t ldx, const int64_t* x_map, const float* row_scale, float* y, int64_t ldy, const int64_t* y_map, int64_t rows, int cols,
+                      int accumulate, void* stream);
 /* Head of a residual branch's backward in the Stage-1 towers (the `x = x + drop_path(branch(x))` sites of vit_helper.py:364-376 / modeling_ast.py ASTLayer):
  * y = bf16(s[r / seq_rows] * dx[r, :]) (the dY operand of the branch's output Linear) and dbias (=|+=) the fp32 column sums of the scaled gradient, in one
  * pass over dx (seq_scale may be NULL).  Replaces sf_scale_seq_add -> sf_cast_bf16 -> sf_colsum.  cols % 32 == 0; workspace >= cols * ceil(rows / 64) floats. */

@@ -250,9 +250,11 @@ def global_transformer(v, a, sd, p='transformer', apply_head=True, masks=None):
     (or the ln_f output (B, 1+Sv+1+Sa, D) when apply_head is False)."""
     B = v.shape[0]
     v, a = _ln(v, sd, p + '.vis_in_lnorm', EPS_SYNC), _ln(a, sd, p + '.aud_in_lnorm', EPS_SYNC)
+    masks = masks or {}
+    if 'tok_v' in masks:                                              # tok_drop_vis / tok_drop_aud in train mode: Dropout1d on (B, S, D) = whole tokens (sync_model.py:131-134, 160-161);
+        v, a = v * masks['tok_v'], a * masks['tok_a']                 # explicit multipliers (B, S, 1), already scaled by 1 / (1 - p)
     x = torch.cat([sd[p + '.OFF_tok'].expand(B, 1, -1), v, sd[p + '.MOD_tok'].expand(B, 1, -1), a], 1)
     x = x + sd[p + '.pos_emb_cfg.pos_emb'][:, :x.shape[1]]
-    masks = masks or {}
     if 'embd' in masks:                                               # self.drop(x) in train mode (sync_model.py:166)
         x = x * masks['embd']
     i = 0

@@ -101,6 +101,46 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     return OUT
 
 
+AB_DIR = PKG / 'lib' / 'ab'
+AB_OUT = AB_DIR / 'libsynchformer_hip_ablation.so'
+
+
+def build_ablation(force: bool = False, verbose: bool = True) -> Path:
+    """lib/ab/libsynchformer_hip_ablation.so: the same sources with -DSF_ABLATION, i.e. INCLUDING the measured-slower alternatives the product library no longer carries
+    (sf_gemm_bf16 tile configs 1-3, 5, 6, 8-10, 12; schedule 2 of sf_gemm_res_ln768).  Loaded explicitly by the bit-identity tests and the tools/ benchmarks
+    (`_lib.load_ablation()`), never by the package."""
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    obj = AB_DIR / 'obj'
+    obj.mkdir(parents=True, exist_ok=True)
+    hdrs = _headers()
+    flags = CFLAGS + ['-DSF_ABLATION']
+    stamp = obj / '.flags'
+    if not stamp.exists() or stamp.read_text() != ' '.join(flags):
+        force = True
+    jobs = [(src, obj / (src.stem + '.o')) for src in sources() if force or _stale(obj / (src.stem + '.o'), [src] + hdrs)]
+    if not jobs and AB_OUT.exists():
+        return AB_OUT
+
+    def compile_one(job):
+        cmd = [hipcc, *flags, '-c', str(job[0]), '-o', str(job[1])]
+        if verbose:
+            print('[build]', ' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(compile_one, jobs))
+    stamp.write_text(' '.join(flags))
+    tmp = AB_OUT.with_suffix('.so.tmp')
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *[str(obj / (s.stem + '.o')) for s in sources()], '-o', str(tmp)]
+    if verbose:
+        print('[build]', ' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(tmp, AB_OUT)
+    return AB_OUT
+
+
 if __name__ == '__main__':
     import sys
     build(force='--force' in sys.argv)
+    if '--ablation' in sys.argv:
+        build_ablation(force='--force' in sys.argv)

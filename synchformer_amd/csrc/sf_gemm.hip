@@ -568,6 +568,7 @@ static int dispatch_gemm_persistent(const GemmArgs& a, bool out_bf16, bool gelu,
   return res ? launch_gemm_persistent<false, false, true>(a, s) : launch_gemm_persistent<false, false, false>(a, s);
 }
 
+#ifdef SF_ABLATION   // measured-slower alternatives live in the ablation build only (synchformer_amd/build.py::build_ablation, tests load it explicitly)
 // =========================================================================================================
 // Config 10: the same persistent 256 x 256 x 64 tile on FOUR waves (one per SIMD), 128 x 128 accumulators each (256 registers: the
 // accumulator half of the unified file) - the wave shape the vendor library uses on these shapes.  Per k-tile a wave reads (128 + 128) x 64
@@ -769,6 +770,8 @@ static int dispatch_gemm_w4(const GemmArgs& a, bool out_bf16, bool gelu, bool re
   return res ? launch_gemm_w4<false, false, true>(a, s) : launch_gemm_w4<false, false, false>(a, s);
 }
 
+#endif  // SF_ABLATION
+
 //                 BM   BN  WM WN BK NS wg/CU
 typedef GemmCfg<128, 128, 2, 2, 64, 2, 2> Cfg0;   // 4 waves,  64 KiB: small-M GEMMs (AST, aggregators, sync, heads)
 typedef GemmCfg<256, 256, 2, 4, 64, 2, 1> Cfg1;   // 8 waves, 128 KiB, 2-stage
@@ -877,24 +880,33 @@ extern "C" int sf_gemm_bf16(const bf16_t* A, int64_t lda, const bf16_t* W, int64
   if (w_kmajor && cfg != 7 && cfg != 11) { sf_set_error("sf_gemm_bf16: only the persistent kernels (configs 7, 11) read a k-tile-major weight (forced config %d)", cfg); return -1; }
   switch (cfg) {
     case 0: return dispatch_gemm<Cfg0>(a, obf, gelu, res, fast, s);
+#ifdef SF_ABLATION
     case 1: return dispatch_gemm<Cfg1>(a, obf, gelu, res, fast, s);
     case 2: return dispatch_gemm<Cfg2>(a, obf, gelu, res, fast, s);
     case 3: return dispatch_gemm<Cfg3>(a, obf, gelu, res, fast, s);
-    case 4: return dispatch_gemm<Cfg4>(a, obf, gelu, res, fast, s);
     case 5: return dispatch_gemm<Cfg5>(a, obf, gelu, res, fast, s);
     case 6: return dispatch_gemm<Cfg6>(a, obf, gelu, res, fast, s);
     case 8: return dispatch_gemm<Cfg8>(a, obf, gelu, res, fast, s);
     case 9: return dispatch_gemm<Cfg9>(a, obf, gelu, res, fast, s);
+#else
+    case 1: case 2: case 3: case 5: case 6: case 8: case 9: case 10: case 12:
+      sf_set_error("sf_gemm_bf16: tile config %d is a measured-slower alternative that only the ablation build carries (libsynchformer_hip_ablation.so, -DSF_ABLATION); "
+                   "the product library holds configs 0 (128 x 128), 4 (batched), 7 and 11 (persistent 256 x 256)", cfg);
+      return -1;
+#endif
+    case 4: return dispatch_gemm<Cfg4>(a, obf, gelu, res, fast, s);
     case 7: if (!fast) { sf_set_error("sf_gemm_bf16: config 7 needs N %% 64 == 0"); return -1; }
             return dispatch_gemm_persistent(a, obf, gelu, res, s);
     case 11: if (!fast || !sf_gemm_pp_supported(a)) { sf_set_error("sf_gemm_bf16: config 11 needs N %% 64 == 0, K %% 128 == 0, K >= 256"); return -1; }
              return sf_gemm_pp_dispatch(a, obf, gelu, res, s);
+#ifdef SF_ABLATION
     case 10: if (!fast || w_kmajor || M * lda * 2 >= ((int64_t)1 << 32) || N * ldw * 2 >= ((int64_t)1 << 32)) {
               sf_set_error("sf_gemm_bf16: config 10 needs N %% 64 == 0, a row-major weight and operands below 4 GiB"); return -1; }
             return dispatch_gemm_w4(a, obf, gelu, res, s);
     case 12: if (!fast || !obf || res || !sf_gemm_r4_supported(a)) {
               sf_set_error("sf_gemm_bf16: config 12 needs a bf16 output without residual, N %% 128 == 0, K %% 128 == 0, K >= 256, row strides %% 64 == 0, a row-major weight"); return -1; }
             return sf_gemm_r4_dispatch(a, gelu, s);
+#endif
     default: sf_set_error("sf_gemm_bf16: unknown tile config %d", cfg); return -1;
   }
 }

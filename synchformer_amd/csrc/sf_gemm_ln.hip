@@ -534,8 +534,12 @@ extern "C" int sf_gemm_res_ln768(const bf16_t* A, int64_t lda, const bf16_t* W, 
     static int sched2 = -1;
     if (sched2 < 0) { const char* e = getenv("SF_RL_SCHED"); sched2 = (e ? atoi(e) : SF_RL_DEFAULT_SCHED) == 2 ? 1 : 0; }
     const bool want2 = g_rl_force_sched == 2 || (g_rl_force_sched < 0 && sched2);
+#ifdef SF_ABLATION
     if (want2 && !w_kmajor && (K % 128) == 0 && K >= 128 && (lda % 64) == 0 && (ldw % 64) == 0 && ldw >= K)
       return sf_gemm_res_ln768_v2_launch(A, lda, W, ldw, bias, R, ldr, X, ldx, gamma, beta, eps, Y, ldy, M, K, stream);
+#else
+    if (want2) { sf_set_error("sf_gemm_res_ln768: schedule 2 is a measured-slower alternative that only the ablation build carries (libsynchformer_hip_ablation.so, -DSF_ABLATION)"); return -1; }
+#endif
   }
   const int64_t m_pad = ((M + RL_BM - 1) / RL_BM) * RL_BM;
   // 32-bit byte offsets: buffer descriptors for R / X / Y (rows >= M are dropped by the hardware range check) and the lane offsets of the

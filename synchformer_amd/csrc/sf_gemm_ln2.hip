@@ -14,6 +14,7 @@
 // cross-workgroup exchange, no atomics.
 // MEASURED SLOWER than schedule 1 (proj 991 us against 672 us, fc2 2003 us against 1551 us at 224 segments: the epilogue is not hidden under a main loop, 7.15 rounds of
 // tiles; profiles/r04_experiments.md section 6): kept as the tested alternative behind sf_gemm_res_ln_force_schedule(2) / SF_RL_SCHED=2, not used by the engine.
+#ifdef SF_ABLATION   // schedule 2 of sf_gemm_res_ln768: a measured-slower alternative, compiled into the ablation build only
 #include "sf_common.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -394,3 +395,5 @@ int sf_gemm_res_ln768_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* 
   SF_LAUNCH_CHECK();
   return 0;
 }
+
+#endif  // SF_ABLATION

@@ -23,6 +23,7 @@
 // (no epilogue) 1048-1079 / 1372-1387 us.  The loop is bound by L2 -> LDS delivery (no-MFMA build: 865 us = 45 KB/us per CU, the same wall every GEMM of this library
 // sits on) next to an MFMA stream of the same length, and one wave per SIMD cannot run the VALU-bound GELU (256 elements per lane) under its own MFMAs: 4,500
 // instructions per tile against ~5 issue slots per MFMA gap x 768 MFMAs, and packed-fp32 VALU beside MFMAs is an anti-lever (MI355X_MICROARCH.md).
+#ifdef SF_ABLATION   // config 12: a measured-slower alternative, compiled into the ablation build only
 #include "sf_gemm_common.h"
 #include <type_traits>
 
@@ -397,3 +398,5 @@ bool sf_gemm_r4_supported(const GemmArgs& a) {
 int sf_gemm_r4_dispatch(const GemmArgs& a, bool gelu, hipStream_t s) {
   return gelu ? launch_gemm_r4<true>(a, s) : launch_gemm_r4<false>(a, s);
 }
+
+#endif  // SF_ABLATION

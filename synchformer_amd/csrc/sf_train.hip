@@ -685,6 +685,42 @@ extern "C" int sf_scale_seq_add(const float* x, int64_t ldx, const float* seq_sc
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Whole-token dropout of the sync transformer's inputs (GlobalTransformer.tok_drop_vis / tok_drop_aud: torch.nn.Dropout1d on (B, S, D) drops whole TOKENS,
+// sync_model.py:131-134, 160-161): y[ymap(r), :] (=|+=) row_scale[r] * x[xmap(r), :], fp32, row_scale[r] = 0 or 1 / (1 - p) per token (sf_dropout over a vector of
+// ones, as the stochastic-depth scales).  Forward: x = the input LayerNorm's rows (contiguous), y = the token matrix with the segment tokens' row map, accumulate on
+// top of the positional table; backward: x = the gradient of the token matrix read through the same map, y = the LayerNorm backward's dY rows.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scale_rows_map_kernel(const float* __restrict__ x, int64_t ldx, RowMap xmap, const float* __restrict__ row_scale,
+                                                              float* __restrict__ y, int64_t ldy, RowMap ymap, int64_t rows, int cols4, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols4) return;
+  const int64_t row = i / cols4;
+  const int c = (int)(i - row * cols4) * 4;
+  const float sc = row_scale[row];
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (sc != 0.f) {                                                  // a dropped token is not even read
+    v = *reinterpret_cast<const float4*>(x + map_row(xmap, row) * ldx + c);
+    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+  }
+  float* dst = y + map_row(ymap, row) * ldy + c;
+  if (accumulate) { const float4 t = *reinterpret_cast<const float4*>(dst); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+  *reinterpret_cast<float4*>(dst) = v;
+}
+
+extern "C" int sf_scale_rows_map(const float* x, int64_t ldx, const int64_t* x_map, const float* row_scale, float* y, int64_t ldy, const int64_t* y_map,
+                                 int64_t rows, int cols, int accumulate, void* stream) {
+  SF_CHECK_ARG(x && row_scale && y && cols >= 4 && (cols % 4) == 0, "sf_scale_rows_map: bad arguments");
+  SF_CHECK_ARG((ldx % 4) == 0 && (ldy % 4) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0, "sf_scale_rows_map: rows must be 16-byte aligned");
+  SF_CHECK_ARG(rows < ((int64_t)1 << 32), "sf_scale_rows_map: the row maps index 32-bit rows");
+  if (rows <= 0) return 0;
+  const int64_t n = rows * (cols / 4);
+  hipLaunchKernelGGL(scale_rows_map_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, sf_rowmap(x_map), row_scale, y, ldy,
+                     sf_rowmap(y_map), rows, cols / 4, accumulate);
+  SF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Head of a residual branch's backward (Stage-1 towers): from the fp32 gradient of the block output dx
 //     y[r, :]   = bf16( s[r / seq_rows] * dx[r, :] )              the dY operand of the proj / fc2 weight- and data-gradient GEMMs
 //     dbias[c]  (=|+=) sum_r s[r / seq_rows] * dx[r, c]           in fp32, BEFORE the rounding (biases are cancellation-prone)

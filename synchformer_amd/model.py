@@ -250,7 +250,7 @@ class GlobalTransformer(torch.nn.Module):
         if n_embd != 768 or n_head != 8:
             raise NotImplementedError('native sync transformer is built for n_embd=768, n_head=8 (configs/sync.yaml:44-46)')
         # whole-token dropout (sync_model.py:131-134, 160-161) acts in train() mode only: the value is kept, evaluation ignores it like the reference's
-        # Dropout1d in eval(); a TRAINING forward with tok_pdrop > 0 is refused (none of the configs sets it: sync.yaml:42, ft_synchability.yaml)
+        # Dropout1d in eval(); the TRAINING forward of Synchformer applies it (train.SyncTrainer.tok_pdrop: sf_scale_rows_map on the input norms' rows and on their gradient)
         self.tok_pdrop = float(tok_pdrop or 0.0)
         self.n_layer, self.n_head, self.n_embd = n_layer, n_head, n_embd
         self.pdrops = dict(embd_pdrop=embd_pdrop, resid_pdrop=resid_pdrop, attn_pdrop=attn_pdrop)
@@ -276,7 +276,8 @@ class GlobalTransformer(torch.nn.Module):
         """sync_model.py:150-173: logits (B, n_out) - or, with attempt_to_apply_heads=False, ln_f of ALL tokens (B, 2 + Sv + Sa, 768), which is what the
         reference's subclass asks its parent for (sync_model.py:187)."""
         if self.training and self.tok_pdrop > 0:                          # (the reference's Dropout1d drops tokens in train() mode whatever the grad mode, sync_model.py:131-134,160-161)
-            raise NotImplementedError('tok_pdrop > 0 in a training-mode forward (whole-token dropout) is not built; the configs use 0.0')
+            raise NotImplementedError('a STANDALONE GlobalTransformer.forward in train() mode runs the inference schedule (no dropout of any kind); whole-token dropout is '
+                                      'applied where training happens - Synchformer.forward with grad enabled (train.SyncTrainer, tok_pdrop) - or call .eval() here')
         eng = _engine_for(self, 'transformer.')
         B = v.shape[0]
         return eng.global_transformer(v.reshape(B, -1, self.n_embd).float(), a.reshape(B, -1, self.n_embd).float(), apply_head=bool(attempt_to_apply_heads))
@@ -465,8 +466,6 @@ class Synchformer(torch.nn.Module):
             raise NotImplementedError('only Stage-2 training with frozen extractors (is_trainable: False, configs/sync.yaml:7,19) has a '
                                       'backward; requires_grad_(False) the extractors as scripts/train_utils.py:199-204 does')
         pd = getattr(self.transformer, 'pdrops', {}) if self.transformer.training else {}
-        if self.transformer.training and getattr(self.transformer, 'tok_pdrop', 0.0) > 0:
-            raise NotImplementedError('tok_pdrop > 0 in a training forward (whole-token dropout, sync_model.py:160-161) is not built; the configs use 0.0')
         if any(not p.requires_grad for p in trainable.values()):
             raise NotImplementedError('partially frozen sync transformer is not supported')
         eng = self._engine(need_sync=False)
@@ -477,6 +476,7 @@ class Synchformer(torch.nn.Module):
             object.__setattr__(self, '_sf_trainer_key', None)
         tr.engine = eng
         tr.embd_pdrop, tr.resid_pdrop, tr.attn_pdrop = (float(pd.get(k) or 0.0) for k in ('embd_pdrop', 'resid_pdrop', 'attn_pdrop'))
+        tr.tok_pdrop = float(getattr(self.transformer, 'tok_pdrop', 0.0) or 0.0) if self.transformer.training else 0.0    # whole-token dropout (sync_model.py:131-134, 160-161)
         key = tuple((p.data_ptr(), p._version) for p in trainable.values())
         if key != self._sf_trainer_key:                      # an external optimizer moved the nn.Parameters
             tr.load_params({k: p.detach() for k, p in trainable.items()})

@@ -192,6 +192,22 @@ def make_masks(B: int, S: int = 14, seed: int = 1337, T: int = 16, H: int = 224,
     return torch.from_numpy(vm), torch.from_numpy(am)
 
 
+def make_masks_fused_case(B: int = 1, S: int = 6, seed: int = 77):
+    """The mask set of the fused-schedule token-mask parity case (tests/golden/e2e_masked_B1S6.npz, tests/test_e2e_gpu.py): `make_masks` plus, in clip 0,
+    segment 1: video frames 4-5 = one WHOLE token frame (all 196 keys of a space group masked for nobody, every time group loses one key);
+    segment 2: patches 0-3 in all 8 token frames = one whole wave of sf_qkv_time_attention2 (a CLS partial record with every key masked: m = -inf, l = 0);
+    segment 3: pixel columns 32-47 in every frame = one whole PATCH COLUMN (14 patches x 8 frames: 14 complete time groups masked, one key in 14 of every space group);
+    segment 4: patches 192-195 in all frames = the left-over rows both fused launches take from the side GEMM."""
+    vm, am = make_masks(B, S, seed)
+    vm[0, 1, 4:6] = False
+    vm[0, 2, :, :, 0:16, 0:64] = False
+    if S > 3:
+        vm[0, 3, :, :, :, 32:48] = False
+    if S > 4:
+        vm[0, 4, :, :, 208:224, 160:224] = False
+    return vm, am
+
+
 def make_targets(B: int, n_cls: int = 21, seed: int = 1337) -> torch.Tensor:
     g = _rng(seed, f'targets{B}')
     return torch.from_numpy(g.integers(0, n_cls, size=(B,), dtype=np.int64))

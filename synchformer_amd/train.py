@@ -381,8 +381,9 @@ class FlatTrainer:
 class SyncTrainer(FlatTrainer):
     def __init__(self, state_dict: Dict[str, torch.Tensor], device='cuda:0', lr: float = 2e-6, betas=(0.9, 0.999), eps: float = 1e-7,
                  max_clip_norm: float = 1.0, embd_pdrop: float = 0.0, resid_pdrop: float = 0.0, attn_pdrop: float = 0.0, seed: int = 1337,
-                 seg_chunk: int = 224, engine: Optional[SynchformerEngine] = None, fp8_towers: bool = False):
+                 seg_chunk: int = 224, engine: Optional[SynchformerEngine] = None, fp8_towers: bool = False, tok_pdrop: float = 0.0):
         self.embd_pdrop, self.resid_pdrop, self.attn_pdrop, self.seed = float(embd_pdrop or 0), float(resid_pdrop or 0), float(attn_pdrop or 0), seed
+        self.tok_pdrop = float(tok_pdrop or 0)            # whole-token dropout of the segment tokens (Dropout1d, sync_model.py:131-134, 160-161); every config uses 0.0
         self.fwd_count = 0
         self.engine = engine if engine is not None else SynchformerEngine(state_dict, torch.device(device), seg_chunk=seg_chunk,
                                                                           fp8_towers=fp8_towers)   # frozen extractors (MXFP8 GEMMs in the FT configuration)
@@ -393,10 +394,19 @@ class SyncTrainer(FlatTrainer):
         self.n_out = self.p[f'transformer.{self.head_name}.weight'].shape[0]
 
     def _site_seed(self, site: int) -> int:
-        """uint32 seed of dropout site `site` for the current forward pass (embd 0; block i: attn 1+3i, proj 2+3i, mlp 3+3i)."""
+        """uint32 seed of dropout site `site` for the current forward pass (embd 0; block i: attn 1+3i, proj 2+3i, mlp 3+3i; whole-token dropout: 1000 vis, 1001 aud)."""
         h = (self.seed * 0x9E3779B1 + self.fwd_count * 0x85EBCA6B + site * 0xC2B2AE35 + 0x165667B1) & 0xFFFFFFFF
         h ^= h >> 15
         return (h * 0x2C1B3C6D) & 0xFFFFFFFF
+
+    def _token_scales(self, tag: str, n: int, seed: int) -> torch.Tensor:
+        """(n,) fp32: 0 or 1 / (1 - tok_pdrop) per token - sf_dropout over a vector of ones, so the backward (and a recomputed forward) regenerates it from the seed."""
+        w = ((n + 3) // 4) * 4
+        ones = self._buf('tok_ones', (1, w), torch.float32)
+        ones.fill_(1.0)
+        sc = self._buf(f'{tag}_tok_scale', (1, w), torch.float32)
+        dropout(ones, sc, 1, w, self.tok_pdrop, seed)
+        return sc
 
     # ---- forward with saved activations ----------------------------------------------------------------------
     def _forward(self, vfeat, afeat):
@@ -419,11 +429,19 @@ class SyncTrainer(FlatTrainer):
         table[1 + Sv] += self.p[f'{t}.MOD_tok'][0, 0]
         x = self._buf('x0', (M, D), torch.float32)
         ops.broadcast_rows(x, table.contiguous(), n_seq=B, dst_seq_rows=L)
-        ops.layernorm(sv['v_proj'], self.p[f'{t}.vis_in_lnorm.weight'], self.p[f'{t}.vis_in_lnorm.bias'], x, EPS_SYNC,
-                      out_map=ops.rowmap(Sv, Sv, L, 0, 1, 1), accumulate=True)
-        ops.layernorm(sv['a_proj'], self.p[f'{t}.aud_in_lnorm.weight'], self.p[f'{t}.aud_in_lnorm.bias'], x, EPS_SYNC,
-                      out_map=ops.rowmap(Sa, Sa, L, 0, 1, 2 + Sv), accumulate=True)
         self.fwd_count += 1
+        for tag, ln, n_tok, off in (('v', 'vis_in_lnorm', Sv, 1), ('a', 'aud_in_lnorm', Sa, 2 + Sv)):
+            tokmap = ops.rowmap(n_tok, n_tok, L, 0, 1, off)
+            if self.tok_pdrop > 0:
+                # v, a = tok_drop_vis(v), tok_drop_aud(a) between the input norms and the concat (sync_model.py:158-163): Dropout1d on (B, S, D) zeroes whole tokens
+                # and scales the kept ones by 1 / (1 - p).  The norm's rows go to a buffer of their own and enter the token matrix through sf_scale_rows_map.
+                n = B * n_tok
+                lnout = self._buf(f'{tag}_lnout', (n, D), torch.float32)
+                ops.layernorm(sv[f'{tag}_proj'], self.p[f'{t}.{ln}.weight'], self.p[f'{t}.{ln}.bias'], lnout, EPS_SYNC)
+                sc = sv[f'{tag}_tok_scale'] = self._token_scales(tag, n, self._site_seed(1000 + (tag == 'a')))
+                _chk(_lib.load().sf_scale_rows_map(lnout.data_ptr(), D, None, sc.data_ptr(), x.data_ptr(), D, ops._map(tokmap), n, D, 1, _st()), 'sf_scale_rows_map')
+            else:
+                ops.layernorm(sv[f'{tag}_proj'], self.p[f'{t}.{ln}.weight'], self.p[f'{t}.{ln}.bias'], x, EPS_SYNC, out_map=tokmap, accumulate=True)
         if self.embd_pdrop > 0:                                                          # self.drop(x), sync_model.py:166
             sv['embd_seed'] = self._site_seed(0)
             dropout(x, x, M, D, self.embd_pdrop, sv['embd_seed'])
@@ -558,8 +576,14 @@ class SyncTrainer(FlatTrainer):
         self.g[f'{t}.MOD_tok'][0, 0].copy_(gtab[1 + Sv])
         for tag, ln, n_tok, off in (('v', 'vis_in_lnorm', Sv, 1), ('a', 'aud_in_lnorm', Sa, 2 + Sv)):
             dpr = self._buf('dproj', (B * n_tok, D), torch.float32)
-            ln_bwd(sv[f'{tag}_proj'], self.p[f'{t}.{ln}.weight'], dx, dpr, self.g[f'{t}.{ln}.weight'], self.g[f'{t}.{ln}.bias'], lnws, B * n_tok,
-                   EPS_SYNC, dy_map=ops.rowmap(n_tok, n_tok, L, 0, 1, off))
+            if f'{tag}_tok_scale' in sv:                                               # whole-token dropout: d(norm rows) = scale[token] * d(token matrix rows)
+                dln = self._buf(f'{tag}_dlnout', (B * n_tok, D), torch.float32)
+                _chk(_lib.load().sf_scale_rows_map(dx.data_ptr(), D, ops._map(ops.rowmap(n_tok, n_tok, L, 0, 1, off)), sv[f'{tag}_tok_scale'].data_ptr(),
+                                                   dln.data_ptr(), D, None, B * n_tok, D, 0, _st()), 'sf_scale_rows_map')
+                ln_bwd(sv[f'{tag}_proj'], self.p[f'{t}.{ln}.weight'], dln, dpr, self.g[f'{t}.{ln}.weight'], self.g[f'{t}.{ln}.bias'], lnws, B * n_tok, EPS_SYNC)
+            else:
+                ln_bwd(sv[f'{tag}_proj'], self.p[f'{t}.{ln}.weight'], dx, dpr, self.g[f'{t}.{ln}.weight'], self.g[f'{t}.{ln}.bias'], lnws, B * n_tok,
+                       EPS_SYNC, dy_map=ops.rowmap(n_tok, n_tok, L, 0, 1, off))
             cast_bf16(dpr, dy_b[:B * n_tok, :D], B * n_tok, D)
             self._lin_bwd(f'{tag}proj', dy_b[:B * n_tok, :D], sv[f'{tag}_in'], B * n_tok, need_dx=False)
 

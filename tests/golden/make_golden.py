@@ -417,6 +417,77 @@ def e2e_masked(B=1, S=2, gain=2.0):
     print('masked logits', logits, 'unmasked', logits_nomask, 'max diff', float((logits - logits_nomask).abs().max()))
 
 
+def e2e_masked_fused(B=1, S=6, gain=2.0, seed=77):
+    """token masks at a batch large enough for the FUSED launches (6 segments = 9,414 token rows >= engine.py's 128 * 64 threshold:
+    sf_qkv_space_attention_masked / sf_qkv_time_attention2_masked / sf_gemm_res_ln768) through the REAL reference (sync_model.py:72-89, vit_helper.py:107-141),
+    with one whole frame, one whole wave, one whole patch column and the left-over patches masked (synth.make_masks_fused_case)."""
+    n_pos = 2 + S * 14
+    model = ref_import.build_reference_synchformer(n_segments_tokens=n_pos)
+    model.load_state_dict(synth.make_state_dict(SEED, gain=gain, n_pos=n_pos), strict=True)
+    vis = rgb_frontend_ref(synth.make_video_u8(B, S, seed)).float()
+    aud = synth.make_spectrogram(B, S, seed)
+    vm, am = synth.make_masks_fused_case(B, S, seed)
+    names = ['vfeat_extractor.spatial_attn_agg', 'afeat_extractor.freq_attn_agg', 'vfeat_extractor.blocks.0', 'vfeat_extractor.blocks.11']
+    with torch.no_grad():
+        _, logits_nomask = model(vis, aud)
+    store, hooks = capture(model, names)
+    with torch.no_grad():
+        _, logits = model(vis, aud, vis_mask=vm, aud_mask=am)
+    for h in hooks:
+        h.remove()
+    out = dict(seed=np.int64(seed), B=np.int64(B), S=np.int64(S), gain=np.float64(gain), logits=logits.numpy(), logits_nomask=logits_nomask.numpy(),
+               vfeat=store['vfeat_extractor.spatial_attn_agg'].numpy(), afeat=store['afeat_extractor.freq_attn_agg'].numpy(),
+               vblock0_rows=store['vfeat_extractor.blocks.0'][:, TOK_V].numpy(), vblock11_rows=store['vfeat_extractor.blocks.11'][:, TOK_V].numpy())
+    np.savez_compressed(HERE / f'e2e_masked_B{B}S{S}.npz', **out)
+    print('masked (fused-schedule case) logits', logits, 'unmasked', logits_nomask, 'max diff', float((logits - logits_nomask).abs().max()))
+
+
+SYNC_HEAD_SCALE = 5.0     # 'trained' variant of the synchronizability fixture: sync_head.weight x this on top of gain-2 weights
+
+
+def syncability_state_dict(variant):
+    """The two inits of the syncability_logits fixture (configs/ft_synchability.yaml: 184-token pos_emb, 2-way sync_head): 'gain1' = the reference-like init;
+    'trained' = gain-2 weights with the head scaled so that l1 - l0 has a trained model's spread.  tests/test_e2e_gpu.py rebuilds the same dicts on the GPU box."""
+    if variant == 'gain1':
+        return synth.make_state_dict(SEED, n_pos=184, n_out=2, head='sync_head')
+    sd = synth.make_state_dict(SEED, gain=2.0, n_pos=184, n_out=2, head='sync_head')
+    sd['transformer.sync_head.weight'] = sd['transformer.sync_head.weight'] * SYNC_HEAD_SCALE
+    return sd
+
+
+def syncability_logits(n_clips=32, per=2, variants=('gain1', 'trained')):
+    """VERDICT r5 item 3b - BASELINE configs[4]'s Acc@1-parity number: `n_clips` structured 13-segment clips through the REAL reference with the
+    GlobalTransformerWithSyncabilityHead (sync_model.py:176-190), 2-way logits only, at the reference-like init and at a trained scale.  The GPU test asserts the
+    2-way argmax agreement and max |d(l1 - l0)| for the bf16 engine AND for the MXFP8 towers configs[4] runs on."""
+    out = dict(seed=np.int64(SEED), n_clips=np.int64(n_clips), head_scale=np.float64(SYNC_HEAD_SCALE))
+    part = Path(os.environ.get('SYNCABILITY_PARTIAL', '/tmp/syncability_logits_partial.npz'))          # resumable
+    done = dict(np.load(part)) if part.exists() else {}
+    for variant in variants:
+        model = None
+        rows = []
+        for c0 in range(0, n_clips, per):
+            key = f'{variant}_{c0}'
+            if key not in done:
+                if model is None:
+                    model = ref_import.build_reference_synchformer(n_segments_tokens=184, transformer_target='model.sync_model.GlobalTransformerWithSyncabilityHead')
+                    model.load_state_dict(syncability_state_dict(variant), strict=True)
+                    model.eval()
+                u8, aud = synth.make_structured_clips(c0, min(per, n_clips - c0), 13, SEED)
+                with torch.no_grad():
+                    _, logits = model(rgb_frontend_ref(u8).float(), aud)
+                done[key] = logits.numpy()
+                np.savez(part, **done)
+            rows.append(done[key])
+            print(variant, c0, rows[-1].tolist(), flush=True)
+        out['logits_' + variant] = np.concatenate(rows, 0)
+    import zlib
+    for c in (0, n_clips - 1):
+        u8, aud = synth.make_structured_clip(c, 13, SEED)
+        out[f'crc_vis_{c}'] = np.int64(zlib.crc32(u8.numpy().tobytes()))
+        out[f'crc_aud_{c}'] = np.int64(zlib.crc32(aud.numpy().tobytes()))
+    np.savez_compressed(HERE / f'syncability_logits_{n_clips}.npz', **out)
+
+
 LOGITS_HEAD_SCALE = 5.0   # 'trained' variant: off_head.weight x this on top of gain-2 weights -> top logit ~ 10 like the released model's (README.md:79)
 
 
@@ -545,5 +616,9 @@ if __name__ == '__main__':
         e2e_masked(1, 2)
     if 'checkpoints' in which:
         checkpoints()
+    if 'masked_fused' in which:                                           # ~1 min of CPU; not in the default list
+        e2e_masked_fused(1, 6)
+    if 'syncability_logits' in which:                                     # ~40 min of CPU (64 reference forwards of 13 segments); not in the default list
+        syncability_logits(int(os.environ.get('N_CLIPS', '32')))
     if 'logits_only' in which:                                            # ~25 min of CPU (64 reference forwards); not in the default list
         logits_only(int(os.environ.get('N_CLIPS', '32')))

@@ -1,7 +1,7 @@
 """Import the REAL reference (v-iashin/Synchformer at /root/reference) in the build container.
 
 Test-time helper only: used by tests/golden/make_golden.py (fixture generation) and by
-tests/test_oracle_vs_reference.py (skipped when /root/reference is absent, i.e. on the GPU box).
+tests/test_oracle_cpu.py::test_oracle_matches_real_reference (skipped when /root/reference is absent, i.e. on the GPU box).
 Nothing in the shipped package, bench.py or smoke() imports this file.
 
 Recipe = SURVEY.md Appendix A: shims for omegaconf/timm on sys.path, two transformers-5.x patches,

@@ -75,13 +75,20 @@ def test_argument_validation_without_gpu():
     rc = lib.sf_side_rows(p, 768, q, 768, 768, p, 6400, None, 0, 6, 1, 196, None)
     assert rc == -1 and b'come in pairs' in lib.sf_last_error()
     assert lib.sf_side_rows(p, 1536, q, 1536, 1536, None, 0, None, 0, 0, 0, 196, None) == 0
-    # config 12 of sf_gemm_bf16 serves bf16 outputs without residual only
+    # config 12 of sf_gemm_bf16 (ablation build only since round 6) serves bf16 outputs without residual only; the product library refuses it altogether
     lib.sf_gemm_force_config(12)
     try:
-        rc = lib.sf_gemm_bf16(p, 768, p, 768, None, q, 0, 768, None, None, 0, None, 0, 256, 768, 768, None)      # c_dtype 0 = fp32
-        assert rc == -1 and b'config 12' in lib.sf_last_error()
+        rc = lib.sf_gemm_bf16(p, 768, p, 768, None, q, 1, 768, None, None, 0, None, 0, 256, 768, 768, None)      # c_dtype 1 = bf16: a call config 12 would serve
+        assert rc == -1 and b'ablation build' in lib.sf_last_error()
     finally:
         lib.sf_gemm_force_config(-1)
+    ab = _lib.load_ablation()
+    ab.sf_gemm_force_config(12)
+    try:
+        rc = ab.sf_gemm_bf16(p, 768, p, 768, None, q, 0, 768, None, None, 0, None, 0, 256, 768, 768, None)       # c_dtype 0 = fp32
+        assert rc == -1 and b'config 12' in ab.sf_last_error()
+    finally:
+        ab.sf_gemm_force_config(-1)
 
 
 def test_no_cpu_fallback():

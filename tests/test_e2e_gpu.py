@@ -439,21 +439,37 @@ def test_token_masks_match_reference_golden(gpu):
 
 def test_masked_forward_on_the_fused_schedule(gpu):
     """Masks at a batch large enough for every fused launch (6 segments = 9414 token rows: sf_qkv_time_attention2_masked, sf_qkv_space_attention_masked,
-    sf_gemm_res_ln768): against the un-fused masked schedule of round 2 (which the real reference's golden pins at 2 segments), and an all-ones mask
-    bit-equal to no mask.  One whole frame and one whole 4-patch x 8-frame wave are masked on top of the random boxes, so that a CLS partial record with
-    every key masked (m = -inf, l = 0) goes through the combine."""
+    sf_gemm_res_ln768).  Round 6: against the REAL reference's masked forward on the same inputs (tests/golden/e2e_masked_B1S6.npz,
+    make_golden.py::e2e_masked_fused - sync_model.py:72-89, vit_helper.py:107-141) - logits, segment features, and token rows of blocks 0 and 11 -, then against
+    the un-fused masked schedule of round 2, and an all-ones mask bit-equal to no mask.  One whole frame, one whole 4-patch x 8-frame wave, one whole patch column
+    and the left-over patches 192-195 are masked on top of the random boxes (synth.make_masks_fused_case), so that CLS partial records and whole time groups with
+    every key masked (m = -inf, l = 0) go through the kernels."""
     import os
     from synchformer_amd import synth
     from synchformer_amd.engine import SynchformerEngine
-    B, S = 1, 6
-    sd = synth.make_state_dict(1337, gain=2.0, n_pos=2 + S * 14)
+    g = np.load(GOLD / 'e2e_masked_B1S6.npz')
+    B, S, seed = int(g['B']), int(g['S']), int(g['seed'])
+    assert (B, S) == (1, 6) and B * S * 1569 >= 128 * 64          # the fused launches' threshold (engine._visual_chunk)
+    sd = synth.make_state_dict(1337, gain=float(g['gain']), n_pos=2 + S * 14)
     eng = SynchformerEngine(sd, gpu)
-    u8, aud = synth.make_video_u8(B, S, 77), synth.make_spectrogram(B, S, 77)
-    vm, am = synth.make_masks(B, S, 77)
-    vm[0, 1, 4:6] = False                                                     # segment 1: frames 4-5 = one whole token frame
-    vm[0, 2, :, :, 0:16, 0:64] = False                                        # segment 2: patches 0-3 in all 8 token frames = one whole wave of the fused kernel
+    u8, aud = synth.make_video_u8(B, S, seed), synth.make_spectrogram(B, S, seed)
+    vm, am = synth.make_masks_fused_case(B, S, seed)
+    eng.capture_blocks = {}
+    vf = eng.extract_vfeats(u8.to(gpu), vm.to(gpu)).cpu()
+    blocks, eng.capture_blocks = eng.capture_blocks, None
+    af = eng.extract_afeats(aud.to(gpu), am.to(gpu)).cpu()
+    TOK_V = [0, 1, 2, 197, 1000, 1568]
+    ev = _rel_rms(vf.reshape(-1, 768), torch.from_numpy(g['vfeat']).reshape(-1, 768))
+    ea = _rel_rms(af.reshape(-1, 768), torch.from_numpy(g['afeat']).reshape(-1, 768))
+    e0 = _rel_rms(blocks[0].cpu().view(B * S, 1569, 768)[:, TOK_V], torch.from_numpy(g['vblock0_rows']))
+    e11 = _rel_rms(blocks[11].cpu().view(B * S, 1569, 768)[:, TOK_V], torch.from_numpy(g['vblock11_rows']))
     fused = eng.forward(u8.to(gpu), aud.to(gpu), vm.to(gpu), am.to(gpu))
     assert torch.isfinite(fused).all()
+    dl = (fused.cpu() - torch.from_numpy(g['logits'])).abs().max().item()
+    dref = float(np.abs(g['logits'] - g['logits_nomask']).max())
+    print(f'masked, fused launches vs the REAL reference: vfeat relrms {ev:.4f} afeat {ea:.4f} block0 rows {e0:.4f} block11 rows {e11:.4f} logits max {dl:.5f} '
+          f'(the masks move the reference logits by {dref:.3f})')
+    assert ev < 1.5e-2 and ea < 1.5e-2 and e0 < 1e-2 and e11 < 1.5e-2 and dl < 4e-2 and dref > 0.1       # bars of test_token_masks_match_reference_golden (gain-2 init)
     old = os.environ.get('SF_CLS_FUSION')
     os.environ['SF_CLS_FUSION'] = 'none'
     eng.fuse_time = False

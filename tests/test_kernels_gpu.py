@@ -29,12 +29,46 @@ def test_gemm_identity_asymmetric(gpu, gemm_cfg):
     torch.testing.assert_close(out.cpu(), w.t().contiguous(), rtol=0, atol=0)
 
 
+PRODUCT_CFGS = (-1, 0, 4, 7, 11)     # tile configurations of the product library; every other one is a measured-slower alternative of the ablation build (-DSF_ABLATION)
+
+
 @pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11], ids=['auto'] + [f'cfg{i}' for i in range(12)])
 def gemm_cfg(request, gpu):
     from synchformer_amd import _lib
-    _lib.load().sf_gemm_force_config(request.param)
-    yield request.param
-    _lib.load().sf_gemm_force_config(-1)
+    lib = _lib.load() if request.param in PRODUCT_CFGS else _lib.load_ablation()
+    with _lib.using(lib):
+        lib.sf_gemm_force_config(request.param)
+        yield request.param
+        lib.sf_gemm_force_config(-1)
+
+
+@pytest.fixture
+def ablation(gpu):
+    """ops.* launch into lib/ab/libsynchformer_hip_ablation.so for the duration of the test (schedule 2 of sf_gemm_res_ln768, config 10 / 12 of sf_gemm_bf16)."""
+    from synchformer_amd import _lib
+    with _lib.using(_lib.load_ablation()) as lib:
+        yield lib
+
+
+def test_product_library_refuses_ablation_only_alternatives(gpu):
+    """configs 1-3, 5, 6, 8-10, 12 of sf_gemm_bf16 and schedule 2 of sf_gemm_res_ln768 are not in libsynchformer_hip.so."""
+    from synchformer_amd import ops, _lib
+    lib = _lib.load()
+    a, w = torch.zeros(512, 768, device=gpu, dtype=torch.bfloat16), torch.zeros(768, 768, device=gpu, dtype=torch.bfloat16)
+    out = torch.empty(512, 768, device=gpu, dtype=torch.bfloat16)
+    for cfg in (1, 2, 3, 5, 6, 8, 9, 10, 12):
+        lib.sf_gemm_force_config(cfg)
+        try:
+            with pytest.raises(RuntimeError, match='ablation build'):
+                ops.gemm(a, w, None, out)
+        finally:
+            lib.sf_gemm_force_config(-1)
+    lib.sf_gemm_res_ln_force_schedule(2)
+    try:
+        with pytest.raises(RuntimeError, match='ablation build'):
+            ops.gemm_res_ln(a, w, None, torch.zeros(512, 768, device=gpu), torch.ones(768, device=gpu), torch.zeros(768, device=gpu), out, 1e-6)
+    finally:
+        lib.sf_gemm_res_ln_force_schedule(-1)
 
 
 @pytest.mark.parametrize('M,N,K', [(300, 768, 768), (9000, 768, 768), (8500, 2304, 768), (128, 2304, 768), (1000, 768, 3072), (257, 3072, 768), (5, 21, 768),
@@ -359,7 +393,7 @@ def test_gemm_res_ln_schedules_bitwise(gpu, M, K):
 
 
 @pytest.mark.parametrize('M,K', [(192 * 300 + 37, 768), (192 * 270 + 191, 3072), (192 * 256 + 1, 768), (100, 768), (192, 3072)])
-def test_gemm_res_ln_schedule2(gpu, M, K):
+def test_gemm_res_ln_schedule2(gpu, ablation, M, K):
     """Schedule 2 of sf_gemm_res_ln768 (round 4: 192-row tiles, two 384-column passes, the residual and the chunk exchange through LDS) against
     fp32 torch and against schedule 1 on the same operands: X to fp32 summation order, Y to one bf16 rounding; rows beyond M untouched; A rows beyond
     M poisoned (the ragged last tile clamps its reads); five repetitions bit-identical (a screen for LDS-DMA / ds_read ordering races)."""
@@ -817,10 +851,12 @@ def test_qkv_time_attention_schedules_bitwise(gpu, n_seq):
 
 
 @pytest.mark.parametrize('cfg', [7, 10, 11])
-def test_gemm_persistent_epilogues(gpu, cfg):
+def test_gemm_persistent_epilogues(gpu, request, cfg):
     """The persistent 256x256 kernels (8 waves, 4 waves) over several tile rounds with a ragged last row
     panel: GELU -> bf16 and in-place fp32 residual against fp32 torch on the same bf16 operands."""
     from synchformer_amd import ops, _lib
+    if cfg not in PRODUCT_CFGS:
+        request.getfixturevalue('ablation')           # config 10 (4 waves) lives in the ablation build
     M, N, K = 256 * 70 + 37, 768, 768
     a, w, b = _bf(_rand(M, K, seed=40)).to(gpu), _bf(_rand(N, K, seed=41, scale=0.05)).to(gpu), _rand(N, seed=42).to(gpu)
     lin = a.float() @ w.float().t() + b
@@ -874,7 +910,7 @@ def test_gemm_pp_bitwise_equals_config7(gpu, M, N, K, gelu, res):
     (8192 + 130, 768, 3072, True, True),            # long K
     (300, 128, 384, False, True),                   # one tile, N < 256: the wn = 1 waves of the tile's second column half have nothing to store
 ])
-def test_gemm_r4_bitwise_equals_config11(gpu, M, N, K, gelu, bias):
+def test_gemm_r4_bitwise_equals_config11(gpu, ablation, M, N, K, gelu, bias):
     """Config 12 (sf_gemm_w4.hip: four waves, register-resident fragments, one LDS-DMA piece behind every fourth MFMA) multiplies the same 32x32x16 blocks in the
     same k order as config 11 and runs the same bias / exact-erf GELU / bf16 rounding on them: bit-identical outputs on every repetition (the repetitions screen
     for LDS-DMA / ds_read ordering races of the landing ring); rows beyond M stay untouched."""

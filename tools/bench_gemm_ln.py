@@ -8,6 +8,7 @@ from synchformer_amd import ops, _lib
 import os
 
 dev = torch.device('cuda:0')
+_lib.using(_lib.load_ablation()).__enter__()      # schedule 2 lives in the ablation build (the product library refuses it)
 
 
 def timeit(fn, iters=6):
