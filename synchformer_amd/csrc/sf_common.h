@@ -69,8 +69,23 @@ __device__ __forceinline__ float f16_to_f32(uint16_t h) { return __half2float(__
 
 // ---- MXFP8 quantisation pieces shared by the kernels that write an MX operand themselves (the rule of sf_quantize_mxfp8) ------------
 // E8M0 byte of a 32-element block with absolute maximum `amax` (>= 0): its exponent - 8 (448 = 1.75 * 2^8), clamped to [1, 254]
+// SF_MX_SCALE_RULE - how a block's shared exponent follows its absolute maximum:
+//   0: the OCP Microscaling floor rule, e = floor(log2 amax) - 8: amax / 2^e lies in [256, 512), everything above 448 (the largest e4m3 normal) SATURATES - up to
+//      12.5 % off on the largest element of every fifth block, always towards zero;
+//   1: the no-saturation rule: one exponent up whenever amax / 2^e would exceed 448 (mantissa of amax above 1.75), so the block maximum is always representable; the
+//      other elements of such a block lose one bit.  Which of the two is the product rule, and what it does to the logits: DESIGN 4 / profiles/r06_mxfp8_scale_rule.md.
+#ifndef SF_MX_SCALE_RULE
+#define SF_MX_SCALE_RULE 0
+#endif
+// biased E8M0 exponent of a block with absolute maximum `amax` (>= 0), before clamping to the byte's range
+__device__ __forceinline__ int sf_mx_be(float amax) {
+  const uint32_t u = __float_as_uint(amax);
+  int be = (int)((u >> 23) & 0xff) - 8;
+  if (SF_MX_SCALE_RULE == 1) be += (u & 0x7fffffu) > 0x600000u ? 1 : 0;
+  return be;
+}
 __device__ __forceinline__ int sf_mx_exp(float amax) {
-  const int be = (int)((__float_as_uint(amax) >> 23) & 0xff) - 8;
+  const int be = sf_mx_be(amax);
   return be < 1 ? 1 : (be > 254 ? 254 : be);
 }
 // the reciprocal of that block scale, 2^(127 - be)

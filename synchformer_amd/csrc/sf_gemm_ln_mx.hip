@@ -434,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_res_ln768_kernel(MxResLnArgs p
           amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(amax), 0xB1, 0xF, 0xF, true)));
           amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(amax), 0x4E, 0xF, 0xF, true)));
           amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(amax), 0x141, 0xF, 0xF, true)));
-          int be = (int)((__float_as_uint(amax) >> 23) & 0xff) - 8;
+          int be = sf_mx_be(amax);
           be = be < 1 ? 1 : (be > 254 ? 254 : be);
           const float inv = __uint_as_float((uint32_t)(254 - be) << 23);
           int wq = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f0 * inv, 448.f, -448.f), __builtin_amdgcn_fmed3f(f1 * inv, 448.f, -448.f), 0, false);

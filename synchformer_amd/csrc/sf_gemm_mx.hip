@@ -118,7 +118,7 @@ __device__ __forceinline__ void mx_epi_store(float4 (&v)[NPS], const float4& bia
       amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(amax), 0xB1, 0xF, 0xF, true)));
       amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(amax), 0x4E, 0xF, 0xF, true)));
       amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(amax), 0x141, 0xF, 0xF, true)));
-      int be = (int)((__float_as_uint(amax) >> 23) & 0xff) - 8;
+      int be = sf_mx_be(amax);
       be = be < 1 ? 1 : (be > 254 ? 254 : be);
       const float inv = __uint_as_float((uint32_t)(254 - be) << 23);
       int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f0 * inv, 448.f, -448.f), __builtin_amdgcn_fmed3f(f1 * inv, 448.f, -448.f), 0, false);
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_pp_kernel(MxArgs p) {
               const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
               amax = fmaxf(__uint_as_float(sw2[0]), __uint_as_float(sw2[1]));
             }
-            int be = (int)((__float_as_uint(amax) >> 23) & 0xff) - 8;
+            int be = sf_mx_be(amax);
             be = be < 1 ? 1 : (be > 254 ? 254 : be);
             const float inv = __uint_as_float((uint32_t)(254 - be) << 23);
             be2 |= (uint32_t)be << (8 * j);
@@ -933,7 +933,7 @@ __global__ __launch_bounds__(256) void quantize_mxfp8_kernel(const bf16_t* __res
   }
 #pragma unroll
   for (int e = 0; e < 32; ++e) amax = fmaxf(amax, fabsf(v[e]));
-  int be = (int)((__float_as_uint(amax) >> 23) & 0xff) - 8;      // biased exponent of amax, minus emax(e4m3); subnormal / zero amax -> clamp
+  int be = sf_mx_be(amax);      // biased exponent of amax, minus emax(e4m3); subnormal / zero amax -> clamp
   if (be < 1) be = 1;
   if (be > 254) be = 254;
   const float inv = __uint_as_float((uint32_t)(254 - be) << 23);  // 2^-(be - 127)

@@ -35,6 +35,9 @@
 #define QT2_A_BYTES (QT2_ROWS * 128)     // 24 KiB: 192 rows x 64 k (bf16)
 #define QT2_W_PART (128 * 128)           // 16 KiB: 4 wave columns x 32 features x 64 k
 #define QT2_STAGE (QT2_A_BYTES + 3 * QT2_W_PART)   // 72 KiB
+#ifndef QT2_ABL_HALF
+#define QT2_ABL_HALF 0
+#endif
 #define QT2_ARR (QT2_ROWS * 128)         // one K / V / Q array: 192 rows of 128 B (24 KiB); the six arrays overlay the two operand stages exactly
 #define QT2_CB_OFF (6 * QT2_ARR)         // 144 KiB: CLS blocks Kc[2] | Vc[2] | Qc[2], 16 rows of 128 B each, row 0 = the sequence's CLS k / v / q of the head, rows 1..15 zero
 #define QT2_BIAS_OFF (QT2_CB_OFF + 6 * 2048)       // 156 KiB: the tile's 384 bias floats
@@ -355,7 +358,12 @@ __device__ __forceinline__ void qkv_time2_attn_body(const Qt2Args& p) {
               uint2 w;
               w.x = pack_bf2(acc[j][i][g * 4 + 0], acc[j][i][g * 4 + 1]);
               w.y = pack_bf2(acc[j][i][g * 4 + 2], acc[j][i][g * 4 + 3]);
+#if QT2_ABL_HALF   // measurement only (WRONG results): lanes l and l + 8 of a 16-lane store group share a 16-byte chunk slot - here they take different halves of it, which
+                   // makes the hand-over stores conflict-free: what do the 2-way conflicts of the product layout cost?  (profiles/r06_attention_fabric.md)
+              *reinterpret_cast<uint2*>(smem + arr + qt2_arr_off(rowp[i], (feat0 >> 3) + g) + (ehi ^ ((el31 >> 3) & 1)) * 8) = w;
+#else
               *reinterpret_cast<uint2*>(smem + arr + qt2_arr_off(rowp[i], (feat0 >> 3) + g) + ehi * 8) = w;
+#endif
             }
           }
         }

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void layernorm768_mxfp8_kernel(const float* __
     o.x = __uint_as_float(p01 << 16); o.y = __uint_as_float(p01 & 0xffff0000u); o.z = __uint_as_float(p23 << 16); o.w = __uint_as_float(p23 & 0xffff0000u);
     float amax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
     amax = fmaxf(amax, __shfl_xor(amax, 1, 64)); amax = fmaxf(amax, __shfl_xor(amax, 2, 64)); amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
-    int be = (int)((__float_as_uint(amax) >> 23) & 0xff) - 8;
+    int be = sf_mx_be(amax);
     be = be < 1 ? 1 : (be > 254 ? 254 : be);
     const float inv = __uint_as_float((uint32_t)(254 - be) << 23);
     int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(o.x * inv, 448.f, -448.f), __builtin_amdgcn_fmed3f(o.y * inv, 448.f, -448.f), 0, false);

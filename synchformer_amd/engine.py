@@ -82,6 +82,9 @@ class SynchformerEngine:
         self.fuse_mx_time = True                     # fp8 towers: sf_qkv_time_attention_mx instead of sf_gemm_mxfp8 + the time attention kernels
         self.fuse_mx_attn = os.environ.get('SF_MX_ATTN', '1') != '0'   # fp8 towers: the space attention writes MXFP8 itself (sf_attention_cls_partial_mx; off = bf16 output + sf_quantize_mxfp8)
         self.fuse_mx_ln = True                       # fp8 towers: sf_gemm_mx_res_ln768 instead of sf_gemm_mxfp8 + sf_layernorm768_mxfp8 (tests switch it off to compare)
+        # fp8 towers, mixed policy (measurement: DESIGN 4 / profiles/r06_mxfp8_policy.md): the Linears named here keep bf16 operands - 'proj' (both attention projections)
+        # and / or 'fc2'; their outputs are re-quantised by sf_quantize_mxfp8 for the next MX launch.  Empty = every big Linear on MXFP8 (the product's fp8_towers mode).
+        self.mx_bf16 = frozenset(x for x in os.environ.get('SF_MX_BF16', '').split(',') if x)
         self.capture_blocks = None          # tests: a dict -> the fp32 residual stream after each visual block is cloned into it (key = block index)
         self._ws = {}
         self.audio_side_stream = os.environ.get('SF_AUDIO_SIDE_STREAM', '1') != '0'
@@ -96,6 +99,12 @@ class SynchformerEngine:
         # again (profiles/r06_small_m.md).  Up to `vis_split_max` segments the visual tower therefore runs as TWO independent halves of the segments on two HIP
         # streams (segments are independent until vproj, motionformer.py:200-207): one half's one-round launches run beside the other half's multi-round ones.
         self.vis_split_max = int(os.environ.get('SF_VIS_SPLIT_MAX', '0'))
+        self.vis_split_min = int(os.environ.get('SF_VIS_SPLIT_MIN', '2'))
+        # experiment (profiles/r06_small_m.md): each half's persistent launches sized for this many CUs (0 = whole device), the second half started `vis_split_lag`
+        # launches of the first block behind the first (so that one half's HBM-bound projection runs beside the other half's matrix-bound launches)
+        self.vis_split_cus = int(os.environ.get('SF_VIS_SPLIT_CUS', '0'))
+        self.vis_split_lag = int(os.environ.get('SF_VIS_SPLIT_LAG', '0'))
+        self._lag_hook = None
         self._ws_tag = ''
         self._v_side = None
         self.load_weights(state_dict)
@@ -363,11 +372,15 @@ class SynchformerEngine:
                 ops.gemm(xn, b['t_qkv'].w, b['t_qkv'].b, qkv)
                 divided('time')
                 t_out = xn
+            if self._lag_hook is not None and self._ws_tag == '':
+                self._lag_hook(bi, 1)
             if fuse_ln:
                 ops.gemm_res_ln(t_out, b['t_proj'].wk, b['t_proj'].b, X, b['norm1'].g, b['norm1'].b, xn, EPS_VIS)
             else:
                 ops.gemm(t_out, b['t_proj'].w, b['t_proj'].b, X, residual=X)
                 ops.layernorm(X, b['norm1'].g, b['norm1'].b, xn, EPS_VIS)
+            if self._lag_hook is not None and self._ws_tag == '':
+                self._lag_hook(bi, 2)
             if fuse_space:
                 # spatial qkv + space attention in one launch (sf_qkv_space_attention): the 2304-wide projection never reaches HBM.  The rows the launch does not
                 # project itself - the CLS row and the last 4 tokens of every frame (196 = 6 x 32 + 4) - go through a 33-rows-per-segment GEMM up front.
@@ -380,12 +393,18 @@ class SynchformerEngine:
                 ops.gemm(xn, b['s_qkv'].w, b['s_qkv'].b, qkv)
                 divided('space')
                 s_out = xn
+            if self._lag_hook is not None and self._ws_tag == '':
+                self._lag_hook(bi, 3)
             if fuse_ln:
                 ops.gemm_res_ln(s_out, b['s_proj'].wk, b['s_proj'].b, X, b['norm2'].g, b['norm2'].b, xn, EPS_VIS)
             else:
                 ops.gemm(s_out, b['s_proj'].w, b['s_proj'].b, X, residual=X)
                 ops.layernorm(X, b['norm2'].g, b['norm2'].b, xn, EPS_VIS)
+            if self._lag_hook is not None and self._ws_tag == '':
+                self._lag_hook(bi, 4)
             ops.gemm(xn, b['fc1'].w, b['fc1'].b, hid, gelu=True)
+            if self._lag_hook is not None and self._ws_tag == '':
+                self._lag_hook(bi, 5)
             if fuse_ln and self.fuse_ln_fc2 and bi + 1 < nb:
                 nx = self.v_blocks[bi + 1]['norm3']
                 ops.gemm_res_ln(hid, b['fc2'].wk, b['fc2'].b, X, nx.g, nx.b, xn, EPS_VIS)
@@ -435,11 +454,24 @@ class SynchformerEngine:
             side = self._buf('side', n33 * 3 * D, torch.bfloat16).view(n33, 3 * D)
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         nb = len(self.v_blocks)
+        # mixed policy (self.mx_bf16): bf16 views of BIG for the attention output / the MLP hidden, as in the bf16 schedule
+        proj_bf16 = 'proj' in self.mx_bf16 and fuse and fuse_space and fuse_time2
+        fc2_bf16 = 'fc2' in self.mx_bf16 and fuse and rows >= 128 * 64
+        if proj_bf16 or fc2_bf16:
+            big = self._buf('BIG', n * 8 * AGG_V * FF, torch.bfloat16)
+            att_b, hid_b = big[:rows * D].view(rows, D), big[:rows * FF].view(rows, FF)
         for bi, b in enumerate(self.v_blocks):
             mx = b['mx']
             if bi == 0 or not fuse:
                 ops.layernorm_mxfp8(X, b['norm3'].g, b['norm3'].b, xq, xs, EPS_VIS)
-            if fuse_time2:
+            if fuse_time2 and proj_bf16:
+                ops.space_side_rows_mx(xq, xs, sq, ss, n)
+                ops.gemm_mxfp8(sq, ss, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, side)
+                ops.qkv_time_attention2_mx(xq, xs, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, side, att_b, part, n_seq=n, scale=0.125)
+                ops.attention_cls_combine(part, att_b, n_part=33, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
+                ops.gemm_res_ln(att_b, b['t_proj'].wk, b['t_proj'].b, X, b['norm1'].g, b['norm1'].b, xn, EPS_VIS)
+                ops.quantize_mxfp8(xn, xq, xs)
+            elif fuse_time2:
                 ops.space_side_rows_mx(xq, xs, sq, ss, n)
                 ops.gemm_mxfp8(sq, ss, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, side)
                 ops.qkv_time_attention2_mx(xq, xs, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, side, aq, part, n_seq=n, scale=0.125, out_scales=as_)
@@ -458,17 +490,27 @@ class SynchformerEngine:
             else:
                 ops.gemm_mxfp8(xq, xs, mx['t_qkv'].q, mx['t_qkv'].s, mx['t_qkv'].b, qkv)
                 divided('time')
-            if fuse_time and fuse_attn:
-                tq, ts = aq, as_
+            if fuse_time2 and proj_bf16:
+                pass                                                       # (projected and re-quantised above)
             else:
+                if fuse_time and fuse_attn:
+                    tq, ts = aq, as_
+                else:
+                    ops.quantize_mxfp8(xn, xq, xs)
+                    tq, ts = xq, xs
+                if fuse:
+                    ops.gemm_mx_res_ln(tq, ts, mx['t_proj'].q, mx['t_proj'].s, mx['t_proj'].b, X, b['norm1'].g, b['norm1'].b, xq, xs, EPS_VIS)
+                else:
+                    ops.gemm_mxfp8(tq, ts, mx['t_proj'].q, mx['t_proj'].s, mx['t_proj'].b, X, residual=X)
+                    ops.layernorm_mxfp8(X, b['norm1'].g, b['norm1'].b, xq, xs, EPS_VIS)
+            if fuse_space and proj_bf16:
+                ops.space_side_rows_mx(xq, xs, sq, ss, n)
+                ops.gemm_mxfp8(sq, ss, mx['s_qkv'].q, mx['s_qkv'].s, mx['s_qkv'].b, side)
+                ops.qkv_space_attention_mx(xq, xs, mx['s_qkv'].q, mx['s_qkv'].s, mx['s_qkv'].b, side, att_b, part, n_seq=n, scale=0.125)
+                ops.attention_cls_combine(part, att_b, n_part=8, n_seq=n, out_seq_rows=VIS_L, out_row=0, heads=12)
+                ops.gemm_res_ln(att_b, b['s_proj'].wk, b['s_proj'].b, X, b['norm2'].g, b['norm2'].b, xn, EPS_VIS)
                 ops.quantize_mxfp8(xn, xq, xs)
-                tq, ts = xq, xs
-            if fuse:
-                ops.gemm_mx_res_ln(tq, ts, mx['t_proj'].q, mx['t_proj'].s, mx['t_proj'].b, X, b['norm1'].g, b['norm1'].b, xq, xs, EPS_VIS)
-            else:
-                ops.gemm_mxfp8(tq, ts, mx['t_proj'].q, mx['t_proj'].s, mx['t_proj'].b, X, residual=X)
-                ops.layernorm_mxfp8(X, b['norm1'].g, b['norm1'].b, xq, xs, EPS_VIS)
-            if fuse_space:
+            elif fuse_space:
                 ops.space_side_rows_mx(xq, xs, sq, ss, n)
                 ops.gemm_mxfp8(sq, ss, mx['s_qkv'].q, mx['s_qkv'].s, mx['s_qkv'].b, side)
                 ops.qkv_space_attention_mx(xq, xs, mx['s_qkv'].q, mx['s_qkv'].s, mx['s_qkv'].b, side, aq, part, n_seq=n, scale=0.125, out_scales=as_)
@@ -487,11 +529,22 @@ class SynchformerEngine:
             else:
                 divided('space')
                 ops.quantize_mxfp8(xn, xq, xs)
-            if fuse:
+            if fuse_space and proj_bf16:
+                pass
+            elif fuse:
                 ops.gemm_mx_res_ln(pq, ps, mx['s_proj'].q, mx['s_proj'].s, mx['s_proj'].b, X, b['norm2'].g, b['norm2'].b, xq, xs, EPS_VIS)
             else:
                 ops.gemm_mxfp8(pq, ps, mx['s_proj'].q, mx['s_proj'].s, mx['s_proj'].b, X, residual=X)
                 ops.layernorm_mxfp8(X, b['norm2'].g, b['norm2'].b, xq, xs, EPS_VIS)
+            if fc2_bf16:
+                ops.gemm_mxfp8(xq, xs, mx['fc1'].q, mx['fc1'].s, mx['fc1'].b, hid_b, gelu=True)            # bf16 hidden
+                if bi + 1 < nb:
+                    nx = self.v_blocks[bi + 1]['norm3']
+                    ops.gemm_res_ln(hid_b, b['fc2'].wk, b['fc2'].b, X, nx.g, nx.b, xn, EPS_VIS)
+                    ops.quantize_mxfp8(xn, xq, xs)
+                else:
+                    ops.gemm(hid_b, b['fc2'].w, b['fc2'].b, X, residual=X)
+                continue
             ops.gemm_mxfp8(xq, xs, mx['fc1'].q, mx['fc1'].s, mx['fc1'].b, hq, gelu=True, out_scales=hs)
             if fuse and bi + 1 < nb:
                 nx = self.v_blocks[bi + 1]['norm3']
@@ -525,7 +578,7 @@ class SynchformerEngine:
                 raise ValueError(f'vis_mask {tuple(vis_mask.shape)} must have the shape of vis {tuple(vis.shape)}')
             keep = vis_mask.to(self.dev).to(torch.bool).reshape(vid.shape).contiguous()
         out = torch.empty(B * S * 8, D, device=self.dev, dtype=torch.float32)
-        if 2 <= B * S <= self.vis_split_max:
+        if max(2, self.vis_split_min) <= B * S <= self.vis_split_max:
             h = (B * S + 1) // 2
             self._two_halves(lambda: self._visual_chunk(vid[:h], out[:h * 8], keep=None if keep is None else keep[:h]),
                              lambda: self._visual_chunk(vid[h:], out[h * 8:], keep=None if keep is None else keep[h:]))
@@ -537,21 +590,47 @@ class SynchformerEngine:
 
     def _two_halves(self, first, second):
         """Run two independent sub-schedules side by side: `first` on the current stream, `second` on the engine's second visual stream with workspaces of its
-        own (`_ws_tag`); fork / join by events, so the pair captures into a HIP graph like any other part of the forward."""
+        own (`_ws_tag`); fork / join by events, so the pair captures into a HIP graph like any other part of the forward.  With `vis_split_cus` both halves' persistent
+        launches are sized for that many CUs (sf_set_cu_limit) and with `vis_split_lag` = k the second half starts behind the k-th launch group of the first half's
+        first block (the host issues `first` FIRST in that case: an event must be recorded before a stream can wait for it)."""
+        from . import _lib
         if self._v_side is None:
-            self._v_side, self._v_fork, self._v_join = torch.cuda.Stream(device=self.dev), torch.cuda.Event(), torch.cuda.Event()
+            self._v_side, self._v_fork, self._v_join, self._v_lag = torch.cuda.Stream(device=self.dev), torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         main = torch.cuda.current_stream()
-        self._v_fork.record(main)
-        with torch.cuda.stream(self._v_side):
-            self._v_side.wait_event(self._v_fork)
-            self._ws_tag = 'h1:'
-            try:
-                second()
-            finally:
-                self._ws_tag = ''
-            self._v_join.record(self._v_side)
-        first()
-        main.wait_event(self._v_join)
+        lib = _lib.load()
+        if self.vis_split_cus > 0:
+            lib.sf_set_cu_limit(self.vis_split_cus)
+        try:
+            self._v_fork.record(main)
+            lagged = self.vis_split_lag > 0
+            if lagged:
+                fired = []
+
+                def hook(bi, stage):
+                    if not fired and (bi, stage) >= (0, self.vis_split_lag):
+                        self._v_lag.record(main)
+                        fired.append(1)
+                self._lag_hook = hook
+                try:
+                    first()
+                finally:
+                    self._lag_hook = None
+                if not fired:
+                    self._v_lag.record(main)
+            with torch.cuda.stream(self._v_side):
+                self._v_side.wait_event(self._v_lag if lagged else self._v_fork)
+                self._ws_tag = 'h1:'
+                try:
+                    second()
+                finally:
+                    self._ws_tag = ''
+                self._v_join.record(self._v_side)
+            if not lagged:
+                first()
+            main.wait_event(self._v_join)
+        finally:
+            if self.vis_split_cus > 0:
+                lib.sf_set_cu_limit(0)
 
     # ------------------------------------------------------------------------------------------------
     # audio branch

@@ -4,8 +4,10 @@
 cd /tmp && export TMPDIR=/tmp
 FILT=$1; shift
 i=0
-for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" \
-           "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY" "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+#   PMC_GROUPS="FETCH_SIZE;WRITE_SIZE GRBM_GUI_ACTIVE" restricts the passes (';'-separated counter groups)
+DEFAULT_GROUPS="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU;SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT;SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY;FETCH_SIZE;WRITE_SIZE GRBM_GUI_ACTIVE;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
+IFS=';' read -ra GROUPS_ <<< "${PMC_GROUPS:-$DEFAULT_GROUPS}"
+for grp in "${GROUPS_[@]}"; do
   i=$((i+1)); rm -rf /tmp/pk$i
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pk$i -o f -- "$@" > /tmp/pk$i.log 2>&1
   f=$(find /tmp/pk$i -name '*counter_collection.csv' | head -1)
