@@ -34,11 +34,6 @@ int sf_abi_version(void);
 const char* sf_last_error(void);
 /* "gfx950" + build flags; lets the host assert it loaded the library it built */
 const char* sf_build_info(void);
-/* Workgroup budget of the calling thread's persistent launches (0 = the whole device): while n > 0 every persistent kernel of this library (the GEMM family, the fused
- * attention launches) sizes its grid for at most n CUs.  No counterpart in the reference (PyTorch's launches are not persistent); the engine uses it to run two
- * independent halves of a batch side by side on two HIP streams (engine.SynchformerEngine._two_halves). */
-void sf_set_cu_limit(int n);
-
 /* C[cmap(m), n] = epi(sum_k A[m,k] * W[n,k] + bias[n]) (+ R[rmap(m), n]);  A: M x K bf16 (row stride lda),
  * W: N x K bf16 (an nn.Linear / flattened conv weight, row stride ldw), bias fp32 or NULL, C bf16|fp32,
  * R fp32 or NULL (may alias C for an in-place residual).  K % 64 == 0.  Exact-erf GELU when SF_EPI_GELU.

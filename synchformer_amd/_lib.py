@@ -21,7 +21,6 @@ SIGNATURES = {
     'sf_abi_version': [],
     'sf_last_error': [],
     'sf_build_info': [],
-    'sf_set_cu_limit': [_i32],
     'sf_gemm_bf16': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i64, _ptr, _ptr, _i64, _ptr, _i32, _i64, _i64, _i64, _ptr],
     'sf_gemm_bf16_batched': [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _ptr, _ptr, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _ptr],
     'sf_gemm_tn_splitk': [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i32, _i64, _ptr],
@@ -108,7 +107,7 @@ SIGNATURES = {
     'sf_attention_cls_partial_masked': [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _ptr, _ptr, _ptr],
     'sf_attention_cls': [_ptr, _i64, _i32, _ptr, _ptr, _i64, _i64, _i32, _i32, _ptr, _i64, _i64, _i32, _i64, _i32, _i32, _f32, _ptr],
 }
-_RESTYPES = {'sf_set_cu_limit': None, 'sf_last_error': C.c_char_p, 'sf_build_info': C.c_char_p, 'sf_gemm_force_config': None, 'sf_gemm_res_ln_force_schedule': None, 'sf_qkv_time_force_schedule': None, 'sf_gemm_mx_force_schedule': None}
+_RESTYPES = {'sf_last_error': C.c_char_p, 'sf_build_info': C.c_char_p, 'sf_gemm_force_config': None, 'sf_gemm_res_ln_force_schedule': None, 'sf_qkv_time_force_schedule': None, 'sf_gemm_mx_force_schedule': None}
 
 _lib = None
 

@@ -23,7 +23,6 @@ extern "C" const char* sf_build_info(void) { return "libsynchformer_hip gfx950 (
 static std::mutex g_prep_mutex;
 static std::set<std::pair<const void*, int>> g_prepared;          // (kernel, device) whose dynamic-LDS limit has been raised
 static int g_cus[64] = {0};
-static thread_local int g_cu_limit = 0;
 
 int sf_prepare_kernel(const void* kernel, int lds_bytes, const char* who) {
   int dev = 0;
@@ -45,11 +44,5 @@ int sf_cu_count(const char* who) {
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { sf_set_error("%s: device query failed", who); return 0; }
     g_cus[dev] = prop.multiProcessorCount;
   }
-  const int lim = g_cu_limit;
-  return (lim > 0 && lim < g_cus[dev]) ? lim : g_cus[dev];
+  return g_cus[dev];
 }
-
-// Workgroup budget of the persistent launches of the CALLING THREAD: while > 0, every persistent kernel sizes its grid for at most this many CUs (rounded down to
-// whole XCDs by the launchers as usual).  Used by the engine when it runs two independent halves of a batch on two streams: two half-grid launches share the chip
-// instead of the second queueing behind the first (0 = the whole device).
-extern "C" void sf_set_cu_limit(int n) { g_cu_limit = n > 0 ? n : 0; }

@@ -94,17 +94,13 @@ class SynchformerEngine:
         self.fuse_space = os.environ.get('SF_FUSE_SPACE', '1') != '0'     # spatial qkv projection + space attention in one launch (sf_qkv_space_attention, round 4)
         self.fuse_time2 = os.environ.get('SF_FUSE_TIME2', '1') != '0'     # the temporal launch on the spatial kernel's 192 x 384 main loop (sf_qkv_time_attention2, round 4)
         self._a_side = None
-        # Small batches (BASELINE configs[0]: ONE clip = 14 segments, M = 21,966 rows): the launches of a block leave a fifth of the CU-time idle - 172 full-row tiles
-        # of sf_gemm_res_ln768 for 256 CUs, 4.03 / 2.95 / 2.6 rounds in fc1 / the two attention launches - and a tile cannot be made smaller without streaming W
-        # again (profiles/r06_small_m.md).  Up to `vis_split_max` segments the visual tower therefore runs as TWO independent halves of the segments on two HIP
-        # streams (segments are independent until vproj, motionformer.py:200-207): one half's one-round launches run beside the other half's multi-round ones.
-        self.vis_split_max = int(os.environ.get('SF_VIS_SPLIT_MAX', '0'))
-        self.vis_split_min = int(os.environ.get('SF_VIS_SPLIT_MIN', '2'))
-        # experiment (profiles/r06_small_m.md): each half's persistent launches sized for this many CUs (0 = whole device), the second half started `vis_split_lag`
-        # launches of the first block behind the first (so that one half's HBM-bound projection runs beside the other half's matrix-bound launches)
-        self.vis_split_cus = int(os.environ.get('SF_VIS_SPLIT_CUS', '0'))
-        self.vis_split_lag = int(os.environ.get('SF_VIS_SPLIT_LAG', '0'))
-        self._lag_hook = None
+        # Small batches: the launches of a block leave a fifth of the CU-time idle (one clip = 14 segments, M = 21,966 rows: 172 full-row tiles of sf_gemm_res_ln768
+        # for 256 CUs, 4.03 / 2.95 / 2.6 rounds in fc1 / the two attention launches), and a tile cannot be made smaller without streaming W again
+        # (profiles/r06_small_m.md).  Between `vis_split_min` and `vis_split_max` segments (two clips) the visual tower runs as TWO independent halves of the segments
+        # on two HIP streams (segments are independent until vproj, motionformer.py:200-207), one half's partial rounds beside the other's: -2 % eager / -4 % under a
+        # HIP graph at two clips; measured a LOSS at one clip (7 + 7 segments: twice the launches for 86-tile launches) and neutral at 16 clips, hence the window.
+        self.vis_split_min = int(os.environ.get('SF_VIS_SPLIT_MIN', '15'))
+        self.vis_split_max = int(os.environ.get('SF_VIS_SPLIT_MAX', '28'))
         self._ws_tag = ''
         self._v_side = None
         self.load_weights(state_dict)
@@ -372,15 +368,11 @@ class SynchformerEngine:
                 ops.gemm(xn, b['t_qkv'].w, b['t_qkv'].b, qkv)
                 divided('time')
                 t_out = xn
-            if self._lag_hook is not None and self._ws_tag == '':
-                self._lag_hook(bi, 1)
             if fuse_ln:
                 ops.gemm_res_ln(t_out, b['t_proj'].wk, b['t_proj'].b, X, b['norm1'].g, b['norm1'].b, xn, EPS_VIS)
             else:
                 ops.gemm(t_out, b['t_proj'].w, b['t_proj'].b, X, residual=X)
                 ops.layernorm(X, b['norm1'].g, b['norm1'].b, xn, EPS_VIS)
-            if self._lag_hook is not None and self._ws_tag == '':
-                self._lag_hook(bi, 2)
             if fuse_space:
                 # spatial qkv + space attention in one launch (sf_qkv_space_attention): the 2304-wide projection never reaches HBM.  The rows the launch does not
                 # project itself - the CLS row and the last 4 tokens of every frame (196 = 6 x 32 + 4) - go through a 33-rows-per-segment GEMM up front.
@@ -393,18 +385,12 @@ class SynchformerEngine:
                 ops.gemm(xn, b['s_qkv'].w, b['s_qkv'].b, qkv)
                 divided('space')
                 s_out = xn
-            if self._lag_hook is not None and self._ws_tag == '':
-                self._lag_hook(bi, 3)
             if fuse_ln:
                 ops.gemm_res_ln(s_out, b['s_proj'].wk, b['s_proj'].b, X, b['norm2'].g, b['norm2'].b, xn, EPS_VIS)
             else:
                 ops.gemm(s_out, b['s_proj'].w, b['s_proj'].b, X, residual=X)
                 ops.layernorm(X, b['norm2'].g, b['norm2'].b, xn, EPS_VIS)
-            if self._lag_hook is not None and self._ws_tag == '':
-                self._lag_hook(bi, 4)
             ops.gemm(xn, b['fc1'].w, b['fc1'].b, hid, gelu=True)
-            if self._lag_hook is not None and self._ws_tag == '':
-                self._lag_hook(bi, 5)
             if fuse_ln and self.fuse_ln_fc2 and bi + 1 < nb:
                 nx = self.v_blocks[bi + 1]['norm3']
                 ops.gemm_res_ln(hid, b['fc2'].wk, b['fc2'].b, X, nx.g, nx.b, xn, EPS_VIS)
@@ -590,47 +576,21 @@ class SynchformerEngine:
 
     def _two_halves(self, first, second):
         """Run two independent sub-schedules side by side: `first` on the current stream, `second` on the engine's second visual stream with workspaces of its
-        own (`_ws_tag`); fork / join by events, so the pair captures into a HIP graph like any other part of the forward.  With `vis_split_cus` both halves' persistent
-        launches are sized for that many CUs (sf_set_cu_limit) and with `vis_split_lag` = k the second half starts behind the k-th launch group of the first half's
-        first block (the host issues `first` FIRST in that case: an event must be recorded before a stream can wait for it)."""
-        from . import _lib
+        own (`_ws_tag`); fork / join by events, so the pair captures into a HIP graph like any other part of the forward."""
         if self._v_side is None:
-            self._v_side, self._v_fork, self._v_join, self._v_lag = torch.cuda.Stream(device=self.dev), torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            self._v_side, self._v_fork, self._v_join = torch.cuda.Stream(device=self.dev), torch.cuda.Event(), torch.cuda.Event()
         main = torch.cuda.current_stream()
-        lib = _lib.load()
-        if self.vis_split_cus > 0:
-            lib.sf_set_cu_limit(self.vis_split_cus)
-        try:
-            self._v_fork.record(main)
-            lagged = self.vis_split_lag > 0
-            if lagged:
-                fired = []
-
-                def hook(bi, stage):
-                    if not fired and (bi, stage) >= (0, self.vis_split_lag):
-                        self._v_lag.record(main)
-                        fired.append(1)
-                self._lag_hook = hook
-                try:
-                    first()
-                finally:
-                    self._lag_hook = None
-                if not fired:
-                    self._v_lag.record(main)
-            with torch.cuda.stream(self._v_side):
-                self._v_side.wait_event(self._v_lag if lagged else self._v_fork)
-                self._ws_tag = 'h1:'
-                try:
-                    second()
-                finally:
-                    self._ws_tag = ''
-                self._v_join.record(self._v_side)
-            if not lagged:
-                first()
-            main.wait_event(self._v_join)
-        finally:
-            if self.vis_split_cus > 0:
-                lib.sf_set_cu_limit(0)
+        self._v_fork.record(main)
+        with torch.cuda.stream(self._v_side):
+            self._v_side.wait_event(self._v_fork)
+            self._ws_tag = 'h1:'
+            try:
+                second()
+            finally:
+                self._ws_tag = ''
+            self._v_join.record(self._v_side)
+        first()
+        main.wait_event(self._v_join)
 
     # ------------------------------------------------------------------------------------------------
     # audio branch

@@ -168,6 +168,34 @@ def test_forward_through_the_dispatcher(gpu):
             assert d2.calls > 100 and not torch.equal(dm, direct)
 
 
+def test_two_stream_split_of_small_batches(gpu):
+    """Round 6: between 15 and 28 segments (two clips) the visual tower runs as two halves of the segments on two HIP streams with workspaces of their own
+    (engine._two_halves; profiles/r06_small_m.md).  The halves are independent until vproj, so the split changes launch geometry only: logits within the bar of
+    test_chunking_invariance's geometry case (tile configurations follow M), bit-identical on repetition, identical under a captured HIP graph, and one clip
+    (14 segments) / 16 clips keep the single-stream schedule."""
+    from synchformer_amd import synth
+    from synchformer_amd.engine import SynchformerEngine
+    sd = synth.make_state_dict(1337)
+    eng = SynchformerEngine(sd, gpu)
+    assert (eng.vis_split_min, eng.vis_split_max) == (15, 28)
+    u8, aud = synth.make_video_u8(2, 14, 5).to(gpu), synth.make_spectrogram(2, 14, 5).to(gpu)
+    split = eng.forward(u8, aud).clone()
+    assert eng._v_side is not None                                  # the second visual stream was used
+    assert torch.equal(eng.forward(u8, aud), split)
+    eng.vis_split_max = 0
+    single = eng.forward(u8, aud).clone()
+    eng.vis_split_max = 28
+    d = (split - single).abs().max().item()
+    print(f'two-stream split vs single stream, 2 clips: max |dlogit| {d:.5f}')
+    assert d < 8e-3
+    run = eng.capture(u8, aud)
+    assert torch.equal(run(u8, aud), split)
+    u1, a1 = u8[:1].contiguous(), aud[:1].contiguous()
+    eng2 = SynchformerEngine(sd, gpu)
+    eng2.forward(u1, a1)
+    assert eng2._v_side is None                                     # one clip: below the window
+
+
 def test_dispatcher_operators_check_their_buffers(gpu):
     """the C ABI sees raw pointers, so the public `torch.ops.synchformer.*` operators must refuse what would become a silent out-of-bounds device access or a
     reinterpreted buffer - wrong dtype, too few rows, partials too small, out aliasing x - exactly as the ctypes wrappers of ops.py do; and they launch on the tensor's device."""
