@@ -41,7 +41,7 @@ FLOP_PER_CLIP_EXECUTED = 5.725e12 - 0.247e12 - 0.014e12
 PEAK_BF16 = 2.5e15                # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_MXFP8 = 5.0e15               # dense MX-fp8 MFMA peak
 HBM_ACHIEVABLE = 6.3e12           # achievable HBM3E stream rate (MI355X_MICROARCH.md: 6.29 TB/s measured of 8 TB/s)
-TRAFFIC_FILE = 'profiles/r05_bench_roofline.json'
+TRAFFIC_FILE = 'profiles/r06_bench_roofline.json'
 
 
 def parse():
@@ -276,7 +276,7 @@ def pmc_traffic(kernel=None):
     """HBM bytes per launch from the committed PMC passes of this same command (tools/profile_bench.sh -> profiles/*_bench_roofline.json; counters cannot
     be read from inside the benchmark process): the NAMED kernel's own FETCH_SIZE (x2, gfx950) + WRITE_SIZE when the file carries a per-kernel table
     (r04 on), else the GEMM-family average labelled as such.  (value, source) or (None, None)."""
-    for f in (TRAFFIC_FILE, 'profiles/r04_bench_roofline.json', 'profiles/r03_bench_roofline.json', 'profiles/r02_bench_roofline.json', 'profiles/r01_bench_roofline.json'):
+    for f in (TRAFFIC_FILE, 'profiles/r05_bench_roofline.json', 'profiles/r04_bench_roofline.json', 'profiles/r03_bench_roofline.json', 'profiles/r02_bench_roofline.json', 'profiles/r01_bench_roofline.json'):
         try:
             with open(ROOT / f) as fh:
                 d = json.load(fh)
