@@ -572,6 +572,10 @@ extern "C" int sf_gemm_res_ln768(const bf16_t* A, int64_t lda, const bf16_t* W, 
   if (pp) {
     switch (abl) {     // ablations: 1 no residual, 2 no X stores, 4 no Y stores, 8 no refills after the first two stages, 16 no MFMA
       case 0: RL_LAUNCH(0, true, RP_LDS); break;
+#ifdef SF_ABLATION
+      case 1: RL_LAUNCH(1, true, RP_LDS); break;     // round 6: which part of the epilogue's memory traffic costs what (profiles/r06_gemm_ln_epilogue.md)
+      case 4: RL_LAUNCH(4, true, RP_LDS); break;
+#endif
       case 7: RL_LAUNCH(7, true, RP_LDS); break;
       case 15: RL_LAUNCH(15, true, RP_LDS); break;
       case 23: RL_LAUNCH(23, true, RP_LDS); break;
