@@ -594,7 +594,23 @@ def single_clip_and_dispatcher_legs(w, B, steps):
         calls = vd.calls
     cap = eng.capture(v1, mel(a1))
     graph_b1 = med_ms(lambda: cap(v1, mel(a1)))
-    return {'latency_b1_ms': {'eager': eager_b1, 'hip_graph': graph_b1, 'clips': 1, 'segments': w['S'],
+    # two clips = 28 segments: inside the window where a CAPTURED forward runs the visual tower as two halves on two HIP streams (engine._two_halves, round 6); beside it the
+    # same graph with the single-stream schedule and the eager forward (single stream: issued eagerly, twice the launches are a host cost that depends on the box)
+    b2 = None
+    if w['vis'].shape[0] >= 2:
+        v2, a2 = w['vis'][:2].contiguous(), w['aud'][:2].contiguous()
+        eager_b2 = med_ms(lambda: eng.forward(v2, mel(a2)))
+        cap2 = eng.capture(v2, mel(a2))
+        graph_split = med_ms(lambda: cap2(v2, mel(a2)))
+        keep, eng.vis_split_mode = eng.vis_split_mode, 'never'
+        try:
+            cap2s = eng.capture(v2, mel(a2))
+            graph_single = med_ms(lambda: cap2s(v2, mel(a2)))
+        finally:
+            eng.vis_split_mode = keep
+        b2 = {'eager': eager_b2, 'hip_graph': graph_split, 'hip_graph_single_stream': graph_single, 'clips': 2, 'segments': 2 * w['S']}
+    return {'latency_b2_ms': b2,
+            'latency_b1_ms': {'eager': eager_b1, 'hip_graph': graph_b1, 'clips': 1, 'segments': w['S'],
                               'what': 'one 14-segment clip, uint8 frames + waveform resident in HBM -> logits (mel front-end included), median of 15 synchronised forwards'},
             'dispatcher_route': {'ms_per_step_direct': direct_bB, 'ms_per_step_dispatcher': disp_bB, 'overhead_frac': round(disp_bB / direct_bB - 1.0, 4),
                                  'latency_b1_ms_dispatcher': disp_b1, 'latency_b1_ms_direct': eager_b1, 'clips_per_gpu': B, 'dispatcher_calls_counted': calls,
@@ -804,6 +820,7 @@ def main():
             try:
                 extra = single_clip_and_dispatcher_legs(w, B, max(args.workload_steps, 3))
                 out['latency_b1_ms'] = extra['latency_b1_ms']
+                out['latency_b2_ms'] = extra['latency_b2_ms']
                 wl_out['dispatcher_route'] = extra['dispatcher_route']
             except Exception as ex:                                # noqa: BLE001
                 out['latency_b1_ms'] = {'error': f'{type(ex).__name__}: {ex}'[:300]}

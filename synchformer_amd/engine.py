@@ -97,10 +97,14 @@ class SynchformerEngine:
         # Small batches: the launches of a block leave a fifth of the CU-time idle (one clip = 14 segments, M = 21,966 rows: 172 full-row tiles of sf_gemm_res_ln768
         # for 256 CUs, 4.03 / 2.95 / 2.6 rounds in fc1 / the two attention launches), and a tile cannot be made smaller without streaming W again
         # (profiles/r06_small_m.md).  Between `vis_split_min` and `vis_split_max` segments (two clips) the visual tower runs as TWO independent halves of the segments
-        # on two HIP streams (segments are independent until vproj, motionformer.py:200-207), one half's partial rounds beside the other's: -2 % eager / -4 % under a
-        # HIP graph at two clips; measured a LOSS at one clip (7 + 7 segments: twice the launches for 86-tile launches) and neutral at 16 clips, hence the window.
+        # on two HIP streams (segments are independent until vproj, motionformer.py:200-207), one half's partial rounds beside the other's: -4 % under a HIP graph at two
+        # clips; measured a LOSS at one clip (7 + 7 segments: twice the launches for 86-tile launches) and neutral at 16 clips, hence the window.
         self.vis_split_min = int(os.environ.get('SF_VIS_SPLIT_MIN', '15'))
         self.vis_split_max = int(os.environ.get('SF_VIS_SPLIT_MAX', '28'))
+        # 'graph' (default): only inside capture() - a replayed HIP graph has no per-launch host cost, there the split is a clean -4 %; issued eagerly the two halves are twice
+        # the launches for the host, and whether the GPU-side gain survives that depends on the box's CPU (measured -2 % on one box, +8 % on another).  'always' / 'never' override.
+        self.vis_split_mode = os.environ.get('SF_VIS_SPLIT', 'graph')
+        self._in_capture = False
         self._ws_tag = ''
         self._v_side = None
         self.load_weights(state_dict)
@@ -564,7 +568,8 @@ class SynchformerEngine:
                 raise ValueError(f'vis_mask {tuple(vis_mask.shape)} must have the shape of vis {tuple(vis.shape)}')
             keep = vis_mask.to(self.dev).to(torch.bool).reshape(vid.shape).contiguous()
         out = torch.empty(B * S * 8, D, device=self.dev, dtype=torch.float32)
-        if max(2, self.vis_split_min) <= B * S <= self.vis_split_max and self.capture_blocks is None:      # (the tests' per-block capture wants one chunk)
+        split_on = self.vis_split_mode == 'always' or (self.vis_split_mode == 'graph' and self._in_capture)
+        if split_on and max(2, self.vis_split_min) <= B * S <= self.vis_split_max and self.capture_blocks is None:      # (the tests' per-block capture wants one chunk)
             h = (B * S + 1) // 2
             self._two_halves(lambda: self._visual_chunk(vid[:h], out[:h * 8], keep=None if keep is None else keep[:h]),
                              lambda: self._visual_chunk(vid[h:], out[h * 8:], keep=None if keep is None else keep[h:]))
@@ -794,13 +799,17 @@ class SynchformerEngine:
         static_vis, static_aud = vis.clone(), aud.clone()
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
-        with torch.cuda.stream(side):                                # warm-up off the capture: workspaces, lazy function attributes
-            for _ in range(2):
-                self.forward(static_vis, static_aud)
-        torch.cuda.current_stream(self.dev).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_out = self.forward(static_vis, static_aud)
+        self._in_capture = True                                      # (the two-halves split of small batches is a graph-mode schedule: warm-up and capture both take it)
+        try:
+            with torch.cuda.stream(side):                            # warm-up off the capture: workspaces, lazy function attributes
+                for _ in range(2):
+                    self.forward(static_vis, static_aud)
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self.forward(static_vis, static_aud)
+        finally:
+            self._in_capture = False
         generation = getattr(self, '_sync_generation', 0)
 
         def run(v: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
