@@ -169,7 +169,7 @@ def test_forward_through_the_dispatcher(gpu):
 
 
 def test_two_stream_split_of_small_batches(gpu):
-    """Round 6: between 15 and 28 segments (two clips) a CAPTURED forward runs the visual tower as two halves of the segments on two HIP streams with workspaces of their
+    """Round 6: between 15 and 112 segments (two to eight clips) a CAPTURED forward runs the visual tower as two halves of the segments on two HIP streams with workspaces of their
     own (engine._two_halves; profiles/r06_small_m.md; eager forwards keep one stream unless vis_split_mode = 'always': issued eagerly the doubled launch count is a host
     cost).  The halves are independent until vproj, so the split changes launch geometry only: logits within the bar of test_benchmarked_geometry_parity's geometry case
     (tile configurations follow M), bit-identical on repetition, the graph replays them bit for bit, and one clip keeps the single-stream schedule."""
@@ -177,7 +177,7 @@ def test_two_stream_split_of_small_batches(gpu):
     from synchformer_amd.engine import SynchformerEngine
     sd = synth.make_state_dict(1337)
     eng = SynchformerEngine(sd, gpu)
-    assert (eng.vis_split_min, eng.vis_split_max, eng.vis_split_mode) == (15, 28, 'graph')
+    assert (eng.vis_split_min, eng.vis_split_max, eng.vis_split_mode) == (15, 112, 'graph')
     u8, aud = synth.make_video_u8(2, 14, 5).to(gpu), synth.make_spectrogram(2, 14, 5).to(gpu)
     single = eng.forward(u8, aud).clone()
     assert eng._v_side is None                                      # eager: one stream
