@@ -96,10 +96,10 @@ class SynchformerEngine:
         self._a_side = None
         # Small batches: the launches of a block leave a fifth of the CU-time idle (one clip = 14 segments, M = 21,966 rows: 172 full-row tiles of sf_gemm_res_ln768
         # for 256 CUs, 4.03 / 2.95 / 2.6 rounds in fc1 / the two attention launches), and a tile cannot be made smaller without streaming W again
-        # (profiles/r06_small_m.md).  Between `vis_split_min` and `vis_split_max` segments (two to eight clips) the visual tower runs as TWO independent halves of the segments
+        # (profiles/r06_small_m.md).  Between `vis_split_min` and `vis_split_max` segments (one to eight clips) the visual tower runs as TWO independent halves of the segments
         # on two HIP streams (segments are independent until vproj, motionformer.py:200-207), one half's partial rounds beside the other's: under a HIP graph -7 % at two clips,
-        # -5 % at three, -1..2 % at four to eight, +0.3 % at sixteen (tools/r06_split_window.py); at one clip (7 + 7 segments) two boxes disagreed (-2.5 % / +2 %): hence the window.
-        self.vis_split_min = int(os.environ.get('SF_VIS_SPLIT_MIN', '15'))
+        # -5 % at three, -1..2 % at four to eight, +0.3 % at sixteen, -1.2 .. -2.5 % at one clip on three boxes (tools/r06_split_window.py): hence the window.
+        self.vis_split_min = int(os.environ.get('SF_VIS_SPLIT_MIN', '14'))
         self.vis_split_max = int(os.environ.get('SF_VIS_SPLIT_MAX', '112'))
         # 'graph' (default): only inside capture() - a replayed HIP graph has no per-launch host cost, there the split is a clean -4 %; issued eagerly the two halves are twice
         # the launches for the host, and whether the GPU-side gain survives that depends on the box's CPU (measured -2 % on one box, +8 % on another).  'always' / 'never' override.

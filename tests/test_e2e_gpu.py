@@ -169,15 +169,15 @@ def test_forward_through_the_dispatcher(gpu):
 
 
 def test_two_stream_split_of_small_batches(gpu):
-    """Round 6: between 15 and 112 segments (two to eight clips) a CAPTURED forward runs the visual tower as two halves of the segments on two HIP streams with workspaces of their
+    """Round 6: between 14 and 112 segments (one to eight clips) a CAPTURED forward runs the visual tower as two halves of the segments on two HIP streams with workspaces of their
     own (engine._two_halves; profiles/r06_small_m.md; eager forwards keep one stream unless vis_split_mode = 'always': issued eagerly the doubled launch count is a host
     cost).  The halves are independent until vproj, so the split changes launch geometry only: logits within the bar of test_benchmarked_geometry_parity's geometry case
-    (tile configurations follow M), bit-identical on repetition, the graph replays them bit for bit, and one clip keeps the single-stream schedule."""
+    (tile configurations follow M), bit-identical on repetition, the graph replays them bit for bit; fewer than 14 segments keep the single-stream schedule."""
     from synchformer_amd import synth
     from synchformer_amd.engine import SynchformerEngine
     sd = synth.make_state_dict(1337)
     eng = SynchformerEngine(sd, gpu)
-    assert (eng.vis_split_min, eng.vis_split_max, eng.vis_split_mode) == (15, 112, 'graph')
+    assert (eng.vis_split_min, eng.vis_split_max, eng.vis_split_mode) == (14, 112, 'graph')
     u8, aud = synth.make_video_u8(2, 14, 5).to(gpu), synth.make_spectrogram(2, 14, 5).to(gpu)
     single = eng.forward(u8, aud).clone()
     assert eng._v_side is None                                      # eager: one stream
@@ -192,10 +192,10 @@ def test_two_stream_split_of_small_batches(gpu):
     run = eng.capture(u8, aud)                                      # the captured forward takes the split
     assert torch.equal(run(u8, aud), split)
     assert torch.equal(eng.forward(u8, aud), single)                # ... and leaves the eager schedule alone
-    u1, a1 = u8[:1].contiguous(), aud[:1].contiguous()
-    eng2 = SynchformerEngine(sd, gpu)
+    u1, a1 = u8[:1, :6].contiguous(), aud[:1, :6].contiguous()
+    eng2 = SynchformerEngine(synth.make_state_dict(1337, n_pos=2 + 6 * 14), gpu)
     run1 = eng2.capture(u1, a1)
-    assert eng2._v_side is None and torch.isfinite(run1(u1, a1)).all()      # one clip: below the window, also under capture
+    assert eng2._v_side is None and torch.isfinite(run1(u1, a1)).all()      # 6 segments: below the window, also under capture
 
 
 def test_dispatcher_operators_check_their_buffers(gpu):

@@ -21,7 +21,7 @@ def med(fn, n=15):
     return 1e3 * sorted(ts)[n // 2]
 
 
-for B in (1, 2, 3, 4, 6, 8, 16):
+for B in ((1, 1, 1, 2) if len(sys.argv) > 1 and sys.argv[1] == "b1" else (1, 2, 3, 4, 6, 8, 16)):
     vis, aud = synth.make_video_u8(B, 14, 3).to(dev), synth.make_spectrogram(B, 14, 3).to(dev)
     out = {}
     for mode in ('never', 'always'):
