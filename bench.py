@@ -594,7 +594,7 @@ def single_clip_and_dispatcher_legs(w, B, steps):
         calls = vd.calls
     cap = eng.capture(v1, mel(a1))
     graph_b1 = med_ms(lambda: cap(v1, mel(a1)))
-    # two clips = 28 segments: inside the window where a CAPTURED forward runs the visual tower as two halves on two HIP streams (engine._two_halves, round 6); beside it the
+    # two clips = 28 segments: inside the window where a CAPTURED forward runs the visual tower as two halves on two HIP streams (engine._parts, round 6); beside it the
     # same graph with the single-stream schedule and the eager forward (single stream: issued eagerly, twice the launches are a host cost that depends on the box)
     b2 = None
     if w['vis'].shape[0] >= 2:

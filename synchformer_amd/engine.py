@@ -105,6 +105,7 @@ class SynchformerEngine:
         # the launches for the host, and whether the GPU-side gain survives that depends on the box's CPU (measured -2 % on one box, +8 % on another).  'always' / 'never' override.
         self.vis_split_mode = os.environ.get('SF_VIS_SPLIT', 'graph')
         self._in_capture = False
+        self.vis_split_parts = int(os.environ.get('SF_VIS_SPLIT_PARTS', '2'))
         self._ws_tag = ''
         self._v_side = None
         self.load_weights(state_dict)
@@ -570,32 +571,38 @@ class SynchformerEngine:
         out = torch.empty(B * S * 8, D, device=self.dev, dtype=torch.float32)
         split_on = self.vis_split_mode == 'always' or (self.vis_split_mode == 'graph' and self._in_capture)
         if split_on and max(2, self.vis_split_min) <= B * S <= self.vis_split_max and self.capture_blocks is None:      # (the tests' per-block capture wants one chunk)
-            h = (B * S + 1) // 2
-            self._two_halves(lambda: self._visual_chunk(vid[:h], out[:h * 8], keep=None if keep is None else keep[:h]),
-                             lambda: self._visual_chunk(vid[h:], out[h * 8:], keep=None if keep is None else keep[h:]))
+            n, k = B * S, self.vis_split_parts
+            cuts = [(n * i + k - 1) // k for i in range(k + 1)]
+            self._parts([(lambda lo=lo, hi=hi: self._visual_chunk(vid[lo:hi], out[lo * 8:hi * 8], keep=None if keep is None else keep[lo:hi]))
+                         for lo, hi in zip(cuts[:-1], cuts[1:]) if hi > lo])
             return out.view(B, S, 8, D)
         for s0 in range(0, B * S, self.seg_chunk):
             n = min(self.seg_chunk, B * S - s0)
             self._visual_chunk(vid[s0:s0 + n], out[s0 * 8:(s0 + n) * 8], keep=None if keep is None else keep[s0:s0 + n])
         return out.view(B, S, 8, D)
 
-    def _two_halves(self, first, second):
-        """Run two independent sub-schedules side by side: `first` on the current stream, `second` on the engine's second visual stream with workspaces of its
-        own (`_ws_tag`); fork / join by events, so the pair captures into a HIP graph like any other part of the forward."""
+    def _parts(self, fns):
+        """Run independent sub-schedules side by side: fns[0] on the current stream, the others on the engine's further visual streams with workspaces of their own
+        (`_ws_tag`); fork / join by events, so the set captures into a HIP graph like any other part of the forward."""
         if self._v_side is None:
-            self._v_side, self._v_fork, self._v_join = torch.cuda.Stream(device=self.dev), torch.cuda.Event(), torch.cuda.Event()
+            self._v_side, self._v_fork = [], torch.cuda.Event()
+        while len(self._v_side) < len(fns) - 1:
+            self._v_side.append((torch.cuda.Stream(device=self.dev), torch.cuda.Event()))
         main = torch.cuda.current_stream()
         self._v_fork.record(main)
-        with torch.cuda.stream(self._v_side):
-            self._v_side.wait_event(self._v_fork)
-            self._ws_tag = 'h1:'
-            try:
-                second()
-            finally:
-                self._ws_tag = ''
-            self._v_join.record(self._v_side)
-        first()
-        main.wait_event(self._v_join)
+        for i, fn in enumerate(fns[1:]):
+            side, join = self._v_side[i]
+            with torch.cuda.stream(side):
+                side.wait_event(self._v_fork)
+                self._ws_tag = f'h{i + 1}:'
+                try:
+                    fn()
+                finally:
+                    self._ws_tag = ''
+                join.record(side)
+        fns[0]()
+        for i in range(len(fns) - 1):
+            main.wait_event(self._v_side[i][1])
 
     # ------------------------------------------------------------------------------------------------
     # audio branch

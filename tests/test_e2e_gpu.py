@@ -170,7 +170,7 @@ def test_forward_through_the_dispatcher(gpu):
 
 def test_two_stream_split_of_small_batches(gpu):
     """Round 6: between 14 and 112 segments (one to eight clips) a CAPTURED forward runs the visual tower as two halves of the segments on two HIP streams with workspaces of their
-    own (engine._two_halves; profiles/r06_small_m.md; eager forwards keep one stream unless vis_split_mode = 'always': issued eagerly the doubled launch count is a host
+    own (engine._parts; profiles/r06_small_m.md; eager forwards keep one stream unless vis_split_mode = 'always': issued eagerly the doubled launch count is a host
     cost).  The halves are independent until vproj, so the split changes launch geometry only: logits within the bar of test_benchmarked_geometry_parity's geometry case
     (tile configurations follow M), bit-identical on repetition, the graph replays them bit for bit; fewer than 14 segments keep the single-stream schedule."""
     from synchformer_amd import synth

@@ -21,12 +21,12 @@ def med(fn, n=15):
     return 1e3 * sorted(ts)[n // 2]
 
 
-for B in ((1, 1, 1, 2) if len(sys.argv) > 1 and sys.argv[1] == "b1" else (1, 2, 3, 4, 6, 8, 16)):
+for B in ((1, 1, 2) if len(sys.argv) > 1 and sys.argv[1] == "b1" else (1, 2, 3, 4, 6, 8, 16)):
     vis, aud = synth.make_video_u8(B, 14, 3).to(dev), synth.make_spectrogram(B, 14, 3).to(dev)
     out = {}
-    for mode in ('never', 'always'):
-        eng.vis_split_mode = mode
+    for mode, parts in (('never', 1), ('always', 2), ('always', 3), ('always', 4)):
+        eng.vis_split_mode, eng.vis_split_parts = mode, max(parts, 2)
         run = eng.capture(vis, aud)
-        out[mode] = med(lambda: run(vis, aud))
+        out[parts] = med(lambda: run(vis, aud))
         del run
-    print(f'{B:2d} clips ({B * 14:3d} segments): graph single stream {out["never"]:8.3f} ms | two halves {out["always"]:8.3f} ms | {100 * (out["always"] / out["never"] - 1):+5.1f} %', flush=True)
+    print(f'{B:2d} clips ({B * 14:3d} segments): graph single stream {out[1]:8.3f} ms | 2 parts {out[2]:8.3f} ({100 * (out[2] / out[1] - 1):+5.1f} %) | 3 parts {out[3]:8.3f} ({100 * (out[3] / out[1] - 1):+5.1f} %) | 4 parts {out[4]:8.3f} ({100 * (out[4] / out[1] - 1):+5.1f} %)', flush=True)
