@@ -82,14 +82,6 @@ class AVCLIPTrainer(FlatTrainer):
         self.fuse_branch = os.environ.get('SF_FUSE_BRANCH', '1') != '0'
         self._pre_dy = {}
         self.two_streams = os.environ.get('SF_STAGE1_TWO_STREAMS', '1') != '0'   # audio tower next to the visual one (forward_backward)
-        # round 6: the visual tower's forward and backward as TWO halves of the segments on two HIP streams (single rank, two_streams mode): one half's partial tile rounds
-        # and HBM-bound passes run beside the other half's launches (at M = 43,932 the config-11 GEMMs are 2.02 / 6.05 / 8.06 rounds).  The second half writes its parameter
-        # gradients into a second flat buffer (every gradient is written with '=': no ordering between the halves), summed into flat_g once at the end.
-        self.vis_split = os.environ.get('SF_S1_SPLIT', '1') != '0'
-        self.vis_split_window = (12, 64)                                   # segments per rank: halves of >= 6 segments keep every launch on its large-M path
-        self._vside = None
-        self.flat_g2 = self.g2 = None
-        self._dp_full = self._dp_slice = None
         self._side = None
         self._ls_host = self._ls_ev = None  # pinned host mirror of logit_scale + the event behind its copy (forward_backward / _head)
         self._ls_pending = False
@@ -136,9 +128,6 @@ class AVCLIPTrainer(FlatTrainer):
     def _dp_scales(self, block: int, site: int, n: int):
         """Per-segment branch scales (0 or 1 / keep) of DropPath site `site` (0 = space attention, 1 = MLP) of visual block `block` for the current
         forward pass, or None when that site is inactive.  sf_dropout over a vector of ones: counter-based, so the backward needs no saved mask."""
-        if self._dp_full is not None:                                          # a half of a split step: its slice of the whole batch's scales (drawn once, before the fork)
-            full = self._dp_full[(block, site)]
-            return None if full is None else full[:, self._dp_slice[0]:self._dp_slice[1]]
         p_ = self.drop_path_rate * block / max(1, self.n_vblocks - 1)
         if p_ <= 0.0:
             return None
@@ -686,13 +675,7 @@ class AVCLIPTrainer(FlatTrainer):
             aout = self._fwd_audio(aud3)
             self._ws_prefix = ''
             self._ev[1].record(side)
-        vid = vis.reshape(n, *vis.shape[2:])
-        world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
-        split = self.vis_split and world == 1 and self.vis_split_window[0] <= n <= self.vis_split_window[1]
-        if split:
-            vout, halves = self._fwd_visual_halves(vid, main)
-        else:
-            vout = self._fwd_visual(vid)
+        vout = self._fwd_visual(vis.reshape(n, *vis.shape[2:]))
         main.wait_event(self._ev[1])
         self.vfeat, self.afeat = self._pool(vout, 8, n, 'v'), self._pool(aout, self.sv_a['nt'], n, 'a')
         dv, da = self._head(self.vfeat, self.afeat)
@@ -705,74 +688,10 @@ class AVCLIPTrainer(FlatTrainer):
             if on_ready:
                 on_ready(self._key_range(A + '.', 'logit_scale'))                  # issued from the side stream: the collective waits for THIS tower
             self._ev[3].record(side)
-        if split:
-            self._bwd_visual_halves(self._pool_bwd(vout, 8, dv, n, 'v'), halves, main)
-            if on_ready:
-                on_ready(self._key_range(V + '.'))
-        else:
-            self._bwd_visual(self._pool_bwd(vout, 8, dv, n, 'v'), on_ready)
+        self._bwd_visual(self._pool_bwd(vout, 8, dv, n, 'v'), on_ready)
         main.wait_event(self._ev[3])
         self.loss = self.losses.mean()
         return self.loss
-
-    # ---- the visual tower as two halves of the segments on two streams (round 6) ---------------------------------------------------------------
-    def _fwd_visual_halves(self, vid, main):
-        n = vid.shape[0]
-        h = (n + 1) // 2
-        if self._vside is None:
-            self._vside = torch.cuda.Stream(device=self.dev)
-            self._vev = [torch.cuda.Event() for _ in range(4)]
-        if self.flat_g2 is None:                                               # the second half's gradient buffer (same packing as flat_g)
-            self.flat_g2 = torch.zeros_like(self.flat_g)
-            self.g2, o = {}, 0
-            for k in self.keys:
-                sz = self.p[k].numel()
-                self.g2[k] = self.flat_g2[o:o + sz].view(self.p[k].shape)
-                o += sz
-        if os.environ.get('SF_S1_POISON') == '1':
-            self.flat_g2.fill_(float('nan'))
-        # the stochastic-depth scales of the WHOLE batch, drawn once on this stream: segment j keeps the mask it has in the un-split step
-        self._dp_full = None
-        self._dp_full = {(i, st): self._dp_scales(i, st, n) for i in range(self.n_vblocks) for st in (0, 1)}
-        self._vev[0].record(main)
-        with torch.cuda.stream(self._vside):
-            self._vside.wait_event(self._vev[0])
-            self._ws_prefix, self._dp_slice = 'b:', (h, n)
-            try:
-                out_b = self._fwd_visual(vid[h:])
-                sv_b = self.sv_v
-            finally:
-                self._ws_prefix = ''
-            self._vev[1].record(self._vside)
-        self._dp_slice = (0, h)
-        out_a = self._fwd_visual(vid[:h])
-        sv_a = self.sv_v
-        main.wait_event(self._vev[1])
-        vout = self._buf('v_out_full', (n * 8, D), torch.float32)
-        vout[:h * 8].copy_(out_a)
-        vout[h * 8:].copy_(out_b)
-        return vout, (h, n, sv_a, sv_b)
-
-    def _bwd_visual_halves(self, dvout, halves, main):
-        h, n, sv_a, sv_b = halves
-        self._vev[2].record(main)
-        with torch.cuda.stream(self._vside):
-            self._vside.wait_event(self._vev[2])
-            self._ws_prefix, self._dp_slice, self.sv_v = 'b:', (h, n), sv_b
-            g_main, self.g = self.g, self.g2                                   # every self.g[...] the backward writes is the second buffer's view
-            try:
-                self._bwd_visual(dvout[h * 8:], None)
-            finally:
-                self.g, self._ws_prefix = g_main, ''
-            self._vev[3].record(self._vside)
-        self._dp_slice, self.sv_v = (0, h), sv_a
-        try:
-            self._bwd_visual(dvout[:h * 8], None)
-        finally:
-            self._dp_full = self._dp_slice = None
-        main.wait_event(self._vev[3])
-        lo, hi = self._key_range(V + '.')
-        self.flat_g[lo:hi].add_(self.flat_g2[lo:hi])                           # dW = dW(first half) + dW(second half)
 
     def _key_range(self, *prefixes):
         """[lo, hi) of the flat buffers covered by the keys starting with any of `prefixes` (they are contiguous by construction)."""
