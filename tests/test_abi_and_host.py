@@ -32,6 +32,8 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib.SIGNATURES) == set(decl), set(_lib.SIGNATURES) ^ set(decl)
     assert lib.sf_abi_version() == _lib.ABI_VERSION
     assert b'gfx950' in lib.sf_build_info()
+    ab = _lib.load_ablation()            # the ablation build (-DSF_ABLATION: product kernels + the measured-slower alternatives) exports the same ABI
+    assert all(hasattr(ab, name) for name in decl) and ab.sf_abi_version() == _lib.ABI_VERSION
 
 
 def test_argument_validation_without_gpu():
